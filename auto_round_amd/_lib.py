@@ -1,0 +1,89 @@
+"""ctypes binding of the C-ABI library `libar_mi355x.so` (include/ar_mi355x.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C auto_round_amd/csrc` for gfx950 and is the
+ONLY compute path of this package: there is no CPU or eager-PyTorch fallback.  Loading fails loudly
+(`Mi355xLibraryError`) when the shared object is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libar_mi355x.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
+AR_ERR_UNSUPPORTED = -1
+ABI_VERSION = 1
+
+
+class Mi355xLibraryError(RuntimeError):
+    """The HIP library is missing, stale, or a kernel launch failed."""
+
+
+# name -> (restype, argtypes); mirrors include/ar_mi355x.h one to one (checked by tests/test_abi.py)
+P, F, I, L = c_void_p, c_float, c_int, c_int64
+SIGNATURES = {
+    "ar_abi_version": (c_int, []),
+    "ar_error_string": (c_char_p, [c_int]),
+    "ar_group_minmax": (c_int, [P, P, P, L, I, I, P]),
+    "ar_group_absmax": (c_int, [P, P, P, L, I, I, P]),
+    "ar_qdq_int_fwd": (c_int, [P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, F, F, F, P]),
+    "ar_qdq_int_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, F, F, F, P]),
+    "ar_sign_sgd": (c_int, [P, P, L, P, P]),
+    "ar_qdq_int_bwd_sgd": (c_int, [P, P, P, P, P, P, P, L, I, I, I, I, I, F, F, F, P, P, I, P, P, P, P, P, P]),
+    "ar_mse_workspace_bytes": (c_int64, []),
+    "ar_mse_loss_fwd_bwd": (c_int, [P, P, P, P, P, F, L, I, F, P, P]),
+    "ar_best_loss_update": (c_int, [P, P, P, c_int32, P]),
+    "ar_gather_rows": (c_int, [P, P, P, L, L, P]),
+    "ar_pack_int": (c_int, [P, P, P, F, L, L, I, I, I, I, I, P, P, P, P]),
+    "ar_qdq_fp4_fwd": (c_int, [P, P, P, P, F, P, P, P, L, I, I, I, F, F, P]),
+    "ar_qdq_fp4_bwd_sgd": (c_int, [P, P, P, P, P, F, P, L, I, I, I, F, F, P, P, I, P, P, P, P, P, P]),
+    "ar_pack_fp4": (c_int, [P, P, P, L, L, I, I, I, P, P, P]),
+}
+
+_lib = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU). Returns the .so path."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise Mi355xLibraryError(f"hipcc build failed (see output above): {' '.join(cmd)}")
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the C-ABI library.  Never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Mi355xLibraryError(
+            f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C {CSRC}`); this package has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise Mi355xLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ar_abi_version() != ABI_VERSION:
+        raise Mi355xLibraryError(f"ABI mismatch: library {lib.ar_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().ar_error_string(code)
+        raise Mi355xLibraryError(f"{what} failed: [{code}] {msg.decode() if msg else '?'}")

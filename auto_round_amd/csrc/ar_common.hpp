@@ -1,0 +1,184 @@
+// ar_common.hpp -- device helpers shared by the gfx950 kernels (dtype conversion, 16-byte vector access,
+// per-group scale arithmetic).  CDNA4 only: 64-wide wavefronts are assumed everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ar_mi355x.h"
+
+namespace ar {
+
+constexpr int kWave = 64;   // CDNA wavefront
+constexpr int kTPB = 256;   // threads per workgroup (4 waves, one per SIMD)
+constexpr int kEPT = 8;     // elements per lane per chunk: 16 B of bf16/f16, 32 B of fp32
+
+// ---- scalar dtype conversions (RNE, identical to torch .to()) ------------------------------------------------
+__device__ __forceinline__ float bf16_lo(uint32_t pair) { return __uint_as_float(pair << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t pair) { return __uint_as_float(pair & 0xffff0000u); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float f16_to_f32(uint32_t h) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+}
+__device__ __forceinline__ uint32_t f32_to_f16(float f) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);   // v_cvt_f16_f32, RNE
+}
+template <int DT> __device__ __forceinline__ float round_to(float v) {
+    if constexpr (DT == AR_DT_BF16) return __uint_as_float(f32_to_bf16(v) << 16);
+    else if constexpr (DT == AR_DT_F16) return f16_to_f32(f32_to_f16(v));
+    else return v;
+}
+__device__ __forceinline__ float round_to_rt(int dt, float v) {
+    if (dt == AR_DT_BF16) return round_to<AR_DT_BF16>(v);
+    if (dt == AR_DT_F16) return round_to<AR_DT_F16>(v);
+    return v;
+}
+template <int DT> __device__ __forceinline__ float load1(const void* p, int64_t i) {
+    if constexpr (DT == AR_DT_BF16) return __uint_as_float((uint32_t)((const uint16_t*)p)[i] << 16);
+    else if constexpr (DT == AR_DT_F16) return f16_to_f32(((const uint16_t*)p)[i]);
+    else return ((const float*)p)[i];
+}
+template <int DT> __device__ __forceinline__ void store1(void* p, int64_t i, float v) {
+    if constexpr (DT == AR_DT_BF16) ((uint16_t*)p)[i] = (uint16_t)f32_to_bf16(v);
+    else if constexpr (DT == AR_DT_F16) ((uint16_t*)p)[i] = (uint16_t)f32_to_f16(v);
+    else ((float*)p)[i] = v;
+}
+__device__ __forceinline__ float load1_rt(int dt, const void* p, int64_t i) {
+    if (dt == AR_DT_BF16) return load1<AR_DT_BF16>(p, i);
+    if (dt == AR_DT_F16) return load1<AR_DT_F16>(p, i);
+    return load1<AR_DT_F32>(p, i);
+}
+__device__ __forceinline__ void store1_rt(int dt, void* p, int64_t i, float v) {
+    if (dt == AR_DT_BF16) store1<AR_DT_BF16>(p, i, v);
+    else if (dt == AR_DT_F16) store1<AR_DT_F16>(p, i, v);
+    else store1<AR_DT_F32>(p, i, v);
+}
+
+// ---- 8-element (one chunk) register tiles with 16-byte global accesses ------------------------------------------
+template <int DT> struct Raw8;                         // what one lane holds for one chunk, still packed
+template <> struct Raw8<AR_DT_BF16> { uint4 q; };
+template <> struct Raw8<AR_DT_F16> { uint4 q; };
+template <> struct Raw8<AR_DT_F32> { float4 a, b; };
+
+template <int DT> __device__ __forceinline__ Raw8<DT> load8_raw(const void* base, int64_t elem) {
+    Raw8<DT> r;
+    if constexpr (DT == AR_DT_F32) {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+        r.a = p[0]; r.b = p[1];
+    } else {
+        r.q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + elem);
+    }
+    return r;
+}
+template <int DT> __device__ __forceinline__ void unpack8(const Raw8<DT>& r, float (&o)[8]) {
+    if constexpr (DT == AR_DT_F32) {
+        o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
+    } else if constexpr (DT == AR_DT_BF16) {
+        o[0] = bf16_lo(r.q.x); o[1] = bf16_hi(r.q.x); o[2] = bf16_lo(r.q.y); o[3] = bf16_hi(r.q.y);
+        o[4] = bf16_lo(r.q.z); o[5] = bf16_hi(r.q.z); o[6] = bf16_lo(r.q.w); o[7] = bf16_hi(r.q.w);
+    } else {
+        o[0] = f16_to_f32(r.q.x & 0xffffu); o[1] = f16_to_f32(r.q.x >> 16); o[2] = f16_to_f32(r.q.y & 0xffffu);
+        o[3] = f16_to_f32(r.q.y >> 16); o[4] = f16_to_f32(r.q.z & 0xffffu); o[5] = f16_to_f32(r.q.z >> 16);
+        o[6] = f16_to_f32(r.q.w & 0xffffu); o[7] = f16_to_f32(r.q.w >> 16);
+    }
+}
+template <int DT> __device__ __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
+    if constexpr (DT == AR_DT_F32) {
+        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem);
+        p[0] = make_float4(v[0], v[1], v[2], v[3]);
+        p[1] = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        uint4 q;
+        if constexpr (DT == AR_DT_BF16) {
+            q.x = f32_to_bf16(v[0]) | (f32_to_bf16(v[1]) << 16); q.y = f32_to_bf16(v[2]) | (f32_to_bf16(v[3]) << 16);
+            q.z = f32_to_bf16(v[4]) | (f32_to_bf16(v[5]) << 16); q.w = f32_to_bf16(v[6]) | (f32_to_bf16(v[7]) << 16);
+        } else {
+            q.x = f32_to_f16(v[0]) | (f32_to_f16(v[1]) << 16); q.y = f32_to_f16(v[2]) | (f32_to_f16(v[3]) << 16);
+            q.z = f32_to_f16(v[4]) | (f32_to_f16(v[5]) << 16); q.w = f32_to_f16(v[6]) | (f32_to_f16(v[7]) << 16);
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + elem) = q;
+    }
+}
+struct F8 { float4 a, b; };
+__device__ __forceinline__ F8 load8_f32(const float* base, int64_t elem) {
+    const float4* p = reinterpret_cast<const float4*>(base + elem);
+    F8 r; r.a = p[0]; r.b = p[1]; return r;
+}
+__device__ __forceinline__ void unpack_f8(const F8& r, float (&o)[8]) {
+    o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
+}
+__device__ __forceinline__ void store8_f32(float* base, int64_t elem, const float (&v)[8]) {
+    float4* p = reinterpret_cast<float4*>(base + elem);
+    p[0] = make_float4(v[0], v[1], v[2], v[3]);
+    p[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// ---- small math -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+// forward value of the reference's round_ste: (x.round() - x).detach() + x  == rint(x) with a zero result always +0
+__device__ __forceinline__ float round_ste_value(float y) {
+    float d = __builtin_rintf(y) - y;
+    return d + y;
+}
+// butterfly all-reduce (sum) over `width` consecutive lanes (width = power of two <= 64)
+__device__ __forceinline__ float lanes_sum(float v, int width) {
+    for (int m = width >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+__device__ __forceinline__ float lanes_max(float v, int width) {
+    for (int m = width >> 1; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));
+    return v;
+}
+__device__ __forceinline__ float lanes_min(float v, int width) {
+    for (int m = width >> 1; m > 0; m >>= 1) v = fminf(v, __shfl_xor(v, m, kWave));
+    return v;
+}
+
+// ---- per-group INT scale / zero-point (runs once per group, off the streaming path) -----------------------------
+// Mirrors auto_round/data_type/int.py:221-227 (sym) and :283-293 (asym) with the dtype choreography of
+// SURVEY App. A.1/A.2; min/max scale are clamped to [lo,hi] as WrapperLinear._qdq_weight does (wrapper.py:257-259).
+struct IntCfg {
+    int bits, sym, s_dt, w_dt;
+    float thresh;      // q_scale_thresh
+    float lo, hi;      // min/max-scale bounds
+};
+struct GroupQ {
+    float ms, Ms, wmin, wmax;   // clamped scales, float(wmin0/wmax0)
+    float a, b;                 // sym: -(wmin*ms), wmax*Ms ; asym: lo, hi
+    float sgn;                  // sym only (+1 / -1)
+    float s_raw, s, zp;         // scale before / after the threshold clamp ; zero point (sym: maxq, informational)
+};
+__device__ __forceinline__ void group_scale(const IntCfg& c, float wmin, float wmax, float ms_raw, float Ms_raw, GroupQ& q) {
+    q.ms = clamp3(ms_raw, c.lo, c.hi);
+    q.Ms = clamp3(Ms_raw, c.lo, c.hi);
+    q.wmin = wmin; q.wmax = wmax;
+    const float t = round_to_rt(c.s_dt, c.thresh);
+    if (c.sym) {
+        const float maxq = (float)(1 << (c.bits - 1));
+        q.a = -(wmin * q.ms);
+        q.b = wmax * q.Ms;
+        q.sgn = (q.b < q.a) ? 1.f : -1.f;
+        const float m = (q.a > q.b) ? q.a : q.b;
+        q.s_raw = round_to_rt(c.s_dt, (q.sgn * m) / maxq);
+        q.s = (q.s_raw < 0.f) ? ((q.s_raw > -t) ? -t : q.s_raw) : ((q.s_raw < t) ? t : q.s_raw);
+        q.zp = maxq;
+    } else {
+        const float maxq = (float)((1 << c.bits) - 1);
+        q.a = wmin * q.ms;
+        q.b = wmax * q.Ms;
+        q.sgn = 1.f;
+        q.s_raw = round_to_rt(c.s_dt, (q.b - q.a) / maxq);
+        q.s = (q.s_raw < t) ? t : q.s_raw;
+        q.zp = __builtin_rintf((-q.a) / q.s);
+    }
+}
+
+// error plumbing for the C ABI
+inline int launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace ar

@@ -1,0 +1,530 @@
+// ar_int.hip -- INT (W2/W3/W4/W8, sym + asym) fake-quant kernels for gfx950:
+//   k_group_minmax : per-group min/max (wave shuffle reductions)
+//   k_int_fwd      : K1  fake-quant forward                    8 B/elem + 12 B/group   (HBM bound)
+//   k_int_bwd      : K2(+K3) backward [+ sign-SGD + best-param snapshot + next forward], 12 B/elem + 8 B/group
+//
+// Design (DESIGN.md "kernels"): the weight is a flat array of groups.  A workgroup (256 lanes = 4 waves) owns a
+// tile of up to 8192 consecutive elements (whole groups).  Per tile:
+//   (A) up to 256 "group lanes" load the 4 per-group parameters and                      [12 B/group]
+//   (B) every lane issues all of its 16-byte streaming loads (W, V[, dWq]) up front,     [the HBM stream]
+//   (C) the group lanes turn the parameters into (scale, zp) -- fp16 cast, threshold clamp, true IEEE division,
+//       all the data-dependent branching -- and stage them in LDS while the streaming loads are in flight,
+//   (D) one barrier, then every lane consumes its registers against the LDS-staged scales and stores 16 B.
+// The backward additionally reduces 2-4 per-group sums with a DPP/bpermute butterfly over the gs/8 lanes that share
+// a group, hands them to the group lane through LDS, and the group lane applies the sign step to min/max scale.
+// There is no inter-workgroup reuse, so no XCD-aware remap is needed: consecutive tiles simply round-robin over the
+// 8 XCDs and stream straight from HBM.
+#include "ar_common.hpp"
+
+namespace ar {
+
+// ------------------------------------------------------------------------------------------------------------------
+// group min/max
+// ------------------------------------------------------------------------------------------------------------------
+template <int WDT>
+__global__ __launch_bounds__(kTPB) void k_group_minmax(const void* __restrict__ W, void* __restrict__ wmin,
+                                                       void* __restrict__ wmax, float* __restrict__ absmax,
+                                                       float* __restrict__ tensor_absmax, int64_t n_groups, int cpg) {
+    // one group per `cpg` lanes when cpg <= 64, else one group per wave looping over the group
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave_global = ((int64_t)blockIdx.x * kTPB + threadIdx.x) / kWave;
+    const int64_t n_waves = (int64_t)gridDim.x * kTPB / kWave;
+    float tmax = 0.f;
+    if (cpg <= kWave) {
+        const int gpw = kWave / cpg;  // groups per wave pass
+        for (int64_t gb = wave_global * gpw; gb < n_groups; gb += n_waves * gpw) {
+            const int64_t g = gb + lane / cpg;
+            float lo = INFINITY, hi = -INFINITY;
+            if (g < n_groups) {
+                float v[8];
+                unpack8<WDT>(load8_raw<WDT>(W, (g * cpg + (lane % cpg)) * kEPT), v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { lo = fminf(lo, v[k]); hi = fmaxf(hi, v[k]); }
+            }
+            lo = lanes_min(lo, cpg);
+            hi = lanes_max(hi, cpg);
+            if (g < n_groups && (lane % cpg) == 0) {
+                if (wmin) store1<WDT>(wmin, g, fminf(lo, 0.f));
+                if (wmax) store1<WDT>(wmax, g, fmaxf(hi, 0.f));
+                const float am = fmaxf(-lo, hi);
+                if (absmax) absmax[g] = am;
+                tmax = fmaxf(tmax, am);
+            }
+        }
+    } else {
+        for (int64_t g = wave_global; g < n_groups; g += n_waves) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (int c = lane; c < cpg; c += kWave) {
+                float v[8];
+                unpack8<WDT>(load8_raw<WDT>(W, (g * cpg + c) * kEPT), v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { lo = fminf(lo, v[k]); hi = fmaxf(hi, v[k]); }
+            }
+            lo = lanes_min(lo, kWave);
+            hi = lanes_max(hi, kWave);
+            if (lane == 0) {
+                if (wmin) store1<WDT>(wmin, g, fminf(lo, 0.f));
+                if (wmax) store1<WDT>(wmax, g, fmaxf(hi, 0.f));
+                const float am = fmaxf(-lo, hi);
+                if (absmax) absmax[g] = am;
+                tmax = fmaxf(tmax, am);
+            }
+        }
+    }
+    if (tensor_absmax) {
+        tmax = lanes_max(tmax, kWave);
+        // non-negative floats order like their bit patterns
+        if (lane == 0 && tmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(tensor_absmax), __float_as_uint(tmax));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    const void* W; const float* V; const void* wmin; const void* wmax; const float* min_s; const float* max_s;
+    void* Wq; void* scale_out; float* zp_out;
+    int64_t n_groups;
+    int cpg, cpg_shift;   // chunks (of 8 elements) per group; shift = log2(cpg) or -1
+    int x_dt;             // dtype in which W/scale is evaluated (torch promotion of w_dt and s_dt)
+    float qlo, qhi;       // clamp bounds of the integer grid (sym: -maxq..maxq-1 with zp 0; asym: 0..maxq with zp)
+    IntCfg cfg;
+};
+
+__device__ __forceinline__ int group_of_chunk(int cl, int cpg, int shift) { return shift >= 0 ? (cl >> shift) : (cl / cpg); }
+
+// one chunk of the forward: o = s * (clamp(rint(w/s + v) + zp, qlo, qhi) - zp)
+template <int XR>
+__device__ __forceinline__ void qdq8(const float (&w)[8], const float (&v)[8], float s, float zp, float qlo, float qhi,
+                                     float (&o)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float x = round_to<XR>(w[k] / s);           // true IEEE division (v_div_scale/fmas/fixup), never rcp*mul
+        float r = round_ste_value(x + v[k]);
+        float qq = clamp3(r + zp, qlo, qhi) - zp;
+        o[k] = s * qq;
+    }
+}
+
+template <int WDT, int UNROLL>
+__global__ __launch_bounds__(kTPB) void k_int_fwd(const FwdArgs a) {
+    __shared__ float2 sg[2][kTPB];
+    const int tid = threadIdx.x;
+    const int cpg = a.cpg, shift = a.cpg_shift;
+    const int u_eff = cpg < UNROLL ? cpg : UNROLL;
+    const int tile_chunks = kTPB * u_eff;
+    const int tile_groups = tile_chunks / cpg > 0 ? tile_chunks / cpg : 1;
+    const int64_t total_chunks = a.n_groups * cpg;
+    const int64_t n_tiles = (a.n_groups + tile_groups - 1) / tile_groups;
+    int par = 0;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
+        const int64_t c0 = tile * (int64_t)tile_groups * cpg;
+        // (A) group parameters
+        const int64_t g = tile * tile_groups + tid;
+        const bool has_g = tid < tile_groups && g < a.n_groups;
+        float wmn = 0.f, wmx = 0.f, ms = 1.f, Ms = 1.f;
+        if (has_g) {
+            wmn = load1<WDT>(a.wmin, g);
+            wmx = load1<WDT>(a.wmax, g);
+            if (a.min_s) ms = a.min_s[g];
+            if (a.max_s) Ms = a.max_s[g];
+        }
+        // (B) streaming loads, all issued before anything waits on them
+        Raw8<WDT> wr[UNROLL];
+        F8 vr[UNROLL];
+        bool ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t c = c0 + u * kTPB + tid;
+            ok[u] = (u < u_eff) && (u * kTPB + tid < tile_groups * cpg) && (c < total_chunks);
+            if (ok[u]) {
+                wr[u] = load8_raw<WDT>(a.W, c * kEPT);
+                if (a.V) vr[u] = load8_f32(a.V, c * kEPT);
+            }
+        }
+        // (C) scales -> LDS
+        if (has_g) {
+            GroupQ q;
+            group_scale(a.cfg, wmn, wmx, ms, Ms, q);
+            sg[par][tid] = make_float2(q.s, a.cfg.sym ? 0.f : q.zp);
+            if (a.scale_out) store1_rt(a.cfg.s_dt, a.scale_out, g, q.s);
+            if (a.zp_out) a.zp_out[g] = q.zp;
+        }
+        __syncthreads();
+        // (D) consume
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (!ok[u]) continue;
+            const float2 sz = sg[par][group_of_chunk(u * kTPB + tid, cpg, shift)];
+            float w[8], v[8], o[8];
+            unpack8<WDT>(wr[u], w);
+            if (a.V) unpack_f8(vr[u], v);
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = 0.f;
+            }
+            if (a.x_dt == AR_DT_F32) qdq8<AR_DT_F32>(w, v, sz.x, sz.y, a.qlo, a.qhi, o);
+            else if (a.x_dt == AR_DT_F16) qdq8<AR_DT_F16>(w, v, sz.x, sz.y, a.qlo, a.qhi, o);
+            else qdq8<AR_DT_BF16>(w, v, sz.x, sz.y, a.qlo, a.qhi, o);
+            store8<WDT>(a.Wq, (c0 + u * kTPB + tid) * kEPT, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward (+ sign-SGD, + snapshot, + next forward)
+// ------------------------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    const void* dWq; const void* W; float* V; const void* wmin; const void* wmax; float* min_s; float* max_s;
+    float* dV; float* dmin; float* dmax;            // unfused outputs (optional)
+    const float* lr_v; const float* lr_mm;          // device learning rates (NULL => no update)
+    const int32_t* snap; float* best_V; float* best_min; float* best_max;
+    void* Wq_next;
+    int64_t n_groups;
+    int cpg, cpg_shift, x_dt, tune_minmax;
+    float qlo, qhi;
+    IntCfg cfg;
+};
+
+struct Sums { float c1, c2, e, dy; };
+
+template <int XR>
+__device__ __forceinline__ void bwd8(const float (&g)[8], const float (&w)[8], const float (&v)[8], float s, float zp,
+                                     float qlo, float qhi, float (&dy)[8], Sums& acc) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float x = round_to<XR>(w[k] / s);
+        const float r = round_ste_value(x + v[k]);
+        const float t = r + zp;
+        const bool inside = (t >= qlo) && (t <= qhi);
+        const float qq = clamp3(t, qlo, qhi) - zp;
+        const float e = g[k] * s;                         // MulBackward, `other` side
+        dy[k] = inside ? e : 0.f;                          // ClampBackward (where), STE through round
+        acc.c1 += g[k] * qq;                               // MulBackward, scale side (summed over the group)
+        const float dx = round_to<XR>(dy[k]);
+        const float t2 = round_to<XR>(x / s);
+        acc.c2 += round_to<XR>((-dx) * t2);                // DivBackward, scale side
+        acc.e += -e;                                       // SubBackward -> zp (asym)
+        acc.dy += dy[k];                                   // AddBackward -> zp (asym)
+    }
+}
+
+template <int WDT, int UNROLL>
+__global__ __launch_bounds__(kTPB) void k_int_bwd(const BwdArgs a) {
+    __shared__ float2 sg[kTPB];        // (scale, zp) of the tile's groups
+    __shared__ float4 ssum[kTPB];      // per-group reduced sums, written by the first lane of each lane-group
+    __shared__ float2 sg2[kTPB];       // updated (scale, zp) for the fused next forward
+    const int tid = threadIdx.x;
+    const int cpg = a.cpg, shift = a.cpg_shift;      // cpg is a power of two <= 64 here
+    const int u_eff = cpg < UNROLL ? cpg : UNROLL;
+    const int tile_chunks = kTPB * u_eff;
+    const int tile_groups = tile_chunks >> shift;    // <= kTPB
+    const int64_t total_chunks = a.n_groups << shift;
+    const int64_t n_tiles = (a.n_groups + tile_groups - 1) / tile_groups;
+    const bool sym = a.cfg.sym != 0;
+    const bool do_snap = a.snap != nullptr && *a.snap != 0;
+    const float alpha_v = a.lr_v ? -(*a.lr_v) : 0.f;
+    const float alpha_mm = a.lr_mm ? -(*a.lr_mm) : 0.f;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t c0 = tile * (int64_t)tile_chunks;
+        const int64_t g = tile * tile_groups + tid;
+        const bool has_g = tid < tile_groups && g < a.n_groups;
+        float wmn = 0.f, wmx = 0.f, ms = 1.f, Ms = 1.f;
+        if (has_g) {
+            wmn = load1<WDT>(a.wmin, g);
+            wmx = load1<WDT>(a.wmax, g);
+            if (a.min_s) ms = a.min_s[g];
+            if (a.max_s) Ms = a.max_s[g];
+        }
+        Raw8<WDT> gr[UNROLL], wr[UNROLL];
+        F8 vr[UNROLL];
+        bool ok[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t c = c0 + u * kTPB + tid;
+            ok[u] = (u < u_eff) && (c < total_chunks);
+            if (ok[u]) {
+                gr[u] = load8_raw<WDT>(a.dWq, c * kEPT);
+                wr[u] = load8_raw<WDT>(a.W, c * kEPT);
+                if (a.V) vr[u] = load8_f32(a.V, c * kEPT);
+            }
+        }
+        GroupQ q;
+        if (has_g) {
+            group_scale(a.cfg, wmn, wmx, ms, Ms, q);
+            sg[tid] = make_float2(q.s, sym ? 0.f : q.zp);
+        }
+        __syncthreads();
+
+        float vnew[UNROLL][8];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            // every lane of a lane-group must take part in the butterfly, so no early `continue` here
+            const int gl = (u * kTPB + tid) >> shift;
+            const float2 sz = sg[gl < tile_groups ? gl : 0];
+            float gg[8], w[8], v[8], dy[8];
+            Sums acc = {0.f, 0.f, 0.f, 0.f};
+            if (ok[u]) {
+                unpack8<WDT>(gr[u], gg);
+                unpack8<WDT>(wr[u], w);
+                if (a.V) unpack_f8(vr[u], v);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+                }
+                if (a.x_dt == AR_DT_F32) bwd8<AR_DT_F32>(gg, w, v, sz.x, sz.y, a.qlo, a.qhi, dy, acc);
+                else if (a.x_dt == AR_DT_F16) bwd8<AR_DT_F16>(gg, w, v, sz.x, sz.y, a.qlo, a.qhi, dy, acc);
+                else bwd8<AR_DT_BF16>(gg, w, v, sz.x, sz.y, a.qlo, a.qhi, dy, acc);
+                const int64_t e0 = (c0 + u * kTPB + tid) * kEPT;
+                if (a.dV) store8_f32(a.dV, e0, dy);
+                if (a.lr_v) {
+                    if (do_snap && a.best_V) store8_f32(a.best_V, e0, v);   // pre-update V == the best iterate
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) vnew[u][k] = v[k] + alpha_v * sgnf(dy[k]);
+                    store8_f32(a.V, e0, vnew[u]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) vnew[u][k] = v[k];
+                }
+            }
+            if (u < u_eff) {   // wave-uniform
+                acc.c1 = lanes_sum(acc.c1, cpg);
+                acc.c2 = lanes_sum(acc.c2, cpg);
+                if (!sym) { acc.e = lanes_sum(acc.e, cpg); acc.dy = lanes_sum(acc.dy, cpg); }
+                if ((tid & (cpg - 1)) == 0 && gl < tile_groups) ssum[gl] = make_float4(acc.c1, acc.c2, acc.e, acc.dy);
+            }
+        }
+        __syncthreads();
+
+        if (has_g) {
+            const float4 sm = ssum[tid];
+            const int s_dt = a.cfg.s_dt;
+            const float maxq = sym ? (float)(1 << (a.cfg.bits - 1)) : (float)((1 << a.cfg.bits) - 1);
+            const float c1 = round_to_rt(s_dt, sm.x);
+            const float c2 = round_to_rt(s_dt, round_to_rt(a.x_dt, sm.y));
+            float ds_c = round_to_rt(s_dt, c1 + c2);
+            float dlo_zp = 0.f;
+            if (!sym) {
+                const float dzp = sm.z + sm.w;
+                const float u_over_s = ((-q.a) / q.s) / q.s;
+                const float c3 = round_to_rt(s_dt, (-dzp) * u_over_s);
+                ds_c = round_to_rt(s_dt, ds_c + c3);
+                dlo_zp = -(dzp / q.s);
+            }
+            const float t = round_to_rt(s_dt, a.cfg.thresh);
+            float ds;
+            if (sym) ds = (q.s_raw < 0.f) ? ((q.s_raw <= -t) ? ds_c : 0.f) : ((q.s_raw >= t) ? ds_c : 0.f);
+            else ds = (q.s_raw >= t) ? ds_c : 0.f;
+            const float d32 = ds / maxq;
+            float gmin, gmax;
+            if (sym) {
+                const float dm = d32 * q.sgn;
+                float da, db;
+                if (q.a == q.b) { da = dm / 2.f; db = dm / 2.f; }
+                else if (q.a > q.b) { da = dm; db = 0.f; }
+                else { da = 0.f; db = dm; }
+                gmin = (-da) * q.wmin;
+                gmax = db * q.wmax;
+            } else {
+                gmin = ((-d32) + dlo_zp) * q.wmin;
+                gmax = d32 * q.wmax;
+            }
+            if (a.dmin) a.dmin[g] = gmin;
+            if (a.dmax) a.dmax[g] = gmax;
+            float ms_new = ms, Ms_new = Ms;
+            if (a.lr_mm && a.tune_minmax) {
+                if (do_snap) {
+                    if (a.best_min) a.best_min[g] = q.ms;
+                    if (a.best_max) a.best_max[g] = q.Ms;
+                }
+                ms_new = q.ms + alpha_mm * sgnf(gmin);   // the clamp happened "in place" at the forward
+                Ms_new = q.Ms + alpha_mm * sgnf(gmax);
+                a.min_s[g] = ms_new;
+                a.max_s[g] = Ms_new;
+            }
+            if (a.Wq_next) {
+                GroupQ q2;
+                group_scale(a.cfg, wmn, wmx, ms_new, Ms_new, q2);
+                sg2[tid] = make_float2(q2.s, sym ? 0.f : q2.zp);
+            }
+        }
+        if (a.Wq_next) {   // kernel-uniform
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (!ok[u]) continue;
+                const float2 sz = sg2[(u * kTPB + tid) >> shift];
+                float w[8], o[8];
+                unpack8<WDT>(wr[u], w);
+                if (a.x_dt == AR_DT_F32) qdq8<AR_DT_F32>(w, vnew[u], sz.x, sz.y, a.qlo, a.qhi, o);
+                else if (a.x_dt == AR_DT_F16) qdq8<AR_DT_F16>(w, vnew[u], sz.x, sz.y, a.qlo, a.qhi, o);
+                else qdq8<AR_DT_BF16>(w, vnew[u], sz.x, sz.y, a.qlo, a.qhi, o);
+                store8<WDT>(a.Wq_next, (c0 + u * kTPB + tid) * kEPT, o);
+            }
+        }
+        __syncthreads();   // sg / ssum / sg2 are reused by the next tile
+    }
+}
+
+// unfused sign-SGD
+__global__ __launch_bounds__(kTPB) void k_sign_sgd(float* __restrict__ p, const float* __restrict__ g, int64_t n,
+                                                   const float* __restrict__ lr) {
+    const float alpha = -(*lr);
+    const int64_t n4 = n / 4;
+    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    for (int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x; i < n4; i += stride) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        pv.x += alpha * sgnf(gv.x); pv.y += alpha * sgnf(gv.y); pv.z += alpha * sgnf(gv.z); pv.w += alpha * sgnf(gv.w);
+        reinterpret_cast<float4*>(p)[i] = pv;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kTPB + threadIdx.x; i < n; i += stride) p[i] += alpha * sgnf(g[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------------------------------------
+static inline int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+static inline int promote_dt(int a, int b) { return a == b ? a : AR_DT_F32; }
+static inline int grid_for_tiles(int64_t n_tiles) {
+    const int64_t cap = 256 * 8;   // 256 CUs x 8 resident workgroups; the kernels grid-stride over the rest
+    return (int)(n_tiles < cap ? (n_tiles > 0 ? n_tiles : 1) : cap);
+}
+static inline bool fill_cfg(IntCfg& c, float& qlo, float& qhi, int bits, int sym, int w_dt, int s_dt, float th, float lo,
+                            float hi) {
+    if (bits < 2 || bits > 8) return false;
+    if (w_dt < 0 || w_dt > 2 || s_dt < 0 || s_dt > 2) return false;
+    c.bits = bits; c.sym = sym ? 1 : 0; c.s_dt = s_dt; c.w_dt = w_dt; c.thresh = th; c.lo = lo; c.hi = hi;
+    if (sym) { const float m = (float)(1 << (bits - 1)); qlo = -m; qhi = m - 1.f; }
+    else { qlo = 0.f; qhi = (float)((1 << bits) - 1); }
+    return true;
+}
+
+}  // namespace ar
+
+using namespace ar;
+
+extern "C" int ar_group_minmax(const void* W, void* wmin, void* wmax, int64_t n_groups, int gs, int w_dt,
+                               ar_stream_t stream) {
+    if (gs <= 0 || gs % kEPT || n_groups < 0) return AR_ERR_UNSUPPORTED;
+    if (n_groups == 0) return AR_OK;
+    const int cpg = gs / kEPT;
+    if (cpg <= kWave && ilog2_exact(cpg) < 0) return AR_ERR_UNSUPPORTED;
+    const int64_t waves = cpg <= kWave ? (n_groups + (kWave / cpg) - 1) / (kWave / cpg) : n_groups;
+    const int grid = grid_for_tiles((waves + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    switch (w_dt) {
+        case AR_DT_BF16: hipLaunchKernelGGL(k_group_minmax<AR_DT_BF16>, grid, kTPB, 0, st, W, wmin, wmax, nullptr, nullptr, n_groups, cpg); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_group_minmax<AR_DT_F16>, grid, kTPB, 0, st, W, wmin, wmax, nullptr, nullptr, n_groups, cpg); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_group_minmax<AR_DT_F32>, grid, kTPB, 0, st, W, wmin, wmax, nullptr, nullptr, n_groups, cpg); break;
+        default: return AR_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}
+
+extern "C" int ar_group_absmax(const void* W, float* absmax, float* tensor_absmax, int64_t n_groups, int gs, int w_dt,
+                               ar_stream_t stream) {
+    if (gs <= 0 || gs % kEPT || n_groups < 0) return AR_ERR_UNSUPPORTED;
+    if (n_groups == 0) return AR_OK;
+    const int cpg = gs / kEPT;
+    if (cpg <= kWave && ilog2_exact(cpg) < 0) return AR_ERR_UNSUPPORTED;
+    const int64_t waves = cpg <= kWave ? (n_groups + (kWave / cpg) - 1) / (kWave / cpg) : n_groups;
+    const int grid = grid_for_tiles((waves + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    switch (w_dt) {
+        case AR_DT_BF16: hipLaunchKernelGGL(k_group_minmax<AR_DT_BF16>, grid, kTPB, 0, st, W, nullptr, nullptr, absmax, tensor_absmax, n_groups, cpg); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_group_minmax<AR_DT_F16>, grid, kTPB, 0, st, W, nullptr, nullptr, absmax, tensor_absmax, n_groups, cpg); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_group_minmax<AR_DT_F32>, grid, kTPB, 0, st, W, nullptr, nullptr, absmax, tensor_absmax, n_groups, cpg); break;
+        default: return AR_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}
+
+#ifndef AR_FWD_UNROLL
+#define AR_FWD_UNROLL 4
+#endif
+#ifndef AR_BWD_UNROLL
+#define AR_BWD_UNROLL 2
+#endif
+
+extern "C" int ar_qdq_int_fwd(const void* W, const float* V, const void* wmin, const void* wmax, const float* min_s,
+                              const float* max_s, void* Wq, void* scale_out, float* zp_out, int64_t n_groups, int gs,
+                              int bits, int sym, int w_dt, int s_dt, float q_thresh, float lo_bound, float hi_bound,
+                              ar_stream_t stream) {
+    FwdArgs a;
+    if (!fill_cfg(a.cfg, a.qlo, a.qhi, bits, sym, w_dt, s_dt, q_thresh, lo_bound, hi_bound)) return AR_ERR_UNSUPPORTED;
+    if (gs <= 0 || gs % kEPT || gs / kEPT > kTPB * AR_FWD_UNROLL || n_groups < 0) return AR_ERR_UNSUPPORTED;
+    if (n_groups == 0) return AR_OK;
+    a.W = W; a.V = V; a.wmin = wmin; a.wmax = wmax; a.min_s = min_s; a.max_s = max_s; a.Wq = Wq;
+    a.scale_out = scale_out; a.zp_out = zp_out; a.n_groups = n_groups;
+    a.cpg = gs / kEPT; a.cpg_shift = ilog2_exact(a.cpg); a.x_dt = promote_dt(w_dt, s_dt);
+    const int u_eff = a.cpg < AR_FWD_UNROLL ? a.cpg : AR_FWD_UNROLL;
+    int tile_groups = kTPB * u_eff / a.cpg;
+    if (tile_groups < 1) tile_groups = 1;
+    const int grid = grid_for_tiles((n_groups + tile_groups - 1) / tile_groups);
+    hipStream_t st = (hipStream_t)stream;
+    switch (w_dt) {
+        case AR_DT_BF16: hipLaunchKernelGGL((k_int_fwd<AR_DT_BF16, AR_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        case AR_DT_F16: hipLaunchKernelGGL((k_int_fwd<AR_DT_F16, AR_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        default: hipLaunchKernelGGL((k_int_fwd<AR_DT_F32, AR_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
+    }
+    return launch_status();
+}
+
+static int launch_int_bwd(BwdArgs& a, int gs, int bits, int sym, int w_dt, int s_dt, float q_thresh, float lo, float hi,
+                          ar_stream_t stream) {
+    if (!fill_cfg(a.cfg, a.qlo, a.qhi, bits, sym, w_dt, s_dt, q_thresh, lo, hi)) return AR_ERR_UNSUPPORTED;
+    if (gs <= 0 || gs % kEPT || a.n_groups < 0) return AR_ERR_UNSUPPORTED;
+    a.cpg = gs / kEPT; a.cpg_shift = ilog2_exact(a.cpg); a.x_dt = promote_dt(w_dt, s_dt);
+    if (a.cpg_shift < 0 || a.cpg > kWave) return AR_ERR_UNSUPPORTED;   // lane-group butterfly needs gs in {8,...,512}
+    if (a.n_groups == 0) return AR_OK;
+    const int u_eff = a.cpg < AR_BWD_UNROLL ? a.cpg : AR_BWD_UNROLL;
+    const int tile_groups = kTPB * u_eff / a.cpg;
+    const int grid = grid_for_tiles((a.n_groups + tile_groups - 1) / tile_groups);
+    hipStream_t st = (hipStream_t)stream;
+    switch (w_dt) {
+        case AR_DT_BF16: hipLaunchKernelGGL((k_int_bwd<AR_DT_BF16, AR_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        case AR_DT_F16: hipLaunchKernelGGL((k_int_bwd<AR_DT_F16, AR_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        default: hipLaunchKernelGGL((k_int_bwd<AR_DT_F32, AR_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
+    }
+    return launch_status();
+}
+
+extern "C" int ar_qdq_int_bwd(const void* dWq, const void* W, const float* V, const void* wmin, const void* wmax,
+                              const float* min_s, const float* max_s, float* dV, float* dmin, float* dmax,
+                              int64_t n_groups, int gs, int bits, int sym, int w_dt, int s_dt, float q_thresh,
+                              float lo_bound, float hi_bound, ar_stream_t stream) {
+    BwdArgs a = {};
+    a.dWq = dWq; a.W = W; a.V = const_cast<float*>(V); a.wmin = wmin; a.wmax = wmax;
+    a.min_s = const_cast<float*>(min_s); a.max_s = const_cast<float*>(max_s);
+    a.dV = dV; a.dmin = dmin; a.dmax = dmax; a.n_groups = n_groups; a.tune_minmax = 0;
+    return launch_int_bwd(a, gs, bits, sym, w_dt, s_dt, q_thresh, lo_bound, hi_bound, stream);
+}
+
+extern "C" int ar_qdq_int_bwd_sgd(const void* dWq, const void* W, float* V, const void* wmin, const void* wmax,
+                                  float* min_s, float* max_s, int64_t n_groups, int gs, int bits, int sym, int w_dt,
+                                  int s_dt, float q_thresh, float lo_bound, float hi_bound, const float* lr_v_dev,
+                                  const float* lr_mm_dev, int tune_minmax, const int32_t* snapshot_flag, float* best_V,
+                                  float* best_min, float* best_max, void* Wq_next, ar_stream_t stream) {
+    if (!V || !lr_v_dev) return AR_ERR_UNSUPPORTED;
+    BwdArgs a = {};
+    a.dWq = dWq; a.W = W; a.V = V; a.wmin = wmin; a.wmax = wmax; a.min_s = min_s; a.max_s = max_s;
+    a.lr_v = lr_v_dev; a.lr_mm = (tune_minmax && min_s && max_s) ? lr_mm_dev : nullptr;
+    a.tune_minmax = (tune_minmax && min_s && max_s && lr_mm_dev) ? 1 : 0;
+    a.snap = snapshot_flag; a.best_V = best_V; a.best_min = best_min; a.best_max = best_max;
+    a.Wq_next = Wq_next; a.n_groups = n_groups;
+    return launch_int_bwd(a, gs, bits, sym, w_dt, s_dt, q_thresh, lo_bound, hi_bound, stream);
+}
+
+extern "C" int ar_sign_sgd(float* p, const float* g, int64_t n, const float* lr_dev, ar_stream_t stream) {
+    if (n <= 0) return AR_OK;
+    const int grid = grid_for_tiles((n / 4 + kTPB - 1) / kTPB);
+    hipLaunchKernelGGL(k_sign_sgd, grid, kTPB, 0, (hipStream_t)stream, p, g, n, lr_dev);
+    return launch_status();
+}

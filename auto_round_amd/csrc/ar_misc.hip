@@ -1,0 +1,259 @@
+// ar_misc.hip -- the small kernels around the quant kernels: MSE loss fwd+bwd, best-loss bookkeeping, calibration
+// activation gather, INT packer.  All HBM-bound byte/integer work; nothing here is GEMM shaped.
+#include <float.h>
+
+#include "ar_common.hpp"
+
+namespace ar {
+
+// ------------------------------------------------------------------------------------------------------------------
+// MSE loss forward + backward in one pass over (pred, ref): 2 reads + 1 write of the activation dtype.
+// Stage 1: per-workgroup partial sums (fp32 per lane over a strided slice, fp64 across lanes) into the workspace.
+// Stage 2: a single workgroup adds the partials in a fixed order -> deterministic loss (the loss feeds the
+//          best-iterate decision, so it must not depend on atomics ordering).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kMseMaxBlocks = 1024;
+
+template <int ADT>
+__global__ __launch_bounds__(kTPB) void k_mse_stage1(const void* __restrict__ pred, const void* __restrict__ ref,
+                                                     void* __restrict__ dpred, double* __restrict__ partials, int64_t n,
+                                                     float alpha, float gout) {
+    __shared__ double red[kTPB / kWave];
+    const int64_t n_chunks = n / kEPT;
+    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    float acc = 0.f;
+    for (int64_t c = (int64_t)blockIdx.x * kTPB + threadIdx.x; c < n_chunks; c += stride) {
+        float p[8], r[8], d[8];
+        unpack8<ADT>(load8_raw<ADT>(pred, c * kEPT), p);
+        unpack8<ADT>(load8_raw<ADT>(ref, c * kEPT), r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float df = p[k] - r[k];
+            acc += df * df;
+            d[k] = (alpha * df) * gout;   // ATen mse_loss_backward: alpha * (a - b) * grad_output
+        }
+        if (dpred) store8<ADT>(dpred, c * kEPT, d);
+    }
+    // tail (n not a multiple of 8)
+    for (int64_t i = n_chunks * kEPT + (int64_t)blockIdx.x * kTPB + threadIdx.x; i < n; i += stride) {
+        const float df = load1<ADT>(pred, i) - load1<ADT>(ref, i);
+        acc += df * df;
+        if (dpred) store1<ADT>(dpred, i, (alpha * df) * gout);
+    }
+    double dacc = (double)acc;
+    for (int m = kWave >> 1; m > 0; m >>= 1) dacc += __shfl_xor(dacc, m, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = dacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < kTPB / kWave; ++w) s += red[w];
+        partials[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(kTPB) void k_mse_stage2(const double* __restrict__ partials, int n_partials, int64_t n,
+                                                     float* __restrict__ loss_out, float* __restrict__ loss_accum,
+                                                     float accum_scale) {
+    __shared__ double red[kTPB];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_partials; i += kTPB) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = kTPB / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mean = (float)(red[0] / (double)n);
+        if (loss_out) *loss_out = mean;
+        if (loss_accum) *loss_accum += mean * accum_scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// best-loss bookkeeping (one lane)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float tl = *total_loss;
+    if (iter == 0) state[1] = tl;
+    state[2] = tl;
+    if (tl < state[0]) {
+        state[0] = tl;
+        istate[0] = 1;
+        istate[1] = iter;
+    } else {
+        istate[0] = 0;
+    }
+    *total_loss = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// row gather: dst[j,:] = src[idx[j],:], 16 bytes per lane per step
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTPB) void k_gather_rows(const uint4* __restrict__ src, const int64_t* __restrict__ idx,
+                                                      uint4* __restrict__ dst, int64_t row_vecs) {
+    const int64_t j = blockIdx.y;
+    const int64_t s = idx[j];
+    const uint4* sp = src + s * row_vecs;
+    uint4* dp = dst + j * row_vecs;
+    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    for (int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x; i < row_vecs; i += stride) dp[i] = sp[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// INT packer.  One lane owns one (32-input block, output column) pair: it re-derives 32 integers from the baked
+// weight exactly as the reference (fp32 division, rint, + zp) and emits `bits` words with the reference's additive
+// arithmetic (see oracle/ar_oracle.c pack32 for the rationale).  Lanes are mapped so that stores to
+// qweight[row, o] are coalesced along o; the 64-byte reads of Wq[o, 32 inputs] are full sectors.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pack32_words(const int32_t (&v)[32], int bits, uint32_t (&w)[8]) {
+    if (bits != 3) {
+        const int P = 32 / bits;
+        for (int k = 0; k < bits; ++k) {
+            uint32_t acc = 0;
+            for (int j = 0; j < P; ++j) acc += (uint32_t)v[k * P + j] << (bits * j);
+            w[k] = acc;
+        }
+        return;
+    }
+    uint32_t a0 = 0, a1 = 0, a2 = 0;
+    for (int j = 0; j < 10; ++j) a0 += (uint32_t)v[j] << (3 * j);
+    for (int j = 0; j < 10; ++j) a1 += (uint32_t)v[11 + j] << (3 * j + 1);
+    for (int j = 0; j < 10; ++j) a2 += (uint32_t)v[22 + j] << (3 * j + 2);
+    w[0] = a0 | ((uint32_t)v[10] << 30);
+    w[1] = (((uint32_t)(v[10] >> 2)) & 1u) | a1 | ((uint32_t)v[21] << 31);
+    w[2] = (((uint32_t)(v[21] >> 1)) & 3u) | a2;
+}
+
+template <int WDT>
+__global__ __launch_bounds__(kTPB) void k_pack_qweight(const void* __restrict__ Wq, const void* __restrict__ scale,
+                                                       const float* __restrict__ zp_tensor, float zp_scalar,
+                                                       int64_t out_f, int64_t in_f, int gs, int bits, int s_dt,
+                                                       int32_t* __restrict__ qweight) {
+    const int64_t o = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+    const int64_t blk = blockIdx.y;
+    if (o >= out_f) return;
+    const int64_t n_groups = (in_f + gs - 1) / gs;
+    int32_t v[32];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float w[8];
+        unpack8<WDT>(load8_raw<WDT>(Wq, o * in_f + blk * 32 + c * 8), w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = blk * 32 + c * 8 + k;
+            const int64_t gi = o * n_groups + i / gs;
+            const float s = load1_rt(s_dt, scale, gi);
+            const float z = zp_tensor ? zp_tensor[gi] : zp_scalar;
+            v[c * 8 + k] = (int32_t)__builtin_rintf(w[k] / s + z);
+        }
+    }
+    uint32_t words[8];
+    pack32_words(v, bits, words);
+    for (int k = 0; k < bits; ++k) qweight[(blk * bits + k) * out_f + o] = (int32_t)words[k];
+}
+
+__global__ __launch_bounds__(kTPB) void k_pack_qzeros_scales(const void* __restrict__ scale,
+                                                             const float* __restrict__ zp_tensor, float zp_scalar,
+                                                             int64_t out_f, int64_t n_groups, int bits, int s_dt,
+                                                             int zp_off, int32_t* __restrict__ qzeros,
+                                                             uint16_t* __restrict__ scales_t) {
+    const int64_t n_blk = out_f / 32;
+    const int64_t zcols = n_blk * bits;
+    const int64_t total_z = n_groups * n_blk;
+    const int64_t total_s = n_groups * out_f;
+    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    for (int64_t t = (int64_t)blockIdx.x * kTPB + threadIdx.x; t < total_z; t += stride) {
+        const int64_t ig = t / n_blk, blk = t % n_blk;
+        int32_t v[32];
+        for (int j = 0; j < 32; ++j) {
+            const int64_t o = blk * 32 + j;
+            const float z = zp_tensor ? zp_tensor[o * n_groups + ig] : zp_scalar;
+            v[j] = (int32_t)(z - (float)zp_off);   // `zeros -= 1` in float, then .to(int32)
+        }
+        uint32_t words[8];
+        pack32_words(v, bits, words);
+        for (int k = 0; k < bits; ++k) qzeros[ig * zcols + blk * bits + k] = (int32_t)words[k];
+    }
+    for (int64_t t = (int64_t)blockIdx.x * kTPB + threadIdx.x; t < total_s; t += stride) {
+        const int64_t ig = t / out_f, o = t % out_f;
+        scales_t[t] = (uint16_t)f32_to_f16(load1_rt(s_dt, scale, o * n_groups + ig));
+    }
+}
+
+}  // namespace ar
+
+using namespace ar;
+
+extern "C" int ar_abi_version(void) { return 1; }
+
+extern "C" const char* ar_error_string(int code) {
+    if (code == AR_OK) return "ok";
+    if (code == AR_ERR_UNSUPPORTED) return "argument combination not supported by this build";
+    return hipGetErrorString((hipError_t)code);
+}
+
+extern "C" int64_t ar_mse_workspace_bytes(void) { return (int64_t)kMseMaxBlocks * sizeof(double); }
+
+extern "C" int ar_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpred, float* loss_out, float* loss_accum,
+                                   float accum_scale, int64_t n, int act_dt, float grad_scale, void* workspace,
+                                   ar_stream_t stream) {
+    if (n <= 0 || !workspace) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t want = (n / kEPT + kTPB - 1) / kTPB;
+    const int grid = (int)(want < 1 ? 1 : (want > kMseMaxBlocks ? kMseMaxBlocks : want));
+    const float alpha = (float)(2.0 / (double)n);
+    double* partials = (double*)workspace;
+    switch (act_dt) {
+        case AR_DT_BF16: hipLaunchKernelGGL(k_mse_stage1<AR_DT_BF16>, grid, kTPB, 0, st, pred, ref, dpred, partials, n, alpha, grad_scale); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_mse_stage1<AR_DT_F16>, grid, kTPB, 0, st, pred, ref, dpred, partials, n, alpha, grad_scale); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_mse_stage1<AR_DT_F32>, grid, kTPB, 0, st, pred, ref, dpred, partials, n, alpha, grad_scale); break;
+        default: return AR_ERR_UNSUPPORTED;
+    }
+    int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mse_stage2, 1, kTPB, 0, st, partials, grid, n, loss_out, loss_accum, accum_scale);
+    return launch_status();
+}
+
+extern "C" int ar_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter, ar_stream_t stream) {
+    hipLaunchKernelGGL(k_best_loss_update, 1, kWave, 0, (hipStream_t)stream, total_loss, state, istate, iter);
+    return launch_status();
+}
+
+extern "C" int ar_gather_rows(const void* src, const int64_t* idx_dev, void* dst, int64_t n_idx, int64_t row_bytes,
+                              ar_stream_t stream) {
+    if (row_bytes % 16 || n_idx < 0 || n_idx > 65535) return AR_ERR_UNSUPPORTED;
+    if (n_idx == 0 || row_bytes == 0) return AR_OK;
+    const int64_t row_vecs = row_bytes / 16;
+    int64_t gx = (row_vecs + kTPB * 4 - 1) / (kTPB * 4);
+    if (gx > 512) gx = 512;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)gx, (unsigned)n_idx), kTPB, 0, (hipStream_t)stream,
+                       (const uint4*)src, idx_dev, (uint4*)dst, row_vecs);
+    return launch_status();
+}
+
+extern "C" int ar_pack_int(const void* Wq, const void* scale, const float* zp_tensor, float zp_scalar, int64_t out_f,
+                           int64_t in_f, int gs, int bits, int w_dt, int s_dt, int zp_off, int32_t* qweight,
+                           int32_t* qzeros, uint16_t* scales_t, ar_stream_t stream) {
+    if (!(bits == 2 || bits == 3 || bits == 4 || bits == 8) || in_f % 32 || gs <= 0 || out_f <= 0) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_groups = (in_f + gs - 1) / gs;
+    dim3 grid((unsigned)((out_f + kTPB - 1) / kTPB), (unsigned)(in_f / 32));
+    switch (w_dt) {
+        case AR_DT_BF16: hipLaunchKernelGGL(k_pack_qweight<AR_DT_BF16>, grid, kTPB, 0, st, Wq, scale, zp_tensor, zp_scalar, out_f, in_f, gs, bits, s_dt, qweight); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_pack_qweight<AR_DT_F16>, grid, kTPB, 0, st, Wq, scale, zp_tensor, zp_scalar, out_f, in_f, gs, bits, s_dt, qweight); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_pack_qweight<AR_DT_F32>, grid, kTPB, 0, st, Wq, scale, zp_tensor, zp_scalar, out_f, in_f, gs, bits, s_dt, qweight); break;
+        default: return AR_ERR_UNSUPPORTED;
+    }
+    int rc = launch_status();
+    if (rc) return rc;
+    int64_t work = n_groups * out_f;
+    int g2 = (int)((work + kTPB - 1) / kTPB);
+    if (g2 > 2048) g2 = 2048;
+    hipLaunchKernelGGL(k_pack_qzeros_scales, g2, kTPB, 0, st, scale, zp_tensor, zp_scalar, out_f, n_groups, bits, s_dt,
+                       zp_off, qzeros, scales_t);
+    return launch_status();
+}

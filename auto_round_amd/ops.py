@@ -1,0 +1,180 @@
+"""Thin torch-tensor front end of the C ABI: every function here validates its tensors, hands raw device pointers
+and the CURRENT torch HIP stream to `libar_mi355x.so`, and returns.  No arithmetic happens in Python.
+
+PyTorch is plumbing only (device memory, streams); the kernels are the product.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AR_DT_BF16, AR_DT_F16, AR_DT_F32, check, load
+
+_DT = {torch.bfloat16: AR_DT_BF16, torch.float16: AR_DT_F16, torch.float32: AR_DT_F32}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dtype}; expected bf16/f16/f32") from None
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.Mi355xLibraryError(
+            f"{name} is on {t.device}: the MI355X path only runs on a HIP device and has no CPU fallback")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _p(t: Optional[torch.Tensor], name: str = "tensor"):
+    return None if t is None else _dev(t, name).data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def group_minmax(W: torch.Tensor, gs: int):
+    """-> (wmin, wmax) in W.dtype, [numel/gs].  (wrapper.py:154-164)"""
+    G = W.numel() // gs
+    wmin = torch.empty(G, dtype=W.dtype, device=W.device)
+    wmax = torch.empty(G, dtype=W.dtype, device=W.device)
+    check(load().ar_group_minmax(_p(W, "W"), _p(wmin), _p(wmax), G, gs, dt_code(W.dtype), _stream()), "ar_group_minmax")
+    return wmin, wmax
+
+
+def group_absmax(W: torch.Tensor, gs: int, want_tensor_max: bool = False):
+    G = W.numel() // gs
+    am = torch.empty(G, dtype=torch.float32, device=W.device)
+    tm = torch.zeros(1, dtype=torch.float32, device=W.device) if want_tensor_max else None
+    check(load().ar_group_absmax(_p(W, "W"), _p(am), _p(tm), G, gs, dt_code(W.dtype), _stream()), "ar_group_absmax")
+    return am, tm
+
+
+def qdq_int_fwd(W, V, wmin, wmax, min_s, max_s, *, gs, bits, sym, scale_dtype=torch.float16, q_thresh=1e-5,
+                bounds=(0.0, 1.0), out=None, want_scale=False):
+    """Fake-quant forward over a flat group array. -> Wq [, scale, zp]"""
+    G = W.numel() // gs
+    Wq = out if out is not None else torch.empty_like(W)
+    scale = torch.empty(G, dtype=scale_dtype, device=W.device) if want_scale else None
+    zp = torch.empty(G, dtype=torch.float32, device=W.device) if want_scale else None
+    check(load().ar_qdq_int_fwd(_p(W, "W"), _p(V, "V"), _p(wmin, "wmin"), _p(wmax, "wmax"), _p(min_s, "min_scale"),
+                                _p(max_s, "max_scale"), _p(Wq, "Wq"), _p(scale), _p(zp), G, gs, bits, int(sym),
+                                dt_code(W.dtype), dt_code(scale_dtype), q_thresh, bounds[0], bounds[1], _stream()),
+          "ar_qdq_int_fwd")
+    return (Wq, scale, zp) if want_scale else Wq
+
+
+def qdq_int_bwd(dWq, W, V, wmin, wmax, min_s, max_s, *, gs, bits, sym, scale_dtype=torch.float16, q_thresh=1e-5,
+                bounds=(0.0, 1.0)):
+    """Unfused backward -> (dV, dmin, dmax) fp32."""
+    G = W.numel() // gs
+    dV = torch.empty(W.numel(), dtype=torch.float32, device=W.device)
+    dmin = torch.empty(G, dtype=torch.float32, device=W.device)
+    dmax = torch.empty(G, dtype=torch.float32, device=W.device)
+    check(load().ar_qdq_int_bwd(_p(dWq, "dWq"), _p(W, "W"), _p(V, "V"), _p(wmin), _p(wmax), _p(min_s), _p(max_s), _p(dV),
+                                _p(dmin), _p(dmax), G, gs, bits, int(sym), dt_code(W.dtype), dt_code(scale_dtype),
+                                q_thresh, bounds[0], bounds[1], _stream()), "ar_qdq_int_bwd")
+    return dV, dmin, dmax
+
+
+def sign_sgd_(p: torch.Tensor, g: torch.Tensor, lr_dev: torch.Tensor):
+    check(load().ar_sign_sgd(_p(p, "param"), _p(g, "grad"), p.numel(), _p(lr_dev, "lr"), _stream()), "ar_sign_sgd")
+    return p
+
+
+def qdq_int_bwd_sgd_(dWq, W, V, wmin, wmax, min_s, max_s, *, gs, bits, sym, lr_v, lr_mm, tune_minmax=True,
+                     scale_dtype=torch.float16, q_thresh=1e-5, bounds=(0.0, 1.0), snapshot_flag=None, best_V=None,
+                     best_min=None, best_max=None, Wq_next=None):
+    """Fused backward + sign-SGD (in place on V, min_s, max_s) [+ snapshot] [+ next forward]."""
+    G = W.numel() // gs
+    check(load().ar_qdq_int_bwd_sgd(_p(dWq, "dWq"), _p(W, "W"), _p(V, "V"), _p(wmin), _p(wmax), _p(min_s), _p(max_s), G,
+                                    gs, bits, int(sym), dt_code(W.dtype), dt_code(scale_dtype), q_thresh, bounds[0],
+                                    bounds[1], _p(lr_v, "lr_v"), _p(lr_mm, "lr_mm"), int(tune_minmax),
+                                    _p(snapshot_flag), _p(best_V), _p(best_min), _p(best_max), _p(Wq_next), _stream()),
+          "ar_qdq_int_bwd_sgd")
+
+
+_mse_ws = {}
+
+
+def mse_workspace(device) -> torch.Tensor:
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ws = _mse_ws.get(key)
+    if ws is None:
+        ws = torch.empty(load().ar_mse_workspace_bytes(), dtype=torch.uint8, device=f"cuda:{key}")
+        _mse_ws[key] = ws
+    return ws
+
+
+def mse_loss_fwd_bwd(pred, ref, *, dpred=None, loss_out=None, loss_accum=None, accum_scale=1.0, grad_scale=1000.0):
+    """loss = mean((pred-ref)^2) ; dpred = d(loss*grad_scale)/dpred in pred.dtype. -> (loss_out [1] f32, dpred)"""
+    if dpred is None:
+        dpred = torch.empty_like(pred)
+    if loss_out is None:
+        loss_out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    check(load().ar_mse_loss_fwd_bwd(_p(pred, "pred"), _p(ref, "ref"), _p(dpred), _p(loss_out), _p(loss_accum),
+                                     accum_scale, pred.numel(), dt_code(pred.dtype), grad_scale,
+                                     _p(mse_workspace(pred.device)), _stream()), "ar_mse_loss_fwd_bwd")
+    return loss_out, dpred
+
+
+def best_loss_update(total_loss, state, istate, it: int):
+    check(load().ar_best_loss_update(_p(total_loss), _p(state), _p(istate), it, _stream()), "ar_best_loss_update")
+
+
+def gather_rows(src: torch.Tensor, idx_dev: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """out[j] = src[idx[j]] along dim 0 (rows must be a multiple of 16 bytes)."""
+    row_bytes = src[0].numel() * src.element_size()
+    n = idx_dev.numel()
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    if idx_dev.dtype != torch.int64:
+        raise TypeError("idx must be int64")
+    check(load().ar_gather_rows(_p(src, "src"), _p(idx_dev, "idx"), _p(out, "out"), n, row_bytes, _stream()),
+          "ar_gather_rows")
+    return out
+
+
+def pack_int(Wq2d: torch.Tensor, scale2d: torch.Tensor, zp, *, gs, bits, zp_off=1):
+    """-> (qweight int32 [in/32*bits, out], qzeros int32 [in/gs, out/32*bits], scales fp16 [in/gs, out])"""
+    out_f, in_f = Wq2d.shape
+    ng = (in_f + gs - 1) // gs
+    dev = Wq2d.device
+    qweight = torch.empty((in_f // 32 * bits, out_f), dtype=torch.int32, device=dev)
+    qzeros = torch.empty((ng, out_f // 32 * bits), dtype=torch.int32, device=dev)
+    scales_t = torch.empty((ng, out_f), dtype=torch.float16, device=dev)
+    if isinstance(zp, torch.Tensor):
+        zt, zs = zp.to(device=dev, dtype=torch.float32).contiguous(), 0.0
+    else:
+        zt, zs = None, float(zp)
+    check(load().ar_pack_int(_p(Wq2d, "Wq"), _p(scale2d, "scale"), _p(zt), zs, out_f, in_f, gs, bits, dt_code(Wq2d.dtype),
+                             dt_code(scale2d.dtype), zp_off, _p(qweight), _p(qzeros), _p(scales_t), _stream()),
+          "ar_pack_int")
+    return qweight, qzeros, scales_t
+
+
+def qdq_fp4_fwd(X, V, absmax, max_s, *, mode, gs, init_scale=1.0, global_scale=None, bounds=(0.0, 1.0), out=None,
+                want_scale=False):
+    G = X.numel() // gs
+    Xq = out if out is not None else torch.empty_like(X)
+    scale = None
+    if want_scale:
+        scale = torch.empty(G, dtype=X.dtype if mode == 0 else torch.float32, device=X.device)
+    check(load().ar_qdq_fp4_fwd(_p(X, "X"), _p(V), _p(absmax), _p(max_s), init_scale, _p(global_scale), _p(Xq), _p(scale),
+                                G, gs, mode, dt_code(X.dtype), bounds[0], bounds[1], _stream()), "ar_qdq_fp4_fwd")
+    return (Xq, scale) if want_scale else Xq
+
+
+def pack_fp4(Wq2d, scale, *, mode, gs, global_scale=None):
+    out_f, in_f = Wq2d.shape
+    packed = torch.empty((out_f, in_f // 2), dtype=torch.uint8, device=Wq2d.device)
+    sb = torch.empty((out_f, in_f // gs), dtype=torch.uint8, device=Wq2d.device)
+    check(load().ar_pack_fp4(_p(Wq2d, "Wq"), _p(scale, "scale"), _p(global_scale), out_f, in_f, gs, mode,
+                             dt_code(Wq2d.dtype), _p(packed), _p(sb), _stream()), "ar_pack_fp4")
+    return packed, sb

@@ -1,0 +1,154 @@
+/*
+ * ar_mi355x.h -- C ABI of the MI355X (gfx950 / CDNA4) implementation of AutoRound's block-tuning hot path.
+ *
+ * This is the drop-in boundary: plain pointers + sizes + a hipStream_t, no torch types.  Every entry point
+ *   - takes DEVICE pointers (HBM resident; 16-byte aligned for the bulk arrays),
+ *   - enqueues work on `stream` and returns immediately (never synchronises, never allocates),
+ *   - returns 0 on success or the hipError_t of the failed launch (ar_error_string() decodes it);
+ *     AR_ERR_UNSUPPORTED (-1) means the argument combination is outside what this build implements.
+ *
+ * Each function names the reference interface it replaces (paths relative to the intel/auto-round tree).
+ * The Python host layer (auto_round_amd/) binds these with ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add to call them from auto_round's own plugin points.
+ *
+ * Layout conventions (identical to the reference's group-reshaped tensors, data_type/utils.py:29-71):
+ *   W, Wq, dWq : [n_groups * gs] row-major == the [out, in] weight viewed as [out*in/gs, gs]  (in % gs == 0)
+ *   V          : [n_groups * gs] fp32 rounding offsets (WrapperLinear.value)
+ *   wmin, wmax : [n_groups] in the weight dtype, min clamped to <=0 / max clamped to >=0 (wrapper.py:154-164)
+ *   min_s,max_s: [n_groups] fp32 (WrapperLinear.min_scale / max_scale)
+ * A whole transformer block may be passed as ONE call: the per-layer arrays are slices of block-wide flat
+ * buffers, so n_groups is the block total (grouped launch; no per-layer descriptor table is needed).
+ */
+#ifndef AR_MI355X_H
+#define AR_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ar_stream_t; /* hipStream_t */
+
+enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
+enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
+
+/* ABI version of this header; bump on any signature change. */
+int ar_abi_version(void);
+/* Human-readable text for a non-zero return code of any function below. */
+const char* ar_error_string(int code);
+
+/* ---- weight statistics --------------------------------------------------------------------------------------
+ * replaces: WrapperLinear._init_tuning_params_and_quant_func weight_min/weight_max (auto_round/wrapper.py:154-164)
+ * wmin[g] = min(min_k W[g,k], 0), wmax[g] = max(max_k W[g,k], 0)  -- wavefront shuffle reductions. */
+int ar_group_minmax(const void* W, void* wmin, void* wmax, int64_t n_groups, int gs, int w_dt, ar_stream_t stream);
+
+/* absmax[g] = max_k |W[g,k]| (fp32 out); *tensor_absmax (optional, fp32, must be zeroed by the caller) receives the
+ * global max via atomic max.  replaces: torch.max(torch.abs(tensor)) in quant_mx (data_type/mxfp.py:268) and
+ * calculate_gparam (data_type/nvfp.py:56-64). */
+int ar_group_absmax(const void* W, float* absmax, float* tensor_absmax, int64_t n_groups, int gs, int w_dt,
+                    ar_stream_t stream);
+
+/* ---- INT fake-quant forward (W2/W3/W4/W8; sym "full range" and asym) -----------------------------------------
+ * replaces: quant_tensor_sym / quant_tensor_asym (auto_round/data_type/int.py:165-238, :241-298) as called by
+ *           WrapperLinear._qdq_weight (auto_round/wrapper.py:244-293), including its in-place [lo,hi] clamp of
+ *           min_scale/max_scale (wrapper.py:257-259; applied on read, see ar_qdq_int_bwd_sgd for the write-back).
+ * V, min_s, max_s may be NULL (treated as 0 / 1 / 1 == plain RTN).  scale_out [n_groups] (s_dt) and zp_out
+ * [n_groups] (fp32; sym writes 2^(bits-1)) are optional (NULL during tuning, set for the final unwrap call). */
+int ar_qdq_int_fwd(const void* W, const float* V, const void* wmin, const void* wmax, const float* min_s,
+                   const float* max_s, void* Wq, void* scale_out, float* zp_out, int64_t n_groups, int gs, int bits,
+                   int sym, int w_dt, int s_dt, float q_thresh, float lo_bound, float hi_bound, ar_stream_t stream);
+
+/* ---- INT fake-quant backward (unfused; for step-level parity tests) ------------------------------------------
+ * replaces: torch autograd through the forward above.  dV [n_groups*gs], dmin/dmax
+ * [n_groups] fp32; any of the three may be NULL. */
+int ar_qdq_int_bwd(const void* dWq, const void* W, const float* V, const void* wmin, const void* wmax,
+                   const float* min_s, const float* max_s, float* dV, float* dmin, float* dmax, int64_t n_groups,
+                   int gs, int bits, int sym, int w_dt, int s_dt, float q_thresh, float lo_bound, float hi_bound,
+                   ar_stream_t stream);
+
+/* ---- sign-SGD (unfused) --------------------------------------------------------------------------------------
+ * replaces: SignSGD.step -> _single_tensor_sgd: param.add_(sign(g), alpha=-lr)
+ *           (auto_round/algorithms/quantization/sign_round/sign_sgd.py:356-389).  lr is read from device memory
+ * (one fp32) so that a captured hipGraph can be replayed with a new learning rate. */
+int ar_sign_sgd(float* p, const float* g, int64_t n, const float* lr_dev, ar_stream_t stream);
+
+/* ---- fused backward + sign-SGD (+ best-parameter snapshot, + next forward) -----------------------------------
+ * One pass over the block: reads dWq, W, V; writes V (and min_s/max_s, clamped-then-stepped); dV never exists in
+ * HBM.  replaces, per iteration: autograd backward of the qdq, optimizer.step(), zero_grad()
+ * (sign_round/quantizer.py:502,523,805-821) and, when snapshot_flag != NULL and *snapshot_flag != 0, the
+ * collect_best_params deep copy (compressors/utils.py:205-217): best_* receive the PRE-update values (V and the
+ * clamped scales), i.e. the parameters that produced the loss that was just found to be the best.
+ * lr_v_dev / lr_mm_dev: device fp32 learning rates for V and for min/max scales (LinearLR runs on the host).
+ * tune_minmax == 0 leaves min_s/max_s untouched (enable_minmax_tuning=False).
+ * Wq_next (optional): when non-NULL the kernel also emits the NEXT iteration's fake-quant weight from the updated
+ * parameters (same arithmetic as ar_qdq_int_fwd), saving that kernel's read of W and V. */
+int ar_qdq_int_bwd_sgd(const void* dWq, const void* W, float* V, const void* wmin, const void* wmax, float* min_s,
+                       float* max_s, int64_t n_groups, int gs, int bits, int sym, int w_dt, int s_dt, float q_thresh,
+                       float lo_bound, float hi_bound, const float* lr_v_dev, const float* lr_mm_dev, int tune_minmax,
+                       const int32_t* snapshot_flag, float* best_V, float* best_min, float* best_max, void* Wq_next,
+                       ar_stream_t stream);
+
+/* ---- MSE output loss, forward + backward in one pass ---------------------------------------------------------
+ * replaces: _get_loss (MSELoss on fp32 casts, sign_round/quantizer.py:127-158) + (loss*1000).backward()
+ *           (:789-803) up to the gradient w.r.t. the block output.
+ * dpred (act dtype) = ((2/n) * (pred-ref)) * grad_scale ; *loss_out = mean((pred-ref)^2) ;
+ * if loss_accum != NULL: *loss_accum += mean * accum_scale  (the loop's `total_loss += loss.item()/num_elm`
+ * without the host sync).  workspace: >= ar_mse_workspace_bytes() bytes of device scratch. */
+int64_t ar_mse_workspace_bytes(void);
+int ar_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpred, float* loss_out, float* loss_accum,
+                        float accum_scale, int64_t n, int act_dt, float grad_scale, void* workspace,
+                        ar_stream_t stream);
+
+/* ---- best-loss bookkeeping on the device ---------------------------------------------------------------------
+ * replaces: `if total_loss < best_loss: best_loss = total_loss; last_best_iter = i` (sign_round/quantizer.py:508-517)
+ * state[0]=best_loss (init FLT_MAX) state[1]=init_loss state[2]=last total_loss ; istate[0]=snapshot flag
+ * istate[1]=last_best_iter.  Also zeroes *total_loss for the next iteration. */
+int ar_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter, ar_stream_t stream);
+
+/* ---- calibration-activation gather ---------------------------------------------------------------------------
+ * replaces: torch.cat([inputs[i] for i in indices]) in BlockForwardRunner._select_batch
+ *           (auto_round/algorithms/block_runner.py:368-422) and the fp_outputs gather (sign_round/quantizer.py:482).
+ * dst[j, :] = src[idx[j], :] for j < n_idx ; rows are row_bytes long (multiple of 16). idx lives on the device. */
+int ar_gather_rows(const void* src, const int64_t* idx_dev, void* dst, int64_t n_idx, int64_t row_bytes,
+                   ar_stream_t stream);
+
+/* ---- INT packer (GPTQ order) ---------------------------------------------------------------------------------
+ * replaces: QuantLinear.pack -> pack_248_bits / pack_3bits of auto_round_extension/torch/qlinear_torch_zp.py:93-263
+ *           (zp_off = 1, the "zp-1" convention) and auto_round_extension/torch/qlinear_torch.py:110-281 (zp_off = 0).
+ * Wq [out,in] baked fake-quant weight, scale [out, in/gs] (s_dt), zp_tensor [out, in/gs] fp32 or NULL (then
+ * zp_scalar).  qweight [in/32*bits, out] int32, qzeros [in/gs, out/32*bits] int32, scales_t [in/gs, out] fp16.
+ * Integers are re-derived as rint(Wq/scale + zp) and packed with the reference's exact (additive) arithmetic. */
+int ar_pack_int(const void* Wq, const void* scale, const float* zp_tensor, float zp_scalar, int64_t out_f,
+                int64_t in_f, int gs, int bits, int w_dt, int s_dt, int zp_off, int32_t* qweight, int32_t* qzeros,
+                uint16_t* scales_t, ar_stream_t stream);
+
+/* ---- MXFP4 / NVFP4 fake-quant -------------------------------------------------------------------------------
+ * replaces: quant_mx (auto_round/data_type/mxfp.py:233-291, element rounding :49-85) and
+ *           nv_fp4 -> ref_nvfp4_quant -> cast_to_fp4 (auto_round/data_type/nvfp.py:83-98, :67-80, :26-39),
+ * for weights (V, max_s tunable) and activations (V = NULL, max_s = NULL).
+ * mode 0 = MXFP4 (gs 32; scale_out = shared exponent in the tensor dtype), 1 = NVFP4 (gs 16; scale_out fp32 holding
+ * e4m3 values; global_scale_dev = device fp32).  absmax [n_groups] fp32 from ar_group_absmax (weights: computed once). */
+int ar_qdq_fp4_fwd(const void* X, const float* V, const float* absmax, const float* max_s, float init_scale,
+                   const float* global_scale_dev, void* Xq, void* scale_out, int64_t n_groups, int gs, int mode,
+                   int x_dt, float lo_bound, float hi_bound, ar_stream_t stream);
+/* fused backward + sign-SGD for the fp4 weight path (V and max_scale); same contract as ar_qdq_int_bwd_sgd.
+ * dV_out/dmax_out (optional) additionally export the raw gradients for parity tests (then no update is applied
+ * when lr_v_dev == NULL). */
+int ar_qdq_fp4_bwd_sgd(const void* dXq, const void* X, float* V, const float* absmax, float* max_s, float init_scale,
+                       const float* global_scale_dev, int64_t n_groups, int gs, int mode, int x_dt, float lo_bound,
+                       float hi_bound, const float* lr_v_dev, const float* lr_mm_dev, int tune_minmax,
+                       const int32_t* snapshot_flag, float* best_V, float* best_max, float* dV_out, float* dmax_out,
+                       ar_stream_t stream);
+
+/* ---- FP4 packer ----------------------------------------------------------------------------------------------
+ * replaces: qlinear_fp.QuantLinear.pack + _pack_fp4_to_uint8 (auto_round/export/export_to_autoround/qlinear_fp.py
+ *           :141-193, :235-265).  packed [out, in/2] uint8 (low nibble = even index), scale_bytes [out, in/gs]
+ * (e8m0 for mode 0, e4m3fn for mode 1). */
+int ar_pack_fp4(const void* Wq, const void* scale, const float* global_scale_dev, int64_t out_f, int64_t in_f, int gs,
+                int mode, int w_dt, uint8_t* packed, uint8_t* scale_bytes, ar_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AR_MI355X_H */

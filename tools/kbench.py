@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the quant kernels at BASELINE sizes (achieved algorithmic GB/s). GPU box only."""
+import argparse
+import json
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from auto_round_amd import ops
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=218103808)   # Llama-3-8B block
+    ap.add_argument("--gs", type=int, default=128)
+    ap.add_argument("--bits", type=int, default=4)
+    ap.add_argument("--asym", action="store_true")
+    a = ap.parse_args()
+    n, gs = a.n // a.gs * a.gs, a.gs
+    G = n // gs
+    g = torch.Generator(device="cuda").manual_seed(0)
+    W = (torch.randn(n, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    V = torch.rand(n, generator=g, device="cuda") - 0.5
+    dWq = (torch.randn(n, generator=g, device="cuda") * 1e-3).to(torch.bfloat16)
+    ms = torch.ones(G, device="cuda"); Ms = torch.ones(G, device="cuda")
+    wmin, wmax = ops.group_minmax(W, gs)
+    Wq = torch.empty_like(W)
+    lr = torch.tensor([1e-9], device="cuda")
+    sym = not a.asym
+    res = {}
+    t = timeit(lambda: ops.qdq_int_fwd(W, V, wmin, wmax, ms, Ms, gs=gs, bits=a.bits, sym=sym, out=Wq))
+    res["fwd_ms"] = t; res["fwd_GBps"] = (8 * n + 12 * G) / t / 1e6
+    t = timeit(lambda: ops.qdq_int_bwd_sgd_(dWq, W, V, wmin, wmax, ms, Ms, gs=gs, bits=a.bits, sym=sym, lr_v=lr, lr_mm=lr))
+    res["bwd_sgd_ms"] = t; res["bwd_sgd_GBps"] = (12 * n + 8 * G) / t / 1e6
+    t = timeit(lambda: ops.qdq_int_bwd_sgd_(dWq, W, V, wmin, wmax, ms, Ms, gs=gs, bits=a.bits, sym=sym, lr_v=lr, lr_mm=lr, Wq_next=Wq))
+    res["bwd_sgd_fwd_ms"] = t; res["bwd_sgd_fwd_GBps"] = (14 * n + 8 * G) / t / 1e6
+    t = timeit(lambda: Wq.copy_(W))
+    res["copy_bf16_ms"] = t; res["copy_GBps"] = 4 * n / t / 1e6
+    t = timeit(lambda: ops.group_minmax(W, gs))
+    res["minmax_ms"] = t; res["minmax_GBps"] = 2 * n / t / 1e6
+    print(json.dumps({k: round(v, 3) for k, v in res.items()}))
+
+
+if __name__ == "__main__":
+    main()
