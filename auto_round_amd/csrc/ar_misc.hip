@@ -82,6 +82,7 @@ __global__ void k_best_loss_update(float* total_loss, float* state, int32_t* ist
         state[0] = tl;
         istate[0] = 1;
         istate[1] = iter;
+        istate[2] += 1;
     } else {
         istate[0] = 0;
     }

@@ -1,0 +1,139 @@
+"""Packing side of the hot path: mirrors of the reference's pack-only `QuantLinear` duck type
+(`QuantLinear(bits, group_size, infeatures, outfeatures, bias, weight_dtype=...).pack(linear, scales, zeros, g_idx,
+device)`; export/export_to_autoround/export.py:206-228) backed by the HIP packers.
+
+  QuantLinearZP   <- auto_round_extension/torch/qlinear_torch_zp.py  ("auto_round:auto_gptq", sym int; stores zp-1)
+  QuantLinearPlain<- auto_round_extension/torch/qlinear_torch.py     ("auto_round", asym int; stores zp)
+  QuantLinearFP4  <- auto_round/export/export_to_autoround/qlinear_fp.py (MXFP4 / NVFP4 nibbles + e8m0/e4m3 scales)
+
+Buffers have the reference's names, shapes and dtypes (qweight int32 [in/32*bits, out], qzeros int32
+[in/gs, out/32*bits], scales fp16 [in/gs, out]; weight_packed uint8 [out, in/2], weight_scale uint8/e4m3) and are
+bit-identical to the reference's for the same baked layer (tests/test_gpu_kernels.py::test_pack_*).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+
+
+class _QuantLinearInt(torch.nn.Module):
+    ZP_OFF = 1
+    QUANT_TYPE = "mi355x"
+
+    def __init__(self, bits, group_size, infeatures, outfeatures, bias=False, weight_dtype=torch.bfloat16, **kwargs):
+        super().__init__()
+        if bits not in (2, 3, 4, 8):
+            raise NotImplementedError("Only 2,3,4,8 bits are supported.")
+        if infeatures % 32 or outfeatures % 32:
+            raise NotImplementedError("in_features and out_features must be divisible by 32.")
+        self.bits, self.infeatures, self.outfeatures = bits, infeatures, outfeatures
+        self.group_size = group_size if group_size != -1 else infeatures
+        ng = (infeatures + self.group_size - 1) // self.group_size
+        self.register_buffer("qweight", torch.zeros((infeatures // 32 * bits, outfeatures), dtype=torch.int32))
+        self.register_buffer("qzeros", torch.zeros((ng, outfeatures // 32 * bits), dtype=torch.int32))
+        self.register_buffer("scales", torch.zeros((ng, outfeatures), dtype=torch.float16))
+        if bias:
+            self.register_buffer("bias", torch.zeros((outfeatures,), dtype=torch.float16))
+        else:
+            self.bias = None
+
+    def pack(self, linear, scales, zeros, g_idx=None, device=None):
+        dev = torch.device(device) if device is not None else linear.weight.device
+        if dev.type != "cuda":
+            dev = torch.device("cuda", torch.cuda.current_device())
+        W = linear.weight.data.to(dev)
+        if W.dim() == 4:
+            W = W.flatten(1)
+        try:
+            from transformers.pytorch_utils import Conv1D
+
+            if isinstance(linear, Conv1D):
+                W = W.t()
+        except Exception:  # pragma: no cover
+            pass
+        W = W.contiguous()
+        s = scales.to(dev).contiguous()
+        z = zeros.to(dev) if isinstance(zeros, torch.Tensor) else zeros
+        qw, qz, st = ops.pack_int(W, s, z, gs=self.group_size, bits=self.bits, zp_off=self.ZP_OFF)
+        self.qweight, self.qzeros, self.scales = qw, qz, st
+        if getattr(linear, "bias", None) is not None:
+            self.bias = linear.bias.detach().clone().half()
+
+
+class QuantLinearZP(_QuantLinearInt):
+    """GPTQ "zp-1" convention (reference qlinear_torch_zp.py:129,143)."""
+    ZP_OFF = 1
+
+
+class QuantLinearPlain(_QuantLinearInt):
+    """stores the zero point unchanged (reference qlinear_torch.py)."""
+    ZP_OFF = 0
+
+
+class QuantLinearFP4(torch.nn.Module):
+    def __init__(self, bits, group_size, infeatures, outfeatures, bias=False, data_type="mx_fp", **kwargs):
+        super().__init__()
+        if bits != 4:
+            raise NotImplementedError("QuantLinearFP4 packs 4-bit MXFP4/NVFP4 only")
+        self.is_mx = data_type.startswith("mx")
+        self.is_nv = data_type.startswith("nv")
+        self.bits, self.group_size, self.infeatures, self.outfeatures = bits, group_size, infeatures, outfeatures
+        self.register_buffer("weight_packed", torch.zeros((outfeatures, infeatures // 2), dtype=torch.uint8))
+        self.bias = None
+
+    def pack(self, linear, scales, zeros=None, g_idx=None, global_scale=None, input_global_scale=None, device=None):
+        dev = linear.weight.device if linear.weight.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        W = linear.weight.data.to(dev).contiguous()
+        mode = 0 if self.is_mx else 1
+        s = scales.to(dev).contiguous()
+        gsc = None
+        if self.is_nv:
+            gsc = global_scale.to(device=dev, dtype=torch.float32).reshape(1)
+            s = s.to(torch.float32)
+        packed, sb = ops.pack_fp4(W, s.reshape(-1), mode=mode, gs=self.group_size, global_scale=gsc)
+        self.weight_packed = packed
+        self.weight_scale = sb if self.is_mx else sb.view(torch.float8_e4m3fn)
+        if gsc is not None:
+            self.weight_global_scale = gsc
+        if input_global_scale is not None:
+            self.input_global_scale = input_global_scale.to(torch.float32).to(dev).reshape([1])
+        if getattr(linear, "bias", None) is not None:
+            self.bias = linear.bias.detach().to(torch.float16)
+
+
+def dynamic_import_quant_linear_for_packing(backend: str, bits: int, group_size: int, sym: bool, act_bits: int = 16):
+    """reference: export/export_to_autoround/export.py:56-95 -- which packer a backend string selects."""
+    if "auto_round" in backend and "awq" not in backend and "gptq" not in backend:
+        return QuantLinearPlain
+    if "auto_round" in backend and "gptq" in backend and "gptqmodel" not in backend:
+        return QuantLinearZP
+    raise ValueError(f"unsupported backend for the MI355X packers: {backend}")
+
+
+def pack_layer(layer: torch.nn.Linear, backend: str = "auto_round:auto_gptq", device=None):
+    """reference: export/export_to_autoround/export.py:143-239 for one already-unwrapped layer carrying
+    `scale` / `zp`.  Returns the packed QuantLinear (does not splice it into a model)."""
+    bits, gs, sym = int(layer.bits), int(layer.group_size), bool(layer.sym)
+    QL = dynamic_import_quant_linear_for_packing(backend, bits, gs, sym)
+    out_f, in_f = layer.weight.shape
+    ql = QL(bits, gs, in_f, out_f, bias=layer.bias is not None, weight_dtype=layer.weight.dtype)
+    zp = layer.zp
+    if sym and isinstance(zp, torch.Tensor) and QL is QuantLinearPlain:
+        zp = int(zp.flatten()[0])
+    ql.pack(layer, layer.scale, zp, None, device=device)
+    return ql
+
+
+def pack_block(block, backend: Optional[str] = None) -> Dict[str, torch.nn.Module]:
+    """Pack every tuned linear of an unwrapped block (the orchestrator's immediate_pack, orchestrator.py:327-337).
+    backend defaults to what AutoRoundFormat picks: sym int -> auto_round:auto_gptq, asym -> auto_round
+    (export/formats/backends/autoround.py:59-70)."""
+    out = {}
+    for n, m in block.named_modules():
+        if isinstance(m, torch.nn.Linear) and hasattr(m, "scale") and int(getattr(m, "bits", 16)) < 16:
+            be = backend or ("auto_round:auto_gptq" if m.sym else "auto_round")
+            out[n] = pack_layer(m, be)
+    return out

@@ -1,0 +1,354 @@
+"""Host side of the per-block sign-gradient tuning loop, mirroring the reference's operator interface:
+
+    SignRoundQuantizer.quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=None)
+        reference: auto_round/algorithms/quantization/sign_round/quantizer.py:311-552
+    block_forward / IndexSampler / collect_best_params
+        reference: auto_round/compressors/utils.py:109-172, :388-438, :205-217
+    compress_block (reference fp forward -> quantize_block -> quantized-output forward)
+        reference: auto_round/algorithms/composer.py:360-483 (steps 3, 4, 6)
+
+What is different from the reference, by design (MI355X-first, device resident):
+  * calibration inputs/targets are ONE contiguous [nsamples, seq, hidden] HBM tensor each; minibatches are gathered
+    by an index kernel from a pre-uploaded index schedule (the Python `random` stream is consumed exactly as the
+    reference's IndexSampler consumes it);
+  * per iteration the quant work is two grouped launches for the whole block (qdq forward; fused backward +
+    sign-SGD + best-snapshot + next forward) instead of ~30 eager kernels per layer;
+  * the loss, the `total_loss < best_loss` decision and the best-parameter copy stay on the device: there is no
+    `.item()` per batch -- one host sync per block (unless dynamic_max_gap early stopping is requested).
+The block's GEMMs/attention run through PyTorch-ROCm (hipBLASLt / SDPA on MFMA).
+"""
+from __future__ import annotations
+
+import copy
+import inspect
+import random
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, List, Optional, Sequence, Union
+
+import torch
+
+from . import ops
+from .sign_sgd import SignSGD
+from .wrapper import WrapperLinear, unwrapper_block, wrapper_block
+
+FLT_MAX = float(torch.finfo(torch.float32).max)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# small mirrors of reference helpers
+# ----------------------------------------------------------------------------------------------------------------------
+class IndexSampler:
+    """Cyclic shuffled minibatch sampler drawing from Python's GLOBAL `random` stream, exactly like the reference
+    (auto_round/compressors/utils.py:388-438): shuffle at construction, reshuffle when fewer than `batch_size`
+    indices remain.  `transformers.set_seed(seed)` / `random.seed(seed)` before the run fixes the schedule."""
+
+    def __init__(self, nsamples: int, batch_size: int) -> None:
+        if batch_size <= 0 or batch_size > nsamples:
+            raise ValueError("batch_size must be > 0 and <= nsamples")
+        self.nsamples = nsamples
+        self.batch_size = batch_size
+        self.index = 0
+        self.indices = list(range(nsamples))
+        random.shuffle(self.indices)
+
+    def next_batch(self) -> List[int]:
+        if self.index + self.batch_size > self.nsamples:
+            random.shuffle(self.indices)
+            self.index = 0
+        batch = self.indices[self.index:self.index + self.batch_size]
+        self.index += self.batch_size
+        return batch
+
+
+def block_forward(block, input_ids, input_others, amp=False, amp_dtype=torch.bfloat16, device=None, output_return_id=0):
+    """reference: auto_round/compressors/utils.py:109-172 -- first positional parameter of block.forward receives the
+    hidden states, everything else goes by keyword; tuple outputs are reduced to element `output_return_id`."""
+    others = dict(input_others) if input_others else {}
+    positional = others.pop("positional_inputs", None) or ()
+    names = [p for p in inspect.signature(block.forward).parameters.keys() if p != "self"]
+    first = names[0] if names else "hidden_states"
+    if first not in others:
+        others[first] = input_ids
+    for i, val in enumerate(positional):
+        if i + 1 < len(names) and names[i + 1] not in others:
+            others[names[i + 1]] = val
+    if amp:
+        with torch.autocast(device_type="cuda", dtype=amp_dtype):
+            out = block(**others)
+    else:
+        out = block(**others)
+    if isinstance(out, (tuple, list)):
+        out = out[output_return_id]
+    return out
+
+
+def collect_best_params(block, cache_device=None) -> Dict[str, Dict[str, torch.Tensor]]:
+    """reference: auto_round/compressors/utils.py:205-217 -- deep copy of every wrapper's tunable parameters."""
+    params = {}
+    for n, m in block.named_modules():
+        if hasattr(m, "orig_layer"):
+            params[n] = {k: (p.data.to(cache_device, copy=True) if cache_device is not None else p.data.clone())
+                         for k, p in m.params.items()}
+    return params
+
+
+def stack_samples(samples: Union[torch.Tensor, Sequence[torch.Tensor]], device) -> torch.Tensor:
+    """list of [1, S, H] (the reference's per-sample cache) or an [N, S, H] tensor -> contiguous [N, S, H] in HBM."""
+    if isinstance(samples, torch.Tensor):
+        return samples.to(device).contiguous()
+    return torch.cat([s.to(device) for s in samples], dim=0).contiguous()
+
+
+@dataclass
+class BlockContext:
+    """reference: algorithms BlockContext -- only the fields the quantizer reads."""
+    block_index: int = 0
+    block_cnt: int = 1
+    block_name: str = ""
+
+
+@dataclass
+class SignRoundConfig:
+    """The fields of the reference's SignRoundConfig / QuantizationConfig that steer the hot path
+    (auto_round/algorithms/quantization/sign_round/config.py:20-170)."""
+    iters: int = 200
+    lr: Optional[float] = None
+    minmax_lr: Optional[float] = None
+    lr_scheduler: Any = None
+    momentum: float = 0.0
+    enable_minmax_tuning: bool = True
+    enable_norm_bias_tuning: bool = False
+    gradient_accumulate_steps: int = 1
+    not_use_best_mse: bool = False
+    dynamic_max_gap: int = -1
+    enable_quanted_input: bool = True
+    batch_size: int = 8
+    bits: Optional[int] = 4
+    amp: bool = True
+    amp_dtype: torch.dtype = torch.bfloat16
+    fuse_next_forward: bool = True       # MI355X: emit iteration i+1's Wq from the fused backward kernel
+
+    def __post_init__(self):
+        if self.iters < 0:
+            self.iters = 200
+        self.lr_is_auto = self.lr is None and self.iters > 0
+        self.minmax_lr_is_auto = self.minmax_lr is None
+        if self.lr_is_auto:
+            self.lr = self._lr_for_bits(self.bits)
+        self.minmax_lr = self.minmax_lr or self.lr
+
+    def _lr_for_bits(self, bits):
+        if self.iters <= 0:
+            return None
+        if self.iters >= 1000 and bits is not None and bits <= 3:
+            return 2.0 / self.iters
+        return 1.0 / self.iters
+
+    def compute_lr(self, bits):
+        return self._lr_for_bits(bits) if self.lr_is_auto else self.lr
+
+    def compute_minmax_lr(self, bits):
+        return self.compute_lr(bits) if self.minmax_lr_is_auto else self.minmax_lr
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the quantizer
+# ----------------------------------------------------------------------------------------------------------------------
+class SignRoundQuantizer:
+    """MI355X implementation of the reference's block quantizer contract (quantization/base.py:148-179):
+    `quantize_block(...) -> best_params`; post-conditions identical to the reference (block unwrapped in place,
+    each quantised layer's weight holds the qdq values and carries `scale` / `zp`)."""
+
+    wrapper_block = staticmethod(wrapper_block)
+    optimizer = SignSGD
+
+    def __init__(self, config: Optional[SignRoundConfig] = None, device: Union[str, torch.device] = "cuda", **kwargs):
+        self.config = config or SignRoundConfig(**kwargs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("SignRoundQuantizer needs a HIP device; there is no CPU fallback")
+        c = self.config
+        if c.enable_norm_bias_tuning:
+            raise NotImplementedError("enable_norm_bias_tuning is outside the MI355X hot path")
+        if c.momentum not in (0, 0.0, None):
+            raise NotImplementedError("momentum != 0 is outside the MI355X hot path")
+        self.last_stats: Dict[str, Any] = {}
+
+    # convenience accessors with the reference's attribute names
+    @property
+    def iters(self): return self.config.iters
+    @property
+    def lr(self): return self.config.lr
+    @property
+    def minmax_lr(self): return self.config.minmax_lr
+    @property
+    def enable_minmax_tuning(self): return self.config.enable_minmax_tuning
+    @property
+    def enable_quanted_input(self): return self.config.enable_quanted_input
+    @property
+    def not_use_best_mse(self): return self.config.not_use_best_mse
+    @property
+    def dynamic_max_gap(self): return self.config.dynamic_max_gap
+    @property
+    def gradient_accumulate_steps(self): return self.config.gradient_accumulate_steps
+
+    def block_forward(self, block, x, input_others):
+        return block_forward(block, x, input_others, amp=self.config.amp, amp_dtype=self.config.amp_dtype)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def quantize_block(self, block, fp_inputs, input_others, fp_outputs, q_inputs=None, block_ctx=None, input_ids=None,
+                       **kwargs) -> dict:
+        cfg = self.config
+        device = self.device
+        active_inputs = q_inputs if (q_inputs is not None and cfg.enable_quanted_input) else fp_inputs
+        X = stack_samples(active_inputs, device)
+        Y = stack_samples(fp_outputs, device)
+        nsamples = X.shape[0]
+
+        quantized_names, unquantized_names = self.wrapper_block(
+            block, cfg.enable_minmax_tuning, cfg.enable_norm_bias_tuning, enable_torch_compile=False, device=device,
+            iters=cfg.iters)
+        arenas = getattr(block, "_ar_arenas", [])
+        if not arenas or cfg.iters <= 0:
+            unwrapper_block(block, {})
+            return {}
+
+        # one (round, minmax) pair of param groups per arena; lr by the arena's bit-width (quantizer.py:374-417)
+        groups = []
+        for ai, a in enumerate(arenas):
+            layer_lr = cfg.compute_lr(a.bits) or cfg.lr
+            layer_mm = cfg.compute_minmax_lr(a.bits) or cfg.minmax_lr
+            groups.append({"params": [l.params["value"] for l in a.layers if "value" in l.params],
+                           "lr": torch.tensor(layer_lr), "kind": "round", "arena": ai})
+            if cfg.enable_minmax_tuning:
+                mm = []
+                for l in a.layers:
+                    mm += [p for k, p in l.params.items() if "min" in k or "max" in k]
+                groups.append({"params": mm, "lr": torch.tensor(layer_mm), "kind": "minmax", "arena": ai})
+        optimizer = self.optimizer(groups, lr=torch.tensor(cfg.lr), weight_decay=0, arenas=arenas)
+        optimizer.fuse_next_fwd = cfg.fuse_next_forward
+        if cfg.lr_scheduler is None:
+            lr_schedule = torch.optim.lr_scheduler.LinearLR(optimizer, start_factor=1.0, end_factor=0.0,
+                                                            total_iters=cfg.iters)
+        else:
+            lr_schedule = copy.deepcopy(cfg.lr_scheduler)
+
+        batch_size = cfg.batch_size
+        global_bs = min(nsamples, batch_size * cfg.gradient_accumulate_steps)
+        accum = cfg.gradient_accumulate_steps != 1
+        sampler = IndexSampler(nsamples, global_bs)
+        early_stop = (not cfg.not_use_best_mse) and cfg.dynamic_max_gap > 0
+        # the whole index schedule is drawn up front (same draws, same order as one next_batch() per iteration) and
+        # uploaded once; with early stopping the draws must stay lazy so later blocks see the reference's stream.
+        if early_stop:
+            sched_dev = None
+        else:
+            sched = [sampler.next_batch() for _ in range(cfg.iters)]
+            sched_dev = torch.tensor(sched, dtype=torch.int64).to(device, non_blocking=True)
+
+        total_loss = torch.zeros(1, dtype=torch.float32, device=device)
+        state = torch.tensor([FLT_MAX, 0.0, 0.0], dtype=torch.float32, device=device)
+        istate = torch.zeros(4, dtype=torch.int32, device=device)
+        track_best = not cfg.not_use_best_mse
+        if track_best:
+            optimizer.snapshot_flag = istate[0:1]
+        xb = torch.empty((min(batch_size, global_bs),) + tuple(X.shape[1:]), dtype=X.dtype, device=device)
+        yb = torch.empty((min(batch_size, global_bs),) + tuple(Y.shape[1:]), dtype=Y.dtype, device=device)
+        dpred = None
+        last_iter = cfg.iters - 1
+
+        for i in range(cfg.iters):
+            if sched_dev is None:
+                gidx = torch.tensor(sampler.next_batch(), dtype=torch.int64).to(device)
+            else:
+                gidx = sched_dev[i]
+            num_elm = 1
+            if accum:
+                num_elm = global_bs * X[0].numel()
+            for b0 in range(0, global_bs, batch_size):
+                idx = gidx[b0:b0 + batch_size]
+                nb = idx.numel()
+                x = ops.gather_rows(X, idx, out=xb[:nb])
+                ref = ops.gather_rows(Y, idx, out=yb[:nb])
+                pred = self.block_forward(block, x, input_others)
+                pred_c = pred if pred.is_contiguous() else pred.contiguous()
+                if dpred is None or dpred.shape != pred_c.shape or dpred.dtype != pred_c.dtype:
+                    dpred = torch.empty_like(pred_c)
+                n = pred_c.numel()
+                if accum:   # reduction="sum" and loss/num_elm in the reference (quantizer.py:436-452, :496)
+                    ops.mse_loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred=dpred, loss_accum=total_loss,
+                                         accum_scale=float(n) / float(num_elm), grad_scale=1000.0 * float(n))
+                else:
+                    ops.mse_loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred=dpred, loss_accum=total_loss,
+                                         accum_scale=1.0, grad_scale=1000.0)
+                pred_c.backward(dpred)
+            ops.best_loss_update(total_loss, state, istate, i)
+            if early_stop:
+                last_best = int(istate[1].item())
+                if 0 < cfg.dynamic_max_gap <= i - last_best:
+                    last_iter = i
+                    break
+            optimizer.step()
+            optimizer.zero_grad()
+            lr_schedule.step()
+
+        # one host sync per block
+        st = state.tolist()
+        ist = istate.tolist()
+        best_loss, init_loss, last_loss = st
+        n_improved = ist[2]
+        best_params: Dict[str, Dict[str, torch.Tensor]] = {}
+        if track_best:
+            if n_improved > 0:
+                for a in arenas:
+                    for l in a.layers:
+                        name = _name_of(block, l)
+                        bp = {}
+                        if "value" in l.params:
+                            bp["value"] = a.best_V[l._off:l._off + l.numel].view(l.n_groups, l.gs)
+                        if "min_scale" in l.params:
+                            bp["min_scale"] = a.best_min[l._goff:l._goff + l.n_groups]
+                            bp["max_scale"] = a.best_max[l._goff:l._goff + l.n_groups]
+                        best_params[name] = bp
+            best_iter, shown_loss = ist[1], best_loss
+        else:
+            best_params = collect_best_params(block)
+            best_iter, shown_loss = cfg.iters, last_loss
+        self.last_stats = dict(init_loss=init_loss, best_loss=best_loss, last_loss=last_loss, best_iter=best_iter,
+                               iters_run=last_iter + 1, quantized=len(quantized_names),
+                               unquantized=len(unquantized_names), n_improved=n_improved)
+        with torch.no_grad():
+            unwrapper_block(block, best_params)
+        # hand out independent copies: the arenas' best_* buffers are released with the block's wrappers
+        return {n: {k: v.clone() for k, v in d.items()} for n, d in best_params.items()}
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_all(self, block, inputs: torch.Tensor, input_others, batch_size: Optional[int] = None) -> torch.Tensor:
+        """No-grad forward of every cached sample in minibatches -> [N, S, H] (composer.py steps 3 and 6)."""
+        bs = batch_size or self.config.batch_size
+        outs = []
+        for b0 in range(0, inputs.shape[0], bs):
+            outs.append(self.block_forward(block, inputs[b0:b0 + bs], input_others))
+        return torch.cat(outs, dim=0)
+
+    def compress_block(self, block, fp_inputs, input_others, q_inputs=None, block_ctx=None):
+        """reference: AlgorithmComposer.compress_block (composer.py:360-483):
+        (3) reference forward with the fp weights, (4) quantize_block, (6) forward of the quantised block to produce
+        the next block's quantised input.  -> (fp_outputs [N,S,H], q_outputs [N,S,H] or None, best_params)"""
+        device = self.device
+        X = stack_samples(fp_inputs, device)
+        fp_out = self.forward_all(block, X, input_others)
+        Xq = stack_samples(q_inputs, device) if (q_inputs is not None and self.config.enable_quanted_input) else None
+        best = self.quantize_block(block, X, input_others, fp_out, Xq, block_ctx)
+        q_out = None
+        if self.config.enable_quanted_input:
+            q_out = self.forward_all(block, Xq if Xq is not None else X, input_others)
+        return fp_out, q_out, best
+
+
+def _name_of(block, module) -> str:
+    for n, m in block.named_modules():
+        if m is module:
+            return n
+    raise KeyError("wrapper not found in block")

@@ -1,0 +1,369 @@
+"""Host-side mirror of the reference's fake-quant tuning wrappers (auto_round/wrapper.py), MI355X-first.
+
+Same names and argument meaning as the reference -- `WrapperLinear`, `wrapper_block`, `unwrapper_block` -- so that
+tests and callers read like the reference's, but the layout underneath is different by design:
+
+* All quantised linears of a transformer block live in ONE `BlockArena`: block-wide flat HBM buffers
+  (W, Wq, dWq in the weight dtype; V, best_V fp32; min/max scale, wmin/wmax per group).  Each layer's weight,
+  `value`, `min_scale`, `max_scale` are views into those buffers.
+* The per-layer `_qdq_weight` of the reference (wrapper.py:244-293) becomes one grouped `ar_qdq_int_fwd` launch per
+  iteration for the whole block (the fake-quant weight only depends on parameters, never on activations), and the
+  autograd backward + `SignSGD.step()` + `collect_best_params` become one fused `ar_qdq_int_bwd_sgd` launch.
+* `WrapperLinear.forward` is a plain MFMA GEMM (hipBLASLt through F.linear) against the layer's Wq view; its
+  backward writes dWq = dY^T X straight into the layer's slice of the arena's dWq buffer.
+
+There is no CPU path: every tensor must be on a HIP device.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+try:  # Conv1D (GPT-2 style) is handled like the reference does: weight is stored transposed
+    from transformers.pytorch_utils import Conv1D
+except Exception:  # pragma: no cover
+    Conv1D = ()
+
+SUPPORTED_INT = ("int", "int_sym", "int_asym")
+
+
+def is_int_dtype(data_type: str) -> bool:
+    return data_type in SUPPORTED_INT or data_type.startswith("int")
+
+
+def is_mx_fp(data_type: str) -> bool:
+    return data_type.startswith("mx_fp")
+
+
+def is_nv_fp(data_type: str) -> bool:
+    return data_type.startswith("nv_fp")
+
+
+def check_to_quantized(layer) -> bool:
+    """reference: auto_round/utils check_to_quantized -- a layer is tuned iff bits < 16 (or act_bits < 16)."""
+    return int(getattr(layer, "bits", 16)) < 16
+
+
+def get_scale_shape(weight: torch.Tensor, group_size: int) -> int:
+    """Number of groups of a [out, in] weight (reference: wrapper.py get_scale_shape, int group sizes)."""
+    out_f, in_f = weight.shape
+    if group_size == -1 or in_f < group_size:
+        return out_f
+    if group_size == 0:
+        return 1
+    return out_f * ((in_f + group_size - 1) // group_size)
+
+
+class _QLinearFn(torch.autograd.Function):
+    """y = x @ Wq^T (+ b) with the weight gradient written into a preallocated arena slice.
+
+    `token` is a dummy requires-grad scalar that keeps autograd interested even when x itself has no grad (the
+    first linear of a block sees the cached calibration activations)."""
+
+    @staticmethod
+    def forward(ctx, x, token, wq, bias, dwq_out, accumulate):
+        ctx.x_dtype = x.dtype
+        xc = x if x.dtype == wq.dtype else x.to(wq.dtype)
+        ctx.save_for_backward(xc, wq)
+        ctx.dwq_out = dwq_out
+        ctx.accumulate = accumulate
+        ctx.x_needs_grad = x.requires_grad
+        return F.linear(xc, wq, None if bias is None else bias.to(wq.dtype))
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wq = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != wq.dtype:
+            dy2 = dy2.to(wq.dtype)
+        x2 = xc.reshape(-1, xc.shape[-1])
+        # dWq[out,in] = dY^T X  -- MFMA GEMM straight into the arena (no autograd accumulation buffers)
+        if ctx.accumulate[0]:
+            ctx.dwq_out.addmm_(dy2.t(), x2)
+        else:
+            torch.mm(dy2.t(), x2, out=ctx.dwq_out)
+            ctx.accumulate[0] = True
+        dx = None
+        if ctx.x_needs_grad:
+            dx = torch.mm(dy2, wq).reshape(xc.shape)
+            if dx.dtype != ctx.x_dtype:
+                dx = dx.to(ctx.x_dtype)
+        return dx, None, None, None, None, None
+
+
+class BlockArena:
+    """Block-wide flat HBM buffers for all layers that share (bits, group_size, sym, data_type, dtypes)."""
+
+    def __init__(self, key, device):
+        (self.data_type, self.bits, self.gs, self.sym, self.w_dtype, self.scale_dtype, self.bounds) = key
+        self.device = device
+        self.layers: List["WrapperLinear"] = []
+        self.n = 0
+        self.G = 0
+        self.built = False
+        self.q_thresh = 1e-8 if self.scale_dtype == torch.float32 else 1e-5
+        self.tune_minmax = True
+        self.wq_fresh = False       # Wq corresponds to the current parameters
+
+    # -- construction ---------------------------------------------------------------------------------------------
+    def add(self, layer: "WrapperLinear") -> Tuple[int, int]:
+        off, goff = self.n, self.G
+        self.layers.append(layer)
+        self.n += layer.numel
+        self.G += layer.n_groups
+        return off, goff
+
+    def build(self, tune_minmax: bool):
+        dev, wd = self.device, self.w_dtype
+        self.tune_minmax = tune_minmax
+        self.W = torch.empty(self.n, dtype=wd, device=dev)
+        self.Wq = torch.empty(self.n, dtype=wd, device=dev)
+        self.dWq = torch.zeros(self.n, dtype=wd, device=dev)
+        self.V = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.min_scale = torch.ones(self.G, dtype=torch.float32, device=dev)
+        self.max_scale = torch.ones(self.G, dtype=torch.float32, device=dev)
+        self.best_V = None
+        self.best_min = None
+        self.best_max = None
+        for lyr in self.layers:
+            lyr._bind(self)
+        self.wmin, self.wmax = ops.group_minmax(self.W, self.gs)
+        self.token = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
+        self.built = True
+
+    def alloc_best(self):
+        if self.best_V is None:
+            self.best_V = self.V.clone()
+            self.best_min = self.min_scale.clone()
+            self.best_max = self.max_scale.clone()
+
+    # -- the two grouped launches of an iteration ---------------------------------------------------------------------
+    def qdq_forward(self, V=None, min_s=None, max_s=None, want_scale=False):
+        """K1 for every layer of the block in one launch."""
+        V = self.V if V is None else V
+        mn = self.min_scale if min_s is None else min_s
+        mx = self.max_scale if max_s is None else max_s
+        res = ops.qdq_int_fwd(self.W, V, self.wmin, self.wmax, mn, mx, gs=self.gs, bits=self.bits, sym=self.sym,
+                              scale_dtype=self.scale_dtype, q_thresh=self.q_thresh, bounds=self.bounds, out=self.Wq,
+                              want_scale=want_scale)
+        self.wq_fresh = V is self.V and mn is self.min_scale and mx is self.max_scale
+        return res
+
+    def backward_step(self, lr_v: torch.Tensor, lr_mm: torch.Tensor, snapshot_flag=None, fuse_next_fwd=True):
+        """K2+K3 (+ snapshot + next K1) for every layer of the block in one launch; consumes self.dWq."""
+        if snapshot_flag is not None:
+            self.alloc_best()
+        ops.qdq_int_bwd_sgd_(self.dWq, self.W, self.V, self.wmin, self.wmax, self.min_scale, self.max_scale, gs=self.gs,
+                             bits=self.bits, sym=self.sym, lr_v=lr_v, lr_mm=lr_mm, tune_minmax=self.tune_minmax,
+                             scale_dtype=self.scale_dtype, q_thresh=self.q_thresh, bounds=self.bounds,
+                             snapshot_flag=snapshot_flag, best_V=self.best_V, best_min=self.best_min,
+                             best_max=self.best_max, Wq_next=self.Wq if fuse_next_fwd else None)
+        self.wq_fresh = bool(fuse_next_fwd)
+        for lyr in self.layers:
+            lyr._dw_accum[0] = False
+
+    def param_grads(self):
+        """Unfused backward (ar_qdq_int_bwd): materialises dV / d min_scale / d max_scale like autograd would."""
+        return ops.qdq_int_bwd(self.dWq, self.W, self.V, self.wmin, self.wmax, self.min_scale, self.max_scale, gs=self.gs,
+                               bits=self.bits, sym=self.sym, scale_dtype=self.scale_dtype, q_thresh=self.q_thresh,
+                               bounds=self.bounds)
+
+
+class WrapperLinear(torch.nn.Module):
+    """Mirror of auto_round.wrapper.WrapperLinear (wrapper.py:62-565) for INT weight-only schemes.
+
+    The wrapped layer must carry the scheme attributes the reference's `apply_plan_to_model` sets: `bits`,
+    `group_size`, `sym`, `data_type`, `scale_dtype`, `act_bits` (compressors/layer_config/resolver.py:482-497).
+    Tunable parameters (fp32, same shapes as the reference): `value` [G, gs], `min_scale` [G], `max_scale` [G].
+    """
+
+    minmax_scale_bound = (0.0, 1.0)
+
+    def __init__(self, orig_layer, enable_minmax_tuning=True, enable_norm_bias_tuning=False, device="cuda",
+                 enable_round_tuning=True, enable_torch_compile=False, disable_opt_rtn=True, **kwargs):
+        super().__init__()
+        if enable_norm_bias_tuning:
+            raise NotImplementedError("norm/bias tuning is outside the MI355X hot path (SURVEY 8a: off by default)")
+        self.orig_layer = orig_layer
+        self.orig_layer.iters = kwargs.pop("iters", 200)
+        self.device = torch.device(getattr(orig_layer, "tuning_device", device))
+        if self.device.type != "cuda":
+            raise RuntimeError(f"WrapperLinear needs a HIP device, got {self.device}; there is no CPU fallback")
+        self.output_device = self.device
+        self.enable_minmax_tuning = enable_minmax_tuning
+        self.enable_round_tuning = enable_round_tuning
+        self.enable_act_quant = int(getattr(orig_layer, "act_bits", 16)) <= 8
+        if self.enable_act_quant:
+            raise NotImplementedError("activation fake-quant (act_bits<=8) is not part of this round's INT path")
+        self.is_conv1d = bool(Conv1D) and isinstance(orig_layer, Conv1D)
+        w = orig_layer.weight.data
+        self.out_features, self.in_features = (w.shape[1], w.shape[0]) if self.is_conv1d else tuple(w.shape)
+        gs = int(orig_layer.group_size)
+        if gs == -1 or self.in_features < gs:
+            gs = self.in_features
+        if gs <= 0 or self.in_features % gs or gs % 8:
+            raise NotImplementedError(f"group_size={orig_layer.group_size} with in_features={self.in_features}: only "
+                                      "in_features % group_size == 0 and group_size % 8 == 0 are implemented")
+        self.gs = gs
+        self.numel = self.out_features * self.in_features
+        self.n_groups = self.numel // gs
+        self.bits = int(orig_layer.bits)
+        self.sym = bool(orig_layer.sym)
+        self.data_type = str(getattr(orig_layer, "data_type", "int"))
+        if not is_int_dtype(self.data_type):
+            raise NotImplementedError(f"data_type {self.data_type}: the tuning wrappers implement the INT schemes")
+        self.scale_dtype = getattr(orig_layer, "scale_dtype", torch.float16) or torch.float16
+        self.q_scale_thresh = 1e-8 if self.scale_dtype == torch.float32 else 1e-5
+        self.params: Dict[str, torch.nn.Parameter] = {}
+        self._dw_accum = [False]
+        self.arena: Optional[BlockArena] = None
+
+    # arenas are keyed by everything the grouped kernels treat as launch-uniform
+    def arena_key(self):
+        return (self.data_type, self.bits, self.gs, self.sym, self.orig_layer.weight.dtype, self.scale_dtype,
+                tuple(self.minmax_scale_bound))
+
+    def _bind(self, arena: BlockArena):
+        off, goff = self._off, self._goff
+        self.arena = arena
+        n, G = self.numel, self.n_groups
+        w = self.orig_layer.weight.data
+        w2d = w.t() if self.is_conv1d else w
+        arena.W[off:off + n].view(self.out_features, self.in_features).copy_(w2d)
+        if not self.is_conv1d:  # the layer's weight now lives in the arena (no second copy of the block in HBM)
+            self.orig_layer.weight.data = arena.W[off:off + n].view(self.out_features, self.in_features)
+        self.weight_q = arena.Wq[off:off + n].view(self.out_features, self.in_features)
+        self.weight_grad = arena.dWq[off:off + n].view(self.out_features, self.in_features)
+        tunable_v = self.enable_round_tuning and self.bits < 16
+        tunable_mm = self.enable_minmax_tuning and self.bits < 16
+        self.value = torch.nn.Parameter(arena.V[off:off + n].view(G, self.gs), requires_grad=tunable_v)
+        self.min_scale = torch.nn.Parameter(arena.min_scale[goff:goff + G], requires_grad=tunable_mm)
+        self.max_scale = torch.nn.Parameter(arena.max_scale[goff:goff + G], requires_grad=tunable_mm)
+        if tunable_v:
+            self.params["value"] = self.value
+        if tunable_mm:
+            self.params["min_scale"] = self.min_scale
+            self.params["max_scale"] = self.max_scale
+
+    @property
+    def weight(self):
+        return self.orig_layer.weight
+
+    @property
+    def bias(self):
+        return self.orig_layer.bias
+
+    @property
+    def weight_min(self):
+        return self.arena.wmin[self._goff:self._goff + self.n_groups]
+
+    @property
+    def weight_max(self):
+        return self.arena.wmax[self._goff:self._goff + self.n_groups]
+
+    def _qdq_weight(self, value=None, min_scale=None, max_scale=None):
+        """Per-layer fake-quant (reference signature, wrapper.py:244-293) -> (weight_q, scale, zp).
+        The tuning loop does not call this (it uses the arena's grouped launch); unwrapper and tests do."""
+        a = self.arena
+        sl = slice(self._off, self._off + self.numel)
+        gl = slice(self._goff, self._goff + self.n_groups)
+
+        def flat(t, default, n):
+            if t is None:
+                return default
+            t = t.to(device=self.device, dtype=torch.float32)
+            if t.numel() == 1:      # reference passes tensor(0.0)/tensor(1.0) when a parameter is not tunable
+                return t.reshape(1).expand(n).contiguous()
+            return t.reshape(-1).contiguous()
+
+        V = flat(value, a.V[sl], self.numel)
+        mn = flat(min_scale, a.min_scale[gl], self.n_groups)
+        mx = flat(max_scale, a.max_scale[gl], self.n_groups)
+        Wq, scale, zp = ops.qdq_int_fwd(a.W[sl], V, a.wmin[gl], a.wmax[gl], mn, mx, gs=self.gs, bits=self.bits,
+                                        sym=self.sym, scale_dtype=self.scale_dtype, q_thresh=self.q_scale_thresh,
+                                        bounds=self.minmax_scale_bound, want_scale=True)
+        wq2d = Wq.view(self.out_features, self.in_features)
+        if self.is_conv1d:
+            wq2d = wq2d.t()
+        if self.sym:
+            zp = int(2 ** (self.bits - 1))
+        return wq2d, scale.view(self.n_groups, 1), zp if self.sym else zp.view(self.n_groups, 1)
+
+    def forward(self, x):
+        a = self.arena
+        if not a.wq_fresh:
+            a.qdq_forward()
+        return _QLinearFn.apply(x, a.token, self.weight_q, self.orig_layer.bias, self.weight_grad, self._dw_accum)
+
+    def unwrapper(self, best_params):
+        """Bake the best parameters into the layer (reference: wrapper.py:345-468): weight <- qdq weight,
+        attributes `scale` [out, in/gs] (CPU, scale dtype), `zp` (int for sym, [out, in/gs] CPU tensor for asym)."""
+        best_params = best_params or {}
+        v = best_params.get("value", torch.tensor(0.0))
+        mn = best_params.get("min_scale", torch.tensor(1.0))
+        mx = best_params.get("max_scale", torch.tensor(1.0))
+        wq, scale, zp = self._qdq_weight(v, mn, mx)
+        self.orig_layer.weight.data.copy_(wq)
+        self.orig_layer.weight.grad = None
+        self.orig_layer.scale = scale.reshape(self.out_features, -1).to("cpu")
+        if isinstance(zp, torch.Tensor):
+            self.orig_layer.zp = zp.reshape(self.out_features, -1).to("cpu")
+        else:
+            self.orig_layer.zp = zp
+        return self.orig_layer
+
+
+def _quantizable(m) -> bool:
+    return isinstance(m, torch.nn.Linear) or (bool(Conv1D) and isinstance(m, Conv1D))
+
+
+def _set_module(root, name, new):
+    parts = name.split(".")
+    parent = root
+    for p in parts[:-1]:
+        parent = getattr(parent, p)
+    setattr(parent, parts[-1], new)
+
+
+def wrapper_block(block, enable_minmax_tuning, enable_norm_bias_tuning, enable_torch_compile=False, device="cuda",
+                  wrapper_cls=WrapperLinear, **kwargs):
+    """Swap every quantisable linear of `block` for a tuning wrapper and build the block arenas.
+    reference: auto_round/wrapper.py:774-828.  Returns (quantized_layer_names, unquantized_layer_names)."""
+    quantized, unquantized = [], []
+    wrappers = []
+    for n, m in list(block.named_modules()):
+        if not _quantizable(m):
+            continue
+        if not check_to_quantized(m):
+            unquantized.append(n)
+            continue
+        w = wrapper_cls(m, enable_minmax_tuning=enable_minmax_tuning, enable_norm_bias_tuning=enable_norm_bias_tuning,
+                        device=device, enable_torch_compile=enable_torch_compile, **kwargs)
+        _set_module(block, n, w)
+        wrappers.append(w)
+        quantized.append(n)
+    arenas: Dict[tuple, BlockArena] = {}
+    for w in wrappers:
+        key = w.arena_key()
+        if key not in arenas:
+            arenas[key] = BlockArena(key, w.device)
+        w._off, w._goff = arenas[key].add(w)
+    for a in arenas.values():
+        a.build(enable_minmax_tuning)
+    block._ar_arenas = list(arenas.values())
+    return quantized, unquantized
+
+
+@torch.no_grad()
+def unwrapper_block(block, best_params):
+    """reference: auto_round/wrapper.py:861-878 -- restores the original layers with the best parameters baked in."""
+    for n, m in list(block.named_modules()):
+        if hasattr(m, "orig_layer"):
+            bp = best_params.get(n) if best_params else None
+            _set_module(block, n, m.unwrapper(bp))
+    if hasattr(block, "_ar_arenas"):
+        del block._ar_arenas

@@ -103,7 +103,8 @@ int ar_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpred, float* l
 /* ---- best-loss bookkeeping on the device ---------------------------------------------------------------------
  * replaces: `if total_loss < best_loss: best_loss = total_loss; last_best_iter = i` (sign_round/quantizer.py:508-517)
  * state[0]=best_loss (init FLT_MAX) state[1]=init_loss state[2]=last total_loss ; istate[0]=snapshot flag
- * istate[1]=last_best_iter.  Also zeroes *total_loss for the next iteration. */
+ * istate[1]=last_best_iter istate[2]=number of improvements (0 => the loss was never finite: keep RTN).
+ * Also zeroes *total_loss for the next iteration. */
 int ar_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter, ar_stream_t stream);
 
 /* ---- calibration-activation gather ---------------------------------------------------------------------------

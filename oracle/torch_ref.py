@@ -1,0 +1,206 @@
+"""torch restatement of the reference's tuning loop (WrapperLinear fake-quant + autograd + SignSGD + best-MSE
+bookkeeping), device agnostic.
+
+TEST INFRASTRUCTURE ONLY (see oracle/ar_oracle.c header): used by tests/ as the loop-level checker, by
+__graft_entry__.smoke(), and by bench.py's `cpu_baseline` leg (kind "port": this file timed on the host cores).
+Nothing under auto_round_amd/ imports it.
+
+Parity status: PINNED -- tests/test_torch_ref.py checks it bit-for-bit against the committed golden vectors
+(tests/golden/int_qdq_*.npz, step_*.npz) that the real reference produced, and, when /root/reference is importable
+(build container), directly against the reference's own WrapperLinear / SignSGD on the same seeded layer.
+
+Reference entry points restated here (paths relative to /root/reference):
+  qdq_int            <- auto_round/data_type/int.py:165-238 (sym), :241-298 (asym)
+  RefWrapperLinear   <- auto_round/wrapper.py:139-293, :517-565
+  sign_sgd_step      <- auto_round/algorithms/quantization/sign_round/sign_sgd.py:356-389
+  tune_block         <- auto_round/algorithms/quantization/sign_round/quantizer.py:311-552
+"""
+from __future__ import annotations
+
+import copy
+import random
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def _ste(fn, x):
+    return (fn(x) - x).detach() + x
+
+
+def qdq_int(W2d, bits, gs, sym, v, min_scale, max_scale, wmin, wmax, scale_dtype=torch.float16, thresh=1e-5):
+    """Fake-quant of a [out, in] weight with per-group scales; differentiable w.r.t. v, min_scale, max_scale.
+    Returns (Wq [out,in] in W dtype, scale [G,1], zp (int for sym, [G,1] tensor for asym))."""
+    Wg = W2d.reshape(-1, gs)
+    if sym:
+        maxq = 2 ** (bits - 1)
+        a = -(wmin * min_scale)
+        b = wmax * max_scale
+        sgn = 2 * (b < a).int() - 1
+        s = ((sgn * torch.max(b, a)) / maxq).to(scale_dtype)
+        s = torch.where(s < 0, torch.clamp(s, max=-thresh), torch.clamp(s, min=thresh)).unsqueeze(-1)
+        q = torch.clamp(_ste(torch.round, Wg / s + v), -maxq, maxq - 1)
+        return (s * q).to(W2d.dtype).reshape(W2d.shape), s, maxq
+    maxq = 2 ** bits - 1
+    lo = wmin * min_scale
+    hi = wmax * max_scale
+    s = torch.clamp(((hi - lo) / maxq).to(scale_dtype), min=thresh)
+    zp = _ste(torch.round, -lo / s).unsqueeze(-1)
+    s = s.unsqueeze(-1)
+    q = torch.clamp(_ste(torch.round, Wg / s + v) + zp, 0, maxq)
+    return (s * (q - zp)).to(W2d.dtype).reshape(W2d.shape), s, zp
+
+
+class RefWrapperLinear(torch.nn.Module):
+    """Plain-torch tuning wrapper around an nn.Linear carrying bits/group_size/sym/scale_dtype attributes."""
+
+    def __init__(self, layer: torch.nn.Linear, enable_minmax_tuning=True):
+        super().__init__()
+        self.orig_layer = layer
+        self.bits, self.sym = int(layer.bits), bool(layer.sym)
+        gs = int(layer.group_size)
+        self.gs = layer.in_features if (gs == -1 or layer.in_features < gs) else gs
+        self.scale_dtype = getattr(layer, "scale_dtype", torch.float16)
+        self.thresh = 1e-8 if self.scale_dtype == torch.float32 else 1e-5
+        W = layer.weight.data
+        Wg = W.reshape(-1, self.gs)
+        self.wmin = torch.clamp(Wg.min(1)[0], max=0)
+        self.wmax = torch.clamp(Wg.max(1)[0], min=0)
+        dev = W.device
+        self.value = torch.nn.Parameter(torch.zeros(Wg.shape, dtype=torch.float32, device=dev))
+        self.min_scale = torch.nn.Parameter(torch.ones(Wg.shape[0], dtype=torch.float32, device=dev),
+                                            requires_grad=enable_minmax_tuning)
+        self.max_scale = torch.nn.Parameter(torch.ones(Wg.shape[0], dtype=torch.float32, device=dev),
+                                            requires_grad=enable_minmax_tuning)
+        self.params = {"value": self.value}
+        if enable_minmax_tuning:
+            self.params.update(min_scale=self.min_scale, max_scale=self.max_scale)
+
+    def qdq(self, v=None, mn=None, mx=None):
+        v = self.value if v is None else v
+        mn = self.min_scale if mn is None else mn
+        mx = self.max_scale if mx is None else mx
+        mn.data.clamp_(0, 1)
+        mx.data.clamp_(0, 1)
+        return qdq_int(self.orig_layer.weight, self.bits, self.gs, self.sym, v, mn, mx, self.wmin, self.wmax,
+                       self.scale_dtype, self.thresh)
+
+    def forward(self, x):
+        wq, _, _ = self.qdq()
+        return F.linear(x, wq, self.orig_layer.bias)
+
+    def unwrap(self, best: Optional[Dict[str, torch.Tensor]]):
+        best = best or {}
+        dev = self.orig_layer.weight.device
+        v = best.get("value", torch.tensor(0.0)).to(dev)
+        mn = best.get("min_scale", torch.tensor(1.0)).to(dev)
+        mx = best.get("max_scale", torch.tensor(1.0)).to(dev)
+        with torch.no_grad():
+            wq, s, zp = self.qdq(v, mn, mx)
+            self.orig_layer.weight.data.copy_(wq)
+        out_f = self.orig_layer.weight.shape[0]
+        self.orig_layer.scale = s.reshape(out_f, -1).cpu()
+        self.orig_layer.zp = zp.reshape(out_f, -1).cpu() if isinstance(zp, torch.Tensor) else zp
+        return self.orig_layer
+
+
+def wrap_block(block, enable_minmax_tuning=True) -> List[str]:
+    names = []
+    for n, m in list(block.named_modules()):
+        if isinstance(m, torch.nn.Linear) and int(getattr(m, "bits", 16)) < 16:
+            parent = block
+            parts = n.split(".")
+            for p in parts[:-1]:
+                parent = getattr(parent, p)
+            setattr(parent, parts[-1], RefWrapperLinear(m, enable_minmax_tuning))
+            names.append(n)
+    return names
+
+
+def unwrap_block(block, best):
+    for n, m in list(block.named_modules()):
+        if isinstance(m, RefWrapperLinear):
+            parent = block
+            parts = n.split(".")
+            for p in parts[:-1]:
+                parent = getattr(parent, p)
+            setattr(parent, parts[-1], m.unwrap(best.get(n) if best else None))
+
+
+@torch.no_grad()
+def sign_sgd_step(params, lr: float):
+    for p in params:
+        if p.grad is not None:
+            p.add_(torch.sign(p.grad), alpha=-lr)
+
+
+def linear_lr_stream(lr0: float, iters: int) -> List[float]:
+    """The fp32 learning rates LinearLR(1.0 -> 0.0, total_iters=iters) hands to the optimizer, by running the real
+    torch scheduler on a dummy parameter (values are pinned by tests/golden/step_*.npz `lr_stream`)."""
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([{"params": [p], "lr": torch.tensor(lr0)}], lr=lr0)
+    sch = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=0.0, total_iters=iters)
+    out = []
+    for _ in range(iters):
+        out.append(float(opt.param_groups[0]["lr"]))
+        opt.step()
+        sch.step()
+    return out
+
+
+class Sampler:
+    """Same draws from Python's global `random` as the reference IndexSampler (compressors/utils.py:388-438)."""
+
+    def __init__(self, n, bs):
+        self.n, self.bs, self.i = n, bs, 0
+        self.idx = list(range(n))
+        random.shuffle(self.idx)
+
+    def next_batch(self):
+        if self.i + self.bs > self.n:
+            random.shuffle(self.idx)
+            self.i = 0
+        b = self.idx[self.i:self.i + self.bs]
+        self.i += self.bs
+        return b
+
+
+def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others: dict, *, iters=200, batch_size=8,
+               lr=None, enable_minmax_tuning=True, amp_dtype=torch.bfloat16, forward=None, record=None,
+               max_iters_to_run=None):
+    """The reference's quantize_block loop in plain torch.  inputs/targets: [N, S, H].  Returns best_params and
+    leaves the block unwrapped with baked weights.  `forward(block, x, others)` defaults to block(x, **others)[0]."""
+    names = wrap_block(block, enable_minmax_tuning)
+    wrappers = {n: m for n, m in block.named_modules() if isinstance(m, RefWrapperLinear)}
+    lr0 = lr if lr is not None else 1.0 / iters
+    lrs = linear_lr_stream(lr0, iters)
+    params = [p for w in wrappers.values() for p in w.params.values()]
+    sampler = Sampler(inputs.shape[0], min(batch_size, inputs.shape[0]))
+    dev_type = inputs.device.type
+    best_loss, best, last_best = float(torch.finfo(torch.float32).max), {}, 0
+    mse = torch.nn.MSELoss()
+    losses = []
+    run = iters if max_iters_to_run is None else min(iters, max_iters_to_run)
+    for i in range(run):
+        idx = sampler.next_batch()
+        x = inputs[idx]
+        ref = targets[idx]
+        with torch.autocast(device_type=dev_type, dtype=amp_dtype):
+            out = forward(block, x, input_others) if forward else block(x, **input_others)
+            if isinstance(out, (tuple, list)):
+                out = out[0]
+        loss = mse(out.to(torch.float32), ref.to(torch.float32))
+        total = loss.item()
+        (loss * 1000).backward()
+        losses.append(total)
+        if total < best_loss:
+            best_loss, last_best = total, i
+            best = {n: {k: p.data.clone() for k, p in w.params.items()} for n, w in wrappers.items()}
+        if record is not None:
+            record(i, wrappers, total)
+        sign_sgd_step(params, lrs[i])
+        for p in params:
+            p.grad = None
+    unwrap_block(block, best)
+    return best, dict(losses=losses, best_loss=best_loss, best_iter=last_best, names=names)

@@ -1,0 +1,183 @@
+"""Block-level parity on the GPU: auto_round_amd's quantize_block (HIP path) against oracle/torch_ref.tune_block
+(the pinned torch restatement of the reference loop) run on the SAME device with the SAME GEMM library, seeds and
+index schedule.  Integer/baked results are compared exactly at iteration granularity where the arithmetic is
+order-free, and statistically where the reference itself is not bit-reproducible (trajectories
+diverge with GEMM summation order because sign-SGD is chaotic)."""
+import copy
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_layer(kind="llama", bits=4, gs=32, sym=True, seed=0, hidden=256, ffn=512):
+    import __graft_entry__ as ge
+
+    if kind == "llama":
+        layer, rope, cfg = ge._tiny_llama_layer(hidden=hidden, ffn=ffn, seed=seed, bits=bits, gs=gs, sym=sym)
+        return layer.cuda(), rope.cuda(), cfg
+    from transformers import OPTConfig
+    from transformers.models.opt.modeling_opt import OPTDecoderLayer
+
+    torch.manual_seed(seed)
+    cfg = OPTConfig(hidden_size=hidden, ffn_dim=ffn, num_attention_heads=4, num_hidden_layers=1, vocab_size=128,
+                    max_position_embeddings=128, word_embed_proj_dim=hidden)
+    cfg._attn_implementation = "sdpa"
+    layer = OPTDecoderLayer(cfg).to(torch.bfloat16).eval()
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.bits, m.group_size, m.sym, m.data_type, m.scale_dtype, m.act_bits = bits, gs, sym, "int", torch.float16, 16
+    return layer.cuda(), None, cfg
+
+
+def make_data(rope, cfg, N=16, S=32, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(N, S, cfg.hidden_size, generator=g).to(torch.bfloat16).cuda()
+    others = {}
+    if rope is not None:
+        pos = torch.arange(S, device="cuda").unsqueeze(0)
+        cos, sin = rope(X[:1], pos)
+        others = {"position_embeddings": (cos, sin), "attention_mask": None, "position_ids": pos}
+    return X, others
+
+
+def fwd(blk, x, others):
+    out = blk(x, **others)
+    return out[0] if isinstance(out, (tuple, list)) else out
+
+
+def targets(layer, X, others, bs=4):
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        return torch.cat([fwd(layer, X[i:i + bs], others) for i in range(0, X.shape[0], bs)])
+
+
+def linears(block):
+    return {n: m for n, m in block.named_modules() if isinstance(m, torch.nn.Linear)}
+
+
+@pytest.mark.parametrize("kind,bits,gs,sym", [("llama", 4, 32, True), ("opt", 4, 128, True), ("llama", 2, 32, False)])
+def test_quantize_block_vs_torch_ref_loop(kind, bits, gs, sym):
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from oracle import torch_ref as tr
+
+    layer, rope, cfg = make_layer(kind, bits, gs, sym)
+    X, others = make_data(rope, cfg)
+    Y = targets(layer, X, others)
+    iters, bs = 4, 4
+
+    blk_o = copy.deepcopy(layer)
+    random.seed(11)
+    best_o, info = tr.tune_block(blk_o, X, Y, others, iters=iters, batch_size=bs, forward=fwd)
+
+    blk_m = copy.deepcopy(layer)
+    random.seed(11)
+    q = SignRoundQuantizer(SignRoundConfig(iters=iters, batch_size=bs, bits=bits), device="cuda")
+    best_m = q.quantize_block(blk_m, X, others, Y, None, None)
+    st = q.last_stats
+    # iteration 0 sees identical parameters (V=0, scales=1): identical fake-quant weights, same GEMMs -> same loss
+    assert abs(st["init_loss"] - info["losses"][0]) <= 2e-3 * info["losses"][0], (st, info["losses"])
+    assert abs(st["best_loss"] - info["best_loss"]) <= 2e-2 * info["best_loss"]
+    lo, lm = linears(blk_o), linears(blk_m)
+    agree = []
+    for n in lo:
+        assert tuple(lm[n].scale.shape) == tuple(lo[n].scale.shape) and lm[n].scale.dtype == torch.float16
+        assert lm[n].scale.device.type == "cpu"
+        if sym:
+            assert lm[n].zp == lo[n].zp == 2 ** (bits - 1)
+        else:
+            assert tuple(lm[n].zp.shape) == tuple(lo[n].zp.shape)
+        agree.append((lm[n].weight == lo[n].weight).float().mean().item())
+        # V moved by at most sum(lr) and only in multiples consistent with sign steps
+        assert float(best_m[n]["value"].abs().max()) <= sum(tr.linear_lr_stream(1.0 / iters, iters)) + 1e-6
+    assert np.mean(agree) > 0.97, agree
+
+
+def test_first_step_is_bit_exact_vs_torch_ref():
+    """One iteration, no best-tracking subtleties: after step 0 every V/min/max equals the autograd + SignSGD result
+    computed by torch on the same device (dWq from the same GEMM; group sums only matter in sign)."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from oracle import torch_ref as tr
+
+    layer, rope, cfg = make_layer("llama", 4, 32, True, seed=3)
+    X, others = make_data(rope, cfg, N=8)
+    Y = targets(layer, X, others)
+    rec = {}
+
+    def record(i, wrappers, total):
+        rec["grads"] = {n: {k: p.grad.clone() for k, p in w.params.items()} for n, w in wrappers.items()}
+
+    blk_o = copy.deepcopy(layer)
+    random.seed(5)
+    best_o, info = tr.tune_block(blk_o, X, Y, others, iters=200, batch_size=4, forward=fwd, record=record, max_iters_to_run=1)
+    # params after one step with lr0 = 1/200 : -lr0 * sign(grad)
+    blk_m = copy.deepcopy(layer)
+    random.seed(5)
+    q = SignRoundQuantizer(SignRoundConfig(iters=200, batch_size=4, bits=4, not_use_best_mse=True), device="cuda")
+    # run exactly one iteration by limiting iters through a custom scheduler-free config copy
+    q.config.iters = 1
+    q.config.lr = 1.0 / 200
+    q.config.minmax_lr = 1.0 / 200
+    q.config.lr_is_auto = False
+    q.config.minmax_lr_is_auto = False
+    best_m = q.quantize_block(blk_m, X, others, Y, None, None)
+    lr0 = np.float32(1.0 / 200)
+    tot = mism = 0
+    for n, gd in rec["grads"].items():
+        v_exp = -lr0 * torch.sign(gd["value"])
+        v_got = best_m[n]["value"]
+        tot += v_exp.numel()
+        mism += int((v_exp != v_got).sum())
+        for k in ("min_scale", "max_scale"):
+            exp = 1.0 - lr0 * torch.sign(gd[k])
+            assert (exp == best_m[n][k]).float().mean() > 0.98, (n, k)
+    # dWq comes from torch.mm(dY^T, X) here and from autograd's linear backward there: same hipBLASLt GEMM in
+    # practice; allow a vanishing fraction of sign flips of near-zero gradients
+    assert mism / tot < 2e-3, (mism, tot)
+
+
+def test_post_conditions_and_options():
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.wrapper import WrapperLinear
+
+    layer, rope, cfg = make_layer("llama", 4, 32, True, seed=2)
+    X, others = make_data(rope, cfg, N=8)
+    W0 = {n: m.weight.detach().clone() for n, m in linears(layer).items()}
+    for kw in (dict(), dict(enable_minmax_tuning=False), dict(not_use_best_mse=True), dict(gradient_accumulate_steps=2),
+               dict(dynamic_max_gap=1), dict(fuse_next_forward=False)):
+        blk = copy.deepcopy(layer)
+        random.seed(0)
+        q = SignRoundQuantizer(SignRoundConfig(iters=5, batch_size=2, bits=4, **kw), device="cuda")
+        fp_out, q_out, best = q.compress_block(blk, X, others)
+        assert not any(isinstance(m, WrapperLinear) for m in blk.modules()), kw
+        assert not hasattr(blk, "_ar_arenas")
+        st = q.last_stats
+        assert st["quantized"] == 7 and np.isfinite(st["best_loss"]), (kw, st)
+        if kw.get("dynamic_max_gap"):
+            assert st["iters_run"] <= 5
+        for n, m in linears(blk).items():
+            s = m.scale.float().cuda().repeat_interleave(32, 1)
+            qint = torch.round(m.weight.float() / s)
+            assert float(qint.min()) >= -8 and float(qint.max()) <= 7, (kw, n)
+            assert torch.equal((s * qint).to(torch.bfloat16), m.weight), (kw, n)
+            if kw.get("enable_minmax_tuning") is False:
+                assert "min_scale" not in best[n]
+            assert not torch.equal(m.weight, W0[n])
+        # tuned block is closer to the fp block than plain RTN (V=0, scales=1) on the calibration data
+        if not kw:
+            blk_rtn = copy.deepcopy(layer)
+            q0 = SignRoundQuantizer(SignRoundConfig(iters=0, batch_size=2, bits=4), device="cuda")
+            _, rtn_out, _ = q0.compress_block(blk_rtn, X, others)
+            e_tuned = (q_out.float() - fp_out.float()).pow(2).mean().item()
+            e_rtn = (rtn_out.float() - fp_out.float()).pow(2).mean().item()
+            assert e_tuned < e_rtn, (e_tuned, e_rtn)
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+
+    ge.smoke()
