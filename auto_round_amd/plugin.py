@@ -1,0 +1,81 @@
+"""Registration of the MI355X hot path with the reference's own plugin points, for when
+auto-round itself is installed next to this package.  Nothing here is needed for standalone use.
+
+    import auto_round_amd.plugin as p; p.register()
+    AutoRound(model, tokenizer, scheme="W4A16", alg_configs=p.MI355XSignRoundConfig(iters=200), device_map=0)
+    # or by alias:  AutoRound(..., alg_configs="mi355x_signround")
+
+P1  algorithm registry   register_pipeline_member(ConfigCls) / register_algorithm(name, aliases, config_factory)
+                         (auto_round/algorithms/registry.py:56-87,163-168)
+P2  wrapper injection    the quantizer attribute `wrapper_block` (sign_round/quantizer.py:66)
+P4  export duck type     QuantLinear(bits, group_size, in, out, bias, weight_dtype).pack(linear, scales, zeros, g_idx, device)
+                         (export/export_to_autoround/export.py:206-228) -> auto_round_amd.export.QuantLinearZP / Plain
+"""
+from __future__ import annotations
+
+MI355XSignRoundConfig = None
+MI355XSignRoundQuantizer = None
+
+
+def register():
+    """Idempotent.  Raises ImportError when auto_round is not importable."""
+    global MI355XSignRoundConfig, MI355XSignRoundQuantizer
+    if MI355XSignRoundQuantizer is not None:
+        return MI355XSignRoundConfig, MI355XSignRoundQuantizer
+
+    from auto_round.algorithms.quantization.sign_round.config import SignRoundConfig as _RefConfig
+    from auto_round.algorithms.quantization.sign_round.quantizer import SignRoundQuantizer as _RefQuantizer
+    from auto_round.algorithms.registry import register_algorithm, register_pipeline_member
+
+    class _Config(_RefConfig):
+        """Same fields as the reference SignRoundConfig; selects the MI355X quantizer.  Being a subclass it is not
+        coerced to the V2/Adam variants by normalize_algorithm_config (registry.py: `type(config) is SignRoundConfig`)."""
+
+    @register_pipeline_member(_Config)
+    class _Quantizer(_RefQuantizer):
+        """Reference lifecycle (bind / prepare_run / dispatch_block / finalize_run) inherited unchanged; only the
+        per-block tuning step is replaced by the HIP path."""
+
+        def quantize_block(self, block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=None, **kw):
+            import torch
+
+            from auto_round.utils.device_manager import device_manager
+
+            from .quantizer import SignRoundConfig, SignRoundQuantizer
+
+            c = self._config
+            cfg = SignRoundConfig(
+                iters=self.iters, lr=None if getattr(c, "lr_is_auto", False) else self.lr,
+                minmax_lr=None if getattr(c, "minmax_lr_is_auto", False) else self.minmax_lr,
+                lr_scheduler=self.lr_scheduler, enable_minmax_tuning=self.enable_minmax_tuning,
+                enable_norm_bias_tuning=self.enable_norm_bias_tuning,
+                gradient_accumulate_steps=self.gradient_accumulate_steps, not_use_best_mse=self.not_use_best_mse,
+                dynamic_max_gap=self.dynamic_max_gap, enable_quanted_input=self.enable_quanted_input,
+                batch_size=self.calibration_context.batch_size, bits=getattr(c, "bits", None),
+                amp=bool(self.model_context.amp), amp_dtype=self.model_context.amp_dtype or torch.bfloat16)
+            q = SignRoundQuantizer(cfg, device=device_manager.device)
+            best = q.quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=input_ids)
+            st = q.last_stats
+            try:
+                from auto_round.logger import logger
+
+                logger.infoclean(
+                    f"quantized {st['quantized']}/{st['quantized'] + st['unquantized']} layers in the block, "
+                    f"loss iter 0: {st['init_loss']:.6f} -> iter {st['best_iter']}: {st['best_loss']:.6f}")
+            except Exception:  # pragma: no cover
+                pass
+            return best
+
+    register_algorithm("mi355x_signround", aliases=("mi355x", "signround_mi355x"), config_factory=_Config,
+                       summary="SignRound block tuning on MI355X (hand-written HIP kernels, auto_round_amd)")
+    _Config.__name__ = "MI355XSignRoundConfig"
+    _Quantizer.__name__ = "MI355XSignRoundQuantizer"
+    MI355XSignRoundConfig, MI355XSignRoundQuantizer = _Config, _Quantizer
+    return _Config, _Quantizer
+
+
+def packing_quant_linear(backend: str, bits: int, group_size: int, sym: bool):
+    """Drop-in for export.dynamic_import_quant_linear_for_packing (export_to_autoround/export.py:56-95)."""
+    from .export import dynamic_import_quant_linear_for_packing
+
+    return dynamic_import_quant_linear_for_packing(backend, bits, group_size, sym)

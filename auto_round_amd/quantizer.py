@@ -236,11 +236,15 @@ class SignRoundQuantizer:
         batch_size = cfg.batch_size
         global_bs = min(nsamples, batch_size * cfg.gradient_accumulate_steps)
         accum = cfg.gradient_accumulate_steps != 1
-        sampler = IndexSampler(nsamples, global_bs)
+        sampler = IndexSampler(nsamples, global_bs) if kwargs.get("index_schedule") is None else None
         early_stop = (not cfg.not_use_best_mse) and cfg.dynamic_max_gap > 0
         # the whole index schedule is drawn up front (same draws, same order as one next_batch() per iteration) and
         # uploaded once; with early stopping the draws must stay lazy so later blocks see the reference's stream.
-        if early_stop:
+        index_schedule = kwargs.get("index_schedule")
+        if index_schedule is not None:      # sharded runs replay the sequential run's schedule for this block
+            sched_dev = torch.tensor(index_schedule, dtype=torch.int64).to(device, non_blocking=True)
+            early_stop = False
+        elif early_stop:
             sched_dev = None
         else:
             sched = [sampler.next_batch() for _ in range(cfg.iters)]

@@ -1,0 +1,140 @@
+"""Block-level sharding of the tuning path across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).  The reference has no block-level parallelism
+(SURVEY 2.3); this is the MI355X-first strategy of SURVEY 8e.
+
+Independent units: with `enable_quanted_input=False` block k is tuned on the fp activation chain only
+(fp_in[k] -> fp_out[k] = fp_in[k+1]), so blocks are independent once their (input, target) pair exists.
+
+Data path (no per-iteration collective anywhere):
+  1. `broadcast_calibration`   one RCCL broadcast of the block-0 input [nsamples, seq, hidden] from the root
+     (2.15 GB for Llama-3-8B; xGMI is point-to-point, the root drives its 7 links concurrently).
+  2. `relay_fp_chain`          owner(k) computes fp_out[k] with the SAME in-loop forward path it later tunes with
+     (pre-cached vs in-loop forwards are not numerically identical, reference utils/resume.py:14-23) and sends it
+     point-to-point to owner(k+1); each owner keeps (fp_in, fp_out) of its blocks in HBM.
+  3. every rank tunes its own blocks with the index schedule it would have had in a sequential run
+     (`replay_index_schedules`: the Python `random` stream is replayed per block on every rank).
+  4. `gather_results`          packed buffers / stats are gathered on the root (or each rank writes its own shard).
+"""
+from __future__ import annotations
+
+import random
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def assign_blocks(n_blocks: int, world_size: int, policy: str = "round_robin") -> List[List[int]]:
+    """Block indices owned by each rank.  round_robin keeps the fp-chain relay flowing rank r -> r+1."""
+    if world_size <= 0:
+        raise ValueError("world_size must be positive")
+    if policy == "round_robin":
+        return [list(range(r, n_blocks, world_size)) for r in range(world_size)]
+    if policy == "contiguous":
+        per, extra = divmod(n_blocks, world_size)
+        out, start = [], 0
+        for r in range(world_size):
+            cnt = per + (1 if r < extra else 0)
+            out.append(list(range(start, start + cnt)))
+            start += cnt
+        return out
+    raise ValueError(f"unknown policy {policy}")
+
+
+def owner_of(block: int, n_blocks: int, world_size: int, policy: str = "round_robin") -> int:
+    if policy == "round_robin":
+        return block % world_size
+    for r, blocks in enumerate(assign_blocks(n_blocks, world_size, policy)):
+        if block in blocks:
+            return r
+    raise IndexError(block)
+
+
+def replay_index_schedules(seed: int, n_blocks: int, nsamples: int, batch_size: int, iters: int,
+                           gradient_accumulate_steps: int = 1) -> List[List[List[int]]]:
+    """The minibatch index schedule of EVERY block exactly as a sequential reference run draws it: the reference seeds
+    Python's global `random` once (transformers.set_seed -> random.seed, compressors/base.py:360) and IndexSampler is
+    its only consumer (compressors/utils.py:420-438), one sampler per block in block order.  Every rank replays the
+    whole stream (cheap: n_blocks * (1 + iters*bs/nsamples) shuffles) and keeps the rows of its own blocks."""
+    from .quantizer import IndexSampler
+
+    state = random.getstate()
+    try:
+        random.seed(seed)
+        gbs = min(nsamples, batch_size * gradient_accumulate_steps)
+        out = []
+        for _ in range(n_blocks):
+            s = IndexSampler(nsamples, gbs)
+            out.append([s.next_batch() for _ in range(iters)])
+        return out
+    finally:
+        random.setstate(state)
+
+
+def broadcast_calibration(x: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    """In-place broadcast of the shared calibration activations (allocated with the same shape on every rank)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(x, src=src, group=group)
+    return x
+
+
+def relay_fp_chain(blocks: Sequence[Optional[torch.nn.Module]], x0: torch.Tensor, forward_all: Callable,
+                   policy: str = "round_robin", group=None) -> Dict[int, tuple]:
+    """Run the fp chain once across ranks.  `blocks[k]` is the module on its owner and may be None elsewhere.
+    `forward_all(block, x) -> y` must be the tuning-time forward (same batching/autocast).  Returns
+    {k: (fp_in[k], fp_out[k])} for the blocks this rank owns."""
+    n = len(blocks)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine: Dict[int, tuple] = {}
+    cur = x0 if owner_of(0, n, world, policy) == rank else None
+    for k in range(n):
+        own = owner_of(k, n, world, policy)
+        nxt = owner_of(k + 1, n, world, policy) if k + 1 < n else None
+        if own == rank:
+            y = forward_all(blocks[k], cur)
+            mine[k] = (cur, y)
+            if nxt is not None and nxt != rank:
+                dist.send(y.contiguous(), dst=nxt, group=group)
+                cur = None
+            else:
+                cur = y
+        elif nxt == rank:
+            # the next block is mine: receive its input from the current owner
+            buf = torch.empty_like(x0)
+            dist.recv(buf, src=own, group=group)
+            cur = buf
+    return mine
+
+
+def tune_sharded(blocks: Sequence[Optional[torch.nn.Module]], x0: torch.Tensor, input_others: dict, quantizer,
+                 seed: int = 42, policy: str = "round_robin", group=None) -> Dict[int, dict]:
+    """Shard `blocks` over the ranks and tune the local ones against the fp chain.  Every rank must pass the same
+    x0 buffer shape; rank `src=0` holds the data.  Returns {block index: stats/best_params} for local blocks."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n = len(blocks)
+    broadcast_calibration(x0, 0, group)
+    cfg = quantizer.config
+    scheds = replay_index_schedules(seed, n, x0.shape[0], cfg.batch_size, cfg.iters, cfg.gradient_accumulate_steps)
+    pairs = relay_fp_chain(blocks, x0, lambda b, x: quantizer.forward_all(b, x, input_others), policy, group)
+    out = {}
+    for k, (xin, yout) in pairs.items():
+        best = quantizer.quantize_block(blocks[k], xin, input_others, yout, None, None, index_schedule=scheds[k])
+        out[k] = {"best_params": best, "stats": dict(quantizer.last_stats)}
+    return out
+
+
+def gather_results(local: dict, dst: int = 0, group=None):
+    """Gather per-block python results (stats, CPU tensors) on `dst`; returns the merged dict there, None elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return dict(local)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    bucket = [None] * world if rank == dst else None
+    dist.gather_object(local, bucket, dst=dst, group=group)
+    if rank != dst:
+        return None
+    merged = {}
+    for part in bucket:
+        merged.update(part)
+    return merged
