@@ -12,12 +12,12 @@ import subprocess
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libar_mi355x.so")
+LIB_PATH = os.environ.get("AR_MI355X_LIB", os.path.join(_PKG, "lib", "libar_mi355x.so"))  # override: kernel A/B builds
 CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -42,6 +42,7 @@ SIGNATURES = {
     "ar_pack_int": (c_int, [P, P, P, F, L, L, I, I, I, I, I, P, P, P, P]),
     "ar_qdq_fp4_fwd": (c_int, [P, P, P, P, F, P, P, P, L, I, I, I, F, F, P]),
     "ar_qdq_fp4_bwd_sgd": (c_int, [P, P, P, P, P, F, P, L, I, I, I, F, F, P, P, I, P, P, P, P, P, P]),
+    "ar_fp4_act_bwd": (c_int, [P, P, P, P, L, I, I, I, P]),
     "ar_pack_fp4": (c_int, [P, P, P, L, L, I, I, I, P, P, P]),
 }
 

@@ -64,13 +64,52 @@ template <> struct Raw8<AR_DT_BF16> { uint4 q; };
 template <> struct Raw8<AR_DT_F16> { uint4 q; };
 template <> struct Raw8<AR_DT_F32> { float4 a, b; };
 
+// 16-byte global accesses.  AR_NT=1 marks the streaming arrays non-temporal (read once / written once per launch:
+// keeping them out of the way of L2 is what MI355X_MICROARCH.md's nt-weights row measures as a win for one-pass streams).
+#ifndef AR_NT
+#define AR_NT 1
+#endif
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16(const void* p) {
+#if AR_NT
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+__device__ __forceinline__ float4 ld16f(const void* p) {
+#if AR_NT
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void st16(void* p, uint4 q) {
+#if AR_NT
+    u32x4_t v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = q;
+#endif
+}
+__device__ __forceinline__ void st16f(void* p, float4 q) {
+#if AR_NT
+    f32x4_t v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = q;
+#endif
+}
 template <int DT> __device__ __forceinline__ Raw8<DT> load8_raw(const void* base, int64_t elem) {
     Raw8<DT> r;
     if constexpr (DT == AR_DT_F32) {
-        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
-        r.a = p[0]; r.b = p[1];
+        const float* p = reinterpret_cast<const float*>(base) + elem;
+        r.a = ld16f(p); r.b = ld16f(p + 4);
     } else {
-        r.q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + elem);
+        r.q = ld16(reinterpret_cast<const uint16_t*>(base) + elem);
     }
     return r;
 }
@@ -88,9 +127,9 @@ template <int DT> __device__ __forceinline__ void unpack8(const Raw8<DT>& r, flo
 }
 template <int DT> __device__ __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
     if constexpr (DT == AR_DT_F32) {
-        float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem);
-        p[0] = make_float4(v[0], v[1], v[2], v[3]);
-        p[1] = make_float4(v[4], v[5], v[6], v[7]);
+        float* p = reinterpret_cast<float*>(base) + elem;
+        st16f(p, make_float4(v[0], v[1], v[2], v[3]));
+        st16f(p + 4, make_float4(v[4], v[5], v[6], v[7]));
     } else {
         uint4 q;
         if constexpr (DT == AR_DT_BF16) {
@@ -100,21 +139,19 @@ template <int DT> __device__ __forceinline__ void store8(void* base, int64_t ele
             q.x = f32_to_f16(v[0]) | (f32_to_f16(v[1]) << 16); q.y = f32_to_f16(v[2]) | (f32_to_f16(v[3]) << 16);
             q.z = f32_to_f16(v[4]) | (f32_to_f16(v[5]) << 16); q.w = f32_to_f16(v[6]) | (f32_to_f16(v[7]) << 16);
         }
-        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + elem) = q;
+        st16(reinterpret_cast<uint16_t*>(base) + elem, q);
     }
 }
 struct F8 { float4 a, b; };
 __device__ __forceinline__ F8 load8_f32(const float* base, int64_t elem) {
-    const float4* p = reinterpret_cast<const float4*>(base + elem);
-    F8 r; r.a = p[0]; r.b = p[1]; return r;
+    F8 r; r.a = ld16f(base + elem); r.b = ld16f(base + elem + 4); return r;
 }
 __device__ __forceinline__ void unpack_f8(const F8& r, float (&o)[8]) {
     o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
 }
 __device__ __forceinline__ void store8_f32(float* base, int64_t elem, const float (&v)[8]) {
-    float4* p = reinterpret_cast<float4*>(base + elem);
-    p[0] = make_float4(v[0], v[1], v[2], v[3]);
-    p[1] = make_float4(v[4], v[5], v[6], v[7]);
+    st16f(base + elem, make_float4(v[0], v[1], v[2], v[3]));
+    st16f(base + elem + 4, make_float4(v[4], v[5], v[6], v[7]));
 }
 
 // ---- small math -------------------------------------------------------------------------------------------------

@@ -237,12 +237,262 @@ extern "C" int ar_pack_fp4(const void* Wq, const void* scale, const float* globa
     return launch_status();
 }
 
-// fp4 backward + sign-SGD: implemented in ar_fp4_bwd.hip once its oracle is pinned; until then the entry point
-// reports "unsupported" instead of silently doing nothing.
-#ifndef AR_HAVE_FP4_BWD
-extern "C" int ar_qdq_fp4_bwd_sgd(const void*, const void*, float*, const float*, float*, float, const float*, int64_t, int,
-                                  int, int, float, float, const float*, const float*, int, const int32_t*, float*, float*,
-                                  float*, float*, ar_stream_t) {
-    return AR_ERR_UNSUPPORTED;
+// ------------------------------------------------------------------------------------------------------------------
+// fp4 backward (+ sign-SGD on V and max_scale, + best snapshot).  Closed forms of what autograd computes through
+// quant_mx / nv_fp4 (derivation: oracle/ar_oracle.c oracle_qdq_fp4_bwd):
+//   MXFP4: dq/dt = 0 (t==0) | 1 (|t|<1) | q/t (|t|>=1);  dV = g*sc*dq/dt*[|t_pre|<=6];
+//          dsc = sum g*q - sum dV*((W/sc)/sc);  dMs = ((dsc*(sc*ln2))/(m*ln2))*amax*init
+//   NVFP4: dq/dx = 0 (x==0) | 1;  dV = g*ro*dq/dx*[|x_pre|<=6];
+//          dosc = sum dV*W - (sum g*q)*ro^2;  dr = -dosc*osc^2;  ds = dr/gs;  dMs = (((ds*gs)/6)*amax)*init
+// Deliberate deviation: for an all-zero group the reference's autograd yields NaN for d max_scale (the unselected
+// branch of torch.where(max_val==0, 1, log2(max_val)) / get_reciprocal back-propagates 0*inf) and SignSGD then poisons
+// the parameter with NaN; here that gradient is 0 and the group simply stays at its RTN value.
+// ------------------------------------------------------------------------------------------------------------------
+namespace ar {
+
+struct Fp4BwdArgs {
+    const void* dXq; const void* X; float* V; const float* absmax; float* max_s; const float* gscale;
+    const float* lr_v; const float* lr_mm; const int32_t* snap; float* best_V; float* best_max; float* dV_out; float* dmax_out;
+    int64_t n_groups;
+    int cpg, mode, tune_minmax;
+    float init_scale, lo, hi;
+};
+
+template <int XDT>
+__global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
+    const int cpg = a.cpg;
+    const int64_t total_chunks = a.n_groups * cpg;
+    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    const float gscale = (a.mode == 1 && a.gscale) ? *a.gscale : 1.0f;
+    const float alpha_v = a.lr_v ? -(*a.lr_v) : 0.f;
+    const float alpha_mm = a.lr_mm ? -(*a.lr_mm) : 0.f;
+    const bool do_snap = a.snap != nullptr && *a.snap != 0;
+    const float LN2 = 0.6931471805599453f;
+    const float r6 = (float)(1.0 / 6.0);
+    const int64_t limit = (total_chunks + kWave - 1) / kWave * kWave;
+    for (int64_t c = (int64_t)blockIdx.x * kTPB + threadIdx.x; c < limit; c += stride) {
+        const bool ok = c < total_chunks;
+        const int64_t g = ok ? c / cpg : 0;
+        float s_gq = 0.f, s_dvw = 0.f;
+        float amax = 0.f, Ms_raw = 1.f, Ms = 1.f, sc = 1.f, rsc = 1.f, m = 0.f, se_un = 0.f, s_pre = 0.f, r = 0.f;
+        if (ok) {
+            float gg[8], w[8], v[8], dv[8];
+            unpack8<XDT>(load8_raw<XDT>(a.dXq, c * kEPT), gg);
+            unpack8<XDT>(load8_raw<XDT>(a.X, c * kEPT), w);
+            if (a.V) unpack_f8(load8_f32(a.V, c * kEPT), v);
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = 0.f;
+            }
+            amax = a.absmax[g];
+            Ms_raw = a.max_s ? a.max_s[g] : 1.0f;
+            Ms = a.max_s ? clamp3(Ms_raw, a.lo, a.hi) : 1.0f;
+            if (a.mode == 0) {
+                m = amax * (a.init_scale * Ms);
+                float se = (m == 0.f) ? 1.0f : log2f(m);
+                se_un = floorf(se) - 2.0f;
+                sc = ldexpf(1.0f, (int)clamp3(se_un, -127.f, 127.f));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float ws = w[k] / sc;
+                    const float tp = ws + v[k];
+                    const float t = clamp3(tp, -6.f, 6.f);
+                    const float q = mx_e2m1(t);
+                    const float d = (t == 0.f) ? 0.f : ((fabsf(t) < 1.0f) ? 1.0f : q / t);
+                    const bool inside = (tp >= -6.f) && (tp <= 6.f);
+                    dv[k] = inside ? (gg[k] * sc) * d : 0.f;
+                    s_gq += gg[k] * q;
+                    s_dvw += dv[k] * (ws / sc);
+                }
+            } else {
+                const float vm = amax * (Ms * a.init_scale);
+                s_pre = gscale * (vm * r6);
+                const float s = e4m3_to_f32(f32_to_e4m3(clamp3(s_pre, -448.f, 448.f)));
+                r = s * recip0(gscale);
+                sc = recip0(r);        // osc
+                rsc = recip0(sc);      // ro
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float xp = w[k] * sc + v[k];
+                    const float x = clamp3(xp, -6.f, 6.f);
+                    const float q = nv_e2m1(x);
+                    const bool inside = (xp >= -6.f) && (xp <= 6.f);
+                    dv[k] = (inside && x != 0.f) ? gg[k] * rsc : 0.f;
+                    s_gq += gg[k] * q;
+                    s_dvw += dv[k] * w[k];
+                }
+            }
+            if (a.dV_out) store8_f32(a.dV_out, c * kEPT, dv);
+            if (a.lr_v && a.V) {
+                if (do_snap && a.best_V) store8_f32(a.best_V, c * kEPT, v);
+                float vn[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vn[k] = v[k] + alpha_v * sgnf(dv[k]);
+                store8_f32(a.V, c * kEPT, vn);
+            }
+        }
+        s_gq = lanes_sum(s_gq, cpg);
+        s_dvw = lanes_sum(s_dvw, cpg);
+        if (ok && (c % cpg) == 0) {
+            float dMs;
+            if (a.mode == 0) {
+                const float dsc = s_gq - s_dvw;
+                const bool pass = (se_un >= -127.f) && (se_un <= 127.f);
+                dMs = (m == 0.f || !pass) ? 0.f : ((dsc * (sc * LN2)) / (m * LN2)) * amax * a.init_scale;
+            } else {
+                const float dosc = (sc == 0.f) ? 0.f : (s_dvw - s_gq * (rsc * rsc));
+                const float dr = (r == 0.f) ? 0.f : -dosc * (sc * sc);
+                float ds = dr * recip0(gscale);
+                if (!((s_pre >= -448.f) && (s_pre <= 448.f))) ds = 0.f;
+                dMs = (((ds * gscale) * r6) * amax) * a.init_scale;
+            }
+            if (a.dmax_out) a.dmax_out[g] = dMs;
+            if (a.lr_mm && a.tune_minmax && a.max_s) {
+                if (do_snap && a.best_max) a.best_max[g] = Ms;
+                a.max_s[g] = Ms + alpha_mm * sgnf(dMs);
+            }
+        }
+    }
 }
-#endif
+
+}  // namespace ar
+
+extern "C" int ar_qdq_fp4_bwd_sgd(const void* dXq, const void* X, float* V, const float* absmax, float* max_s,
+                                  float init_scale, const float* global_scale_dev, int64_t n_groups, int gs, int mode,
+                                  int x_dt, float lo_bound, float hi_bound, const float* lr_v_dev, const float* lr_mm_dev,
+                                  int tune_minmax, const int32_t* snapshot_flag, float* best_V, float* best_max,
+                                  float* dV_out, float* dmax_out, ar_stream_t stream) {
+    if (!((mode == 0 && gs == 32) || (mode == 1 && gs == 16)) || n_groups < 0 || !absmax) return AR_ERR_UNSUPPORTED;
+    if (mode == 1 && !global_scale_dev) return AR_ERR_UNSUPPORTED;
+    if (n_groups == 0) return AR_OK;
+    Fp4BwdArgs a;
+    a.dXq = dXq; a.X = X; a.V = V; a.absmax = absmax; a.max_s = max_s; a.gscale = global_scale_dev;
+    a.lr_v = lr_v_dev; a.lr_mm = lr_mm_dev; a.snap = snapshot_flag; a.best_V = best_V; a.best_max = best_max;
+    a.dV_out = dV_out; a.dmax_out = dmax_out; a.n_groups = n_groups; a.cpg = gs / kEPT; a.mode = mode;
+    a.tune_minmax = tune_minmax; a.init_scale = init_scale; a.lo = lo_bound; a.hi = hi_bound;
+    const int grid = fp4_grid(n_groups * a.cpg);
+    hipStream_t st = (hipStream_t)stream;
+    switch (x_dt) {
+        case AR_DT_BF16: hipLaunchKernelGGL(k_fp4_bwd<AR_DT_BF16>, grid, kTPB, 0, st, a); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_fp4_bwd<AR_DT_F16>, grid, kTPB, 0, st, a); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_fp4_bwd<AR_DT_F32>, grid, kTPB, 0, st, a); break;
+        default: return AR_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// activation fake-quant backward w.r.t. the input (see oracle_fp4_act_bwd for the derivation)
+// ------------------------------------------------------------------------------------------------------------------
+namespace ar {
+__device__ __forceinline__ int lanes_min_i(int v, int width) {
+    for (int m = width >> 1; m > 0; m >>= 1) { const int o = __shfl_xor(v, m, kWave); v = o < v ? o : v; }
+    return v;
+}
+
+template <int XDT>
+__global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ dXq, const void* __restrict__ X,
+                                                      void* __restrict__ dX, const float* __restrict__ gscale_dev,
+                                                      int64_t n_groups, int cpg, int mode) {
+    const int64_t total_chunks = n_groups * cpg;
+    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    const float gscale = (mode == 1 && gscale_dev) ? *gscale_dev : 1.0f;
+    const float LN2 = 0.6931471805599453f;
+    const float r6 = (float)(1.0 / 6.0);
+    const int64_t limit = (total_chunks + kWave - 1) / kWave * kWave;
+    for (int64_t c = (int64_t)blockIdx.x * kTPB + threadIdx.x; c < limit; c += stride) {
+        const bool ok = c < total_chunks;
+        float gg[8], x[8], dx[8];
+        float lmax = -1.f;
+        int lk = 0;
+        if (ok) {
+            unpack8<XDT>(load8_raw<XDT>(dXq, c * kEPT), gg);
+            unpack8<XDT>(load8_raw<XDT>(X, c * kEPT), x);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float a = fabsf(x[k]); if (a > lmax) { lmax = a; lk = k; } }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { gg[k] = 0.f; x[k] = 0.f; }
+        }
+        const float amax = lanes_max(lmax, cpg);
+        const int my_pos = ((int)(c % cpg)) * kEPT + lk;
+        const int kstar = lanes_min_i((ok && lmax == amax) ? my_pos : 0x7fffffff, cpg);   // first index attaining the max
+        float s_gq = 0.f, s_dvw = 0.f;
+        float sc = 1.f, rsc = 1.f, m = amax, se_un = 0.f, s_pre = 0.f, r = 0.f;
+        if (mode == 0) {
+            float se = (m == 0.f) ? 1.0f : log2f(m);
+            se_un = floorf(se) - 2.0f;
+            sc = ldexpf(1.0f, (int)clamp3(se_un, -127.f, 127.f));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float ws = x[k] / sc;
+                const float t = clamp3(ws, -6.f, 6.f);
+                const float q = mx_e2m1(t);
+                const float d = (t == 0.f) ? 0.f : ((fabsf(t) < 1.0f) ? 1.0f : q / t);
+                const bool inside = (ws >= -6.f) && (ws <= 6.f);
+                const float dtp = inside ? (gg[k] * sc) * d : 0.f;
+                dx[k] = dtp / sc;
+                s_gq += gg[k] * q;
+                s_dvw += dtp * (ws / sc);
+            }
+        } else {
+            s_pre = gscale * (amax * r6);
+            const float s = e4m3_to_f32(f32_to_e4m3(clamp3(s_pre, -448.f, 448.f)));
+            r = s * recip0(gscale);
+            sc = recip0(r);
+            rsc = recip0(sc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xp = x[k] * sc;
+                const float xc = clamp3(xp, -6.f, 6.f);
+                const float q = nv_e2m1(xc);
+                const bool inside = (xp >= -6.f) && (xp <= 6.f);
+                const float dxp = (inside && xc != 0.f) ? gg[k] * rsc : 0.f;
+                dx[k] = dxp * sc;
+                s_gq += gg[k] * q;
+                s_dvw += dxp * x[k];
+            }
+        }
+        s_gq = lanes_sum(s_gq, cpg);
+        s_dvw = lanes_sum(s_dvw, cpg);
+        if (!ok) continue;
+        float extra;
+        if (mode == 0) {
+            const float dsc = s_gq - s_dvw;
+            const bool pass = (se_un >= -127.f) && (se_un <= 127.f);
+            extra = (m == 0.f || !pass) ? 0.f : (dsc * (sc * LN2)) / (m * LN2);
+        } else {
+            const float dosc = (sc == 0.f) ? 0.f : (s_dvw - s_gq * (rsc * rsc));
+            const float dr = (r == 0.f) ? 0.f : -dosc * (sc * sc);
+            float ds = dr * recip0(gscale);
+            if (!((s_pre >= -448.f) && (s_pre <= 448.f))) ds = 0.f;
+            extra = (ds * gscale) * r6;
+        }
+        const int base = ((int)(c % cpg)) * kEPT;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool star = (base + k) == kstar;
+            if (mode == 0) dx[k] = dx[k] + (star ? extra * sgnf(x[k]) : 0.f);
+            else dx[k] = round_to<XDT>(dx[k]) + (star ? round_to<XDT>(extra) * sgnf(x[k]) : 0.f);
+        }
+        store8<XDT>(dX, c * kEPT, dx);
+    }
+}
+}  // namespace ar
+
+extern "C" int ar_fp4_act_bwd(const void* dXq, const void* X, void* dX, const float* global_scale_dev, int64_t n_groups,
+                              int gs, int mode, int x_dt, ar_stream_t stream) {
+    if (!((mode == 0 && gs == 32) || (mode == 1 && gs == 16)) || n_groups < 0) return AR_ERR_UNSUPPORTED;
+    if (mode == 1 && !global_scale_dev) return AR_ERR_UNSUPPORTED;
+    if (n_groups == 0) return AR_OK;
+    const int cpg = gs / kEPT;
+    const int grid = fp4_grid(n_groups * cpg);
+    hipStream_t st = (hipStream_t)stream;
+    switch (x_dt) {
+        case AR_DT_BF16: hipLaunchKernelGGL(k_fp4_act_bwd<AR_DT_BF16>, grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_fp4_act_bwd<AR_DT_F16>, grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_fp4_act_bwd<AR_DT_F32>, grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
+        default: return AR_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}

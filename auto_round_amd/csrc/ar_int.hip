@@ -393,7 +393,10 @@ static inline int ilog2_exact(int v) {
 }
 static inline int promote_dt(int a, int b) { return a == b ? a : AR_DT_F32; }
 static inline int grid_for_tiles(int64_t n_tiles) {
-    const int64_t cap = 256 * 8;   // 256 CUs x 8 resident workgroups; the kernels grid-stride over the rest
+#ifndef AR_GRID_CAP
+#define AR_GRID_CAP (256 * 8)      // 256 CUs x 8 resident workgroups; the kernels grid-stride over the rest
+#endif
+    const int64_t cap = AR_GRID_CAP;
     return (int)(n_tiles < cap ? (n_tiles > 0 ? n_tiles : 1) : cap);
 }
 static inline bool fill_cfg(IntCfg& c, float& qlo, float& qhi, int bits, int sym, int w_dt, int s_dt, float th, float lo,

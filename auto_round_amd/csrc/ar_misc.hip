@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kTPB) void k_pack_qzeros_scales(const void* __restr
 
 using namespace ar;
 
-extern "C" int ar_abi_version(void) { return 1; }
+extern "C" int ar_abi_version(void) { return 2; }
 
 extern "C" const char* ar_error_string(int code) {
     if (code == AR_OK) return "ok";

@@ -171,6 +171,27 @@ def qdq_fp4_fwd(X, V, absmax, max_s, *, mode, gs, init_scale=1.0, global_scale=N
     return (Xq, scale) if want_scale else Xq
 
 
+def qdq_fp4_bwd_sgd_(dXq, X, V, absmax, max_s, *, mode, gs, init_scale=1.0, global_scale=None, bounds=(0.0, 1.0), lr_v=None,
+                     lr_mm=None, tune_minmax=True, snapshot_flag=None, best_V=None, best_max=None, want_grads=False):
+    """fp4 backward: with lr_v/lr_mm fused sign-SGD in place on V / max_s; want_grads also returns (dV, dmax)."""
+    G = X.numel() // gs
+    dV = torch.empty(X.numel(), dtype=torch.float32, device=X.device) if want_grads else None
+    dmax = torch.empty(G, dtype=torch.float32, device=X.device) if want_grads else None
+    check(load().ar_qdq_fp4_bwd_sgd(_p(dXq, "dXq"), _p(X, "X"), _p(V), _p(absmax, "absmax"), _p(max_s), init_scale,
+                                    _p(global_scale), G, gs, mode, dt_code(X.dtype), bounds[0], bounds[1], _p(lr_v),
+                                    _p(lr_mm), int(tune_minmax), _p(snapshot_flag), _p(best_V), _p(best_max), _p(dV),
+                                    _p(dmax), _stream()), "ar_qdq_fp4_bwd_sgd")
+    return (dV, dmax) if want_grads else None
+
+
+def fp4_act_bwd(dXq, X, *, mode, gs, global_scale=None, out=None):
+    """Gradient of the dynamic activation fake-quant w.r.t. its input (same dtype/shape as X)."""
+    dX = out if out is not None else torch.empty_like(X)
+    check(load().ar_fp4_act_bwd(_p(dXq, "dXq"), _p(X, "X"), _p(dX), _p(global_scale), X.numel() // gs, gs, mode,
+                                dt_code(X.dtype), _stream()), "ar_fp4_act_bwd")
+    return dX
+
+
 def pack_fp4(Wq2d, scale, *, mode, gs, global_scale=None):
     out_f, in_f = Wq2d.shape
     packed = torch.empty((out_f, in_f // 2), dtype=torch.uint8, device=Wq2d.device)

@@ -86,7 +86,7 @@ def collect_best_params(block, cache_device=None) -> Dict[str, Dict[str, torch.T
     """reference: auto_round/compressors/utils.py:205-217 -- deep copy of every wrapper's tunable parameters."""
     params = {}
     for n, m in block.named_modules():
-        if hasattr(m, "orig_layer"):
+        if hasattr(m, "orig_layer") and hasattr(m, "params"):
             params[n] = {k: (p.data.to(cache_device, copy=True) if cache_device is not None else p.data.clone())
                          for k, p in m.params.items()}
     return params

@@ -95,6 +95,60 @@ class _QLinearFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+class _ActQdqFn(torch.autograd.Function):
+    """Dynamic fp4 fake-quant of an activation tensor (grouped along the last dim) with the reference's autograd
+    semantics: `ar_qdq_fp4_fwd` (V = absmax = max_scale = NULL) forward, `ar_fp4_act_bwd` backward.
+    reference: WrapperLinear._qdq_act (wrapper.py:295-321) -> quant_mx / nv_fp4_with_static_gs."""
+
+    @staticmethod
+    def forward(ctx, x, mode, gs, gscale):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc)
+        ctx.mode, ctx.gs, ctx.gscale = mode, gs, gscale
+        return ops.qdq_fp4_fwd(xc.view(-1), None, None, None, mode=mode, gs=gs, global_scale=gscale).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        dyc = dy.contiguous()
+        if dyc.dtype != xc.dtype:
+            dyc = dyc.to(xc.dtype)
+        dx = ops.fp4_act_bwd(dyc.view(-1), xc.view(-1), mode=ctx.mode, gs=ctx.gs, global_scale=ctx.gscale)
+        return dx.view(xc.shape), None, None, None
+
+
+def act_fake_quant(x: torch.Tensor, layer) -> torch.Tensor:
+    """Activation fake-quant as configured on `layer` (act_bits / act_data_type / act_group_size / act_max)."""
+    adt = str(getattr(layer, "act_data_type", ""))
+    gs = int(getattr(layer, "act_group_size", 0))
+    if int(getattr(layer, "act_bits", 16)) != 4 or x.shape[-1] % max(gs, 1):
+        raise NotImplementedError("activation fake-quant implements 4-bit MXFP4 (gs 32) / NVFP4 (gs 16)")
+    if is_mx_fp(adt) and gs == 32:
+        return _ActQdqFn.apply(x, 0, 32, None)
+    if is_nv_fp(adt) and gs == 16:
+        act_max = getattr(layer, "act_max", None)
+        if act_max is None:     # nv_fp4_with_static_gs falls back to the tensor's own max (nvfp.py:107-108)
+            _, tmax = ops.group_absmax(x.detach().contiguous().view(-1), 16, want_tensor_max=True)
+        else:
+            tmax = torch.as_tensor(act_max, dtype=torch.float32, device=x.device).abs().max().reshape(1)
+        gscale = torch.where(tmax == 0, torch.zeros_like(tmax), (448.0 * 6.0) * (1.0 / tmax))
+        return _ActQdqFn.apply(x, 1, 16, gscale.contiguous())
+    raise NotImplementedError(f"act_data_type={adt} with act_group_size={gs}")
+
+
+class WrapperWALayer(torch.nn.Module):
+    """What the reference leaves in the model after unwrapping an activation-quantised layer (wrapper.py:568-638):
+    the baked weight plus the activation fake-quant applied at every forward."""
+
+    def __init__(self, orig_layer):
+        super().__init__()
+        self.orig_layer = orig_layer
+
+    def forward(self, x):
+        x = act_fake_quant(x, self.orig_layer)
+        return F.linear(x.to(self.orig_layer.weight.dtype), self.orig_layer.weight, self.orig_layer.bias)
+
+
 class BlockArena:
     """Block-wide flat HBM buffers for all layers that share (bits, group_size, sym, data_type, dtypes)."""
 
@@ -108,6 +162,8 @@ class BlockArena:
         self.q_thresh = 1e-8 if self.scale_dtype == torch.float32 else 1e-5
         self.tune_minmax = True
         self.wq_fresh = False       # Wq corresponds to the current parameters
+        self.kind = "mx" if is_mx_fp(self.data_type) else ("nv" if is_nv_fp(self.data_type) else "int")
+        self.mode = {"int": -1, "mx": 0, "nv": 1}[self.kind]
 
     # -- construction ---------------------------------------------------------------------------------------------
     def add(self, layer: "WrapperLinear") -> Tuple[int, int]:
@@ -131,7 +187,14 @@ class BlockArena:
         self.best_max = None
         for lyr in self.layers:
             lyr._bind(self)
-        self.wmin, self.wmax = ops.group_minmax(self.W, self.gs)
+        if self.kind == "int":
+            self.wmin, self.wmax = ops.group_minmax(self.W, self.gs)
+        else:   # fp4: per-group absmax is constant during tuning; NVFP4 also needs the per-layer global scale
+            self.wmin = self.wmax = None
+            self.absmax, _ = ops.group_absmax(self.W, self.gs)
+            if self.kind == "nv":
+                for lyr in self.layers:
+                    lyr._init_global_scale()
         self.token = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
         self.built = True
 
@@ -147,6 +210,15 @@ class BlockArena:
         V = self.V if V is None else V
         mn = self.min_scale if min_s is None else min_s
         mx = self.max_scale if max_s is None else max_s
+        if self.kind != "int":
+            self.wq_fresh = V is self.V and mx is self.max_scale
+            if self.kind == "mx":
+                return ops.qdq_fp4_fwd(self.W, V, self.absmax, mx, mode=0, gs=self.gs, bounds=self.bounds, out=self.Wq)
+            for l in self.layers:   # NVFP4: one launch per layer (each layer has its own global scale)
+                sl, gl = slice(l._off, l._off + l.numel), slice(l._goff, l._goff + l.n_groups)
+                ops.qdq_fp4_fwd(self.W[sl], V[sl], self.absmax[gl], mx[gl], mode=1, gs=self.gs,
+                                global_scale=l.weight_global_scale_dev, bounds=self.bounds, out=self.Wq[sl])
+            return self.Wq
         res = ops.qdq_int_fwd(self.W, V, self.wmin, self.wmax, mn, mx, gs=self.gs, bits=self.bits, sym=self.sym,
                               scale_dtype=self.scale_dtype, q_thresh=self.q_thresh, bounds=self.bounds, out=self.Wq,
                               want_scale=want_scale)
@@ -157,6 +229,21 @@ class BlockArena:
         """K2+K3 (+ snapshot + next K1) for every layer of the block in one launch; consumes self.dWq."""
         if snapshot_flag is not None:
             self.alloc_best()
+        if self.kind != "int":
+            layers = [None] if self.kind == "mx" else self.layers
+            for l in layers:
+                sl = slice(None) if l is None else slice(l._off, l._off + l.numel)
+                gl = slice(None) if l is None else slice(l._goff, l._goff + l.n_groups)
+                ops.qdq_fp4_bwd_sgd_(self.dWq[sl], self.W[sl], self.V[sl], self.absmax[gl], self.max_scale[gl],
+                                     mode=self.mode, gs=self.gs, bounds=self.bounds,
+                                     global_scale=None if l is None else l.weight_global_scale_dev, lr_v=lr_v, lr_mm=lr_mm,
+                                     tune_minmax=self.tune_minmax, snapshot_flag=snapshot_flag,
+                                     best_V=None if self.best_V is None else self.best_V[sl],
+                                     best_max=None if self.best_max is None else self.best_max[gl])
+            self.wq_fresh = False
+            for lyr in self.layers:
+                lyr._dw_accum[0] = False
+            return
         ops.qdq_int_bwd_sgd_(self.dWq, self.W, self.V, self.wmin, self.wmax, self.min_scale, self.max_scale, gs=self.gs,
                              bits=self.bits, sym=self.sym, lr_v=lr_v, lr_mm=lr_mm, tune_minmax=self.tune_minmax,
                              scale_dtype=self.scale_dtype, q_thresh=self.q_thresh, bounds=self.bounds,
@@ -168,6 +255,8 @@ class BlockArena:
 
     def param_grads(self):
         """Unfused backward (ar_qdq_int_bwd): materialises dV / d min_scale / d max_scale like autograd would."""
+        if self.kind != "int":
+            raise NotImplementedError("unfused gradients are exposed for the INT path only")
         return ops.qdq_int_bwd(self.dWq, self.W, self.V, self.wmin, self.wmax, self.min_scale, self.max_scale, gs=self.gs,
                                bits=self.bits, sym=self.sym, scale_dtype=self.scale_dtype, q_thresh=self.q_thresh,
                                bounds=self.bounds)
@@ -197,8 +286,6 @@ class WrapperLinear(torch.nn.Module):
         self.enable_minmax_tuning = enable_minmax_tuning
         self.enable_round_tuning = enable_round_tuning
         self.enable_act_quant = int(getattr(orig_layer, "act_bits", 16)) <= 8
-        if self.enable_act_quant:
-            raise NotImplementedError("activation fake-quant (act_bits<=8) is not part of this round's INT path")
         self.is_conv1d = bool(Conv1D) and isinstance(orig_layer, Conv1D)
         w = orig_layer.weight.data
         self.out_features, self.in_features = (w.shape[1], w.shape[0]) if self.is_conv1d else tuple(w.shape)
@@ -214,8 +301,16 @@ class WrapperLinear(torch.nn.Module):
         self.bits = int(orig_layer.bits)
         self.sym = bool(orig_layer.sym)
         self.data_type = str(getattr(orig_layer, "data_type", "int"))
-        if not is_int_dtype(self.data_type):
-            raise NotImplementedError(f"data_type {self.data_type}: the tuning wrappers implement the INT schemes")
+        if is_mx_fp(self.data_type):
+            if self.bits != 4 or self.gs != 32:
+                raise NotImplementedError("MX path implements mx_fp4 with group_size 32 (MXFP4)")
+        elif is_nv_fp(self.data_type):
+            if self.bits != 4 or self.gs != 16:
+                raise NotImplementedError("NV path implements nv_fp4 with group_size 16 (NVFP4)")
+        elif not is_int_dtype(self.data_type):
+            raise NotImplementedError(f"data_type {self.data_type}: implemented are int (sym/asym), mx_fp4, nv_fp4")
+        self.weight_global_scale = getattr(orig_layer, "weight_global_scale", None)
+        self.weight_global_scale_dev = None
         self.scale_dtype = getattr(orig_layer, "scale_dtype", torch.float16) or torch.float16
         self.q_scale_thresh = 1e-8 if self.scale_dtype == torch.float32 else 1e-5
         self.params: Dict[str, torch.nn.Parameter] = {}
@@ -248,6 +343,15 @@ class WrapperLinear(torch.nn.Module):
         if tunable_mm:
             self.params["min_scale"] = self.min_scale
             self.params["max_scale"] = self.max_scale
+
+    def _init_global_scale(self):
+        """NVFP4 per-tensor global scale 448*6/amax(W) (reference: calculate_gparam, data_type/nvfp.py:56-64) unless the
+        caller already attached a (possibly q/k/v- or gate/up-unified) `weight_global_scale` to the layer."""
+        a = self.arena
+        if self.weight_global_scale is None:
+            amax = a.absmax[self._goff:self._goff + self.n_groups].max()
+            self.weight_global_scale = torch.where(amax == 0, torch.zeros_like(amax), (448.0 * 6.0) * (1.0 / amax))
+        self.weight_global_scale_dev = self.weight_global_scale.to(device=self.device, dtype=torch.float32).reshape(1).contiguous()
 
     @property
     def weight(self):
@@ -283,6 +387,11 @@ class WrapperLinear(torch.nn.Module):
         V = flat(value, a.V[sl], self.numel)
         mn = flat(min_scale, a.min_scale[gl], self.n_groups)
         mx = flat(max_scale, a.max_scale[gl], self.n_groups)
+        if a.kind != "int":
+            Wq, scale = ops.qdq_fp4_fwd(a.W[sl], V, a.absmax[gl], mx, mode=a.mode, gs=self.gs, bounds=self.minmax_scale_bound,
+                                        global_scale=self.weight_global_scale_dev, want_scale=True)
+            wq2d = Wq.view(self.out_features, self.in_features)
+            return (wq2d.t() if self.is_conv1d else wq2d), scale.view(self.n_groups, 1), None
         Wq, scale, zp = ops.qdq_int_fwd(a.W[sl], V, a.wmin[gl], a.wmax[gl], mn, mx, gs=self.gs, bits=self.bits,
                                         sym=self.sym, scale_dtype=self.scale_dtype, q_thresh=self.q_scale_thresh,
                                         bounds=self.minmax_scale_bound, want_scale=True)
@@ -297,6 +406,8 @@ class WrapperLinear(torch.nn.Module):
         a = self.arena
         if not a.wq_fresh:
             a.qdq_forward()
+        if self.enable_act_quant:
+            x = act_fake_quant(x, self.orig_layer)
         return _QLinearFn.apply(x, a.token, self.weight_q, self.orig_layer.bias, self.weight_grad, self._dw_accum)
 
     def unwrapper(self, best_params):
@@ -314,6 +425,10 @@ class WrapperLinear(torch.nn.Module):
             self.orig_layer.zp = zp.reshape(self.out_features, -1).to("cpu")
         else:
             self.orig_layer.zp = zp
+        if self.weight_global_scale_dev is not None:
+            self.orig_layer.weight_global_scale = self.weight_global_scale_dev.to("cpu")
+        if self.enable_act_quant:
+            return WrapperWALayer(self.orig_layer)
         return self.orig_layer
 
 
@@ -362,7 +477,7 @@ def wrapper_block(block, enable_minmax_tuning, enable_norm_bias_tuning, enable_t
 def unwrapper_block(block, best_params):
     """reference: auto_round/wrapper.py:861-878 -- restores the original layers with the best parameters baked in."""
     for n, m in list(block.named_modules()):
-        if hasattr(m, "orig_layer"):
+        if hasattr(m, "orig_layer") and hasattr(m, "unwrapper"):
             bp = best_params.get(n) if best_params else None
             _set_module(block, n, m.unwrapper(bp))
     if hasattr(block, "_ar_arenas"):

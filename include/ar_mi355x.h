@@ -142,6 +142,14 @@ int ar_qdq_fp4_bwd_sgd(const void* dXq, const void* X, float* V, const float* ab
                        const int32_t* snapshot_flag, float* best_V, float* best_max, float* dV_out, float* dmax_out,
                        ar_stream_t stream);
 
+/* activation fake-quant backward w.r.t. the INPUT (dynamic per-group scale taken from the data itself).
+ * replaces: autograd through WrapperLinear._qdq_act (auto_round/wrapper.py:295-321, :530-540) -> quant_mx(x, v=0) /
+ * nv_fp4_with_static_gs(x, tensor_max=act_max): the direct path plus the path through the group max (routed to the
+ * first index attaining max|x|, times sign(x), like torch.max(dim)).  The forward is ar_qdq_fp4_fwd with V = absmax =
+ * max_s = NULL.  dX has the dtype of X. */
+int ar_fp4_act_bwd(const void* dXq, const void* X, void* dX, const float* global_scale_dev, int64_t n_groups, int gs,
+                   int mode, int x_dt, ar_stream_t stream);
+
 /* ---- FP4 packer ----------------------------------------------------------------------------------------------
  * replaces: qlinear_fp.QuantLinear.pack + _pack_fp4_to_uint8 (auto_round/export/export_to_autoround/qlinear_fp.py
  *           :141-193, :235-265).  packed [out, in/2] uint8 (low nibble = even index), scale_bytes [out, in/gs]

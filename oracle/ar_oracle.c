@@ -595,3 +595,171 @@ uint16_t oracle_f32_to_f16(float f) { return f32_to_f16_bits(f); }
 float oracle_f16_to_f32(uint16_t h) { return f16_bits_to_f32(h); }
 uint8_t oracle_f32_to_e4m3(float f) { return f32_to_e4m3_bits(f); }
 float oracle_e4m3_to_f32(uint8_t b) { return e4m3_bits_to_f32(b); }
+
+/* ------------------------------------------------------------------------------------------
+ * FP4 fake-quant backward (what torch autograd computes for oracle_qdq_mxfp4_fwd / _nvfp4_fwd)
+ * reference: autograd through auto_round/data_type/mxfp.py:233-291 (+ quant_element :49-85) and
+ *            auto_round/data_type/nvfp.py:67-98 (+ cast_to_fp4 :26-39).
+ * Closed forms (derivation in DESIGN.md section 3, "fp4 backward"):
+ *   MXFP4  t_pre = W/sc + V, t = clamp(t_pre,+-6), q = e2m1(t)
+ *          dq/dt = 0 if t == 0 ; 1 if |t| < 1 (private exponent clipped at 0, no grad through it) ;
+ *                  q/t if |t| >= 1 (the STE through floor(log2|t|) cancels the direct path and leaves q/t)
+ *          dV = g*sc * dq/dt * [|t_pre| <= 6]
+ *          dsc = sum g*q - sum dV*((W/sc)/sc) ; sc = 2^(floor_ste(log2 m) - 2), m = amax*(init*Ms)
+ *          dMs = ((dsc * (sc*ln2)) / (m*ln2)) * amax * init            (0 when m == 0)
+ *   NVFP4  x_pre = W*osc + V, x = clamp(x_pre,+-6), q = cast_to_fp4(x), out = q*ro, ro = 1/osc, osc = 1/r,
+ *          r = s/gs, s = e4m3_ste(clamp(gs*(vm/6), +-448)), vm = amax*(Ms*init)
+ *          dq/dx = 0 if x == 0 else 1 ; dV = g*ro * dq/dx * [|x_pre| <= 6]
+ *          dosc = sum dV*W - (sum g*q)*(ro*ro) ; dr = -dosc*(osc*osc) ; ds = dr*(1/gs) ;
+ *          dMs = (((ds*gs) * (1/6)) * amax) * init , masked by the +-448 clamp and the zero guards
+ * Group sums in double (order-free).  Only sign(dV) and sign(dMs) reach SignSGD.
+ * ---------------------------------------------------------------------------------------- */
+void oracle_qdq_fp4_bwd(const void* dXq, const void* W, const float* V, const float* max_s, float init_scale,
+                        float global_scale, int64_t G, int gs, int mode, int w_dt, float lo_bound,
+                        float hi_bound, float* dV, float* dmax) {
+    const float LN2 = 0.6931471805599453f;
+    const float r6 = (float)(1.0 / 6.0);
+    for (int64_t g = 0; g < G; ++g) {
+        float amax = 0.f;
+        for (int k = 0; k < gs; ++k) { float a = fabsf(load_as_f32(W, g * gs + k, w_dt)); if (a > amax) amax = a; }
+        const float Ms = max_s ? clampf(max_s[g], lo_bound, hi_bound) : 1.0f;
+        double s_gq = 0.0, s_dvw = 0.0;
+        if (mode == 0) {
+            const float m = amax * (init_scale * Ms);
+            float se = (m == 0.f) ? 1.0f : log2f(m);
+            const float se_un = floorf(se) - 2.0f;
+            se = clampf(se_un, -127.f, 127.f);
+            const float sc = exp2f(se);
+            for (int k = 0; k < gs; ++k) {
+                const int64_t i = g * gs + k;
+                const float gk = load_as_f32(dXq, i, w_dt), w = load_as_f32(W, i, w_dt);
+                const float ws = w / sc;
+                const float tp = ws + (V ? V[i] : 0.f);
+                const float t = clampf(tp, -6.f, 6.f);
+                const float q = mx_quant_element_fp4(t);
+                const float a = fabsf(t);
+                const float d = (t == 0.f) ? 0.f : ((a < 1.0f) ? 1.0f : q / t);
+                const float inside = (tp >= -6.f && tp <= 6.f) ? 1.f : 0.f;
+                const float dv = (gk * sc) * d * inside;
+                if (dV) dV[i] = dv;
+                s_gq += (double)(gk * q);
+                s_dvw += (double)(dv * (ws / sc));
+            }
+            if (dmax) {
+                const float dsc = (float)s_gq - (float)s_dvw;
+                const int pass = (se_un >= -127.f && se_un <= 127.f);
+                dmax[g] = (m == 0.f || !pass) ? 0.f : ((dsc * (sc * LN2)) / (m * LN2)) * amax * init_scale;
+            }
+        } else {
+            const float vm = rnd(w_dt, amax) * (Ms * init_scale);
+            const float s_pre = global_scale * (vm * r6);
+            const float s_c = clampf(s_pre, -448.f, 448.f);
+            const float s = e4m3_bits_to_f32(f32_to_e4m3_bits(s_c));
+            const float rg = recip0(global_scale);
+            const float r = s * rg;
+            const float osc = recip0(r), ro = recip0(osc);
+            for (int k = 0; k < gs; ++k) {
+                const int64_t i = g * gs + k;
+                const float gk = load_as_f32(dXq, i, w_dt), w = load_as_f32(W, i, w_dt);
+                const float xp = w * osc + (V ? V[i] : 0.f);
+                const float x = clampf(xp, -6.f, 6.f);
+                const float q = cast_to_fp4_ref(x);
+                const float d = (x == 0.f) ? 0.f : 1.f;
+                const float inside = (xp >= -6.f && xp <= 6.f) ? 1.f : 0.f;
+                const float dv = (gk * ro) * d * inside;
+                if (dV) dV[i] = dv;
+                s_gq += (double)(gk * q);
+                s_dvw += (double)(dv * w);
+            }
+            if (dmax) {
+                float dosc = (osc == 0.f) ? 0.f : ((float)s_dvw - (float)s_gq * (ro * ro));
+                float dr = (r == 0.f) ? 0.f : -dosc * (osc * osc);
+                float ds = dr * rg;
+                if (!(s_pre >= -448.f && s_pre <= 448.f)) ds = 0.f;
+                dmax[g] = (((ds * global_scale) * r6) * rnd(w_dt, amax)) * init_scale;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Activation fp4 fake-quant backward w.r.t. the INPUT (dynamic per-group scale from the data):
+ *   WrapperLinear._qdq_act (wrapper.py:295-321) -> quant_mx(x, v=0, max_scale=1) | nv_fp4_with_static_gs(x, tensor_max)
+ * Two paths reach x: the direct one (through x/scale) and the one through the group max (the scale is a function
+ * of max|x|; torch.max(dim) routes that gradient to the FIRST index attaining the max, times sign(x)).
+ *   MXFP4 (all fp32 after x.float()):  dx = x_dt( dt_pre/sc + [k == k*] * dm * sign(x_k) )
+ *   NVFP4 (max taken in the input dtype): dx = x_dt( x_dt(dxp*osc) + [k == k*] * x_dt(dvm) * sign(x_k) )
+ * with dt_pre, dsc, dm, dxp, dosc, dvm as in oracle_qdq_fp4_bwd (amax -> max|x|, Ms = init = 1).
+ * All-zero groups: the reference produces NaN at k* (0*inf through the unselected where branch); here 0.
+ * ---------------------------------------------------------------------------------------- */
+void oracle_fp4_act_bwd(const void* dXq, const void* X, float global_scale, int64_t G, int gs, int mode, int x_dt,
+                        void* dX) {
+    const float LN2 = 0.6931471805599453f;
+    const float r6 = (float)(1.0 / 6.0);
+    float* tmp = (float*)malloc(sizeof(float) * gs);
+    for (int64_t g = 0; g < G; ++g) {
+        float amax = -1.f; int kstar = 0;
+        for (int k = 0; k < gs; ++k) { float a = fabsf(load_as_f32(X, g * gs + k, x_dt)); if (a > amax) { amax = a; kstar = k; } }
+        double s_gq = 0.0, s_dvw = 0.0;
+        float extra = 0.f;
+        if (mode == 0) {
+            const float m = amax;
+            float se = (m == 0.f) ? 1.0f : log2f(m);
+            const float se_un = floorf(se) - 2.0f;
+            const float sc = exp2f(clampf(se_un, -127.f, 127.f));
+            for (int k = 0; k < gs; ++k) {
+                const int64_t i = g * gs + k;
+                const float gk = load_as_f32(dXq, i, x_dt), x = load_as_f32(X, i, x_dt);
+                const float ws = x / sc;
+                const float t = clampf(ws, -6.f, 6.f);
+                const float q = mx_quant_element_fp4(t);
+                const float d = (t == 0.f) ? 0.f : ((fabsf(t) < 1.0f) ? 1.0f : q / t);
+                const float inside = (ws >= -6.f && ws <= 6.f) ? 1.f : 0.f;
+                const float dtp = (gk * sc) * d * inside;
+                tmp[k] = dtp / sc;
+                s_gq += (double)(gk * q);
+                s_dvw += (double)(dtp * (ws / sc));
+            }
+            const float dsc = (float)s_gq - (float)s_dvw;
+            const int pass = (se_un >= -127.f && se_un <= 127.f);
+            extra = (m == 0.f || !pass) ? 0.f : (dsc * (sc * LN2)) / (m * LN2);
+            for (int k = 0; k < gs; ++k) {
+                const float x = load_as_f32(X, g * gs + k, x_dt);
+                const float sg = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+                store_from_f32(dX, g * gs + k, x_dt, tmp[k] + ((k == kstar) ? extra * sg : 0.f));
+            }
+        } else {
+            const float vm = amax;
+            const float s_pre = global_scale * (vm * r6);
+            const float s = e4m3_bits_to_f32(f32_to_e4m3_bits(clampf(s_pre, -448.f, 448.f)));
+            const float rg = recip0(global_scale);
+            const float r = s * rg;
+            const float osc = recip0(r), ro = recip0(osc);
+            for (int k = 0; k < gs; ++k) {
+                const int64_t i = g * gs + k;
+                const float gk = load_as_f32(dXq, i, x_dt), x = load_as_f32(X, i, x_dt);
+                const float xp = x * osc;
+                const float xc = clampf(xp, -6.f, 6.f);
+                const float q = cast_to_fp4_ref(xc);
+                const float inside = (xp >= -6.f && xp <= 6.f) ? 1.f : 0.f;
+                const float dxp = (xc == 0.f) ? 0.f : (gk * ro) * inside;
+                tmp[k] = dxp * osc;
+                s_gq += (double)(gk * q);
+                s_dvw += (double)(dxp * x);
+            }
+            float dosc = (osc == 0.f) ? 0.f : ((float)s_dvw - (float)s_gq * (ro * ro));
+            float dr = (r == 0.f) ? 0.f : -dosc * (osc * osc);
+            float ds = dr * rg;
+            if (!(s_pre >= -448.f && s_pre <= 448.f)) ds = 0.f;
+            extra = (ds * global_scale) * r6;
+            for (int k = 0; k < gs; ++k) {
+                const float x = load_as_f32(X, g * gs + k, x_dt);
+                const float sg = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+                const float direct = rnd(x_dt, tmp[k]);
+                const float viamax = (k == kstar) ? rnd(x_dt, extra) * sg : 0.f;
+                store_from_f32(dX, g * gs + k, x_dt, direct + viamax);
+            }
+        }
+    }
+    free(tmp);
+}

@@ -188,3 +188,19 @@ def pack_fp4(W, scale, out_f, in_f, gs, mode, w_dt=DT_BF16, global_scale=1.0):
     lib().oracle_pack_fp4(_p(W), _p(scale), _f(global_scale), ctypes.c_int64(out_f), ctypes.c_int64(in_f), gs,
                           mode, w_dt, _p(packed), _p(sb))
     return packed, sb
+
+
+def qdq_fp4_bwd(dXq, W, V, max_s, G, gs, mode, w_dt=DT_BF16, init_scale=1.0, global_scale=1.0, bounds=(0.0, 1.0)):
+    """-> (dV f32 [G*gs], dmax f32 [G]) : autograd-equivalent gradients of the fp4 fake-quant."""
+    dV = np.empty(G * gs, dtype=np.float32)
+    dmax = np.empty(G, dtype=np.float32)
+    lib().oracle_qdq_fp4_bwd(_p(dXq), _p(W), _p(V), _p(max_s), _f(init_scale), _f(global_scale), ctypes.c_int64(G), gs,
+                             mode, w_dt, _f(bounds[0]), _f(bounds[1]), _p(dV), _p(dmax))
+    return dV, dmax
+
+
+def fp4_act_bwd(dXq, X, G, gs, mode, x_dt=DT_BF16, global_scale=1.0):
+    """-> dX bits [G*gs]: gradient of the dynamic activation fake-quant w.r.t. its input."""
+    dX = np.empty(G * gs, dtype=np_dtype(x_dt))
+    lib().oracle_fp4_act_bwd(_p(dXq), _p(X), _f(global_scale), ctypes.c_int64(G), gs, mode, x_dt, _p(dX))
+    return dX

@@ -52,6 +52,82 @@ def qdq_int(W2d, bits, gs, sym, v, min_scale, max_scale, wmin, wmax, scale_dtype
     return (s * (q - zp)).to(W2d.dtype).reshape(W2d.shape), s, zp
 
 
+def _recip0(x):
+    return torch.where(x == 0, torch.zeros_like(x), 1.0 / x)
+
+
+def _e2m1_mx(t):
+    """E2M1 element rounding with the MX reference's STE structure (data_type/mxfp.py:49-85, ebits=2 mbits=3)."""
+    pe = _ste(torch.floor, torch.log2(t.abs() + (t == 0).to(t.dtype))).clip(min=0.0)
+    x = t / (2.0 ** pe.float()) * 2.0
+    a = x.abs()
+    tie = ((a - 0.5) % 2 == torch.zeros_like(a)).to(t.dtype)
+    x = torch.sign(x) * (_ste(torch.floor, a + 0.5) - tie)
+    x = x / 2.0 * (2.0 ** pe.float())
+    return torch.clamp(x, min=-6.0, max=6.0)
+
+
+def qdq_mxfp4(X, gs, v, max_scale, init_scale=1.0):
+    """MXFP4 fake-quant (data_type/mxfp.py:233-291).  X [..., in]; groups of gs along the last dim.
+    Returns (Xq like X, shared exponent [G,1] in X dtype)."""
+    od = X.dtype
+    t = X.reshape(-1, gs).to(torch.float32)
+    m, _ = torch.max(t.abs(), dim=-1, keepdim=True)
+    m = m * (init_scale * max_scale.unsqueeze(-1))
+    se = torch.where(m == 0, torch.ones_like(m), torch.log2(m))
+    se = (_ste(torch.floor, se) - 2).clamp(min=-127.0, max=127.0)
+    sc = torch.pow(2.0, se.float())
+    t = torch.clamp(t / sc + v, min=-6.0, max=6.0)
+    out = _e2m1_mx(t) * sc
+    return out.reshape(X.shape).to(od), se.to(od)
+
+
+def _e2m1_nv(x):
+    """cast_to_fp4 (data_type/nvfp.py:26-39)."""
+    sign = torch.sign(x)
+    a = x.abs()
+    s1 = _ste(torch.round, 2.0 * a) / 2.0
+    s2 = _ste(torch.round, a)
+    s3 = 2.0 * _ste(torch.round, a / 2.0)
+    m1, m2 = a < 2.0, a < 4.0
+    y = s1 * m1 + s2 * (~m1) * m2 + s3 * (~m1) * (~m2)
+    return y.clamp(-6, 6) * sign
+
+
+def qdq_nvfp4(X, gs, v, max_scale, global_scale, init_scale=1.0):
+    """NVFP4 fake-quant (data_type/nvfp.py:67-98).  Returns (Xq like X, e4m3-valued scale [G,1] fp32)."""
+    od = X.dtype
+    xg = X.reshape(-1, gs)
+    coeff = max_scale * init_scale
+    if isinstance(coeff, torch.Tensor):
+        coeff = coeff.view(-1, 1)
+    vm = torch.max(xg.abs(), dim=-1, keepdim=True)[0].to(torch.float32) * coeff
+    s = global_scale * (vm * (1.0 / 6.0))
+    s = torch.clamp(s, min=-448.0, max=448.0)
+    s = ((s.to(torch.float8_e4m3fn).to(s.dtype) - s).detach() + s).to(torch.float32)
+    osc = _recip0(s * _recip0(global_scale))
+    x = torch.clamp(xg.to(torch.float32) * osc + v, -6.0, 6.0)
+    out = _e2m1_nv(x) * _recip0(osc)
+    return out.reshape(X.shape).to(od), s
+
+
+def nvfp4_global_scale(t):
+    return 448.0 * 6.0 * _recip0(t.to(torch.float32).abs().max())
+
+
+def act_fake_quant(x, layer):
+    """WrapperLinear._qdq_act for the fp4 activation schemes (wrapper.py:295-321)."""
+    adt = str(getattr(layer, "act_data_type", ""))
+    one = torch.tensor(1.0, device=x.device)
+    if adt.startswith("mx_fp"):
+        return qdq_mxfp4(x, int(layer.act_group_size), 0, one)[0]
+    if adt.startswith("nv_fp"):
+        am = getattr(layer, "act_max", None)
+        tmax = x.to(torch.float32).abs().max() if am is None else torch.as_tensor(am, dtype=torch.float32, device=x.device).abs().max()
+        return qdq_nvfp4(x, int(layer.act_group_size), 0, 1.0, 448.0 * 6.0 * _recip0(tmax))[0]
+    raise NotImplementedError(adt)
+
+
 class RefWrapperLinear(torch.nn.Module):
     """Plain-torch tuning wrapper around an nn.Linear carrying bits/group_size/sym/scale_dtype attributes."""
 
@@ -59,6 +135,8 @@ class RefWrapperLinear(torch.nn.Module):
         super().__init__()
         self.orig_layer = layer
         self.bits, self.sym = int(layer.bits), bool(layer.sym)
+        self.data_type = str(getattr(layer, "data_type", "int"))
+        self.act_quant = int(getattr(layer, "act_bits", 16)) <= 8
         gs = int(layer.group_size)
         self.gs = layer.in_features if (gs == -1 or layer.in_features < gs) else gs
         self.scale_dtype = getattr(layer, "scale_dtype", torch.float16)
@@ -83,11 +161,25 @@ class RefWrapperLinear(torch.nn.Module):
         mx = self.max_scale if mx is None else mx
         mn.data.clamp_(0, 1)
         mx.data.clamp_(0, 1)
+        W = self.orig_layer.weight
+        if self.data_type.startswith("mx_fp"):
+            wq, se = qdq_mxfp4(W, self.gs, v, mx)
+            return wq, se, None
+        if self.data_type.startswith("nv_fp"):
+            if not hasattr(self, "gscale"):
+                self.gscale = getattr(self.orig_layer, "weight_global_scale", None)
+                if self.gscale is None:
+                    self.gscale = nvfp4_global_scale(W)
+                self.gscale = self.gscale.to(W.device)
+            wq, sc = qdq_nvfp4(W, self.gs, v, mx, self.gscale)
+            return wq, sc, None
         return qdq_int(self.orig_layer.weight, self.bits, self.gs, self.sym, v, mn, mx, self.wmin, self.wmax,
                        self.scale_dtype, self.thresh)
 
     def forward(self, x):
         wq, _, _ = self.qdq()
+        if self.act_quant:
+            x = act_fake_quant(x, self.orig_layer)
         return F.linear(x, wq, self.orig_layer.bias)
 
     def unwrap(self, best: Optional[Dict[str, torch.Tensor]]):
@@ -102,7 +194,18 @@ class RefWrapperLinear(torch.nn.Module):
         out_f = self.orig_layer.weight.shape[0]
         self.orig_layer.scale = s.reshape(out_f, -1).cpu()
         self.orig_layer.zp = zp.reshape(out_f, -1).cpu() if isinstance(zp, torch.Tensor) else zp
+        if self.act_quant:
+            return RefWALayer(self.orig_layer)
         return self.orig_layer
+
+
+class RefWALayer(torch.nn.Module):
+    def __init__(self, layer):
+        super().__init__()
+        self.orig_layer = layer
+
+    def forward(self, x):
+        return F.linear(act_fake_quant(x, self.orig_layer), self.orig_layer.weight, self.orig_layer.bias)
 
 
 def wrap_block(block, enable_minmax_tuning=True) -> List[str]:

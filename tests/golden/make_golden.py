@@ -317,3 +317,36 @@ if __name__ == "__main__":
     if "fp4" in which: gen_fp4()
     if "sampler" in which: gen_sampler()
     if "mse" in which: gen_mse()
+
+
+def gen_act():
+    """Activation fake-quant (dynamic MXFP4; NVFP4 with a static global scale) forward + autograd w.r.t. the input:
+    WrapperLinear._qdq_act (wrapper.py:295-321) -> quant_mx / nv_fp4_with_static_gs with v=0, max_scale=1."""
+    from auto_round.data_type.mxfp import quant_mx
+    from auto_round.data_type.nvfp import nv_fp4_with_static_gs
+
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(4, 24, 128, generator=g)
+    x[0, 0, :32] = 0.0                       # an all-zero group
+    x[0, 1, :32] = x[0, 1, :32].abs()
+    x[0, 2, 5] = 40.0                        # an outlier: most of its group rounds to 0
+    x[0, 3, 7] = -x[0, 3, :32].abs().max() * 1.0   # tie in |x| -> first index wins the max gradient
+    x[0, 3, 3] = x[0, 3, 7].abs()
+    for kind in ("mxfp4", "nvfp4"):
+        xb = x.to(torch.bfloat16).requires_grad_(True)
+        if kind == "mxfp4":
+            xq, _, _ = quant_mx(xb, bits=4, group_size=32, v=0, max_scale=torch.tensor(1.0), data_type="mx_fp")
+            rec = {}
+        else:
+            act_max = xb.detach().float().abs().max()
+            xq, _, _ = nv_fp4_with_static_gs(xb, bits=4, group_size=16, v=0, tensor_max=act_max)
+            rec = {"act_max": np.float32(act_max.item())}
+        dy = (torch.randn(x.shape, generator=g) * 1e-2).to(torch.bfloat16)
+        xq.backward(dy)
+        rec.update(x=bits(xb), xq=bits(xq), dy=bits(dy), dx=bits(xb.grad))
+        np.savez_compressed(os.path.join(HERE, f"act_{kind}.npz"), **rec)
+        print("act", kind, "nan grads:", int(torch.isnan(xb.grad.float()).sum()))
+
+
+if __name__ == "__main__" and ("act" in sys.argv[1:] or not sys.argv[1:]):
+    gen_act()

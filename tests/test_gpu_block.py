@@ -195,3 +195,51 @@ def test_smoke_entry():
     import __graft_entry__ as ge
 
     ge.smoke()
+
+
+def _set_scheme(layer, data_type, gs, act):
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.bits, m.group_size, m.sym, m.data_type = 4, gs, True, data_type
+            if act:
+                m.act_bits, m.act_group_size, m.act_sym, m.act_dynamic = 4, gs, True, True
+                m.act_data_type = "mx_fp" if data_type.startswith("mx") else "nv_fp4_with_static_gs"
+
+
+@pytest.mark.parametrize("data_type,gs,act", [("mx_fp", 32, False), ("mx_fp", 32, True), ("nv_fp", 16, False), ("nv_fp", 16, True)])
+def test_fp4_schemes_vs_torch_ref_loop(data_type, gs, act):
+    """MXFP4 / NVFP4 weight tuning (with and without 4-bit activation fake-quant, the cfg-5 schemes) against the torch
+    restatement of the reference loop on the same device."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.wrapper import WrapperWALayer
+    from oracle import torch_ref as tr
+
+    layer, rope, cfg = make_layer("llama", 4, gs, True, seed=7)
+    _set_scheme(layer, data_type, gs, act)
+    X, others = make_data(rope, cfg)
+    Y = targets(layer, X, others)
+    iters, bs = 4, 4
+    blk_o = copy.deepcopy(layer)
+    random.seed(3)
+    best_o, info = tr.tune_block(blk_o, X, Y, others, iters=iters, batch_size=bs, forward=fwd)
+    blk_m = copy.deepcopy(layer)
+    random.seed(3)
+    q = SignRoundQuantizer(SignRoundConfig(iters=iters, batch_size=bs, bits=4), device="cuda")
+    best_m = q.quantize_block(blk_m, X, others, Y, None, None)
+    st = q.last_stats
+    assert abs(st["init_loss"] - info["losses"][0]) <= 5e-3 * info["losses"][0], (st, info["losses"])
+    assert abs(st["best_loss"] - info["best_loss"]) <= 5e-2 * info["best_loss"]
+    agree = []
+    for (n1, m1), (n2, m2) in zip(blk_o.named_modules(), blk_m.named_modules()):
+        if isinstance(m1, torch.nn.Linear):
+            assert isinstance(m2, torch.nn.Linear) and m2.zp is None
+            assert tuple(m2.scale.shape) == tuple(m1.scale.shape), (n1, m2.scale.shape, m1.scale.shape)
+            if data_type == "nv_fp":
+                assert float(m2.weight_global_scale) == float(getattr(m1, "weight_global_scale", m2.weight_global_scale))
+            agree.append((m1.weight == m2.weight).float().mean().item())
+    assert np.mean(agree) > 0.95, agree
+    assert any(isinstance(m, WrapperWALayer) for m in blk_m.modules()) == act
+    # the unwrapped block (with its activation fake-quant layers) still runs
+    with torch.no_grad():
+        out = q.forward_all(blk_m, X, others)
+    assert torch.isfinite(out.float()).all()

@@ -151,3 +151,41 @@ def test_tune_block_equals_reference_loop_on_cpu():
     for n in best:
         for k in best[n]:
             assert torch.equal(best[n][k], best_o[n][k]), (n, k)
+
+
+def test_fp4_restatements_equal_reference_golden():
+    """qdq_mxfp4 / qdq_nvfp4 (weights, with V and max_scale) and the activation variants: forward bits and autograd
+    gradients identical to the reference's (same torch ops on CPU -> same bits, NaNs included)."""
+    for kind, gs in (("mxfp4", 32), ("nvfp4", 16)):
+        z = np.load(os.path.join(GOLDEN, f"fp4_{kind}.npz"))
+        _, rows, cols = [int(x) for x in z["meta"]]
+        W = orc.from_bits(z["W"], orc.DT_BF16).reshape(rows, cols)
+        V = torch.from_numpy(z["V"].copy()).requires_grad_(True)
+        Ms = torch.from_numpy(z["max_scale"].copy()).requires_grad_(True)
+        if kind == "mxfp4":
+            Wq, se = tr.qdq_mxfp4(W, gs, V, Ms)
+            assert np.array_equal(orc.to_bits(se.reshape(-1)), z["exp"])
+        else:
+            gsc = tr.nvfp4_global_scale(W)
+            assert np.float32(gsc.item()) == z["global_scale"]
+            Wq, sc = tr.qdq_nvfp4(W, gs, V, Ms, gsc)
+            assert np.array_equal(sc.detach().reshape(-1).numpy(), z["scale"])
+        assert np.array_equal(orc.to_bits(Wq), z["Wq"])
+        Wq.backward(orc.from_bits(z["dWq"], orc.DT_BF16).reshape(rows, cols))
+        assert np.array_equal(V.grad.numpy(), z["dV"])
+        assert np.array_equal(Ms.grad.numpy(), z["dmax"], equal_nan=True)
+
+        za = np.load(os.path.join(GOLDEN, f"act_{kind}.npz"))
+        x = orc.from_bits(za["x"], orc.DT_BF16).requires_grad_(True)
+
+        class L:  # the attributes act_fake_quant reads
+            act_data_type = "mx_fp" if kind == "mxfp4" else "nv_fp4_with_static_gs"
+            act_group_size = gs
+            act_max = None if kind == "mxfp4" else float(za["act_max"])
+
+        xq = tr.act_fake_quant(x, L)
+        assert np.array_equal(orc.to_bits(xq), za["xq"])
+        xq.backward(orc.from_bits(za["dy"], orc.DT_BF16))
+        a, b = orc.to_bits(x.grad), za["dx"]
+        nan = np.isnan(orc.from_bits(b, orc.DT_BF16).float().numpy())
+        assert np.array_equal(a[~nan], b[~nan])
