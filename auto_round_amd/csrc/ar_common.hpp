@@ -64,10 +64,12 @@ template <> struct Raw8<AR_DT_BF16> { uint4 q; };
 template <> struct Raw8<AR_DT_F16> { uint4 q; };
 template <> struct Raw8<AR_DT_F32> { float4 a, b; };
 
-// 16-byte global accesses.  AR_NT=1 marks the streaming arrays non-temporal (read once / written once per launch:
-// keeping them out of the way of L2 is what MI355X_MICROARCH.md's nt-weights row measures as a win for one-pass streams).
+// 16-byte global accesses.  AR_NT=1 would mark the streaming arrays non-temporal.  Measured on MI355X (round 1, A/B in one
+// session, Llama-3-8B block): no gain for these kernels (fwd 5.0-5.2 TB/s either way), and with ROCm 7.2 the
+// __builtin_nontemporal_store path lost the sign of a -0 in the high fp16 half of the 4th dword (caught by the f16
+// golden test), so it stays off.
 #ifndef AR_NT
-#define AR_NT 1
+#define AR_NT 0
 #endif
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));

@@ -187,6 +187,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # AR_BENCH_ONE_DEVICE_DEBUG=1: run every rank on cuda:0 over gloo -- only to exercise the N>1 code path on a 1-GPU box
+    one_dev_debug = os.environ.get("AR_BENCH_ONE_DEVICE_DEBUG") == "1"
+    if one_dev_debug:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -194,7 +198,10 @@ def main():
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        if one_dev_debug:
+            dist_mod.init_process_group("gloo")
+        else:
+            dist_mod.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
         dist = dist_mod
 
     from auto_round_amd import ops
