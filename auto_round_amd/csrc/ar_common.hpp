@@ -127,6 +127,43 @@ template <int DT> __device__ __forceinline__ void unpack8(const Raw8<DT>& r, flo
         o[6] = f16_to_f32(r.q.w & 0xffffu); o[7] = f16_to_f32(r.q.w >> 16);
     }
 }
+// two fp32 -> packed bf16x2 with the gfx950 conversion instruction (v_cvt_pk_bf16_f32: RNE, NaN quieted); verified
+// against the integer RNE formula over all 2^32 inputs by tools/exactcheck (profiles/r01_exactcheck.json).
+#ifndef AR_HW_BF16
+#define AR_HW_BF16 1
+#endif
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#if AR_HW_BF16
+    f32x2_t v; v.x = lo; v.y = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+#else
+    return f32_to_bf16(lo) | (f32_to_bf16(hi) << 16);
+#endif
+}
+
+// ---- exact division by a per-group scale in 3 instructions --------------------------------------------------------
+// y = 1/s is the correctly rounded reciprocal (one IEEE division per lane per chunk, shared by its 8 elements); then
+//     q0 = w*y ; r = fma(-q0, s, w) (exact residual) ; q = fma(r, y, q0)
+// is the correctly rounded quotient w/s (Markstein's theorem) as long as nothing under/overflows.  tools/exactcheck
+// enumerates ALL bf16/fp16 weights x ALL admissible fp16 scales (2^32 pairs each, both for w/s and for (w/s)/s) and
+// finds bit-identical results to the IEEE division whenever |w| is in [2^-64, 2^64] or w == 0; outside that window the
+// kernels take the plain IEEE division (wave-uniform branch, never taken for real checkpoints).
+#ifndef AR_FASTDIV
+#define AR_FASTDIV 1
+#endif
+__device__ __forceinline__ bool div_fast_ok(float w) {
+    const uint32_t e = (__float_as_uint(w) >> 23) & 0xffu;
+    return (e - 63u <= 128u) || (w == 0.f);
+}
+__device__ __forceinline__ float div_fast(float w, float s, float y) {
+    const float q0 = w * y;
+    const float r = __builtin_fmaf(-q0, s, w);
+    const float q1 = __builtin_fmaf(r, y, q0);
+    return (w == 0.f) ? q0 : q1;
+}
+
 template <int DT> __device__ __forceinline__ void store8(void* base, int64_t elem, const float (&v)[8]) {
     if constexpr (DT == AR_DT_F32) {
         float* p = reinterpret_cast<float*>(base) + elem;
@@ -135,8 +172,8 @@ template <int DT> __device__ __forceinline__ void store8(void* base, int64_t ele
     } else {
         uint4 q;
         if constexpr (DT == AR_DT_BF16) {
-            q.x = f32_to_bf16(v[0]) | (f32_to_bf16(v[1]) << 16); q.y = f32_to_bf16(v[2]) | (f32_to_bf16(v[3]) << 16);
-            q.z = f32_to_bf16(v[4]) | (f32_to_bf16(v[5]) << 16); q.w = f32_to_bf16(v[6]) | (f32_to_bf16(v[7]) << 16);
+            q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]);
+            q.z = pack_bf16x2(v[4], v[5]); q.w = pack_bf16x2(v[6], v[7]);
         } else {
             q.x = f32_to_f16(v[0]) | (f32_to_f16(v[1]) << 16); q.y = f32_to_f16(v[2]) | (f32_to_f16(v[3]) << 16);
             q.z = f32_to_f16(v[4]) | (f32_to_f16(v[5]) << 16); q.w = f32_to_f16(v[6]) | (f32_to_f16(v[7]) << 16);

@@ -94,20 +94,41 @@ struct FwdArgs {
 __device__ __forceinline__ int group_of_chunk(int cl, int cpg, int shift) { return shift >= 0 ? (cl >> shift) : (cl / cpg); }
 
 // one chunk of the forward: o = s * (clamp(rint(w/s + v) + zp, qlo, qhi) - zp)
-template <int XR>
-__device__ __forceinline__ void qdq8(const float (&w)[8], const float (&v)[8], float s, float zp, float qlo, float qhi,
-                                     float (&o)[8]) {
+template <int XR, bool FAST>
+__device__ __forceinline__ void qdq8_impl(const float (&w)[8], const float (&v)[8], float s, float y, float zp, float qlo,
+                                          float qhi, float (&o)[8]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        float x = round_to<XR>(w[k] / s);           // true IEEE division (v_div_scale/fmas/fixup), never rcp*mul
+        // correctly rounded w/s: exact 3-instruction form (ar_common.hpp) or the IEEE division; never rcp*mul
+        float x = round_to<XR>(FAST ? div_fast(w[k], s, y) : w[k] / s);
         float r = round_ste_value(x + v[k]);
         float qq = clamp3(r + zp, qlo, qhi) - zp;
         o[k] = s * qq;
     }
 }
+template <int XR>
+__device__ __forceinline__ void qdq8(const float (&w)[8], const float (&v)[8], float s, float zp, float qlo, float qhi,
+                                     float (&o)[8]) {
+#if AR_FASTDIV
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ok = ok && div_fast_ok(w[k]);
+    if (__all(ok)) {                       // wave-uniform
+        qdq8_impl<XR, true>(w, v, s, 1.0f / s, zp, qlo, qhi, o);
+        return;
+    }
+#endif
+    qdq8_impl<XR, false>(w, v, s, 0.f, zp, qlo, qhi, o);
+}
 
-template <int WDT, int UNROLL>
-__global__ __launch_bounds__(kTPB) void k_int_fwd(const FwdArgs a) {
+#ifndef AR_FWD_MINW
+#define AR_FWD_MINW 1
+#endif
+#ifndef AR_BWD_MINW
+#define AR_BWD_MINW 1
+#endif
+template <int WDT, int XR, int UNROLL>
+__global__ __launch_bounds__(kTPB, AR_FWD_MINW) void k_int_fwd(const FwdArgs a) {
     __shared__ float2 sg[2][kTPB];
     const int tid = threadIdx.x;
     const int cpg = a.cpg, shift = a.cpg_shift;
@@ -163,9 +184,7 @@ __global__ __launch_bounds__(kTPB) void k_int_fwd(const FwdArgs a) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = 0.f;
             }
-            if (a.x_dt == AR_DT_F32) qdq8<AR_DT_F32>(w, v, sz.x, sz.y, a.qlo, a.qhi, o);
-            else if (a.x_dt == AR_DT_F16) qdq8<AR_DT_F16>(w, v, sz.x, sz.y, a.qlo, a.qhi, o);
-            else qdq8<AR_DT_BF16>(w, v, sz.x, sz.y, a.qlo, a.qhi, o);
+            qdq8<XR>(w, v, sz.x, sz.y, a.qlo, a.qhi, o);
             store8<WDT>(a.Wq, (c0 + u * kTPB + tid) * kEPT, o);
         }
     }
@@ -188,12 +207,12 @@ struct BwdArgs {
 
 struct Sums { float c1, c2, e, dy; };
 
-template <int XR>
-__device__ __forceinline__ void bwd8(const float (&g)[8], const float (&w)[8], const float (&v)[8], float s, float zp,
-                                     float qlo, float qhi, float (&dy)[8], Sums& acc) {
+template <int XR, bool FAST>
+__device__ __forceinline__ void bwd8_impl(const float (&g)[8], const float (&w)[8], const float (&v)[8], float s, float y,
+                                          float zp, float qlo, float qhi, float (&dy)[8], Sums& acc) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float x = round_to<XR>(w[k] / s);
+        const float x = round_to<XR>(FAST ? div_fast(w[k], s, y) : w[k] / s);
         const float r = round_ste_value(x + v[k]);
         const float t = r + zp;
         const bool inside = (t >= qlo) && (t <= qhi);
@@ -202,15 +221,29 @@ __device__ __forceinline__ void bwd8(const float (&g)[8], const float (&w)[8], c
         dy[k] = inside ? e : 0.f;                          // ClampBackward (where), STE through round
         acc.c1 += g[k] * qq;                               // MulBackward, scale side (summed over the group)
         const float dx = round_to<XR>(dy[k]);
-        const float t2 = round_to<XR>(x / s);
+        const float t2 = round_to<XR>(FAST ? div_fast(x, s, y) : x / s);
         acc.c2 += round_to<XR>((-dx) * t2);                // DivBackward, scale side
         acc.e += -e;                                       // SubBackward -> zp (asym)
         acc.dy += dy[k];                                   // AddBackward -> zp (asym)
     }
 }
+template <int XR>
+__device__ __forceinline__ void bwd8(const float (&g)[8], const float (&w)[8], const float (&v)[8], float s, float zp,
+                                     float qlo, float qhi, float (&dy)[8], Sums& acc) {
+#if AR_FASTDIV
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ok = ok && div_fast_ok(w[k]);
+    if (__all(ok)) {                       // wave-uniform; x = w/s then stays inside the verified window as well
+        bwd8_impl<XR, true>(g, w, v, s, 1.0f / s, zp, qlo, qhi, dy, acc);
+        return;
+    }
+#endif
+    bwd8_impl<XR, false>(g, w, v, s, 0.f, zp, qlo, qhi, dy, acc);
+}
 
-template <int WDT, int UNROLL>
-__global__ __launch_bounds__(kTPB) void k_int_bwd(const BwdArgs a) {
+template <int WDT, int XR, int UNROLL>
+__global__ __launch_bounds__(kTPB, AR_BWD_MINW) void k_int_bwd(const BwdArgs a) {
     __shared__ float2 sg[kTPB];        // (scale, zp) of the tile's groups
     __shared__ float4 ssum[kTPB];      // per-group reduced sums, written by the first lane of each lane-group
     __shared__ float2 sg2[kTPB];       // updated (scale, zp) for the fused next forward
@@ -273,9 +306,7 @@ __global__ __launch_bounds__(kTPB) void k_int_bwd(const BwdArgs a) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = 0.f;
                 }
-                if (a.x_dt == AR_DT_F32) bwd8<AR_DT_F32>(gg, w, v, sz.x, sz.y, a.qlo, a.qhi, dy, acc);
-                else if (a.x_dt == AR_DT_F16) bwd8<AR_DT_F16>(gg, w, v, sz.x, sz.y, a.qlo, a.qhi, dy, acc);
-                else bwd8<AR_DT_BF16>(gg, w, v, sz.x, sz.y, a.qlo, a.qhi, dy, acc);
+                bwd8<XR>(gg, w, v, sz.x, sz.y, a.qlo, a.qhi, dy, acc);
                 const int64_t e0 = (c0 + u * kTPB + tid) * kEPT;
                 if (a.dV) store8_f32(a.dV, e0, dy);
                 if (a.lr_v) {
@@ -302,7 +333,7 @@ __global__ __launch_bounds__(kTPB) void k_int_bwd(const BwdArgs a) {
             const int s_dt = a.cfg.s_dt;
             const float maxq = sym ? (float)(1 << (a.cfg.bits - 1)) : (float)((1 << a.cfg.bits) - 1);
             const float c1 = round_to_rt(s_dt, sm.x);
-            const float c2 = round_to_rt(s_dt, round_to_rt(a.x_dt, sm.y));
+            const float c2 = round_to_rt(s_dt, round_to<XR>(sm.y));
             float ds_c = round_to_rt(s_dt, c1 + c2);
             float dlo_zp = 0.f;
             if (!sym) {
@@ -357,9 +388,7 @@ __global__ __launch_bounds__(kTPB) void k_int_bwd(const BwdArgs a) {
                 const float2 sz = sg2[(u * kTPB + tid) >> shift];
                 float w[8], o[8];
                 unpack8<WDT>(wr[u], w);
-                if (a.x_dt == AR_DT_F32) qdq8<AR_DT_F32>(w, vnew[u], sz.x, sz.y, a.qlo, a.qhi, o);
-                else if (a.x_dt == AR_DT_F16) qdq8<AR_DT_F16>(w, vnew[u], sz.x, sz.y, a.qlo, a.qhi, o);
-                else qdq8<AR_DT_BF16>(w, vnew[u], sz.x, sz.y, a.qlo, a.qhi, o);
+                qdq8<XR>(w, vnew[u], sz.x, sz.y, a.qlo, a.qhi, o);
                 store8<WDT>(a.Wq_next, (c0 + u * kTPB + tid) * kEPT, o);
             }
         }
@@ -394,7 +423,7 @@ static inline int ilog2_exact(int v) {
 static inline int promote_dt(int a, int b) { return a == b ? a : AR_DT_F32; }
 static inline int grid_for_tiles(int64_t n_tiles) {
 #ifndef AR_GRID_CAP
-#define AR_GRID_CAP (256 * 8)      // 256 CUs x 8 resident workgroups; the kernels grid-stride over the rest
+#define AR_GRID_CAP (1 << 24)      // effectively one tile per workgroup (measured: >= the capped grid-stride form)
 #endif
     const int64_t cap = AR_GRID_CAP;
     return (int)(n_tiles < cap ? (n_tiles > 0 ? n_tiles : 1) : cap);
@@ -472,10 +501,18 @@ extern "C" int ar_qdq_int_fwd(const void* W, const float* V, const void* wmin, c
     if (tile_groups < 1) tile_groups = 1;
     const int grid = grid_for_tiles((n_groups + tile_groups - 1) / tile_groups);
     hipStream_t st = (hipStream_t)stream;
+    // W/scale is evaluated in torch's promoted dtype: the 16-bit type when weight and scale share it, else fp32
+    const bool same16 = (a.x_dt == w_dt) && (w_dt != AR_DT_F32);
     switch (w_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL((k_int_fwd<AR_DT_BF16, AR_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
-        case AR_DT_F16: hipLaunchKernelGGL((k_int_fwd<AR_DT_F16, AR_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
-        default: hipLaunchKernelGGL((k_int_fwd<AR_DT_F32, AR_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        case AR_DT_BF16:
+            if (same16) hipLaunchKernelGGL((k_int_fwd<AR_DT_BF16, AR_DT_BF16, AR_FWD_UNROLL>), grid, kTPB, 0, st, a);
+            else hipLaunchKernelGGL((k_int_fwd<AR_DT_BF16, AR_DT_F32, AR_FWD_UNROLL>), grid, kTPB, 0, st, a);
+            break;
+        case AR_DT_F16:
+            if (same16) hipLaunchKernelGGL((k_int_fwd<AR_DT_F16, AR_DT_F16, AR_FWD_UNROLL>), grid, kTPB, 0, st, a);
+            else hipLaunchKernelGGL((k_int_fwd<AR_DT_F16, AR_DT_F32, AR_FWD_UNROLL>), grid, kTPB, 0, st, a);
+            break;
+        default: hipLaunchKernelGGL((k_int_fwd<AR_DT_F32, AR_DT_F32, AR_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
     }
     return launch_status();
 }
@@ -491,10 +528,17 @@ static int launch_int_bwd(BwdArgs& a, int gs, int bits, int sym, int w_dt, int s
     const int tile_groups = kTPB * u_eff / a.cpg;
     const int grid = grid_for_tiles((a.n_groups + tile_groups - 1) / tile_groups);
     hipStream_t st = (hipStream_t)stream;
+    const bool same16 = (a.x_dt == w_dt) && (w_dt != AR_DT_F32);
     switch (w_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL((k_int_bwd<AR_DT_BF16, AR_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
-        case AR_DT_F16: hipLaunchKernelGGL((k_int_bwd<AR_DT_F16, AR_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
-        default: hipLaunchKernelGGL((k_int_bwd<AR_DT_F32, AR_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        case AR_DT_BF16:
+            if (same16) hipLaunchKernelGGL((k_int_bwd<AR_DT_BF16, AR_DT_BF16, AR_BWD_UNROLL>), grid, kTPB, 0, st, a);
+            else hipLaunchKernelGGL((k_int_bwd<AR_DT_BF16, AR_DT_F32, AR_BWD_UNROLL>), grid, kTPB, 0, st, a);
+            break;
+        case AR_DT_F16:
+            if (same16) hipLaunchKernelGGL((k_int_bwd<AR_DT_F16, AR_DT_F16, AR_BWD_UNROLL>), grid, kTPB, 0, st, a);
+            else hipLaunchKernelGGL((k_int_bwd<AR_DT_F16, AR_DT_F32, AR_BWD_UNROLL>), grid, kTPB, 0, st, a);
+            break;
+        default: hipLaunchKernelGGL((k_int_bwd<AR_DT_F32, AR_DT_F32, AR_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
     }
     return launch_status();
 }

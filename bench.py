@@ -46,7 +46,7 @@ WORKLOADS = {
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def build_block(w, bits, gs, sym, device, seed):
+def build_block(w, bits, gs, sym, device, seed, attn="sdpa"):
     torch.manual_seed(seed)
     if w["family"] == "llama":
         from transformers import LlamaConfig
@@ -55,7 +55,7 @@ def build_block(w, bits, gs, sym, device, seed):
         cfg = LlamaConfig(hidden_size=w["hidden"], intermediate_size=w["ffn"], num_attention_heads=w["heads"],
                           num_key_value_heads=w["kv"], num_hidden_layers=1, vocab_size=128256, rope_theta=500000.0,
                           max_position_embeddings=8192)
-        cfg._attn_implementation = "sdpa"
+        cfg._attn_implementation = attn
         with torch.device(device):
             layer = LlamaDecoderLayer(cfg, 0).to(torch.bfloat16)
             rope = LlamaRotaryEmbedding(cfg)
@@ -65,7 +65,7 @@ def build_block(w, bits, gs, sym, device, seed):
 
         cfg = OPTConfig(hidden_size=w["hidden"], ffn_dim=w["ffn"], num_attention_heads=w["heads"], num_hidden_layers=1,
                         vocab_size=50272, max_position_embeddings=2048, word_embed_proj_dim=w["hidden"])
-        cfg._attn_implementation = "sdpa"
+        cfg._attn_implementation = attn
         with torch.device(device):
             layer = OPTDecoderLayer(cfg).to(torch.bfloat16)
         rope = None
@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--asym", action="store_true")
     ap.add_argument("--fuse-next-forward", action="store_true",
                     help="emit the next iteration's Wq from the fused backward kernel (K1 then runs once per block)")
+    ap.add_argument("--sdpa", default="efficient", choices=["auto", "efficient", "flash", "math"],
+                    help="SDPA backend priority for the block attention (see SignRoundConfig.sdpa_backend)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -204,13 +206,25 @@ def main():
             dist_mod.init_process_group("nccl", device_id=device)   # "nccl" is RCCL on ROCm
         dist = dist_mod
 
-    from auto_round_amd import ops
+    from auto_round_amd import _lib, ops
+
+    if not os.path.exists(_lib.LIB_PATH):      # fresh checkout: compile the HIP library first (no other code path exists)
+        if rank == 0:
+            print(f"[bench] {_lib.LIB_PATH} missing -> building with hipcc", file=sys.stderr)
+            _lib.build()
+        if dist is not None:
+            dist.barrier()
     from auto_round_amd.export import pack_block
     from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
 
     w = WORKLOADS[args.workload]
     sym = not args.asym
-    layer, rope, cfg, n_w = build_block(w, args.bits, args.group_size, sym, device, seed=1234 + rank)
+    attn = "sdpa"
+    if args.sdpa == "efficient":     # explicit K/V head repeat so that the efficient SDPA kernels are eligible for GQA
+        from auto_round_amd.attention import register_mi355x_sdpa
+
+        attn = register_mi355x_sdpa()
+    layer, rope, cfg, n_w = build_block(w, args.bits, args.group_size, sym, device, seed=1234 + rank, attn=attn)
     master = {n: p.detach().clone() for n, p in layer.named_parameters()}
     S, H, N = args.seqlen, w["hidden"], args.nsamples
     X = torch.empty(N, S, H, dtype=torch.bfloat16, device=device)
@@ -225,7 +239,7 @@ def main():
         ops.qdq_int_bwd_sgd_ = timer.wrap("k_int_bwd_sgd", ops.qdq_int_bwd_sgd_)
 
     qcfg = SignRoundConfig(iters=args.iters, batch_size=args.batch_size, bits=args.bits,
-                           fuse_next_forward=args.fuse_next_forward)
+                           fuse_next_forward=args.fuse_next_forward, sdpa_backend=args.sdpa)
     quantizer = SignRoundQuantizer(qcfg, device=device)
     random.seed(42 + rank)
 
@@ -274,12 +288,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 weights/activations (MFMA GEMMs), fp32 rounding parameters, fp16 scales",
+            "dtype": "bf16",
+            "dtype_detail": "bf16 weights/activations and MFMA GEMMs (fp32 accumulate); fp32 rounding offsets V and min/max "
+                            "scales; fp16 quant scales; int4 packed output",
             "data": "synthetic: random-init weights of the named architecture, N(0,1) bf16 hidden states",
             "config": {"workload": w["desc"], "bits": args.bits, "group_size": args.group_size, "sym": sym,
                        "iters": args.iters, "nsamples": N, "seqlen": S, "batch_size": args.batch_size,
                        "weights_per_block": n_w, "groups_per_block": G, "includes_packing": True,
-                       "fuse_next_forward": bool(args.fuse_next_forward), "parallelism": f"block-sharded x{world}"},
+                       "fuse_next_forward": bool(args.fuse_next_forward), "sdpa_backend": args.sdpa, "parallelism": f"block-sharded x{world}"},
             "ms_per_iter": 1000.0 * elapsed / args.steps / max(args.iters, 1),
             "loss": {"init": stats["init_loss"], "best": stats["best_loss"], "best_iter": stats["best_iter"]},
         }

@@ -38,3 +38,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_library_built():
+    """A fresh checkout has no .so (it is git-ignored): compile it once per session.  This is the native code itself,
+    not a fallback -- every op still fails loudly if the library cannot be built or loaded."""
+    from auto_round_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    yield

@@ -1,0 +1,95 @@
+// exactcheck.hip -- exhaustive GPU verification of the two "fast but exact" primitives of the streaming kernels
+// (auto_round_amd/csrc/ar_common.hpp), against the plain IEEE / integer formulations the reference arithmetic implies.
+//  (1) div_fast: y = 1/s ; q0 = w*y ; r = fma(-q0,s,w) ; q = fma(r,y,q0)  (guarded by div_fast_ok) vs  w/s,
+//      for ALL finite bf16 and fp16 weights x ALL fp16 scales with |s| >= fp16(1e-5)  (2^32 pairs per dtype),
+//      and for the backward's second quotient (w/s)/s;  plus 2^32 pseudo-random (fp32 weight, fp16 scale) pairs.
+//  (2) pack_bf16x2 (v_cvt_pk_bf16_f32) vs the integer round-to-nearest-even formula, for ALL 2^32 fp32 inputs.
+// Prints one JSON object per check; every "mismatch" field must be 0.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define AR_FASTDIV 1
+#define AR_HW_BF16 1
+#include "../auto_round_amd/csrc/ar_common.hpp"
+using namespace ar;
+
+__device__ __forceinline__ float guarded_div(float w, float s, float y) { return div_fast_ok(w) ? div_fast(w, s, y) : w / s; }
+
+template <int WDT>
+__global__ void check_div(unsigned long long* out) {
+    const float s = f16_to_f32(blockIdx.x);
+    const float as = fabsf(s);
+    if (!(as >= 1.00135803e-05f) || !(as <= 65504.f)) return;
+    const float y = 1.0f / s;
+    unsigned long long b1 = 0, b2 = 0, tot = 0, fastn = 0;
+    for (uint32_t wb = threadIdx.x; wb < 65536; wb += blockDim.x) {
+        const float w = WDT == 0 ? __uint_as_float(wb << 16) : f16_to_f32(wb);
+        if (!(fabsf(w) <= 3.4e38f)) continue;
+        const float q = w / s;
+        if (__float_as_uint(q) != __float_as_uint(guarded_div(w, s, y))) ++b1;
+        // the kernels decide fast/slow on w only and then use the same mode for x = w/s
+        const float q2 = q / s;
+        const float f2 = div_fast_ok(w) ? div_fast(q, s, y) : q / s;
+        if (__float_as_uint(q2) != __float_as_uint(f2)) ++b2;
+        fastn += div_fast_ok(w) ? 1 : 0;
+        ++tot;
+    }
+    atomicAdd(out + 0, b1); atomicAdd(out + 1, b2); atomicAdd(out + 2, tot); atomicAdd(out + 3, fastn);
+}
+
+__global__ void check_div_f32(unsigned long long* out) {
+    // 2^32 pseudo-random pairs: fp32 weight bit patterns from a counter hash, fp16 scales from the low bits
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long b1 = 0, tot = 0;
+    for (int rep = 0; rep < 256; ++rep) {
+        uint64_t h = (gid * 256 + rep) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+        const float w = __uint_as_float((uint32_t)h);
+        const float s = f16_to_f32((uint32_t)(h >> 32) & 0xffffu);
+        const float as = fabsf(s);
+        if (!(as >= 1.00135803e-05f) || !(as <= 65504.f) || !(fabsf(w) <= 3.4e38f)) continue;
+        const float y = 1.0f / s;
+        if (__float_as_uint(w / s) != __float_as_uint(guarded_div(w, s, y))) ++b1;
+        ++tot;
+    }
+    atomicAdd(out + 0, b1); atomicAdd(out + 2, tot);
+}
+
+__global__ void check_bf16(unsigned long long* out) {
+    const uint32_t base = ((uint32_t)blockIdx.x * blockDim.x + threadIdx.x) * 256u;
+    unsigned long long bad = 0;
+    for (uint32_t i = 0; i < 256; i += 2) {
+        const float a = __uint_as_float(base + i), b = __uint_as_float(base + i + 1);
+        const uint32_t hw = pack_bf16x2(a, b);
+        const uint32_t sw = f32_to_bf16(a) | (f32_to_bf16(b) << 16);
+        // NaN payloads may differ (both are quiet NaNs): compare NaN-ness only
+        const bool na = (__float_as_uint(a) & 0x7fffffffu) > 0x7f800000u, nb = (__float_as_uint(b) & 0x7fffffffu) > 0x7f800000u;
+        const uint32_t m = (na ? 0u : 0xffffu) | (nb ? 0u : 0xffff0000u);
+        if ((hw & m) != (sw & m)) ++bad;
+        if (na && ((hw & 0x7fffu) <= 0x7f80u)) ++bad;
+        if (nb && (((hw >> 16) & 0x7fffu) <= 0x7f80u)) ++bad;
+    }
+    atomicAdd(out, bad);
+}
+
+int main() {
+    unsigned long long *d, h[4];
+    hipMalloc(&d, sizeof(h));
+    for (int wdt = 0; wdt < 2; ++wdt) {
+        hipMemset(d, 0, sizeof(h));
+        if (wdt == 0) hipLaunchKernelGGL(check_div<0>, 65536, 256, 0, 0, d); else hipLaunchKernelGGL(check_div<1>, 65536, 256, 0, 0, d);
+        hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        printf("{\"check\": \"div_fast\", \"weights\": \"%s\", \"scales\": \"fp16\", \"pairs\": %llu, \"fast_path_pairs\": %llu, "
+               "\"mismatch_w_over_s\": %llu, \"mismatch_w_over_s_over_s\": %llu}\n", wdt == 0 ? "bf16" : "fp16", h[2], h[3], h[0], h[1]);
+    }
+    hipMemset(d, 0, sizeof(h));
+    hipLaunchKernelGGL(check_div_f32, 65536, 256, 0, 0, d);
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    printf("{\"check\": \"div_fast\", \"weights\": \"fp32 (random bit patterns)\", \"scales\": \"fp16\", \"pairs\": %llu, \"mismatch_w_over_s\": %llu}\n", h[2], h[0]);
+    hipMemset(d, 0, sizeof(h));
+    hipLaunchKernelGGL(check_bf16, 65536, 256, 0, 0, d);
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    printf("{\"check\": \"pack_bf16x2 (v_cvt_pk_bf16_f32) vs integer RNE\", \"inputs\": 4294967296, \"mismatch\": %llu}\n", h[0]);
+    return 0;
+}
