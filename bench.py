@@ -307,7 +307,7 @@ def main():
             abytes = 8 * n_w + 12 * G
             out["roofline"] = {"kernel": "k_int_fwd (INT fake-quant forward, whole block per launch)", "bound": "hbm",
                                "achieved": abytes / fwd_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": abytes / fwd_ms / 1e6 / HBM_PEAK_GBPS, "traffic": read_traffic("k_int_fwd"),
+                               "frac": abytes / fwd_ms / 1e6 / HBM_PEAK_GBPS, "traffic": read_traffic("k_int_fwd", abytes),
                                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": fwd_ms}
         ms2, cnt2 = timer.mean_ms("k_int_bwd_sgd")
         if ms2 is not None:
@@ -316,7 +316,8 @@ def main():
             out["roofline_bwd_sgd"] = {"kernel": "k_int_bwd (fused qdq backward + sign-SGD" +
                                        (" + next forward)" if args.fuse_next_forward else ")"), "bound": "hbm",
                                        "achieved": abytes / ms2 / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                       "frac": abytes / ms2 / 1e6 / HBM_PEAK_GBPS, "traffic": read_traffic("k_int_bwd"),
+                                       "frac": abytes / ms2 / 1e6 / HBM_PEAK_GBPS,
+                                       "traffic": read_traffic("k_int_bwd_with_next_fwd" if args.fuse_next_forward else "k_int_bwd", abytes),
                                        "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": ms2, "launches": cnt2}
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -338,12 +339,16 @@ def timer_block_mean(timer, name, n_w):
     return sum(big) / len(big)
 
 
-def read_traffic(kernel):
-    """HBM bytes per launch from the committed PMC profile of this same command (profiles/pmc_traffic.json), or null."""
+def read_traffic(kernel, abytes=None):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json), or null.  The PMC run was made at
+    the Llama-3-8B g128 block size; it is only reported when this run launches the same number of algorithmic bytes."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(kernel)
+            d = json.load(f)
+        if abytes is not None and d.get("algorithmic", {}).get(kernel) != abytes:
+            return None
+        return d.get(kernel)
     except Exception:
         return None
 
