@@ -30,7 +30,9 @@ __global__ __launch_bounds__(kTPB) void k_group_minmax(const void* __restrict__ 
     const int64_t wave_global = ((int64_t)blockIdx.x * kTPB + threadIdx.x) / kWave;
     const int64_t n_waves = (int64_t)gridDim.x * kTPB / kWave;
     float tmax = 0.f;
-    if (cpg <= kWave) {
+    const bool lane_groups = cpg > 0;   // host passes -cpg to select the wave-per-group form (long or non-pow2 groups)
+    if (!lane_groups) cpg = -cpg;
+    if (lane_groups) {
         const int gpw = kWave / cpg;  // groups per wave pass
         for (int64_t gb = wave_global * gpw; gb < n_groups; gb += n_waves * gpw) {
             const int64_t g = gb + lane / cpg;
@@ -242,6 +244,44 @@ __device__ __forceinline__ void bwd8(const float (&g)[8], const float (&w)[8], c
     bwd8_impl<XR, false>(g, w, v, s, 0.f, zp, qlo, qhi, dy, acc);
 }
 
+// Gradients of min_scale / max_scale from the reduced group sums: autograd's scale path mirrored op by op
+// (oracle/ar_oracle.c oracle_qdq_int_bwd): partial sums rounded to the scale dtype, accumulated in it, threshold-clamp
+// mask, /maxq, sign, maximum() routing (sym) or the zero-point path (asym).
+template <int XR>
+__device__ __forceinline__ void minmax_grads(const IntCfg& cfg, const GroupQ& q, float4 sm, float& gmin, float& gmax) {
+    const bool sym = cfg.sym != 0;
+    const int s_dt = cfg.s_dt;
+    const float maxq = sym ? (float)(1 << (cfg.bits - 1)) : (float)((1 << cfg.bits) - 1);
+    const float c1 = round_to_rt(s_dt, sm.x);
+    const float c2 = round_to_rt(s_dt, round_to<XR>(sm.y));
+    float ds_c = round_to_rt(s_dt, c1 + c2);
+    float dlo_zp = 0.f;
+    if (!sym) {
+        const float dzp = sm.z + sm.w;
+        const float u_over_s = ((-q.a) / q.s) / q.s;
+        const float c3 = round_to_rt(s_dt, (-dzp) * u_over_s);
+        ds_c = round_to_rt(s_dt, ds_c + c3);
+        dlo_zp = -(dzp / q.s);
+    }
+    const float t = round_to_rt(s_dt, cfg.thresh);
+    float ds;
+    if (sym) ds = (q.s_raw < 0.f) ? ((q.s_raw <= -t) ? ds_c : 0.f) : ((q.s_raw >= t) ? ds_c : 0.f);
+    else ds = (q.s_raw >= t) ? ds_c : 0.f;
+    const float d32 = ds / maxq;
+    if (sym) {
+        const float dm = d32 * q.sgn;
+        float da, db;
+        if (q.a == q.b) { da = dm / 2.f; db = dm / 2.f; }
+        else if (q.a > q.b) { da = dm; db = 0.f; }
+        else { da = 0.f; db = dm; }
+        gmin = (-da) * q.wmin;
+        gmax = db * q.wmax;
+    } else {
+        gmin = ((-d32) + dlo_zp) * q.wmin;
+        gmax = d32 * q.wmax;
+    }
+}
+
 template <int WDT, int XR, int UNROLL>
 __global__ __launch_bounds__(kTPB, AR_BWD_MINW) void k_int_bwd(const BwdArgs a) {
     __shared__ float2 sg[kTPB];        // (scale, zp) of the tile's groups
@@ -329,38 +369,8 @@ __global__ __launch_bounds__(kTPB, AR_BWD_MINW) void k_int_bwd(const BwdArgs a) 
         __syncthreads();
 
         if (has_g) {
-            const float4 sm = ssum[tid];
-            const int s_dt = a.cfg.s_dt;
-            const float maxq = sym ? (float)(1 << (a.cfg.bits - 1)) : (float)((1 << a.cfg.bits) - 1);
-            const float c1 = round_to_rt(s_dt, sm.x);
-            const float c2 = round_to_rt(s_dt, round_to<XR>(sm.y));
-            float ds_c = round_to_rt(s_dt, c1 + c2);
-            float dlo_zp = 0.f;
-            if (!sym) {
-                const float dzp = sm.z + sm.w;
-                const float u_over_s = ((-q.a) / q.s) / q.s;
-                const float c3 = round_to_rt(s_dt, (-dzp) * u_over_s);
-                ds_c = round_to_rt(s_dt, ds_c + c3);
-                dlo_zp = -(dzp / q.s);
-            }
-            const float t = round_to_rt(s_dt, a.cfg.thresh);
-            float ds;
-            if (sym) ds = (q.s_raw < 0.f) ? ((q.s_raw <= -t) ? ds_c : 0.f) : ((q.s_raw >= t) ? ds_c : 0.f);
-            else ds = (q.s_raw >= t) ? ds_c : 0.f;
-            const float d32 = ds / maxq;
             float gmin, gmax;
-            if (sym) {
-                const float dm = d32 * q.sgn;
-                float da, db;
-                if (q.a == q.b) { da = dm / 2.f; db = dm / 2.f; }
-                else if (q.a > q.b) { da = dm; db = 0.f; }
-                else { da = 0.f; db = dm; }
-                gmin = (-da) * q.wmin;
-                gmax = db * q.wmax;
-            } else {
-                gmin = ((-d32) + dlo_zp) * q.wmin;
-                gmax = d32 * q.wmax;
-            }
+            minmax_grads<XR>(a.cfg, q, ssum[tid], gmin, gmax);
             if (a.dmin) a.dmin[g] = gmin;
             if (a.dmax) a.dmax[g] = gmax;
             float ms_new = ms, Ms_new = Ms;
@@ -393,6 +403,97 @@ __global__ __launch_bounds__(kTPB, AR_BWD_MINW) void k_int_bwd(const BwdArgs a) 
             }
         }
         __syncthreads();   // sg / ssum / sg2 are reused by the next tile
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// generic group sizes (any multiple of 8: per-channel rows of 11008 / 28672, non power-of-two groups, gs > 512):
+// one wave owns one group and strides over its chunks; same arithmetic, same LDS-free wave reductions.  Slower per
+// byte than the tiled kernels (one group's parameters per wave), used only where those do not apply.
+// ------------------------------------------------------------------------------------------------------------------
+template <int WDT, int XR>
+__global__ __launch_bounds__(kTPB) void k_int_fwd_generic(const FwdArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave0 = ((int64_t)blockIdx.x * kTPB + threadIdx.x) / kWave;
+    const int64_t n_waves = (int64_t)gridDim.x * (kTPB / kWave);
+    for (int64_t g = wave0; g < a.n_groups; g += n_waves) {
+        GroupQ q;
+        group_scale(a.cfg, load1<WDT>(a.wmin, g), load1<WDT>(a.wmax, g), a.min_s ? a.min_s[g] : 1.f,
+                    a.max_s ? a.max_s[g] : 1.f, q);
+        if (lane == 0) {
+            if (a.scale_out) store1_rt(a.cfg.s_dt, a.scale_out, g, q.s);
+            if (a.zp_out) a.zp_out[g] = q.zp;
+        }
+        const float zp = a.cfg.sym ? 0.f : q.zp;
+        for (int c = lane; c < a.cpg; c += kWave) {
+            const int64_t e0 = (g * a.cpg + c) * kEPT;
+            float w[8], v[8], o[8];
+            unpack8<WDT>(load8_raw<WDT>(a.W, e0), w);
+            if (a.V) unpack_f8(load8_f32(a.V, e0), v);
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = 0.f;
+            }
+            qdq8<XR>(w, v, q.s, zp, a.qlo, a.qhi, o);
+            store8<WDT>(a.Wq, e0, o);
+        }
+    }
+}
+
+template <int WDT, int XR>
+__global__ __launch_bounds__(kTPB) void k_int_bwd_generic(const BwdArgs a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave0 = ((int64_t)blockIdx.x * kTPB + threadIdx.x) / kWave;
+    const int64_t n_waves = (int64_t)gridDim.x * (kTPB / kWave);
+    const bool sym = a.cfg.sym != 0;
+    const bool do_snap = a.snap != nullptr && *a.snap != 0;
+    const float alpha_v = a.lr_v ? -(*a.lr_v) : 0.f;
+    const float alpha_mm = a.lr_mm ? -(*a.lr_mm) : 0.f;
+    for (int64_t g = wave0; g < a.n_groups; g += n_waves) {
+        const float wmn = load1<WDT>(a.wmin, g), wmx = load1<WDT>(a.wmax, g);
+        const float ms = a.min_s ? a.min_s[g] : 1.f, Ms = a.max_s ? a.max_s[g] : 1.f;
+        GroupQ q;
+        group_scale(a.cfg, wmn, wmx, ms, Ms, q);
+        const float zp = sym ? 0.f : q.zp;
+        Sums acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < a.cpg; c += kWave) {
+            const int64_t e0 = (g * a.cpg + c) * kEPT;
+            float gg[8], w[8], v[8], dy[8];
+            unpack8<WDT>(load8_raw<WDT>(a.dWq, e0), gg);
+            unpack8<WDT>(load8_raw<WDT>(a.W, e0), w);
+            if (a.V) unpack_f8(load8_f32(a.V, e0), v);
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = 0.f;
+            }
+            bwd8<XR>(gg, w, v, q.s, zp, a.qlo, a.qhi, dy, acc);
+            if (a.dV) store8_f32(a.dV, e0, dy);
+            if (a.lr_v) {
+                if (do_snap && a.best_V) store8_f32(a.best_V, e0, v);
+                float vn[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vn[k] = v[k] + alpha_v * sgnf(dy[k]);
+                store8_f32(a.V, e0, vn);
+            }
+        }
+        acc.c1 = lanes_sum(acc.c1, kWave);
+        acc.c2 = lanes_sum(acc.c2, kWave);
+        if (!sym) { acc.e = lanes_sum(acc.e, kWave); acc.dy = lanes_sum(acc.dy, kWave); }
+        if (lane == 0) {
+            float gmin, gmax;
+            minmax_grads<XR>(a.cfg, q, make_float4(acc.c1, acc.c2, acc.e, acc.dy), gmin, gmax);
+            if (a.dmin) a.dmin[g] = gmin;
+            if (a.dmax) a.dmax[g] = gmax;
+            if (a.lr_mm && a.tune_minmax) {
+                if (do_snap) {
+                    if (a.best_min) a.best_min[g] = q.ms;
+                    if (a.best_max) a.best_max[g] = q.Ms;
+                }
+                a.min_s[g] = q.ms + alpha_mm * sgnf(gmin);
+                a.max_s[g] = q.Ms + alpha_mm * sgnf(gmax);
+            }
+        }
     }
 }
 
@@ -447,14 +548,14 @@ extern "C" int ar_group_minmax(const void* W, void* wmin, void* wmax, int64_t n_
     if (gs <= 0 || gs % kEPT || n_groups < 0) return AR_ERR_UNSUPPORTED;
     if (n_groups == 0) return AR_OK;
     const int cpg = gs / kEPT;
-    if (cpg <= kWave && ilog2_exact(cpg) < 0) return AR_ERR_UNSUPPORTED;
-    const int64_t waves = cpg <= kWave ? (n_groups + (kWave / cpg) - 1) / (kWave / cpg) : n_groups;
+    const bool lane_groups = cpg <= kWave && ilog2_exact(cpg) >= 0;
+    const int64_t waves = lane_groups ? (n_groups + (kWave / cpg) - 1) / (kWave / cpg) : n_groups;
     const int grid = grid_for_tiles((waves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     switch (w_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL(k_group_minmax<AR_DT_BF16>, grid, kTPB, 0, st, W, wmin, wmax, nullptr, nullptr, n_groups, cpg); break;
-        case AR_DT_F16: hipLaunchKernelGGL(k_group_minmax<AR_DT_F16>, grid, kTPB, 0, st, W, wmin, wmax, nullptr, nullptr, n_groups, cpg); break;
-        case AR_DT_F32: hipLaunchKernelGGL(k_group_minmax<AR_DT_F32>, grid, kTPB, 0, st, W, wmin, wmax, nullptr, nullptr, n_groups, cpg); break;
+        case AR_DT_BF16: hipLaunchKernelGGL(k_group_minmax<AR_DT_BF16>, grid, kTPB, 0, st, W, wmin, wmax, nullptr, nullptr, n_groups, lane_groups ? cpg : -cpg); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_group_minmax<AR_DT_F16>, grid, kTPB, 0, st, W, wmin, wmax, nullptr, nullptr, n_groups, lane_groups ? cpg : -cpg); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_group_minmax<AR_DT_F32>, grid, kTPB, 0, st, W, wmin, wmax, nullptr, nullptr, n_groups, lane_groups ? cpg : -cpg); break;
         default: return AR_ERR_UNSUPPORTED;
     }
     return launch_status();
@@ -465,14 +566,14 @@ extern "C" int ar_group_absmax(const void* W, float* absmax, float* tensor_absma
     if (gs <= 0 || gs % kEPT || n_groups < 0) return AR_ERR_UNSUPPORTED;
     if (n_groups == 0) return AR_OK;
     const int cpg = gs / kEPT;
-    if (cpg <= kWave && ilog2_exact(cpg) < 0) return AR_ERR_UNSUPPORTED;
-    const int64_t waves = cpg <= kWave ? (n_groups + (kWave / cpg) - 1) / (kWave / cpg) : n_groups;
+    const bool lane_groups = cpg <= kWave && ilog2_exact(cpg) >= 0;
+    const int64_t waves = lane_groups ? (n_groups + (kWave / cpg) - 1) / (kWave / cpg) : n_groups;
     const int grid = grid_for_tiles((waves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     switch (w_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL(k_group_minmax<AR_DT_BF16>, grid, kTPB, 0, st, W, nullptr, nullptr, absmax, tensor_absmax, n_groups, cpg); break;
-        case AR_DT_F16: hipLaunchKernelGGL(k_group_minmax<AR_DT_F16>, grid, kTPB, 0, st, W, nullptr, nullptr, absmax, tensor_absmax, n_groups, cpg); break;
-        case AR_DT_F32: hipLaunchKernelGGL(k_group_minmax<AR_DT_F32>, grid, kTPB, 0, st, W, nullptr, nullptr, absmax, tensor_absmax, n_groups, cpg); break;
+        case AR_DT_BF16: hipLaunchKernelGGL(k_group_minmax<AR_DT_BF16>, grid, kTPB, 0, st, W, nullptr, nullptr, absmax, tensor_absmax, n_groups, lane_groups ? cpg : -cpg); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_group_minmax<AR_DT_F16>, grid, kTPB, 0, st, W, nullptr, nullptr, absmax, tensor_absmax, n_groups, lane_groups ? cpg : -cpg); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_group_minmax<AR_DT_F32>, grid, kTPB, 0, st, W, nullptr, nullptr, absmax, tensor_absmax, n_groups, lane_groups ? cpg : -cpg); break;
         default: return AR_ERR_UNSUPPORTED;
     }
     return launch_status();
@@ -491,7 +592,7 @@ extern "C" int ar_qdq_int_fwd(const void* W, const float* V, const void* wmin, c
                               ar_stream_t stream) {
     FwdArgs a;
     if (!fill_cfg(a.cfg, a.qlo, a.qhi, bits, sym, w_dt, s_dt, q_thresh, lo_bound, hi_bound)) return AR_ERR_UNSUPPORTED;
-    if (gs <= 0 || gs % kEPT || gs / kEPT > kTPB * AR_FWD_UNROLL || n_groups < 0) return AR_ERR_UNSUPPORTED;
+    if (gs <= 0 || gs % kEPT || n_groups < 0) return AR_ERR_UNSUPPORTED;
     if (n_groups == 0) return AR_OK;
     a.W = W; a.V = V; a.wmin = wmin; a.wmax = wmax; a.min_s = min_s; a.max_s = max_s; a.Wq = Wq;
     a.scale_out = scale_out; a.zp_out = zp_out; a.n_groups = n_groups;
@@ -503,6 +604,21 @@ extern "C" int ar_qdq_int_fwd(const void* W, const float* V, const void* wmin, c
     hipStream_t st = (hipStream_t)stream;
     // W/scale is evaluated in torch's promoted dtype: the 16-bit type when weight and scale share it, else fp32
     const bool same16 = (a.x_dt == w_dt) && (w_dt != AR_DT_F32);
+    if (a.cpg > kTPB * AR_FWD_UNROLL) {   // very long groups (per-channel rows): one wave per group
+        const int ggrid = grid_for_tiles((n_groups + 3) / 4);
+        switch (w_dt) {
+            case AR_DT_BF16:
+                if (same16) hipLaunchKernelGGL((k_int_fwd_generic<AR_DT_BF16, AR_DT_BF16>), ggrid, kTPB, 0, st, a);
+                else hipLaunchKernelGGL((k_int_fwd_generic<AR_DT_BF16, AR_DT_F32>), ggrid, kTPB, 0, st, a);
+                break;
+            case AR_DT_F16:
+                if (same16) hipLaunchKernelGGL((k_int_fwd_generic<AR_DT_F16, AR_DT_F16>), ggrid, kTPB, 0, st, a);
+                else hipLaunchKernelGGL((k_int_fwd_generic<AR_DT_F16, AR_DT_F32>), ggrid, kTPB, 0, st, a);
+                break;
+            default: hipLaunchKernelGGL((k_int_fwd_generic<AR_DT_F32, AR_DT_F32>), ggrid, kTPB, 0, st, a); break;
+        }
+        return launch_status();
+    }
     switch (w_dt) {
         case AR_DT_BF16:
             if (same16) hipLaunchKernelGGL((k_int_fwd<AR_DT_BF16, AR_DT_BF16, AR_FWD_UNROLL>), grid, kTPB, 0, st, a);
@@ -522,8 +638,25 @@ static int launch_int_bwd(BwdArgs& a, int gs, int bits, int sym, int w_dt, int s
     if (!fill_cfg(a.cfg, a.qlo, a.qhi, bits, sym, w_dt, s_dt, q_thresh, lo, hi)) return AR_ERR_UNSUPPORTED;
     if (gs <= 0 || gs % kEPT || a.n_groups < 0) return AR_ERR_UNSUPPORTED;
     a.cpg = gs / kEPT; a.cpg_shift = ilog2_exact(a.cpg); a.x_dt = promote_dt(w_dt, s_dt);
-    if (a.cpg_shift < 0 || a.cpg > kWave) return AR_ERR_UNSUPPORTED;   // lane-group butterfly needs gs in {8,...,512}
     if (a.n_groups == 0) return AR_OK;
+    if (a.cpg_shift < 0 || a.cpg > kWave) {   // lane-group butterfly needs gs in {8,16,...,512}: otherwise one wave per group
+        if (a.Wq_next) return AR_ERR_UNSUPPORTED;      // the fused next forward exists in the tiled kernel only
+        const bool same16g = (a.x_dt == w_dt) && (w_dt != AR_DT_F32);
+        const int ggrid = grid_for_tiles((a.n_groups + 3) / 4);
+        hipStream_t gst = (hipStream_t)stream;
+        switch (w_dt) {
+            case AR_DT_BF16:
+                if (same16g) hipLaunchKernelGGL((k_int_bwd_generic<AR_DT_BF16, AR_DT_BF16>), ggrid, kTPB, 0, gst, a);
+                else hipLaunchKernelGGL((k_int_bwd_generic<AR_DT_BF16, AR_DT_F32>), ggrid, kTPB, 0, gst, a);
+                break;
+            case AR_DT_F16:
+                if (same16g) hipLaunchKernelGGL((k_int_bwd_generic<AR_DT_F16, AR_DT_F16>), ggrid, kTPB, 0, gst, a);
+                else hipLaunchKernelGGL((k_int_bwd_generic<AR_DT_F16, AR_DT_F32>), ggrid, kTPB, 0, gst, a);
+                break;
+            default: hipLaunchKernelGGL((k_int_bwd_generic<AR_DT_F32, AR_DT_F32>), ggrid, kTPB, 0, gst, a); break;
+        }
+        return launch_status();
+    }
     const int u_eff = a.cpg < AR_BWD_UNROLL ? a.cpg : AR_BWD_UNROLL;
     const int tile_groups = kTPB * u_eff / a.cpg;
     const int grid = grid_for_tiles((a.n_groups + tile_groups - 1) / tile_groups);

@@ -163,6 +163,8 @@ class BlockArena:
         self.tune_minmax = True
         self.wq_fresh = False       # Wq corresponds to the current parameters
         self.kind = "mx" if is_mx_fp(self.data_type) else ("nv" if is_nv_fp(self.data_type) else "int")
+        cpg = self.gs // 8
+        self.tiled = cpg <= 64 and (cpg & (cpg - 1)) == 0     # lane-group kernels; otherwise one wave per group
         self.mode = {"int": -1, "mx": 0, "nv": 1}[self.kind]
 
     # -- construction ---------------------------------------------------------------------------------------------
@@ -248,8 +250,8 @@ class BlockArena:
                              bits=self.bits, sym=self.sym, lr_v=lr_v, lr_mm=lr_mm, tune_minmax=self.tune_minmax,
                              scale_dtype=self.scale_dtype, q_thresh=self.q_thresh, bounds=self.bounds,
                              snapshot_flag=snapshot_flag, best_V=self.best_V, best_min=self.best_min,
-                             best_max=self.best_max, Wq_next=self.Wq if fuse_next_fwd else None)
-        self.wq_fresh = bool(fuse_next_fwd)
+                             best_max=self.best_max, Wq_next=self.Wq if (fuse_next_fwd and self.tiled) else None)
+        self.wq_fresh = bool(fuse_next_fwd and self.tiled)
         for lyr in self.layers:
             lyr._dw_accum[0] = False
 
@@ -291,12 +293,17 @@ class WrapperLinear(torch.nn.Module):
         self.out_features, self.in_features = (w.shape[1], w.shape[0]) if self.is_conv1d else tuple(w.shape)
         gs = int(orig_layer.group_size)
         if gs == -1 or self.in_features < gs:
-            gs = self.in_features
-        if gs <= 0 or self.in_features % gs or gs % 8:
-            raise NotImplementedError(f"group_size={orig_layer.group_size} with in_features={self.in_features}: only "
-                                      "in_features % group_size == 0 and group_size % 8 == 0 are implemented")
+            gs = self.in_features            # per-output-channel groups (data_type/utils.py:47-48)
+        if gs <= 0 or gs % 8:
+            raise NotImplementedError(f"group_size={orig_layer.group_size} with in_features={self.in_features}: group "
+                                      "sizes must be a multiple of 8 (per-tensor group_size=0 and 2-D block groups are "
+                                      "outside the hot path)")
         self.gs = gs
-        self.numel = self.out_features * self.in_features
+        # rows are zero-padded to a multiple of the group size exactly like reshape_pad_tensor_by_group_size
+        # (data_type/utils.py:52-56); the pad columns never receive a gradient, so their V stays 0
+        self.in_pad = (self.in_features + gs - 1) // gs * gs
+        self.padded = self.in_pad != self.in_features
+        self.numel = self.out_features * self.in_pad
         self.n_groups = self.numel // gs
         self.bits = int(orig_layer.bits)
         self.sym = bool(orig_layer.sym)
@@ -328,11 +335,14 @@ class WrapperLinear(torch.nn.Module):
         n, G = self.numel, self.n_groups
         w = self.orig_layer.weight.data
         w2d = w.t() if self.is_conv1d else w
-        arena.W[off:off + n].view(self.out_features, self.in_features).copy_(w2d)
-        if not self.is_conv1d:  # the layer's weight now lives in the arena (no second copy of the block in HBM)
-            self.orig_layer.weight.data = arena.W[off:off + n].view(self.out_features, self.in_features)
-        self.weight_q = arena.Wq[off:off + n].view(self.out_features, self.in_features)
-        self.weight_grad = arena.dWq[off:off + n].view(self.out_features, self.in_features)
+        Wv = arena.W[off:off + n].view(self.out_features, self.in_pad)
+        if self.padded:
+            Wv.zero_()
+        Wv[:, :self.in_features].copy_(w2d)
+        if not self.is_conv1d and not self.padded:  # the layer's weight now lives in the arena (no second copy in HBM)
+            self.orig_layer.weight.data = Wv
+        self.weight_q = arena.Wq[off:off + n].view(self.out_features, self.in_pad)[:, :self.in_features]
+        self.weight_grad = arena.dWq[off:off + n].view(self.out_features, self.in_pad)[:, :self.in_features]
         tunable_v = self.enable_round_tuning and self.bits < 16
         tunable_mm = self.enable_minmax_tuning and self.bits < 16
         self.value = torch.nn.Parameter(arena.V[off:off + n].view(G, self.gs), requires_grad=tunable_v)
@@ -390,12 +400,12 @@ class WrapperLinear(torch.nn.Module):
         if a.kind != "int":
             Wq, scale = ops.qdq_fp4_fwd(a.W[sl], V, a.absmax[gl], mx, mode=a.mode, gs=self.gs, bounds=self.minmax_scale_bound,
                                         global_scale=self.weight_global_scale_dev, want_scale=True)
-            wq2d = Wq.view(self.out_features, self.in_features)
+            wq2d = Wq.view(self.out_features, self.in_pad)[:, :self.in_features]
             return (wq2d.t() if self.is_conv1d else wq2d), scale.view(self.n_groups, 1), None
         Wq, scale, zp = ops.qdq_int_fwd(a.W[sl], V, a.wmin[gl], a.wmax[gl], mn, mx, gs=self.gs, bits=self.bits,
                                         sym=self.sym, scale_dtype=self.scale_dtype, q_thresh=self.q_scale_thresh,
                                         bounds=self.minmax_scale_bound, want_scale=True)
-        wq2d = Wq.view(self.out_features, self.in_features)
+        wq2d = Wq.view(self.out_features, self.in_pad)[:, :self.in_features]
         if self.is_conv1d:
             wq2d = wq2d.t()
         if self.sym:

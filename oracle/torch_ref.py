@@ -32,7 +32,14 @@ def _ste(fn, x):
 def qdq_int(W2d, bits, gs, sym, v, min_scale, max_scale, wmin, wmax, scale_dtype=torch.float16, thresh=1e-5):
     """Fake-quant of a [out, in] weight with per-group scales; differentiable w.r.t. v, min_scale, max_scale.
     Returns (Wq [out,in] in W dtype, scale [G,1], zp (int for sym, [G,1] tensor for asym))."""
-    Wg = W2d.reshape(-1, gs)
+    out_f, in_f = W2d.shape
+    pad = (-in_f) % gs          # zero-pad every row to a multiple of gs (data_type/utils.py:52-56), cut again at the end
+    Wg = (F.pad(W2d, (0, pad)) if pad else W2d).reshape(-1, gs)
+
+    def back(x):
+        x = x.to(W2d.dtype)
+        return x.reshape(out_f, in_f + pad)[:, :in_f] if pad else x.reshape(W2d.shape)
+
     if sym:
         maxq = 2 ** (bits - 1)
         a = -(wmin * min_scale)
@@ -41,7 +48,7 @@ def qdq_int(W2d, bits, gs, sym, v, min_scale, max_scale, wmin, wmax, scale_dtype
         s = ((sgn * torch.max(b, a)) / maxq).to(scale_dtype)
         s = torch.where(s < 0, torch.clamp(s, max=-thresh), torch.clamp(s, min=thresh)).unsqueeze(-1)
         q = torch.clamp(_ste(torch.round, Wg / s + v), -maxq, maxq - 1)
-        return (s * q).to(W2d.dtype).reshape(W2d.shape), s, maxq
+        return back(s * q), s, maxq
     maxq = 2 ** bits - 1
     lo = wmin * min_scale
     hi = wmax * max_scale
@@ -49,7 +56,7 @@ def qdq_int(W2d, bits, gs, sym, v, min_scale, max_scale, wmin, wmax, scale_dtype
     zp = _ste(torch.round, -lo / s).unsqueeze(-1)
     s = s.unsqueeze(-1)
     q = torch.clamp(_ste(torch.round, Wg / s + v) + zp, 0, maxq)
-    return (s * (q - zp)).to(W2d.dtype).reshape(W2d.shape), s, zp
+    return back(s * (q - zp)), s, zp
 
 
 def _recip0(x):
@@ -142,7 +149,8 @@ class RefWrapperLinear(torch.nn.Module):
         self.scale_dtype = getattr(layer, "scale_dtype", torch.float16)
         self.thresh = 1e-8 if self.scale_dtype == torch.float32 else 1e-5
         W = layer.weight.data
-        Wg = W.reshape(-1, self.gs)
+        pad = (-W.shape[1]) % self.gs
+        Wg = (F.pad(W, (0, pad)) if pad else W).reshape(-1, self.gs)
         self.wmin = torch.clamp(Wg.min(1)[0], max=0)
         self.wmax = torch.clamp(Wg.max(1)[0], min=0)
         dev = W.device

@@ -243,3 +243,31 @@ def test_fp4_schemes_vs_torch_ref_loop(data_type, gs, act):
     with torch.no_grad():
         out = q.forward_all(blk_m, X, others)
     assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("gs,bits,sym", [(96, 4, True), (-1, 4, False), (80, 2, False)])
+def test_padded_and_per_channel_groups_vs_torch_ref(gs, bits, sym):
+    """group sizes that do not divide in_features (zero-padded rows) and per-output-channel groups."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from oracle import torch_ref as tr
+
+    layer, rope, cfg = make_layer("opt", bits, gs, sym, seed=9)     # hidden 256, ffn 512: 96 / 80 divide neither
+    X, others = make_data(rope, cfg)
+    Y = targets(layer, X, others)
+    iters, bs = 3, 4
+    blk_o = copy.deepcopy(layer)
+    random.seed(2)
+    best_o, info = tr.tune_block(blk_o, X, Y, others, iters=iters, batch_size=bs, forward=fwd)
+    blk_m = copy.deepcopy(layer)
+    random.seed(2)
+    q = SignRoundQuantizer(SignRoundConfig(iters=iters, batch_size=bs, bits=bits), device="cuda")
+    best_m = q.quantize_block(blk_m, X, others, Y, None, None)
+    st = q.last_stats
+    assert abs(st["init_loss"] - info["losses"][0]) <= 2e-3 * info["losses"][0], (st, info["losses"])
+    lo, lm = linears(blk_o), linears(blk_m)
+    agree = []
+    for n in lo:
+        assert tuple(lm[n].scale.shape) == tuple(lo[n].scale.shape), (n, lm[n].scale.shape, lo[n].scale.shape)
+        assert tuple(best_m[n]["value"].shape) == tuple(best_o[n]["value"].shape)
+        agree.append((lm[n].weight == lo[n].weight).float().mean().item())
+    assert np.mean(agree) > 0.97, agree
