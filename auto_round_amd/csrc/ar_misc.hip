@@ -17,28 +17,37 @@ constexpr int kMseMaxBlocks = 1024;
 template <int ADT>
 __global__ __launch_bounds__(kTPB) void k_mse_stage1(const void* __restrict__ pred, const void* __restrict__ ref,
                                                      void* __restrict__ dpred, double* __restrict__ partials, int64_t n,
-                                                     float alpha, float gout) {
+                                                     float alpha, float gout, const uint8_t* __restrict__ mask,
+                                                     int64_t row_len) {
     __shared__ double red[kTPB / kWave];
     const int64_t n_chunks = n / kEPT;
     const int64_t stride = (int64_t)gridDim.x * kTPB;
     float acc = 0.f;
     for (int64_t c = (int64_t)blockIdx.x * kTPB + threadIdx.x; c < n_chunks; c += stride) {
         float p[8], r[8], d[8];
-        unpack8<ADT>(load8_raw<ADT>(pred, c * kEPT), p);
-        unpack8<ADT>(load8_raw<ADT>(ref, c * kEPT), r);
+        // row_len % 8 == 0 (checked on the host): a chunk never straddles two tokens
+        const bool valid = mask == nullptr || mask[(c * kEPT) / row_len] != 0;
+        if (valid) {
+            unpack8<ADT>(load8_raw<ADT>(pred, c * kEPT), p);
+            unpack8<ADT>(load8_raw<ADT>(ref, c * kEPT), r);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float df = p[k] - r[k];
-            acc += df * df;
-            d[k] = (alpha * df) * gout;   // ATen mse_loss_backward: alpha * (a - b) * grad_output
+            for (int k = 0; k < 8; ++k) {
+                const float df = p[k] - r[k];
+                acc += df * df;
+                d[k] = (alpha * df) * gout;   // ATen mse_loss_backward: alpha * (a - b) * grad_output
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = 0.f;
         }
         if (dpred) store8<ADT>(dpred, c * kEPT, d);
     }
     // tail (n not a multiple of 8)
     for (int64_t i = n_chunks * kEPT + (int64_t)blockIdx.x * kTPB + threadIdx.x; i < n; i += stride) {
-        const float df = load1<ADT>(pred, i) - load1<ADT>(ref, i);
+        const bool valid = mask == nullptr || mask[i / row_len] != 0;
+        const float df = valid ? load1<ADT>(pred, i) - load1<ADT>(ref, i) : 0.f;
         acc += df * df;
-        if (dpred) store1<ADT>(dpred, i, (alpha * df) * gout);
+        if (dpred) store1<ADT>(dpred, i, valid ? (alpha * df) * gout : 0.f);
     }
     double dacc = (double)acc;
     for (int m = kWave >> 1; m > 0; m >>= 1) dacc += __shfl_xor(dacc, m, kWave);
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(kTPB) void k_pack_qzeros_scales(const void* __restr
 
 using namespace ar;
 
-extern "C" int ar_abi_version(void) { return 2; }
+extern "C" int ar_abi_version(void) { return 3; }
 
 extern "C" const char* ar_error_string(int code) {
     if (code == AR_OK) return "ok";
@@ -198,18 +207,20 @@ extern "C" const char* ar_error_string(int code) {
 extern "C" int64_t ar_mse_workspace_bytes(void) { return (int64_t)kMseMaxBlocks * sizeof(double); }
 
 extern "C" int ar_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpred, float* loss_out, float* loss_accum,
-                                   float accum_scale, int64_t n, int act_dt, float grad_scale, void* workspace,
-                                   ar_stream_t stream) {
+                                   float accum_scale, int64_t n, int act_dt, float grad_scale, const uint8_t* token_mask,
+                                   int64_t row_len, void* workspace, ar_stream_t stream) {
     if (n <= 0 || !workspace) return AR_ERR_UNSUPPORTED;
+    if (token_mask && (row_len <= 0 || row_len % kEPT || n % row_len)) return AR_ERR_UNSUPPORTED;
+    if (!token_mask) row_len = 1;
     hipStream_t st = (hipStream_t)stream;
     int64_t want = (n / kEPT + kTPB - 1) / kTPB;
     const int grid = (int)(want < 1 ? 1 : (want > kMseMaxBlocks ? kMseMaxBlocks : want));
     const float alpha = (float)(2.0 / (double)n);
     double* partials = (double*)workspace;
     switch (act_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL(k_mse_stage1<AR_DT_BF16>, grid, kTPB, 0, st, pred, ref, dpred, partials, n, alpha, grad_scale); break;
-        case AR_DT_F16: hipLaunchKernelGGL(k_mse_stage1<AR_DT_F16>, grid, kTPB, 0, st, pred, ref, dpred, partials, n, alpha, grad_scale); break;
-        case AR_DT_F32: hipLaunchKernelGGL(k_mse_stage1<AR_DT_F32>, grid, kTPB, 0, st, pred, ref, dpred, partials, n, alpha, grad_scale); break;
+        case AR_DT_BF16: hipLaunchKernelGGL(k_mse_stage1<AR_DT_BF16>, grid, kTPB, 0, st, pred, ref, dpred, partials, n, alpha, grad_scale, token_mask, row_len); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_mse_stage1<AR_DT_F16>, grid, kTPB, 0, st, pred, ref, dpred, partials, n, alpha, grad_scale, token_mask, row_len); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_mse_stage1<AR_DT_F32>, grid, kTPB, 0, st, pred, ref, dpred, partials, n, alpha, grad_scale, token_mask, row_len); break;
         default: return AR_ERR_UNSUPPORTED;
     }
     int rc = launch_status();

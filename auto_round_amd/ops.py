@@ -112,15 +112,18 @@ def mse_workspace(device) -> torch.Tensor:
     return ws
 
 
-def mse_loss_fwd_bwd(pred, ref, *, dpred=None, loss_out=None, loss_accum=None, accum_scale=1.0, grad_scale=1000.0):
-    """loss = mean((pred-ref)^2) ; dpred = d(loss*grad_scale)/dpred in pred.dtype. -> (loss_out [1] f32, dpred)"""
+def mse_loss_fwd_bwd(pred, ref, *, dpred=None, loss_out=None, loss_accum=None, accum_scale=1.0, grad_scale=1000.0,
+                     token_mask=None):
+    """loss = mean((pred-ref)^2) ; dpred = d(loss*grad_scale)/dpred in pred.dtype. -> (loss_out [1] f32, dpred).
+    token_mask: optional uint8 [tokens] valid-token mask (rows of pred.shape[-1] elements)."""
     if dpred is None:
         dpred = torch.empty_like(pred)
     if loss_out is None:
         loss_out = torch.empty(1, dtype=torch.float32, device=pred.device)
     check(load().ar_mse_loss_fwd_bwd(_p(pred, "pred"), _p(ref, "ref"), _p(dpred), _p(loss_out), _p(loss_accum),
-                                     accum_scale, pred.numel(), dt_code(pred.dtype), grad_scale,
-                                     _p(mse_workspace(pred.device)), _stream()), "ar_mse_loss_fwd_bwd")
+                                     accum_scale, pred.numel(), dt_code(pred.dtype), grad_scale, _p(token_mask, "token_mask"),
+                                     pred.shape[-1] if token_mask is not None else 0, _p(mse_workspace(pred.device)),
+                                     _stream()), "ar_mse_loss_fwd_bwd")
     return loss_out, dpred
 
 

@@ -270,6 +270,18 @@ class SignRoundQuantizer:
             sched = [sampler.next_batch() for _ in range(cfg.iters)]
             sched_dev = torch.tensor(sched, dtype=torch.int64).to(device, non_blocking=True)
 
+        # valid-token loss mask (reference: quantization/base.py:257-280): positions whose token id the calibrator set
+        # to -100 (pads, the last token of every sample) are excluded from the loss; all-valid -> unmasked fast path
+        mask_dev, valid_counts = None, None
+        if input_ids is not None:
+            ids = input_ids if isinstance(input_ids, torch.Tensor) else torch.cat([t.reshape(1, -1) for t in input_ids], 0)
+            valid = ids.reshape(nsamples, -1) != -100
+            if not bool(valid.all()):
+                mask_dev = valid.to(torch.uint8).to(device).contiguous()
+                valid_counts = valid.sum(dim=1).tolist()
+                mb = torch.empty((min(batch_size, global_bs), mask_dev.shape[1]), dtype=torch.uint8, device=device)
+        sched_host = index_schedule if index_schedule is not None else (None if sched_dev is None else sched)
+
         total_loss = torch.zeros(1, dtype=torch.float32, device=device)
         state = torch.tensor([FLT_MAX, 0.0, 0.0], dtype=torch.float32, device=device)
         istate = torch.zeros(4, dtype=torch.int32, device=device)
@@ -283,11 +295,15 @@ class SignRoundQuantizer:
 
         for i in range(cfg.iters):
             if sched_dev is None:
-                gidx = torch.tensor(sampler.next_batch(), dtype=torch.int64).to(device)
+                host_idx = sampler.next_batch()
+                gidx = torch.tensor(host_idx, dtype=torch.int64).to(device)
             else:
+                host_idx = sched_host[i]
                 gidx = sched_dev[i]
             num_elm = 1
-            if accum:
+            if valid_counts is not None:   # number of valid tokens in the global batch (quantizer.py:477-478)
+                num_elm = max(1, sum(valid_counts[j] for j in host_idx))
+            elif accum:
                 num_elm = global_bs * X[0].numel()
             for b0 in range(0, global_bs, batch_size):
                 idx = gidx[b0:b0 + batch_size]
@@ -299,12 +315,19 @@ class SignRoundQuantizer:
                 if dpred is None or dpred.shape != pred_c.shape or dpred.dtype != pred_c.dtype:
                     dpred = torch.empty_like(pred_c)
                 n = pred_c.numel()
+                tmask = None
+                if mask_dev is not None:
+                    if mask_dev.shape[1] % 16 == 0:
+                        tmask = ops.gather_rows(mask_dev, idx, out=mb[:nb]).view(-1)
+                    else:
+                        tmask = mask_dev.index_select(0, idx).contiguous().view(-1)
                 if accum:   # reduction="sum" and loss/num_elm in the reference (quantizer.py:436-452, :496)
                     ops.mse_loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred=dpred, loss_accum=total_loss,
-                                         accum_scale=float(n) / float(num_elm), grad_scale=1000.0 * float(n))
+                                         accum_scale=float(n) / float(num_elm), grad_scale=1000.0 * float(n),
+                                         token_mask=tmask)
                 else:
                     ops.mse_loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred=dpred, loss_accum=total_loss,
-                                         accum_scale=1.0, grad_scale=1000.0)
+                                         accum_scale=1.0 / float(num_elm), grad_scale=1000.0, token_mask=tmask)
                 pred_c.backward(dpred)
             ops.best_loss_update(total_loss, state, istate, i)
             if early_stop:
@@ -356,7 +379,7 @@ class SignRoundQuantizer:
             outs.append(self.block_forward(block, inputs[b0:b0 + bs], input_others))
         return torch.cat(outs, dim=0)
 
-    def compress_block(self, block, fp_inputs, input_others, q_inputs=None, block_ctx=None):
+    def compress_block(self, block, fp_inputs, input_others, q_inputs=None, block_ctx=None, input_ids=None):
         """reference: AlgorithmComposer.compress_block (composer.py:360-483):
         (3) reference forward with the fp weights, (4) quantize_block, (6) forward of the quantised block to produce
         the next block's quantised input.  -> (fp_outputs [N,S,H], q_outputs [N,S,H] or None, best_params)"""
@@ -364,7 +387,7 @@ class SignRoundQuantizer:
         X = stack_samples(fp_inputs, device)
         fp_out = self.forward_all(block, X, input_others)
         Xq = stack_samples(q_inputs, device) if (q_inputs is not None and self.config.enable_quanted_input) else None
-        best = self.quantize_block(block, X, input_others, fp_out, Xq, block_ctx)
+        best = self.quantize_block(block, X, input_others, fp_out, Xq, block_ctx, input_ids=input_ids)
         q_out = None
         if self.config.enable_quanted_input:
             q_out = self.forward_all(block, Xq if Xq is not None else X, input_others)

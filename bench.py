@@ -232,6 +232,10 @@ def main():
         g = torch.Generator(device=device).manual_seed(2)
         X.copy_(torch.randn(N, S, H, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16))
     others = make_others(rope, S, device, X[:1])
+    # token ids as the reference's calibrator caches them: the last position of every sample is marked -100 and is
+    # excluded from the loss (calibration/llm.py:340-360) -> the masked loss path is the reference's default path
+    token_ids = torch.randint(0, 32000, (N, S), generator=torch.Generator().manual_seed(3))
+    token_ids[:, -1] = -100
 
     timer = KernelTimer()
     if not args.no_kernel_timing:
@@ -251,7 +255,7 @@ def main():
 
     def one_block():
         restore()                                           # "dispatch_block": fresh fp weights in HBM
-        fp_out, q_out, best = quantizer.compress_block(layer, X, others)
+        fp_out, q_out, best = quantizer.compress_block(layer, X, others, input_ids=token_ids)
         packed = pack_block(layer)                          # final low-bit packing kernel, GPTQ-order int32 words
         return quantizer.last_stats, packed
 

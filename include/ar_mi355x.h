@@ -94,11 +94,14 @@ int ar_qdq_int_bwd_sgd(const void* dWq, const void* W, float* V, const void* wmi
  *           (:789-803) up to the gradient w.r.t. the block output.
  * dpred (act dtype) = ((2/n) * (pred-ref)) * grad_scale ; *loss_out = mean((pred-ref)^2) ;
  * if loss_accum != NULL: *loss_accum += mean * accum_scale  (the loop's `total_loss += loss.item()/num_elm`
- * without the host sync).  workspace: >= ar_mse_workspace_bytes() bytes of device scratch. */
+ * without the host sync).  workspace: >= ar_mse_workspace_bytes() bytes of device scratch.
+ * token_mask (optional, uint8 [n / row_len]): the valid-token loss mask of the reference (positions whose token id was
+ * marked -100 by the calibrator: pads and the last token of every sample; quantization/base.py:257-280,
+ * sign_round/quantizer.py:142-151): masked rows contribute 0 to the (still n-normalised) mean and get a zero gradient. */
 int64_t ar_mse_workspace_bytes(void);
 int ar_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpred, float* loss_out, float* loss_accum,
-                        float accum_scale, int64_t n, int act_dt, float grad_scale, void* workspace,
-                        ar_stream_t stream);
+                        float accum_scale, int64_t n, int act_dt, float grad_scale, const uint8_t* token_mask,
+                        int64_t row_len, void* workspace, ar_stream_t stream);
 
 /* ---- best-loss bookkeeping on the device ---------------------------------------------------------------------
  * replaces: `if total_loss < best_loss: best_loss = total_loss; last_best_iter = i` (sign_round/quantizer.py:508-517)

@@ -349,10 +349,13 @@ void oracle_sign_sgd(float* p, const float* g, int64_t n, float lr) {
  * loss is accumulated in double here (order-free value).
  * ---------------------------------------------------------------------------------------- */
 void oracle_mse_fwd_bwd(const void* pred, const void* ref, int64_t n, int act_dt, float gout,
-                        float* loss_out, void* dpred) {
+                        float* loss_out, void* dpred, const uint8_t* token_mask, int64_t row_len) {
+    /* token_mask (optional): the valid-token mask of sign_round/quantizer.py:142-151 -- loss_func((pred*m).float(),
+     * (ref*m).float()): masked rows add 0 to the n-normalised mean and receive a zero gradient. */
     double acc = 0.0;
     const float alpha = (float)(2.0 / (double)n);
     for (int64_t i = 0; i < n; ++i) {
+        if (token_mask && !token_mask[i / row_len]) { if (dpred) store_from_f32(dpred, i, act_dt, 0.f); continue; }
         float p = load_as_f32(pred, i, act_dt), r = load_as_f32(ref, i, act_dt);
         float d = p - r;
         acc += (double)(d * d);

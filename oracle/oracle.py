@@ -127,11 +127,13 @@ def sign_sgd(p: np.ndarray, g: np.ndarray, lr: float) -> np.ndarray:
     return p
 
 
-def mse_fwd_bwd(pred, ref, act_dt=DT_BF16, gout=1000.0):
+def mse_fwd_bwd(pred, ref, act_dt=DT_BF16, gout=1000.0, token_mask=None, row_len=0):
     n = pred.size
     loss = np.zeros(1, dtype=np.float32)
     dpred = np.empty(n, dtype=np_dtype(act_dt))
-    lib().oracle_mse_fwd_bwd(_p(pred), _p(ref), ctypes.c_int64(n), act_dt, _f(gout), _p(loss), _p(dpred))
+    tm = None if token_mask is None else np.ascontiguousarray(token_mask, dtype=np.uint8)
+    lib().oracle_mse_fwd_bwd(_p(pred), _p(ref), ctypes.c_int64(n), act_dt, _f(gout), _p(loss), _p(dpred), _p(tm),
+                             ctypes.c_int64(row_len))
     return float(loss[0]), dpred
 
 

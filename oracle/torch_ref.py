@@ -279,7 +279,7 @@ class Sampler:
 
 def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others: dict, *, iters=200, batch_size=8,
                lr=None, enable_minmax_tuning=True, amp_dtype=torch.bfloat16, forward=None, record=None,
-               max_iters_to_run=None):
+               max_iters_to_run=None, input_ids=None):
     """The reference's quantize_block loop in plain torch.  inputs/targets: [N, S, H].  Returns best_params and
     leaves the block unwrapped with baked weights.  `forward(block, x, others)` defaults to block(x, **others)[0]."""
     names = wrap_block(block, enable_minmax_tuning)
@@ -293,6 +293,12 @@ def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others:
     mse = torch.nn.MSELoss()
     losses = []
     run = iters if max_iters_to_run is None else min(iters, max_iters_to_run)
+    vmask = None
+    if input_ids is not None:   # valid-token mask: ids == -100 are excluded (quantization/base.py:257-280)
+        ids = input_ids if isinstance(input_ids, torch.Tensor) else torch.cat([t.reshape(1, -1) for t in input_ids], 0)
+        vm = (ids.reshape(inputs.shape[0], -1) != -100).to(torch.long)
+        if not bool(vm.all()):
+            vmask = vm.to(inputs.device)
     for i in range(run):
         idx = sampler.next_batch()
         x = inputs[idx]
@@ -301,8 +307,13 @@ def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others:
             out = forward(block, x, input_others) if forward else block(x, **input_others)
             if isinstance(out, (tuple, list)):
                 out = out[0]
-        loss = mse(out.to(torch.float32), ref.to(torch.float32))
-        total = loss.item()
+        if vmask is not None:
+            m = vmask[idx].unsqueeze(-1)
+            loss = mse((out * m).to(torch.float32), (ref * m).to(torch.float32))
+            total = loss.item() / max(1, int(torch.count_nonzero(vmask[idx]).item()))
+        else:
+            loss = mse(out.to(torch.float32), ref.to(torch.float32))
+            total = loss.item()
         (loss * 1000).backward()
         losses.append(total)
         if total < best_loss:

@@ -303,8 +303,21 @@ def gen_mse():
     ref = (pred.detach().float() + 0.05 * torch.randn(2, 16, 64, generator=g)).to(torch.bfloat16)
     loss = torch.nn.MSELoss()(pred.to(torch.float32), ref.to(torch.float32))
     (loss * 1000).backward()
-    np.savez_compressed(os.path.join(HERE, "mse.npz"), pred=bits(pred), ref=bits(ref), loss=np.float32(loss.item()),
-                        dpred=bits(pred.grad))
+    rec = dict(pred=bits(pred), ref=bits(ref), loss=np.float32(loss.item()), dpred=bits(pred.grad))
+    # the same through the reference's own masked loss (SignRoundQuantizer._get_loss with a valid-token mask)
+    from types import SimpleNamespace
+
+    from auto_round.algorithms.quantization.sign_round.quantizer import SignRoundQuantizer as RefQ
+
+    fake = SimpleNamespace(model_context=SimpleNamespace(amp=True, amp_dtype=torch.bfloat16))
+    mask = [torch.ones(1, 16, dtype=torch.long), torch.ones(1, 16, dtype=torch.long)]
+    mask[0][0, -1] = 0; mask[1][0, -1] = 0; mask[1][0, 3:6] = 0
+    pred2 = pred.detach().clone().requires_grad_(True)
+    loss2 = RefQ._get_loss(fake, pred2, ref, [0, 1], torch.nn.MSELoss(), "cpu", mask)
+    (loss2 * 1000).backward()
+    rec.update(mask=torch.cat(mask).reshape(-1).numpy().astype(np.uint8), loss_masked=np.float32(loss2.item()),
+               dpred_masked=bits(pred2.grad))
+    np.savez_compressed(os.path.join(HERE, "mse.npz"), **rec)
     print("mse ok")
 
 

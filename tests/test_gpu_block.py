@@ -271,3 +271,35 @@ def test_padded_and_per_channel_groups_vs_torch_ref(gs, bits, sym):
         assert tuple(best_m[n]["value"].shape) == tuple(best_o[n]["value"].shape)
         agree.append((lm[n].weight == lo[n].weight).float().mean().item())
     assert np.mean(agree) > 0.97, agree
+
+
+def test_valid_token_mask_matches_torch_ref():
+    """input_ids with -100 at the last position of every sample (what the reference's calibrator always produces) and a
+    few padded positions: the masked loss / gradient path vs the torch restatement."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from oracle import torch_ref as tr
+
+    layer, rope, cfg = make_layer("llama", 4, 32, True, seed=12)
+    X, others = make_data(rope, cfg)
+    Y = targets(layer, X, others)
+    ids = torch.randint(0, 100, (X.shape[0], X.shape[1]))
+    ids[:, -1] = -100
+    ids[3, -5:] = -100
+    id_list = list(torch.split(ids, 1, dim=0))
+    iters, bs = 3, 4
+    blk_o = copy.deepcopy(layer)
+    random.seed(4)
+    best_o, info = tr.tune_block(blk_o, X, Y, others, iters=iters, batch_size=bs, forward=fwd, input_ids=id_list)
+    blk_m = copy.deepcopy(layer)
+    random.seed(4)
+    q = SignRoundQuantizer(SignRoundConfig(iters=iters, batch_size=bs, bits=4), device="cuda")
+    best_m = q.quantize_block(blk_m, X, others, Y, None, None, input_ids=id_list)
+    st = q.last_stats
+    assert abs(st["init_loss"] - info["losses"][0]) <= 2e-3 * info["losses"][0], (st, info["losses"])
+    # and the mask really changes the loss normalisation compared to the unmasked path
+    blk_u = copy.deepcopy(layer)
+    random.seed(4)
+    q.quantize_block(blk_u, X, others, Y, None, None)
+    assert q.last_stats["init_loss"] > 10 * st["init_loss"]
+    agree = [(a.weight == b.weight).float().mean().item() for a, b in zip(linears(blk_o).values(), linears(blk_m).values())]
+    assert np.mean(agree) > 0.97, agree
