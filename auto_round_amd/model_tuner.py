@@ -1,0 +1,54 @@
+"""The caller of the hot path, for standalone use: the per-block driver loop of the reference's orchestrator
+(`CompressionOrchestrator._quantize_blocks`, auto_round/compressors/orchestrator.py:176-388) reduced to what the path
+needs -- walk the decoder blocks in order, tune each one, hand its outputs to the next:
+
+    for block k:  fp_out, q_out, best = quantizer.compress_block(block_k, fp_in, input_others, q_in)
+                  [pack immediately]                                      (orchestrator.py:327-337, immediate_pack)
+                  fp_in <- fp_out ;  q_in <- q_out   (enable_quanted_input, composer.py:460,476-481)
+
+Model loading, calibration-data capture and checkpoint writing stay with the reference.
+`tune_blocks_sharded` is the multi-GPU form (blocks independent on the fp chain, see sharding.py)."""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from .export import pack_block
+from .quantizer import BlockContext, SignRoundQuantizer, stack_samples
+
+
+def tune_blocks(blocks: Sequence[torch.nn.Module], block0_inputs, input_others: dict, quantizer: SignRoundQuantizer,
+                input_ids=None, pack: bool = False, block_names: Optional[List[str]] = None,
+                on_block_done: Optional[Callable] = None) -> List[Dict]:
+    """Sequentially tune `blocks` (already on the quantizer's device, or movable to it).  Returns one record per block:
+    {"name", "stats", "best_params", "packed" (if pack)}.  Weights are baked in place like the reference does."""
+    device = quantizer.device
+    fp_in = stack_samples(block0_inputs, device)
+    q_in = None
+    out = []
+    n = len(blocks)
+    for k, block in enumerate(blocks):
+        block.to(device)
+        ctx = BlockContext(block_index=k, block_cnt=n, block_name=(block_names[k] if block_names else str(k)))
+        fp_out, q_out, best = quantizer.compress_block(block, fp_in, input_others, q_in, ctx, input_ids=input_ids)
+        rec = {"name": ctx.block_name, "stats": dict(quantizer.last_stats), "best_params": best}
+        if pack:
+            rec["packed"] = pack_block(block)
+        out.append(rec)
+        if on_block_done is not None:
+            on_block_done(k, block, rec)
+        fp_in = fp_out
+        q_in = q_out if quantizer.config.enable_quanted_input else None
+    return out
+
+
+def tune_blocks_sharded(blocks, block0_inputs, input_others, quantizer, seed: int = 42, policy: str = "round_robin",
+                        group=None):
+    """Multi-GPU form: requires enable_quanted_input=False (blocks are only independent on the fp chain)."""
+    from . import sharding
+
+    if quantizer.config.enable_quanted_input:
+        raise ValueError("block sharding needs enable_quanted_input=False: with quantised-input chaining block k+1 "
+                         "depends on the tuned block k (SURVEY 8e) -- run replicas instead")
+    return sharding.tune_sharded(blocks, block0_inputs, input_others, quantizer, seed=seed, policy=policy, group=group)

@@ -303,3 +303,47 @@ def test_valid_token_mask_matches_torch_ref():
     assert q.last_stats["init_loss"] > 10 * st["init_loss"]
     agree = [(a.weight == b.weight).float().mean().item() for a, b in zip(linears(blk_o).values(), linears(blk_m).values())]
     assert np.mean(agree) > 0.97, agree
+
+
+def test_three_block_stack_with_quantised_input_chaining():
+    """The per-block driver loop (orchestrator._quantize_blocks): block k+1 is tuned on the QUANTISED output of block k
+    against the fp chain; compared with the same loop built from the torch restatement."""
+    from auto_round_amd.model_tuner import tune_blocks
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from oracle import torch_ref as tr
+
+    layers = []
+    rope = cfg = None
+    for k in range(3):
+        layer, rope, cfg = make_layer("llama", 4, 32, True, seed=20 + k)
+        layers.append(layer)
+    X, others = make_data(rope, cfg, N=8)
+    iters, bs = 3, 4
+    # oracle loop
+    ref_blocks = [copy.deepcopy(l) for l in layers]
+    random.seed(9)
+    fp_in, q_in, ref_losses = X, None, []
+    for blk in ref_blocks:
+        fp_out = targets(blk, fp_in, others, bs)
+        _, info = tr.tune_block(blk, q_in if q_in is not None else fp_in, fp_out, others, iters=iters, batch_size=bs, forward=fwd)
+        ref_losses.append(info["losses"][0])
+        q_in = targets(blk, q_in if q_in is not None else fp_in, others, bs)
+        fp_in = fp_out
+    # product loop
+    my_blocks = [copy.deepcopy(l) for l in layers]
+    random.seed(9)
+    q = SignRoundQuantizer(SignRoundConfig(iters=iters, batch_size=bs, bits=4), device="cuda")
+    recs = tune_blocks(my_blocks, X, others, q, pack=True)
+    assert len(recs) == 3 and all("packed" in r and len(r["packed"]) == 7 for r in recs)
+    for r, l0 in zip(recs, ref_losses):
+        assert abs(r["stats"]["init_loss"] - l0) <= 2e-2 * l0, (r["stats"], l0)   # later blocks see slightly different q inputs
+    agree = []
+    for a, b in zip(ref_blocks, my_blocks):
+        for (n1, m1), (n2, m2) in zip(linears(a).items(), linears(b).items()):
+            agree.append((m1.weight == m2.weight).float().mean().item())
+    assert np.mean(agree) > 0.95, agree
+    # packed buffers of the first block have the GPTQ shapes
+    pk = recs[0]["packed"]["self_attn.q_proj"]
+    assert pk.qweight.shape == (256 // 32 * 4, 256) and pk.qweight.dtype == torch.int32
+    assert pk.scales.shape == (256 // 32, 256) and pk.qzeros.shape == (256 // 32, 256 // 32 * 4)
+    assert bool((pk.qzeros.view(torch.int32) == 0x77777777).all())
