@@ -117,8 +117,13 @@ def pack_layer(layer: torch.nn.Linear, backend: str = "auto_round:auto_gptq", de
     """reference: export/export_to_autoround/export.py:143-239 for one already-unwrapped layer carrying
     `scale` / `zp`.  Returns the packed QuantLinear (does not splice it into a model)."""
     bits, gs, sym = int(layer.bits), int(layer.group_size), bool(layer.sym)
-    QL = dynamic_import_quant_linear_for_packing(backend, bits, gs, sym)
     out_f, in_f = layer.weight.shape
+    dt = str(getattr(layer, "data_type", "int"))
+    if dt.startswith("mx_fp") or dt.startswith("nv_fp"):      # export_to_nvfp_mx.pack_layer -> qlinear_fp.QuantLinear.pack
+        ql = QuantLinearFP4(bits, gs, in_f, out_f, bias=layer.bias is not None, data_type=dt)
+        ql.pack(layer, layer.scale, global_scale=getattr(layer, "weight_global_scale", None), device=device)
+        return ql
+    QL = dynamic_import_quant_linear_for_packing(backend, bits, gs, sym)
     ql = QL(bits, gs, in_f, out_f, bias=layer.bias is not None, weight_dtype=layer.weight.dtype)
     zp = layer.zp
     if sym and isinstance(zp, torch.Tensor) and QL is QuantLinearPlain:

@@ -30,7 +30,7 @@ import torch
 
 from . import ops
 from .sign_sgd import SignSGD
-from .wrapper import WrapperLinear, unwrapper_block, wrapper_block
+from .wrapper import WrapperLinear, unwrapper_block, update_block_global_scale_if_needed, wrapper_block
 
 FLT_MAX = float(torch.finfo(torch.float32).max)
 
@@ -385,6 +385,7 @@ class SignRoundQuantizer:
         the next block's quantised input.  -> (fp_outputs [N,S,H], q_outputs [N,S,H] or None, best_params)"""
         device = self.device
         X = stack_samples(fp_inputs, device)
+        update_block_global_scale_if_needed(block)      # composer.py:438-451 (NVFP4 only; no-op otherwise)
         fp_out = self.forward_all(block, X, input_others)
         Xq = stack_samples(q_inputs, device) if (q_inputs is not None and self.config.enable_quanted_input) else None
         best = self.quantize_block(block, X, input_others, fp_out, Xq, block_ctx, input_ids=input_ids)

@@ -231,6 +231,11 @@ class BlockArena:
         """K2+K3 (+ snapshot + next K1) for every layer of the block in one launch; consumes self.dWq."""
         if snapshot_flag is not None:
             self.alloc_best()
+        # a layer whose forward did not run this iteration (e.g. a MoE expert that received no token) has no gradient:
+        # the reference's SignSGD skips parameters with grad None; here a zero dWq slice makes every sign step 0
+        for lyr in self.layers:
+            if not lyr._dw_accum[0]:
+                lyr.weight_grad.zero_()
         if self.kind != "int":
             layers = [None] if self.kind == "mx" else self.layers
             for l in layers:
@@ -440,6 +445,32 @@ class WrapperLinear(torch.nn.Module):
         if self.enable_act_quant:
             return WrapperWALayer(self.orig_layer)
         return self.orig_layer
+
+
+def update_block_global_scale_if_needed(block) -> None:
+    """NVFP4: give every nv_fp layer a `weight_global_scale` = 448*6/amax(W) and unify it (minimum) across q/k/v, across
+    gate/up and across a MoE expert's w1/w3, as the reference does before tuning a block so that fused inference kernels
+    can share one scale (data_type/utils.py:433-530; AR_NVFP4_FUSED_LAYER_GLOBAL_SCALE=0 disables the unification)."""
+    import os
+
+    nv = [m for m in block.modules() if _quantizable(m) and check_to_quantized(m) and is_nv_fp(str(getattr(m, "data_type", "")))]
+    if not nv:
+        return
+    for m in nv:
+        if not hasattr(m, "weight_global_scale"):
+            amax = m.weight.detach().to(torch.float32).abs().max()
+            m.weight_global_scale = torch.where(amax == 0, torch.zeros_like(amax), (448.0 * 6.0) * (1.0 / amax))
+    if os.environ.get("AR_NVFP4_FUSED_LAYER_GLOBAL_SCALE", "1") in ("0", "false", "False"):
+        return
+    for mod in block.modules():
+        for names in (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"), ("w1", "w3")):
+            if all(hasattr(mod, n) for n in names):
+                members = [getattr(mod, n) for n in names if hasattr(getattr(mod, n), "weight_global_scale")]
+                if members:
+                    g = torch.min(torch.stack([x.weight_global_scale.reshape(1).to(members[0].weight.device) for x in members]), dim=0).values
+                    for x in members:
+                        x.weight_global_scale = g.clone()
+                break
 
 
 def _quantizable(m) -> bool:

@@ -42,12 +42,27 @@ WORKLOADS = {
                        desc="Llama-3-70B decoder block, W4 group_size=128 sym (configs[3], one block per step)"),
     "opt-125m": dict(hidden=768, ffn=3072, heads=12, kv=12, family="opt",
                      desc="OPT-125M decoder block, W4 group_size=128 sym (BASELINE.json configs[0])"),
+    "mixtral-8x7b": dict(hidden=4096, ffn=14336, heads=32, kv=8, family="moe", experts=8, top_k=2,
+                         desc="Mixtral-8x7B-shaped sparse-MoE decoder block (8 experts, top-2, experts as nn.Linear "
+                              "w1/w2/w3 as after the reference's fused-MoE unfusing; BASELINE.json configs[4])"),
 }
+SCHEMES = ("W4A16", "W2A16G32", "MXFP4", "NVFP4", "MXFP4_W", "NVFP4_W")
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def build_block(w, bits, gs, sym, device, seed, attn="sdpa"):
+def build_block(w, bits, gs, sym, device, seed, attn="sdpa", scheme=None):
     torch.manual_seed(seed)
+    if w["family"] == "moe":
+        from auto_round_amd.testing.moe import build_moe_decoder_layer, set_scheme
+
+        layer, rope, cfg = build_moe_decoder_layer(w["hidden"], w["ffn"], w["heads"], w["kv"], w["experts"], w["top_k"],
+                                                   device=device, attn=attn, seed=seed)
+        n_w = set_scheme(layer, scheme or "W4A16")
+        if scheme is None:
+            for m in layer.modules():
+                if isinstance(m, torch.nn.Linear) and getattr(m, "bits", 16) < 16:
+                    m.bits, m.group_size, m.sym = bits, gs, sym
+        return layer, rope, cfg, n_w
     if w["family"] == "llama":
         from transformers import LlamaConfig
         from transformers.models.llama.modeling_llama import LlamaDecoderLayer, LlamaRotaryEmbedding
@@ -77,6 +92,10 @@ def build_block(w, bits, gs, sym, device, seed, attn="sdpa"):
         if isinstance(m, torch.nn.Linear):
             m.bits, m.group_size, m.sym, m.data_type, m.scale_dtype, m.act_bits = bits, gs, sym, "int", torch.float16, 16
             n_w += m.weight.numel()
+    if scheme is not None:
+        from auto_round_amd.testing.moe import set_scheme
+
+        n_w = set_scheme(layer, scheme)
     return layer, rope, cfg, n_w
 
 
@@ -174,6 +193,8 @@ def main():
     ap.add_argument("--bits", type=int, default=4)
     ap.add_argument("--group-size", type=int, default=128)
     ap.add_argument("--asym", action="store_true")
+    ap.add_argument("--scheme", default=None, choices=SCHEMES,
+                    help="reference scheme preset (overrides --bits/--group-size/--asym); MXFP4/NVFP4 include 4-bit activations")
     ap.add_argument("--fuse-next-forward", action="store_true",
                     help="emit the next iteration's Wq from the fused backward kernel (K1 then runs once per block)")
     ap.add_argument("--sdpa", default="efficient", choices=["auto", "efficient", "flash", "math"],
@@ -224,7 +245,12 @@ def main():
         from auto_round_amd.attention import register_mi355x_sdpa
 
         attn = register_mi355x_sdpa()
-    layer, rope, cfg, n_w = build_block(w, args.bits, args.group_size, sym, device, seed=1234 + rank, attn=attn)
+    layer, rope, cfg, n_w = build_block(w, args.bits, args.group_size, sym, device, seed=1234 + rank, attn=attn,
+                                        scheme=args.scheme)
+    fp4 = args.scheme is not None and args.scheme.startswith(("MXFP4", "NVFP4"))
+    if args.scheme is not None:
+        some = next(m for m in layer.modules() if isinstance(m, torch.nn.Linear) and getattr(m, "bits", 16) < 16)
+        args.bits, args.group_size, sym = int(some.bits), int(some.group_size), bool(some.sym)
     master = {n: p.detach().clone() for n, p in layer.named_parameters()}
     S, H, N = args.seqlen, w["hidden"], args.nsamples
     X = torch.empty(N, S, H, dtype=torch.bfloat16, device=device)
@@ -241,6 +267,11 @@ def main():
     if not args.no_kernel_timing:
         ops.qdq_int_fwd = timer.wrap("k_int_fwd", ops.qdq_int_fwd)
         ops.qdq_int_bwd_sgd_ = timer.wrap("k_int_bwd_sgd", ops.qdq_int_bwd_sgd_)
+        ops.qdq_fp4_bwd_sgd_ = timer.wrap("k_fp4_bwd_sgd", ops.qdq_fp4_bwd_sgd_)
+        _fp4_fwd = ops.qdq_fp4_fwd
+        _timed_w = timer.wrap("k_fp4_fwd", _fp4_fwd)
+        # weight launches pass absmax; activation fake-quant launches (absmax=None) are not the roofline kernel
+        ops.qdq_fp4_fwd = lambda X_, V_, absmax_, *a_, **k_: (_timed_w if absmax_ is not None else _fp4_fwd)(X_, V_, absmax_, *a_, **k_)
 
     qcfg = SignRoundConfig(iters=args.iters, batch_size=args.batch_size, bits=args.bits,
                            fuse_next_forward=args.fuse_next_forward, sdpa_backend=args.sdpa)
@@ -296,29 +327,41 @@ def main():
             "dtype_detail": "bf16 weights/activations and MFMA GEMMs (fp32 accumulate); fp32 rounding offsets V and min/max "
                             "scales; fp16 quant scales; int4 packed output",
             "data": "synthetic: random-init weights of the named architecture, N(0,1) bf16 hidden states",
-            "config": {"workload": w["desc"], "bits": args.bits, "group_size": args.group_size, "sym": sym,
+            "config": {"workload": w["desc"], "scheme": args.scheme or "int", "bits": args.bits, "group_size": args.group_size, "sym": sym,
                        "iters": args.iters, "nsamples": N, "seqlen": S, "batch_size": args.batch_size,
                        "weights_per_block": n_w, "groups_per_block": G, "includes_packing": True,
                        "fuse_next_forward": bool(args.fuse_next_forward), "sdpa_backend": args.sdpa, "parallelism": f"block-sharded x{world}"},
             "ms_per_iter": 1000.0 * elapsed / args.steps / max(args.iters, 1),
             "loss": {"init": stats["init_loss"], "best": stats["best_loss"], "best_iter": stats["best_iter"]},
         }
-        ms, cnt = timer.mean_ms("k_int_fwd")
+        if fp4:
+            fname, bname, per_g_f, per_g_b = "k_fp4_fwd", "k_fp4_bwd_sgd", 8, 8
+        else:
+            fname, bname, per_g_f, per_g_b = "k_int_fwd", "k_int_bwd_sgd", 12, 8
+        ms, cnt = timer.mean_ms(fname)
         # only block-wide launches count (the per-layer unwrap calls are smaller): filter by duration is fragile,
         # so the block-wide figure is taken from the launches made by the arena (count = iters per step)
         if ms is not None:
-            fwd_ms = timer_block_mean(timer, "k_int_fwd", n_w)
-            abytes = 8 * n_w + 12 * G
-            out["roofline"] = {"kernel": "k_int_fwd (INT fake-quant forward, whole block per launch)", "bound": "hbm",
+            fwd_ms = timer_block_mean(timer, fname, n_w)
+            abytes = 8 * n_w + per_g_f * G
+            if fp4 and args.scheme.startswith("NVFP4"):   # NVFP4 launches per layer (own global scale): use the byte-weighted mean
+                tot = sum(s.elapsed_time(e) for s, e in timer.pairs[fname])
+                launches_per_block = 4 + 3 * w.get("experts", 0) if w["family"] == "moe" else 7
+                fwd_ms = tot / (len(timer.pairs[fname]) / launches_per_block)
+            out["roofline"] = {"kernel": fname + (" (fp4 weight fake-quant forward)" if fp4 else
+                                                   " (INT fake-quant forward, whole block per launch)"), "bound": "hbm",
                                "achieved": abytes / fwd_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": abytes / fwd_ms / 1e6 / HBM_PEAK_GBPS, "traffic": read_traffic("k_int_fwd", abytes),
+                               "frac": abytes / fwd_ms / 1e6 / HBM_PEAK_GBPS, "traffic": read_traffic(fname, abytes),
                                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": fwd_ms}
-        ms2, cnt2 = timer.mean_ms("k_int_bwd_sgd")
+        ms2, cnt2 = timer.mean_ms(bname)
         if ms2 is not None:
-            per = 12 + (2 if args.fuse_next_forward else 0)
-            abytes = per * n_w + 8 * G
-            out["roofline_bwd_sgd"] = {"kernel": "k_int_bwd (fused qdq backward + sign-SGD" +
-                                       (" + next forward)" if args.fuse_next_forward else ")"), "bound": "hbm",
+            per = 12 + (2 if (args.fuse_next_forward and not fp4) else 0)
+            abytes = per * n_w + per_g_b * G
+            if fp4 and args.scheme.startswith("NVFP4"):
+                launches_per_block = 4 + 3 * w.get("experts", 0) if w["family"] == "moe" else 7
+                ms2 = ms2 * launches_per_block
+            out["roofline_bwd_sgd"] = {"kernel": ("k_fp4_bwd" if fp4 else "k_int_bwd") + " (fused qdq backward + sign-SGD" +
+                                       (" + next forward)" if (args.fuse_next_forward and not fp4) else ")"), "bound": "hbm",
                                        "achieved": abytes / ms2 / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": abytes / ms2 / 1e6 / HBM_PEAK_GBPS,
                                        "traffic": read_traffic("k_int_bwd_with_next_fwd" if args.fuse_next_forward else "k_int_bwd", abytes),
