@@ -11,13 +11,14 @@ namespace ar {
 // (auto_round/data_type/mxfp.py:49-85).  floor(log2|t|) clipped at 0 is 0/1/2 by comparison (exact in this range).
 __device__ __forceinline__ float mx_e2m1(float t) {
     const float a0 = fabsf(t);
-    const float pscale = (a0 >= 4.f) ? 4.f : ((a0 >= 2.f) ? 2.f : 1.f);   // 2^private_exp
-    const float x = t / pscale * 2.0f;
+    // 2^private_exp in {1,2,4}: t / 2^pe * 2 and v / 2 * 2^pe are exact power-of-two scalings -> multiplications
+    const float up = (a0 >= 4.f) ? 0.5f : ((a0 >= 2.f) ? 1.0f : 2.0f);    // 2 / 2^pe
+    const float dn = (a0 >= 4.f) ? 2.0f : ((a0 >= 2.f) ? 1.0f : 0.5f);    // 2^pe / 2
+    const float x = t * up;
     const float a = fabsf(x);
-    const float h = a - 0.5f;
-    const float mask = (h == 2.0f * floorf(h * 0.5f)) ? 1.f : 0.f;        // (a - 0.5) % 2 == 0
-    float v = sgnf(x) * (floorf(a + 0.5f) - mask);
-    v = v / 2.0f * pscale;
+    // (a - 0.5) % 2 == 0  <=>  a in {0.5, 2.5, 4.5, ...}  <=>  fract(a/2) == 0.25   (a <= 12 here)
+    const float mask = (__builtin_amdgcn_fractf(a * 0.5f) == 0.25f) ? 1.f : 0.f;
+    const float v = sgnf(x) * (floorf(a + 0.5f) - mask) * dn;
     return clamp3(v, -6.f, 6.f);
 }
 // literal restatement of nvfp.cast_to_fp4 (auto_round/data_type/nvfp.py:26-39)
@@ -72,7 +73,7 @@ __device__ __forceinline__ void fp4_group_scale(int mode, float amax, float Ms, 
         se = clamp3(floorf(se) - 2.0f, -127.f, 127.f);
         sc = ldexpf(1.0f, (int)se);
         aux = se;
-        rsc = sc;
+        rsc = ldexpf(1.0f, -(int)se);      // 1/sc, exact: x / 2^e == x * 2^-e bit for bit (also for subnormal results)
     } else {
         const float vm = amax * (Ms * init_scale);
         float s = gscale * (vm * (float)(1.0 / 6.0));
@@ -84,54 +85,82 @@ __device__ __forceinline__ void fp4_group_scale(int mode, float amax, float Ms, 
     }
 }
 
-template <int XDT>
+#ifndef AR_FP4_FWD_UNROLL
+#define AR_FP4_FWD_UNROLL 4
+#endif
+#ifndef AR_FP4_BWD_UNROLL
+#define AR_FP4_BWD_UNROLL 2
+#endif
+
+template <int XDT, int U>
 __global__ __launch_bounds__(kTPB) void k_fp4_fwd(const Fp4Args a) {
     const int cpg = a.cpg;
     const int64_t total_chunks = a.n_groups * cpg;
-    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    const int64_t stride = (int64_t)gridDim.x * kTPB * U;
     const float gscale = (a.mode == 1 && a.gscale) ? *a.gscale : 1.0f;
-    // total_chunks is padded up to a multiple of the wave so that every lane of a lane-group joins the butterfly
+    // the chunk range is padded up to a multiple of the wave so that every lane of a lane-group joins the butterfly
     const int64_t limit = (total_chunks + kWave - 1) / kWave * kWave;
-    for (int64_t c = (int64_t)blockIdx.x * kTPB + threadIdx.x; c < limit; c += stride) {
-        const bool ok = c < total_chunks;
-        const int64_t g = c / cpg;
-        float x[8], v[8], o[8];
-        float amax = 0.f;
-        if (ok) {
-            unpack8<XDT>(load8_raw<XDT>(a.X, c * kEPT), x);
-            if (a.V) unpack_f8(load8_f32(a.V, c * kEPT), v);
-            else {
+    for (int64_t c0 = (int64_t)blockIdx.x * kTPB * U + threadIdx.x; c0 < limit; c0 += stride) {
+        Raw8<XDT> xr[U];
+        F8 vr[U];
+        float am[U], msr[U];
+        bool ok[U];
+        // all streaming loads of this lane are issued before anything waits on them
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = 0.f;
-            }
-            if (a.absmax) amax = a.absmax[g];
-            else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(x[k]));
-            }
-        }
-        if (!a.absmax) amax = lanes_max(amax, cpg);
-        if (!ok) continue;
-        const float Ms = a.max_s ? clamp3(a.max_s[g], a.lo, a.hi) : 1.0f;
-        float sc, aux, rsc;
-        fp4_group_scale(a.mode, amax, Ms, a.init_scale, gscale, sc, aux, rsc);
-        if (a.mode == 0) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float t = clamp3(x[k] / sc + v[k], -6.f, 6.f);
-                o[k] = mx_e2m1(t) * sc;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float t = clamp3(x[k] * sc + v[k], -6.f, 6.f);
-                o[k] = nv_e2m1(t) * rsc;
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = c0 + (int64_t)u * kTPB;
+            ok[u] = c < total_chunks;
+            am[u] = 0.f; msr[u] = 1.f;
+            if (ok[u]) {
+                xr[u] = load8_raw<XDT>(a.X, c * kEPT);
+                if (a.V) vr[u] = load8_f32(a.V, c * kEPT);
+                const int64_t g = c / cpg;
+                if (a.absmax) am[u] = a.absmax[g];
+                if (a.max_s) msr[u] = a.max_s[g];
             }
         }
-        store8<XDT>(a.Xq, c * kEPT, o);
-        if (a.scale_out && (c % cpg) == 0) {
-            if (a.mode == 0) store1<XDT>(a.scale_out, g, aux);
-            else ((float*)a.scale_out)[g] = aux;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = c0 + (int64_t)u * kTPB;
+            if (c >= limit) break;          // wave-uniform (limit is a multiple of the wave)
+            float x[8], v[8], o[8];
+            float amax = am[u];
+            if (ok[u]) {
+                unpack8<XDT>(xr[u], x);
+                if (a.V) unpack_f8(vr[u], v);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+                }
+                if (!a.absmax) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(x[k]));
+                }
+            }
+            if (!a.absmax) amax = lanes_max(amax, cpg);
+            if (!ok[u]) continue;
+            const int64_t g = c / cpg;
+            const float Ms = a.max_s ? clamp3(msr[u], a.lo, a.hi) : 1.0f;
+            float sc, aux, rsc;
+            fp4_group_scale(a.mode, amax, Ms, a.init_scale, gscale, sc, aux, rsc);
+            if (a.mode == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float t = clamp3(x[k] * rsc + v[k], -6.f, 6.f);    // == x / sc (power-of-two scale)
+                    o[k] = mx_e2m1(t) * sc;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float t = clamp3(x[k] * sc + v[k], -6.f, 6.f);
+                    o[k] = nv_e2m1(t) * rsc;
+                }
+            }
+            store8<XDT>(a.Xq, c * kEPT, o);
+            if (a.scale_out && (c % cpg) == 0) {
+                if (a.mode == 0) store1<XDT>(a.scale_out, g, aux);
+                else ((float*)a.scale_out)[g] = aux;
+            }
         }
     }
 }
@@ -198,8 +227,8 @@ __global__ __launch_bounds__(kTPB) void k_pack_fp4(const void* __restrict__ W, c
 using namespace ar;
 
 static inline int fp4_grid(int64_t chunks) {
-    int64_t b = (chunks + kTPB - 1) / kTPB;
-    return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+    int64_t b = (chunks + kTPB - 1) / kTPB;   // one pass per workgroup (measured >= capped grid-stride for these streams)
+    return (int)(b < 1 ? 1 : (b > (1 << 24) ? (1 << 24) : b));
 }
 
 extern "C" int ar_qdq_fp4_fwd(const void* X, const float* V, const float* absmax, const float* max_s, float init_scale,
@@ -211,12 +240,12 @@ extern "C" int ar_qdq_fp4_fwd(const void* X, const float* V, const float* absmax
     Fp4Args a;
     a.X = X; a.V = V; a.absmax = absmax; a.max_s = max_s; a.gscale = global_scale_dev; a.Xq = Xq; a.scale_out = scale_out;
     a.n_groups = n_groups; a.cpg = gs / kEPT; a.mode = mode; a.init_scale = init_scale; a.lo = lo_bound; a.hi = hi_bound;
-    const int grid = fp4_grid(n_groups * a.cpg);
+    const int grid = fp4_grid((n_groups * a.cpg + AR_FP4_FWD_UNROLL - 1) / AR_FP4_FWD_UNROLL);
     hipStream_t st = (hipStream_t)stream;
     switch (x_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL(k_fp4_fwd<AR_DT_BF16>, grid, kTPB, 0, st, a); break;
-        case AR_DT_F16: hipLaunchKernelGGL(k_fp4_fwd<AR_DT_F16>, grid, kTPB, 0, st, a); break;
-        case AR_DT_F32: hipLaunchKernelGGL(k_fp4_fwd<AR_DT_F32>, grid, kTPB, 0, st, a); break;
+        case AR_DT_BF16: hipLaunchKernelGGL((k_fp4_fwd<AR_DT_BF16, AR_FP4_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        case AR_DT_F16: hipLaunchKernelGGL((k_fp4_fwd<AR_DT_F16, AR_FP4_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        case AR_DT_F32: hipLaunchKernelGGL((k_fp4_fwd<AR_DT_F32, AR_FP4_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
         default: return AR_ERR_UNSUPPORTED;
     }
     return launch_status();
@@ -258,11 +287,11 @@ struct Fp4BwdArgs {
     float init_scale, lo, hi;
 };
 
-template <int XDT>
+template <int XDT, int U>
 __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
     const int cpg = a.cpg;
     const int64_t total_chunks = a.n_groups * cpg;
-    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    const int64_t stride = (int64_t)gridDim.x * kTPB * U;
     const float gscale = (a.mode == 1 && a.gscale) ? *a.gscale : 1.0f;
     const float alpha_v = a.lr_v ? -(*a.lr_v) : 0.f;
     const float alpha_mm = a.lr_mm ? -(*a.lr_mm) : 0.f;
@@ -270,86 +299,110 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
     const float LN2 = 0.6931471805599453f;
     const float r6 = (float)(1.0 / 6.0);
     const int64_t limit = (total_chunks + kWave - 1) / kWave * kWave;
-    for (int64_t c = (int64_t)blockIdx.x * kTPB + threadIdx.x; c < limit; c += stride) {
-        const bool ok = c < total_chunks;
-        const int64_t g = ok ? c / cpg : 0;
-        float s_gq = 0.f, s_dvw = 0.f;
-        float amax = 0.f, Ms_raw = 1.f, Ms = 1.f, sc = 1.f, rsc = 1.f, m = 0.f, se_un = 0.f, s_pre = 0.f, r = 0.f;
-        if (ok) {
-            float gg[8], w[8], v[8], dv[8];
-            unpack8<XDT>(load8_raw<XDT>(a.dXq, c * kEPT), gg);
-            unpack8<XDT>(load8_raw<XDT>(a.X, c * kEPT), w);
-            if (a.V) unpack_f8(load8_f32(a.V, c * kEPT), v);
-            else {
+    for (int64_t c0 = (int64_t)blockIdx.x * kTPB * U + threadIdx.x; c0 < limit; c0 += stride) {
+        Raw8<XDT> gr[U], wr[U];
+        F8 vr[U];
+        float am[U], msr[U];
+        bool okk[U];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = 0.f;
-            }
-            amax = a.absmax[g];
-            Ms_raw = a.max_s ? a.max_s[g] : 1.0f;
-            Ms = a.max_s ? clamp3(Ms_raw, a.lo, a.hi) : 1.0f;
-            if (a.mode == 0) {
-                m = amax * (a.init_scale * Ms);
-                float se = (m == 0.f) ? 1.0f : log2f(m);
-                se_un = floorf(se) - 2.0f;
-                sc = ldexpf(1.0f, (int)clamp3(se_un, -127.f, 127.f));
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float ws = w[k] / sc;
-                    const float tp = ws + v[k];
-                    const float t = clamp3(tp, -6.f, 6.f);
-                    const float q = mx_e2m1(t);
-                    const float d = (t == 0.f) ? 0.f : ((fabsf(t) < 1.0f) ? 1.0f : q / t);
-                    const bool inside = (tp >= -6.f) && (tp <= 6.f);
-                    dv[k] = inside ? (gg[k] * sc) * d : 0.f;
-                    s_gq += gg[k] * q;
-                    s_dvw += dv[k] * (ws / sc);
-                }
-            } else {
-                const float vm = amax * (Ms * a.init_scale);
-                s_pre = gscale * (vm * r6);
-                const float s = e4m3_to_f32(f32_to_e4m3(clamp3(s_pre, -448.f, 448.f)));
-                r = s * recip0(gscale);
-                sc = recip0(r);        // osc
-                rsc = recip0(sc);      // ro
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float xp = w[k] * sc + v[k];
-                    const float x = clamp3(xp, -6.f, 6.f);
-                    const float q = nv_e2m1(x);
-                    const bool inside = (xp >= -6.f) && (xp <= 6.f);
-                    dv[k] = (inside && x != 0.f) ? gg[k] * rsc : 0.f;
-                    s_gq += gg[k] * q;
-                    s_dvw += dv[k] * w[k];
-                }
-            }
-            if (a.dV_out) store8_f32(a.dV_out, c * kEPT, dv);
-            if (a.lr_v && a.V) {
-                if (do_snap && a.best_V) store8_f32(a.best_V, c * kEPT, v);
-                float vn[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) vn[k] = v[k] + alpha_v * sgnf(dv[k]);
-                store8_f32(a.V, c * kEPT, vn);
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = c0 + (int64_t)u * kTPB;
+            okk[u] = c < total_chunks;
+            am[u] = 0.f; msr[u] = 1.f;
+            if (okk[u]) {
+                gr[u] = load8_raw<XDT>(a.dXq, c * kEPT);
+                wr[u] = load8_raw<XDT>(a.X, c * kEPT);
+                if (a.V) vr[u] = load8_f32(a.V, c * kEPT);
+                const int64_t g = c / cpg;
+                am[u] = a.absmax[g];
+                if (a.max_s) msr[u] = a.max_s[g];
             }
         }
-        s_gq = lanes_sum(s_gq, cpg);
-        s_dvw = lanes_sum(s_dvw, cpg);
-        if (ok && (c % cpg) == 0) {
-            float dMs;
-            if (a.mode == 0) {
-                const float dsc = s_gq - s_dvw;
-                const bool pass = (se_un >= -127.f) && (se_un <= 127.f);
-                dMs = (m == 0.f || !pass) ? 0.f : ((dsc * (sc * LN2)) / (m * LN2)) * amax * a.init_scale;
-            } else {
-                const float dosc = (sc == 0.f) ? 0.f : (s_dvw - s_gq * (rsc * rsc));
-                const float dr = (r == 0.f) ? 0.f : -dosc * (sc * sc);
-                float ds = dr * recip0(gscale);
-                if (!((s_pre >= -448.f) && (s_pre <= 448.f))) ds = 0.f;
-                dMs = (((ds * gscale) * r6) * amax) * a.init_scale;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = c0 + (int64_t)u * kTPB;
+            if (c >= limit) break;          // wave-uniform
+            const bool ok = okk[u];
+            const int64_t g = ok ? c / cpg : 0;
+            float s_gq = 0.f, s_dvw = 0.f;
+            const float amax = am[u];
+            float Ms = 1.f, sc = 1.f, rsc = 1.f, m = 0.f, se_un = 0.f, s_pre = 0.f, r = 0.f;
+            if (ok) {
+                float gg[8], w[8], v[8], dv[8];
+                unpack8<XDT>(gr[u], gg);
+                unpack8<XDT>(wr[u], w);
+                if (a.V) unpack_f8(vr[u], v);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+                }
+                Ms = a.max_s ? clamp3(msr[u], a.lo, a.hi) : 1.0f;
+                if (a.mode == 0) {
+                    m = amax * (a.init_scale * Ms);
+                    float se = (m == 0.f) ? 1.0f : log2f(m);
+                    se_un = floorf(se) - 2.0f;
+                    const int sei = (int)clamp3(se_un, -127.f, 127.f);
+                    sc = ldexpf(1.0f, sei);
+                    rsc = ldexpf(1.0f, -sei);          // exact reciprocal of the power-of-two scale
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float ws = w[k] * rsc;
+                        const float tp = ws + v[k];
+                        const float t = clamp3(tp, -6.f, 6.f);
+                        const float q = mx_e2m1(t);
+                        const float d = (t == 0.f) ? 0.f : ((fabsf(t) < 1.0f) ? 1.0f : q / t);
+                        const bool inside = (tp >= -6.f) && (tp <= 6.f);
+                        dv[k] = inside ? (gg[k] * sc) * d : 0.f;
+                        s_gq += gg[k] * q;
+                        s_dvw += dv[k] * (ws * rsc);
+                    }
+                } else {
+                    const float vm = amax * (Ms * a.init_scale);
+                    s_pre = gscale * (vm * r6);
+                    const float s = e4m3_to_f32(f32_to_e4m3(clamp3(s_pre, -448.f, 448.f)));
+                    r = s * recip0(gscale);
+                    sc = recip0(r);        // osc
+                    rsc = recip0(sc);      // ro
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float xp = w[k] * sc + v[k];
+                        const float x = clamp3(xp, -6.f, 6.f);
+                        const float q = nv_e2m1(x);
+                        const bool inside = (xp >= -6.f) && (xp <= 6.f);
+                        dv[k] = (inside && x != 0.f) ? gg[k] * rsc : 0.f;
+                        s_gq += gg[k] * q;
+                        s_dvw += dv[k] * w[k];
+                    }
+                }
+                if (a.dV_out) store8_f32(a.dV_out, c * kEPT, dv);
+                if (a.lr_v && a.V) {
+                    if (do_snap && a.best_V) store8_f32(a.best_V, c * kEPT, v);
+                    float vn[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) vn[k] = v[k] + alpha_v * sgnf(dv[k]);
+                    store8_f32(a.V, c * kEPT, vn);
+                }
             }
-            if (a.dmax_out) a.dmax_out[g] = dMs;
-            if (a.lr_mm && a.tune_minmax && a.max_s) {
-                if (do_snap && a.best_max) a.best_max[g] = Ms;
-                a.max_s[g] = Ms + alpha_mm * sgnf(dMs);
+            s_gq = lanes_sum(s_gq, cpg);
+            s_dvw = lanes_sum(s_dvw, cpg);
+            if (ok && (c % cpg) == 0) {
+                float dMs;
+                if (a.mode == 0) {
+                    const float dsc = s_gq - s_dvw;
+                    const bool pass = (se_un >= -127.f) && (se_un <= 127.f);
+                    dMs = (m == 0.f || !pass) ? 0.f : ((dsc * (sc * LN2)) / (m * LN2)) * amax * a.init_scale;
+                } else {
+                    const float dosc = (sc == 0.f) ? 0.f : (s_dvw - s_gq * (rsc * rsc));
+                    const float dr = (r == 0.f) ? 0.f : -dosc * (sc * sc);
+                    float ds = dr * recip0(gscale);
+                    if (!((s_pre >= -448.f) && (s_pre <= 448.f))) ds = 0.f;
+                    dMs = (((ds * gscale) * r6) * amax) * a.init_scale;
+                }
+                if (a.dmax_out) a.dmax_out[g] = dMs;
+                if (a.lr_mm && a.tune_minmax && a.max_s) {
+                    if (do_snap && a.best_max) a.best_max[g] = Ms;
+                    a.max_s[g] = Ms + alpha_mm * sgnf(dMs);
+                }
             }
         }
     }
@@ -370,12 +423,12 @@ extern "C" int ar_qdq_fp4_bwd_sgd(const void* dXq, const void* X, float* V, cons
     a.lr_v = lr_v_dev; a.lr_mm = lr_mm_dev; a.snap = snapshot_flag; a.best_V = best_V; a.best_max = best_max;
     a.dV_out = dV_out; a.dmax_out = dmax_out; a.n_groups = n_groups; a.cpg = gs / kEPT; a.mode = mode;
     a.tune_minmax = tune_minmax; a.init_scale = init_scale; a.lo = lo_bound; a.hi = hi_bound;
-    const int grid = fp4_grid(n_groups * a.cpg);
+    const int grid = fp4_grid((n_groups * a.cpg + AR_FP4_BWD_UNROLL - 1) / AR_FP4_BWD_UNROLL);
     hipStream_t st = (hipStream_t)stream;
     switch (x_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL(k_fp4_bwd<AR_DT_BF16>, grid, kTPB, 0, st, a); break;
-        case AR_DT_F16: hipLaunchKernelGGL(k_fp4_bwd<AR_DT_F16>, grid, kTPB, 0, st, a); break;
-        case AR_DT_F32: hipLaunchKernelGGL(k_fp4_bwd<AR_DT_F32>, grid, kTPB, 0, st, a); break;
+        case AR_DT_BF16: hipLaunchKernelGGL((k_fp4_bwd<AR_DT_BF16, AR_FP4_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        case AR_DT_F16: hipLaunchKernelGGL((k_fp4_bwd<AR_DT_F16, AR_FP4_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        case AR_DT_F32: hipLaunchKernelGGL((k_fp4_bwd<AR_DT_F32, AR_FP4_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
         default: return AR_ERR_UNSUPPORTED;
     }
     return launch_status();
@@ -390,24 +443,34 @@ __device__ __forceinline__ int lanes_min_i(int v, int width) {
     return v;
 }
 
-template <int XDT>
+template <int XDT, int U>
 __global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ dXq, const void* __restrict__ X,
                                                       void* __restrict__ dX, const float* __restrict__ gscale_dev,
                                                       int64_t n_groups, int cpg, int mode) {
     const int64_t total_chunks = n_groups * cpg;
-    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    const int64_t stride = (int64_t)gridDim.x * kTPB * U;
     const float gscale = (mode == 1 && gscale_dev) ? *gscale_dev : 1.0f;
     const float LN2 = 0.6931471805599453f;
     const float r6 = (float)(1.0 / 6.0);
     const int64_t limit = (total_chunks + kWave - 1) / kWave * kWave;
-    for (int64_t c = (int64_t)blockIdx.x * kTPB + threadIdx.x; c < limit; c += stride) {
+    for (int64_t c0 = (int64_t)blockIdx.x * kTPB * U + threadIdx.x; c0 < limit; c0 += stride) {
+      Raw8<XDT> gr[U], xr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {          // all loads first
+          const int64_t cu = c0 + (int64_t)u * kTPB;
+          if (cu < total_chunks) { gr[u] = load8_raw<XDT>(dXq, cu * kEPT); xr[u] = load8_raw<XDT>(X, cu * kEPT); }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t c = c0 + (int64_t)u * kTPB;
+        if (c >= limit) break;               // wave-uniform
         const bool ok = c < total_chunks;
         float gg[8], x[8], dx[8];
         float lmax = -1.f;
         int lk = 0;
         if (ok) {
-            unpack8<XDT>(load8_raw<XDT>(dXq, c * kEPT), gg);
-            unpack8<XDT>(load8_raw<XDT>(X, c * kEPT), x);
+            unpack8<XDT>(gr[u], gg);
+            unpack8<XDT>(xr[u], x);
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const float a = fabsf(x[k]); if (a > lmax) { lmax = a; lk = k; } }
         } else {
@@ -422,18 +485,20 @@ __global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ d
         if (mode == 0) {
             float se = (m == 0.f) ? 1.0f : log2f(m);
             se_un = floorf(se) - 2.0f;
-            sc = ldexpf(1.0f, (int)clamp3(se_un, -127.f, 127.f));
+            const int sei = (int)clamp3(se_un, -127.f, 127.f);
+            sc = ldexpf(1.0f, sei);
+            rsc = ldexpf(1.0f, -sei);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float ws = x[k] / sc;
+                const float ws = x[k] * rsc;
                 const float t = clamp3(ws, -6.f, 6.f);
                 const float q = mx_e2m1(t);
                 const float d = (t == 0.f) ? 0.f : ((fabsf(t) < 1.0f) ? 1.0f : q / t);
                 const bool inside = (ws >= -6.f) && (ws <= 6.f);
                 const float dtp = inside ? (gg[k] * sc) * d : 0.f;
-                dx[k] = dtp / sc;
+                dx[k] = dtp * rsc;
                 s_gq += gg[k] * q;
-                s_dvw += dtp * (ws / sc);
+                s_dvw += dtp * (ws * rsc);
             }
         } else {
             s_pre = gscale * (amax * r6);
@@ -476,6 +541,7 @@ __global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ d
             else dx[k] = round_to<XDT>(dx[k]) + (star ? round_to<XDT>(extra) * sgnf(x[k]) : 0.f);
         }
         store8<XDT>(dX, c * kEPT, dx);
+      }
     }
 }
 }  // namespace ar
@@ -486,12 +552,12 @@ extern "C" int ar_fp4_act_bwd(const void* dXq, const void* X, void* dX, const fl
     if (mode == 1 && !global_scale_dev) return AR_ERR_UNSUPPORTED;
     if (n_groups == 0) return AR_OK;
     const int cpg = gs / kEPT;
-    const int grid = fp4_grid(n_groups * cpg);
+    const int grid = fp4_grid((n_groups * cpg + 1) / 2);
     hipStream_t st = (hipStream_t)stream;
     switch (x_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL(k_fp4_act_bwd<AR_DT_BF16>, grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
-        case AR_DT_F16: hipLaunchKernelGGL(k_fp4_act_bwd<AR_DT_F16>, grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
-        case AR_DT_F32: hipLaunchKernelGGL(k_fp4_act_bwd<AR_DT_F32>, grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
+        case AR_DT_BF16: hipLaunchKernelGGL((k_fp4_act_bwd<AR_DT_BF16, 2>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
+        case AR_DT_F16: hipLaunchKernelGGL((k_fp4_act_bwd<AR_DT_F16, 2>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
+        case AR_DT_F32: hipLaunchKernelGGL((k_fp4_act_bwd<AR_DT_F32, 2>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
         default: return AR_ERR_UNSUPPORTED;
     }
     return launch_status();

@@ -53,6 +53,20 @@ def main():
     res["copy_bf16_ms"] = t; res["copy_GBps"] = 4 * n / t / 1e6
     t = timeit(lambda: ops.group_minmax(W, gs))
     res["minmax_ms"] = t; res["minmax_GBps"] = 2 * n / t / 1e6
+    # fp4 weight kernels (MXFP4 g32, NVFP4 g16)
+    for name, mode, fgs in (("mx", 0, 32), ("nv", 1, 16)):
+        Gf = n // fgs
+        absmax, tmax = ops.group_absmax(W, fgs, want_tensor_max=True)
+        gsc = (448.0 * 6.0 / tmax) if mode == 1 else None
+        Msf = torch.ones(Gf, device="cuda")
+        t = timeit(lambda: ops.qdq_fp4_fwd(W, V, absmax, Msf, mode=mode, gs=fgs, global_scale=gsc, out=Wq))
+        res[f"{name}fp4_fwd_GBps"] = (8 * n + 8 * Gf) / t / 1e6
+        t = timeit(lambda: ops.qdq_fp4_bwd_sgd_(dWq, W, V, absmax, Msf, mode=mode, gs=fgs, global_scale=gsc, lr_v=lr, lr_mm=lr))
+        res[f"{name}fp4_bwd_sgd_GBps"] = (12 * n + 8 * Gf) / t / 1e6
+        t = timeit(lambda: ops.qdq_fp4_fwd(W, None, None, None, mode=mode, gs=fgs, global_scale=gsc, out=Wq))
+        res[f"{name}fp4_act_fwd_GBps"] = 4 * n / t / 1e6
+        t = timeit(lambda: ops.fp4_act_bwd(dWq, W, mode=mode, gs=fgs, global_scale=gsc, out=Wq))
+        res[f"{name}fp4_act_bwd_GBps"] = 6 * n / t / 1e6
     print(json.dumps({k: round(v, 3) for k, v in res.items()}))
 
 
