@@ -3,8 +3,12 @@
 //   k_int_fwd      : K1  fake-quant forward                    8 B/elem + 12 B/group   (HBM bound)
 //   k_int_bwd      : K2(+K3) backward [+ sign-SGD + best-param snapshot + next forward], 12 B/elem + 8 B/group
 //
-// Design (DESIGN.md "kernels"): the weight is a flat array of groups.  A workgroup (256 lanes = 4 waves) owns a
-// tile of up to 8192 consecutive elements (whole groups).  Per tile:
+// Two implementations of the hot pair are kept and selectable at build time (AR_INT_FLAT):
+//  * flat (default, faster): every lane issues its 16-byte streaming loads up front, derives its group's (scale, zp)
+//    itself from four broadcast-loaded group parameters, and the gs/8 lanes of a group meet only in the shuffle
+//    butterfly; no LDS, no barrier (k_int_fwd_flat / k_int_bwd_flat).
+//  * LDS-tiled (the first design): the weight is a flat array of groups; a workgroup (256 lanes = 4 waves) owns a
+//    tile of up to 8192 consecutive elements (whole groups).  Per tile:
 //   (A) up to 256 "group lanes" load the 4 per-group parameters and                      [12 B/group]
 //   (B) every lane issues all of its 16-byte streaming loads (W, V[, dWq]) up front,     [the HBM stream]
 //   (C) the group lanes turn the parameters into (scale, zp) -- fp16 cast, threshold clamp, true IEEE division,
@@ -497,6 +501,157 @@ __global__ __launch_bounds__(kTPB) void k_int_bwd_generic(const BwdArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// "flat" variants of the two hot kernels (AR_INT_FLAT=1): no LDS tile, no barrier.  Every lane derives the (scale, zp)
+// of its chunk's group itself from the four group parameters (broadcast loads; gs/8 lanes repeat the same ~40 VALU
+// operations), the gs/8 lanes of a group meet only in the shuffle butterfly, and the first lane of the group applies
+// the min/max step.  A/B against the LDS-staged kernels is recorded in DESIGN.md section 3.
+// ------------------------------------------------------------------------------------------------------------------
+template <int WDT, int XR, int U>
+__global__ __launch_bounds__(kTPB) void k_int_fwd_flat(const FwdArgs a) {
+    const int shift = a.cpg_shift;
+    const int64_t total_chunks = a.n_groups << shift;
+    const int64_t stride = (int64_t)gridDim.x * kTPB * U;
+    for (int64_t c0 = (int64_t)blockIdx.x * kTPB * U + threadIdx.x; c0 < total_chunks; c0 += stride) {
+        Raw8<WDT> wr[U];
+        F8 vr[U];
+        float wmn[U], wmx[U], ms[U], Ms[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = c0 + (int64_t)u * kTPB;
+            ok[u] = c < total_chunks;
+            ms[u] = 1.f; Ms[u] = 1.f; wmn[u] = 0.f; wmx[u] = 0.f;
+            if (ok[u]) {
+                wr[u] = load8_raw<WDT>(a.W, c * kEPT);
+                if (a.V) vr[u] = load8_f32(a.V, c * kEPT);
+                const int64_t g = c >> shift;
+                wmn[u] = load1<WDT>(a.wmin, g);
+                wmx[u] = load1<WDT>(a.wmax, g);
+                if (a.min_s) ms[u] = a.min_s[g];
+                if (a.max_s) Ms[u] = a.max_s[g];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const int64_t c = c0 + (int64_t)u * kTPB;
+            GroupQ q;
+            group_scale(a.cfg, wmn[u], wmx[u], ms[u], Ms[u], q);
+            if ((c & ((1 << shift) - 1)) == 0) {
+                const int64_t g = c >> shift;
+                if (a.scale_out) store1_rt(a.cfg.s_dt, a.scale_out, g, q.s);
+                if (a.zp_out) a.zp_out[g] = q.zp;
+            }
+            float w[8], v[8], o[8];
+            unpack8<WDT>(wr[u], w);
+            if (a.V) unpack_f8(vr[u], v);
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = 0.f;
+            }
+            qdq8<XR>(w, v, q.s, a.cfg.sym ? 0.f : q.zp, a.qlo, a.qhi, o);
+            store8<WDT>(a.Wq, c * kEPT, o);
+        }
+    }
+}
+
+template <int WDT, int XR, int U>
+__global__ __launch_bounds__(kTPB) void k_int_bwd_flat(const BwdArgs a) {
+    const int shift = a.cpg_shift, cpg = a.cpg;
+    const int64_t total_chunks = a.n_groups << shift;
+    const int64_t stride = (int64_t)gridDim.x * kTPB * U;
+    const bool sym = a.cfg.sym != 0;
+    const bool do_snap = a.snap != nullptr && *a.snap != 0;
+    const float alpha_v = a.lr_v ? -(*a.lr_v) : 0.f;
+    const float alpha_mm = a.lr_mm ? -(*a.lr_mm) : 0.f;
+    const int64_t limit = (total_chunks + kWave - 1) / kWave * kWave;
+    for (int64_t c0 = (int64_t)blockIdx.x * kTPB * U + threadIdx.x; c0 < limit; c0 += stride) {
+        Raw8<WDT> gr[U], wr[U];
+        F8 vr[U];
+        float wmn[U], wmx[U], ms[U], Ms[U];
+        bool okk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = c0 + (int64_t)u * kTPB;
+            okk[u] = c < total_chunks;
+            ms[u] = 1.f; Ms[u] = 1.f; wmn[u] = 0.f; wmx[u] = 0.f;
+            if (okk[u]) {
+                gr[u] = load8_raw<WDT>(a.dWq, c * kEPT);
+                wr[u] = load8_raw<WDT>(a.W, c * kEPT);
+                if (a.V) vr[u] = load8_f32(a.V, c * kEPT);
+                const int64_t g = c >> shift;
+                wmn[u] = load1<WDT>(a.wmin, g);
+                wmx[u] = load1<WDT>(a.wmax, g);
+                if (a.min_s) ms[u] = a.min_s[g];
+                if (a.max_s) Ms[u] = a.max_s[g];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = c0 + (int64_t)u * kTPB;
+            if (c >= limit) break;              // wave-uniform
+            const bool ok = okk[u];
+            GroupQ q;
+            group_scale(a.cfg, wmn[u], wmx[u], ms[u], Ms[u], q);
+            const float zp = sym ? 0.f : q.zp;
+            Sums acc = {0.f, 0.f, 0.f, 0.f};
+            float w[8], vnew[8];
+            if (ok) {
+                float gg[8], v[8], dy[8];
+                unpack8<WDT>(gr[u], gg);
+                unpack8<WDT>(wr[u], w);
+                if (a.V) unpack_f8(vr[u], v);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+                }
+                bwd8<XR>(gg, w, v, q.s, zp, a.qlo, a.qhi, dy, acc);
+                if (a.dV) store8_f32(a.dV, c * kEPT, dy);
+                if (a.lr_v) {
+                    if (do_snap && a.best_V) store8_f32(a.best_V, c * kEPT, v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) vnew[k] = v[k] + alpha_v * sgnf(dy[k]);
+                    store8_f32(a.V, c * kEPT, vnew);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) vnew[k] = v[k];
+                }
+            }
+            acc.c1 = lanes_sum(acc.c1, cpg);
+            acc.c2 = lanes_sum(acc.c2, cpg);
+            if (!sym) { acc.e = lanes_sum(acc.e, cpg); acc.dy = lanes_sum(acc.dy, cpg); }
+            if (!ok) continue;
+            float gmin, gmax;
+            minmax_grads<XR>(a.cfg, q, make_float4(acc.c1, acc.c2, acc.e, acc.dy), gmin, gmax);
+            float ms_new = ms[u], Ms_new = Ms[u];
+            const bool upd = a.lr_mm && a.tune_minmax;
+            if (upd) { ms_new = q.ms + alpha_mm * sgnf(gmin); Ms_new = q.Ms + alpha_mm * sgnf(gmax); }
+            if ((c & (cpg - 1)) == 0) {
+                const int64_t g = c >> shift;
+                if (a.dmin) a.dmin[g] = gmin;
+                if (a.dmax) a.dmax[g] = gmax;
+                if (upd) {
+                    if (do_snap) {
+                        if (a.best_min) a.best_min[g] = q.ms;
+                        if (a.best_max) a.best_max[g] = q.Ms;
+                    }
+                    a.min_s[g] = ms_new;
+                    a.max_s[g] = Ms_new;
+                }
+            }
+            if (a.Wq_next) {   // every lane already knows its group's new scales: no hand-off needed
+                GroupQ q2;
+                group_scale(a.cfg, wmn[u], wmx[u], ms_new, Ms_new, q2);
+                float o[8];
+                qdq8<XR>(w, vnew, q2.s, sym ? 0.f : q2.zp, a.qlo, a.qhi, o);
+                store8<WDT>(a.Wq_next, c * kEPT, o);
+            }
+        }
+    }
+}
+
 // unfused sign-SGD
 __global__ __launch_bounds__(kTPB) void k_sign_sgd(float* __restrict__ p, const float* __restrict__ g, int64_t n,
                                                    const float* __restrict__ lr) {
@@ -579,6 +734,17 @@ extern "C" int ar_group_absmax(const void* W, float* absmax, float* tensor_absma
     return launch_status();
 }
 
+// AR_INT_FLAT=1 (default): the flat kernels; 0: the LDS-tiled ones.  A/B on MI355X, Llama-3-8B block, same session:
+//   forward 5.82 vs 5.44 TB/s, fused backward+sign-SGD 5.02 vs 4.70 TB/s, backward+next-forward 5.12 vs 4.83 TB/s.
+#ifndef AR_INT_FLAT
+#define AR_INT_FLAT 1
+#endif
+#ifndef AR_FLAT_FWD_UNROLL
+#define AR_FLAT_FWD_UNROLL 4
+#endif
+#ifndef AR_FLAT_BWD_UNROLL
+#define AR_FLAT_BWD_UNROLL 2
+#endif
 #ifndef AR_FWD_UNROLL
 #define AR_FWD_UNROLL 4
 #endif
@@ -619,6 +785,23 @@ extern "C" int ar_qdq_int_fwd(const void* W, const float* V, const void* wmin, c
         }
         return launch_status();
     }
+#if AR_INT_FLAT
+    if (a.cpg_shift >= 0 && a.cpg <= kWave) {
+        const int fgrid = grid_for_tiles((n_groups * a.cpg + kTPB * AR_FLAT_FWD_UNROLL - 1) / (kTPB * AR_FLAT_FWD_UNROLL));
+        switch (w_dt) {
+            case AR_DT_BF16:
+                if (same16) hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_BF16, AR_DT_BF16, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                else hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                break;
+            case AR_DT_F16:
+                if (same16) hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_F16, AR_DT_F16, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                else hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_F16, AR_DT_F32, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                break;
+            default: hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_F32, AR_DT_F32, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a); break;
+        }
+        return launch_status();
+    }
+#endif
     switch (w_dt) {
         case AR_DT_BF16:
             if (same16) hipLaunchKernelGGL((k_int_fwd<AR_DT_BF16, AR_DT_BF16, AR_FWD_UNROLL>), grid, kTPB, 0, st, a);
@@ -662,6 +845,23 @@ static int launch_int_bwd(BwdArgs& a, int gs, int bits, int sym, int w_dt, int s
     const int grid = grid_for_tiles((a.n_groups + tile_groups - 1) / tile_groups);
     hipStream_t st = (hipStream_t)stream;
     const bool same16 = (a.x_dt == w_dt) && (w_dt != AR_DT_F32);
+#if AR_INT_FLAT
+    {
+        const int fgrid = grid_for_tiles((a.n_groups * a.cpg + kTPB * AR_FLAT_BWD_UNROLL - 1) / (kTPB * AR_FLAT_BWD_UNROLL));
+        switch (w_dt) {
+            case AR_DT_BF16:
+                if (same16) hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_BF16, AR_DT_BF16, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                else hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                break;
+            case AR_DT_F16:
+                if (same16) hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_F16, AR_DT_F16, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                else hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_F16, AR_DT_F32, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                break;
+            default: hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_F32, AR_DT_F32, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a); break;
+        }
+        return launch_status();
+    }
+#endif
     switch (w_dt) {
         case AR_DT_BF16:
             if (same16) hipLaunchKernelGGL((k_int_bwd<AR_DT_BF16, AR_DT_BF16, AR_BWD_UNROLL>), grid, kTPB, 0, st, a);
