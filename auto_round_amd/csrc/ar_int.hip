@@ -77,10 +77,17 @@ __global__ __launch_bounds__(kTPB) void k_group_minmax(const void* __restrict__ 
             }
         }
     }
-    if (tensor_absmax) {
+    if (tensor_absmax) {    // wave -> workgroup -> ONE atomic per workgroup (the grid is capped for this case on the host)
+        __shared__ float wmaxs[kTPB / kWave];
         tmax = lanes_max(tmax, kWave);
-        // non-negative floats order like their bit patterns
-        if (lane == 0 && tmax > 0.f) atomicMax(reinterpret_cast<unsigned int*>(tensor_absmax), __float_as_uint(tmax));
+        if (lane == 0) wmaxs[threadIdx.x / kWave] = tmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = wmaxs[0];
+            for (int w = 1; w < kTPB / kWave; ++w) m = fmaxf(m, wmaxs[w]);
+            // non-negative floats order like their bit patterns
+            if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(tensor_absmax), __float_as_uint(m));
+        }
     }
 }
 
@@ -723,7 +730,8 @@ extern "C" int ar_group_absmax(const void* W, float* absmax, float* tensor_absma
     const int cpg = gs / kEPT;
     const bool lane_groups = cpg <= kWave && ilog2_exact(cpg) >= 0;
     const int64_t waves = lane_groups ? (n_groups + (kWave / cpg) - 1) / (kWave / cpg) : n_groups;
-    const int grid = grid_for_tiles((waves + 3) / 4);
+    int grid = grid_for_tiles((waves + 3) / 4);
+    if (tensor_absmax && grid > 256 * 8) grid = 256 * 8;   // grid-stride: at most 2048 atomics on the global max
     hipStream_t st = (hipStream_t)stream;
     switch (w_dt) {
         case AR_DT_BF16: hipLaunchKernelGGL(k_group_minmax<AR_DT_BF16>, grid, kTPB, 0, st, W, nullptr, nullptr, absmax, tensor_absmax, n_groups, lane_groups ? cpg : -cpg); break;

@@ -48,9 +48,9 @@ def group_minmax(W: torch.Tensor, gs: int):
     return wmin, wmax
 
 
-def group_absmax(W: torch.Tensor, gs: int, want_tensor_max: bool = False):
+def group_absmax(W: torch.Tensor, gs: int, want_tensor_max: bool = False, want_groups: bool = True):
     G = W.numel() // gs
-    am = torch.empty(G, dtype=torch.float32, device=W.device)
+    am = torch.empty(G, dtype=torch.float32, device=W.device) if want_groups else None
     tm = torch.zeros(1, dtype=torch.float32, device=W.device) if want_tensor_max else None
     check(load().ar_group_absmax(_p(W, "W"), _p(am), _p(tm), G, gs, dt_code(W.dtype), _stream()), "ar_group_absmax")
     return am, tm

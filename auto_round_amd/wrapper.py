@@ -128,7 +128,7 @@ def act_fake_quant(x: torch.Tensor, layer) -> torch.Tensor:
     if is_nv_fp(adt) and gs == 16:
         act_max = getattr(layer, "act_max", None)
         if act_max is None:     # nv_fp4_with_static_gs falls back to the tensor's own max (nvfp.py:107-108)
-            _, tmax = ops.group_absmax(x.detach().contiguous().view(-1), 16, want_tensor_max=True)
+            _, tmax = ops.group_absmax(x.detach().contiguous().view(-1), 16, want_tensor_max=True, want_groups=False)
         else:
             tmax = torch.as_tensor(act_max, dtype=torch.float32, device=x.device).abs().max().reshape(1)
         gscale = torch.where(tmax == 0, torch.zeros_like(tmax), (448.0 * 6.0) * (1.0 / tmax))
