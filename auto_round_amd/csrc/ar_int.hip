@@ -900,6 +900,7 @@ extern "C" int ar_qdq_int_bwd_sgd(const void* dWq, const void* W, float* V, cons
                                   int s_dt, float q_thresh, float lo_bound, float hi_bound, const float* lr_v_dev,
                                   const float* lr_mm_dev, int tune_minmax, const int32_t* snapshot_flag, float* best_V,
                                   float* best_min, float* best_max, void* Wq_next, ar_stream_t stream) {
+    if (n_groups == 0) return AR_OK;                 // empty block: nothing to launch (pointers may be NULL)
     if (!V || !lr_v_dev) return AR_ERR_UNSUPPORTED;
     BwdArgs a = {};
     a.dWq = dWq; a.W = W; a.V = V; a.wmin = wmin; a.wmax = wmax; a.min_s = min_s; a.max_s = max_s;

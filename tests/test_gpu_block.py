@@ -408,3 +408,76 @@ def test_layer_without_gradient_is_not_stepped():
     best = q.quantize_block(blk, X, {}, Y, None, None)
     assert float(best["b"]["value"].abs().max()) == 0.0 and bool((best["b"]["min_scale"] == 1).all())
     assert float(best["a"]["value"].abs().max()) > 0.0
+
+
+def test_edge_cases_empty_ragged_and_unquantized():
+    """Empty launches, nsamples not divisible by the batch, batch larger than nsamples, a block without any quantised
+    layer, and a GPT-2 style block whose projections are transformers Conv1D modules (weight stored [in, out])."""
+    from auto_round_amd import ops
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    # empty group arrays are a no-op, not an error
+    e = torch.empty(0, dtype=torch.bfloat16, device="cuda")
+    f = torch.empty(0, dtype=torch.float32, device="cuda")
+    assert ops.qdq_int_fwd(e, f, e, e, f, f, gs=128, bits=4, sym=True).numel() == 0
+    lr = torch.tensor([0.01], device="cuda")
+    ops.qdq_int_bwd_sgd_(e, e, f, e, e, f, f, gs=128, bits=4, sym=True, lr_v=lr, lr_mm=lr)
+
+    layer, rope, cfg = make_layer("llama", 4, 32, True, seed=31)
+    # 10 samples, batch 4: the sampler reshuffles when fewer than a batch remain (compressors/utils.py:388-438)
+    X, others = make_data(rope, cfg, N=10)
+    blk = copy.deepcopy(layer)
+    random.seed(1)
+    q = SignRoundQuantizer(SignRoundConfig(iters=7, batch_size=4, bits=4), device="cuda")
+    fp_out, q_out, best = q.compress_block(blk, X, others)
+    assert fp_out.shape[0] == 10 and q_out.shape[0] == 10 and np.isfinite(q.last_stats["best_loss"])
+    # batch larger than nsamples -> clamped to nsamples (quantizer.py:441-442)
+    blk = copy.deepcopy(layer)
+    q = SignRoundQuantizer(SignRoundConfig(iters=3, batch_size=64, bits=4), device="cuda")
+    q.compress_block(blk, X[:3], others)
+    assert np.isfinite(q.last_stats["best_loss"])
+    # nothing to quantise: returns {} and leaves the block untouched
+    blk = copy.deepcopy(layer)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.bits = 16
+    W0 = [m.weight.clone() for m in blk.modules() if isinstance(m, torch.nn.Linear)]
+    q = SignRoundQuantizer(SignRoundConfig(iters=3, batch_size=4, bits=4), device="cuda")
+    assert q.quantize_block(blk, X, others, targets(blk, X, others, 5), None, None) == {}
+    assert all(torch.equal(a, m.weight) for a, m in zip(W0, [m for m in blk.modules() if isinstance(m, torch.nn.Linear)]))
+
+
+def test_conv1d_block_gpt2_style():
+    from transformers import GPT2Config
+    from transformers.models.gpt2.modeling_gpt2 import GPT2Block
+    from transformers.pytorch_utils import Conv1D
+
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    torch.manual_seed(0)
+    cfg = GPT2Config(n_embd=128, n_head=4, n_layer=1, n_positions=64, vocab_size=100)
+    cfg._attn_implementation = "sdpa"
+    blk = GPT2Block(cfg, layer_idx=0).to(torch.bfloat16).cuda().eval()
+    for p in blk.parameters():
+        p.requires_grad_(False)
+    convs = {n: m for n, m in blk.named_modules() if isinstance(m, Conv1D)}
+    assert len(convs) == 4
+    for m in convs.values():
+        m.bits, m.group_size, m.sym, m.data_type, m.scale_dtype, m.act_bits = 4, 32, True, "int", torch.float16, 16
+    X = torch.randn(8, 16, 128, generator=torch.Generator().manual_seed(2)).to(torch.bfloat16).cuda()
+    W0 = {n: m.weight.detach().clone() for n, m in convs.items()}
+    random.seed(3)
+    q = SignRoundQuantizer(SignRoundConfig(iters=20, batch_size=4, bits=4), device="cuda")
+    fp_out, q_out, best = q.compress_block(blk, X, {})
+    st = q.last_stats
+    assert st["quantized"] == 4 and st["best_loss"] <= st["init_loss"]
+    for n, m in blk.named_modules():
+        if isinstance(m, Conv1D):
+            in_f, out_f = m.weight.shape                       # Conv1D stores [in, out]
+            assert tuple(m.scale.shape) == (out_f, in_f // 32)
+            w2d = m.weight.t().float()                         # [out, in] view the quantizer works on
+            s = m.scale.float().cuda().repeat_interleave(32, 1)
+            qi = torch.round(w2d / s)
+            assert float(qi.min()) >= -8 and float(qi.max()) <= 7
+            assert torch.equal((s * qi).to(torch.bfloat16), m.weight.t())
+            assert not torch.equal(m.weight, W0[n])
