@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""End-to-end parity + speed report on one MI355X: auto_round_amd (HIP path) vs oracle/torch_ref (the pinned torch
+"""(test infrastructure; lives under tests/ because it uses the oracle)
+End-to-end parity + speed report on one MI355X: auto_round_amd (HIP path) vs oracle/torch_ref (the pinned torch
 restatement of the reference loop, i.e. what the reference's eager path computes) on the SAME device, seeds, data and
 index schedule, for full-size blocks and the full 200 iterations.  Writes one JSON line per workload.
 
