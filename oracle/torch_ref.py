@@ -279,7 +279,7 @@ class Sampler:
 
 def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others: dict, *, iters=200, batch_size=8,
                lr=None, enable_minmax_tuning=True, amp_dtype=torch.bfloat16, forward=None, record=None,
-               max_iters_to_run=None, input_ids=None):
+               max_iters_to_run=None, input_ids=None, amp=True):
     """The reference's quantize_block loop in plain torch.  inputs/targets: [N, S, H].  Returns best_params and
     leaves the block unwrapped with baked weights.  `forward(block, x, others)` defaults to block(x, **others)[0]."""
     names = wrap_block(block, enable_minmax_tuning)
@@ -303,7 +303,7 @@ def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others:
         idx = sampler.next_batch()
         x = inputs[idx]
         ref = targets[idx]
-        with torch.autocast(device_type=dev_type, dtype=amp_dtype):
+        with torch.autocast(device_type=dev_type, dtype=amp_dtype, enabled=amp):
             out = forward(block, x, input_others) if forward else block(x, **input_others)
             if isinstance(out, (tuple, list)):
                 out = out[0]

@@ -481,3 +481,35 @@ def test_conv1d_block_gpt2_style():
             assert float(qi.min()) >= -8 and float(qi.max()) <= 7
             assert torch.equal((s * qi).to(torch.bfloat16), m.weight.t())
             assert not torch.equal(m.weight, W0[n])
+
+
+@pytest.mark.parametrize("wdtype,amp", [(torch.float32, False), (torch.float16, True)])
+def test_non_default_weight_dtypes_vs_torch_ref(wdtype, amp):
+    """fp32 weights without autocast (amp=False, the reference's fallback when bf16 is unsupported) and fp16 weights
+    with fp16 autocast: the W/scale division then happens in fp32 resp. fp16 (torch type promotion)."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from oracle import torch_ref as tr
+
+    layer, rope, cfg = make_layer("opt", 4, 32, True, seed=41)
+    layer = layer.to(wdtype)
+    X, others = make_data(rope, cfg, N=8)
+    X = X.to(wdtype)
+
+    def tg(blk):
+        with torch.no_grad(), torch.autocast("cuda", dtype=wdtype if amp else torch.bfloat16, enabled=amp):
+            return torch.cat([fwd(blk, X[i:i + 4], others) for i in range(0, 8, 4)])
+
+    Y = tg(layer)
+    blk_o = copy.deepcopy(layer)
+    random.seed(8)
+    best_o, info = tr.tune_block(blk_o, X, Y, others, iters=3, batch_size=4, forward=fwd, amp=amp, amp_dtype=wdtype if amp else torch.bfloat16)
+    blk_m = copy.deepcopy(layer)
+    random.seed(8)
+    q = SignRoundQuantizer(SignRoundConfig(iters=3, batch_size=4, bits=4, amp=amp, amp_dtype=wdtype if amp else torch.bfloat16), device="cuda")
+    best_m = q.quantize_block(blk_m, X, others, Y, None, None)
+    st = q.last_stats
+    assert abs(st["init_loss"] - info["losses"][0]) <= 2e-3 * info["losses"][0], (st, info["losses"])
+    lo, lm = linears(blk_o), linears(blk_m)
+    agree = [(lm[n].weight == lo[n].weight).float().mean().item() for n in lo]
+    assert all(lm[n].weight.dtype == wdtype for n in lm)
+    assert np.mean(agree) > 0.97, agree
