@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -40,6 +40,7 @@ SIGNATURES = {
     "ar_best_loss_update": (c_int, [P, P, P, c_int32, P]),
     "ar_gather_rows": (c_int, [P, P, P, L, L, P]),
     "ar_pack_int": (c_int, [P, P, P, F, L, L, I, I, I, I, I, P, P, P, P]),
+    "ar_pack_awq": (c_int, [P, P, P, F, L, L, I, I, I, P, P, P, P]),
     "ar_qdq_fp4_fwd": (c_int, [P, P, P, P, F, P, P, P, L, I, I, I, F, F, P]),
     "ar_qdq_fp4_bwd_sgd": (c_int, [P, P, P, P, P, F, P, L, I, I, I, F, F, P, P, I, P, P, P, P, P, P]),
     "ar_fp4_act_bwd": (c_int, [P, P, P, P, L, I, I, I, P]),

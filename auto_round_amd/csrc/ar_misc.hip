@@ -192,11 +192,79 @@ __global__ __launch_bounds__(kTPB) void k_pack_qzeros_scales(const void* __restr
     }
 }
 
+// AWQ GEMM packer: one lane owns (input row i, word w): the eight output channels 8w..8w+7 of input i.
+// Lanes run along i, so the eight strided reads Wq[(8w+j)*in + i] are coalesced across the wave.
+template <int WDT>
+__global__ __launch_bounds__(kTPB) void k_pack_awq(const void* __restrict__ Wq, const void* __restrict__ scale,
+                                                   const float* __restrict__ zp_tensor, float zp_scalar, int64_t out_f,
+                                                   int64_t in_f, int gs, int s_dt, int32_t* __restrict__ qweight) {
+    const int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+    const int64_t w = blockIdx.y;
+    if (i >= in_f) return;
+    const int64_t n_groups = in_f / gs;
+    const int64_t ig = i / gs;
+    const int order[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t o = w * 8 + j;
+        const float s = load1_rt(s_dt, scale, o * n_groups + ig);
+        const float z = zp_tensor ? zp_tensor[o * n_groups + ig] : zp_scalar;
+        const int32_t v = (int32_t)__builtin_rintf(load1<WDT>(Wq, o * in_f + i) / s + z);
+        acc += (uint32_t)v << (4 * order[j]);
+    }
+    qweight[i * (out_f / 8) + w] = (int32_t)acc;
+}
+
+__global__ __launch_bounds__(kTPB) void k_pack_awq_zeros_scales(const void* __restrict__ scale,
+                                                                const float* __restrict__ zp_tensor, float zp_scalar,
+                                                                int64_t out_f, int64_t n_groups, int s_dt,
+                                                                int32_t* __restrict__ qzeros, uint16_t* __restrict__ scales_t) {
+    const int64_t words = out_f / 8;
+    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    const int order[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    for (int64_t t = (int64_t)blockIdx.x * kTPB + threadIdx.x; t < n_groups * words; t += stride) {
+        const int64_t ig = t / words, w = t % words;
+        uint32_t acc = 0;
+        for (int j = 0; j < 8; ++j) {
+            const int64_t o = w * 8 + j;
+            const float z = zp_tensor ? zp_tensor[o * n_groups + ig] : zp_scalar;
+            acc += (uint32_t)(int32_t)z << (4 * order[j]);
+        }
+        qzeros[t] = (int32_t)acc;
+    }
+    for (int64_t t = (int64_t)blockIdx.x * kTPB + threadIdx.x; t < n_groups * out_f; t += stride) {
+        const int64_t ig = t / out_f, o = t % out_f;
+        scales_t[t] = (uint16_t)f32_to_f16(load1_rt(s_dt, scale, o * n_groups + ig));
+    }
+}
+
 }  // namespace ar
 
 using namespace ar;
 
-extern "C" int ar_abi_version(void) { return 3; }
+extern "C" int ar_pack_awq(const void* Wq, const void* scale, const float* zp_tensor, float zp_scalar, int64_t out_f,
+                           int64_t in_f, int gs, int w_dt, int s_dt, int32_t* qweight, int32_t* qzeros, uint16_t* scales_t,
+                           ar_stream_t stream) {
+    if (gs <= 0 || in_f % gs || out_f % 8 || out_f <= 0 || in_f <= 0) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((in_f + kTPB - 1) / kTPB), (unsigned)(out_f / 8));
+    switch (w_dt) {
+        case AR_DT_BF16: hipLaunchKernelGGL(k_pack_awq<AR_DT_BF16>, grid, kTPB, 0, st, Wq, scale, zp_tensor, zp_scalar, out_f, in_f, gs, s_dt, qweight); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_pack_awq<AR_DT_F16>, grid, kTPB, 0, st, Wq, scale, zp_tensor, zp_scalar, out_f, in_f, gs, s_dt, qweight); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_pack_awq<AR_DT_F32>, grid, kTPB, 0, st, Wq, scale, zp_tensor, zp_scalar, out_f, in_f, gs, s_dt, qweight); break;
+        default: return AR_ERR_UNSUPPORTED;
+    }
+    int rc = launch_status();
+    if (rc) return rc;
+    const int64_t n_groups = in_f / gs;
+    int g2 = (int)((n_groups * out_f + kTPB - 1) / kTPB);
+    if (g2 > 2048) g2 = 2048;
+    hipLaunchKernelGGL(k_pack_awq_zeros_scales, g2, kTPB, 0, st, scale, zp_tensor, zp_scalar, out_f, n_groups, s_dt, qzeros, scales_t);
+    return launch_status();
+}
+
+extern "C" int ar_abi_version(void) { return 4; }
 
 extern "C" const char* ar_error_string(int code) {
     if (code == AR_OK) return "ok";

@@ -73,6 +73,36 @@ class QuantLinearPlain(_QuantLinearInt):
     ZP_OFF = 0
 
 
+class WQLinear_GEMM(torch.nn.Module):
+    """AWQ GEMM container, the reference's default for W4 asym (export/export_to_awq/utils.py:139-274)."""
+
+    def __init__(self, w_bit, group_size, in_features, out_features, bias, dev=None, training=False):
+        super().__init__()
+        if w_bit != 4:
+            raise NotImplementedError("Only 4-bit are supported for now.")
+        self.w_bit, self.in_features, self.out_features = w_bit, in_features, out_features
+        self.group_size = group_size if group_size != -1 else in_features
+        if in_features % self.group_size or out_features % 8:
+            raise ValueError("shape mismatch for the AWQ container")
+        self.bias = None
+
+    @classmethod
+    def from_linear(cls, linear, w_bit, group_size, init_only=False, scales=None, zeros=None, device=None):
+        """scales / zeros arrive TRANSPOSED ([in/gs, out]) like in the reference's pack_layer (export_to_awq/export.py:129-133)."""
+        q = cls(w_bit, group_size, linear.in_features, linear.out_features, linear.bias is not None)
+        if init_only:
+            return q
+        if scales is None or zeros is None:
+            raise ValueError("Both 'scales' and 'zeros' must be provided (not None)")
+        dev = linear.weight.device if linear.weight.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        s2d = scales.to(dev).t().contiguous()
+        z = zeros.to(dev).t().contiguous() if isinstance(zeros, torch.Tensor) else zeros
+        q.qweight, q.qzeros, q.scales = ops.pack_awq(linear.weight.data.to(dev).contiguous(), s2d, z, gs=q.group_size)
+        if linear.bias is not None:
+            q.bias = linear.bias.detach().clone().half()
+        return q
+
+
 class QuantLinearFP4(torch.nn.Module):
     def __init__(self, bits, group_size, infeatures, outfeatures, bias=False, data_type="mx_fp", **kwargs):
         super().__init__()
@@ -123,6 +153,13 @@ def pack_layer(layer: torch.nn.Linear, backend: str = "auto_round:auto_gptq", de
         ql = QuantLinearFP4(bits, gs, in_f, out_f, bias=layer.bias is not None, data_type=dt)
         ql.pack(layer, layer.scale, global_scale=getattr(layer, "weight_global_scale", None), device=device)
         return ql
+    if "awq" in backend:      # export_to_awq.pack_layer (export.py:114-143)
+        scale, zp = layer.scale.t().contiguous(), layer.zp
+        if isinstance(zp, torch.Tensor):
+            zp = zp.t().contiguous().to(torch.float32)
+            if sym:
+                zp = int(zp.flatten()[0])
+        return WQLinear_GEMM.from_linear(layer, bits, gs, scales=scale, zeros=zp, device=device)
     QL = dynamic_import_quant_linear_for_packing(backend, bits, gs, sym)
     ql = QL(bits, gs, in_f, out_f, bias=layer.bias is not None, weight_dtype=layer.weight.dtype)
     zp = layer.zp
@@ -134,11 +171,11 @@ def pack_layer(layer: torch.nn.Linear, backend: str = "auto_round:auto_gptq", de
 
 def pack_block(block, backend: Optional[str] = None) -> Dict[str, torch.nn.Module]:
     """Pack every tuned linear of an unwrapped block (the orchestrator's immediate_pack, orchestrator.py:327-337).
-    backend defaults to what AutoRoundFormat picks: sym int -> auto_round:auto_gptq, asym -> auto_round
-    (export/formats/backends/autoround.py:59-70)."""
+    backend defaults to what AutoRoundFormat picks: sym int -> auto_round:auto_gptq, W4 asym -> auto_round:auto_awq,
+    other asym -> auto_round (export/formats/backends/autoround.py:59-70)."""
     out = {}
     for n, m in block.named_modules():
         if isinstance(m, torch.nn.Linear) and hasattr(m, "scale") and int(getattr(m, "bits", 16)) < 16:
-            be = backend or ("auto_round:auto_gptq" if m.sym else "auto_round")
+            be = backend or ("auto_round:auto_gptq" if m.sym else ("auto_round:auto_awq" if int(m.bits) == 4 else "auto_round"))
             out[n] = pack_layer(m, be)
     return out

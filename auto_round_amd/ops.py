@@ -162,6 +162,22 @@ def pack_int(Wq2d: torch.Tensor, scale2d: torch.Tensor, zp, *, gs, bits, zp_off=
     return qweight, qzeros, scales_t
 
 
+def pack_awq(Wq2d: torch.Tensor, scale2d: torch.Tensor, zp, *, gs):
+    """AWQ GEMM container (4-bit). -> (qweight int32 [in, out/8], qzeros int32 [in/gs, out/8], scales fp16 [in/gs, out])"""
+    out_f, in_f = Wq2d.shape
+    dev = Wq2d.device
+    qweight = torch.empty((in_f, out_f // 8), dtype=torch.int32, device=dev)
+    qzeros = torch.empty((in_f // gs, out_f // 8), dtype=torch.int32, device=dev)
+    scales_t = torch.empty((in_f // gs, out_f), dtype=torch.float16, device=dev)
+    if isinstance(zp, torch.Tensor):
+        zt, zs = zp.to(device=dev, dtype=torch.float32).contiguous(), 0.0
+    else:
+        zt, zs = None, float(zp)
+    check(load().ar_pack_awq(_p(Wq2d, "Wq"), _p(scale2d, "scale"), _p(zt), zs, out_f, in_f, gs, dt_code(Wq2d.dtype),
+                             dt_code(scale2d.dtype), _p(qweight), _p(qzeros), _p(scales_t), _stream()), "ar_pack_awq")
+    return qweight, qzeros, scales_t
+
+
 def qdq_fp4_fwd(X, V, absmax, max_s, *, mode, gs, init_scale=1.0, global_scale=None, bounds=(0.0, 1.0), out=None,
                 want_scale=False):
     G = X.numel() // gs

@@ -127,6 +127,15 @@ int ar_pack_int(const void* Wq, const void* scale, const float* zp_tensor, float
                 int64_t in_f, int gs, int bits, int w_dt, int s_dt, int zp_off, int32_t* qweight, int32_t* qzeros,
                 uint16_t* scales_t, ar_stream_t stream);
 
+/* AWQ "GEMM" wire format (4-bit only), the reference's default container for W4 asym under format="auto_round"
+ * (export/formats/backends/autoround.py:61-70 -> auto_round:auto_awq).
+ * replaces: WQLinear_GEMM.from_linear (auto_round/export/export_to_awq/utils.py:196-274).
+ * qweight [in, out/8] int32: eight consecutive OUTPUT channels per word at nibble positions {0,4,1,5,2,6,3,7};
+ * qzeros [in/gs, out/8] int32: the zero points packed the same way (stored unchanged); scales [in/gs, out] fp16.
+ * Integers are rint(Wq/scale + zp) with the reference's additive (unmasked, wrapping) packing arithmetic. */
+int ar_pack_awq(const void* Wq, const void* scale, const float* zp_tensor, float zp_scalar, int64_t out_f, int64_t in_f,
+                int gs, int w_dt, int s_dt, int32_t* qweight, int32_t* qzeros, uint16_t* scales_t, ar_stream_t stream);
+
 /* ---- MXFP4 / NVFP4 fake-quant -------------------------------------------------------------------------------
  * replaces: quant_mx (auto_round/data_type/mxfp.py:233-291, element rounding :49-85) and
  *           nv_fp4 -> ref_nvfp4_quant -> cast_to_fp4 (auto_round/data_type/nvfp.py:83-98, :67-80, :26-39),

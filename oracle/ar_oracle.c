@@ -766,3 +766,39 @@ void oracle_fp4_act_bwd(const void* dXq, const void* X, float global_scale, int6
     }
     free(tmp);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * AWQ "GEMM" packer (4-bit): qweight [in, out/8] with eight consecutive output channels per word at nibble positions
+ * {0,4,1,5,2,6,3,7}; qzeros [in/gs, out/8] likewise (zero point stored unchanged); scales [in/gs, out] fp16.
+ * reference: auto_round/export/export_to_awq/utils.py:196-274 (WQLinear_GEMM.from_linear): `intweight << new_order_map`
+ * then torch.sum -> wrapping int32 SUM of unmasked values.
+ * ---------------------------------------------------------------------------------------- */
+void oracle_pack_awq(const void* Wq, const void* scale, const float* zp_tensor, float zp_scalar, int64_t out_f,
+                     int64_t in_f, int gs, int w_dt, int s_dt, int32_t* qweight, int32_t* qzeros, uint16_t* scales_t) {
+    static const int order[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    const int64_t n_groups = in_f / gs, words = out_f / 8;
+    for (int64_t i = 0; i < in_f; ++i)
+        for (int64_t w = 0; w < words; ++w) {
+            uint32_t acc = 0;
+            for (int j = 0; j < 8; ++j) {
+                int64_t o = w * 8 + j, gi = o * n_groups + i / gs;
+                float s = load_as_f32(scale, gi, s_dt);
+                float z = zp_tensor ? zp_tensor[gi] : zp_scalar;
+                int32_t v = (int32_t)nearbyintf(load_as_f32(Wq, o * in_f + i, w_dt) / s + z);
+                acc += (uint32_t)v << (4 * order[j]);
+            }
+            qweight[i * words + w] = (int32_t)acc;
+        }
+    for (int64_t ig = 0; ig < n_groups; ++ig) {
+        for (int64_t w = 0; w < words; ++w) {
+            uint32_t acc = 0;
+            for (int j = 0; j < 8; ++j) {
+                int64_t o = w * 8 + j;
+                float z = zp_tensor ? zp_tensor[o * n_groups + ig] : zp_scalar;
+                acc += (uint32_t)(int32_t)z << (4 * order[j]);
+            }
+            qzeros[ig * words + w] = (int32_t)acc;
+        }
+        for (int64_t o = 0; o < out_f; ++o) scales_t[ig * out_f + o] = f32_to_f16_bits(load_as_f32(scale, o * n_groups + ig, s_dt));
+    }
+}

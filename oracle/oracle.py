@@ -206,3 +206,13 @@ def fp4_act_bwd(dXq, X, G, gs, mode, x_dt=DT_BF16, global_scale=1.0):
     dX = np.empty(G * gs, dtype=np_dtype(x_dt))
     lib().oracle_fp4_act_bwd(_p(dXq), _p(X), _f(global_scale), ctypes.c_int64(G), gs, mode, x_dt, _p(dX))
     return dX
+
+
+def pack_awq(Wq, scale, zp, out_f, in_f, gs, w_dt=DT_BF16, s_dt=DT_F16):
+    qweight = np.empty((in_f, out_f // 8), dtype=np.int32)
+    qzeros = np.empty((in_f // gs, out_f // 8), dtype=np.int32)
+    scales_t = np.empty((in_f // gs, out_f), dtype=np.uint16)
+    zt, zs = (None, float(zp)) if not isinstance(zp, np.ndarray) else (np.ascontiguousarray(zp, np.float32), 0.0)
+    lib().oracle_pack_awq(_p(Wq), _p(scale), _p(zt), _f(zs), ctypes.c_int64(out_f), ctypes.c_int64(in_f), gs, w_dt, s_dt,
+                          _p(qweight), _p(qzeros), _p(scales_t))
+    return qweight, qzeros, scales_t

@@ -212,6 +212,12 @@ def gen_pack_int():
             rec[f"qweight_{tag}"] = ql.qweight.numpy().copy()
             rec[f"qzeros_{tag}"] = ql.qzeros.numpy().copy()
             rec[f"scales_{tag}"] = bits(ql.scales)
+        if nbits == 4:   # AWQ GEMM container through the reference's own from_linear (export_to_awq/export.py:129-142)
+            from auto_round.export.export_to_awq.utils import WQLinear_GEMM
+
+            z_awq = zp2d.t().contiguous().to(torch.float32) if isinstance(zp2d, torch.Tensor) else zp2d
+            aq = WQLinear_GEMM.from_linear(lin, nbits, gs, scales=scale2d.t().contiguous(), zeros=z_awq, device="cpu")
+            rec.update(awq_qweight=aq.qweight.numpy().copy(), awq_qzeros=aq.qzeros.numpy().copy(), awq_scales=bits(aq.scales))
         np.savez_compressed(os.path.join(HERE, f"pack_int_{name}.npz"), **rec)
         print("pack_int", name, rec["qweight_zp"].shape, rec["qzeros_zp"].shape)
 
