@@ -20,7 +20,7 @@ from .quantizer import BlockContext, SignRoundQuantizer, stack_samples
 
 def tune_blocks(blocks: Sequence[torch.nn.Module], block0_inputs, input_others: dict, quantizer: SignRoundQuantizer,
                 input_ids=None, pack: bool = False, block_names: Optional[List[str]] = None,
-                on_block_done: Optional[Callable] = None) -> List[Dict]:
+                on_block_done: Optional[Callable] = None, shard_writer=None) -> List[Dict]:
     """Sequentially tune `blocks` (already on the quantizer's device, or movable to it).  Returns one record per block:
     {"name", "stats", "best_params", "packed" (if pack)}.  Weights are baked in place like the reference does."""
     device = quantizer.device
@@ -33,8 +33,10 @@ def tune_blocks(blocks: Sequence[torch.nn.Module], block0_inputs, input_others: 
         ctx = BlockContext(block_index=k, block_cnt=n, block_name=(block_names[k] if block_names else str(k)))
         fp_out, q_out, best = quantizer.compress_block(block, fp_in, input_others, q_in, ctx, input_ids=input_ids)
         rec = {"name": ctx.block_name, "stats": dict(quantizer.last_stats), "best_params": best}
-        if pack:
+        if pack or shard_writer is not None:
             rec["packed"] = pack_block(block)
+            if shard_writer is not None:      # immediate saving: stream the finished block out (orchestrator.py:340-353)
+                shard_writer.write_block(ctx.block_name, rec["packed"])
         out.append(rec)
         if on_block_done is not None:
             on_block_done(k, block, rec)
