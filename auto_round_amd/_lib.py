@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -41,8 +41,9 @@ SIGNATURES = {
     "ar_gather_rows": (c_int, [P, P, P, L, L, P]),
     "ar_pack_int": (c_int, [P, P, P, F, L, L, I, I, I, I, I, P, P, P, P]),
     "ar_pack_awq": (c_int, [P, P, P, F, L, L, I, I, I, P, P, P, P]),
-    "ar_qdq_fp4_fwd": (c_int, [P, P, P, P, F, P, P, P, L, I, I, I, F, F, P]),
-    "ar_qdq_fp4_bwd_sgd": (c_int, [P, P, P, P, P, F, P, L, I, I, I, F, F, P, P, I, P, P, P, P, P, P]),
+    "ar_qdq_fp4_fwd": (c_int, [P, P, P, P, F, P, P, P, P, L, I, I, I, F, F, P]),
+    "ar_qdq_fp4_bwd_sgd": (c_int, [P, P, P, P, P, F, P, P, L, I, I, I, F, F, P, P, I, P, P, P, P, P, P]),
+    "ar_search_fp4_scale": (c_int, [P, P, P, L, P, P, I, P, L, I, I, I, P]),
     "ar_fp4_act_bwd": (c_int, [P, P, P, P, L, I, I, I, P]),
     "ar_pack_fp4": (c_int, [P, P, P, L, L, I, I, I, P, P, P]),
 }

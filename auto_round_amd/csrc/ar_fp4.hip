@@ -57,7 +57,7 @@ __device__ __forceinline__ float e4m3_to_f32(uint32_t b) {
 __device__ __forceinline__ float recip0(float x) { return x == 0.f ? 0.f : 1.0f / x; }
 
 struct Fp4Args {
-    const void* X; const float* V; const float* absmax; const float* max_s; const float* gscale;
+    const void* X; const float* V; const float* absmax; const float* max_s; const float* gscale; const float* init_dev;
     void* Xq; void* scale_out;
     int64_t n_groups;
     int cpg, mode;
@@ -103,20 +103,21 @@ __global__ __launch_bounds__(kTPB) void k_fp4_fwd(const Fp4Args a) {
     for (int64_t c0 = (int64_t)blockIdx.x * kTPB * U + threadIdx.x; c0 < limit; c0 += stride) {
         Raw8<XDT> xr[U];
         F8 vr[U];
-        float am[U], msr[U];
+        float am[U], msr[U], inr[U];
         bool ok[U];
         // all streaming loads of this lane are issued before anything waits on them
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t c = c0 + (int64_t)u * kTPB;
             ok[u] = c < total_chunks;
-            am[u] = 0.f; msr[u] = 1.f;
+            am[u] = 0.f; msr[u] = 1.f; inr[u] = a.init_scale;
             if (ok[u]) {
                 xr[u] = load8_raw<XDT>(a.X, c * kEPT);
                 if (a.V) vr[u] = load8_f32(a.V, c * kEPT);
                 const int64_t g = c / cpg;
                 if (a.absmax) am[u] = a.absmax[g];
                 if (a.max_s) msr[u] = a.max_s[g];
+                inr[u] = a.init_dev ? a.init_dev[g] : a.init_scale;
             }
         }
 #pragma unroll
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(kTPB) void k_fp4_fwd(const Fp4Args a) {
             const int64_t g = c / cpg;
             const float Ms = a.max_s ? clamp3(msr[u], a.lo, a.hi) : 1.0f;
             float sc, aux, rsc;
-            fp4_group_scale(a.mode, amax, Ms, a.init_scale, gscale, sc, aux, rsc);
+            fp4_group_scale(a.mode, amax, Ms, inr[u], gscale, sc, aux, rsc);
             if (a.mode == 0) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -232,13 +233,15 @@ static inline int fp4_grid(int64_t chunks) {
 }
 
 extern "C" int ar_qdq_fp4_fwd(const void* X, const float* V, const float* absmax, const float* max_s, float init_scale,
-                              const float* global_scale_dev, void* Xq, void* scale_out, int64_t n_groups, int gs, int mode,
-                              int x_dt, float lo_bound, float hi_bound, ar_stream_t stream) {
+                              const float* init_scale_dev, const float* global_scale_dev, void* Xq, void* scale_out,
+                              int64_t n_groups, int gs, int mode, int x_dt, float lo_bound, float hi_bound,
+                              ar_stream_t stream) {
     if (!((mode == 0 && gs == 32) || (mode == 1 && gs == 16)) || n_groups < 0) return AR_ERR_UNSUPPORTED;
     if (mode == 1 && !global_scale_dev) return AR_ERR_UNSUPPORTED;
     if (n_groups == 0) return AR_OK;
     Fp4Args a;
     a.X = X; a.V = V; a.absmax = absmax; a.max_s = max_s; a.gscale = global_scale_dev; a.Xq = Xq; a.scale_out = scale_out;
+    a.init_dev = init_scale_dev;
     a.n_groups = n_groups; a.cpg = gs / kEPT; a.mode = mode; a.init_scale = init_scale; a.lo = lo_bound; a.hi = hi_bound;
     const int grid = fp4_grid((n_groups * a.cpg + AR_FP4_FWD_UNROLL - 1) / AR_FP4_FWD_UNROLL);
     hipStream_t st = (hipStream_t)stream;
@@ -280,7 +283,7 @@ extern "C" int ar_pack_fp4(const void* Wq, const void* scale, const float* globa
 namespace ar {
 
 struct Fp4BwdArgs {
-    const void* dXq; const void* X; float* V; const float* absmax; float* max_s; const float* gscale;
+    const void* dXq; const void* X; float* V; const float* absmax; float* max_s; const float* gscale; const float* init_dev;
     const float* lr_v; const float* lr_mm; const int32_t* snap; float* best_V; float* best_max; float* dV_out; float* dmax_out;
     int64_t n_groups;
     int cpg, mode, tune_minmax;
@@ -302,13 +305,13 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
     for (int64_t c0 = (int64_t)blockIdx.x * kTPB * U + threadIdx.x; c0 < limit; c0 += stride) {
         Raw8<XDT> gr[U], wr[U];
         F8 vr[U];
-        float am[U], msr[U];
+        float am[U], msr[U], inr[U];
         bool okk[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t c = c0 + (int64_t)u * kTPB;
             okk[u] = c < total_chunks;
-            am[u] = 0.f; msr[u] = 1.f;
+            am[u] = 0.f; msr[u] = 1.f; inr[u] = a.init_scale;
             if (okk[u]) {
                 gr[u] = load8_raw<XDT>(a.dXq, c * kEPT);
                 wr[u] = load8_raw<XDT>(a.X, c * kEPT);
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
                 const int64_t g = c / cpg;
                 am[u] = a.absmax[g];
                 if (a.max_s) msr[u] = a.max_s[g];
+                if (a.init_dev) inr[u] = a.init_dev[g];
             }
         }
 #pragma unroll
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
             const bool ok = okk[u];
             const int64_t g = ok ? c / cpg : 0;
             float s_gq = 0.f, s_dvw = 0.f;
-            const float amax = am[u];
+            const float amax = am[u], init = inr[u];
             float Ms = 1.f, sc = 1.f, rsc = 1.f, m = 0.f, se_un = 0.f, s_pre = 0.f, r = 0.f;
             if (ok) {
                 float gg[8], w[8], v[8], dv[8];
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
                 }
                 Ms = a.max_s ? clamp3(msr[u], a.lo, a.hi) : 1.0f;
                 if (a.mode == 0) {
-                    m = amax * (a.init_scale * Ms);
+                    m = amax * (init * Ms);
                     float se = (m == 0.f) ? 1.0f : log2f(m);
                     se_un = floorf(se) - 2.0f;
                     const int sei = (int)clamp3(se_un, -127.f, 127.f);
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
                         s_dvw += dv[k] * (ws * rsc);
                     }
                 } else {
-                    const float vm = amax * (Ms * a.init_scale);
+                    const float vm = amax * (Ms * init);
                     s_pre = gscale * (vm * r6);
                     const float s = e4m3_to_f32(f32_to_e4m3(clamp3(s_pre, -448.f, 448.f)));
                     r = s * recip0(gscale);
@@ -390,13 +394,13 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
                 if (a.mode == 0) {
                     const float dsc = s_gq - s_dvw;
                     const bool pass = (se_un >= -127.f) && (se_un <= 127.f);
-                    dMs = (m == 0.f || !pass) ? 0.f : ((dsc * (sc * LN2)) / (m * LN2)) * amax * a.init_scale;
+                    dMs = (m == 0.f || !pass) ? 0.f : ((dsc * (sc * LN2)) / (m * LN2)) * amax * init;
                 } else {
                     const float dosc = (sc == 0.f) ? 0.f : (s_dvw - s_gq * (rsc * rsc));
                     const float dr = (r == 0.f) ? 0.f : -dosc * (sc * sc);
                     float ds = dr * recip0(gscale);
                     if (!((s_pre >= -448.f) && (s_pre <= 448.f))) ds = 0.f;
-                    dMs = (((ds * gscale) * r6) * amax) * a.init_scale;
+                    dMs = (((ds * gscale) * r6) * amax) * init;
                 }
                 if (a.dmax_out) a.dmax_out[g] = dMs;
                 if (a.lr_mm && a.tune_minmax && a.max_s) {
@@ -411,7 +415,8 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
 }  // namespace ar
 
 extern "C" int ar_qdq_fp4_bwd_sgd(const void* dXq, const void* X, float* V, const float* absmax, float* max_s,
-                                  float init_scale, const float* global_scale_dev, int64_t n_groups, int gs, int mode,
+                                  float init_scale, const float* init_scale_dev, const float* global_scale_dev,
+                                  int64_t n_groups, int gs, int mode,
                                   int x_dt, float lo_bound, float hi_bound, const float* lr_v_dev, const float* lr_mm_dev,
                                   int tune_minmax, const int32_t* snapshot_flag, float* best_V, float* best_max,
                                   float* dV_out, float* dmax_out, ar_stream_t stream) {
@@ -420,6 +425,7 @@ extern "C" int ar_qdq_fp4_bwd_sgd(const void* dXq, const void* X, float* V, cons
     if (n_groups == 0) return AR_OK;
     Fp4BwdArgs a;
     a.dXq = dXq; a.X = X; a.V = V; a.absmax = absmax; a.max_s = max_s; a.gscale = global_scale_dev;
+    a.init_dev = init_scale_dev;
     a.lr_v = lr_v_dev; a.lr_mm = lr_mm_dev; a.snap = snapshot_flag; a.best_V = best_V; a.best_max = best_max;
     a.dV_out = dV_out; a.dmax_out = dmax_out; a.n_groups = n_groups; a.cpg = gs / kEPT; a.mode = mode;
     a.tune_minmax = tune_minmax; a.init_scale = init_scale; a.lo = lo_bound; a.hi = hi_bound;
@@ -558,6 +564,75 @@ extern "C" int ar_fp4_act_bwd(const void* dXq, const void* X, void* dX, const fl
         case AR_DT_BF16: hipLaunchKernelGGL((k_fp4_act_bwd<AR_DT_BF16, 2>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
         case AR_DT_F16: hipLaunchKernelGGL((k_fp4_act_bwd<AR_DT_F16, 2>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
         case AR_DT_F32: hipLaunchKernelGGL((k_fp4_act_bwd<AR_DT_F32, 2>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
+        default: return AR_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// init-scale search (algorithm extension): try every candidate coefficient on every group, keep the first strictly best
+// importance-weighted squared error.  One group per gs/8 lanes, the group's elements stay in registers across all
+// candidates; the only cross-lane traffic is one butterfly sum per candidate.
+// ------------------------------------------------------------------------------------------------------------------
+namespace ar {
+template <int XDT>
+__global__ __launch_bounds__(kTPB) void k_search_fp4_scale(const void* __restrict__ X, const float* __restrict__ absmax,
+                                                           const float* __restrict__ qw_row, int64_t groups_per_row,
+                                                           const float* __restrict__ gscale_dev,
+                                                           const float* __restrict__ cand, int n_cand,
+                                                           float* __restrict__ best_out, int64_t n_groups, int cpg, int mode) {
+    const int64_t total_chunks = n_groups * cpg;
+    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    const float gscale = (mode == 1 && gscale_dev) ? *gscale_dev : 1.0f;
+    const int64_t limit = (total_chunks + kWave - 1) / kWave * kWave;
+    for (int64_t c = (int64_t)blockIdx.x * kTPB + threadIdx.x; c < limit; c += stride) {
+        const bool ok = c < total_chunks;
+        const int64_t g = ok ? c / cpg : 0;
+        float x[8], qw[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { x[k] = 0.f; qw[k] = 1.f; }
+        float amax = 0.f;
+        if (ok) {
+            unpack8<XDT>(load8_raw<XDT>(X, c * kEPT), x);
+            amax = absmax[g];
+            if (qw_row) unpack_f8(load8_f32(qw_row, ((g % groups_per_row) * cpg + (c % cpg)) * kEPT), qw);
+        }
+        float best = 0.f, best_c = 1.0f;
+        for (int ci = 0; ci < n_cand; ++ci) {
+            const float coeff = cand[ci];
+            float sc, aux, rsc;
+            fp4_group_scale(mode, amax, coeff, 1.0f, gscale, sc, aux, rsc);
+            float part = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float q;
+                if (mode == 0) q = mx_e2m1(clamp3(x[k] * rsc, -6.f, 6.f)) * sc;
+                else q = nv_e2m1(clamp3(x[k] * sc, -6.f, 6.f)) * rsc;
+                const float d = q - x[k];
+                part += (d * d) * qw[k];
+            }
+            const float loss = lanes_sum(part, cpg);
+            if (ci == 0 || loss < best) { best = loss; best_c = coeff; }
+        }
+        if (ok && (c % cpg) == 0) best_out[g] = best_c;
+    }
+}
+}  // namespace ar
+
+extern "C" int ar_search_fp4_scale(const void* X, const float* absmax, const float* qw_row, int64_t groups_per_row,
+                                   const float* global_scale_dev, const float* candidates_dev, int n_candidates,
+                                   float* best_out, int64_t n_groups, int gs, int mode, int x_dt, ar_stream_t stream) {
+    if (!((mode == 0 && gs == 32) || (mode == 1 && gs == 16)) || n_groups < 0 || n_candidates <= 0 || !absmax) return AR_ERR_UNSUPPORTED;
+    if (mode == 1 && !global_scale_dev) return AR_ERR_UNSUPPORTED;
+    if (qw_row && groups_per_row <= 0) return AR_ERR_UNSUPPORTED;
+    if (n_groups == 0) return AR_OK;
+    const int cpg = gs / kEPT;
+    const int grid = fp4_grid(n_groups * cpg);
+    hipStream_t st = (hipStream_t)stream;
+    switch (x_dt) {
+        case AR_DT_BF16: hipLaunchKernelGGL(k_search_fp4_scale<AR_DT_BF16>, grid, kTPB, 0, st, X, absmax, qw_row, groups_per_row, global_scale_dev, candidates_dev, n_candidates, best_out, n_groups, cpg, mode); break;
+        case AR_DT_F16: hipLaunchKernelGGL(k_search_fp4_scale<AR_DT_F16>, grid, kTPB, 0, st, X, absmax, qw_row, groups_per_row, global_scale_dev, candidates_dev, n_candidates, best_out, n_groups, cpg, mode); break;
+        case AR_DT_F32: hipLaunchKernelGGL(k_search_fp4_scale<AR_DT_F32>, grid, kTPB, 0, st, X, absmax, qw_row, groups_per_row, global_scale_dev, candidates_dev, n_candidates, best_out, n_groups, cpg, mode); break;
         default: return AR_ERR_UNSUPPORTED;
     }
     return launch_status();

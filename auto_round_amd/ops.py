@@ -179,28 +179,39 @@ def pack_awq(Wq2d: torch.Tensor, scale2d: torch.Tensor, zp, *, gs):
 
 
 def qdq_fp4_fwd(X, V, absmax, max_s, *, mode, gs, init_scale=1.0, global_scale=None, bounds=(0.0, 1.0), out=None,
-                want_scale=False):
+                want_scale=False, init_scale_dev=None):
     G = X.numel() // gs
     Xq = out if out is not None else torch.empty_like(X)
     scale = None
     if want_scale:
         scale = torch.empty(G, dtype=X.dtype if mode == 0 else torch.float32, device=X.device)
-    check(load().ar_qdq_fp4_fwd(_p(X, "X"), _p(V), _p(absmax), _p(max_s), init_scale, _p(global_scale), _p(Xq), _p(scale),
+    check(load().ar_qdq_fp4_fwd(_p(X, "X"), _p(V), _p(absmax), _p(max_s), init_scale, _p(init_scale_dev), _p(global_scale), _p(Xq), _p(scale),
                                 G, gs, mode, dt_code(X.dtype), bounds[0], bounds[1], _stream()), "ar_qdq_fp4_fwd")
     return (Xq, scale) if want_scale else Xq
 
 
 def qdq_fp4_bwd_sgd_(dXq, X, V, absmax, max_s, *, mode, gs, init_scale=1.0, global_scale=None, bounds=(0.0, 1.0), lr_v=None,
-                     lr_mm=None, tune_minmax=True, snapshot_flag=None, best_V=None, best_max=None, want_grads=False):
+                     lr_mm=None, tune_minmax=True, snapshot_flag=None, best_V=None, best_max=None, want_grads=False,
+                     init_scale_dev=None):
     """fp4 backward: with lr_v/lr_mm fused sign-SGD in place on V / max_s; want_grads also returns (dV, dmax)."""
     G = X.numel() // gs
     dV = torch.empty(X.numel(), dtype=torch.float32, device=X.device) if want_grads else None
     dmax = torch.empty(G, dtype=torch.float32, device=X.device) if want_grads else None
     check(load().ar_qdq_fp4_bwd_sgd(_p(dXq, "dXq"), _p(X, "X"), _p(V), _p(absmax, "absmax"), _p(max_s), init_scale,
-                                    _p(global_scale), G, gs, mode, dt_code(X.dtype), bounds[0], bounds[1], _p(lr_v),
+                                    _p(init_scale_dev), _p(global_scale), G, gs, mode, dt_code(X.dtype), bounds[0], bounds[1], _p(lr_v),
                                     _p(lr_mm), int(tune_minmax), _p(snapshot_flag), _p(best_V), _p(best_max), _p(dV),
                                     _p(dmax), _stream()), "ar_qdq_fp4_bwd_sgd")
     return (dV, dmax) if want_grads else None
+
+
+def search_fp4_scale(X, absmax, candidates, *, mode, gs, qw_row=None, groups_per_row=0, global_scale=None):
+    """Per-group init-scale search over `candidates` (fp32 device tensor, evaluated in order). -> fp32 [numel/gs]"""
+    G = X.numel() // gs
+    best = torch.empty(G, dtype=torch.float32, device=X.device)
+    check(load().ar_search_fp4_scale(_p(X, "X"), _p(absmax, "absmax"), _p(qw_row), groups_per_row, _p(global_scale),
+                                     _p(candidates, "candidates"), candidates.numel(), _p(best), G, gs, mode,
+                                     dt_code(X.dtype), _stream()), "ar_search_fp4_scale")
+    return best
 
 
 def fp4_act_bwd(dXq, X, *, mode, gs, global_scale=None, out=None):

@@ -143,16 +143,30 @@ int ar_pack_awq(const void* Wq, const void* scale, const float* zp_tensor, float
  * mode 0 = MXFP4 (gs 32; scale_out = shared exponent in the tensor dtype), 1 = NVFP4 (gs 16; scale_out fp32 holding
  * e4m3 values; global_scale_dev = device fp32).  absmax [n_groups] fp32 from ar_group_absmax (weights: computed once). */
 int ar_qdq_fp4_fwd(const void* X, const float* V, const float* absmax, const float* max_s, float init_scale,
-                   const float* global_scale_dev, void* Xq, void* scale_out, int64_t n_groups, int gs, int mode,
-                   int x_dt, float lo_bound, float hi_bound, ar_stream_t stream);
+                   const float* init_scale_dev, const float* global_scale_dev, void* Xq, void* scale_out,
+                   int64_t n_groups, int gs, int mode, int x_dt, float lo_bound, float hi_bound, ar_stream_t stream);
+/* init_scale_dev (optional, fp32 [n_groups]) replaces the scalar init_scale per group: the searched init scale of the
+ * reference's algorithm extension (SignRoundOptimizedWrapperLinear, sign_roundv2/quantizer.py:101-126). */
 /* fused backward + sign-SGD for the fp4 weight path (V and max_scale); same contract as ar_qdq_int_bwd_sgd.
  * dV_out/dmax_out (optional) additionally export the raw gradients for parity tests (then no update is applied
  * when lr_v_dev == NULL). */
 int ar_qdq_fp4_bwd_sgd(const void* dXq, const void* X, float* V, const float* absmax, float* max_s, float init_scale,
-                       const float* global_scale_dev, int64_t n_groups, int gs, int mode, int x_dt, float lo_bound,
+                       const float* init_scale_dev, const float* global_scale_dev, int64_t n_groups, int gs, int mode,
+                       int x_dt, float lo_bound,
                        float hi_bound, const float* lr_v_dev, const float* lr_mm_dev, int tune_minmax,
                        const int32_t* snapshot_flag, float* best_V, float* best_max, float* dV_out, float* dmax_out,
                        ar_stream_t stream);
+
+/* ---- init-scale search for the fp4 schemes (algorithm extension) ------------------------------------------------
+ * replaces: search_mx_scale (auto_round/data_type/mxfp.py:102-169: candidates 1.0, 0.5, 2.0) and search_nvfp4_scale
+ *           (auto_round/data_type/nvfp.py:328-386: 1.0 then 0.50 ... 1.51 step 0.01).
+ * For every group: evaluates the fake-quant (V = 0) with max_scale := candidate c for c in candidates (in order) and
+ * keeps the first candidate with the strictly smallest importance-weighted squared error
+ * sum_k (qdq_k - x_k)^2 * qw_k.  qw_row (optional fp32 [in_pad]) is the per-input-channel importance (imatrix); the
+ * weight of element k of group g is qw_row[(g % groups_per_row) * gs + k]; NULL means 1.  best_out fp32 [n_groups]. */
+int ar_search_fp4_scale(const void* X, const float* absmax, const float* qw_row, int64_t groups_per_row,
+                        const float* global_scale_dev, const float* candidates_dev, int n_candidates, float* best_out,
+                        int64_t n_groups, int gs, int mode, int x_dt, ar_stream_t stream);
 
 /* activation fake-quant backward w.r.t. the INPUT (dynamic per-group scale taken from the data itself).
  * replaces: autograd through WrapperLinear._qdq_act (auto_round/wrapper.py:295-321, :530-540) -> quant_mx(x, v=0) /

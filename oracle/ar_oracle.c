@@ -802,3 +802,49 @@ void oracle_pack_awq(const void* Wq, const void* scale, const float* zp_tensor, 
         for (int64_t o = 0; o < out_f; ++o) scales_t[ig * out_f + o] = f32_to_f16_bits(load_as_f32(scale, o * n_groups + ig, s_dt));
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * fp4 init-scale search (algorithm extension)
+ * reference: search_mx_scale (auto_round/data_type/mxfp.py:102-169) and search_nvfp4_scale
+ *            (auto_round/data_type/nvfp.py:328-386).  For each group: loss_c = sum_k (qdq_c(x_k) - x_k)^2 * qw_k for the
+ * candidates in order; the first candidate with the strictly smallest loss wins.  fp32 arithmetic, sequential fp32 sum
+ * (torch's reduction order is unspecified; near-ties can resolve differently).  qw_row: [in_pad] per-input-channel
+ * importance or NULL (== 1); element k of group g uses qw_row[(g % groups_per_row)*gs + k].
+ * ---------------------------------------------------------------------------------------- */
+void oracle_search_fp4_scale(const void* X, const float* qw_row, int64_t groups_per_row, float global_scale,
+                             const float* cand, int n_cand, int64_t G, int gs, int mode, int x_dt, float* best_out) {
+    const float r6 = (float)(1.0 / 6.0);
+    for (int64_t g = 0; g < G; ++g) {
+        float amax = 0.f;
+        for (int k = 0; k < gs; ++k) { float a = fabsf(load_as_f32(X, g * gs + k, x_dt)); if (a > amax) amax = a; }
+        float best = 0.f, best_c = 1.0f;
+        for (int ci = 0; ci < n_cand; ++ci) {
+            const float coeff = cand[ci];
+            float sc = 1.f, rsc = 1.f;
+            if (mode == 0) {
+                const float mv = amax * coeff;
+                float se = (mv == 0.f) ? 1.0f : log2f(mv);
+                se = clampf(floorf(se) - 2.0f, -127.f, 127.f);
+                sc = exp2f(se);
+            } else {
+                const float vm = amax * coeff;
+                float s = clampf(global_scale * (vm * r6), -448.f, 448.f);
+                s = e4m3_bits_to_f32(f32_to_e4m3_bits(s));
+                sc = recip0(s * recip0(global_scale));
+                rsc = recip0(sc);
+            }
+            float loss = 0.f;
+            for (int k = 0; k < gs; ++k) {
+                const float x = load_as_f32(X, g * gs + k, x_dt);
+                float q;
+                if (mode == 0) q = mx_quant_element_fp4(clampf(x / sc, -6.f, 6.f)) * sc;
+                else q = cast_to_fp4_ref(clampf(x * sc, -6.f, 6.f)) * rsc;
+                const float d = q - x;
+                const float w = qw_row ? qw_row[(g % groups_per_row) * gs + k] : 1.0f;
+                loss += (d * d) * w;
+            }
+            if (ci == 0 || loss < best) { best = loss; best_c = coeff; }
+        }
+        best_out[g] = best_c;
+    }
+}

@@ -216,3 +216,19 @@ def pack_awq(Wq, scale, zp, out_f, in_f, gs, w_dt=DT_BF16, s_dt=DT_F16):
     lib().oracle_pack_awq(_p(Wq), _p(scale), _p(zt), _f(zs), ctypes.c_int64(out_f), ctypes.c_int64(in_f), gs, w_dt, s_dt,
                           _p(qweight), _p(qzeros), _p(scales_t))
     return qweight, qzeros, scales_t
+
+
+def fp4_candidates(mode: int) -> np.ndarray:
+    """Candidate coefficients in the reference's evaluation order (mxfp.py:147 ; nvfp.py:358-362)."""
+    if mode == 0:
+        return np.array([1.0, 0.5, 2.0], dtype=np.float32)
+    return np.array([1.0] + [v / 100.0 for v in range(50, 152) if v != 100], dtype=np.float32)
+
+
+def search_fp4_scale(X, G, gs, mode, x_dt=DT_BF16, qw_row=None, groups_per_row=0, global_scale=1.0):
+    cand = fp4_candidates(mode)
+    best = np.empty(G, dtype=np.float32)
+    qw = None if qw_row is None else np.ascontiguousarray(qw_row, dtype=np.float32)
+    lib().oracle_search_fp4_scale(_p(X), _p(qw), ctypes.c_int64(groups_per_row), _f(global_scale), _p(cand), len(cand),
+                                  ctypes.c_int64(G), gs, mode, x_dt, _p(best))
+    return best

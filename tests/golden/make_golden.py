@@ -369,3 +369,46 @@ def gen_act():
 
 if __name__ == "__main__" and ("act" in sys.argv[1:] or not sys.argv[1:]):
     gen_act()
+
+
+def gen_search():
+    """Init-scale searches of the algorithm extension: search_mx_scale / search_nvfp4_scale / search_scales (+ the
+    threshold clamp of search_int), with a per-input-channel importance matrix expanded like reshape_imatrix_for_weight."""
+    from auto_round.data_type.int import search_scales
+    from auto_round.data_type.mxfp import search_mx_scale
+    from auto_round.data_type.nvfp import search_nvfp4_scale
+    from auto_round.data_type.utils import reshape_imatrix_for_weight, search_optimized_init_scale
+
+    rows, cols = 48, 256
+    g = torch.Generator().manual_seed(77)
+    imatrix = (torch.rand(cols, generator=g) * 4.0 + 0.01) ** 2 * 100.0
+    imatrix[5] = 0.0
+    rec = {"imatrix": imatrix.numpy()}
+    for kind, gs in (("mxfp4", 32), ("nvfp4", 16)):
+        W = make_weight(rows, cols, gs, torch.bfloat16, seed=33)
+        Wg = W.reshape(-1, gs)
+        qw = reshape_imatrix_for_weight(imatrix, Wg, gs)
+        fn = search_mx_scale if kind == "mxfp4" else search_nvfp4_scale
+        best_qw = fn(Wg, 4, qw)
+        best_1 = fn(Wg, 4, torch.ones_like(Wg, dtype=torch.float32))
+        rec[f"{kind}_W"] = bits(W)
+        rec[f"{kind}_best_qw"] = best_qw.reshape(-1).float().numpy()
+        rec[f"{kind}_best_ones"] = best_1.reshape(-1).float().numpy()
+        print("search", kind, "distinct:", sorted(set(np.round(best_qw.reshape(-1).float().numpy(), 2).tolist()))[:8])
+    for nbits, gs in ((4, 128), (2, 32), (3, 64)):
+        W = make_weight(rows, cols, gs, torch.bfloat16, seed=34 + nbits)
+        Wg = W.reshape(-1, gs)
+        qw = reshape_imatrix_for_weight(imatrix, Wg, gs)
+        s_raw = search_scales(Wg, nbits, qw)
+        s_init = search_optimized_init_scale(Wg, "int_sym", nbits, qw, 1e-5)
+        s_ones = search_optimized_init_scale(Wg, "int_sym", nbits, None, 1e-5)
+        rec[f"int{nbits}g{gs}_W"] = bits(W)
+        rec[f"int{nbits}g{gs}_raw"] = bits(s_raw.reshape(-1))
+        rec[f"int{nbits}g{gs}_init"] = bits(s_init.reshape(-1))
+        rec[f"int{nbits}g{gs}_init_ones"] = bits(s_ones.reshape(-1))
+        print("search int", nbits, gs, s_init.dtype, tuple(s_init.shape))
+    np.savez_compressed(os.path.join(HERE, "search.npz"), **rec)
+
+
+if __name__ == "__main__" and ("search" in sys.argv[1:] or not sys.argv[1:]):
+    gen_search()
