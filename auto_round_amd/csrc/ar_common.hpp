@@ -219,7 +219,7 @@ __device__ __forceinline__ float lanes_min(float v, int width) {
 // Mirrors auto_round/data_type/int.py:221-227 (sym) and :283-293 (asym) with the dtype choreography of
 // SURVEY App. A.1/A.2; min/max scale are clamped to [lo,hi] as WrapperLinear._qdq_weight does (wrapper.py:257-259).
 struct IntCfg {
-    int bits, sym, s_dt, w_dt;
+    int bits, sym, s_dt, w_dt;   // sym: 0 asym, 1 sym ("full range"), 2 sym with a searched init scale in the wmax slot
     float thresh;      // q_scale_thresh
     float lo, hi;      // min/max-scale bounds
 };
@@ -234,7 +234,15 @@ __device__ __forceinline__ void group_scale(const IntCfg& c, float wmin, float w
     q.Ms = clamp3(Ms_raw, c.lo, c.hi);
     q.wmin = wmin; q.wmax = wmax;
     const float t = round_to_rt(c.s_dt, c.thresh);
-    if (c.sym) {
+    if (c.sym == 2) {
+        // algorithm-extension sym path: the searched init_scale rides in the wmax slot (data_type/int.py:201-216)
+        q.a = 0.f;
+        q.b = wmax * q.Ms;
+        q.sgn = 1.f;
+        q.s_raw = round_to_rt(c.s_dt, q.b);
+        q.s = (q.s_raw < 0.f) ? ((q.s_raw > -t) ? -t : q.s_raw) : ((q.s_raw < t) ? t : q.s_raw);
+        q.zp = (float)(1 << (c.bits - 1));
+    } else if (c.sym) {
         const float maxq = (float)(1 << (c.bits - 1));
         q.a = -(wmin * q.ms);
         q.b = wmax * q.Ms;

@@ -279,7 +279,10 @@ __device__ __forceinline__ void minmax_grads(const IntCfg& cfg, const GroupQ& q,
     if (sym) ds = (q.s_raw < 0.f) ? ((q.s_raw <= -t) ? ds_c : 0.f) : ((q.s_raw >= t) ? ds_c : 0.f);
     else ds = (q.s_raw >= t) ? ds_c : 0.f;
     const float d32 = ds / maxq;
-    if (sym) {
+    if (cfg.sym == 2) {      // scale = (init_scale * max_scale).to(s_dt); min_scale is not part of the graph
+        gmin = 0.f;
+        gmax = ds * q.wmax;
+    } else if (sym) {
         const float dm = d32 * q.sgn;
         float da, db;
         if (q.a == q.b) { da = dm / 2.f; db = dm / 2.f; }
@@ -695,7 +698,7 @@ static inline bool fill_cfg(IntCfg& c, float& qlo, float& qhi, int bits, int sym
                             float hi) {
     if (bits < 2 || bits > 8) return false;
     if (w_dt < 0 || w_dt > 2 || s_dt < 0 || s_dt > 2) return false;
-    c.bits = bits; c.sym = sym ? 1 : 0; c.s_dt = s_dt; c.w_dt = w_dt; c.thresh = th; c.lo = lo; c.hi = hi;
+    c.bits = bits; c.sym = sym == 2 ? 2 : (sym ? 1 : 0); c.s_dt = s_dt; c.w_dt = w_dt; c.thresh = th; c.lo = lo; c.hi = hi;
     if (sym) { const float m = (float)(1 << (bits - 1)); qlo = -m; qhi = m - 1.f; }
     else { qlo = 0.f; qhi = (float)((1 << bits) - 1); }
     return true;
@@ -915,5 +918,155 @@ extern "C" int ar_sign_sgd(float* p, const float* g, int64_t n, const float* lr_
     if (n <= 0) return AR_OK;
     const int grid = grid_for_tiles((n / 4 + kTPB - 1) / kTPB);
     hipLaunchKernelGGL(k_sign_sgd, grid, kTPB, 0, (hipStream_t)stream, p, g, n, lr_dev);
+    return launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// int-sym init-scale search of the algorithm extension (search_scales, auto_round/data_type/int.py:24-86, + the
+// threshold clamp of search_int, data_type/utils.py:203-209).  Runs once per layer before tuning.  A lane-group owns a
+// group and keeps its 8 elements per lane in registers across the ~400 candidates; groups that do not fit a lane-group
+// take a whole wave and re-read their chunks from L2 per candidate.  All arithmetic is rounded to the weight dtype
+// where torch rounds it.
+// ------------------------------------------------------------------------------------------------------------------
+namespace ar {
+template <int XDT> __device__ __forceinline__ float recip_dt(float t) {
+    const float eps = round_to<XDT>(XDT == AR_DT_F16 ? 1e-5f : 1e-30f);
+    return fabsf(t) >= eps ? round_to<XDT>(1.0f / t) : 0.f;
+}
+template <int XDT> __device__ __forceinline__ float search_loss8(const float (&x)[8], const float (&qw)[8], float isc, float sc,
+                                                                 float nmax) {
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float L = clamp3(__builtin_rintf(round_to<XDT>(isc * x[k])), -nmax, nmax - 1.f);
+        const float e = round_to<XDT>(round_to<XDT>(sc * L) - x[k]);
+        part += (e * e) * qw[k];
+    }
+    return part;
+}
+// first-index arg-max of |x| over `width` lanes: (abs, flat index, signed value)
+__device__ __forceinline__ void lanes_argmax(float& a, int& idx, float& v, int width) {
+    for (int m = width >> 1; m > 0; m >>= 1) {
+        const float oa = __shfl_xor(a, m, kWave);
+        const int oi = __shfl_xor(idx, m, kWave);
+        const float ov = __shfl_xor(v, m, kWave);
+        if (oa > a || (oa == a && oi < idx)) { a = oa; idx = oi; v = ov; }
+    }
+}
+
+template <int XDT>
+__global__ __launch_bounds__(kTPB) void k_search_int_scale(const void* __restrict__ X, const float* __restrict__ qw_row,
+                                                           int64_t groups_per_row, const float* __restrict__ cand,
+                                                           int n_cand, void* __restrict__ out_raw,
+                                                           void* __restrict__ out_init, int64_t n_groups, int cpg,
+                                                           float nmax, float thresh) {
+    const int64_t total_chunks = n_groups * cpg;
+    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    const int64_t limit = (total_chunks + kWave - 1) / kWave * kWave;
+    const float th = round_to<XDT>(thresh);
+    for (int64_t c = (int64_t)blockIdx.x * kTPB + threadIdx.x; c < limit; c += stride) {
+        const bool ok = c < total_chunks;
+        const int64_t g = ok ? c / cpg : 0;
+        const int cin = ok ? (int)(c % cpg) : 0;
+        float x[8], qw[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { x[k] = 0.f; qw[k] = ok ? 1.f : 0.f; }
+        if (ok) {
+            unpack8<XDT>(load8_raw<XDT>(X, c * kEPT), x);
+            if (qw_row) unpack_f8(load8_f32(qw_row, ((g % groups_per_row) * cpg + cin) * kEPT), qw);
+        }
+        float am = -1.f, gv = 0.f;
+        int ai = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (fabsf(x[k]) > am) { am = fabsf(x[k]); gv = x[k]; ai = cin * 8 + k; }
+        if (!ok) am = -2.f;
+        lanes_argmax(am, ai, gv, cpg);
+        const float rg = recip_dt<XDT>(gv);
+        float best = 0.f, best_s = 0.f;
+        for (int ci = 0; ci < n_cand; ++ci) {
+            const float isc = round_to<XDT>((-cand[ci]) * rg);
+            const float sc = recip_dt<XDT>(isc);
+            const float loss = lanes_sum(search_loss8<XDT>(x, qw, isc, sc, nmax), cpg);
+            if (ci == 0 || loss < best) { best = loss; best_s = sc; }
+        }
+        if (ok && cin == 0) {
+            if (out_raw) store1<XDT>(out_raw, g, best_s);
+            const float cl = best_s < 0.f ? (best_s > -th ? -th : best_s) : (best_s < th ? th : best_s);
+            if (out_init) store1<XDT>(out_init, g, cl);
+        }
+    }
+}
+
+template <int XDT>
+__global__ __launch_bounds__(kTPB) void k_search_int_scale_wave(const void* __restrict__ X, const float* __restrict__ qw_row,
+                                                                int64_t groups_per_row, const float* __restrict__ cand,
+                                                                int n_cand, void* __restrict__ out_raw,
+                                                                void* __restrict__ out_init, int64_t n_groups, int cpg,
+                                                                float nmax, float thresh) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave0 = ((int64_t)blockIdx.x * kTPB + threadIdx.x) / kWave;
+    const int64_t n_waves = (int64_t)gridDim.x * (kTPB / kWave);
+    const float th = round_to<XDT>(thresh);
+    for (int64_t g = wave0; g < n_groups; g += n_waves) {
+        float am = -1.f, gv = 0.f;
+        int ai = 0;
+        for (int ch = lane; ch < cpg; ch += kWave) {
+            float x[8];
+            unpack8<XDT>(load8_raw<XDT>(X, (g * cpg + ch) * kEPT), x);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (fabsf(x[k]) > am) { am = fabsf(x[k]); gv = x[k]; ai = ch * 8 + k; }
+        }
+        lanes_argmax(am, ai, gv, kWave);
+        const float rg = recip_dt<XDT>(gv);
+        float best = 0.f, best_s = 0.f;
+        for (int ci = 0; ci < n_cand; ++ci) {
+            const float isc = round_to<XDT>((-cand[ci]) * rg);
+            const float sc = recip_dt<XDT>(isc);
+            float part = 0.f;
+            for (int ch = lane; ch < cpg; ch += kWave) {
+                float x[8], qw[8];
+                unpack8<XDT>(load8_raw<XDT>(X, (g * cpg + ch) * kEPT), x);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) qw[k] = 1.f;
+                if (qw_row) unpack_f8(load8_f32(qw_row, ((g % groups_per_row) * cpg + ch) * kEPT), qw);
+                part += search_loss8<XDT>(x, qw, isc, sc, nmax);
+            }
+            const float loss = lanes_sum(part, kWave);
+            if (ci == 0 || loss < best) { best = loss; best_s = sc; }
+        }
+        if (lane == 0) {
+            if (out_raw) store1<XDT>(out_raw, g, best_s);
+            const float cl = best_s < 0.f ? (best_s > -th ? -th : best_s) : (best_s < th ? th : best_s);
+            if (out_init) store1<XDT>(out_init, g, cl);
+        }
+    }
+}
+}  // namespace ar
+
+extern "C" int ar_search_int_scale(const void* X, const float* qw_row, int64_t groups_per_row, const float* candidates_dev,
+                                   int n_candidates, void* out_raw, void* out_init, int64_t n_groups, int gs, int bits,
+                                   int x_dt, float q_thresh, ar_stream_t stream) {
+    if (gs <= 0 || gs % kEPT || n_groups < 0 || n_candidates <= 0 || !candidates_dev || bits < 2 || bits > 8) return AR_ERR_UNSUPPORTED;
+    if (qw_row && groups_per_row <= 0) return AR_ERR_UNSUPPORTED;
+    if (n_groups == 0) return AR_OK;
+    const int cpg = gs / kEPT;
+    const bool lane_groups = cpg <= kWave && ilog2_exact(cpg) >= 0;
+    const float nmax = (float)(1 << (bits - 1));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t want = lane_groups ? (n_groups * cpg + kTPB - 1) / kTPB : (n_groups + kTPB / kWave - 1) / (kTPB / kWave);
+    const int grid = (int)(want < 1 ? 1 : (want > (1 << 20) ? (1 << 20) : want));
+#define AR_LAUNCH_SEARCH(DT)                                                                                              \
+    if (lane_groups) hipLaunchKernelGGL(k_search_int_scale<DT>, grid, kTPB, 0, st, X, qw_row, groups_per_row, candidates_dev, \
+                                        n_candidates, out_raw, out_init, n_groups, cpg, nmax, q_thresh);                  \
+    else hipLaunchKernelGGL(k_search_int_scale_wave<DT>, grid, kTPB, 0, st, X, qw_row, groups_per_row, candidates_dev,    \
+                            n_candidates, out_raw, out_init, n_groups, cpg, nmax, q_thresh)
+    switch (x_dt) {
+        case AR_DT_BF16: AR_LAUNCH_SEARCH(AR_DT_BF16); break;
+        case AR_DT_F16: AR_LAUNCH_SEARCH(AR_DT_F16); break;
+        case AR_DT_F32: AR_LAUNCH_SEARCH(AR_DT_F32); break;
+        default: return AR_ERR_UNSUPPORTED;
+    }
+#undef AR_LAUNCH_SEARCH
     return launch_status();
 }

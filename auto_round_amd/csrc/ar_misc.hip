@@ -80,6 +80,144 @@ __global__ __launch_bounds__(kTPB) void k_mse_stage2(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// outlier-suppressed loss: two-level radix select of the k-th largest |pred-ref| (15-bit magnitude key of the 16-bit
+// difference: 8 high bits, then 7 low bits inside the selected bin), then the masked MSE pass.  Exactly `topk` elements
+// are dropped: every key above the k-th one, plus the lowest-index elements tied with it.  Every workgroup owns one
+// contiguous range of chunks so the tie rank is an ordered prefix: per-workgroup level-2 histograms give the number of
+// ties in the ranges before it, a block scan orders the ties inside it.
+// workspace layout: double partials[kMseMaxBlocks] | u32 hist1[256] | u32 hist2[128] | u32 block_hist2[kMseMaxBlocks][128]
+// ------------------------------------------------------------------------------------------------------------------
+template <int ADT> __device__ __forceinline__ uint32_t diff_key15(float p, float r) {
+    // |pred - ref| evaluated in the activation dtype, magnitude bits only
+    if constexpr (ADT == AR_DT_BF16) return f32_to_bf16(p - r) & 0x7fffu;
+    else return f32_to_f16(p - r) & 0x7fffu;
+}
+__device__ __forceinline__ void select_from_top(const uint32_t* hist, int nbins, uint64_t want, int& bin, uint64_t& above) {
+    // the bin b with count(bins > b) < want <= count(bins >= b); `above` = count(bins > b)
+    uint64_t cum = 0;
+    for (int b = nbins - 1; b > 0; --b) {
+        const uint64_t c = hist[b];
+        if (cum + c >= want) { bin = b; above = cum; return; }
+        cum += c;
+    }
+    bin = 0; above = cum;
+}
+
+template <int ADT, int LEVEL>
+__global__ __launch_bounds__(kTPB) void k_outlier_hist(const void* __restrict__ pred, const void* __restrict__ ref,
+                                                       int64_t n_chunks, int64_t chunks_per_block,
+                                                       uint32_t* __restrict__ hist1, uint32_t* __restrict__ hist2,
+                                                       uint32_t* __restrict__ block_hist2, uint64_t topk) {
+    __shared__ uint32_t lh[256];
+    __shared__ int sbin;
+    for (int i = threadIdx.x; i < 256; i += kTPB) lh[i] = 0;
+    if (LEVEL == 2 && threadIdx.x == 0) { int b; uint64_t ab; select_from_top(hist1, 256, topk, b, ab); sbin = b; }
+    __syncthreads();
+    const int b1 = LEVEL == 2 ? sbin : 0;
+    const int64_t c_lo = (int64_t)blockIdx.x * chunks_per_block;
+    const int64_t c_hi = c_lo + chunks_per_block < n_chunks ? c_lo + chunks_per_block : n_chunks;
+    for (int64_t c = c_lo + threadIdx.x; c < c_hi; c += kTPB) {
+        float p[8], r[8];
+        unpack8<ADT>(load8_raw<ADT>(pred, c * kEPT), p);
+        unpack8<ADT>(load8_raw<ADT>(ref, c * kEPT), r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t key = diff_key15<ADT>(p[k], r[k]);
+            if (LEVEL == 1) atomicAdd(&lh[key >> 7], 1u);
+            else if ((int)(key >> 7) == b1) atomicAdd(&lh[key & 127u], 1u);
+        }
+    }
+    __syncthreads();
+    if (LEVEL == 1) {
+        for (int i = threadIdx.x; i < 256; i += kTPB) if (lh[i]) atomicAdd(&hist1[i], lh[i]);
+    } else {
+        for (int i = threadIdx.x; i < 128; i += kTPB) {
+            block_hist2[(int64_t)blockIdx.x * 128 + i] = lh[i];
+            if (lh[i]) atomicAdd(&hist2[i], lh[i]);
+        }
+    }
+}
+
+template <int ADT>
+__global__ __launch_bounds__(kTPB) void k_outlier_mse(const void* __restrict__ pred, const void* __restrict__ ref,
+                                                      void* __restrict__ dpred, double* __restrict__ partials,
+                                                      int64_t n_chunks, int64_t chunks_per_block, float alpha, float gout,
+                                                      const uint8_t* __restrict__ mask, int64_t row_len,
+                                                      const uint32_t* __restrict__ hist1, const uint32_t* __restrict__ hist2,
+                                                      const uint32_t* __restrict__ block_hist2, uint64_t topk) {
+    __shared__ double red[kTPB / kWave];
+    __shared__ uint32_t sthr, sneed, sprefix;
+    __shared__ uint32_t wtot[2][kTPB / kWave];
+    if (threadIdx.x == 0) {
+        int b1, b2; uint64_t ab1, ab2;
+        select_from_top(hist1, 256, topk, b1, ab1);
+        select_from_top(hist2, 128, topk - ab1, b2, ab2);
+        sthr = ((uint32_t)b1 << 7) | (uint32_t)b2;        // the k-th largest key
+        sneed = (uint32_t)(topk - ab1 - ab2);               // how many elements tied with it are dropped too (>= 1)
+        sprefix = 0;
+    }
+    __syncthreads();
+    const uint32_t thr = sthr, need = sneed;
+    {   // ties that live in the ranges of the workgroups before this one
+        uint32_t t = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += kTPB) t += block_hist2[(int64_t)b * 128 + (thr & 127u)];
+        for (int m = kWave >> 1; m > 0; m >>= 1) t += __shfl_xor(t, m, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0 && t) atomicAdd(&sprefix, t);
+    }
+    __syncthreads();
+    uint32_t running = sprefix;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int64_t c_lo = (int64_t)blockIdx.x * chunks_per_block;
+    const int64_t c_hi = c_lo + chunks_per_block < n_chunks ? c_lo + chunks_per_block : n_chunks;
+    const int64_t iters = (chunks_per_block + kTPB - 1) / kTPB;
+    float acc = 0.f;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t c = c_lo + it * kTPB + threadIdx.x;
+        const bool live = c < c_hi;
+        float p[8], r[8], d[8];
+        uint32_t key[8];
+        uint32_t tc = 0;
+        if (live) {
+            unpack8<ADT>(load8_raw<ADT>(pred, c * kEPT), p);
+            unpack8<ADT>(load8_raw<ADT>(ref, c * kEPT), r);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { key[k] = diff_key15<ADT>(p[k], r[k]); tc += key[k] == thr; }
+        }
+        uint32_t incl = tc;                                  // ordered (index-order) scan of the tie counts
+        for (int m = 1; m < kWave; m <<= 1) { const uint32_t o = __shfl_up(incl, m, kWave); if (lane >= m) incl += o; }
+        if (lane == kWave - 1) wtot[it & 1][wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kTPB / kWave; ++w) { const uint32_t t = wtot[it & 1][w]; total += t; woff += w < wave ? t : 0u; }
+        uint32_t rank = running + woff + incl - tc;
+        running += total;
+        if (live) {
+            const bool valid = mask == nullptr || mask[(c * kEPT) / row_len] != 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                bool drop = key[k] > thr;
+                if (key[k] == thr) { drop = rank < need; ++rank; }
+                const bool keep = valid && !drop;
+                const float df = keep ? p[k] - r[k] : 0.f;
+                acc += df * df;
+                d[k] = keep ? (alpha * df) * gout : 0.f;
+            }
+            if (dpred) store8<ADT>(dpred, c * kEPT, d);
+        }
+    }
+    double dacc = (double)acc;
+    for (int m = kWave >> 1; m > 0; m >>= 1) dacc += __shfl_xor(dacc, m, kWave);
+    if (lane == 0) red[wave] = dacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < kTPB / kWave; ++w) s += red[w];
+        partials[blockIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // best-loss bookkeeping (one lane)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void k_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter) {
@@ -264,7 +402,7 @@ extern "C" int ar_pack_awq(const void* Wq, const void* scale, const float* zp_te
     return launch_status();
 }
 
-extern "C" int ar_abi_version(void) { return 5; }
+extern "C" int ar_abi_version(void) { return 6; }
 
 extern "C" const char* ar_error_string(int code) {
     if (code == AR_OK) return "ok";
@@ -292,6 +430,49 @@ extern "C" int ar_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpre
         default: return AR_ERR_UNSUPPORTED;
     }
     int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mse_stage2, 1, kTPB, 0, st, partials, grid, n, loss_out, loss_accum, accum_scale);
+    return launch_status();
+}
+
+extern "C" int64_t ar_outlier_loss_workspace_bytes(void) {
+    return (int64_t)kMseMaxBlocks * sizeof(double) + (256 + 128 + (int64_t)kMseMaxBlocks * 128) * sizeof(uint32_t);
+}
+
+extern "C" int ar_outlier_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpred, float* loss_out, float* loss_accum,
+                                           float accum_scale, int64_t n, int act_dt, float grad_scale,
+                                           const uint8_t* token_mask, int64_t row_len, int64_t topk, void* workspace,
+                                           ar_stream_t stream) {
+    if (n <= 0 || n % kEPT || !workspace || topk < 1 || topk > n) return AR_ERR_UNSUPPORTED;
+    if (act_dt != AR_DT_BF16 && act_dt != AR_DT_F16) return AR_ERR_UNSUPPORTED;
+    if (token_mask && (row_len <= 0 || row_len % kEPT || n % row_len)) return AR_ERR_UNSUPPORTED;
+    if (!token_mask) row_len = 1;
+    hipStream_t st = (hipStream_t)stream;
+    double* partials = (double*)workspace;
+    uint32_t* hist1 = (uint32_t*)(partials + kMseMaxBlocks);
+    uint32_t* hist2 = hist1 + 256;
+    uint32_t* bh2 = hist2 + 128;
+    int rc = (int)hipMemsetAsync(hist1, 0, (256 + 128) * sizeof(uint32_t), st);
+    if (rc) return rc;
+    const int64_t n_chunks = n / kEPT;
+    int64_t want = (n_chunks + kTPB - 1) / kTPB;
+    int grid = (int)(want < 1 ? 1 : (want > kMseMaxBlocks ? kMseMaxBlocks : want));
+    const int64_t cpb = (n_chunks + grid - 1) / grid;
+    grid = (int)((n_chunks + cpb - 1) / cpb);
+    const float alpha = (float)(2.0 / (double)n);
+    const uint64_t k = (uint64_t)topk;
+    if (act_dt == AR_DT_BF16) {
+        hipLaunchKernelGGL((k_outlier_hist<AR_DT_BF16, 1>), grid, kTPB, 0, st, pred, ref, n_chunks, cpb, hist1, hist2, bh2, k);
+        hipLaunchKernelGGL((k_outlier_hist<AR_DT_BF16, 2>), grid, kTPB, 0, st, pred, ref, n_chunks, cpb, hist1, hist2, bh2, k);
+        hipLaunchKernelGGL(k_outlier_mse<AR_DT_BF16>, grid, kTPB, 0, st, pred, ref, dpred, partials, n_chunks, cpb, alpha,
+                           grad_scale, token_mask, row_len, hist1, hist2, bh2, k);
+    } else {
+        hipLaunchKernelGGL((k_outlier_hist<AR_DT_F16, 1>), grid, kTPB, 0, st, pred, ref, n_chunks, cpb, hist1, hist2, bh2, k);
+        hipLaunchKernelGGL((k_outlier_hist<AR_DT_F16, 2>), grid, kTPB, 0, st, pred, ref, n_chunks, cpb, hist1, hist2, bh2, k);
+        hipLaunchKernelGGL(k_outlier_mse<AR_DT_F16>, grid, kTPB, 0, st, pred, ref, dpred, partials, n_chunks, cpb, alpha,
+                           grad_scale, token_mask, row_len, hist1, hist2, bh2, k);
+    }
+    rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(k_mse_stage2, 1, kTPB, 0, st, partials, grid, n, loss_out, loss_accum, accum_scale);
     return launch_status();

@@ -127,6 +127,31 @@ def mse_loss_fwd_bwd(pred, ref, *, dpred=None, loss_out=None, loss_accum=None, a
     return loss_out, dpred
 
 
+_ol_ws = {}
+
+
+def outlier_mse_loss_fwd_bwd(pred, ref, *, topk=None, dpred=None, loss_out=None, loss_accum=None, accum_scale=1.0,
+                             grad_scale=1000.0, token_mask=None):
+    """Outlier-suppressed MSE of the algorithm extension: the topk = max(1, n//1000) largest |pred-ref| are dropped."""
+    n = pred.numel()
+    if topk is None:
+        topk = max(1, n // 1000)
+    if dpred is None:
+        dpred = torch.empty_like(pred)
+    if loss_out is None:
+        loss_out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    key = pred.device.index if pred.device.index is not None else torch.cuda.current_device()
+    ws = _ol_ws.get(key)
+    if ws is None:
+        ws = torch.empty(load().ar_outlier_loss_workspace_bytes(), dtype=torch.uint8, device=pred.device)
+        _ol_ws[key] = ws
+    check(load().ar_outlier_mse_loss_fwd_bwd(_p(pred, "pred"), _p(ref, "ref"), _p(dpred), _p(loss_out), _p(loss_accum),
+                                             accum_scale, n, dt_code(pred.dtype), grad_scale, _p(token_mask),
+                                             pred.shape[-1] if token_mask is not None else 0, topk, _p(ws), _stream()),
+          "ar_outlier_mse_loss_fwd_bwd")
+    return loss_out, dpred
+
+
 def best_loss_update(total_loss, state, istate, it: int):
     check(load().ar_best_loss_update(_p(total_loss), _p(state), _p(istate), it, _stream()), "ar_best_loss_update")
 
@@ -204,6 +229,14 @@ def qdq_fp4_bwd_sgd_(dXq, X, V, absmax, max_s, *, mode, gs, init_scale=1.0, glob
     return (dV, dmax) if want_grads else None
 
 
+def fp4_search_candidates(mode: int):
+    """Candidate coefficients in the reference's evaluation order: MXFP4 1, 0.5, 2 (data_type/mxfp.py:147);
+    NVFP4 1.0 first, then 0.50 ... 1.51 in steps of 0.01 (data_type/nvfp.py:358-362)."""
+    if mode == 0:
+        return [1.0, 0.5, 2.0]
+    return [1.0] + [v / 100.0 for v in range(50, 152) if v != 100]
+
+
 def search_fp4_scale(X, absmax, candidates, *, mode, gs, qw_row=None, groups_per_row=0, global_scale=None):
     """Per-group init-scale search over `candidates` (fp32 device tensor, evaluated in order). -> fp32 [numel/gs]"""
     G = X.numel() // gs
@@ -212,6 +245,38 @@ def search_fp4_scale(X, absmax, candidates, *, mode, gs, qw_row=None, groups_per
                                      _p(candidates, "candidates"), candidates.numel(), _p(best), G, gs, mode,
                                      dt_code(X.dtype), _stream()), "ar_search_fp4_scale")
     return best
+
+
+def int_search_candidates(bits: int, ratio: float = 0.75):
+    """Candidate numerators of the reference's search_scales grid (auto_round/data_type/int.py:49-64): the plain
+    nmax first (its initial best), then nmax - step*i for i in [-search_min, search_min] \\ {0}, as fp32."""
+    nmax = int(2.0 ** (bits - 1))
+    if bits == 2:
+        search_min, step = 18 * 5, 0.01
+    else:
+        grid = 200
+        search_min = nmax * ratio
+        step = search_min / grid * 2
+        search_min = int(search_min / step)
+    return [float(nmax)] + [nmax - step * i for i in range(-search_min, search_min + 1) if i != 0]
+
+
+_int_cand = {}
+
+
+def search_int_scale(X, *, gs, bits, qw_row=None, groups_per_row=0, q_thresh=1e-5, want_raw=False):
+    """Per-group searched init scale for the sym int path of the algorithm extension -> init_scale [G] in X.dtype."""
+    G = X.numel() // gs
+    key = (bits, X.device.index)
+    cand = _int_cand.get(key)
+    if cand is None:
+        cand = torch.tensor(int_search_candidates(bits), dtype=torch.float32, device=X.device)
+        _int_cand[key] = cand
+    init = torch.empty(G, dtype=X.dtype, device=X.device)
+    raw = torch.empty(G, dtype=X.dtype, device=X.device) if want_raw else None
+    check(load().ar_search_int_scale(_p(X, "X"), _p(qw_row), groups_per_row, _p(cand), cand.numel(), _p(raw), _p(init), G, gs,
+                                     bits, dt_code(X.dtype), q_thresh, _stream()), "ar_search_int_scale")
+    return (raw, init) if want_raw else init
 
 
 def fp4_act_bwd(dXq, X, *, mode, gs, global_scale=None, out=None):

@@ -36,12 +36,23 @@ def register():
         """Reference lifecycle (bind / prepare_run / dispatch_block / finalize_run) inherited unchanged; only the
         per-block tuning step is replaced by the HIP path."""
 
+        def register_fp_input_forward_hooks(self, block):
+            """With enable_alg_ext the importance matrix is collected while the composer runs the fp forward."""
+            handles = super().register_fp_input_forward_hooks(block)
+            if getattr(self, "enable_alg_ext", False):
+                from .quantizer import SignRoundV2Quantizer
+
+                v2 = SignRoundV2Quantizer.__new__(SignRoundV2Quantizer)
+                v2._scheme = SignRoundV2Quantizer._block_scheme(block)
+                handles.extend(SignRoundV2Quantizer.register_fp_input_forward_hooks(v2, block))
+            return handles
+
         def quantize_block(self, block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=None, **kw):
             import torch
 
             from auto_round.utils.device_manager import device_manager
 
-            from .quantizer import SignRoundConfig, SignRoundQuantizer
+            from .quantizer import SignRoundConfig, SignRoundQuantizer, SignRoundV2Quantizer
 
             c = self._config
             cfg = SignRoundConfig(
@@ -53,7 +64,9 @@ def register():
                 dynamic_max_gap=self.dynamic_max_gap, enable_quanted_input=self.enable_quanted_input,
                 batch_size=self.calibration_context.batch_size, bits=getattr(c, "bits", None),
                 amp=bool(self.model_context.amp), amp_dtype=self.model_context.amp_dtype or torch.bfloat16)
-            q = SignRoundQuantizer(cfg, device=device_manager.device)
+            # enable_alg_ext=True selects the algorithm extension (searched init scales, imatrix, outlier-suppressed loss)
+            q_cls = SignRoundV2Quantizer if getattr(self, "enable_alg_ext", False) else SignRoundQuantizer
+            q = q_cls(cfg, device=device_manager.device)
             best = q.quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=input_ids)
             st = q.last_stats
             try:

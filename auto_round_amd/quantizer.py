@@ -20,6 +20,7 @@ The block's GEMMs/attention run through PyTorch-ROCm (hipBLASLt / SDPA on MFMA).
 from __future__ import annotations
 
 import contextlib
+import functools
 import copy
 import inspect
 import random
@@ -30,7 +31,8 @@ import torch
 
 from . import ops
 from .sign_sgd import SignSGD
-from .wrapper import WrapperLinear, unwrapper_block, update_block_global_scale_if_needed, wrapper_block
+from .wrapper import (SignRoundOptimizedWrapperLinear, WrapperLinear, _quantizable, check_to_quantized, unwrapper_block,
+                      update_block_global_scale_if_needed, wrapper_block)
 
 FLT_MAX = float(torch.finfo(torch.float32).max)
 
@@ -321,13 +323,7 @@ class SignRoundQuantizer:
                         tmask = ops.gather_rows(mask_dev, idx, out=mb[:nb]).view(-1)
                     else:
                         tmask = mask_dev.index_select(0, idx).contiguous().view(-1)
-                if accum:   # reduction="sum" and loss/num_elm in the reference (quantizer.py:436-452, :496)
-                    ops.mse_loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred=dpred, loss_accum=total_loss,
-                                         accum_scale=float(n) / float(num_elm), grad_scale=1000.0 * float(n),
-                                         token_mask=tmask)
-                else:
-                    ops.mse_loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred=dpred, loss_accum=total_loss,
-                                         accum_scale=1.0 / float(num_elm), grad_scale=1000.0, token_mask=tmask)
+                self._loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred, total_loss, n, num_elm, accum, tmask)
                 pred_c.backward(dpred)
             ops.best_loss_update(total_loss, state, istate, i)
             if early_stop:
@@ -369,6 +365,23 @@ class SignRoundQuantizer:
         # hand out independent copies: the arenas' best_* buffers are released with the block's wrappers
         return {n: {k: v.clone() for k, v in d.items()} for n, d in best_params.items()}
 
+    def _loss_fwd_bwd(self, pred, ref, dpred, total_loss, n, num_elm, accum, tmask):
+        """loss value into `total_loss` (+= loss/num_elm) and d(1000*loss)/dpred into `dpred`, one fused pass.
+        reference: _get_loss + loss.item()/num_elm + _scale_loss_and_backward (sign_round/quantizer.py:127-158, :487-497)"""
+        if accum:   # reduction="sum" and loss/num_elm in the reference (quantizer.py:436-452, :496)
+            ops.mse_loss_fwd_bwd(pred, ref, dpred=dpred, loss_accum=total_loss, accum_scale=float(n) / float(num_elm),
+                                 grad_scale=1000.0 * float(n), token_mask=tmask)
+        else:
+            ops.mse_loss_fwd_bwd(pred, ref, dpred=dpred, loss_accum=total_loss, accum_scale=1.0 / float(num_elm),
+                                 grad_scale=1000.0, token_mask=tmask)
+
+    def register_fp_input_forward_hooks(self, block) -> list:
+        """Hooks that fire during the reference (fp-weight) forward of the block (quantization/base.py:61-67)."""
+        return []
+
+    def prepare_block(self, block) -> None:
+        """Per-block scheme-dependent setup (the reference does this once per model in prepare_run)."""
+
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward_all(self, block, inputs: torch.Tensor, input_others, batch_size: Optional[int] = None) -> torch.Tensor:
@@ -386,13 +399,101 @@ class SignRoundQuantizer:
         device = self.device
         X = stack_samples(fp_inputs, device)
         update_block_global_scale_if_needed(block)      # composer.py:438-451 (NVFP4 only; no-op otherwise)
-        fp_out = self.forward_all(block, X, input_others)
+        self.prepare_block(block)
+        handles = self.register_fp_input_forward_hooks(block)     # composer.py:284-293 (_get_fp_act_hooks)
+        try:
+            fp_out = self.forward_all(block, X, input_others)
+        finally:
+            for h in handles:
+                h.remove()
         Xq = stack_samples(q_inputs, device) if (q_inputs is not None and self.config.enable_quanted_input) else None
         best = self.quantize_block(block, X, input_others, fp_out, Xq, block_ctx, input_ids=input_ids)
         q_out = None
         if self.config.enable_quanted_input:
             q_out = self.forward_all(block, Xq if Xq is not None else X, input_others)
         return fp_out, q_out, best
+
+
+class SignRoundV2Quantizer(SignRoundQuantizer):
+    """SignRound with the algorithm extension (reference: sign_roundv2/quantizer.py:321-428, `enable_alg_ext=True`):
+
+    * symmetric int / mx_fp4 / nv_fp4 blocks are tuned through `SignRoundOptimizedWrapperLinear` (searched init scale
+      weighted by the importance matrix, max_scale in (0, 2));
+    * the importance matrix -- sum over calibration tokens of x^2 per input channel -- is collected by forward hooks
+      while the block's reference outputs are computed (not for W-int4/A-int4);
+    * when bits < 4 or act_bits <= 4 the loss drops the 0.1% largest |pred - ref| (`ar_outlier_mse_loss_fwd_bwd`).
+
+    The double-quant (`*_dq`, GGUF) wrapper of the reference is outside the hot path."""
+
+    def __init__(self, config: Optional[SignRoundConfig] = None, device: Union[str, torch.device] = "cuda", **kwargs):
+        super().__init__(config, device, **kwargs)
+        self._use_outlier_suppressed_loss = False
+        self._optimized = False
+        self._scheme = None
+
+    @staticmethod
+    def _block_scheme(block):
+        for m in block.modules():
+            if _quantizable(m) and check_to_quantized(m):
+                return dict(bits=int(m.bits), sym=bool(m.sym), data_type=str(getattr(m, "data_type", "int")),
+                            act_bits=int(getattr(m, "act_bits", 16)), act_data_type=str(getattr(m, "act_data_type", "")),
+                            super_group_size=getattr(m, "super_group_size", None))
+        return None
+
+    def prepare_block(self, block) -> None:
+        """reference: SignRoundV2Quantizer.prepare_run (sign_roundv2/quantizer.py:330-357), evaluated on the block's own
+        scheme attributes (the reference reads the model-wide scheme)."""
+        sch = self._scheme = self._block_scheme(block)
+        self._optimized = False
+        self._use_outlier_suppressed_loss = False
+        self.wrapper_block = wrapper_block
+        if sch is None:
+            return
+        dt = sch["data_type"]
+        if dt.endswith("dq"):
+            raise NotImplementedError("double-quant (GGUF *_dq) tuning is outside the MI355X hot path")
+        if sch["sym"] and sch["super_group_size"] is None and (dt.startswith("int") or dt.startswith("mx") or dt.startswith("nv")):
+            self._use_outlier_suppressed_loss = sch["act_bits"] <= 4 or sch["bits"] < 4
+            self._optimized = True
+            self.wrapper_block = functools.partial(wrapper_block, wrapper_cls=SignRoundOptimizedWrapperLinear)
+
+    def _is_wint4aint4(self) -> bool:
+        sch = self._scheme or {}
+        adt, dt = sch.get("act_data_type", ""), sch.get("data_type", "")
+        return (("int4" in adt or ("int" in adt and sch.get("act_bits") == 4))
+                and ("int4" in dt or ("int" in dt and sch.get("bits") == 4)))
+
+    def register_fp_input_forward_hooks(self, block) -> list:
+        """imatrix hooks (sign_roundv2/quantizer.py:401-428): module.imatrix += sum_tokens x^2, fp32 [in_features]."""
+        if self._scheme is None or self._is_wint4aint4():
+            return []
+
+        def collect_imatrix(module, inp, out):
+            x = inp[0] if isinstance(inp, (tuple, list)) else inp
+            sq = torch.sum(torch.pow(x.reshape(-1, x.shape[-1]).to(torch.float32), 2), dim=0).to(torch.float32)
+            if not hasattr(module, "imatrix"):
+                module.imatrix = sq
+            else:
+                module.imatrix += sq.to(module.imatrix.device)
+
+        return [m.register_forward_hook(collect_imatrix) for m in block.modules()
+                if _quantizable(m) and check_to_quantized(m)]
+
+    def quantize_block(self, block, fp_inputs, input_others, fp_outputs, q_inputs=None, block_ctx=None, input_ids=None,
+                       **kwargs) -> dict:
+        if self._scheme is None:          # quantize_block called directly (without compress_block)
+            self.prepare_block(block)
+        try:
+            return super().quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs)
+        finally:
+            self._scheme = None
+
+    def _loss_fwd_bwd(self, pred, ref, dpred, total_loss, n, num_elm, accum, tmask):
+        if not self._use_outlier_suppressed_loss:
+            return super()._loss_fwd_bwd(pred, ref, dpred, total_loss, n, num_elm, accum, tmask)
+        # the outlier-suppressed loss is a mean regardless of the accumulation mode (sign_roundv2/quantizer.py:387-398)
+        ops.outlier_mse_loss_fwd_bwd(pred, ref, dpred=dpred, loss_accum=total_loss, accum_scale=1.0 / float(num_elm),
+                                     grad_scale=1000.0, token_mask=tmask)
 
 
 def _name_of(block, module) -> str:

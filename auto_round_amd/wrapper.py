@@ -153,7 +153,7 @@ class BlockArena:
     """Block-wide flat HBM buffers for all layers that share (bits, group_size, sym, data_type, dtypes)."""
 
     def __init__(self, key, device):
-        (self.data_type, self.bits, self.gs, self.sym, self.w_dtype, self.scale_dtype, self.bounds) = key
+        (self.data_type, self.bits, self.gs, self.sym, self.w_dtype, self.scale_dtype, self.bounds, self.optimized) = key
         self.device = device
         self.layers: List["WrapperLinear"] = []
         self.n = 0
@@ -166,6 +166,9 @@ class BlockArena:
         cpg = self.gs // 8
         self.tiled = cpg <= 64 and (cpg & (cpg - 1)) == 0     # lane-group kernels; otherwise one wave per group
         self.mode = {"int": -1, "mx": 0, "nv": 1}[self.kind]
+        # `sym` as the kernels take it: 0 asym, 1 sym, 2 (AR_SYM_INIT) sym with the searched init scale in the wmax slot
+        self.sym_code = 2 if (self.optimized and self.kind == "int") else int(bool(self.sym))
+        self.init = None            # algorithm extension: per-group searched init scale (int: weight dtype, fp4: fp32)
 
     # -- construction ---------------------------------------------------------------------------------------------
     def add(self, layer: "WrapperLinear") -> Tuple[int, int]:
@@ -197,8 +200,37 @@ class BlockArena:
             if self.kind == "nv":
                 for lyr in self.layers:
                     lyr._init_global_scale()
+        if self.optimized:
+            self._search_init_scales()
         self.token = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
         self.built = True
+
+    def _search_init_scales(self):
+        """Algorithm extension: seed every group with the searched init scale (one search launch per layer, since the
+        importance matrix is per layer).  reference: SignRoundOptimizedWrapperLinear._init_tuning_params_and_quant_func
+        (sign_roundv2/quantizer.py:104-126) -> search_optimized_init_scale (data_type/utils.py:224-254)."""
+        dev = self.device
+        if self.kind == "int":
+            self.init = torch.empty(self.G, dtype=self.w_dtype, device=dev)
+        else:
+            self.init = torch.empty(self.G, dtype=torch.float32, device=dev)
+            cand = torch.tensor(ops.fp4_search_candidates(self.mode), dtype=torch.float32, device=dev)
+        for l in self.layers:
+            sl, gl = slice(l._off, l._off + l.numel), slice(l._goff, l._goff + l.n_groups)
+            qw = l._imatrix_row()
+            gpr = l.in_pad // self.gs
+            if self.kind == "int":
+                self.init[gl] = ops.search_int_scale(self.W[sl], gs=self.gs, bits=self.bits, qw_row=qw, groups_per_row=gpr,
+                                                     q_thresh=self.q_thresh)
+            else:
+                own_gs = None
+                if self.kind == "nv":   # the search always uses the tensor's OWN 448*6/amax (nvfp.py:332-338), even when
+                    amax = self.absmax[gl].max()                   # the layer tunes with a q/k/v- or gate/up-unified one
+                    own_gs = torch.where(amax == 0, torch.zeros_like(amax), (448.0 * 6.0) * (1.0 / amax)).reshape(1)
+                self.init[gl] = ops.search_fp4_scale(self.W[sl], self.absmax[gl], cand, mode=self.mode, gs=self.gs, qw_row=qw,
+                                                     groups_per_row=gpr, global_scale=own_gs)
+        if self.kind == "int":
+            self.wmin = self.wmax = self.init
 
     def alloc_best(self):
         if self.best_V is None:
@@ -215,13 +247,15 @@ class BlockArena:
         if self.kind != "int":
             self.wq_fresh = V is self.V and mx is self.max_scale
             if self.kind == "mx":
-                return ops.qdq_fp4_fwd(self.W, V, self.absmax, mx, mode=0, gs=self.gs, bounds=self.bounds, out=self.Wq)
+                return ops.qdq_fp4_fwd(self.W, V, self.absmax, mx, mode=0, gs=self.gs, bounds=self.bounds, out=self.Wq,
+                                       init_scale_dev=self.init)
             for l in self.layers:   # NVFP4: one launch per layer (each layer has its own global scale)
                 sl, gl = slice(l._off, l._off + l.numel), slice(l._goff, l._goff + l.n_groups)
                 ops.qdq_fp4_fwd(self.W[sl], V[sl], self.absmax[gl], mx[gl], mode=1, gs=self.gs,
-                                global_scale=l.weight_global_scale_dev, bounds=self.bounds, out=self.Wq[sl])
+                                global_scale=l.weight_global_scale_dev, bounds=self.bounds, out=self.Wq[sl],
+                                init_scale_dev=None if self.init is None else self.init[gl])
             return self.Wq
-        res = ops.qdq_int_fwd(self.W, V, self.wmin, self.wmax, mn, mx, gs=self.gs, bits=self.bits, sym=self.sym,
+        res = ops.qdq_int_fwd(self.W, V, self.wmin, self.wmax, mn, mx, gs=self.gs, bits=self.bits, sym=self.sym_code,
                               scale_dtype=self.scale_dtype, q_thresh=self.q_thresh, bounds=self.bounds, out=self.Wq,
                               want_scale=want_scale)
         self.wq_fresh = V is self.V and mn is self.min_scale and mx is self.max_scale
@@ -243,6 +277,7 @@ class BlockArena:
                 gl = slice(None) if l is None else slice(l._goff, l._goff + l.n_groups)
                 ops.qdq_fp4_bwd_sgd_(self.dWq[sl], self.W[sl], self.V[sl], self.absmax[gl], self.max_scale[gl],
                                      mode=self.mode, gs=self.gs, bounds=self.bounds,
+                                     init_scale_dev=None if self.init is None else self.init[gl],
                                      global_scale=None if l is None else l.weight_global_scale_dev, lr_v=lr_v, lr_mm=lr_mm,
                                      tune_minmax=self.tune_minmax, snapshot_flag=snapshot_flag,
                                      best_V=None if self.best_V is None else self.best_V[sl],
@@ -252,7 +287,7 @@ class BlockArena:
                 lyr._dw_accum[0] = False
             return
         ops.qdq_int_bwd_sgd_(self.dWq, self.W, self.V, self.wmin, self.wmax, self.min_scale, self.max_scale, gs=self.gs,
-                             bits=self.bits, sym=self.sym, lr_v=lr_v, lr_mm=lr_mm, tune_minmax=self.tune_minmax,
+                             bits=self.bits, sym=self.sym_code, lr_v=lr_v, lr_mm=lr_mm, tune_minmax=self.tune_minmax,
                              scale_dtype=self.scale_dtype, q_thresh=self.q_thresh, bounds=self.bounds,
                              snapshot_flag=snapshot_flag, best_V=self.best_V, best_min=self.best_min,
                              best_max=self.best_max, Wq_next=self.Wq if (fuse_next_fwd and self.tiled) else None)
@@ -265,7 +300,7 @@ class BlockArena:
         if self.kind != "int":
             raise NotImplementedError("unfused gradients are exposed for the INT path only")
         return ops.qdq_int_bwd(self.dWq, self.W, self.V, self.wmin, self.wmax, self.min_scale, self.max_scale, gs=self.gs,
-                               bits=self.bits, sym=self.sym, scale_dtype=self.scale_dtype, q_thresh=self.q_thresh,
+                               bits=self.bits, sym=self.sym_code, scale_dtype=self.scale_dtype, q_thresh=self.q_thresh,
                                bounds=self.bounds)
 
 
@@ -278,6 +313,7 @@ class WrapperLinear(torch.nn.Module):
     """
 
     minmax_scale_bound = (0.0, 1.0)
+    optimized = False       # True in SignRoundOptimizedWrapperLinear (algorithm extension)
 
     def __init__(self, orig_layer, enable_minmax_tuning=True, enable_norm_bias_tuning=False, device="cuda",
                  enable_round_tuning=True, enable_torch_compile=False, disable_opt_rtn=True, **kwargs):
@@ -332,7 +368,20 @@ class WrapperLinear(torch.nn.Module):
     # arenas are keyed by everything the grouped kernels treat as launch-uniform
     def arena_key(self):
         return (self.data_type, self.bits, self.gs, self.sym, self.orig_layer.weight.dtype, self.scale_dtype,
-                tuple(self.minmax_scale_bound))
+                tuple(self.minmax_scale_bound), bool(self.optimized))
+
+    def _imatrix_row(self):
+        """The layer's importance matrix as one padded fp32 row [in_pad] (pad = 1e-5), or None for uniform importance.
+        reference: reshape_imatrix_for_weight (data_type/utils.py:269-282); the attribute is consumed like the reference
+        does (sign_roundv2/quantizer.py:123-124)."""
+        im = getattr(self.orig_layer, "imatrix", None)
+        if hasattr(self.orig_layer, "imatrix"):
+            del self.orig_layer.imatrix
+        if not isinstance(im, torch.Tensor):
+            return None
+        row = torch.full((self.in_pad,), 1e-5, dtype=torch.float32, device=self.device)
+        row[:self.in_features] = im.reshape(-1).to(device=self.device, dtype=torch.float32)
+        return row
 
     def _bind(self, arena: BlockArena):
         off, goff = self._off, self._goff
@@ -404,11 +453,12 @@ class WrapperLinear(torch.nn.Module):
         mx = flat(max_scale, a.max_scale[gl], self.n_groups)
         if a.kind != "int":
             Wq, scale = ops.qdq_fp4_fwd(a.W[sl], V, a.absmax[gl], mx, mode=a.mode, gs=self.gs, bounds=self.minmax_scale_bound,
-                                        global_scale=self.weight_global_scale_dev, want_scale=True)
+                                        global_scale=self.weight_global_scale_dev, want_scale=True,
+                                        init_scale_dev=None if a.init is None else a.init[gl])
             wq2d = Wq.view(self.out_features, self.in_pad)[:, :self.in_features]
             return (wq2d.t() if self.is_conv1d else wq2d), scale.view(self.n_groups, 1), None
         Wq, scale, zp = ops.qdq_int_fwd(a.W[sl], V, a.wmin[gl], a.wmax[gl], mn, mx, gs=self.gs, bits=self.bits,
-                                        sym=self.sym, scale_dtype=self.scale_dtype, q_thresh=self.q_scale_thresh,
+                                        sym=a.sym_code, scale_dtype=self.scale_dtype, q_thresh=self.q_scale_thresh,
                                         bounds=self.minmax_scale_bound, want_scale=True)
         wq2d = Wq.view(self.out_features, self.in_pad)[:, :self.in_features]
         if self.is_conv1d:
@@ -445,6 +495,26 @@ class WrapperLinear(torch.nn.Module):
         if self.enable_act_quant:
             return WrapperWALayer(self.orig_layer)
         return self.orig_layer
+
+
+class SignRoundOptimizedWrapperLinear(WrapperLinear):
+    """Algorithm-extension wrapper (reference: sign_roundv2/quantizer.py:101-161): every group starts from a searched
+    `init_scale` (importance-weighted grid search, one kernel launch per layer at wrap time) instead of the min/max
+    range, `max_scale` tunes a coefficient on top of it within (0, 2), `min_scale` is not part of the graph.
+    Symmetric int / mx_fp4 / nv_fp4 only, like the reference."""
+
+    minmax_scale_bound = (0.0, 2.0)
+    optimized = True
+
+    def __init__(self, orig_layer, *args, **kwargs):
+        super().__init__(orig_layer, *args, **kwargs)
+        if is_int_dtype(self.data_type) and (not self.sym or "asym" in self.data_type or self.data_type.endswith("dq")):
+            raise ValueError(f"SignRound optimized path does not support data_type={self.data_type!r} (sym={self.sym}); "
+                             "expected a symmetric int / mx / nv type.")
+
+    @property
+    def init_scale(self):
+        return self.arena.init[self._goff:self._goff + self.n_groups].view(self.n_groups, 1)
 
 
 def update_block_global_scale_if_needed(block) -> None:

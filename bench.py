@@ -199,6 +199,8 @@ def main():
                     help="emit the next iteration's Wq from the fused backward kernel (K1 then runs once per block)")
     ap.add_argument("--sdpa", default="efficient", choices=["auto", "efficient", "flash", "math"],
                     help="SDPA backend priority for the block attention (see SignRoundConfig.sdpa_backend)")
+    ap.add_argument("--alg-ext", action="store_true",
+                    help="tune with the algorithm extension (SignRoundV2: imatrix, searched init scales, outlier loss)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -236,7 +238,7 @@ def main():
         if dist is not None:
             dist.barrier()
     from auto_round_amd.export import pack_block
-    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer, SignRoundV2Quantizer
 
     w = WORKLOADS[args.workload]
     sym = not args.asym
@@ -275,7 +277,7 @@ def main():
 
     qcfg = SignRoundConfig(iters=args.iters, batch_size=args.batch_size, bits=args.bits,
                            fuse_next_forward=args.fuse_next_forward, sdpa_backend=args.sdpa)
-    quantizer = SignRoundQuantizer(qcfg, device=device)
+    quantizer = (SignRoundV2Quantizer if args.alg_ext else SignRoundQuantizer)(qcfg, device=device)
     random.seed(42 + rank)
 
     def restore():
@@ -330,7 +332,8 @@ def main():
             "config": {"workload": w["desc"], "scheme": args.scheme or "int", "bits": args.bits, "group_size": args.group_size, "sym": sym,
                        "iters": args.iters, "nsamples": N, "seqlen": S, "batch_size": args.batch_size,
                        "weights_per_block": n_w, "groups_per_block": G, "includes_packing": True,
-                       "fuse_next_forward": bool(args.fuse_next_forward), "sdpa_backend": args.sdpa, "parallelism": f"block-sharded x{world}"},
+                       "fuse_next_forward": bool(args.fuse_next_forward), "sdpa_backend": args.sdpa,
+                       "alg_ext": bool(args.alg_ext), "parallelism": f"block-sharded x{world}"},
             "ms_per_iter": 1000.0 * elapsed / args.steps / max(args.iters, 1),
             "loss": {"init": stats["init_loss"], "best": stats["best_loss"], "best_iter": stats["best_iter"]},
         }

@@ -54,7 +54,11 @@ int ar_group_absmax(const void* W, float* absmax, float* tensor_absmax, int64_t 
  *           WrapperLinear._qdq_weight (auto_round/wrapper.py:244-293), including its in-place [lo,hi] clamp of
  *           min_scale/max_scale (wrapper.py:257-259; applied on read, see ar_qdq_int_bwd_sgd for the write-back).
  * V, min_s, max_s may be NULL (treated as 0 / 1 / 1 == plain RTN).  scale_out [n_groups] (s_dt) and zp_out
- * [n_groups] (fp32; sym writes 2^(bits-1)) are optional (NULL during tuning, set for the final unwrap call). */
+ * [n_groups] (fp32; sym writes 2^(bits-1)) are optional (NULL during tuning, set for the final unwrap call).
+ * sym: 0 = asym, 1 = sym "full range", 2 = sym with a searched init scale (AR_SYM_INIT, the algorithm extension's
+ * quant_tensor_sym(init_scale=...) branch, int.py:201-216): `wmax` then holds init_scale[n_groups] in the weight dtype,
+ * `wmin` is ignored, scale = s_dt(init_scale * max_scale), and the backward yields d min_scale = 0. */
+#define AR_SYM_INIT 2
 int ar_qdq_int_fwd(const void* W, const float* V, const void* wmin, const void* wmax, const float* min_s,
                    const float* max_s, void* Wq, void* scale_out, float* zp_out, int64_t n_groups, int gs, int bits,
                    int sym, int w_dt, int s_dt, float q_thresh, float lo_bound, float hi_bound, ar_stream_t stream);
@@ -102,6 +106,31 @@ int64_t ar_mse_workspace_bytes(void);
 int ar_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpred, float* loss_out, float* loss_accum,
                         float accum_scale, int64_t n, int act_dt, float grad_scale, const uint8_t* token_mask,
                         int64_t row_len, void* workspace, ar_stream_t stream);
+
+/* int-sym init-scale search of the algorithm extension.
+ * replaces: search_scales (auto_round/data_type/int.py:24-86) and the threshold clamp around it in
+ *           _resolve_optimized_dtype_funcs.search_int (auto_round/data_type/utils.py:203-209), as called from
+ *           SignRoundOptimizedWrapperLinear._init_tuning_params_and_quant_func (sign_roundv2/quantizer.py:104-126).
+ * X [n_groups*gs] in x_dt (grouped, padded weight); qw_row [groups_per_row*gs] fp32 per-input-channel importance
+ * (the imatrix, pad = 1e-5) or NULL (== 1).  candidates_dev: fp32 numerators c (scale_c = 1/(-c/gmax)), candidate 0
+ * must be 2^(bits-1); a later candidate wins only with a strictly smaller loss.  out_raw / out_init [n_groups] in
+ * x_dt: the selected scale before / after the signed q_thresh clamp (either may be NULL).  gs % 8 == 0. */
+int ar_search_int_scale(const void* X, const float* qw_row, int64_t groups_per_row, const float* candidates_dev,
+                        int n_candidates, void* out_raw, void* out_init, int64_t n_groups, int gs, int bits, int x_dt,
+                        float q_thresh, ar_stream_t stream);
+
+/* outlier-suppressed MSE loss of the algorithm extension (used when bits < 4 or act_bits <= 4):
+ * replaces: SignRoundV2Quantizer._get_loss (auto_round/algorithms/quantization/sign_roundv2/quantizer.py:362-399):
+ * the `topk` = max(1, n/1000) largest |pred - ref| (ranked on the activation-dtype difference, like torch.topk on the bf16
+ * tensor) are dropped from the loss and get a zero gradient; the rest is the n-normalised MSE above (token mask included).
+ * Selection is a two-level radix select on the 15-bit magnitude pattern of the 16-bit difference.  Exactly `topk`
+ * elements are dropped: everything above the k-th value plus the LOWEST-INDEX elements tied with it (torch.topk picks an
+ * unspecified subset of the ties; the tied values are equal in the ranking dtype, so the loss agrees to fp32 rounding).
+ * 16-bit dtypes only, n % 8 == 0. */
+int64_t ar_outlier_loss_workspace_bytes(void);
+int ar_outlier_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpred, float* loss_out, float* loss_accum,
+                                float accum_scale, int64_t n, int act_dt, float grad_scale, const uint8_t* token_mask,
+                                int64_t row_len, int64_t topk, void* workspace, ar_stream_t stream);
 
 /* ---- best-loss bookkeeping on the device ---------------------------------------------------------------------
  * replaces: `if total_loss < best_loss: best_loss = total_loss; last_best_iter = i` (sign_round/quantizer.py:508-517)

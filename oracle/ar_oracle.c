@@ -175,6 +175,18 @@ static void group_scale_sym(group_q_t* q, int bits, int s_dt, float q_thresh) {
     else q->s = (q->s_raw < t) ? t : q->s_raw;                    /* clamp(min=t) */
     q->zp = maxq;
 }
+/* algorithm-extension sym path (sym == 2): the searched per-group init_scale travels in the `wmax` slot,
+ * scale = s_dt(init_scale * max_scale), same signed threshold clamp (auto_round/data_type/int.py:201-216). */
+static void group_scale_init(group_q_t* q, int bits, int s_dt, float q_thresh) {
+    q->a = 0.f;
+    q->b = q->wmax * q->Ms;
+    q->sgn = 1;
+    q->s_raw = rnd(s_dt, q->b);
+    const float t = thresh_in(s_dt, q_thresh);
+    if (q->s_raw < 0.f) q->s = (q->s_raw > -t) ? -t : q->s_raw;
+    else q->s = (q->s_raw < t) ? t : q->s_raw;
+    q->zp = (float)(1 << (bits - 1));
+}
 static void group_scale_asym(group_q_t* q, int bits, int s_dt, float q_thresh) {
     const float maxq = (float)((1 << bits) - 1);
     q->a = q->wmin * q->ms; /* lo */
@@ -211,7 +223,8 @@ void oracle_qdq_int_fwd(const void* W, const float* V, const void* wmin, const v
         q.Ms = max_s ? clampf(max_s[g], lo_bound, hi_bound) : 1.0f;
         q.wmin = load_as_f32(wmin, g, w_dt);
         q.wmax = load_as_f32(wmax, g, w_dt);
-        if (sym) group_scale_sym(&q, bits, s_dt, q_thresh);
+        if (sym == 2) group_scale_init(&q, bits, s_dt, q_thresh);
+        else if (sym) group_scale_sym(&q, bits, s_dt, q_thresh);
         else group_scale_asym(&q, bits, s_dt, q_thresh);
         if (scale) store_from_f32(scale, g, s_dt, q.s);
         if (zp) zp[g] = q.zp;
@@ -262,7 +275,8 @@ void oracle_qdq_int_bwd(const void* dWq, const void* W, const float* V, const vo
         q.Ms = max_s ? clampf(max_s[g], lo_bound, hi_bound) : 1.0f;
         q.wmin = load_as_f32(wmin, g, w_dt);
         q.wmax = load_as_f32(wmax, g, w_dt);
-        if (sym) group_scale_sym(&q, bits, s_dt, q_thresh);
+        if (sym == 2) group_scale_init(&q, bits, s_dt, q_thresh);
+        else if (sym) group_scale_sym(&q, bits, s_dt, q_thresh);
         else group_scale_asym(&q, bits, s_dt, q_thresh);
         double acc_c1 = 0.0, acc_c2 = 0.0, acc_e = 0.0, acc_dy = 0.0;
         for (int k = 0; k < gs; ++k) {
@@ -310,7 +324,11 @@ void oracle_qdq_int_bwd(const void* dWq, const void* W, const float* V, const vo
         if (sym) ds = (q.s_raw < 0.f) ? ((q.s_raw <= -t) ? ds_c : 0.f) : ((q.s_raw >= t) ? ds_c : 0.f);
         else ds = (q.s_raw >= t) ? ds_c : 0.f;
         float d32 = ds / maxq; /* .to(scale_dtype) backward = cast to fp32, then DivBackward by maxq */
-        if (sym) {
+        if (sym == 2) {
+            /* scale = (init_scale * max_scale).to(s_dt): d max_scale = float(ds) * init_scale; min_scale is unused */
+            if (dmin) dmin[g] = 0.f;
+            if (dmax) dmax[g] = ds * q.wmax;
+        } else if (sym) {
             float dm = d32 * (float)q.sgn;                       /* max_v = sgn * m */
             float da, db;                                        /* m = maximum(a, b) */
             if (q.a == q.b) { da = dm / 2.f; db = dm / 2.f; }
@@ -477,13 +495,14 @@ void oracle_mx_quant_element_fp4(const float* x, int64_t n, float* out) { for (i
 /* ------------------------------------------------------------------------------------------
  * MXFP4 fake-quant forward (group 32, e8m0 shared exponent)
  * reference: auto_round/data_type/mxfp.py:233-291 (quant_mx), :49-85 (quant_element)
- *   all math in fp32; max_scale [G] fp32 or NULL (==1); init_scale scalar
+ *   all math in fp32; max_scale [G] fp32 or NULL (==1); init_scale scalar or per group
  *   exp_out [G] = shared_exp cast to w_dt (what the reference returns as "scale")
  * ---------------------------------------------------------------------------------------- */
-void oracle_qdq_mxfp4_fwd(const void* W, const float* V, const float* max_s, float init_scale,
+void oracle_qdq_mxfp4_fwd(const void* W, const float* V, const float* max_s, float init_scale_scalar, const float* init_scale_arr,
                           int64_t G, int gs, int w_dt, float lo_bound, float hi_bound, void* Wq,
                           void* exp_out) {
     for (int64_t g = 0; g < G; ++g) {
+        const float init_scale = init_scale_arr ? init_scale_arr[g] : init_scale_scalar;   /* searched per-group coefficient (alg. ext.) */
         float amax = 0.f;
         for (int k = 0; k < gs; ++k) { float a = fabsf(load_as_f32(W, g * gs + k, w_dt)); if (a > amax) amax = a; }
         float Ms = max_s ? clampf(max_s[g], lo_bound, hi_bound) : 1.0f;
@@ -515,11 +534,12 @@ float oracle_nvfp4_global_scale(const void* W, int64_t n, int w_dt) {
     for (int64_t i = 0; i < n; ++i) { float a = fabsf(load_as_f32(W, i, w_dt)); if (a > amax) amax = a; }
     return 448.0f * 6.0f * recip0(amax);
 }
-void oracle_qdq_nvfp4_fwd(const void* W, const float* V, const float* max_s, float init_scale,
+void oracle_qdq_nvfp4_fwd(const void* W, const float* V, const float* max_s, float init_scale_scalar, const float* init_scale_arr,
                           float global_scale, int64_t G, int gs, int w_dt, float lo_bound,
                           float hi_bound, void* Wq, float* scale_out) {
     const float r6 = (float)(1.0 / 6.0); /* get_reciprocal(FLOAT4_E2M1_MAX): python double -> fp32 scalar */
     for (int64_t g = 0; g < G; ++g) {
+        const float init_scale = init_scale_arr ? init_scale_arr[g] : init_scale_scalar;   /* searched per-group coefficient (alg. ext.) */
         float amax = 0.f;
         for (int k = 0; k < gs; ++k) { float a = fabsf(load_as_f32(W, g * gs + k, w_dt)); if (a > amax) amax = a; }
         float Ms = max_s ? clampf(max_s[g], lo_bound, hi_bound) : 1.0f;
@@ -617,12 +637,13 @@ float oracle_e4m3_to_f32(uint8_t b) { return e4m3_bits_to_f32(b); }
  *          dMs = (((ds*gs) * (1/6)) * amax) * init , masked by the +-448 clamp and the zero guards
  * Group sums in double (order-free).  Only sign(dV) and sign(dMs) reach SignSGD.
  * ---------------------------------------------------------------------------------------- */
-void oracle_qdq_fp4_bwd(const void* dXq, const void* W, const float* V, const float* max_s, float init_scale,
+void oracle_qdq_fp4_bwd(const void* dXq, const void* W, const float* V, const float* max_s, float init_scale_scalar, const float* init_scale_arr,
                         float global_scale, int64_t G, int gs, int mode, int w_dt, float lo_bound,
                         float hi_bound, float* dV, float* dmax) {
     const float LN2 = 0.6931471805599453f;
     const float r6 = (float)(1.0 / 6.0);
     for (int64_t g = 0; g < G; ++g) {
+        const float init_scale = init_scale_arr ? init_scale_arr[g] : init_scale_scalar;   /* searched per-group coefficient (alg. ext.) */
         float amax = 0.f;
         for (int k = 0; k < gs; ++k) { float a = fabsf(load_as_f32(W, g * gs + k, w_dt)); if (a > amax) amax = a; }
         const float Ms = max_s ? clampf(max_s[g], lo_bound, hi_bound) : 1.0f;
@@ -846,5 +867,87 @@ void oracle_search_fp4_scale(const void* X, const float* qw_row, int64_t groups_
             if (ci == 0 || loss < best) { best = loss; best_c = coeff; }
         }
         best_out[g] = best_c;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * outlier-suppressed MSE (algorithm extension)
+ * reference: SignRoundV2Quantizer._get_loss (sign_roundv2/quantizer.py:362-399): drop the topk largest |pred-ref|
+ * (ranked on the activation-dtype difference), mean over ALL n of ((|p-r| in fp32) * token_mask * keep)^2.
+ * Exactly topk elements are dropped: all above the k-th largest 16-bit magnitude, then the lowest-index ones tied
+ * with it (torch.topk picks an unspecified subset of the ties).
+ * ---------------------------------------------------------------------------------------- */
+static int cmp_u16_desc(const void* a, const void* b) { return (int)(*(const uint16_t*)b) - (int)(*(const uint16_t*)a); }
+void oracle_outlier_mse_fwd_bwd(const void* pred, const void* ref, int64_t n, int act_dt, float gout, int64_t topk,
+                                const uint8_t* token_mask, int64_t row_len, float* loss_out, void* dpred, int64_t* n_dropped) {
+    uint16_t* keys = (uint16_t*)malloc(sizeof(uint16_t) * n);
+    uint16_t* sorted = (uint16_t*)malloc(sizeof(uint16_t) * n);
+    for (int64_t i = 0; i < n; ++i) {
+        float d = load_as_f32(pred, i, act_dt) - load_as_f32(ref, i, act_dt);
+        uint16_t k = (act_dt == AR_DT_BF16 ? f32_to_bf16_bits(d) : f32_to_f16_bits(d)) & 0x7fffu;
+        keys[i] = k; sorted[i] = k;
+    }
+    qsort(sorted, n, sizeof(uint16_t), cmp_u16_desc);
+    const uint16_t thr = sorted[topk - 1];
+    double acc = 0.0;
+    const float alpha = (float)(2.0 / (double)n);
+    int64_t dropped = 0, need = topk;
+    for (int64_t i = 0; i < n; ++i) need -= keys[i] > thr;
+    for (int64_t i = 0; i < n; ++i) {
+        int keep = keys[i] <= thr;
+        if (keys[i] == thr && need > 0) { keep = 0; --need; }
+        if (!keep) ++dropped;
+        if (token_mask && !token_mask[i / row_len]) keep = 0;
+        float d = keep ? load_as_f32(pred, i, act_dt) - load_as_f32(ref, i, act_dt) : 0.f;
+        acc += (double)(d * d);
+        if (dpred) store_from_f32(dpred, i, act_dt, keep ? (alpha * d) * gout : 0.f);
+    }
+    if (loss_out) *loss_out = (float)(acc / (double)n);
+    if (n_dropped) *n_dropped = dropped;
+    free(keys); free(sorted);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * int-sym init-scale search of the algorithm extension
+ * reference: search_scales (auto_round/data_type/int.py:24-86) + the threshold clamp of search_int
+ *            (auto_round/data_type/utils.py:203-209).  Everything runs in the weight dtype (torch op by op):
+ *   gmax   = the first element with the largest |x| (signed)
+ *   isc_c  = wdt( (-c) * recip(gmax) ),  sc_c = recip(isc_c),  recip(t) = |t| >= eps ? wdt(1/t) : 0  (eps 1e-5 f16, else 1e-30)
+ *   L      = clamp(rint(wdt(isc_c * x)), -nmax, nmax-1)
+ *   loss_c = sum_k f32( wdt( wdt(sc_c * L) - x ) )^2 * qw_k      (sequential fp32 sum; torch's order is unspecified)
+ * candidate 0 is c = nmax; a later candidate wins only with a strictly smaller loss.  out = clamped scale in wdt.
+ * ---------------------------------------------------------------------------------------- */
+static inline float recip_dt(float t, int dt) {
+    const float eps = dt == AR_DT_F16 ? 1e-5f : 1e-30f;
+    return fabsf(t) >= rnd(dt, eps) ? rnd(dt, 1.0f / t) : 0.f;
+}
+void oracle_search_int_scale(const void* X, const float* qw_row, int64_t groups_per_row, const float* cand, int n_cand,
+                             int64_t G, int gs, int bits, int x_dt, float q_thresh, void* out_raw, void* out_init) {
+    const float nmax = (float)(1 << (bits - 1));
+    const float th = rnd(x_dt, q_thresh);
+    for (int64_t g = 0; g < G; ++g) {
+        float gmax = 0.f, amax = -1.f;
+        for (int k = 0; k < gs; ++k) {
+            const float x = load_as_f32(X, g * gs + k, x_dt);
+            if (fabsf(x) > amax) { amax = fabsf(x); gmax = x; }
+        }
+        const float rg = recip_dt(gmax, x_dt);
+        float best = 0.f, best_s = 0.f;
+        for (int ci = 0; ci < n_cand; ++ci) {
+            const float isc = rnd(x_dt, (-cand[ci]) * rg);
+            const float sc = recip_dt(isc, x_dt);
+            float loss = 0.f;
+            for (int k = 0; k < gs; ++k) {
+                const float x = load_as_f32(X, g * gs + k, x_dt);
+                const float L = clampf(nearbyintf(rnd(x_dt, isc * x)), -nmax, nmax - 1.f);
+                const float e = rnd(x_dt, rnd(x_dt, sc * L) - x);
+                const float w = qw_row ? qw_row[(g % groups_per_row) * gs + k] : 1.0f;
+                loss += (e * e) * w;
+            }
+            if (ci == 0 || loss < best) { best = loss; best_s = sc; }
+        }
+        if (out_raw) store_from_f32(out_raw, g, x_dt, best_s);
+        const float cl = best_s < 0.f ? (best_s > -th ? -th : best_s) : (best_s < th ? th : best_s);
+        if (out_init) store_from_f32(out_init, g, x_dt, cl);
     }
 }

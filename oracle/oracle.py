@@ -163,10 +163,18 @@ def mx_quant_element_fp4(x: np.ndarray) -> np.ndarray:
     return out
 
 
+def _init(init_scale):
+    """scalar or per-group init_scale -> (c_float scalar, fp32 array or None)"""
+    if isinstance(init_scale, np.ndarray):
+        return _f(1.0), np.ascontiguousarray(init_scale.reshape(-1), dtype=np.float32)
+    return _f(init_scale), None
+
+
 def qdq_mxfp4_fwd(W, V, max_s, G, gs=32, w_dt=DT_BF16, init_scale=1.0, bounds=(0.0, 1.0)):
     Wq = np.empty(G * gs, dtype=np_dtype(w_dt))
     e = np.empty(G, dtype=np_dtype(w_dt))
-    lib().oracle_qdq_mxfp4_fwd(_p(W), _p(V), _p(max_s), _f(init_scale), ctypes.c_int64(G), gs, w_dt,
+    i_s, i_a = _init(init_scale)
+    lib().oracle_qdq_mxfp4_fwd(_p(W), _p(V), _p(max_s), i_s, _p(i_a), ctypes.c_int64(G), gs, w_dt,
                                _f(bounds[0]), _f(bounds[1]), _p(Wq), _p(e))
     return Wq, e
 
@@ -178,7 +186,8 @@ def nvfp4_global_scale(W, w_dt=DT_BF16) -> float:
 def qdq_nvfp4_fwd(W, V, max_s, global_scale, G, gs=16, w_dt=DT_BF16, init_scale=1.0, bounds=(0.0, 1.0)):
     Wq = np.empty(G * gs, dtype=np_dtype(w_dt))
     sc = np.empty(G, dtype=np.float32)
-    lib().oracle_qdq_nvfp4_fwd(_p(W), _p(V), _p(max_s), _f(init_scale), _f(global_scale), ctypes.c_int64(G), gs,
+    i_s, i_a = _init(init_scale)
+    lib().oracle_qdq_nvfp4_fwd(_p(W), _p(V), _p(max_s), i_s, _p(i_a), _f(global_scale), ctypes.c_int64(G), gs,
                                w_dt, _f(bounds[0]), _f(bounds[1]), _p(Wq), _p(sc))
     return Wq, sc
 
@@ -196,7 +205,8 @@ def qdq_fp4_bwd(dXq, W, V, max_s, G, gs, mode, w_dt=DT_BF16, init_scale=1.0, glo
     """-> (dV f32 [G*gs], dmax f32 [G]) : autograd-equivalent gradients of the fp4 fake-quant."""
     dV = np.empty(G * gs, dtype=np.float32)
     dmax = np.empty(G, dtype=np.float32)
-    lib().oracle_qdq_fp4_bwd(_p(dXq), _p(W), _p(V), _p(max_s), _f(init_scale), _f(global_scale), ctypes.c_int64(G), gs,
+    i_s, i_a = _init(init_scale)
+    lib().oracle_qdq_fp4_bwd(_p(dXq), _p(W), _p(V), _p(max_s), i_s, _p(i_a), _f(global_scale), ctypes.c_int64(G), gs,
                              mode, w_dt, _f(bounds[0]), _f(bounds[1]), _p(dV), _p(dmax))
     return dV, dmax
 
@@ -232,3 +242,39 @@ def search_fp4_scale(X, G, gs, mode, x_dt=DT_BF16, qw_row=None, groups_per_row=0
     lib().oracle_search_fp4_scale(_p(X), _p(qw), ctypes.c_int64(groups_per_row), _f(global_scale), _p(cand), len(cand),
                                   ctypes.c_int64(G), gs, mode, x_dt, _p(best))
     return best
+
+
+def outlier_mse_fwd_bwd(pred, ref, act_dt=DT_BF16, gout=1000.0, topk=None, token_mask=None, row_len=0):
+    n = pred.size
+    topk = max(1, n // 1000) if topk is None else topk
+    loss = np.zeros(1, dtype=np.float32)
+    dropped = np.zeros(1, dtype=np.int64)
+    dpred = np.empty(n, dtype=np_dtype(act_dt))
+    tm = None if token_mask is None else np.ascontiguousarray(token_mask, dtype=np.uint8)
+    lib().oracle_outlier_mse_fwd_bwd(_p(pred), _p(ref), ctypes.c_int64(n), act_dt, _f(gout), ctypes.c_int64(topk), _p(tm),
+                                     ctypes.c_int64(row_len), _p(loss), _p(dpred), _p(dropped))
+    return float(loss[0]), dpred, int(dropped[0])
+
+
+def int_search_candidates(bits: int, ratio: float = 0.75) -> np.ndarray:
+    """The candidate numerators of search_scales (auto_round/data_type/int.py:49-64), the initial nmax first."""
+    nmax = int(2.0 ** (bits - 1))
+    if bits == 2:
+        search_min, step = 18 * 5, 0.01
+    else:
+        grid = 200
+        search_min = nmax * ratio
+        step = search_min / grid * 2
+        search_min = int(search_min / step)
+    c = [float(nmax)] + [nmax - step * i for i in range(-search_min, search_min + 1) if i != 0]
+    return np.asarray(c, dtype=np.float32)
+
+
+def search_int_scale(X, G, gs, bits, x_dt=DT_BF16, qw_row=None, groups_per_row=0, q_thresh=1e-5):
+    cand = int_search_candidates(bits)
+    raw = np.empty(G, dtype=np_dtype(x_dt))
+    init = np.empty(G, dtype=np_dtype(x_dt))
+    qw = None if qw_row is None else np.ascontiguousarray(qw_row, dtype=np.float32)
+    lib().oracle_search_int_scale(_p(X), _p(qw), ctypes.c_int64(groups_per_row), _p(cand), len(cand), ctypes.c_int64(G), gs,
+                                  bits, x_dt, _f(q_thresh), _p(raw), _p(init))
+    return raw, init

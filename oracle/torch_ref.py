@@ -14,6 +14,11 @@ Reference entry points restated here (paths relative to /root/reference):
   RefWrapperLinear   <- auto_round/wrapper.py:139-293, :517-565
   sign_sgd_step      <- auto_round/algorithms/quantization/sign_round/sign_sgd.py:356-389
   tune_block         <- auto_round/algorithms/quantization/sign_round/quantizer.py:311-552
+Algorithm extension (enable_alg_ext / SignRoundV2), pinned by tests/golden/search.npz, stepv2_*.npz, outlier_loss.npz:
+  search_int_scale / search_mx_coeff / search_nv_coeff <- data_type/int.py:24-86, mxfp.py:103-170, nvfp.py:329-386
+  RefOptWrapperLinear <- algorithms/quantization/sign_roundv2/quantizer.py:101-161
+  outlier_loss        <- algorithms/quantization/sign_roundv2/quantizer.py:362-399
+  collect_imatrix     <- algorithms/quantization/sign_roundv2/quantizer.py:413-428
 """
 from __future__ import annotations
 
@@ -105,9 +110,9 @@ def qdq_nvfp4(X, gs, v, max_scale, global_scale, init_scale=1.0):
     """NVFP4 fake-quant (data_type/nvfp.py:67-98).  Returns (Xq like X, e4m3-valued scale [G,1] fp32)."""
     od = X.dtype
     xg = X.reshape(-1, gs)
+    if isinstance(max_scale, torch.Tensor) and max_scale.dim() == 1:
+        max_scale = max_scale.view(-1, 1)
     coeff = max_scale * init_scale
-    if isinstance(coeff, torch.Tensor):
-        coeff = coeff.view(-1, 1)
     vm = torch.max(xg.abs(), dim=-1, keepdim=True)[0].to(torch.float32) * coeff
     s = global_scale * (vm * (1.0 / 6.0))
     s = torch.clamp(s, min=-448.0, max=448.0)
@@ -116,6 +121,113 @@ def qdq_nvfp4(X, gs, v, max_scale, global_scale, init_scale=1.0):
     x = torch.clamp(xg.to(torch.float32) * osc + v, -6.0, 6.0)
     out = _e2m1_nv(x) * _recip0(osc)
     return out.reshape(X.shape).to(od), s
+
+
+# ---- algorithm extension: init-scale searches -------------------------------------------------------------------------
+def _recip_eps(t):
+    """get_reciprocal (utils/common.py:903-920): 1/t in t's dtype, 0 where |t| < eps (1e-5 for fp16, else 1e-30)."""
+    eps = 1e-5 if t.dtype == torch.float16 else 1e-30
+    ok = t.abs() >= eps
+    return torch.where(ok, 1.0 / torch.where(ok, t, torch.ones_like(t)), torch.zeros_like(t))
+
+
+def int_search_grid(bits, ratio=0.75):
+    nmax = 2 ** (bits - 1)
+    if bits == 2:
+        n, step = 90, 0.01
+    else:
+        half = nmax * ratio
+        step = half / 200 * 2
+        n = int(half / step)
+    return nmax, [nmax - step * i for i in range(-n, n + 1) if i != 0]
+
+
+def search_int_scale(Wg, bits, qw=None, thresh=1e-5):
+    """Per-group symmetric scale minimising the importance-weighted rounding error over the reference's grid of
+    numerators around nmax; everything in Wg's dtype.  Returns the clamped init scale [G, 1]."""
+    nmax, grid = int_search_grid(bits)
+    idx = Wg.abs().argmax(dim=-1, keepdim=True)
+    rg = _recip_eps(torch.take_along_dim(Wg, idx, dim=-1))
+
+    def trial(c):
+        isc = -c * rg
+        sc = _recip_eps(isc)
+        L = torch.round(isc * Wg).clamp_(-nmax, nmax - 1)
+        err = ((sc * L - Wg).to(torch.float32)) ** 2
+        if qw is not None:
+            err = err * qw
+        return sc, err.sum(dim=-1)
+
+    best_s, best_l = trial(nmax)
+    for c in grid:
+        sc, l = trial(c)
+        better = l < best_l
+        best_s = torch.where(better.unsqueeze(-1), sc, best_s)
+        best_l = torch.where(better, l, best_l)
+    return torch.where(best_s < 0, torch.clamp(best_s, max=-thresh), torch.clamp(best_s, min=thresh))
+
+
+def _search_coeff(qdq_at, X32, cands, qw):
+    best_c, best_l = None, None
+    for c in cands:
+        err = (qdq_at(c) - X32) ** 2
+        if qw is not None:
+            err = err * qw
+        l = err.sum(dim=-1)
+        if best_l is None:
+            best_l, best_c = l, torch.full_like(l, c)
+        else:
+            better = l < best_l
+            best_l = torch.where(better, l, best_l)
+            best_c = torch.where(better, torch.full_like(l, c), best_c)
+    return best_c.unsqueeze(-1)
+
+
+def search_mx_coeff(Wg, qw=None):
+    """MXFP4: which of the coefficients 1, 0.5, 2 on the group max gives the smallest weighted error -> [G, 1] fp32."""
+    X32 = Wg.to(torch.float32)
+    ones = torch.ones(Wg.shape[0], device=Wg.device)
+    return _search_coeff(lambda c: qdq_mxfp4(X32, Wg.shape[-1], 0, ones * c)[0], X32, (1.0, 0.5, 2.0), qw)
+
+
+def search_nv_coeff(Wg, qw=None):
+    """NVFP4: coefficient in {1.0, 0.50 .. 1.51} on the group max (global scale = the tensor's own) -> [G, 1] fp32."""
+    X32 = Wg.to(torch.float32)
+    gsc = nvfp4_global_scale(X32)
+    ones = torch.ones(Wg.shape[0], device=Wg.device)
+    cands = [1.0] + [v / 100.0 for v in range(50, 152) if v != 100]
+    return _search_coeff(lambda c: qdq_nvfp4(X32, Wg.shape[-1], 0, ones * c, gsc)[0], X32, cands, qw)
+
+
+def outlier_loss(pred, ref, token_mask=None):
+    """mean(((|pred-ref| in fp32) * token_mask * keep)^2), keep = all but the max(1, n/1000) largest |pred-ref| ranked in
+    the activation dtype (ties at the k-th value: whatever torch.topk picks)."""
+    d = (pred - ref).abs().view(-1)
+    k = max(1, int(d.numel() / 1000))
+    keep = torch.ones_like(d, dtype=torch.bool)
+    keep[torch.topk(d, k)[1]] = False
+    e = (pred.to(torch.float32) - ref.to(torch.float32)).abs() * keep.view_as(pred)
+    if token_mask is not None:
+        e = e * token_mask
+    return torch.mean(e ** 2)
+
+
+@torch.no_grad()
+def collect_imatrix(block, inputs, input_others, batch_size=8, forward=None, amp_dtype=torch.bfloat16, amp=True):
+    """Run the fp block over all samples and leave `imatrix` = sum over tokens of x^2 (fp32 [in]) on every layer that
+    will be quantised."""
+    def hook(m, inp, out):
+        x = inp[0] if isinstance(inp, (tuple, list)) else inp
+        sq = (x.reshape(-1, x.shape[-1]).to(torch.float32) ** 2).sum(dim=0)
+        m.imatrix = sq if not hasattr(m, "imatrix") else m.imatrix + sq
+
+    hs = [m.register_forward_hook(hook) for m in block.modules()
+          if isinstance(m, torch.nn.Linear) and int(getattr(m, "bits", 16)) < 16]
+    for b0 in range(0, inputs.shape[0], batch_size):
+        with torch.autocast(device_type=inputs.device.type, dtype=amp_dtype, enabled=amp):
+            forward(block, inputs[b0:b0 + batch_size], input_others) if forward else block(inputs[b0:b0 + batch_size], **input_others)
+    for h in hs:
+        h.remove()
 
 
 def nvfp4_global_scale(t):
@@ -207,6 +319,59 @@ class RefWrapperLinear(torch.nn.Module):
         return self.orig_layer
 
 
+class RefOptWrapperLinear(RefWrapperLinear):
+    """Algorithm-extension wrapper: searched init scale (weighted by the layer's `imatrix`, consumed here), max_scale
+    tunes a coefficient on it within (0, 2), min_scale takes no part.  Symmetric int / mx_fp4 / nv_fp4."""
+
+    bounds = (0.0, 2.0)
+
+    def __init__(self, layer, enable_minmax_tuning=True):
+        super().__init__(layer, enable_minmax_tuning)
+        W = layer.weight.data
+        pad = (-W.shape[1]) % self.gs
+        Wg = (F.pad(W, (0, pad)) if pad else W).reshape(-1, self.gs)
+        im = getattr(layer, "imatrix", None)
+        qw = None
+        if isinstance(im, torch.Tensor):
+            row = F.pad(im.reshape(1, -1).to(torch.float32), (0, pad), value=1e-5)
+            qw = row.expand(W.shape[0], -1).reshape(Wg.shape).to(W.device)
+            del layer.imatrix
+        if self.data_type.startswith("mx_fp"):
+            self.init_scale = search_mx_coeff(Wg, qw)
+        elif self.data_type.startswith("nv_fp"):
+            self.init_scale = search_nv_coeff(Wg, qw)
+        elif self.sym:
+            self.init_scale = search_int_scale(Wg, self.bits, qw, self.thresh)
+        else:
+            raise ValueError("the optimized path needs a symmetric int / mx / nv data type")
+
+    def qdq(self, v=None, mn=None, mx=None):
+        v = self.value if v is None else v
+        mn = self.min_scale if mn is None else mn
+        mx = self.max_scale if mx is None else mx
+        mn.data.clamp_(*self.bounds)
+        mx.data.clamp_(*self.bounds)
+        W = self.orig_layer.weight
+        if self.data_type.startswith("mx_fp"):
+            wq, se = qdq_mxfp4(W, self.gs, v, mx, self.init_scale)
+            return wq, se, None
+        if self.data_type.startswith("nv_fp"):
+            if not hasattr(self, "gscale"):
+                g = getattr(self.orig_layer, "weight_global_scale", None)
+                self.gscale = (nvfp4_global_scale(W) if g is None else g).to(W.device)
+            wq, sc = qdq_nvfp4(W, self.gs, v, mx, self.gscale, self.init_scale)
+            return wq, sc, None
+        out_f, in_f = W.shape
+        pad = (-in_f) % self.gs
+        Wg = (F.pad(W, (0, pad)) if pad else W).reshape(-1, self.gs)
+        maxq = 2 ** (self.bits - 1)
+        s = (self.init_scale * (mx.unsqueeze(-1) if mx.dim() == 1 else mx)).to(self.scale_dtype)
+        s = torch.where(s < 0, torch.clamp(s, max=-self.thresh), torch.clamp(s, min=self.thresh))
+        q = torch.clamp(_ste(torch.round, Wg / s + v), -maxq, maxq - 1)
+        wq = (s * q).to(W.dtype).reshape(out_f, in_f + pad)[:, :in_f]
+        return wq, s, maxq
+
+
 class RefWALayer(torch.nn.Module):
     def __init__(self, layer):
         super().__init__()
@@ -216,7 +381,8 @@ class RefWALayer(torch.nn.Module):
         return F.linear(act_fake_quant(x, self.orig_layer), self.orig_layer.weight, self.orig_layer.bias)
 
 
-def wrap_block(block, enable_minmax_tuning=True) -> List[str]:
+def wrap_block(block, enable_minmax_tuning=True, wrapper_cls=None) -> List[str]:
+    wrapper_cls = wrapper_cls or RefWrapperLinear
     names = []
     for n, m in list(block.named_modules()):
         if isinstance(m, torch.nn.Linear) and int(getattr(m, "bits", 16)) < 16:
@@ -224,7 +390,7 @@ def wrap_block(block, enable_minmax_tuning=True) -> List[str]:
             parts = n.split(".")
             for p in parts[:-1]:
                 parent = getattr(parent, p)
-            setattr(parent, parts[-1], RefWrapperLinear(m, enable_minmax_tuning))
+            setattr(parent, parts[-1], wrapper_cls(m, enable_minmax_tuning))
             names.append(n)
     return names
 
@@ -279,10 +445,17 @@ class Sampler:
 
 def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others: dict, *, iters=200, batch_size=8,
                lr=None, enable_minmax_tuning=True, amp_dtype=torch.bfloat16, forward=None, record=None,
-               max_iters_to_run=None, input_ids=None, amp=True):
+               max_iters_to_run=None, input_ids=None, amp=True, alg_ext=False):
     """The reference's quantize_block loop in plain torch.  inputs/targets: [N, S, H].  Returns best_params and
     leaves the block unwrapped with baked weights.  `forward(block, x, others)` defaults to block(x, **others)[0]."""
-    names = wrap_block(block, enable_minmax_tuning)
+    use_outlier_loss = False
+    wrapper_cls = RefWrapperLinear
+    if alg_ext:     # SignRoundV2Quantizer.prepare_run: optimized wrapper for sym int/mx/nv; outlier loss for <4 bits / A4
+        first = next((m for m in block.modules() if isinstance(m, torch.nn.Linear) and int(getattr(m, "bits", 16)) < 16), None)
+        if first is not None and bool(first.sym):
+            wrapper_cls = RefOptWrapperLinear
+            use_outlier_loss = int(getattr(first, "act_bits", 16)) <= 4 or int(first.bits) < 4
+    names = wrap_block(block, enable_minmax_tuning, wrapper_cls)
     wrappers = {n: m for n, m in block.named_modules() if isinstance(m, RefWrapperLinear)}
     lr0 = lr if lr is not None else 1.0 / iters
     lrs = linear_lr_stream(lr0, iters)
@@ -307,7 +480,10 @@ def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others:
             out = forward(block, x, input_others) if forward else block(x, **input_others)
             if isinstance(out, (tuple, list)):
                 out = out[0]
-        if vmask is not None:
+        if use_outlier_loss:
+            loss = outlier_loss(out, ref.to(out.dtype), None if vmask is None else vmask[idx].unsqueeze(-1))
+            total = loss.item() / (1 if vmask is None else max(1, int(torch.count_nonzero(vmask[idx]).item())))
+        elif vmask is not None:
             m = vmask[idx].unsqueeze(-1)
             loss = mse((out * m).to(torch.float32), (ref * m).to(torch.float32))
             total = loss.item() / max(1, int(torch.count_nonzero(vmask[idx]).item()))

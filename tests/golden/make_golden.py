@@ -412,3 +412,91 @@ def gen_search():
 
 if __name__ == "__main__" and ("search" in sys.argv[1:] or not sys.argv[1:]):
     gen_search()
+
+
+def gen_outlier_loss():
+    """Outlier-suppressed loss of the algorithm extension through SignRoundV2Quantizer._get_loss."""
+    from types import SimpleNamespace
+
+    from auto_round.algorithms.quantization.sign_roundv2.quantizer import SignRoundV2Quantizer as V2
+
+    g = torch.Generator().manual_seed(13)
+    pred = torch.randn(4, 64, 128, generator=g).to(torch.bfloat16)
+    ref = (pred.float() + 0.05 * torch.randn(4, 64, 128, generator=g)).to(torch.bfloat16)
+    ref.view(-1)[::997] += 3.0            # a few real outliers
+    fake = SimpleNamespace(_use_outlier_suppressed_loss=True, amp=True, amp_dtype=torch.bfloat16)
+    rec = dict(pred=bits(pred), ref=bits(ref))
+    for tag, vmask in (("plain", None), ("masked", [torch.ones(1, 64, dtype=torch.long) for _ in range(4)])):
+        if vmask is not None:
+            for m in vmask:
+                m[0, -1] = 0
+        p2 = pred.detach().clone().requires_grad_(True)
+        loss = V2._get_loss(fake, p2, ref, [0, 1, 2, 3], torch.nn.MSELoss(), "cpu", vmask)
+        (loss * 1000).backward()
+        rec[f"loss_{tag}"] = np.float32(loss.item())
+        rec[f"dpred_{tag}"] = bits(p2.grad)
+        if vmask is not None:
+            rec["mask"] = torch.cat(vmask).reshape(-1).numpy().astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "outlier_loss.npz"), **rec)
+    print("outlier loss ok", rec["loss_plain"], rec["loss_masked"])
+
+
+if __name__ == "__main__" and ("outlier" in sys.argv[1:] or not sys.argv[1:]):
+    gen_outlier_loss()
+
+
+def gen_steps_v2():
+    """Three tuning steps through the algorithm extension's SignRoundOptimizedWrapperLinear (searched init_scale from the
+    layer's imatrix, min/max-scale bounds (0, 2)) + the reference optimizer, for the three data types it supports."""
+    from auto_round.algorithms.quantization.sign_round.sign_sgd import SignSGD
+    from auto_round.algorithms.quantization.sign_roundv2.quantizer import SignRoundOptimizedWrapperLinear as OptW
+
+    out_f, in_f, iters = 32, 256, 200
+    g0 = torch.Generator().manual_seed(99)
+    imatrix = ((torch.rand(in_f, generator=g0) * 3.0 + 0.05) ** 2 * 50.0).to(torch.float32)
+    for name, nbits, gs, dtype_name in (("w4g128", 4, 128, "int"), ("w2g32", 2, 32, "int"), ("mxfp4", 4, 32, "mx_fp"),
+                                        ("nvfp4", 4, 16, "nv_fp")):
+        lin = attr_linear(in_f, out_f, nbits, gs, True, torch.bfloat16, data_type=dtype_name, seed=41)
+        lin.imatrix = imatrix.clone()
+        lin.iters = iters
+        W0 = lin.weight.data.clone()
+        w = OptW(lin, enable_minmax_tuning=True, enable_torch_compile=False, device="cpu")
+        lr0 = 1.0 / iters
+        opt = SignSGD([{"params": [w.params["value"]], "lr": torch.tensor(lr0)},
+                       {"params": [w.params["min_scale"], w.params["max_scale"]], "lr": torch.tensor(lr0)}],
+                      lr=torch.tensor(lr0), weight_decay=0)
+        sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=0.0, total_iters=iters)
+        g = torch.Generator().manual_seed(4)
+        init = w.init_scale
+        rec = dict(W=bits(W0), imatrix=imatrix.numpy(), meta=np.array([nbits, gs, out_f, in_f, iters]),
+                   init_scale=bits(init.reshape(-1)) if init.dtype != torch.float32 else init.reshape(-1).numpy())
+        if dtype_name == "nv_fp":
+            rec["global_scale"] = np.float32(w.weight_global_scale.item())
+        with torch.no_grad():
+            w.value.copy_((torch.rand(w.value.shape, generator=g) - 0.5))
+            w.max_scale.copy_(0.7 + 1.4 * torch.rand(w.max_scale.shape, generator=g))   # some > 2 -> the (0,2) clamp is live
+        rec["V0"] = w.value.detach().numpy().copy()
+        rec["max0"] = w.max_scale.detach().numpy().copy()
+        for step in range(3):
+            dWq = (torch.randn(out_f, in_f, generator=g) * 1e-3).to(torch.bfloat16)
+            wq, _, _ = w._qdq_weight(w.value, w.min_scale, w.max_scale)
+            rec[f"Wq{step}"] = bits(wq)
+            wq.backward(dWq)
+            rec[f"dWq{step}"] = bits(dWq)
+            rec[f"gmax{step}"] = w.max_scale.grad.numpy().copy()
+            assert w.min_scale.grad is None
+            opt.step(); opt.zero_grad(); sched.step()
+            rec[f"V{step + 1}"] = w.value.detach().numpy().copy()
+            rec[f"max{step + 1}"] = w.max_scale.detach().numpy().copy()
+        best = {k: v.data.clone() for k, v in w.params.items()}
+        with torch.no_grad():
+            layer = w.unwrapper(best)
+        rec["W_final"] = bits(layer.weight.data)
+        sc = layer.scale
+        rec["scale_final"] = bits(sc.reshape(-1)) if sc.dtype in (torch.float16, torch.bfloat16, torch.uint8) else sc.reshape(-1).float().numpy()
+        np.savez_compressed(os.path.join(HERE, f"stepv2_{name}.npz"), **rec)
+        print("stepv2", name, "init dtype", init.dtype, tuple(init.shape), "scale", sc.dtype, tuple(sc.shape))
+
+
+if __name__ == "__main__" and ("stepv2" in sys.argv[1:] or not sys.argv[1:]):
+    gen_steps_v2()

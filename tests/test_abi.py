@@ -34,7 +34,7 @@ def test_header_declares_expected_entry_points():
     fns = header_functions()
     for name in ("ar_qdq_int_fwd", "ar_qdq_int_bwd", "ar_qdq_int_bwd_sgd", "ar_sign_sgd", "ar_mse_loss_fwd_bwd",
                  "ar_gather_rows", "ar_pack_int", "ar_qdq_fp4_fwd", "ar_qdq_fp4_bwd_sgd", "ar_pack_fp4",
-                 "ar_group_minmax", "ar_group_absmax", "ar_best_loss_update", "ar_fp4_act_bwd", "ar_pack_awq", "ar_search_fp4_scale"):
+                 "ar_group_minmax", "ar_group_absmax", "ar_best_loss_update", "ar_fp4_act_bwd", "ar_pack_awq", "ar_search_fp4_scale", "ar_outlier_mse_loss_fwd_bwd"):
         assert name in fns
 
 

@@ -513,3 +513,74 @@ def test_non_default_weight_dtypes_vs_torch_ref(wdtype, amp):
     agree = [(lm[n].weight == lo[n].weight).float().mean().item() for n in lo]
     assert all(lm[n].weight.dtype == wdtype for n in lm)
     assert np.mean(agree) > 0.97, agree
+
+
+@pytest.mark.parametrize("bits,data_type,gs", [(4, "int", 32), (2, "int", 32), (4, "mx_fp", 32), (4, "nv_fp", 16)])
+def test_algorithm_extension_block_vs_torch_ref(bits, data_type, gs):
+    """SignRoundV2Quantizer.compress_block (imatrix hooks -> searched init scales -> optimized wrapper -> outlier-
+    suppressed loss for W2) against torch_ref.tune_block(alg_ext=True), the pinned restatement of the reference's V2."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundV2Quantizer
+    from oracle import torch_ref as tr
+
+    layer, rope, cfg = make_layer("llama", bits, gs, True, seed=2)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.data_type = data_type
+            m.act_data_type = data_type
+    X, others = make_data(rope, cfg)
+    iters, bs = 4, 4
+
+    blk_o = copy.deepcopy(layer)
+    Y = targets(blk_o, X, others, bs)
+    tr.collect_imatrix(blk_o, X, others, batch_size=bs, forward=fwd)
+    im_ref = {n: m.imatrix.clone() for n, m in linears(blk_o).items()}
+    wr_init = {}
+
+    def record(i, wrappers, total):
+        if i == 0:
+            for n, w in wrappers.items():
+                wr_init[n] = w.init_scale.reshape(-1).float().clone()
+
+    random.seed(11)
+    best_o, info = tr.tune_block(blk_o, X, Y, others, iters=iters, batch_size=bs, forward=fwd, alg_ext=True, record=record)
+
+    blk_m = copy.deepcopy(layer)
+    random.seed(11)
+    q = SignRoundV2Quantizer(SignRoundConfig(iters=iters, batch_size=bs, bits=bits, enable_quanted_input=False), device="cuda")
+    # the imatrix the hooks collect == the restatement's
+    q.prepare_block(blk_m)
+    hs = q.register_fp_input_forward_hooks(blk_m)
+    q.forward_all(blk_m, X, others, bs)
+    for h in hs:
+        h.remove()
+    for n, m in linears(blk_m).items():
+        assert torch.allclose(m.imatrix, im_ref[n], rtol=1e-5), n
+        del m.imatrix
+    fp_out, q_out, best_m = q.compress_block(blk_m, X, others)
+    assert q._optimized is not None and (q._use_outlier_suppressed_loss == (bits < 4))
+    st = q.last_stats
+    assert torch.equal(fp_out, Y)
+    assert abs(st["init_loss"] - info["losses"][0]) <= 5e-3 * info["losses"][0], (st, info["losses"])
+    assert abs(st["best_loss"] - info["best_loss"]) <= 3e-2 * info["best_loss"]
+    lo, lm = linears(blk_o), linears(blk_m)
+    agree = [(lm[n].weight == lo[n].weight).float().mean().item() for n in lo]
+    assert np.mean(agree) > 0.97, agree
+    for n in lo:
+        assert float(best_m[n]["max_scale"].max()) <= 2.0 and float(best_m[n]["max_scale"].min()) >= 0.0
+        assert torch.equal(best_m[n]["min_scale"], torch.ones_like(best_m[n]["min_scale"]))
+
+
+def test_algorithm_extension_rejects_asym_and_falls_back_like_reference():
+    """asym int: the reference keeps the plain WrapperLinear (prepare_run's scheme.sym test); the optimized wrapper itself
+    raises for it."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundV2Quantizer
+    from auto_round_amd.wrapper import SignRoundOptimizedWrapperLinear, WrapperLinear
+
+    layer, rope, cfg = make_layer("llama", 4, 32, False, seed=2)
+    q = SignRoundV2Quantizer(SignRoundConfig(iters=2, batch_size=4), device="cuda")
+    q.prepare_block(layer)
+    assert not q._optimized and not q._use_outlier_suppressed_loss and q.register_fp_input_forward_hooks(layer) != []
+    lin = next(m for m in layer.modules() if isinstance(m, torch.nn.Linear))
+    with pytest.raises(ValueError):
+        SignRoundOptimizedWrapperLinear(lin, device="cuda")
+    assert WrapperLinear.minmax_scale_bound == (0.0, 1.0) and SignRoundOptimizedWrapperLinear.minmax_scale_bound == (0.0, 2.0)

@@ -190,3 +190,158 @@ def test_fp4_restatements_equal_reference_golden():
         a, b = orc.to_bits(x.grad), za["dx"]
         nan = np.isnan(orc.from_bits(b, orc.DT_BF16).float().numpy())
         assert np.array_equal(a[~nan], b[~nan])
+
+
+# ---- algorithm extension (SignRoundV2) -------------------------------------------------------------------------------
+def test_alg_ext_init_scale_searches_equal_reference_golden():
+    z = np.load(os.path.join(GOLDEN, "search.npz"))
+    im = torch.from_numpy(z["imatrix"].astype(np.float32))
+    for nb, gs in ((4, 128), (2, 32), (3, 64)):
+        Wg = orc.from_bits(z[f"int{nb}g{gs}_W"].reshape(-1), orc.DT_BF16).reshape(-1, gs)
+        qw = im.reshape(1, -1).expand(Wg.numel() // im.numel(), -1).reshape(Wg.shape)
+        assert np.array_equal(orc.to_bits(tr.search_int_scale(Wg, nb, qw).reshape(-1)), z[f"int{nb}g{gs}_init"])
+        assert np.array_equal(orc.to_bits(tr.search_int_scale(Wg, nb, None).reshape(-1)), z[f"int{nb}g{gs}_init_ones"])
+    for kind, gs, fn in (("mxfp4", 32, tr.search_mx_coeff), ("nvfp4", 16, tr.search_nv_coeff)):
+        Wg = orc.from_bits(z[f"{kind}_W"].reshape(-1), orc.DT_BF16).reshape(-1, gs)
+        qw = im.reshape(1, -1).expand(Wg.numel() // im.numel(), -1).reshape(Wg.shape)
+        assert np.array_equal(fn(Wg, qw).reshape(-1).numpy(), z[f"{kind}_best_qw"])
+        assert np.array_equal(fn(Wg, None).reshape(-1).numpy(), z[f"{kind}_best_ones"])
+
+
+V2_FILES = sorted(glob.glob(os.path.join(GOLDEN, "stepv2_*.npz")))
+
+
+@pytest.mark.parametrize("path", V2_FILES, ids=[os.path.basename(p)[7:-4] for p in V2_FILES])
+def test_alg_ext_wrapper_steps_equal_reference_golden(path):
+    """RefOptWrapperLinear == the reference's SignRoundOptimizedWrapperLinear: init scale, three fwd/bwd/sign-SGD steps."""
+    z = np.load(path)
+    nbits, gs, out_f, in_f, iters = [int(x) for x in z["meta"]]
+    kind = os.path.basename(path)[7:-4]
+    lin = torch.nn.Linear(in_f, out_f, bias=False)
+    lin.weight.data = orc.from_bits(z["W"], orc.DT_BF16).reshape(out_f, in_f)
+    lin.weight.requires_grad_(False)
+    dt = {"mxfp4": "mx_fp", "nvfp4": "nv_fp"}.get(kind, "int")
+    for k, v in dict(bits=nbits, group_size=gs, sym=True, data_type=dt, scale_dtype=torch.float16, act_bits=16).items():
+        setattr(lin, k, v)
+    lin.imatrix = torch.from_numpy(z["imatrix"].copy())
+    w = tr.RefOptWrapperLinear(lin)
+    init = w.init_scale.reshape(-1)
+    if kind.startswith("w"):
+        assert np.array_equal(orc.to_bits(init), z["init_scale"])
+    else:
+        assert np.array_equal(init.numpy(), z["init_scale"])
+    with torch.no_grad():
+        w.value.copy_(torch.from_numpy(z["V0"].copy()))
+        w.max_scale.copy_(torch.from_numpy(z["max0"].copy()))
+    lrs = tr.linear_lr_stream(1.0 / iters, iters)
+    for step in range(3):
+        wq, _, _ = w.qdq()
+        assert np.array_equal(orc.to_bits(wq), z[f"Wq{step}"]), f"step {step}: Wq"
+        wq.backward(orc.from_bits(z[f"dWq{step}"], orc.DT_BF16).reshape(out_f, in_f))
+        assert w.min_scale.grad is None
+        assert np.array_equal(w.max_scale.grad.numpy(), z[f"gmax{step}"], equal_nan=True), f"step {step}: d max_scale"   # all-zero fp4 group: NaN in both
+        tr.sign_sgd_step(list(w.params.values()), lrs[step])
+        for p in w.params.values():
+            p.grad = None
+        assert np.array_equal(w.value.detach().numpy(), z[f"V{step + 1}"]), f"step {step}: V"
+        assert np.array_equal(w.max_scale.detach().numpy(), z[f"max{step + 1}"], equal_nan=True), f"step {step}: max_scale"
+    layer = w.unwrap({k: p.data.clone() for k, p in w.params.items()})
+    assert np.array_equal(orc.to_bits(layer.weight.data), z["W_final"])
+
+
+def test_alg_ext_outlier_loss_equals_reference_golden():
+    z = np.load(os.path.join(GOLDEN, "outlier_loss.npz"))
+    pred = orc.from_bits(z["pred"], orc.DT_BF16).reshape(4, 64, 128)
+    ref = orc.from_bits(z["ref"], orc.DT_BF16).reshape(4, 64, 128)
+    for tag, m in (("plain", None), ("masked", torch.from_numpy(z["mask"].astype(np.int64)).reshape(4, 64, 1))):
+        p = pred.clone().requires_grad_(True)
+        loss = tr.outlier_loss(p, ref, m)
+        (loss * 1000).backward()
+        assert loss.item() == float(z[f"loss_{tag}"])
+        assert np.array_equal(orc.to_bits(p.grad), z[f"dpred_{tag}"])
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("bits,data_type,group_size", [(4, "int", 32), (2, "int", 32), (4, "mx_fp", 32), (4, "nv_fp", 16)])
+def test_alg_ext_tune_block_equals_reference_loop_on_cpu(bits, data_type, group_size):
+    """Same seeded layer and data, 5 iterations of the reference's V2 pieces (imatrix hooks, optimized wrapper, V2
+    loss, SignSGD, LinearLR) vs tune_block(alg_ext=True)."""
+    import copy
+    from types import SimpleNamespace
+
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, REF):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from auto_round.algorithms.quantization.sign_round.sign_sgd import SignSGD
+    from auto_round.algorithms.quantization.sign_roundv2.quantizer import SignRoundOptimizedWrapperLinear, SignRoundV2Quantizer
+    from auto_round.compressors.utils import IndexSampler, collect_best_params
+    from auto_round.wrapper import unwrapper_block, wrapper_block
+
+    iters, bs, N, S, H = 5, 2, 8, 16, 64
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(N, S, H, generator=g).to(torch.bfloat16)
+    base = _opt_layer(group_size=group_size, bits=bits, sym=True)
+    for m in base.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.data_type = data_type
+            m.act_data_type = data_type
+    def fwd(blk, x, others):
+        out = blk(x)
+        return out[0] if isinstance(out, tuple) else out
+
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        Y = torch.cat([fwd(base, X[i:i + 1], {}) for i in range(N)])
+    use_outlier = bits < 4
+
+    # --- reference pieces
+    blk_ref = copy.deepcopy(base)
+    fake = SimpleNamespace(_use_outlier_suppressed_loss=use_outlier, amp=True, amp_dtype=torch.bfloat16,
+                           _is_wint4aint4=lambda: False)
+    hs = SignRoundV2Quantizer._register_imatrix_hooks(fake, blk_ref)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        for b0 in range(0, N, bs):
+            fwd(blk_ref, X[b0:b0 + bs], {})
+    for h in hs:
+        h.remove()
+    random.seed(7)
+    wrapper_block(blk_ref, True, False, enable_torch_compile=False, device="cpu", wrapper_cls=SignRoundOptimizedWrapperLinear)
+    wr = {n: m for n, m in blk_ref.named_modules() if hasattr(m, "orig_layer")}
+    rp = [m.params["value"] for m in wr.values()]
+    mp = [p for m in wr.values() for k, p in m.params.items() if "min" in k or "max" in k]
+    lr0 = 1.0 / iters
+    opt = SignSGD([{"params": rp, "lr": torch.tensor(lr0)}, {"params": mp, "lr": torch.tensor(lr0)}], lr=torch.tensor(lr0),
+                  weight_decay=0)
+    sch = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=0.0, total_iters=iters)
+    sampler = IndexSampler(N, bs)
+    best_loss, best, ref_losses = float("inf"), {}, []
+    for i in range(iters):
+        idx = sampler.next_batch()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = fwd(blk_ref, X[idx], {})
+        if use_outlier:
+            loss = SignRoundV2Quantizer._get_loss(fake, out, Y[idx], idx, torch.nn.MSELoss(), "cpu", None)
+        else:
+            loss = torch.nn.MSELoss()(out.float(), Y[idx].float())
+        ref_losses.append(loss.item())
+        (loss * 1000).backward()
+        if loss.item() < best_loss:
+            best_loss = loss.item()
+            best = collect_best_params(blk_ref, "cpu")
+        opt.step(); opt.zero_grad(); sch.step()
+    with torch.no_grad():
+        unwrapper_block(blk_ref, best)
+
+    # --- restatement
+    blk_o = copy.deepcopy(base)
+    tr.collect_imatrix(blk_o, X, {}, batch_size=bs, forward=fwd)
+    random.seed(7)
+    best_o, info = tr.tune_block(blk_o, X, Y, {}, iters=iters, batch_size=bs, forward=fwd, alg_ext=True)
+    assert info["losses"] == ref_losses
+    for (n1, m1), (n2, m2) in zip(blk_ref.named_modules(), blk_o.named_modules()):
+        if isinstance(m1, torch.nn.Linear):
+            assert torch.equal(m1.weight.view(torch.int16), m2.weight.view(torch.int16)), n1
+    for n in best:
+        for k in best[n]:
+            assert torch.equal(best[n][k], best_o[n][k]), (n, k)
