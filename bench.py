@@ -281,6 +281,11 @@ def main():
     random.seed(42 + rank)
 
     def restore():
+        from auto_round_amd.wrapper import WrapperWALayer, _set_module
+
+        for n, m in list(layer.named_modules()):            # A4 schemes leave activation-quant shells around the layers
+            if isinstance(m, WrapperWALayer):
+                _set_module(layer, n, m.orig_layer)
         with torch.no_grad():
             for n, p in layer.named_parameters():
                 if p.data.shape == master[n].shape:
