@@ -150,8 +150,19 @@ def pack_layer(layer: torch.nn.Linear, backend: str = "auto_round:auto_gptq", de
     out_f, in_f = layer.weight.shape
     dt = str(getattr(layer, "data_type", "int"))
     if dt.startswith("mx_fp") or dt.startswith("nv_fp"):      # export_to_nvfp_mx.pack_layer -> qlinear_fp.QuantLinear.pack
+        # the llm_compressor ("compressed-tensors" nvfp4/mxfp4-pack-quantized) exporter packs through the same
+        # QuantLinear and only adds the static input scale (export_to_llmcompressor/export_to_fp.py:68-131)
+        input_gs = getattr(layer, "input_global_scale", None)
+        adt = str(getattr(layer, "act_data_type", ""))
+        if adt.startswith("nv_fp") and int(getattr(layer, "act_bits", 16)) <= 8 and input_gs is None \
+                and getattr(layer, "act_max", None) is not None:
+            amax = torch.as_tensor(layer.act_max, dtype=torch.float32).abs().max()
+            input_gs = torch.where(amax == 0, torch.zeros_like(amax), (448.0 * 6.0) * (1.0 / amax))   # calculate_gparam
+            layer.input_global_scale = input_gs
+            del layer.act_max
         ql = QuantLinearFP4(bits, gs, in_f, out_f, bias=layer.bias is not None, data_type=dt)
-        ql.pack(layer, layer.scale, global_scale=getattr(layer, "weight_global_scale", None), device=device)
+        ql.pack(layer, layer.scale, global_scale=getattr(layer, "weight_global_scale", None),
+                input_global_scale=input_gs, device=device)
         return ql
     if "awq" in backend:      # export_to_awq.pack_layer (export.py:114-143)
         scale, zp = layer.scale.t().contiguous(), layer.zp

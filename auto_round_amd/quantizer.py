@@ -102,6 +102,65 @@ def stack_samples(samples: Union[torch.Tensor, Sequence[torch.Tensor]], device) 
     return torch.cat([s.to(device) for s in samples], dim=0).contiguous()
 
 
+def check_need_act_calibration(act_dynamic, act_data_type=None, act_bits=16) -> bool:
+    """reference: compressors/utils.py:186-202 -- static activation quantisation needs an `act_max` per layer."""
+    if act_bits is None or act_bits > 8:
+        return False
+    if act_dynamic is not None and not act_dynamic:
+        return True
+    return act_data_type is not None and "static" in act_data_type
+
+
+def register_act_max_hooks(block) -> list:
+    """Forward hooks that track every statically activation-quantised layer's input maximum in `module.act_max`
+    (reference: AlgorithmComposer._register_act_max_hooks, composer.py:223-281): one running max over all calibration
+    tokens for NVFP4 ([1] tensor), a running per-row-group max otherwise."""
+    def collect(module, inp, out):
+        x = inp[0] if isinstance(inp, (tuple, list)) else inp
+        if x.numel() == 0:
+            return
+        adt = str(getattr(module, "act_data_type", None) or getattr(module, "data_type", ""))
+        if adt.startswith("nv_fp"):
+            m = x.detach().abs().max().to(torch.float32).reshape(1)
+            module.act_max = m if not hasattr(module, "act_max") or module.act_max.numel() == 0 \
+                else torch.max(m, module.act_max.to(m.device).max().reshape(1))
+            return
+        gs = int(module.act_group_size)
+        gs = x.shape[-1] if gs in (-1, 0) or x.shape[-1] < gs else gs
+        if x.shape[-1] % gs:
+            raise NotImplementedError("act_max calibration with a padded activation group")
+        m = x.detach().reshape(-1, gs).abs().max(dim=-1).values
+        module.act_max = m if not hasattr(module, "act_max") or module.act_max.numel() == 0 \
+            else torch.max(m, module.act_max.to(m.device))
+
+    return [m.register_forward_hook(collect) for n, m in block.named_modules()
+            if n and _quantizable(m) and check_to_quantized(m) and hasattr(m, "act_dynamic")
+            and check_need_act_calibration(m.act_dynamic, getattr(m, "act_data_type", None), getattr(m, "act_bits", 16))]
+
+
+def set_amax_for_uncalibrated_experts(block, attr_name="act_max") -> int:
+    """MoE experts that received no calibration token have no `act_max`; give them the maximum over their sibling experts'
+    same-named linear (reference: set_amax_for_all_moe_layers / set_amax_for_uncalibrated_experts, utils/model.py:2003-2143).
+    Returns the number of layers filled in."""
+    filled = 0
+    for mod in block.modules():
+        experts = getattr(mod, "experts", None)
+        if experts is None or not isinstance(experts, (list, tuple, torch.nn.ModuleList)):
+            continue
+        names = sorted({n for e in experts for n, c in e.named_children() if _quantizable(c)})
+        for name in names:
+            members = [getattr(e, name) for e in experts if hasattr(e, name)]
+            vals = [getattr(m, attr_name).reshape(-1) for m in members if getattr(m, attr_name, None) is not None]
+            if not vals:
+                continue
+            top = torch.max(torch.cat([v.to(vals[0].device) for v in vals])).reshape(1)
+            for m in members:
+                if getattr(m, attr_name, None) is None:
+                    setattr(m, attr_name, top.clone())
+                    filled += 1
+    return filled
+
+
 @dataclass
 class BlockContext:
     """reference: algorithms BlockContext -- only the fields the quantizer reads."""
@@ -400,13 +459,25 @@ class SignRoundQuantizer:
         X = stack_samples(fp_inputs, device)
         update_block_global_scale_if_needed(block)      # composer.py:438-451 (NVFP4 only; no-op otherwise)
         self.prepare_block(block)
-        handles = self.register_fp_input_forward_hooks(block)     # composer.py:284-293 (_get_fp_act_hooks)
+        Xq = stack_samples(q_inputs, device) if (q_inputs is not None and self.config.enable_quanted_input) else None
+        # calibration hooks (composer.py:284-299, :423-436): act_max of statically activation-quantised layers is taken
+        # from the fp-input forward, or -- with quantised-input chaining -- from one extra forward on the quantised input
+        need_q = bool(self.config.enable_quanted_input)
+        handles = ([] if need_q else register_act_max_hooks(block)) + self.register_fp_input_forward_hooks(block)
         try:
             fp_out = self.forward_all(block, X, input_others)
         finally:
             for h in handles:
                 h.remove()
-        Xq = stack_samples(q_inputs, device) if (q_inputs is not None and self.config.enable_quanted_input) else None
+        if need_q:
+            handles = register_act_max_hooks(block)
+            if handles:
+                try:
+                    self.forward_all(block, Xq if Xq is not None else X, input_others)
+                finally:
+                    for h in handles:
+                        h.remove()
+        set_amax_for_uncalibrated_experts(block)                  # composer.py:438-451
         best = self.quantize_block(block, X, input_others, fp_out, Xq, block_ctx, input_ids=input_ids)
         q_out = None
         if self.config.enable_quanted_input:

@@ -584,3 +584,61 @@ def test_algorithm_extension_rejects_asym_and_falls_back_like_reference():
     with pytest.raises(ValueError):
         SignRoundOptimizedWrapperLinear(lin, device="cuda")
     assert WrapperLinear.minmax_scale_bound == (0.0, 1.0) and SignRoundOptimizedWrapperLinear.minmax_scale_bound == (0.0, 2.0)
+
+
+@pytest.mark.parametrize("quanted_input", [False, True])
+def test_static_activation_scale_calibration_nvfp4(quanted_input):
+    """NVFP4 (nv_fp4_with_static_gs activations): compress_block collects every layer's act_max over ALL calibration
+    samples (from the fp-input forward, or from an extra forward on the quantised input when chaining is on), experts
+    that saw no token inherit their siblings' maximum, tuning uses that static global scale and packing turns it into
+    `input_global_scale` = 448*6/act_max like the reference's llm_compressor / auto_round fp exporters."""
+    from auto_round_amd.export import pack_layer
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.testing.moe import build_moe_decoder_layer, set_scheme
+    from auto_round_amd.wrapper import WrapperWALayer
+
+    layer, rope, cfg = build_moe_decoder_layer(hidden=256, ffn=512, heads=4, kv_heads=2, num_experts=8, top_k=1, seed=5)
+    set_scheme(layer, "NVFP4")
+    X, others = make_data(rope.cuda(), cfg, N=2, S=4)      # 8 tokens, top-1 of 8 experts: some experts stay idle
+    Xq = (X.float() * 1.5).to(torch.bfloat16)
+    src = Xq if quanted_input else X
+
+    # expected maxima: plain hooks on a copy of the fp block
+    probe = copy.deepcopy(layer)
+    seen = {}
+
+    def mk(name):
+        def hook(m, inp, out):
+            if inp[0].numel():
+                seen[name] = max(seen.get(name, 0.0), float(inp[0].abs().max()))
+        return hook
+
+    for n, m in probe.named_modules():
+        if isinstance(m, torch.nn.Linear) and getattr(m, "bits", 16) < 16:
+            m.register_forward_hook(mk(n))
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for b0 in range(0, src.shape[0], 2):
+            fwd(probe, src[b0:b0 + 2], others)
+    idle = [n for n, m in probe.named_modules() if isinstance(m, torch.nn.Linear) and getattr(m, "bits", 16) < 16 and n not in seen]
+    assert idle, "the test needs at least one expert without tokens"
+
+    random.seed(3)
+    q = SignRoundQuantizer(SignRoundConfig(iters=2, batch_size=2, bits=4, enable_quanted_input=quanted_input), device="cuda")
+    q.compress_block(layer, X, others, q_inputs=Xq if quanted_input else None)
+    was = {n: m for n, m in layer.named_modules() if isinstance(m, WrapperWALayer)}
+    assert len(was) == 4 + 3 * 8
+    for n, wa in was.items():
+        am = wa.orig_layer.act_max
+        assert am.numel() == 1
+        if n in seen:
+            assert abs(float(am) - seen[n]) <= 1e-6 * seen[n], n
+        else:       # idle expert: the maximum over its sibling experts' same-named linear
+            leaf = n.rsplit(".", 1)[1]
+            sib = max(v for k, v in seen.items() if ".experts." in k and k.endswith("." + leaf))
+            assert abs(float(am) - sib) <= 1e-6 * sib, n
+    # packing consumes act_max -> input_global_scale
+    n0, wa0 = next(iter(was.items()))
+    amax = float(wa0.orig_layer.act_max)
+    ql = pack_layer(wa0.orig_layer)
+    assert abs(float(ql.input_global_scale) - 448.0 * 6.0 / amax) <= 1e-6 * 448.0 * 6.0 / amax
+    assert not hasattr(wa0.orig_layer, "act_max") and ql.weight_packed.dtype == torch.uint8
