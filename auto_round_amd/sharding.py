@@ -138,3 +138,44 @@ def gather_results(local: dict, dst: int = 0, group=None):
     for part in bucket:
         merged.update(part)
     return merged
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# data parallelism INSIDE one block (for the reference's default quantised-input chaining, where blocks are sequential)
+# ----------------------------------------------------------------------------------------------------------------------
+def dp_world(group=None):
+    """(rank, world) of the data-parallel group, (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def all_reduce_sum_(t: torch.Tensor, group=None, async_op: bool = False):
+    """In-place SUM all-reduce over RCCL (backend "nccl" on ROCm).  The weight-gradient buffers are bf16; gloo (CPU-side
+    test backend) has no bf16 reduction, so there the sum runs on an fp32 copy."""
+    if dist.get_backend(group) == "gloo" and t.dtype in (torch.bfloat16, torch.float16):
+        f = t.to(torch.float32)
+        dist.all_reduce(f, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(f)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def sync_block_gradients(arenas, total_loss: torch.Tensor, group=None, average_loss: bool = True):
+    """What the reference's DDP / `_all_reduce_model_grads` does per iteration (utils/distributed.py:30-140), on this
+    layout: ONE bucket per arena -- the block-wide dWq buffer (bf16, 2 B/weight instead of the reference's 4 B/weight of
+    fp32 parameter gradients; dV, d min_scale and d max_scale are linear in dWq, so reducing dWq before the fused
+    backward + sign-SGD kernel is equivalent to reducing them) -- plus the scalar loss.  Idle layers are zeroed first so
+    every rank contributes a defined value."""
+    _, world = dp_world(group)
+    if world == 1:
+        return
+    for a in arenas:
+        for lyr in a.layers:
+            if not lyr._dw_accum[0]:
+                lyr.weight_grad.zero_()
+                lyr._dw_accum[0] = True
+        all_reduce_sum_(a.dWq, group)
+    dist.all_reduce(total_loss, op=dist.ReduceOp.SUM, group=group)
+    if average_loss:        # "mean" losses: the global mean is the mean of the equally sized local means
+        total_loss.div_(world)

@@ -199,6 +199,9 @@ def main():
                     help="emit the next iteration's Wq from the fused backward kernel (K1 then runs once per block)")
     ap.add_argument("--sdpa", default="efficient", choices=["auto", "efficient", "flash", "math"],
                     help="SDPA backend priority for the block attention (see SignRoundConfig.sdpa_backend)")
+    ap.add_argument("--data-parallel", action="store_true",
+                    help="N>1: all ranks tune the SAME block, each on 1/N of every minibatch, all-reducing the weight-gradient "
+                         "buffer per iteration (strong scaling; for quantised-input chaining). Default N>1 mode: block sharding")
     ap.add_argument("--alg-ext", action="store_true",
                     help="tune with the algorithm extension (SignRoundV2: imatrix, searched init scales, outlier loss)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -247,7 +250,9 @@ def main():
         from auto_round_amd.attention import register_mi355x_sdpa
 
         attn = register_mi355x_sdpa()
-    layer, rope, cfg, n_w = build_block(w, args.bits, args.group_size, sym, device, seed=1234 + rank, attn=attn,
+    dp = bool(args.data_parallel and world > 1)
+    seed_rank = 0 if dp else rank                           # data parallel: every rank holds the same block and samples
+    layer, rope, cfg, n_w = build_block(w, args.bits, args.group_size, sym, device, seed=1234 + seed_rank, attn=attn,
                                         scheme=args.scheme)
     fp4 = args.scheme is not None and args.scheme.startswith(("MXFP4", "NVFP4"))
     if args.scheme is not None:
@@ -276,9 +281,9 @@ def main():
         ops.qdq_fp4_fwd = lambda X_, V_, absmax_, *a_, **k_: (_timed_w if absmax_ is not None else _fp4_fwd)(X_, V_, absmax_, *a_, **k_)
 
     qcfg = SignRoundConfig(iters=args.iters, batch_size=args.batch_size, bits=args.bits,
-                           fuse_next_forward=args.fuse_next_forward, sdpa_backend=args.sdpa)
+                           fuse_next_forward=args.fuse_next_forward, sdpa_backend=args.sdpa, data_parallel=dp)
     quantizer = (SignRoundV2Quantizer if args.alg_ext else SignRoundQuantizer)(qcfg, device=device)
-    random.seed(42 + rank)
+    random.seed(42 + seed_rank)
 
     def restore():
         from auto_round_amd.wrapper import WrapperWALayer, _set_module
@@ -325,11 +330,11 @@ def main():
         G = n_w // args.group_size
         out = {
             "metric": "transformer blocks tuned/sec (200 iters, 128x2048 calib)",
-            "value": world * args.steps / elapsed,
+            "value": (1 if dp else world) * args.steps / elapsed,
             "unit": "blocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if dp else "weak", "vs_baseline": None,
             "dtype": "bf16",
             "dtype_detail": "bf16 weights/activations and MFMA GEMMs (fp32 accumulate); fp32 rounding offsets V and min/max "
                             "scales; fp16 quant scales; int4 packed output",
@@ -338,7 +343,8 @@ def main():
                        "iters": args.iters, "nsamples": N, "seqlen": S, "batch_size": args.batch_size,
                        "weights_per_block": n_w, "groups_per_block": G, "includes_packing": True,
                        "fuse_next_forward": bool(args.fuse_next_forward), "sdpa_backend": args.sdpa,
-                       "alg_ext": bool(args.alg_ext), "parallelism": f"block-sharded x{world}"},
+                       "alg_ext": bool(args.alg_ext),
+                       "parallelism": f"data-parallel inside the block x{world}" if dp else f"block-sharded x{world}"},
             "ms_per_iter": 1000.0 * elapsed / args.steps / max(args.iters, 1),
             "loss": {"init": stats["init_loss"], "best": stats["best_loss"], "best_iter": stats["best_iter"]},
         }

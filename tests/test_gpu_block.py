@@ -642,3 +642,56 @@ def test_static_activation_scale_calibration_nvfp4(quanted_input):
     ql = pack_layer(wa0.orig_layer)
     assert abs(float(ql.input_global_scale) - 448.0 * 6.0 / amax) <= 1e-6 * 448.0 * 6.0 / amax
     assert not hasattr(wa0.orig_layer, "act_max") and ql.weight_packed.dtype == torch.uint8
+
+
+def _dp_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        layer, rope, cfg = make_layer("llama", 4, 32, True, seed=4)
+        X, others = make_data(rope, cfg, N=16, S=16)
+        Y = targets(layer, X, others)
+        random.seed(21)
+        q = SignRoundQuantizer(SignRoundConfig(iters=3, batch_size=4, bits=4, data_parallel=True), device="cuda")
+        best = q.quantize_block(layer, X, others, Y, None, None)
+        if rank == 0:
+            torch.save({"stats": q.last_stats, "weights": {n: m.weight.cpu() for n, m in linears(layer).items()},
+                        "V": {n: b["value"].cpu() for n, b in best.items()}}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_block_tuning_two_ranks_one_gpu(tmp_path):
+    """data_parallel=True: two ranks (sharing this box's single GPU, gloo transport) each run half of every minibatch and
+    all-reduce the block's dWq buffer once per iteration; the result follows the single-process run (identical iteration-0
+    loss up to GEMM batch-split rounding, same trajectory statistics)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    dp = torch.load(out)
+
+    layer, rope, cfg = make_layer("llama", 4, 32, True, seed=4)
+    X, others = make_data(rope, cfg, N=16, S=16)
+    Y = targets(layer, X, others)
+    random.seed(21)
+    q = SignRoundQuantizer(SignRoundConfig(iters=3, batch_size=4, bits=4), device="cuda")
+    best = q.quantize_block(layer, X, others, Y, None, None)
+    st = q.last_stats
+    assert abs(dp["stats"]["init_loss"] - st["init_loss"]) <= 5e-3 * st["init_loss"], (dp["stats"], st)
+    assert abs(dp["stats"]["best_loss"] - st["best_loss"]) <= 5e-2 * st["best_loss"]
+    agree = [(dp["weights"][n] == m.weight.cpu()).float().mean().item() for n, m in linears(layer).items()]
+    assert np.mean(agree) > 0.97, agree
+    # after the first step V is +-lr0 wherever the summed gradient is non-zero: the two runs agree on almost every sign
+    same = [(dp["V"][n].sign() == best[n]["value"].cpu().sign()).float().mean().item() for n in best]
+    assert np.mean(same) > 0.9, same

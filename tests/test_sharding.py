@@ -134,3 +134,45 @@ def test_plugin_registers_with_the_reference_registry():
 
     assert plugin.packing_quant_linear("auto_round:auto_gptq", 4, 128, True) is QuantLinearZP
     assert plugin.packing_quant_linear("auto_round", 4, 128, False) is QuantLinearPlain
+
+
+def _dp_sync_worker(rank, world, port, q):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        class Lyr:
+            def __init__(self, grad, ran):
+                self.weight_grad, self._dw_accum = grad, [ran]
+
+        class Arena:
+            pass
+
+        a = Arena()
+        a.dWq = torch.arange(12, dtype=torch.float32).mul(rank + 1).to(torch.bfloat16)   # rank r holds (r+1) * [0..11]
+        # layer 0 ran on both ranks; layer 1 (an idle MoE expert here) only on rank 1: rank 0's stale slice must count as 0
+        a.layers = [Lyr(a.dWq[:8], True), Lyr(a.dWq[8:], rank == 1)]
+        loss = torch.tensor([float(rank + 1)])
+        sh.sync_block_gradients([a], loss)
+        loss_sum = torch.tensor([float(rank + 1)])
+        sh.sync_block_gradients([], loss_sum, average_loss=False)
+        q.put((rank, a.dWq.float().tolist(), float(loss), float(loss_sum), [l._dw_accum[0] for l in a.layers], sh.dp_world()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_sync_world2_gloo():
+    """sync_block_gradients: one SUM all-reduce of the arena-wide dWq buffer (bf16; fp32 staging under gloo), idle layers
+    contribute zeros, mean losses are averaged and sum losses summed -- identical results on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = [3.0 * i for i in range(8)] + [2.0 * i for i in range(8, 12)]       # layer 1: only rank 1's (x2) values
+    for rank, g, loss, loss_sum, ran, (r, w) in res:
+        assert g == expect and loss == 1.5 and loss_sum == 3.0 and ran == [True, True] and (r, w) == (rank, 2)
+    assert sh.dp_world() == (0, 1)
