@@ -91,10 +91,22 @@ __device__ __forceinline__ void fp4_group_scale(int mode, float amax, float Ms, 
 #ifndef AR_FP4_BWD_UNROLL
 #define AR_FP4_BWD_UNROLL 2
 #endif
+#ifndef AR_FP4_ACT_UNROLL          // chunks per lane of the activation forward (4 B/elem: less HBM time to hide the math)
+#define AR_FP4_ACT_UNROLL 2
+#endif
+#ifndef AR_FP4_ABWD_UNROLL
+#define AR_FP4_ABWD_UNROLL 1
+#endif
 
-template <int XDT, int U>
-__global__ __launch_bounds__(kTPB) void k_fp4_fwd(const Fp4Args a) {
-    const int cpg = a.cpg;
+// MODE (0 MXFP4 / 1 NVFP4) and ACT (dynamic activation fake-quant: no V / absmax / max_scale / init scale) are template
+// parameters: the group width (4 or 2 lanes) and every mode branch fold at compile time, the butterflies become fixed
+// DPP shuffles, and the activation instantiation carries none of the weight path's loads or selects.
+template <int XDT, int U, int MODE, bool ACT>
+__global__ __launch_bounds__(kTPB) void k_fp4_fwd(const Fp4Args a0) {
+    Fp4Args a = a0;
+    if (ACT) { a.V = nullptr; a.absmax = nullptr; a.max_s = nullptr; a.init_dev = nullptr; }
+    a.mode = MODE;
+    constexpr int cpg = MODE == 0 ? 4 : 2;
     const int64_t total_chunks = a.n_groups * cpg;
     const int64_t stride = (int64_t)gridDim.x * kTPB * U;
     const float gscale = (a.mode == 1 && a.gscale) ? *a.gscale : 1.0f;
@@ -243,14 +255,27 @@ extern "C" int ar_qdq_fp4_fwd(const void* X, const float* V, const float* absmax
     a.X = X; a.V = V; a.absmax = absmax; a.max_s = max_s; a.gscale = global_scale_dev; a.Xq = Xq; a.scale_out = scale_out;
     a.init_dev = init_scale_dev;
     a.n_groups = n_groups; a.cpg = gs / kEPT; a.mode = mode; a.init_scale = init_scale; a.lo = lo_bound; a.hi = hi_bound;
-    const int grid = fp4_grid((n_groups * a.cpg + AR_FP4_FWD_UNROLL - 1) / AR_FP4_FWD_UNROLL);
+    const bool act = !V && !absmax && !max_s && !init_scale_dev && init_scale == 1.0f;
+    const int unroll = act ? AR_FP4_ACT_UNROLL : AR_FP4_FWD_UNROLL;
+    const int grid = fp4_grid((n_groups * a.cpg + unroll - 1) / unroll);
     hipStream_t st = (hipStream_t)stream;
+#define AR_FWD(DT)                                                                                                   \
+    do {                                                                                                             \
+        if (mode == 0) {                                                                                             \
+            if (act) hipLaunchKernelGGL((k_fp4_fwd<DT, AR_FP4_ACT_UNROLL, 0, true>), grid, kTPB, 0, st, a);          \
+            else hipLaunchKernelGGL((k_fp4_fwd<DT, AR_FP4_FWD_UNROLL, 0, false>), grid, kTPB, 0, st, a);             \
+        } else {                                                                                                     \
+            if (act) hipLaunchKernelGGL((k_fp4_fwd<DT, AR_FP4_ACT_UNROLL, 1, true>), grid, kTPB, 0, st, a);          \
+            else hipLaunchKernelGGL((k_fp4_fwd<DT, AR_FP4_FWD_UNROLL, 1, false>), grid, kTPB, 0, st, a);             \
+        }                                                                                                            \
+    } while (0)
     switch (x_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL((k_fp4_fwd<AR_DT_BF16, AR_FP4_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
-        case AR_DT_F16: hipLaunchKernelGGL((k_fp4_fwd<AR_DT_F16, AR_FP4_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
-        case AR_DT_F32: hipLaunchKernelGGL((k_fp4_fwd<AR_DT_F32, AR_FP4_FWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        case AR_DT_BF16: AR_FWD(AR_DT_BF16); break;
+        case AR_DT_F16: AR_FWD(AR_DT_F16); break;
+        case AR_DT_F32: AR_FWD(AR_DT_F32); break;
         default: return AR_ERR_UNSUPPORTED;
     }
+#undef AR_FWD
     return launch_status();
 }
 
@@ -290,9 +315,11 @@ struct Fp4BwdArgs {
     float init_scale, lo, hi;
 };
 
-template <int XDT, int U>
-__global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a) {
-    const int cpg = a.cpg;
+template <int XDT, int U, int MODE>
+__global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a0) {
+    Fp4BwdArgs a = a0;
+    a.mode = MODE;
+    constexpr int cpg = MODE == 0 ? 4 : 2;
     const int64_t total_chunks = a.n_groups * cpg;
     const int64_t stride = (int64_t)gridDim.x * kTPB * U;
     const float gscale = (a.mode == 1 && a.gscale) ? *a.gscale : 1.0f;
@@ -431,12 +458,18 @@ extern "C" int ar_qdq_fp4_bwd_sgd(const void* dXq, const void* X, float* V, cons
     a.tune_minmax = tune_minmax; a.init_scale = init_scale; a.lo = lo_bound; a.hi = hi_bound;
     const int grid = fp4_grid((n_groups * a.cpg + AR_FP4_BWD_UNROLL - 1) / AR_FP4_BWD_UNROLL);
     hipStream_t st = (hipStream_t)stream;
+#define AR_BWD(DT)                                                                                                   \
+    do {                                                                                                             \
+        if (mode == 0) hipLaunchKernelGGL((k_fp4_bwd<DT, AR_FP4_BWD_UNROLL, 0>), grid, kTPB, 0, st, a);              \
+        else hipLaunchKernelGGL((k_fp4_bwd<DT, AR_FP4_BWD_UNROLL, 1>), grid, kTPB, 0, st, a);                        \
+    } while (0)
     switch (x_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL((k_fp4_bwd<AR_DT_BF16, AR_FP4_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
-        case AR_DT_F16: hipLaunchKernelGGL((k_fp4_bwd<AR_DT_F16, AR_FP4_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
-        case AR_DT_F32: hipLaunchKernelGGL((k_fp4_bwd<AR_DT_F32, AR_FP4_BWD_UNROLL>), grid, kTPB, 0, st, a); break;
+        case AR_DT_BF16: AR_BWD(AR_DT_BF16); break;
+        case AR_DT_F16: AR_BWD(AR_DT_F16); break;
+        case AR_DT_F32: AR_BWD(AR_DT_F32); break;
         default: return AR_ERR_UNSUPPORTED;
     }
+#undef AR_BWD
     return launch_status();
 }
 
@@ -449,10 +482,12 @@ __device__ __forceinline__ int lanes_min_i(int v, int width) {
     return v;
 }
 
-template <int XDT, int U>
+template <int XDT, int U, int MODE>
 __global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ dXq, const void* __restrict__ X,
                                                       void* __restrict__ dX, const float* __restrict__ gscale_dev,
-                                                      int64_t n_groups, int cpg, int mode) {
+                                                      int64_t n_groups) {
+    constexpr int cpg = MODE == 0 ? 4 : 2;
+    constexpr int mode = MODE;
     const int64_t total_chunks = n_groups * cpg;
     const int64_t stride = (int64_t)gridDim.x * kTPB * U;
     const float gscale = (mode == 1 && gscale_dev) ? *gscale_dev : 1.0f;
@@ -558,14 +593,20 @@ extern "C" int ar_fp4_act_bwd(const void* dXq, const void* X, void* dX, const fl
     if (mode == 1 && !global_scale_dev) return AR_ERR_UNSUPPORTED;
     if (n_groups == 0) return AR_OK;
     const int cpg = gs / kEPT;
-    const int grid = fp4_grid((n_groups * cpg + 1) / 2);
+    const int grid = fp4_grid((n_groups * cpg + AR_FP4_ABWD_UNROLL - 1) / AR_FP4_ABWD_UNROLL);
     hipStream_t st = (hipStream_t)stream;
+#define AR_ABWD(DT)                                                                                                  \
+    do {                                                                                                             \
+        if (mode == 0) hipLaunchKernelGGL((k_fp4_act_bwd<DT, AR_FP4_ABWD_UNROLL, 0>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups); \
+        else hipLaunchKernelGGL((k_fp4_act_bwd<DT, AR_FP4_ABWD_UNROLL, 1>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups); \
+    } while (0)
     switch (x_dt) {
-        case AR_DT_BF16: hipLaunchKernelGGL((k_fp4_act_bwd<AR_DT_BF16, 2>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
-        case AR_DT_F16: hipLaunchKernelGGL((k_fp4_act_bwd<AR_DT_F16, 2>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
-        case AR_DT_F32: hipLaunchKernelGGL((k_fp4_act_bwd<AR_DT_F32, 2>), grid, kTPB, 0, st, dXq, X, dX, global_scale_dev, n_groups, cpg, mode); break;
+        case AR_DT_BF16: AR_ABWD(AR_DT_BF16); break;
+        case AR_DT_F16: AR_ABWD(AR_DT_F16); break;
+        case AR_DT_F32: AR_ABWD(AR_DT_F32); break;
         default: return AR_ERR_UNSUPPORTED;
     }
+#undef AR_ABWD
     return launch_status();
 }
 
