@@ -1,0 +1,231 @@
+"""Standalone caller of the hot path with the reference's front-door names -- `AutoRound(model, tokenizer, scheme=...,
+iters=..., nsamples=..., seqlen=..., batch_size=...).quantize() / .save_quantized() / .quantize_and_save()`
+(auto_round/autoround.py, compressors/base.py) -- reduced to what a decoder-only HF language model needs:
+
+  1. scheme -> per-layer attributes                         (schemes.py; reference: apply_plan_to_model)
+  2. capture the first block's inputs on the calibration tokens (reference: calibration/llm.py cache_inter_data: a forward
+     hook on block 0 records hidden_states + the shared kwargs and stops the forward)
+  3. tune the blocks in order on the GPU                    (model_tuner.tune_blocks -> SignRound[V2]Quantizer)
+  4. pack + stream to safetensors shards                    (export.pack_block, shard_writer.ShardWriter), config.json with
+     the reference's `quantization_config` keys for format "auto_round"
+
+Not rebuilt (use the reference with `auto_round_amd.plugin` for these): dataset download/tokenisation (no network here:
+`dataset` must be token ids), multimodal / diffusion models, AutoScheme, GGUF / FP8 formats, lm_head / embedding quantisation,
+low-memory offloading."""
+from __future__ import annotations
+
+import json
+import os
+import random
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from .model_tuner import tune_blocks
+from .quantizer import SignRoundConfig, SignRoundQuantizer, SignRoundV2Quantizer
+from .schemes import SCHEME_KEYS, apply_scheme, resolve_scheme
+from .shard_writer import ShardWriter
+from .wrapper import WrapperWALayer
+
+
+class _StopForward(Exception):
+    pass
+
+
+def get_block_names(model) -> List[List[str]]:
+    """Names of the repeated decoder blocks: the children of every nn.ModuleList found first on each path from the root
+    (reference: utils/model.py get_block_names, LLM branch)."""
+    groups = []
+
+    def search(prefix, module):
+        for n, m in module.named_children():
+            full = f"{prefix}.{n}" if prefix else n
+            if isinstance(m, torch.nn.ModuleList):
+                groups.append([f"{full}.{i}" for i, _ in m.named_children()])
+            else:
+                search(full, m)
+
+    search("", model)
+    return groups
+
+
+class AutoRound:
+    def __init__(self, model, tokenizer=None, scheme: Union[str, dict] = "W4A16", *, bits=None, group_size=None, sym=None,
+                 iters: int = 200, lr=None, minmax_lr=None, nsamples: int = 128, seqlen: int = 2048, batch_size: int = 8,
+                 dataset=None, enable_alg_ext: bool = False, enable_quanted_input: bool = True,
+                 enable_minmax_tuning: bool = True, gradient_accumulate_steps: int = 1, not_use_best_mse: bool = False,
+                 dynamic_max_gap: int = -1, layer_config: Optional[Dict[str, dict]] = None, device_map=0, seed: int = 42,
+                 amp: bool = True, **kwargs):
+        if kwargs:
+            raise TypeError(f"arguments outside the MI355X hot path: {sorted(kwargs)} (use the reference with auto_round_amd.plugin)")
+        self.model, self.tokenizer = model, tokenizer
+        self.scheme = resolve_scheme(scheme, bits=bits, group_size=group_size, sym=sym)
+        self.nsamples, self.seqlen, self.seed = nsamples, seqlen, seed
+        self.dataset = dataset
+        self.device = torch.device("cuda", device_map) if isinstance(device_map, int) else torch.device(device_map)
+        self.enable_alg_ext = enable_alg_ext
+        amp_dtype = next(model.parameters()).dtype
+        if amp_dtype not in (torch.bfloat16, torch.float16):
+            amp, amp_dtype = False, torch.bfloat16
+        self.config = SignRoundConfig(iters=iters, lr=lr, minmax_lr=minmax_lr, batch_size=batch_size, bits=self.scheme["bits"],
+                                      enable_minmax_tuning=enable_minmax_tuning, enable_quanted_input=enable_quanted_input,
+                                      gradient_accumulate_steps=gradient_accumulate_steps, not_use_best_mse=not_use_best_mse,
+                                      dynamic_max_gap=dynamic_max_gap, amp=amp, amp_dtype=amp_dtype)
+        self.layer_config_in = layer_config
+        self.layer_config: Dict[str, dict] = {}
+        self.block_names: List[str] = []
+        self.records: List[dict] = []
+        self.quantized = False
+
+    # -- calibration -----------------------------------------------------------------------------------------------------
+    def _calibration_tokens(self) -> torch.Tensor:
+        ds = self.dataset
+        if ds is None or isinstance(ds, str):
+            raise ValueError("dataset must be token ids (a [nsamples, seqlen] LongTensor, a list of 1-D/2-D LongTensors or an "
+                             "iterable of such batches): there is no network to fetch a named dataset from")
+        if isinstance(ds, torch.Tensor):
+            rows = [r for r in ds.reshape(-1, ds.shape[-1])]
+        else:
+            rows = []
+            for item in ds:
+                t = item["input_ids"] if isinstance(item, dict) else item
+                t = torch.as_tensor(t)
+                rows.extend(r for r in t.reshape(-1, t.shape[-1]))
+        rows = [r[:self.seqlen] for r in rows if r.numel() >= self.seqlen]      # shorter samples are skipped (llm.py:338)
+        if len(rows) < 1:
+            raise ValueError(f"no calibration sample reaches seqlen={self.seqlen}")
+        return torch.stack(rows[:self.nsamples]).long()
+
+    @torch.no_grad()
+    def _capture_block0_inputs(self, blocks, tokens):
+        first = blocks[0]
+        captured, shared = [], {}
+
+        def hook(module, args, kwargs):
+            hs = args[0] if args else kwargs["hidden_states"]
+            captured.append(hs.detach())
+            if not shared:
+                bs = hs.shape[0]
+                for k, v in kwargs.items():
+                    if k in ("hidden_states", "past_key_values", "past_key_value", "use_cache", "cache_position"):
+                        continue
+                    shared[k] = _first_sample(v, bs)
+            raise _StopForward
+
+        h = first.register_forward_pre_hook(hook, with_kwargs=True)
+        bs = self.config.batch_size
+        try:
+            for b0 in range(0, tokens.shape[0], bs):
+                try:
+                    self.model(input_ids=tokens[b0:b0 + bs].to(self.device), use_cache=False)
+                except _StopForward:
+                    pass
+        finally:
+            h.remove()
+        return torch.cat(captured, dim=0), shared
+
+    # -- the run ---------------------------------------------------------------------------------------------------------
+    def quantize(self):
+        """-> (model, layer_config).  The blocks' tuned linears hold the fake-quant weights and carry `scale` / `zp`."""
+        import transformers
+
+        transformers.set_seed(self.seed)        # seeds `random` (IndexSampler) like the reference's compressor does
+        model = self.model.to(self.device).eval()
+        for p in model.parameters():
+            p.requires_grad_(False)
+        groups = get_block_names(model)
+        if not groups:
+            raise ValueError("no repeated decoder blocks (nn.ModuleList) found in the model")
+        self.block_names = max(groups, key=len)
+        blocks = [model.get_submodule(n) for n in self.block_names]
+        for n, b in zip(self.block_names, blocks):
+            for ln, cfg in apply_scheme(b, self.scheme, layer_config=self.layer_config_in).items():
+                self.layer_config[f"{n}.{ln}"] = cfg
+        tokens = self._calibration_tokens()
+        ids_for_mask = tokens.clone()
+        pad = getattr(self.tokenizer, "pad_token_id", None)
+        if pad is not None:
+            ids_for_mask[ids_for_mask == pad] = -100
+        ids_for_mask[:, -1] = -100              # llm.py:341-360: pads and the last position do not enter the loss
+        # grouped-query "sdpa" attention would silently run on the 2x slower flash kernels (attention.py)
+        cfg_obj, old_attn = getattr(model, "config", None), None
+        if self.config.sdpa_backend == "efficient" and getattr(cfg_obj, "_attn_implementation", None) == "sdpa":
+            from .attention import register_mi355x_sdpa
+
+            old_attn, cfg_obj._attn_implementation = cfg_obj._attn_implementation, register_mi355x_sdpa()
+        try:
+            x0, others = self._capture_block0_inputs(blocks, tokens)
+            q_cls = SignRoundV2Quantizer if self.enable_alg_ext else SignRoundQuantizer
+            self.quantizer = q_cls(self.config, device=self.device)
+            self.records = tune_blocks(blocks, x0, others, self.quantizer, input_ids=ids_for_mask,
+                                       block_names=self.block_names)
+        finally:
+            if old_attn is not None:
+                cfg_obj._attn_implementation = old_attn
+        self.quantized = True
+        return model, self.layer_config
+
+    def _quantization_config(self, backend: str) -> dict:
+        qc = {k: self.scheme.get(k) for k in SCHEME_KEYS if self.scheme.get(k) is not None}
+        qc.update(quant_method="auto-round", packing_format=backend, iters=self.config.iters, nsamples=self.nsamples,
+                  seqlen=self.seqlen, batch_size=self.config.batch_size, enable_alg_ext=self.enable_alg_ext,
+                  enable_quanted_input=self.config.enable_quanted_input,
+                  block_name_to_quantize=os.path.commonprefix(self.block_names).rstrip("."), autoround_version="mi355x-0.1.0")
+        extra = {n: {k: v for k, v in c.items() if c.get(k) != self.scheme.get(k) and v is not None}
+                 for n, c in self.layer_config.items() if any(c.get(k) != self.scheme.get(k) for k in SCHEME_KEYS)}
+        if extra:
+            qc["extra_config"] = extra
+        return qc
+
+    @torch.no_grad()
+    def save_quantized(self, output_dir: str, format: str = "auto_round", max_shard_bytes: int = 5 * 1024 ** 3):
+        """Pack every tuned layer and write an `auto_round`-format checkpoint: safetensors shards (+ index), config.json
+        with `quantization_config`, tokenizer files when a tokenizer was given."""
+        if format not in ("auto_round", "auto_round:auto_gptq", "auto_round:auto_awq"):
+            raise NotImplementedError(f"format {format!r}: the MI355X path writes the auto_round checkpoint layout")
+        if not self.quantized:
+            raise RuntimeError("call quantize() first")
+        from .export import pack_block
+
+        sym, bits = bool(self.scheme["sym"]), int(self.scheme["bits"])
+        int_scheme = str(self.scheme["data_type"]).startswith("int")
+        backend = format if ":" in format else ("auto_round:auto_gptq" if (sym or not int_scheme) else
+                                                ("auto_round:auto_awq" if bits == 4 else "auto_round"))
+        writer = ShardWriter(output_dir, max_shard_bytes=max_shard_bytes)
+        packed_prefixes = []
+        for name in self.block_names:
+            block = self.model.get_submodule(name)
+            packed = pack_block(block, backend if int_scheme else None)
+            writer.write_block(name, packed)
+            for ln in packed:
+                ln = ln[:-len(".orig_layer")] if ln.endswith(".orig_layer") else ln
+                packed_prefixes.append(f"{name}.{ln}.")
+        rest = {}
+        for k, v in self.model.state_dict().items():
+            k2 = k.replace(".orig_layer.", ".")
+            if not any(k2.startswith(p) for p in packed_prefixes):
+                rest[k2] = v.detach().to("cpu").contiguous()
+        writer.write(rest)
+        index = writer.close()
+        cfg = self.model.config.to_dict() if hasattr(self.model, "config") else {}
+        cfg["quantization_config"] = self._quantization_config(backend)
+        with open(os.path.join(output_dir, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=2, default=str)
+        if self.tokenizer is not None and hasattr(self.tokenizer, "save_pretrained"):
+            self.tokenizer.save_pretrained(output_dir)
+        return index
+
+    def quantize_and_save(self, output_dir: str = "tmp_autoround", format: str = "auto_round", **kw):
+        model, _ = self.quantize()
+        self.save_quantized(output_dir, format=format, **kw)
+        return model, output_dir
+
+
+def _first_sample(v, bs):
+    """Shared block kwargs are captured once; tensors that carry the calibration batch dimension keep one row so that they
+    broadcast over any tuning batch size (attention masks, position ids; rotary (cos, sin) tuples are handled element-wise)."""
+    if isinstance(v, torch.Tensor):
+        return v[:1].detach() if (v.dim() > 0 and v.shape[0] == bs and bs > 1) else v.detach()
+    if isinstance(v, (tuple, list)):
+        return type(v)(_first_sample(x, bs) for x in v)
+    return v

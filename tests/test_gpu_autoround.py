@@ -1,0 +1,92 @@
+"""The standalone front door (`auto_round_amd.autoround.AutoRound`) end to end on a tiny random Llama: calibration capture,
+block tuning, packing, streamed safetensors checkpoint with the reference's `auto_round` layout."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_llama(layers=2, hidden=128, ffn=256, heads=4, kv=2, vocab=512, seed=0):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(seed)
+    cfg = LlamaConfig(hidden_size=hidden, intermediate_size=ffn, num_attention_heads=heads, num_key_value_heads=kv,
+                      num_hidden_layers=layers, vocab_size=vocab, max_position_embeddings=256, tie_word_embeddings=False)
+    cfg._attn_implementation = "sdpa"
+    return LlamaForCausalLM(cfg).to(torch.bfloat16)
+
+
+def unpack_w4_gptq(qweight, qzeros, scales, gs):
+    """int32 words -> fp32 weight [out, in]; zero points stored as zp-1 (auto_round:auto_gptq)."""
+    in_f, out_f = qweight.shape[0] * 8, qweight.shape[1]
+    sh = torch.arange(0, 32, 4, dtype=torch.int32)
+    q = ((qweight.unsqueeze(1) >> sh.view(1, 8, 1)) & 15).reshape(in_f, out_f)
+    z = ((qzeros.unsqueeze(2) >> sh.view(1, 1, 8)) & 15).reshape(qzeros.shape[0], out_f) + 1
+    g = torch.arange(in_f) // gs
+    return ((q - z[g]).float() * scales.float()[g]).t()
+
+
+@pytest.mark.parametrize("alg_ext", [False, True])
+def test_autoround_front_door_quantize_and_save(tmp_path, alg_ext):
+    from safetensors import safe_open
+
+    from auto_round_amd.autoround import AutoRound, get_block_names
+
+    model = tiny_llama()
+    assert max(get_block_names(model), key=len) == ["model.layers.0", "model.layers.1"]
+    g = torch.Generator().manual_seed(1)
+    tokens = torch.randint(0, 512, (12, 40), generator=g)          # 12 samples, 40 tokens: cut to seqlen 32, 8 used
+    ar = AutoRound(model, None, scheme="W4A16", group_size=32, iters=4, nsamples=8, seqlen=32, batch_size=4, dataset=tokens,
+                   enable_alg_ext=alg_ext)
+    out = str(tmp_path / "ckpt")
+    qmodel, _ = ar.quantize_and_save(out)
+    assert len(ar.records) == 2 and all(r["stats"]["quantized"] == 7 for r in ar.records)
+    assert ar.records[0]["stats"]["best_loss"] <= ar.records[0]["stats"]["init_loss"]
+    assert ar.layer_config["model.layers.1.mlp.down_proj"]["bits"] == 4
+    cfg = json.load(open(os.path.join(out, "config.json")))
+    qc = cfg["quantization_config"]
+    assert qc["quant_method"] == "auto-round" and qc["packing_format"] == "auto_round:auto_gptq" and qc["bits"] == 4
+    assert qc["group_size"] == 32 and qc["sym"] is True and qc["block_name_to_quantize"] == "model.layers"
+    assert qc["enable_alg_ext"] is alg_ext
+    index = json.load(open(os.path.join(out, "model.safetensors.index.json")))
+    wm = index["weight_map"]
+    tensors = {}
+    for fname in set(wm.values()):
+        with safe_open(os.path.join(out, fname), "pt") as f:
+            for k in f.keys():
+                tensors[k] = f.get_tensor(k)
+    # every block linear is packed, everything else is there in 16 bit, nothing is there twice
+    for li in range(2):
+        for ln in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj",
+                   "mlp.up_proj", "mlp.down_proj"):
+            base = f"model.layers.{li}.{ln}"
+            assert f"{base}.weight" not in tensors
+            W = unpack_w4_gptq(tensors[f"{base}.qweight"], tensors[f"{base}.qzeros"], tensors[f"{base}.scales"], 32)
+            baked = qmodel.get_submodule(base).weight.detach().float().cpu()
+            assert torch.equal(W.to(torch.bfloat16).float(), baked), base     # the checkpoint decodes to the tuned weights
+        assert f"model.layers.{li}.input_layernorm.weight" in tensors
+    assert "model.embed_tokens.weight" in tensors and "lm_head.weight" in tensors and "model.norm.weight" in tensors
+    # the tuned model still runs and stays close to the fp one on the calibration tokens
+    ref = tiny_llama()
+    with torch.no_grad():
+        a = qmodel(input_ids=tokens[:2, :32].cuda()).logits.float()
+        b = ref.cuda()(input_ids=tokens[:2, :32].cuda()).logits.float()
+    assert torch.isfinite(a).all() and (a - b).abs().mean() < 0.25 * b.abs().mean()
+
+
+def test_autoround_front_door_argument_errors():
+    from auto_round_amd.autoround import AutoRound
+
+    model = tiny_llama(layers=1)
+    with pytest.raises(ValueError):
+        AutoRound(model, None, scheme="W4A16", dataset="NeelNanda/pile-10k").quantize()
+    with pytest.raises(ValueError):
+        AutoRound(model, None, scheme="FP8_STATIC", dataset=torch.zeros(1, 8, dtype=torch.long))
+    with pytest.raises(TypeError):
+        AutoRound(model, None, low_gpu_mem_usage=True)
+    with pytest.raises(RuntimeError):
+        AutoRound(model, None, dataset=torch.zeros(1, 8, dtype=torch.long)).save_quantized("/tmp/never")

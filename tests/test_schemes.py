@@ -1,0 +1,73 @@
+"""Host logic of the standalone front door: scheme presets equal the reference's, scheme application, block discovery."""
+import os
+import sys
+
+import pytest
+import torch
+
+from auto_round_amd import schemes as S
+
+REF = "/root/reference"
+
+
+def test_presets_resolve_and_override():
+    w4 = S.resolve_scheme("w4a16")
+    assert (w4["bits"], w4["group_size"], w4["sym"], w4["data_type"], w4["act_bits"]) == (4, 128, True, "int", 16)
+    w2 = S.resolve_scheme("W2A16G32", sym=False)                # BASELINE cfg 3: W2 g32 asym
+    assert (w2["bits"], w2["group_size"], w2["sym"]) == (2, 32, False)
+    nv = S.resolve_scheme("NVFP4")
+    assert nv["act_data_type"] == "nv_fp4_with_static_gs" and nv["group_size"] == 16 and nv["act_bits"] == 4
+    assert S.resolve_scheme({"bits": 3, "group_size": 64, "sym": True, "data_type": "int"}, bits=4)["bits"] == 4
+    with pytest.raises(ValueError):
+        S.resolve_scheme("FP8_STATIC")
+    with pytest.raises(KeyError):
+        S.resolve_scheme("W4A16", super_bits=6)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
+def test_presets_equal_the_reference_presets():
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, REF):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from auto_round.schemes import PRESET_SCHEMES
+
+    for name, mine in S.PRESET_SCHEMES.items():
+        ref = PRESET_SCHEMES[name]
+        for k in ("bits", "group_size", "sym", "data_type", "act_bits"):
+            assert getattr(ref, k) == mine[k], (name, k)
+        if mine["act_bits"] < 16:
+            for k in ("act_data_type", "act_group_size", "act_sym", "act_dynamic"):
+                assert getattr(ref, k) == mine[k], (name, k)
+
+
+def test_apply_scheme_and_block_discovery():
+    from auto_round_amd.autoround import get_block_names
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj = torch.nn.Linear(64, 64, bias=False)
+            self.odd = torch.nn.Linear(64, 48, bias=False)       # 48 % 32 != 0 -> stays 16 bit
+            self.mlp = torch.nn.Module()
+            self.mlp.gate = torch.nn.Linear(64, 8, bias=False)   # MoE router -> stays 16 bit
+            self.mlp.up = torch.nn.Linear(64, 128, bias=False)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed = torch.nn.Embedding(10, 64)
+            self.model = torch.nn.Module()
+            self.model.layers = torch.nn.ModuleList([Blk(), Blk(), Blk()])
+            self.vision = torch.nn.ModuleList([Blk()])
+            self.lm_head = torch.nn.Linear(64, 10, bias=False)
+
+    m = M()
+    groups = get_block_names(m)
+    assert ["model.layers.0", "model.layers.1", "model.layers.2"] in groups and ["vision.0"] in groups
+    cfg = S.apply_scheme(m.model.layers[0], S.resolve_scheme("W4A16", group_size=32), layer_config={"mlp.up": {"bits": 8}})
+    b = m.model.layers[0]
+    assert b.q_proj.bits == 4 and b.q_proj.group_size == 32 and b.q_proj.sym and b.q_proj.scale_dtype == torch.float16
+    assert b.odd.bits == 16 and b.mlp.gate.bits == 16 and b.mlp.up.bits == 8
+    assert cfg["mlp.up"]["bits"] == 8 and cfg["odd"]["bits"] == 16 and set(cfg) == {"q_proj", "odd", "mlp.gate", "mlp.up"}
