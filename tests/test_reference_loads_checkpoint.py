@@ -1,0 +1,68 @@
+"""Format parity with the consumer side: checkpoints WRITTEN by this repository's GPU path (tests/golden/tiny_ckpt_*, made
+on an MI355X by tools/make_tiny_ckpt.py through `AutoRound(...).quantize_and_save()`) are LOADED by the reference's own
+inference stack -- transformers' auto-round quantizer -> auto_round.inference.convert_hf_model -> the reference's torch
+QuantLinear (`auto_round_extension/torch/qlinear_torch[_zp].py`) -- and must reproduce the tuned model's logits.
+Needs /root/reference (build container); the fixtures themselves are also decoded without it."""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+REF = "/root/reference"
+CKPTS = sorted(glob.glob(os.path.join(GOLDEN, "tiny_ckpt_*")))
+
+
+@pytest.mark.parametrize("ck", CKPTS, ids=[os.path.basename(c)[10:] for c in CKPTS])
+def test_fixture_checkpoint_layout(ck):
+    from safetensors import safe_open
+
+    qc = json.load(open(os.path.join(ck, "config.json")))["quantization_config"]
+    assert qc["quant_method"] == "auto-round" and qc["packing_format"].startswith("auto_round")
+    bits, gs = qc["bits"], qc["group_size"]
+    with safe_open(os.path.join(ck, "model.safetensors"), "pt") as f:
+        keys = set(f.keys())
+        qw = f.get_tensor("model.layers.0.mlp.down_proj.qweight")
+        qz = f.get_tensor("model.layers.0.mlp.down_proj.qzeros")
+        sc = f.get_tensor("model.layers.0.mlp.down_proj.scales")
+    in_f, out_f = 256, 128
+    assert qw.dtype == torch.int32 and tuple(qw.shape) == (in_f // 32 * bits, out_f)
+    assert qz.dtype == torch.int32 and tuple(qz.shape) == (in_f // gs, out_f // 32 * bits)
+    assert sc.dtype == torch.float16 and tuple(sc.shape) == (in_f // gs, out_f)
+    assert "model.layers.0.mlp.down_proj.weight" not in keys and "lm_head.weight" in keys and "model.norm.weight" in keys
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("ck", CKPTS, ids=[os.path.basename(c)[10:] for c in CKPTS])
+def test_reference_inference_stack_loads_our_checkpoint(ck):
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, REF):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import auto_round  # noqa: F401  (registers its loader with transformers)
+    from auto_round.inference import backend as B
+    from transformers import AutoModelForCausalLM, AutoRoundConfig
+
+    saved = {}
+    for k, info in B.BackendInfos.items():     # the reference is on sys.path, not pip-installed: its own version pin cannot hold
+        if "torch" in k:
+            saved[k] = info.requirements
+            info.requirements = [r for r in (info.requirements or []) if not r.startswith("auto-round")]
+    try:
+        m = AutoModelForCausalLM.from_pretrained(ck, device_map="cpu", torch_dtype=torch.bfloat16,
+                                                 quantization_config=AutoRoundConfig(backend="torch"))
+    finally:
+        for k, r in saved.items():
+            B.BackendInfos[k].requirements = r
+    ql = m.model.layers[0].self_attn.q_proj
+    assert type(ql).__module__.startswith("auto_round_extension.torch.qlinear_torch"), type(ql)
+    z = np.load(os.path.join(ck, "expected.npz"))
+    with torch.no_grad():
+        logits = m(input_ids=torch.from_numpy(z["tokens"])).logits.float().numpy()
+    # same integer weights and scales, bf16 GEMMs on a different device / summation order
+    assert np.abs(logits - z["logits"]).max() <= 0.05 * np.abs(z["logits"]).mean()

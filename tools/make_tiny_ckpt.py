@@ -1,0 +1,28 @@
+"""GPU box: quantise a tiny random Llama with the standalone front door and write the checkpoint + the tuned model's logits
+(tests/golden/tiny_ckpt_*): the CPU test then loads that checkpoint through the REFERENCE's own inference loader."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_gpu_autoround import tiny_llama  # noqa: E402
+
+from auto_round_amd.autoround import AutoRound  # noqa: E402
+
+out_root = sys.argv[1]
+for tag, kw in (("w4g32_sym", dict(scheme="W4A16", group_size=32)), ("w2g32_asym", dict(scheme="W2A16G32", sym=False)),
+                ("w2g32_sym_algext", dict(scheme="W2A16G32", enable_alg_ext=True)), ("w3g32_sym", dict(scheme="W3A16", group_size=32))):
+    model = tiny_llama(seed=3, vocab=64)
+    g = torch.Generator().manual_seed(1)
+    tokens = torch.randint(0, 64, (8, 32), generator=g)
+    ar = AutoRound(model, None, iters=6, nsamples=8, seqlen=32, batch_size=4, dataset=tokens, **kw)
+    out = os.path.join(out_root, f"tiny_ckpt_{tag}")
+    qmodel, _ = ar.quantize_and_save(out)
+    with torch.no_grad():
+        logits = qmodel(input_ids=tokens[:2].cuda()).logits.float().cpu().numpy()
+    np.savez_compressed(os.path.join(out, "expected.npz"), tokens=tokens[:2].numpy(), logits=logits)
+    print(tag, "ok", os.listdir(out))
