@@ -189,8 +189,11 @@ class AutoRound:
 
         sym, bits = bool(self.scheme["sym"]), int(self.scheme["bits"])
         int_scheme = str(self.scheme["data_type"]).startswith("int")
-        backend = format if ":" in format else ("auto_round:auto_gptq" if (sym or not int_scheme) else
-                                                ("auto_round:auto_awq" if bits == 4 else "auto_round"))
+        if not int_scheme:       # MXFP4 / NVFP4 checkpoints carry the llm_compressor tensor layout (export_to_nvfp_mx.py:178-179)
+            backend = "auto_round:llm_compressor"
+        else:                    # AutoRoundFormat's defaults (export/formats/backends/autoround.py:59-70)
+            backend = format if ":" in format else ("auto_round:auto_gptq" if sym else
+                                                    ("auto_round:auto_awq" if bits == 4 else "auto_round"))
         writer = ShardWriter(output_dir, max_shard_bytes=max_shard_bytes)
         packed_prefixes = []
         for name in self.block_names:

@@ -15,7 +15,8 @@ from auto_round_amd.autoround import AutoRound  # noqa: E402
 
 out_root = sys.argv[1]
 for tag, kw in (("w4g32_sym", dict(scheme="W4A16", group_size=32)), ("w2g32_asym", dict(scheme="W2A16G32", sym=False)),
-                ("w2g32_sym_algext", dict(scheme="W2A16G32", enable_alg_ext=True)), ("w3g32_sym", dict(scheme="W3A16", group_size=32))):
+                ("w2g32_sym_algext", dict(scheme="W2A16G32", enable_alg_ext=True)), ("w3g32_sym", dict(scheme="W3A16", group_size=32)),
+                ("mxfp4", dict(scheme="MXFP4")), ("nvfp4", dict(scheme="NVFP4", enable_alg_ext=True))):
     model = tiny_llama(seed=3, vocab=64)
     g = torch.Generator().manual_seed(1)
     tokens = torch.randint(0, 64, (8, 32), generator=g)
@@ -24,5 +25,11 @@ for tag, kw in (("w4g32_sym", dict(scheme="W4A16", group_size=32)), ("w2g32_asym
     qmodel, _ = ar.quantize_and_save(out)
     with torch.no_grad():
         logits = qmodel(input_ids=tokens[:2].cuda()).logits.float().cpu().numpy()
-    np.savez_compressed(os.path.join(out, "expected.npz"), tokens=tokens[:2].numpy(), logits=logits)
+    def lin(n):          # A4 schemes leave the activation-quant shell around the layer
+        m = model.get_submodule(f"model.layers.0.{n}")
+        return getattr(m, "orig_layer", m)
+
+    baked = {f"W_{n.replace('.', '_')}": lin(n).weight.detach().cpu().view(torch.int16).numpy()
+             for n in ("self_attn.q_proj", "mlp.down_proj")}      # bf16 bit patterns of two tuned weights
+    np.savez_compressed(os.path.join(out, "expected.npz"), tokens=tokens[:2].numpy(), logits=logits, **baked)
     print(tag, "ok", os.listdir(out))
