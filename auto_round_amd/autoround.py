@@ -51,6 +51,7 @@ def get_block_names(model) -> List[List[str]]:
 
 class AutoRound:
     def __init__(self, model, tokenizer=None, scheme: Union[str, dict] = "W4A16", *, bits=None, group_size=None, sym=None,
+                 act_bits=None, act_group_size=None, act_sym=None, act_dynamic=None, act_data_type=None,
                  iters: int = 200, lr=None, minmax_lr=None, nsamples: int = 128, seqlen: int = 2048, batch_size: int = 8,
                  dataset=None, enable_alg_ext: bool = False, enable_quanted_input: bool = True,
                  enable_minmax_tuning: bool = True, gradient_accumulate_steps: int = 1, not_use_best_mse: bool = False,
@@ -59,7 +60,14 @@ class AutoRound:
         if kwargs:
             raise TypeError(f"arguments outside the MI355X hot path: {sorted(kwargs)} (use the reference with auto_round_amd.plugin)")
         self.model, self.tokenizer = model, tokenizer
-        self.scheme = resolve_scheme(scheme, bits=bits, group_size=group_size, sym=sym)
+        self.scheme = resolve_scheme(scheme, bits=bits, group_size=group_size, sym=sym, act_bits=act_bits,
+                                     act_group_size=act_group_size, act_sym=act_sym, act_dynamic=act_dynamic,
+                                     act_data_type=act_data_type)
+        if (self.scheme.get("act_bits") or 16) <= 8:         # the reference resolves unset activation fields from the weights'
+            for k, v in (("act_data_type", self.scheme["data_type"]), ("act_sym", self.scheme["sym"]), ("act_dynamic", True),
+                         ("act_group_size", self.scheme["group_size"])):
+                if self.scheme.get(k) is None:
+                    self.scheme[k] = v
         self.nsamples, self.seqlen, self.seed = nsamples, seqlen, seed
         self.dataset = dataset
         self.device = torch.device("cuda", device_map) if isinstance(device_map, int) else torch.device(device_map)

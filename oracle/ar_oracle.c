@@ -951,3 +951,92 @@ void oracle_search_int_scale(const void* X, const float* qw_row, int64_t groups_
         if (out_init) store_from_f32(out_init, g, x_dt, cl);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * dynamic symmetric INT activation fake-quant (W4A8-style schemes), forward and input gradient
+ * reference: quant_tensor_sym (auto_round/data_type/int.py:165-238) as called by WrapperLinear._qdq_act
+ *            (auto_round/wrapper.py:295-321) with v = 0, tensor_min/max = None and the wrapper's non-tunable 0-dim
+ *            act_min_scale / act_max_scale (= 1.0).  A 0-dim fp32 tensor does not promote a 16-bit tensor, so -- unlike
+ *            the weight path -- the range arithmetic (wmin, wmax, max_v, max_v / maxq) stays in the ACTIVATION dtype.
+ * per group:  wmin = min(min x, 0), wmax = max(max x, 0); a = -wmin, b = wmax; sgn = b < a ? +1 : -1
+ *             s = thresh_clamp( s_dt( a_dt( sgn*max(a,b) / maxq ) ) );  out = a_dt( s * clamp(round_ste(x/s), -maxq, maxq-1) )
+ * backward (autograd mirrored):  dy_k = [inside] (g_k * s);  dx_k = a_dt( dy_k / s )
+ *             ds = s_dt(c1 + c2) as for weights, thresh mask;  d = a_dt( a_dt(ds) / maxq ) * sgn, routed by max(a,b)
+ *             (a == b: half each) to wmin (as -d, if min x <= 0) / wmax (if max x >= 0) and scattered to the FIRST
+ *             arg-min / arg-max element of the group (an a_dt addition).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float s, s_raw, a, b, sgn; int imin, imax; float xmin, xmax; } actq_t;
+static void act_group(const void* X, int64_t base, int gs, int a_dt, int s_dt, int bits, float q_thresh, actq_t* q) {
+    float mn = load_as_f32(X, base, a_dt), mx = mn;
+    q->imin = 0; q->imax = 0;
+    for (int k = 1; k < gs; ++k) {
+        const float x = load_as_f32(X, base + k, a_dt);
+        if (x < mn) { mn = x; q->imin = k; }
+        if (x > mx) { mx = x; q->imax = k; }
+    }
+    q->xmin = mn; q->xmax = mx;
+    const float wmin = mn < 0.f ? mn : 0.f, wmax = mx > 0.f ? mx : 0.f;
+    const float maxq = (float)(1 << (bits - 1));
+    q->a = -wmin; q->b = wmax;
+    q->sgn = (q->b < q->a) ? 1.f : -1.f;
+    const float m = (q->a > q->b) ? q->a : q->b;
+    q->s_raw = rnd(s_dt, rnd(a_dt, (q->sgn * m) / maxq));
+    const float t = rnd(s_dt, q_thresh);
+    if (q->s_raw < 0.f) q->s = (q->s_raw > -t) ? -t : q->s_raw;
+    else q->s = (q->s_raw < t) ? t : q->s_raw;
+}
+void oracle_int_act_fwd(const void* X, int64_t G, int gs, int bits, int a_dt, int s_dt, float q_thresh, void* Xq, void* scale) {
+    const int x_dt = promote(a_dt, s_dt);
+    const float maxq = (float)(1 << (bits - 1));
+    for (int64_t g = 0; g < G; ++g) {
+        actq_t q;
+        act_group(X, g * gs, gs, a_dt, s_dt, bits, q_thresh, &q);
+        if (scale) store_from_f32(scale, g, s_dt, q.s);
+        for (int k = 0; k < gs; ++k) {
+            const float x = load_as_f32(X, g * gs + k, a_dt);
+            const float r = round_ste_value(rnd(x_dt, x / q.s) + 0.f);
+            store_from_f32(Xq, g * gs + k, a_dt, q.s * clampf(r, -maxq, maxq - 1.f));
+        }
+    }
+}
+void oracle_int_act_bwd(const void* dXq, const void* X, int64_t G, int gs, int bits, int a_dt, int s_dt, float q_thresh,
+                        void* dX) {
+    const int x_dt = promote(a_dt, s_dt);
+    const float maxq = (float)(1 << (bits - 1));
+    for (int64_t g = 0; g < G; ++g) {
+        actq_t q;
+        act_group(X, g * gs, gs, a_dt, s_dt, bits, q_thresh, &q);
+        double acc1 = 0.0, acc2 = 0.0;
+        for (int k = 0; k < gs; ++k) {
+            const int64_t i = g * gs + k;
+            const float gk = load_as_f32(dXq, i, a_dt), x = load_as_f32(X, i, a_dt);
+            const float xs = rnd(x_dt, x / q.s);
+            const float r = round_ste_value(xs + 0.f);
+            const float qq = clampf(r, -maxq, maxq - 1.f);
+            const int inside = (r >= -maxq && r <= maxq - 1.f);
+            const float e = rnd(x_dt, gk * q.s);                 /* grad wrt q, in the product dtype */
+            const float dy = inside ? e : 0.f;
+            /* DivBackward (self), the cast back to a_dt, then autograd's accumulation with the dense (zero-filled) min / max
+             * scatter gradients: x + (+0) turns a -0 (masked +0 divided by a negative scale) into +0 */
+            volatile float zero = 0.f;
+            store_from_f32(dX, i, a_dt, rnd(a_dt, rnd(x_dt, dy / q.s)) + zero);
+            acc1 += (double)rnd(x_dt, gk * qq);
+            acc2 += (double)rnd(x_dt, (-dy) * rnd(x_dt, xs / q.s));
+        }
+        const float c1 = rnd(s_dt, rnd(x_dt, (float)acc1));
+        const float c2 = rnd(s_dt, rnd(x_dt, (float)acc2));
+        const float ds_c = rnd(s_dt, c1 + c2);
+        const float t = rnd(s_dt, q_thresh);
+        const float ds = (q.s_raw < 0.f) ? ((q.s_raw <= -t) ? ds_c : 0.f) : ((q.s_raw >= t) ? ds_c : 0.f);
+        const float dm = rnd(a_dt, rnd(a_dt, ds) / maxq) * q.sgn;
+        float da, db;
+        if (q.a == q.b) { da = rnd(a_dt, dm / 2.f); db = da; }
+        else if (q.a > q.b) { da = dm; db = 0.f; }
+        else { da = 0.f; db = dm; }
+        const float dmin = (q.xmin <= 0.f) ? -da : 0.f;
+        const float dmax = (q.xmax >= 0.f) ? db : 0.f;
+        const int64_t i0 = g * gs + q.imin, i1 = g * gs + q.imax;
+        store_from_f32(dX, i0, a_dt, load_as_f32(dX, i0, a_dt) + dmin);
+        store_from_f32(dX, i1, a_dt, load_as_f32(dX, i1, a_dt) + dmax);
+    }
+}

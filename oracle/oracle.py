@@ -278,3 +278,16 @@ def search_int_scale(X, G, gs, bits, x_dt=DT_BF16, qw_row=None, groups_per_row=0
     lib().oracle_search_int_scale(_p(X), _p(qw), ctypes.c_int64(groups_per_row), _p(cand), len(cand), ctypes.c_int64(G), gs,
                                   bits, x_dt, _f(q_thresh), _p(raw), _p(init))
     return raw, init
+
+
+def int_act_fwd(X, G, gs, bits, a_dt=DT_BF16, s_dt=DT_F16, q_thresh=1e-5):
+    Xq = np.empty(G * gs, dtype=np_dtype(a_dt))
+    scale = np.empty(G, dtype=np_dtype(s_dt))
+    lib().oracle_int_act_fwd(_p(X), ctypes.c_int64(G), gs, bits, a_dt, s_dt, _f(q_thresh), _p(Xq), _p(scale))
+    return Xq, scale
+
+
+def int_act_bwd(dXq, X, G, gs, bits, a_dt=DT_BF16, s_dt=DT_F16, q_thresh=1e-5):
+    dX = np.empty(G * gs, dtype=np_dtype(a_dt))
+    lib().oracle_int_act_bwd(_p(dXq), _p(X), ctypes.c_int64(G), gs, bits, a_dt, s_dt, _f(q_thresh), _p(dX))
+    return dX

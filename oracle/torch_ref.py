@@ -234,10 +234,33 @@ def nvfp4_global_scale(t):
     return 448.0 * 6.0 * _recip0(t.to(torch.float32).abs().max())
 
 
+def qdq_int_act_sym(x, bits, gs, scale_dtype=torch.float16, thresh=1e-5):
+    """Dynamic symmetric INT fake-quant of an activation (quant_tensor_sym with v=0, tensor_min/max=None and the wrapper's
+    non-tunable 0-dim act_min_scale / act_max_scale; data_type/int.py:165-238, wrapper.py:295-321).  Unlike the weight path
+    the range arithmetic stays in the ACTIVATION dtype: a 0-dim fp32 tensor does not promote a bf16 tensor."""
+    gs = x.shape[-1] if (gs == -1 or x.shape[-1] < gs) else gs
+    t = x.reshape(-1, gs)
+    maxq = 2 ** (bits - 1)
+    one = torch.tensor(1.0, device=x.device)
+    wmin = torch.clamp(t.min(-1)[0], max=0)
+    wmax = torch.clamp(t.max(-1)[0], min=0)
+    a = -(wmin * one)
+    b = wmax * one
+    max_v = (2 * (b < a).int() - 1) * torch.max(b, a)
+    s = (max_v / maxq).to(scale_dtype)
+    s = torch.where(s < 0, torch.clamp(s, max=-thresh), torch.clamp(s, min=thresh)).unsqueeze(-1)
+    q = torch.clamp(_ste(torch.round, t / s + 0), -maxq, maxq - 1)
+    return (s * q).to(x.dtype).reshape(x.shape), s
+
+
 def act_fake_quant(x, layer):
-    """WrapperLinear._qdq_act for the fp4 activation schemes (wrapper.py:295-321)."""
+    """WrapperLinear._qdq_act for the fp4 and symmetric-int activation schemes (wrapper.py:295-321)."""
     adt = str(getattr(layer, "act_data_type", ""))
     one = torch.tensor(1.0, device=x.device)
+    if adt.startswith("int"):
+        if not bool(getattr(layer, "act_sym", True)):
+            raise NotImplementedError("asymmetric int activations")
+        return qdq_int_act_sym(x, int(layer.act_bits), int(layer.act_group_size), getattr(layer, "scale_dtype", torch.float16))[0]
     if adt.startswith("mx_fp"):
         return qdq_mxfp4(x, int(layer.act_group_size), 0, one)[0]
     if adt.startswith("nv_fp"):

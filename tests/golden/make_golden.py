@@ -500,3 +500,36 @@ def gen_steps_v2():
 
 if __name__ == "__main__" and ("stepv2" in sys.argv[1:] or not sys.argv[1:]):
     gen_steps_v2()
+
+
+def gen_int_act():
+    """Dynamic symmetric INT activation fake-quant (W4A8-style schemes): quant_tensor_sym on the activation with v=0 and
+    the wrapper's non-tunable 0-dim act_min_scale / act_max_scale, forward + autograd backward w.r.t. the input."""
+    from auto_round.data_type.int import quant_tensor_sym
+
+    rec = {}
+    for tag, nbits, gs, dt, hidden in (("a8g32", 8, 32, torch.bfloat16, 128), ("a8g128", 8, 128, torch.bfloat16, 256),
+                                       ("a4g32", 4, 32, torch.bfloat16, 128), ("a8g32_f16", 8, 32, torch.float16, 128),
+                                       ("a8pt", 8, -1, torch.bfloat16, 256)):
+        g = torch.Generator().manual_seed(31 + nbits + max(gs, 0))
+        x = (torch.randn(3, 7, hidden, generator=g) * 1.7)
+        x[0, 0, :32] = 0.0                       # all-zero group
+        x[0, 1, :32] = x[0, 1, :32].abs()        # all-positive group
+        x[0, 2, :32] = -x[0, 2, :32].abs()       # all-negative group
+        x[0, 3, 5] = 9.0; x[0, 3, 9] = 9.0       # tied maxima
+        x[0, 4, 3] = -11.0; x[0, 4, 4] = 11.0    # |min| == max
+        x[1, 0, :32] *= 1e-7                     # below the scale threshold
+        x = x.to(dt).requires_grad_(True)
+        one = torch.tensor(1.0)
+        xq, scale, _ = quant_tensor_sym(x, bits=nbits, group_size=gs, v=0, min_scale=one.clone(), max_scale=one.clone(),
+                                        scale_dtype=torch.float16, tensor_max=None, q_scale_thresh=1e-5)
+        dy = (torch.randn(x.shape, generator=g) * 1e-2).to(dt)
+        xq.backward(dy)
+        rec.update({f"{tag}_x": bits(x), f"{tag}_xq": bits(xq), f"{tag}_scale": bits(scale.reshape(-1)), f"{tag}_dy": bits(dy),
+                    f"{tag}_dx": bits(x.grad), f"{tag}_meta": np.array([nbits, gs, hidden])})
+        print("int act", tag, xq.dtype, scale.dtype, tuple(scale.shape))
+    np.savez_compressed(os.path.join(HERE, "int_act.npz"), **rec)
+
+
+if __name__ == "__main__" and ("intact" in sys.argv[1:] or not sys.argv[1:]):
+    gen_int_act()

@@ -695,3 +695,39 @@ def test_data_parallel_block_tuning_two_ranks_one_gpu(tmp_path):
     # after the first step V is +-lr0 wherever the summed gradient is non-zero: the two runs agree on almost every sign
     same = [(dp["V"][n].sign() == best[n]["value"].cpu().sign()).float().mean().item() for n in best]
     assert np.mean(same) > 0.9, same
+
+
+@pytest.mark.parametrize("act_gs", [32, -1])
+def test_w4a8_int_activation_scheme_vs_torch_ref(act_gs):
+    """W4A8 (the reference's own GPU smoke configuration, test_sign_sgd_pipeline.py:59-82: bits=4, act_bits=8,
+    act_group_size=32, sym): int activation fake-quant inside the tuning loop, WrapperWALayer after unwrapping."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.wrapper import WrapperWALayer
+    from oracle import torch_ref as tr
+
+    layer, rope, cfg = make_layer("llama", 4, 32, True, seed=6)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.act_bits, m.act_group_size, m.act_sym, m.act_dynamic, m.act_data_type = 8, act_gs, True, True, "int"
+    X, others = make_data(rope, cfg)
+    Y = targets(layer, X, others)
+    iters, bs = 4, 4
+    blk_o = copy.deepcopy(layer)
+    random.seed(11)
+    best_o, info = tr.tune_block(blk_o, X, Y, others, iters=iters, batch_size=bs, forward=fwd)
+    blk_m = copy.deepcopy(layer)
+    random.seed(11)
+    q = SignRoundQuantizer(SignRoundConfig(iters=iters, batch_size=bs, bits=4), device="cuda")
+    q.quantize_block(blk_m, X, others, Y, None, None)
+    st = q.last_stats
+    assert abs(st["init_loss"] - info["losses"][0]) <= 5e-3 * info["losses"][0], (st, info["losses"])
+    assert abs(st["best_loss"] - info["best_loss"]) <= 3e-2 * info["best_loss"]
+    was = [m for m in blk_m.modules() if isinstance(m, WrapperWALayer)]
+    assert len(was) == 7
+    agree = [(mo.orig_layer.weight == mm.orig_layer.weight).float().mean().item()
+             for mo, mm in zip([m for m in blk_o.modules() if isinstance(m, tr.RefWALayer)], was)]
+    assert np.mean(agree) > 0.97, agree
+    # the unwrapped block keeps quantising its activations: same output as the restatement's
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        a, b = fwd(blk_m, X[:2], others).float(), fwd(blk_o, X[:2], others).float()
+    assert float((a - b).abs().mean()) <= 0.05 * float(b.abs().mean())

@@ -345,3 +345,15 @@ def test_alg_ext_tune_block_equals_reference_loop_on_cpu(bits, data_type, group_
     for n in best:
         for k in best[n]:
             assert torch.equal(best[n][k], best_o[n][k]), (n, k)
+
+
+@pytest.mark.parametrize("tag", ("a8g32", "a8g128", "a4g32", "a8g32_f16", "a8pt"))
+def test_int_activation_restatement_equals_reference_golden(tag):
+    z = np.load(os.path.join(GOLDEN, "int_act.npz"))
+    nb, gs, hidden = [int(v) for v in z[tag + "_meta"]]
+    dt = orc.DT_F16 if tag.endswith("f16") else orc.DT_BF16
+    x = orc.from_bits(z[tag + "_x"], dt).requires_grad_(True)
+    xq, s = tr.qdq_int_act_sym(x, nb, gs)
+    xq.backward(orc.from_bits(z[tag + "_dy"], dt))
+    assert np.array_equal(orc.to_bits(xq), z[tag + "_xq"]) and np.array_equal(orc.to_bits(s.reshape(-1)), z[tag + "_scale"])
+    assert np.array_equal(orc.to_bits(x.grad), z[tag + "_dx"])

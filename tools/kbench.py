@@ -67,6 +67,12 @@ def main():
         res[f"{name}fp4_act_fwd_GBps"] = 4 * n / t / 1e6
         t = timeit(lambda: ops.fp4_act_bwd(dWq, W, mode=mode, gs=fgs, global_scale=gsc, out=Wq))
         res[f"{name}fp4_act_bwd_GBps"] = 6 * n / t / 1e6
+    # dynamic symmetric int8 activation fake-quant: group 32 / 128 (lane groups) and per-token 4096 (wave per group)
+    for ags in (32, 128, 4096):
+        t = timeit(lambda: ops.qdq_int_act_fwd(W, gs=ags, bits=8, out=Wq))
+        res[f"int8_act_g{ags}_fwd_GBps"] = 4 * n / t / 1e6
+        t = timeit(lambda: ops.int_act_bwd(dWq, W, gs=ags, bits=8, out=Wq))
+        res[f"int8_act_g{ags}_bwd_GBps"] = 6 * n / t / 1e6
     print(json.dumps({k: round(v, 3) for k, v in res.items()}))
 
 
