@@ -90,3 +90,22 @@ def test_autoround_front_door_argument_errors():
         AutoRound(model, None, low_gpu_mem_usage=True)
     with pytest.raises(RuntimeError):
         AutoRound(model, None, dataset=torch.zeros(1, 8, dtype=torch.long)).save_quantized("/tmp/never")
+
+
+def test_autoround_front_door_w4a8_like_the_reference_smoke_test(tmp_path):
+    """The reference's GPU smoke configuration (test/unit/test_cuda/algorithms/test_sign_sgd_pipeline.py:59-82): bits=4,
+    act_bits=8, act_group_size=32, sym, iters=1, nsamples=2, seqlen=16 -> quantize_and_save, then the model still runs."""
+    from auto_round_amd.autoround import AutoRound
+    from auto_round_amd.wrapper import WrapperWALayer
+
+    model = tiny_llama()
+    tokens = torch.randint(0, 512, (2, 16), generator=torch.Generator().manual_seed(2))
+    ar = AutoRound(model, None, bits=4, act_bits=8, group_size=32, act_group_size=32, sym=True, iters=1, nsamples=2, seqlen=16,
+                   batch_size=2, dataset=tokens)
+    qmodel, out = ar.quantize_and_save(str(tmp_path / "w4a8"))
+    qc = json.load(open(os.path.join(out, "config.json")))["quantization_config"]
+    assert qc["act_bits"] == 8 and qc["act_group_size"] == 32 and qc["act_data_type"] == "int" and qc["act_sym"] is True
+    assert sum(isinstance(m, WrapperWALayer) for m in qmodel.modules()) == 14
+    with torch.no_grad():
+        logits = qmodel(input_ids=tokens.cuda()).logits
+    assert logits.shape[0] == 2 and bool(torch.isfinite(logits).all())
