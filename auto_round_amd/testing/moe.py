@@ -69,28 +69,15 @@ def build_moe_decoder_layer(hidden=4096, ffn=14336, heads=32, kv_heads=8, num_ex
     return layer, rope, cfg
 
 
-def set_scheme(layer, scheme: str):
-    """Attach the per-layer scheme attributes of the reference's presets (schemes.py:538-832) to every nn.Linear.
-    scheme in {"W4A16", "W2A16G32", "MXFP4", "NVFP4", "MXFP4_W"(weight only), "NVFP4_W"}.  The router gate stays fp."""
-    presets = {
-        "W4A16": dict(bits=4, group_size=128, sym=True, data_type="int", act_bits=16),
-        "W2A16G32": dict(bits=2, group_size=32, sym=False, data_type="int", act_bits=16),
-        "MXFP4": dict(bits=4, group_size=32, sym=True, data_type="mx_fp", act_bits=4, act_group_size=32, act_sym=True,
-                      act_dynamic=True, act_data_type="mx_fp"),
-        "NVFP4": dict(bits=4, group_size=16, sym=True, data_type="nv_fp", act_bits=4, act_group_size=16, act_sym=True,
-                      act_dynamic=True, act_data_type="nv_fp4_with_static_gs"),
-        "MXFP4_W": dict(bits=4, group_size=32, sym=True, data_type="mx_fp", act_bits=16),
-        "NVFP4_W": dict(bits=4, group_size=16, sym=True, data_type="nv_fp", act_bits=16),
-    }
-    attrs = presets[scheme]
-    n = 0
-    for name, m in layer.named_modules():
-        if isinstance(m, torch.nn.Linear):
-            if name.endswith("mlp.gate"):       # router: not quantised (reference keeps MoE gates in high precision)
-                m.bits, m.act_bits = 16, 16
-                continue
-            for k, v in attrs.items():
-                setattr(m, k, v)
-            m.scale_dtype = torch.float16
-            n += m.weight.numel()
-    return n
+def set_scheme(layer, scheme: str, **overrides):
+    """Attach the per-layer scheme attributes of a preset (auto_round_amd/schemes.py, same names and values as the
+    reference's schemes.py:538-832) to every nn.Linear; `NAME_W` = the weight-only variant of an A4 preset (act_bits 16).
+    The MoE router gate stays in 16 bit.  Returns the number of weights that will be quantised."""
+    from ..schemes import apply_scheme, resolve_scheme
+
+    weight_only = scheme.endswith("_W")
+    cfg = resolve_scheme(scheme[:-2] if weight_only else scheme, **overrides)
+    if weight_only:
+        cfg.update(act_bits=16, act_data_type=None, act_group_size=None, act_sym=None, act_dynamic=None)
+    done = apply_scheme(layer, cfg, skip=("mlp.gate",))
+    return sum(m.weight.numel() for n, m in layer.named_modules() if n in done and done[n]["bits"] < 16)

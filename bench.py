@@ -328,6 +328,12 @@ def main():
 
     if rank == 0:
         G = n_w // args.group_size
+        default_cfg = (args.scheme is None and args.bits == 4 and args.group_size == 128 and sym and args.iters == 200
+                       and N == 128 and S == 2048)
+        # the description names the BASELINE config only when the run really is that config
+        workload_desc = w["desc"] if default_cfg else (
+            w["desc"].split(",")[0] + f", {args.scheme or ('W%dG%d %s' % (args.bits, args.group_size, 'sym' if sym else 'asym'))}"
+            f", iters={args.iters}, calib {N}x{S} (non-default variant of the BASELINE config)")
         out = {
             "metric": "transformer blocks tuned/sec (200 iters, 128x2048 calib)",
             "value": (1 if dp else world) * args.steps / elapsed,
@@ -339,7 +345,7 @@ def main():
             "dtype_detail": "bf16 weights/activations and MFMA GEMMs (fp32 accumulate); fp32 rounding offsets V and min/max "
                             "scales; fp16 quant scales; int4 packed output",
             "data": "synthetic: random-init weights of the named architecture, N(0,1) bf16 hidden states",
-            "config": {"workload": w["desc"], "scheme": args.scheme or "int", "bits": args.bits, "group_size": args.group_size, "sym": sym,
+            "config": {"workload": workload_desc, "scheme": args.scheme or "int", "bits": args.bits, "group_size": args.group_size, "sym": sym,
                        "iters": args.iters, "nsamples": N, "seqlen": S, "batch_size": args.batch_size,
                        "weights_per_block": n_w, "groups_per_block": G, "includes_packing": True,
                        "fuse_next_forward": bool(args.fuse_next_forward), "sdpa_backend": args.sdpa,
