@@ -518,8 +518,13 @@ __global__ __launch_bounds__(kTPB) void k_int_bwd_generic(const BwdArgs a) {
 // operations), the gs/8 lanes of a group meet only in the shuffle butterfly, and the first lane of the group applies
 // the min/max step.  A/B against the LDS-staged kernels is recorded in DESIGN.md section 3.
 // ------------------------------------------------------------------------------------------------------------------
-template <int WDT, int XR, int U>
-__global__ __launch_bounds__(kTPB) void k_int_fwd_flat(const FwdArgs a) {
+// SPEC != 0: instantiation for the configurations the BASELINE runs use -- symmetric, fp16 scales, SPEC lanes per group
+// (16 = group 128, 4 = group 32): the scheme branches, the runtime scale-dtype rounding and the butterfly width fold at
+// compile time (same arithmetic; the generic instantiation serves everything else).
+template <int WDT, int XR, int U, int SPEC = 0>
+__global__ __launch_bounds__(kTPB) void k_int_fwd_flat(const FwdArgs a0) {
+    FwdArgs a = a0;
+    if (SPEC) { a.cfg.sym = 1; a.cfg.s_dt = AR_DT_F16; a.cpg = SPEC; a.cpg_shift = SPEC == 4 ? 2 : 4; }
     const int shift = a.cpg_shift;
     const int64_t total_chunks = a.n_groups << shift;
     const int64_t stride = (int64_t)gridDim.x * kTPB * U;
@@ -567,8 +572,10 @@ __global__ __launch_bounds__(kTPB) void k_int_fwd_flat(const FwdArgs a) {
     }
 }
 
-template <int WDT, int XR, int U>
-__global__ __launch_bounds__(kTPB) void k_int_bwd_flat(const BwdArgs a) {
+template <int WDT, int XR, int U, int SPEC = 0>
+__global__ __launch_bounds__(kTPB) void k_int_bwd_flat(const BwdArgs a0) {
+    BwdArgs a = a0;
+    if (SPEC) { a.cfg.sym = 1; a.cfg.s_dt = AR_DT_F16; a.cpg = SPEC; a.cpg_shift = SPEC == 4 ? 2 : 4; }
     const int shift = a.cpg_shift, cpg = a.cpg;
     const int64_t total_chunks = a.n_groups << shift;
     const int64_t stride = (int64_t)gridDim.x * kTPB * U;
@@ -756,6 +763,9 @@ extern "C" int ar_group_absmax(const void* W, float* absmax, float* tensor_absma
 #ifndef AR_FLAT_BWD_UNROLL
 #define AR_FLAT_BWD_UNROLL 2
 #endif
+#ifndef AR_INT_SPEC
+#define AR_INT_SPEC 1
+#endif
 #ifndef AR_FWD_UNROLL
 #define AR_FWD_UNROLL 4
 #endif
@@ -799,6 +809,14 @@ extern "C" int ar_qdq_int_fwd(const void* W, const float* V, const void* wmin, c
 #if AR_INT_FLAT
     if (a.cpg_shift >= 0 && a.cpg <= kWave) {
         const int fgrid = grid_for_tiles((n_groups * a.cpg + kTPB * AR_FLAT_FWD_UNROLL - 1) / (kTPB * AR_FLAT_FWD_UNROLL));
+#if AR_INT_SPEC
+        // measured (tools/kbench.py): the forward is HBM-bound either way (group 128: equal, group 32: the generic one is
+        // 1.7 % faster), the fused backward gains 4-9 % -- so only group 128 takes the specialised forward
+        if (w_dt == AR_DT_BF16 && !same16 && a.cfg.sym == 1 && s_dt == AR_DT_F16 && a.cpg == 16) {
+            hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_FWD_UNROLL, 16>), fgrid, kTPB, 0, st, a);
+            return launch_status();
+        }
+#endif
         switch (w_dt) {
             case AR_DT_BF16:
                 if (same16) hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_BF16, AR_DT_BF16, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
@@ -859,6 +877,13 @@ static int launch_int_bwd(BwdArgs& a, int gs, int bits, int sym, int w_dt, int s
 #if AR_INT_FLAT
     {
         const int fgrid = grid_for_tiles((a.n_groups * a.cpg + kTPB * AR_FLAT_BWD_UNROLL - 1) / (kTPB * AR_FLAT_BWD_UNROLL));
+#if AR_INT_SPEC
+        if (w_dt == AR_DT_BF16 && !same16 && a.cfg.sym == 1 && s_dt == AR_DT_F16 && (a.cpg == 16 || a.cpg == 4)) {
+            if (a.cpg == 16) hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL, 16>), fgrid, kTPB, 0, st, a);
+            else hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL, 4>), fgrid, kTPB, 0, st, a);
+            return launch_status();
+        }
+#endif
         switch (w_dt) {
             case AR_DT_BF16:
                 if (same16) hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_BF16, AR_DT_BF16, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
