@@ -34,7 +34,7 @@ class _StopForward(Exception):
 
 def get_block_names(model) -> List[List[str]]:
     """Names of the repeated decoder blocks: the children of every nn.ModuleList found first on each path from the root
-    (reference: utils/model.py get_block_names, LLM branch)."""
+    (reference: utils/model.py get_block_names, LLM branch).  The decoder stack is the longest such list."""
     groups = []
 
     def search(prefix, module):
@@ -141,6 +141,9 @@ class AutoRound:
         model = self.model.to(self.device).eval()
         for p in model.parameters():
             p.requires_grad_(False)
+        from .moe_unfuse import unfuse_moe_experts
+
+        self.unfused_moe = unfuse_moe_experts(model)      # fused 3-D expert parameters -> per-expert nn.Linear (moe_unfuse.py)
         groups = get_block_names(model)
         if not groups:
             raise ValueError("no repeated decoder blocks (nn.ModuleList) found in the model")

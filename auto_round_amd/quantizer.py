@@ -145,7 +145,12 @@ def set_amax_for_uncalibrated_experts(block, attr_name="act_max") -> int:
     filled = 0
     for mod in block.modules():
         experts = getattr(mod, "experts", None)
-        if experts is None or not isinstance(experts, (list, tuple, torch.nn.ModuleList)):
+        if experts is None:
+            continue
+        from .moe_unfuse import expert_children
+
+        experts = expert_children(experts)      # ModuleList of experts or an unfused experts module (numbered children)
+        if not experts:
             continue
         names = sorted({n for e in experts for n, c in e.named_children() if _quantizable(c)})
         for name in names:

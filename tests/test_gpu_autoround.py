@@ -109,3 +109,33 @@ def test_autoround_front_door_w4a8_like_the_reference_smoke_test(tmp_path):
     with torch.no_grad():
         logits = qmodel(input_ids=tokens.cuda()).logits
     assert logits.shape[0] == 2 and bool(torch.isfinite(logits).all())
+
+
+@pytest.mark.parametrize("scheme", ["W4A16", "MXFP4"])
+def test_autoround_front_door_on_a_hf_mixtral_with_fused_experts(tmp_path, scheme):
+    """BASELINE cfg 5 shape of problem through the front door: a (tiny, random) transformers MixtralForCausalLM, whose experts
+    are fused 3-D parameters, is unfused, tuned block by block (idle experts included) and written as a checkpoint with
+    per-expert tensors."""
+    from safetensors import safe_open
+
+    from auto_round_amd.autoround import AutoRound
+    from test_moe_unfuse import tiny_mixtral
+
+    model = tiny_mixtral(layers=2, hidden=128, ffn=256, experts=4).to(torch.bfloat16)
+    tokens = torch.randint(0, 96, (8, 32), generator=torch.Generator().manual_seed(4))
+    kw = dict(group_size=32) if scheme == "W4A16" else {}
+    ar = AutoRound(model, None, scheme=scheme, iters=3, nsamples=8, seqlen=32, batch_size=4, dataset=tokens, **kw)
+    qmodel, out = ar.quantize_and_save(str(tmp_path / "moe"))
+    assert ar.unfused_moe == ["model.layers.0.mlp.experts", "model.layers.1.mlp.experts"]
+    assert all(r["stats"]["quantized"] == 4 + 3 * 4 for r in ar.records)
+    keys = set()
+    with safe_open(os.path.join(out, "model.safetensors"), "pt") as f:
+        keys = set(f.keys())
+    leaf = "qweight" if scheme == "W4A16" else "weight_packed"
+    for e in range(4):
+        for p in ("gate_proj", "up_proj", "down_proj"):
+            assert f"model.layers.1.mlp.experts.{e}.{p}.{leaf}" in keys
+    assert "model.layers.0.mlp.gate.weight" in keys and not any("gate_up_proj" in k for k in keys)
+    with torch.no_grad():
+        logits = qmodel(input_ids=tokens[:2].cuda()).logits
+    assert bool(torch.isfinite(logits).all())

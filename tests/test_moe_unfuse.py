@@ -1,0 +1,51 @@
+"""Unfusing of transformers' fused 3-D MoE expert parameters into per-expert nn.Linear (model preparation for cfg 5)."""
+import pytest
+import torch
+
+
+def tiny_mixtral(layers=1, hidden=64, ffn=128, experts=4, top_k=2, seed=0):
+    from transformers import MixtralConfig, MixtralForCausalLM
+
+    torch.manual_seed(seed)
+    cfg = MixtralConfig(hidden_size=hidden, intermediate_size=ffn, num_attention_heads=4, num_key_value_heads=2,
+                        num_hidden_layers=layers, vocab_size=96, max_position_embeddings=64, num_local_experts=experts,
+                        num_experts_per_tok=top_k, tie_word_embeddings=False)
+    cfg._attn_implementation = "sdpa"
+    return MixtralForCausalLM(cfg).eval()
+
+
+def test_unfused_experts_compute_the_same_function_and_expose_linears():
+    from auto_round_amd.moe_unfuse import expert_children, unfuse_moe_experts
+    from auto_round_amd.schemes import apply_scheme, resolve_scheme
+
+    model = tiny_mixtral()
+    tokens = torch.randint(0, 96, (2, 24), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        before = model(input_ids=tokens).logits
+    gu = model.model.layers[0].mlp.experts.gate_up_proj.detach().clone()
+    dn = model.model.layers[0].mlp.experts.down_proj.detach().clone()
+    names = unfuse_moe_experts(model)
+    assert names == ["model.layers.0.mlp.experts"]
+    ex = model.model.layers[0].mlp.experts
+    assert not hasattr(ex, "gate_up_proj") and len(expert_children(ex)) == 4
+    assert torch.equal(ex.get_submodule("2").gate_proj.weight, gu[2, :128]) and torch.equal(ex.get_submodule("2").up_proj.weight, gu[2, 128:])
+    assert torch.equal(ex.get_submodule("3").down_proj.weight, dn[3])
+    with torch.no_grad():
+        after = model(input_ids=tokens).logits
+    assert torch.allclose(before, after, rtol=1e-4, atol=1e-5)          # fp32: one fused GEMM vs two, same math
+    sd = model.state_dict()
+    assert "model.layers.0.mlp.experts.1.up_proj.weight" in sd and "model.layers.0.mlp.experts.gate_up_proj" not in sd
+    assert unfuse_moe_experts(model) == []                               # idempotent
+    cfg = apply_scheme(model.model.layers[0], resolve_scheme("W4A16", group_size=32))
+    assert cfg["mlp.experts.0.gate_proj"]["bits"] == 4 and "mlp.gate" not in cfg     # the router is not an nn.Linear: stays fp
+    assert sum(c["bits"] == 4 for c in cfg.values()) == 4 + 3 * 4
+
+
+def test_dense_models_are_left_alone():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from auto_round_amd.moe_unfuse import unfuse_moe_experts
+
+    m = LlamaForCausalLM(LlamaConfig(hidden_size=32, intermediate_size=64, num_attention_heads=2, num_key_value_heads=2,
+                                     num_hidden_layers=1, vocab_size=32))
+    assert unfuse_moe_experts(m) == []
