@@ -45,6 +45,9 @@ WORKLOADS = {
     "mixtral-8x7b": dict(hidden=4096, ffn=14336, heads=32, kv=8, family="moe", experts=8, top_k=2,
                          desc="Mixtral-8x7B-shaped sparse-MoE decoder block (8 experts, top-2, experts as nn.Linear "
                               "w1/w2/w3 as after the reference's fused-MoE unfusing; BASELINE.json configs[4])"),
+    "mixtral-8x7b-hf": dict(hidden=4096, ffn=14336, heads=32, kv=8, family="moe_hf", experts=8, top_k=2,
+                            desc="Mixtral-8x7B decoder block as transformers builds it (MixtralDecoderLayer; fused 3-D expert "
+                                 "parameters unfused by auto_round_amd.moe_unfuse; BASELINE.json configs[4])"),
 }
 SCHEMES = ("W4A16", "W2A16G32", "MXFP4", "NVFP4", "MXFP4_W", "NVFP4_W")
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
@@ -62,6 +65,29 @@ def build_block(w, bits, gs, sym, device, seed, attn="sdpa", scheme=None):
             for m in layer.modules():
                 if isinstance(m, torch.nn.Linear) and getattr(m, "bits", 16) < 16:
                     m.bits, m.group_size, m.sym = bits, gs, sym
+        return layer, rope, cfg, n_w
+    if w["family"] == "moe_hf":
+        from transformers import MixtralConfig
+        from transformers.models.mixtral.modeling_mixtral import MixtralDecoderLayer, MixtralRotaryEmbedding
+
+        from auto_round_amd.moe_unfuse import unfuse_moe_experts
+        from auto_round_amd.testing.moe import set_scheme
+
+        cfg = MixtralConfig(hidden_size=w["hidden"], intermediate_size=w["ffn"], num_attention_heads=w["heads"],
+                            num_key_value_heads=w["kv"], num_hidden_layers=1, vocab_size=32000, rope_theta=1e6,
+                            max_position_embeddings=32768, num_local_experts=w["experts"], num_experts_per_tok=w["top_k"])
+        cfg._attn_implementation = attn
+        with torch.device(device):
+            layer = MixtralDecoderLayer(cfg, 0).to(torch.bfloat16)
+            rope = MixtralRotaryEmbedding(cfg)
+        for p in layer.parameters():                        # torch.empty expert parameters: give them a weight-like scale
+            if p.dim() == 3:
+                p.data.normal_(0.0, 0.02)
+        layer.eval()
+        for p in layer.parameters():
+            p.requires_grad_(False)
+        unfuse_moe_experts(layer)
+        n_w = set_scheme(layer, scheme or "W4A16")
         return layer, rope, cfg, n_w
     if w["family"] == "llama":
         from transformers import LlamaConfig
@@ -366,7 +392,7 @@ def main():
             abytes = 8 * n_w + per_g_f * G
             if fp4 and args.scheme.startswith("NVFP4"):   # NVFP4 launches per layer (own global scale): use the byte-weighted mean
                 tot = sum(s.elapsed_time(e) for s, e in timer.pairs[fname])
-                launches_per_block = 4 + 3 * w.get("experts", 0) if w["family"] == "moe" else 7
+                launches_per_block = 4 + 3 * w.get("experts", 0) if w["family"] in ("moe", "moe_hf") else 7
                 fwd_ms = tot / (len(timer.pairs[fname]) / launches_per_block)
             out["roofline"] = {"kernel": fname + (" (fp4 weight fake-quant forward)" if fp4 else
                                                    " (INT fake-quant forward, whole block per launch)"), "bound": "hbm",
@@ -378,7 +404,7 @@ def main():
             per = 12 + (2 if (args.fuse_next_forward and not fp4) else 0)
             abytes = per * n_w + per_g_b * G
             if fp4 and args.scheme.startswith("NVFP4"):
-                launches_per_block = 4 + 3 * w.get("experts", 0) if w["family"] == "moe" else 7
+                launches_per_block = 4 + 3 * w.get("experts", 0) if w["family"] in ("moe", "moe_hf") else 7
                 ms2 = ms2 * launches_per_block
             out["roofline_bwd_sgd"] = {"kernel": ("k_fp4_bwd" if fp4 else "k_int_bwd") + " (fused qdq backward + sign-SGD" +
                                        (" + next forward)" if (args.fuse_next_forward and not fp4) else ")"), "bound": "hbm",
