@@ -16,6 +16,13 @@ PRESET_SCHEMES: Dict[str, dict] = {
     "W2A16G32": dict(_INT, bits=2, group_size=32),
     "W3A16": dict(_INT, bits=3, group_size=128),
     "W8A16": dict(_INT, bits=8, group_size=128),
+    # per-channel weights + dynamic per-token symmetric activations
+    "INT8": dict(bits=8, group_size=-1, sym=True, data_type="int", act_bits=8, act_data_type="int", act_group_size=-1,
+                 act_sym=True, act_dynamic=True),
+    "INT8_W8A8": dict(bits=8, group_size=-1, sym=True, data_type="int", act_bits=8, act_data_type="int", act_group_size=-1,
+                      act_sym=True, act_dynamic=True),
+    "INT4": dict(bits=4, group_size=-1, sym=True, data_type="int", act_bits=4, act_data_type="int", act_group_size=-1,
+                 act_sym=True, act_dynamic=True),
     "MXFP4": dict(bits=4, group_size=32, sym=True, data_type="mx_fp", act_bits=4, act_data_type="mx_fp", act_group_size=32,
                   act_sym=True, act_dynamic=True),
     "NVFP4": dict(bits=4, group_size=16, sym=True, data_type="nv_fp", act_bits=4, act_data_type="nv_fp4_with_static_gs",
