@@ -48,12 +48,34 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--train-steps", type=int, default=1500)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--load-model", default=None, help="skip training: use the model / tokens saved by --save-model and only run "
+                                                       "SignRound for W4A16 g32 / W2A16 g32 / W2A16 g32 asym over --seeds")
+    ap.add_argument("--seeds", default="42,43,44")
+    ap.add_argument("--save-model", default=None, help="write the trained bf16 state dict + calibration / held-out tokens here")
     a = ap.parse_args()
     from transformers import LlamaConfig, LlamaForCausalLM
 
     from auto_round_amd.autoround import AutoRound
 
     vocab, seqlen = 64, 128
+    if a.load_model:
+        blob = torch.load(a.load_model)
+        cfg = LlamaConfig(**{k: v for k, v in blob["config"].items() if k not in ("architectures", "model_type", "transformers_version", "dtype")})
+        cfg._attn_implementation = "sdpa"
+        model = LlamaForCausalLM(cfg).to(torch.bfloat16)
+        model.load_state_dict(blob["state_dict"])
+        model = model.cuda().eval()
+        res = {"ppl_bf16": round(perplexity(model, blob["held"]), 4), "iters": a.iters, "seeds": {}}
+        for name, kw in (("W4A16 g32", dict(scheme="W4A16", group_size=32)), ("W2A16 g32", dict(scheme="W2A16G32")),
+                         ("W2A16 g32 asym", dict(scheme="W2A16G32", sym=False))):
+            res["seeds"][name] = {}
+            for seed in [int(x) for x in a.seeds.split(",")]:
+                m = copy.deepcopy(model)
+                AutoRound(m, None, nsamples=128, seqlen=seqlen, batch_size=8, dataset=blob["calib"], iters=a.iters, seed=seed, **kw).quantize()
+                res["seeds"][name][str(seed)] = round(perplexity(m, blob["held"]), 4)
+            print(name, res["seeds"][name], file=sys.stderr)
+        print(json.dumps(res))
+        return
     torch.manual_seed(0)
     cfg = LlamaConfig(hidden_size=256, intermediate_size=768, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=4,
                       vocab_size=vocab, max_position_embeddings=seqlen, tie_word_embeddings=False)
@@ -74,6 +96,9 @@ def main():
         loss = torch.nn.functional.cross_entropy(logits[:, :-1].float().reshape(-1, vocab), t[:, 1:].reshape(-1))
         opt.zero_grad(set_to_none=True); loss.backward(); opt.step(); sched.step()
     model = model.to(torch.bfloat16).eval()
+    if a.save_model:
+        torch.save({"state_dict": {k: v.cpu() for k, v in model.state_dict().items()}, "calib": calib, "held": held,
+                    "config": cfg.to_dict()}, a.save_model)
     res = {"train_s": round(time.time() - t0, 1), "train_loss_last": round(float(loss.detach()), 4), "ppl_bf16": round(perplexity(model, held), 4),
            "model": "Llama 4x256 (ffn 768), vocab 64, synthetic order-2 Markov language (4096 contexts x 4 continuations)", "iters": a.iters, "schemes": {}}
     for name, kw in (("W4A16 g32", dict(scheme="W4A16", group_size=32)), ("W3A16 g32", dict(scheme="W3A16", group_size=32)),
