@@ -57,6 +57,8 @@ def main():
     ap.add_argument("model")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--schemes", default="W4A16 g32;W2A16 g32")
+    ap.add_argument("--skip-torch-ref", action="store_true")
     ap.add_argument("--reference-mask", action="store_true",
                     help="feed the blocks the attention mask the reference's front door ends up caching with transformers >= 5: the "
                          "boolean causal mask cast to the amp dtype (calibration/inputs.py:100-107), i.e. a 0/1 ADDITIVE bias -- "
@@ -71,7 +73,10 @@ def main():
     base.load_state_dict(blob["state_dict"])
     base = base.cuda().eval()
     res = {"ppl_bf16": round(perplexity(base, blob["held"]), 4), "iters": a.iters, "reference_mask": bool(a.reference_mask), "schemes": {}}
-    for name, kw in (("W4A16 g32", dict(scheme="W4A16", group_size=32)), ("W2A16 g32", dict(scheme="W2A16G32"))):
+    all_schemes = {"W4A16 g32": dict(scheme="W4A16", group_size=32), "W2A16 g32": dict(scheme="W2A16G32"),
+                   "MXFP4": dict(scheme="MXFP4"), "NVFP4": dict(scheme="NVFP4"), "INT8 W8A8": dict(scheme="INT8")}
+    for name in [x.strip() for x in a.schemes.split(";")]:
+        kw = all_schemes[name]
         row = {}
         m = copy.deepcopy(base)
         ar0 = AutoRound(m, None, nsamples=128, seqlen=128, batch_size=8, dataset=blob["calib"], iters=a.iters, seed=a.seed, **kw)
@@ -89,6 +94,10 @@ def main():
         ar0.quantize()
         row["hip_engine"] = round(perplexity(m, blob["held"]), 4)
         row["hip_block_losses"] = [[r["stats"]["init_loss"], r["stats"]["best_loss"]] for r in ar0.records]
+        if a.skip_torch_ref:
+            res["schemes"][name] = row
+            print(name, row, file=sys.stderr)
+            continue
         # same driver, torch_ref engine
         m = copy.deepcopy(base)
         ar = AutoRound(m, None, nsamples=128, seqlen=128, batch_size=8, dataset=blob["calib"], iters=a.iters, seed=a.seed, **kw)

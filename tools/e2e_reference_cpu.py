@@ -57,8 +57,11 @@ def main():
     seeds = [int(x) for x in next(iter(ours["seeds"].values())).keys()]
     out = {"ppl_bf16_cpu": None, "ours_ppl_bf16_gpu": ours["ppl_bf16"], "iters": ours["iters"], "schemes": {}}
     os.chdir("/tmp")
-    for name, kw in (("W4A16 g32", dict(scheme="W4A16", group_size=32)), ("W2A16 g32", dict(scheme="W2A16G32")),
-                     ("W2A16 g32 asym", dict(scheme="W2A16G32", sym=False))):
+    all_schemes = {"W4A16 g32": dict(scheme="W4A16", group_size=32), "W2A16 g32": dict(scheme="W2A16G32"),
+                   "W2A16 g32 asym": dict(scheme="W2A16G32", sym=False), "MXFP4": dict(scheme="MXFP4"), "NVFP4": dict(scheme="NVFP4"),
+                   "INT8 W8A8": dict(scheme="INT8")}
+    for name in ours["seeds"]:
+        kw = all_schemes[name]
         ref = {}
         for seed in seeds:
             model = LlamaForCausalLM(cfg).to(torch.bfloat16)
