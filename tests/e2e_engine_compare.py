@@ -75,6 +75,7 @@ def main():
     res = {"ppl_bf16": round(perplexity(base, blob["held"]), 4), "iters": a.iters, "reference_mask": bool(a.reference_mask), "schemes": {}}
     all_schemes = {"W4A16 g32": dict(scheme="W4A16", group_size=32), "W2A16 g32": dict(scheme="W2A16G32"),
                    "W2A16 g32 alg_ext": dict(scheme="W2A16G32", enable_alg_ext=True), "MXFP4 alg_ext": dict(scheme="MXFP4", enable_alg_ext=True),
+                   "W4A8 g32": dict(bits=4, act_bits=8, group_size=32, act_group_size=32, sym=True),
                    "MXFP4": dict(scheme="MXFP4"), "NVFP4": dict(scheme="NVFP4"), "INT8 W8A8": dict(scheme="INT8")}
     for name in [x.strip() for x in a.schemes.split(";")]:
         kw = all_schemes[name]

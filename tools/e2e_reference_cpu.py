@@ -59,6 +59,7 @@ def main():
     os.chdir("/tmp")
     all_schemes = {"W4A16 g32": dict(scheme="W4A16", group_size=32), "W2A16 g32": dict(scheme="W2A16G32"),
                    "W2A16 g32 asym": dict(scheme="W2A16G32", sym=False), "W2A16 g32 alg_ext": dict(scheme="W2A16G32", enable_alg_ext=True), "MXFP4 alg_ext": dict(scheme="MXFP4", enable_alg_ext=True),
+                   "W4A8 g32": dict(bits=4, act_bits=8, group_size=32, act_group_size=32, sym=True),
                    "MXFP4": dict(scheme="MXFP4"), "NVFP4": dict(scheme="NVFP4"),
                    "INT8 W8A8": dict(scheme="INT8")}
     for name in ours["seeds"]:
