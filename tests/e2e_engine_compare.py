@@ -35,6 +35,13 @@ def perplexity(model, tokens, bs=32):
     return math.exp(nll / cnt)
 
 
+def _reference_mask(S, device):
+    """causal AND (key != last token), boolean in transformers >= 5, cast to bf16 by the reference's input cache"""
+    m = torch.tril(torch.ones(S, S, device=device))
+    m[:, -1] = 0
+    return m.to(torch.bfloat16).reshape(1, 1, S, S)
+
+
 def fwd(blk, x, others):
     out = blk(x, **others)
     return out[0] if isinstance(out, (tuple, list)) else out
@@ -88,7 +95,7 @@ def main():
             def cap_with_ref_mask(blocks, tokens):
                 x0, others = cap0(blocks, tokens)
                 S = x0.shape[1]
-                others["attention_mask"] = torch.tril(torch.ones(S, S, device=x0.device)).to(torch.bfloat16).reshape(1, 1, S, S)
+                others["attention_mask"] = _reference_mask(S, x0.device)
                 return x0, others
 
             ar0._capture_block0_inputs = cap_with_ref_mask
@@ -120,7 +127,7 @@ def main():
         x0, others = ar._capture_block0_inputs(blocks, tokens)
         if a.reference_mask:
             S = x0.shape[1]
-            others["attention_mask"] = torch.tril(torch.ones(S, S, device=x0.device)).to(torch.bfloat16).reshape(1, 1, S, S)
+            others["attention_mask"] = _reference_mask(S, x0.device)
         run_torch_ref(ar, blocks, x0, others, ids, a.iters, 8, True)
         row["torch_ref_engine"] = round(perplexity(m, blob["held"]), 4)
         res["schemes"][name] = row

@@ -1,0 +1,155 @@
+"""Whole-pipeline pin of the block-by-block driver flow (fp forward -> tune -> quantised-output forward -> chaining, token
+mask, seeding, best-parameter selection) against the REAL reference front door on CPU: `AutoRound(...).quantize()` of the
+reference vs the same flow written with oracle/torch_ref (what tests/e2e_engine_compare.py and the GPU driver
+`auto_round_amd.model_tuner.tune_blocks` implement), on a tiny random Llama.  Same torch ops on the same device, so the tuned
+weights must be IDENTICAL.  The reference's input cache hands the blocks the boolean causal mask cast to bf16
+(calibration/inputs.py:100-107); the restatement is given the same tensor."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import torch_ref as tr
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
+
+
+class _StubTokenizer:
+    pad_token_id = None
+    pad_token = None
+
+    def save_pretrained(self, *a, **k):
+        pass
+
+
+class _Loader:
+    batch_size = 1
+
+    def __init__(self, tokens):
+        self.tokens = tokens
+
+    def __iter__(self):
+        for r in self.tokens:
+            yield r.reshape(1, -1)
+
+
+def _tiny():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=2,
+                      vocab_size=64, max_position_embeddings=32, tie_word_embeddings=False)
+    cfg._attn_implementation = "sdpa"
+    return LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+
+
+def _fwd(blk, x, others):
+    out = blk(x, **others)
+    return out[0] if isinstance(out, (tuple, list)) else out
+
+
+@pytest.mark.parametrize("kw", [dict(scheme="W4A16", group_size=32), dict(scheme="W2A16G32", sym=False), dict(scheme="MXFP4"),
+                                dict(scheme="W2A16G32", enable_alg_ext=True), dict(scheme="NVFP4", enable_alg_ext=True)],
+                         ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext"])
+def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monkeypatch):
+    import transformers
+
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, REF):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from auto_round import AutoRound
+
+    from auto_round_amd.schemes import apply_scheme, resolve_scheme
+
+    monkeypatch.chdir(tmp_path)                      # the reference writes ./ar_work_space
+    base = _tiny()
+    tokens = torch.randint(0, 64, (8, 16), generator=torch.Generator().manual_seed(1))
+    iters, bs, S = 3, 4, 16
+
+    # --- the reference, front door to tuned weights
+    m_ref = copy.deepcopy(base)
+    ar = AutoRound(m_ref, tokenizer=_StubTokenizer(), iters=iters, nsamples=8, seqlen=S, dataset=_Loader(tokens), device_map="cpu",
+                   batch_size=bs, enable_torch_compile=False, **kw)
+    q_ref, _ = ar.quantize()
+
+    # --- the same flow with the restatement
+    m = copy.deepcopy(base)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    blocks = list(m.model.layers)
+    alg_ext = bool(kw.get("enable_alg_ext", False))
+    sch = resolve_scheme(**{k: v for k, v in kw.items() if k != "enable_alg_ext"})
+    for b in blocks:
+        apply_scheme(b, sch)
+    captured, others = [], {}
+
+    class Stop(Exception):
+        pass
+
+    def hook(mod, args, kwargs):
+        captured.append(args[0].detach())
+        if not others:
+            for k, v in kwargs.items():
+                if k not in ("hidden_states", "past_key_values", "use_cache", "cache_position"):
+                    others[k] = tuple(x[:1] for x in v) if isinstance(v, tuple) else (v[:1] if isinstance(v, torch.Tensor) and v.dim() and v.shape[0] == bs else v)
+        raise Stop
+
+    h = blocks[0].register_forward_pre_hook(hook, with_kwargs=True)
+    with torch.no_grad():
+        for b0 in range(0, 8, bs):
+            try:
+                m(input_ids=tokens[b0:b0 + bs], use_cache=False)
+            except Stop:
+                pass
+    h.remove()
+    x0 = torch.cat(captured, 0)
+    # what the reference caches: its calibrator masks the last token in the 2-D attention mask, transformers turns that into a
+    # boolean [1,1,S,S] mask (causal AND key != last), and the input cache casts it to bf16
+    ref_mask = torch.tril(torch.ones(S, S))
+    ref_mask[:, -1] = 0
+    others["attention_mask"] = ref_mask.to(torch.bfloat16).reshape(1, 1, S, S)
+    # the reference concatenates its per-sample cache entries into batch-sized tensors; a broadcast [1, ...] mask takes another
+    # CPU SDPA path whose last-bit differences are enough to move the importance matrix of the algorithm extension
+    others = {k: (tuple(t.expand(bs, *t.shape[1:]).contiguous() for t in v) if isinstance(v, tuple) else
+                  (v.expand(bs, *v.shape[1:]).contiguous() if isinstance(v, torch.Tensor) and v.dim() and v.shape[0] == 1 else v))
+              for k, v in others.items()}
+    ids = tokens.clone()
+    ids[:, -1] = -100
+
+    @torch.no_grad()
+    def forward_all(blk, x):
+        outs = []
+        for b0 in range(0, x.shape[0], bs):
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                outs.append(_fwd(blk, x[b0:b0 + bs], others))
+        return torch.cat(outs, 0)
+
+    transformers.set_seed(42)
+    fp_in, q_in = x0, None
+    for blk in blocks:
+        if alg_ext:          # the imatrix hooks fire during the reference (fp-input) forward
+            tr.collect_imatrix(blk, fp_in, others, batch_size=bs, forward=_fwd)
+        fp_out = forward_all(blk, fp_in)
+        xin = q_in if q_in is not None else fp_in
+        if str(sch.get("act_data_type", "")).startswith("nv_fp"):      # static activation scales + unified weight global scales
+            from auto_round_amd.quantizer import register_act_max_hooks
+            from auto_round_amd.wrapper import update_block_global_scale_if_needed
+
+            hooks = register_act_max_hooks(blk)                 # composer.py:430-436: collected on the quantised-input forward
+            forward_all(blk, xin)
+            for h2 in hooks:
+                h2.remove()
+            update_block_global_scale_if_needed(blk)
+        tr.tune_block(blk, xin, fp_out, others, iters=iters, batch_size=bs, forward=_fwd, input_ids=ids, alg_ext=alg_ext)
+        q_in = forward_all(blk, xin)
+        fp_in = fp_out
+
+    for (n1, p1), (n2, p2) in zip(q_ref.model.layers.named_modules(), m.model.layers.named_modules()):
+        if isinstance(p1, torch.nn.Linear):
+            assert n1 == n2
+            assert torch.equal(p1.weight.view(torch.int16), p2.weight.view(torch.int16)), n1
