@@ -157,6 +157,12 @@ class AutoRound:
         pad = getattr(self.tokenizer, "pad_token_id", None)
         if pad is not None:
             ids_for_mask[ids_for_mask == pad] = -100
+        else:                                   # llm.py:352-358: without a pad id, trailing repeats of the last token count as padding
+            for b in range(ids_for_mask.shape[0]):
+                last, j = tokens[b, -1], tokens.shape[1] - 2
+                while j >= 0 and tokens[b, j] == last:
+                    ids_for_mask[b, j] = -100
+                    j -= 1
         ids_for_mask[:, -1] = -100              # llm.py:341-360: pads and the last position do not enter the loss
         # grouped-query "sdpa" attention would silently run on the 2x slower flash kernels (attention.py)
         cfg_obj, old_attn = getattr(model, "config", None), None
