@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -37,8 +37,8 @@ SIGNATURES = {
     "ar_qdq_int_bwd_sgd": (c_int, [P, P, P, P, P, P, P, L, I, I, I, I, I, F, F, F, P, P, I, P, P, P, P, P, P]),
     "ar_mse_workspace_bytes": (c_int64, []),
     "ar_mse_loss_fwd_bwd": (c_int, [P, P, P, P, P, F, L, I, F, P, L, P, P]),
-    "ar_qdq_int_act_fwd": (c_int, [P, P, P, L, I, I, I, I, F, P]),
-    "ar_int_act_bwd": (c_int, [P, P, P, L, I, I, I, I, F, P]),
+    "ar_qdq_int_act_fwd": (c_int, [P, P, P, L, I, I, I, I, I, F, P]),
+    "ar_int_act_bwd": (c_int, [P, P, P, L, I, I, I, I, I, F, P]),
     "ar_search_int_scale": (c_int, [P, P, L, P, I, P, P, L, I, I, I, F, P]),
     "ar_outlier_loss_workspace_bytes": (c_int64, []),
     "ar_outlier_mse_loss_fwd_bwd": (c_int, [P, P, P, P, P, F, L, I, F, P, L, L, P, P]),

@@ -279,20 +279,20 @@ def search_int_scale(X, *, gs, bits, qw_row=None, groups_per_row=0, q_thresh=1e-
     return (raw, init) if want_raw else init
 
 
-def qdq_int_act_fwd(X, *, gs, bits, scale_dtype=torch.float16, q_thresh=1e-5, out=None, want_scale=False):
-    """Dynamic symmetric INT fake-quant of an activation tensor, groups of `gs` along the last dimension."""
+def qdq_int_act_fwd(X, *, gs, bits, sym=True, scale_dtype=torch.float16, q_thresh=1e-5, out=None, want_scale=False):
+    """Dynamic INT fake-quant of an activation tensor (symmetric or asymmetric), groups of `gs` along the last dimension."""
     G = X.numel() // gs
     Xq = out if out is not None else torch.empty_like(X)
     scale = torch.empty(G, dtype=scale_dtype, device=X.device) if want_scale else None
-    check(load().ar_qdq_int_act_fwd(_p(X, "X"), _p(Xq), _p(scale), G, gs, bits, dt_code(X.dtype), dt_code(scale_dtype), q_thresh,
+    check(load().ar_qdq_int_act_fwd(_p(X, "X"), _p(Xq), _p(scale), G, gs, bits, int(bool(sym)), dt_code(X.dtype), dt_code(scale_dtype), q_thresh,
                                     _stream()), "ar_qdq_int_act_fwd")
     return (Xq, scale) if want_scale else Xq
 
 
-def int_act_bwd(dXq, X, *, gs, bits, scale_dtype=torch.float16, q_thresh=1e-5, out=None):
+def int_act_bwd(dXq, X, *, gs, bits, sym=True, scale_dtype=torch.float16, q_thresh=1e-5, out=None):
     G = X.numel() // gs
     dX = out if out is not None else torch.empty_like(X)
-    check(load().ar_int_act_bwd(_p(dXq, "dXq"), _p(X, "X"), _p(dX), G, gs, bits, dt_code(X.dtype), dt_code(scale_dtype), q_thresh,
+    check(load().ar_int_act_bwd(_p(dXq, "dXq"), _p(X, "X"), _p(dX), G, gs, bits, int(bool(sym)), dt_code(X.dtype), dt_code(scale_dtype), q_thresh,
                                 _stream()), "ar_int_act_bwd")
     return dX
 

@@ -123,21 +123,21 @@ class _IntActQdqFn(torch.autograd.Function):
     arg-max).  reference: WrapperLinear._qdq_act -> quant_tensor_sym (wrapper.py:295-321, data_type/int.py:165-238)."""
 
     @staticmethod
-    def forward(ctx, x, bits, gs, scale_dtype, thresh):
+    def forward(ctx, x, bits, gs, scale_dtype, thresh, sym=True):
         xc = x.contiguous()
         ctx.save_for_backward(xc)
-        ctx.cfg = (bits, gs, scale_dtype, thresh)
-        return ops.qdq_int_act_fwd(xc.view(-1), gs=gs, bits=bits, scale_dtype=scale_dtype, q_thresh=thresh).view(x.shape)
+        ctx.cfg = (bits, gs, scale_dtype, thresh, sym)
+        return ops.qdq_int_act_fwd(xc.view(-1), gs=gs, bits=bits, sym=sym, scale_dtype=scale_dtype, q_thresh=thresh).view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         (xc,) = ctx.saved_tensors
-        bits, gs, scale_dtype, thresh = ctx.cfg
+        bits, gs, scale_dtype, thresh, sym = ctx.cfg
         dyc = dy.contiguous()
         if dyc.dtype != xc.dtype:
             dyc = dyc.to(xc.dtype)
-        dx = ops.int_act_bwd(dyc.view(-1), xc.view(-1), gs=gs, bits=bits, scale_dtype=scale_dtype, q_thresh=thresh)
-        return dx.view(xc.shape), None, None, None, None
+        dx = ops.int_act_bwd(dyc.view(-1), xc.view(-1), gs=gs, bits=bits, sym=sym, scale_dtype=scale_dtype, q_thresh=thresh)
+        return dx.view(xc.shape), None, None, None, None, None
 
 
 def act_fake_quant(x: torch.Tensor, layer) -> torch.Tensor:
@@ -146,14 +146,15 @@ def act_fake_quant(x: torch.Tensor, layer) -> torch.Tensor:
     gs = getattr(layer, "act_group_size", 0)
     gs = int(gs) if gs is not None else 0
     if is_int_dtype(adt):
-        if not bool(getattr(layer, "act_sym", True)) or not bool(getattr(layer, "act_dynamic", True)):
-            raise NotImplementedError("int activation fake-quant implements the dynamic symmetric case")
+        if getattr(layer, "act_dynamic", True) is False:
+            raise NotImplementedError("int activation fake-quant implements the dynamic case (static act_max scales: NVFP4 only)")
+        asym = getattr(layer, "act_sym", True) is False
         h = x.shape[-1]
         g = h if (gs in (-1, 0) or h < gs) else gs          # data_type/utils.py:47-48
         if g % 8 or h % g:
             raise NotImplementedError(f"act_group_size={gs} with hidden size {h}: groups must be a multiple of 8 that divides it")
         sdt = getattr(layer, "scale_dtype", torch.float16) or torch.float16
-        return _IntActQdqFn.apply(x, int(layer.act_bits), g, sdt, 1e-8 if sdt == torch.float32 else 1e-5)
+        return _IntActQdqFn.apply(x, int(layer.act_bits), g, sdt, 1e-8 if sdt == torch.float32 else 1e-5, not asym)
     if int(getattr(layer, "act_bits", 16)) != 4 or x.shape[-1] % max(gs, 1):
         raise NotImplementedError("activation fake-quant implements MXFP4 (gs 32) / NVFP4 (gs 16) and dynamic symmetric int")
     if is_mx_fp(adt) and gs == 32:

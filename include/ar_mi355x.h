@@ -107,17 +107,17 @@ int ar_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpred, float* l
                         float accum_scale, int64_t n, int act_dt, float grad_scale, const uint8_t* token_mask,
                         int64_t row_len, void* workspace, ar_stream_t stream);
 
-/* ---- dynamic symmetric INT activation fake-quant (W4A8 / W8A8-style schemes) ------------------------------------
- * replaces: quant_tensor_sym (auto_round/data_type/int.py:165-238) as called by WrapperLinear._qdq_act
+/* ---- dynamic INT activation fake-quant (W4A8 / W8A8-style schemes), sym = 1 symmetric / 0 asymmetric ---------------
+ * replaces: quant_tensor_sym / quant_tensor_asym (auto_round/data_type/int.py:165-238, :241-298) as called by WrapperLinear._qdq_act
  *           (auto_round/wrapper.py:295-321, forward :530-540) with v = 0, tensor_min/max = None and the wrapper's
  *           non-tunable act_min_scale / act_max_scale (= 1), plus the autograd backward w.r.t. the activation.
  * X / Xq / dXq / dX: [n_groups * gs] in a_dt, groups of gs consecutive elements along the hidden dimension
  * (gs % 8 == 0; per-token quantisation = gs equal to the hidden size).  scale_out [n_groups] in s_dt, optional.
  * The gradient includes the path through the dynamic scale: it is routed to the first arg-min / arg-max element of
  * each group exactly as torch's min/max backward does. */
-int ar_qdq_int_act_fwd(const void* X, void* Xq, void* scale_out, int64_t n_groups, int gs, int bits, int a_dt, int s_dt,
-                       float q_thresh, ar_stream_t stream);
-int ar_int_act_bwd(const void* dXq, const void* X, void* dX, int64_t n_groups, int gs, int bits, int a_dt, int s_dt,
+int ar_qdq_int_act_fwd(const void* X, void* Xq, void* scale_out, int64_t n_groups, int gs, int bits, int sym, int a_dt,
+                       int s_dt, float q_thresh, ar_stream_t stream);
+int ar_int_act_bwd(const void* dXq, const void* X, void* dX, int64_t n_groups, int gs, int bits, int sym, int a_dt, int s_dt,
                    float q_thresh, ar_stream_t stream);
 
 /* int-sym init-scale search of the algorithm extension.

@@ -1040,3 +1040,91 @@ void oracle_int_act_bwd(const void* dXq, const void* X, int64_t G, int gs, int b
         store_from_f32(dX, i1, a_dt, load_as_f32(dX, i1, a_dt) + dmax);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * dynamic ASYMMETRIC INT activation fake-quant, forward and input gradient
+ * reference: quant_tensor_asym (auto_round/data_type/int.py:241-298) under WrapperLinear._qdq_act, v = 0, dynamic range,
+ *            0-dim act_min_scale / act_max_scale.  Range arithmetic in the activation dtype, zero point in fp32:
+ *   wmin = min(min x, 0), wmax = max(max x, 0);  s = max( s_dt( a_dt( a_dt(wmax - wmin) / maxq ) ), t );  zp = rint( (-wmin) / s )
+ *   out = a_dt( s * (clamp(round_ste(x/s) + zp, 0, maxq) - zp) )
+ * backward:  e_k = g_k*s, dy_k = [inside] e_k, dx_k = a_dt(dy_k / s);  dzp = sum(dy) - sum(e);
+ *   ds = s_dt( s_dt(c1 + c2) + c3 ), c3 = s_dt( -dzp * ((-wmin/s)/s) ), thresh mask;  d = a_dt( a_dt(ds) / maxq )
+ *   d wmax = d;  d wmin = a_dt( (-d) + (-a_dt(dzp / s)) );  clamp masks (min x <= 0, max x >= 0); scatter to first arg-min / arg-max.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float s, s_raw, wmin, wmax, zp, xmin, xmax; int imin, imax; } actqa_t;
+static void act_group_asym(const void* X, int64_t base, int gs, int a_dt, int s_dt, int bits, float q_thresh, actqa_t* q) {
+    float mn = load_as_f32(X, base, a_dt), mx = mn;
+    q->imin = 0; q->imax = 0;
+    for (int k = 1; k < gs; ++k) {
+        const float x = load_as_f32(X, base + k, a_dt);
+        if (x < mn) { mn = x; q->imin = k; }
+        if (x > mx) { mx = x; q->imax = k; }
+    }
+    q->xmin = mn; q->xmax = mx;
+    q->wmin = mn < 0.f ? mn : 0.f; q->wmax = mx > 0.f ? mx : 0.f;
+    const float maxq = (float)((1 << bits) - 1);
+    q->s_raw = rnd(s_dt, rnd(a_dt, rnd(a_dt, q->wmax - q->wmin) / maxq));
+    const float t = rnd(s_dt, q_thresh);
+    q->s = q->s_raw < t ? t : q->s_raw;
+    q->zp = nearbyintf((-q->wmin) / q->s);
+}
+void oracle_int_act_asym_fwd(const void* X, int64_t G, int gs, int bits, int a_dt, int s_dt, float q_thresh, void* Xq, void* scale,
+                             float* zp) {
+    const int x_dt = promote(a_dt, s_dt);
+    const float maxq = (float)((1 << bits) - 1);
+    for (int64_t g = 0; g < G; ++g) {
+        actqa_t q;
+        act_group_asym(X, g * gs, gs, a_dt, s_dt, bits, q_thresh, &q);
+        if (scale) store_from_f32(scale, g, s_dt, q.s);
+        if (zp) zp[g] = q.zp;
+        for (int k = 0; k < gs; ++k) {
+            const float x = load_as_f32(X, g * gs + k, a_dt);
+            const float r = round_ste_value(rnd(x_dt, x / q.s) + 0.f);
+            store_from_f32(Xq, g * gs + k, a_dt, q.s * (clampf(r + q.zp, 0.f, maxq) - q.zp));
+        }
+    }
+}
+void oracle_int_act_asym_bwd(const void* dXq, const void* X, int64_t G, int gs, int bits, int a_dt, int s_dt, float q_thresh,
+                             void* dX) {
+    const int x_dt = promote(a_dt, s_dt);
+    const float maxq = (float)((1 << bits) - 1);
+    for (int64_t g = 0; g < G; ++g) {
+        actqa_t q;
+        act_group_asym(X, g * gs, gs, a_dt, s_dt, bits, q_thresh, &q);
+        double acc1 = 0.0, acc2 = 0.0, acc_e = 0.0, acc_dy = 0.0;
+        for (int k = 0; k < gs; ++k) {
+            const int64_t i = g * gs + k;
+            const float gk = load_as_f32(dXq, i, a_dt), x = load_as_f32(X, i, a_dt);
+            const float xs = rnd(x_dt, x / q.s);
+            const float r = round_ste_value(xs + 0.f);
+            const float tq = r + q.zp;
+            const float qq = clampf(tq, 0.f, maxq) - q.zp;
+            const int inside = (tq >= 0.f && tq <= maxq);
+            const float e = rnd(x_dt, gk * q.s);
+            const float dy = inside ? e : 0.f;
+            volatile float zero = 0.f;
+            store_from_f32(dX, i, a_dt, rnd(a_dt, rnd(x_dt, dy / q.s)) + zero);
+            acc1 += (double)rnd(x_dt, gk * qq);
+            acc2 += (double)rnd(x_dt, (-dy) * rnd(x_dt, xs / q.s));
+            acc_e += (double)(-e);
+            acc_dy += (double)dy;
+        }
+        const float c1 = rnd(s_dt, rnd(x_dt, (float)acc1));
+        const float c2 = rnd(s_dt, rnd(x_dt, (float)acc2));
+        float ds_c = rnd(s_dt, c1 + c2);
+        const float dzp = (float)acc_e + (float)acc_dy;
+        const float u_over_s = ((-q.wmin) / q.s) / q.s;
+        const float c3 = rnd(s_dt, (-dzp) * u_over_s);
+        ds_c = rnd(s_dt, ds_c + c3);
+        const float t = rnd(s_dt, q_thresh);
+        const float ds = (q.s_raw >= t) ? ds_c : 0.f;
+        const float d = rnd(a_dt, rnd(a_dt, ds) / maxq);
+        const float dneg = rnd(a_dt, dzp / q.s);                 /* grad of (-wmin) from the zero-point path, cast to a_dt */
+        const float dwmin = rnd(a_dt, (-d) + (-dneg));
+        const float dmin = (q.xmin <= 0.f) ? dwmin : 0.f;
+        const float dmax = (q.xmax >= 0.f) ? d : 0.f;
+        const int64_t i0 = g * gs + q.imin, i1 = g * gs + q.imax;
+        store_from_f32(dX, i0, a_dt, load_as_f32(dX, i0, a_dt) + dmin);
+        store_from_f32(dX, i1, a_dt, load_as_f32(dX, i1, a_dt) + dmax);
+    }
+}

@@ -291,3 +291,17 @@ def int_act_bwd(dXq, X, G, gs, bits, a_dt=DT_BF16, s_dt=DT_F16, q_thresh=1e-5):
     dX = np.empty(G * gs, dtype=np_dtype(a_dt))
     lib().oracle_int_act_bwd(_p(dXq), _p(X), ctypes.c_int64(G), gs, bits, a_dt, s_dt, _f(q_thresh), _p(dX))
     return dX
+
+
+def int_act_asym_fwd(X, G, gs, bits, a_dt=DT_BF16, s_dt=DT_F16, q_thresh=1e-5):
+    Xq = np.empty(G * gs, dtype=np_dtype(a_dt))
+    scale = np.empty(G, dtype=np_dtype(s_dt))
+    zp = np.empty(G, dtype=np.float32)
+    lib().oracle_int_act_asym_fwd(_p(X), ctypes.c_int64(G), gs, bits, a_dt, s_dt, _f(q_thresh), _p(Xq), _p(scale), _p(zp))
+    return Xq, scale, zp
+
+
+def int_act_asym_bwd(dXq, X, G, gs, bits, a_dt=DT_BF16, s_dt=DT_F16, q_thresh=1e-5):
+    dX = np.empty(G * gs, dtype=np_dtype(a_dt))
+    lib().oracle_int_act_asym_bwd(_p(dXq), _p(X), ctypes.c_int64(G), gs, bits, a_dt, s_dt, _f(q_thresh), _p(dX))
+    return dX

@@ -253,13 +253,29 @@ def qdq_int_act_sym(x, bits, gs, scale_dtype=torch.float16, thresh=1e-5):
     return (s * q).to(x.dtype).reshape(x.shape), s
 
 
+def qdq_int_act_asym(x, bits, gs, scale_dtype=torch.float16, thresh=1e-5):
+    """Dynamic asymmetric INT fake-quant of an activation (quant_tensor_asym with v=0, tensor_min/max=None, 0-dim min/max
+    scale; data_type/int.py:241-298): range arithmetic in the activation dtype, zero point in fp32."""
+    gs = x.shape[-1] if (gs == -1 or x.shape[-1] < gs) else gs
+    t = x.reshape(-1, gs)
+    maxq = 2 ** bits - 1
+    one = torch.tensor(1.0, device=x.device)
+    wmin = torch.clamp(t.min(-1)[0], max=0) * one
+    wmax = torch.clamp(t.max(-1)[0], min=0) * one
+    s = torch.clamp(((wmax - wmin) / maxq).to(scale_dtype), min=thresh)
+    zp = _ste(torch.round, -wmin / s).unsqueeze(-1)
+    s = s.unsqueeze(-1)
+    q = torch.clamp(_ste(torch.round, t / s + 0) + zp, 0, maxq)
+    return (s * (q - zp)).to(x.dtype).reshape(x.shape), s, zp
+
+
 def act_fake_quant(x, layer):
-    """WrapperLinear._qdq_act for the fp4 and symmetric-int activation schemes (wrapper.py:295-321)."""
+    """WrapperLinear._qdq_act for the fp4 and dynamic int activation schemes (wrapper.py:295-321)."""
     adt = str(getattr(layer, "act_data_type", ""))
     one = torch.tensor(1.0, device=x.device)
     if adt.startswith("int"):
         if not bool(getattr(layer, "act_sym", True)):
-            raise NotImplementedError("asymmetric int activations")
+            return qdq_int_act_asym(x, int(layer.act_bits), int(layer.act_group_size), getattr(layer, "scale_dtype", torch.float16))[0]
         return qdq_int_act_sym(x, int(layer.act_bits), int(layer.act_group_size), getattr(layer, "scale_dtype", torch.float16))[0]
     if adt.startswith("mx_fp"):
         return qdq_mxfp4(x, int(layer.act_group_size), 0, one)[0]

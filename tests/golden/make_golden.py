@@ -505,12 +505,13 @@ if __name__ == "__main__" and ("stepv2" in sys.argv[1:] or not sys.argv[1:]):
 def gen_int_act():
     """Dynamic symmetric INT activation fake-quant (W4A8-style schemes): quant_tensor_sym on the activation with v=0 and
     the wrapper's non-tunable 0-dim act_min_scale / act_max_scale, forward + autograd backward w.r.t. the input."""
-    from auto_round.data_type.int import quant_tensor_sym
+    from auto_round.data_type.int import quant_tensor_asym, quant_tensor_sym
 
     rec = {}
     for tag, nbits, gs, dt, hidden in (("a8g32", 8, 32, torch.bfloat16, 128), ("a8g128", 8, 128, torch.bfloat16, 256),
                                        ("a4g32", 4, 32, torch.bfloat16, 128), ("a8g32_f16", 8, 32, torch.float16, 128),
-                                       ("a8pt", 8, -1, torch.bfloat16, 256)):
+                                       ("a8pt", 8, -1, torch.bfloat16, 256), ("asym_a8g32", 8, 32, torch.bfloat16, 128),
+                                       ("asym_a4g128", 4, 128, torch.bfloat16, 256), ("asym_a8pt_f16", 8, -1, torch.float16, 256)):
         g = torch.Generator().manual_seed(31 + nbits + max(gs, 0))
         x = (torch.randn(3, 7, hidden, generator=g) * 1.7)
         x[0, 0, :32] = 0.0                       # all-zero group
@@ -521,8 +522,11 @@ def gen_int_act():
         x[1, 0, :32] *= 1e-7                     # below the scale threshold
         x = x.to(dt).requires_grad_(True)
         one = torch.tensor(1.0)
-        xq, scale, _ = quant_tensor_sym(x, bits=nbits, group_size=gs, v=0, min_scale=one.clone(), max_scale=one.clone(),
-                                        scale_dtype=torch.float16, tensor_max=None, q_scale_thresh=1e-5)
+        fn = quant_tensor_asym if tag.startswith("asym") else quant_tensor_sym
+        xq, scale, zp = fn(x, bits=nbits, group_size=gs, v=0, min_scale=one.clone(), max_scale=one.clone(),
+                           scale_dtype=torch.float16, tensor_max=None, q_scale_thresh=1e-5)
+        if tag.startswith("asym"):
+            rec[f"{tag}_zp"] = zp.detach().reshape(-1).float().numpy()
         dy = (torch.randn(x.shape, generator=g) * 1e-2).to(dt)
         xq.backward(dy)
         rec.update({f"{tag}_x": bits(x), f"{tag}_xq": bits(xq), f"{tag}_scale": bits(scale.reshape(-1)), f"{tag}_dy": bits(dy),

@@ -697,8 +697,8 @@ def test_data_parallel_block_tuning_two_ranks_one_gpu(tmp_path):
     assert np.mean(same) > 0.9, same
 
 
-@pytest.mark.parametrize("act_gs", [32, -1])
-def test_w4a8_int_activation_scheme_vs_torch_ref(act_gs):
+@pytest.mark.parametrize("act_gs,act_sym", [(32, True), (-1, True), (32, False)])
+def test_w4a8_int_activation_scheme_vs_torch_ref(act_gs, act_sym):
     """W4A8 (the reference's own GPU smoke configuration, test_sign_sgd_pipeline.py:59-82: bits=4, act_bits=8,
     act_group_size=32, sym): int activation fake-quant inside the tuning loop, WrapperWALayer after unwrapping."""
     from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
@@ -708,7 +708,7 @@ def test_w4a8_int_activation_scheme_vs_torch_ref(act_gs):
     layer, rope, cfg = make_layer("llama", 4, 32, True, seed=6)
     for m in layer.modules():
         if isinstance(m, torch.nn.Linear):
-            m.act_bits, m.act_group_size, m.act_sym, m.act_dynamic, m.act_data_type = 8, act_gs, True, True, "int"
+            m.act_bits, m.act_group_size, m.act_sym, m.act_dynamic, m.act_data_type = 8, act_gs, act_sym, True, "int"
     X, others = make_data(rope, cfg)
     Y = targets(layer, X, others)
     iters, bs = 4, 4

@@ -357,3 +357,15 @@ def test_int_activation_restatement_equals_reference_golden(tag):
     xq.backward(orc.from_bits(z[tag + "_dy"], dt))
     assert np.array_equal(orc.to_bits(xq), z[tag + "_xq"]) and np.array_equal(orc.to_bits(s.reshape(-1)), z[tag + "_scale"])
     assert np.array_equal(orc.to_bits(x.grad), z[tag + "_dx"])
+
+
+@pytest.mark.parametrize("tag", ("asym_a8g32", "asym_a4g128", "asym_a8pt_f16"))
+def test_asymmetric_int_activation_restatement_equals_reference_golden(tag):
+    z = np.load(os.path.join(GOLDEN, "int_act.npz"))
+    nb, gs, hidden = [int(v) for v in z[tag + "_meta"]]
+    dt = orc.DT_F16 if tag.endswith("f16") else orc.DT_BF16
+    x = orc.from_bits(z[tag + "_x"], dt).requires_grad_(True)
+    xq, s, zp = tr.qdq_int_act_asym(x, nb, gs)
+    xq.backward(orc.from_bits(z[tag + "_dy"], dt))
+    assert np.array_equal(orc.to_bits(xq), z[tag + "_xq"]) and np.array_equal(zp.detach().reshape(-1).numpy(), z[tag + "_zp"])
+    assert np.array_equal(orc.to_bits(x.grad), z[tag + "_dx"])
