@@ -402,7 +402,7 @@ extern "C" int ar_pack_awq(const void* Wq, const void* scale, const float* zp_te
     return launch_status();
 }
 
-extern "C" int ar_abi_version(void) { return 8; }
+extern "C" int ar_abi_version(void) { return AR_ABI_VERSION; }
 
 extern "C" const char* ar_error_string(int code) {
     if (code == AR_OK) return "ok";

@@ -33,7 +33,8 @@ typedef void* ar_stream_t; /* hipStream_t */
 enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
-/* ABI version of this header; bump on any signature change. */
+/* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
+#define AR_ABI_VERSION 8
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);

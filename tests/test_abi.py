@@ -76,6 +76,9 @@ def test_abi_version_and_error_strings(built_lib):
     from auto_round_amd import _lib
 
     assert built_lib.ar_abi_version() == _lib.ABI_VERSION
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'ar_mi355x.h')).read()
+    assert int(re.search(r'#define AR_ABI_VERSION (\d+)', hdr).group(1)) == _lib.ABI_VERSION      # header, library and binding agree
     assert built_lib.ar_error_string(0) == b"ok"
     assert b"not supported" in built_lib.ar_error_string(-1)
     assert built_lib.ar_mse_workspace_bytes() > 0
