@@ -103,6 +103,8 @@ __device__ __forceinline__ void select_from_top(const uint32_t* hist, int nbins,
     bin = 0; above = cum;
 }
 
+__global__ void k_zero_u32(uint32_t* __restrict__ p) { p[threadIdx.x] = 0u; }
+
 template <int ADT, int LEVEL>
 __global__ __launch_bounds__(kTPB) void k_outlier_hist(const void* __restrict__ pred, const void* __restrict__ ref,
                                                        int64_t n_chunks, int64_t chunks_per_block,
@@ -452,8 +454,10 @@ extern "C" int ar_outlier_mse_loss_fwd_bwd(const void* pred, const void* ref, vo
     uint32_t* hist1 = (uint32_t*)(partials + kMseMaxBlocks);
     uint32_t* hist2 = hist1 + 256;
     uint32_t* bh2 = hist2 + 128;
-    int rc = (int)hipMemsetAsync(hist1, 0, (256 + 128) * sizeof(uint32_t), st);
-    if (rc) return rc;
+    // a kernel rather than hipMemsetAsync: memset nodes of a captured hipGraph did not re-execute on replay with ROCm 7.2
+    // (tests/test_gpu_kernels.py::test_kernels_are_hip_graph_capturable...), a kernel node always does
+    hipLaunchKernelGGL(k_zero_u32, 1, 256 + 128, 0, st, hist1);
+    int rc = 0;
     const int64_t n_chunks = n / kEPT;
     int64_t want = (n_chunks + kTPB - 1) / kTPB;
     int grid = (int)(want < 1 ? 1 : (want > kMseMaxBlocks ? kMseMaxBlocks : want));
