@@ -50,8 +50,8 @@ def make_weight(rows, cols, gs, dtype, seed, heavy_tail=True):
     g = torch.Generator().manual_seed(seed)
     w = torch.randn(rows, cols, generator=g) * 0.02
     if heavy_tail:
+        torch.manual_seed(seed)              # StudentT samples from the GLOBAL generator: seed it first (reproducible fixtures)
         t = torch.distributions.StudentT(4.0).sample((rows, cols)) * 0.02
-        torch.manual_seed(seed)
         w = torch.where(torch.rand(rows, cols, generator=g) < 0.3, t, w)
     wg = w.view(-1, gs)
     wg[0] = 0.0                              # all-zero group  -> scale threshold path
