@@ -86,7 +86,7 @@ __device__ __forceinline__ void fp4_group_scale(int mode, float amax, float Ms, 
 }
 
 #ifndef AR_FP4_FWD_UNROLL
-#define AR_FP4_FWD_UNROLL 4
+#define AR_FP4_FWD_UNROLL 1
 #endif
 #ifndef AR_FP4_BWD_UNROLL
 #define AR_FP4_BWD_UNROLL 2

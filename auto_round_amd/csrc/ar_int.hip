@@ -758,7 +758,7 @@ extern "C" int ar_group_absmax(const void* W, float* absmax, float* tensor_absma
 #define AR_INT_FLAT 1
 #endif
 #ifndef AR_FLAT_FWD_UNROLL
-#define AR_FLAT_FWD_UNROLL 4
+#define AR_FLAT_FWD_UNROLL 1
 #endif
 #ifndef AR_FLAT_BWD_UNROLL
 #define AR_FLAT_BWD_UNROLL 2
