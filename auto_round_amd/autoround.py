@@ -71,6 +71,9 @@ class AutoRound:
         self.nsamples, self.seqlen, self.seed = nsamples, seqlen, seed
         self.dataset = dataset
         self.device = torch.device("cuda", device_map) if isinstance(device_map, int) else torch.device(device_map)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError(f"AutoRound (MI355X path) needs a HIP device, got device_map={device_map!r} with "
+                               f"torch.cuda.is_available()={torch.cuda.is_available()}; there is no CPU fallback")
         self.enable_alg_ext = enable_alg_ext
         amp_dtype = next(model.parameters()).dtype
         if amp_dtype not in (torch.bfloat16, torch.float16):

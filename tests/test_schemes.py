@@ -71,3 +71,14 @@ def test_apply_scheme_and_block_discovery():
     assert b.q_proj.bits == 4 and b.q_proj.group_size == 32 and b.q_proj.sym and b.q_proj.scale_dtype == torch.float16
     assert b.odd.bits == 16 and b.mlp.gate.bits == 16 and b.mlp.up.bits == 8
     assert cfg["mlp.up"]["bits"] == 8 and cfg["odd"]["bits"] == 16 and set(cfg) == {"q_proj", "odd", "mlp.gate", "mlp.up"}
+
+
+def test_front_door_fails_loudly_without_a_hip_device():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from auto_round_amd.autoround import AutoRound
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        AutoRound(torch.nn.Linear(32, 32), None, dataset=torch.zeros(1, 8, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        AutoRound(torch.nn.Linear(32, 32), None, device_map="cpu", dataset=torch.zeros(1, 8, dtype=torch.long))
