@@ -82,3 +82,24 @@ def test_front_door_fails_loudly_without_a_hip_device():
         AutoRound(torch.nn.Linear(32, 32), None, dataset=torch.zeros(1, 8, dtype=torch.long))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         AutoRound(torch.nn.Linear(32, 32), None, device_map="cpu", dataset=torch.zeros(1, 8, dtype=torch.long))
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
+def test_learning_rate_rules_equal_the_reference_config():
+    """auto lr = 1/iters, 2/iters for <= 3 bits at >= 1000 iterations; explicit lr wins; minmax_lr falls back to lr
+    (sign_round/config.py:110-140)."""
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, REF):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from auto_round.algorithms.quantization.sign_round.config import SignRoundConfig as RefCfg
+
+    from auto_round_amd.quantizer import SignRoundConfig
+
+    for iters in (1, 50, 200, 999, 1000, 2000):
+        for kw in ({}, {"lr": 0.003}, {"minmax_lr": 0.002}, {"lr": 0.004, "minmax_lr": 0.001}):
+            ref, mine = RefCfg(iters=iters, **kw), SignRoundConfig(iters=iters, **kw)
+            for bits in (2, 3, 4, 8, None):
+                assert ref.compute_lr(bits) == mine.compute_lr(bits), (iters, kw, bits)
+                assert ref.compute_minmax_lr(bits) == mine.compute_minmax_lr(bits), (iters, kw, bits)
