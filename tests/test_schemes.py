@@ -103,3 +103,51 @@ def test_learning_rate_rules_equal_the_reference_config():
             for bits in (2, 3, 4, 8, None):
                 assert ref.compute_lr(bits) == mine.compute_lr(bits), (iters, kw, bits)
                 assert ref.compute_minmax_lr(bits) == mine.compute_minmax_lr(bits), (iters, kw, bits)
+
+
+def _ref_paths():
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, REF):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
+def test_host_helpers_equal_the_reference_helpers():
+    """check_need_act_calibration (truth table), get_block_names (Llama, Mixtral) and the NVFP4 block-wise global-scale
+    unification (q/k/v and gate/up share the minimum) against the reference's own functions."""
+    _ref_paths()
+    from auto_round.compressors.utils import check_need_act_calibration as ref_need
+    from auto_round.data_type.utils import update_block_global_scale_if_needed as ref_update
+    from auto_round.utils import get_block_names as ref_blocks
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from auto_round_amd.autoround import get_block_names
+    from auto_round_amd.quantizer import check_need_act_calibration
+    from auto_round_amd.schemes import apply_scheme, resolve_scheme
+    from auto_round_amd.wrapper import update_block_global_scale_if_needed
+
+    for dyn in (True, False, None):
+        for adt in (None, "int", "mx_fp", "nv_fp4_with_static_gs", "fp8_static"):
+            for bits in (4, 8, 16, None):
+                assert check_need_act_calibration(dyn, adt, bits) == ref_need(dyn, adt, bits), (dyn, adt, bits)
+
+    torch.manual_seed(0)
+    m = LlamaForCausalLM(LlamaConfig(hidden_size=64, intermediate_size=128, num_attention_heads=4, num_key_value_heads=2,
+                                     num_hidden_layers=3, vocab_size=64)).to(torch.bfloat16)
+    assert get_block_names(m) == ref_blocks(m)
+
+    import copy
+
+    blk_a, blk_b = copy.deepcopy(m.model.layers[0]), copy.deepcopy(m.model.layers[0])
+    sch = resolve_scheme("NVFP4")
+    apply_scheme(blk_a, sch)
+    apply_scheme(blk_b, sch)
+    update_block_global_scale_if_needed(blk_a)
+    ref_update(blk_b, "nv_fp", 16)
+    for (n, a), (_, b) in zip(blk_a.named_modules(), blk_b.named_modules()):
+        if isinstance(a, torch.nn.Linear):
+            assert torch.equal(a.weight_global_scale.reshape(-1).float(), b.weight_global_scale.reshape(-1).float()), n
+    qa, ka, va = blk_a.self_attn.q_proj, blk_a.self_attn.k_proj, blk_a.self_attn.v_proj
+    assert float(qa.weight_global_scale) == float(ka.weight_global_scale) == float(va.weight_global_scale)
