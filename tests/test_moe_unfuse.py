@@ -49,3 +49,31 @@ def test_dense_models_are_left_alone():
     m = LlamaForCausalLM(LlamaConfig(hidden_size=32, intermediate_size=64, num_attention_heads=2, num_key_value_heads=2,
                                      num_hidden_layers=1, vocab_size=32))
     assert unfuse_moe_experts(m) == []
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/auto_round"), reason="reference tree not present (GPU box)")
+def test_unfusing_equals_the_reference_preparation():
+    """Same state-dict keys, same weights, bit-identical logits as the reference's prepare_model_for_moe_quantization
+    (auto_round/modeling/fused_moe/moe_experts_interface.py) on a transformers Mixtral."""
+    import copy
+    import os
+    import sys
+
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, "/root/reference"):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from auto_round.modeling.fused_moe.moe_experts_interface import prepare_model_for_moe_quantization
+
+    from auto_round_amd.moe_unfuse import unfuse_moe_experts
+
+    base = tiny_mixtral()
+    a, b = copy.deepcopy(base), copy.deepcopy(base)
+    prepare_model_for_moe_quantization(a)
+    unfuse_moe_experts(b)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert set(sa) == set(sb) and all(torch.equal(sa[k], sb[k]) for k in sa)
+    tok = torch.randint(0, 96, (2, 16), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        assert torch.equal(a(input_ids=tok).logits, b(input_ids=tok).logits)
