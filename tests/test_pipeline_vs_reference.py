@@ -46,14 +46,26 @@ def _tiny():
     return LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
 
 
+def _tiny_moe():
+    from transformers import MixtralConfig, MixtralForCausalLM
+
+    torch.manual_seed(0)
+    cfg = MixtralConfig(hidden_size=64, intermediate_size=128, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=2,
+                        vocab_size=64, max_position_embeddings=32, num_local_experts=4, num_experts_per_tok=2,
+                        tie_word_embeddings=False)
+    cfg._attn_implementation = "sdpa"
+    return MixtralForCausalLM(cfg).to(torch.bfloat16).eval()
+
+
 def _fwd(blk, x, others):
     out = blk(x, **others)
     return out[0] if isinstance(out, (tuple, list)) else out
 
 
 @pytest.mark.parametrize("kw", [dict(scheme="W4A16", group_size=32), dict(scheme="W2A16G32", sym=False), dict(scheme="MXFP4"),
-                                dict(scheme="W2A16G32", enable_alg_ext=True), dict(scheme="NVFP4", enable_alg_ext=True)],
-                         ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext"])
+                                dict(scheme="W2A16G32", enable_alg_ext=True), dict(scheme="NVFP4", enable_alg_ext=True),
+                                dict(scheme="W4A16", group_size=32, moe=True)],
+                         ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32"])
 def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monkeypatch):
     import transformers
 
@@ -67,7 +79,9 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
     from auto_round_amd.schemes import apply_scheme, resolve_scheme
 
     monkeypatch.chdir(tmp_path)                      # the reference writes ./ar_work_space
-    base = _tiny()
+    kw = dict(kw)
+    moe = kw.pop("moe", False)
+    base = _tiny_moe() if moe else _tiny()
     tokens = torch.randint(0, 64, (8, 16), generator=torch.Generator().manual_seed(1))
     iters, bs, S = 3, 4, 16
 
@@ -79,6 +93,10 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
 
     # --- the same flow with the restatement
     m = copy.deepcopy(base)
+    if moe:      # the reference unfuses transformers' 3-D expert parameters itself; here the product's preparation step does
+        from auto_round_amd.moe_unfuse import unfuse_moe_experts
+
+        assert len(unfuse_moe_experts(m)) == 2
     for p in m.parameters():
         p.requires_grad_(False)
     blocks = list(m.model.layers)
@@ -149,7 +167,8 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
         q_in = forward_all(blk, xin)
         fp_in = fp_out
 
-    for (n1, p1), (n2, p2) in zip(q_ref.model.layers.named_modules(), m.model.layers.named_modules()):
-        if isinstance(p1, torch.nn.Linear):
-            assert n1 == n2
-            assert torch.equal(p1.weight.view(torch.int16), p2.weight.view(torch.int16)), n1
+    lin_ref = {n: p for n, p in q_ref.model.layers.named_modules() if isinstance(p, torch.nn.Linear)}
+    lin_mine = {n: p for n, p in m.model.layers.named_modules() if isinstance(p, torch.nn.Linear)}
+    assert set(lin_ref) == set(lin_mine) and len(lin_ref) >= 14
+    for n, p1 in lin_ref.items():
+        assert torch.equal(p1.weight.view(torch.int16), lin_mine[n].weight.view(torch.int16)), n
