@@ -46,12 +46,12 @@ def _tiny():
     return LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
 
 
-def _tiny_moe():
+def _tiny_moe(experts=4, top_k=2):
     from transformers import MixtralConfig, MixtralForCausalLM
 
     torch.manual_seed(0)
     cfg = MixtralConfig(hidden_size=64, intermediate_size=128, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=2,
-                        vocab_size=64, max_position_embeddings=32, num_local_experts=4, num_experts_per_tok=2,
+                        vocab_size=64, max_position_embeddings=32, num_local_experts=experts, num_experts_per_tok=top_k,
                         tie_word_embeddings=False)
     cfg._attn_implementation = "sdpa"
     return MixtralForCausalLM(cfg).to(torch.bfloat16).eval()
@@ -64,8 +64,9 @@ def _fwd(blk, x, others):
 
 @pytest.mark.parametrize("kw", [dict(scheme="W4A16", group_size=32), dict(scheme="W2A16G32", sym=False), dict(scheme="MXFP4"),
                                 dict(scheme="W2A16G32", enable_alg_ext=True), dict(scheme="NVFP4", enable_alg_ext=True),
-                                dict(scheme="W4A16", group_size=32, moe=True)],
-                         ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32"])
+                                dict(scheme="W4A16", group_size=32, moe=True), dict(scheme="NVFP4", moe=(24, 1))],
+                         ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32",
+                              "mixtral_nvfp4_idle_experts"])
 def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monkeypatch):
     import transformers
 
@@ -81,7 +82,7 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
     monkeypatch.chdir(tmp_path)                      # the reference writes ./ar_work_space
     kw = dict(kw)
     moe = kw.pop("moe", False)
-    base = _tiny_moe() if moe else _tiny()
+    base = (_tiny_moe(*moe) if isinstance(moe, tuple) else _tiny_moe()) if moe else _tiny()
     tokens = torch.randint(0, 64, (8, 16), generator=torch.Generator().manual_seed(1))
     iters, bs, S = 3, 4, 16
 
@@ -148,6 +149,7 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
         return torch.cat(outs, 0)
 
     transformers.set_seed(42)
+    n_filled = []
     fp_in, q_in = x0, None
     for blk in blocks:
         if alg_ext:          # the imatrix hooks fire during the reference (fp-input) forward
@@ -162,6 +164,10 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
             forward_all(blk, xin)
             for h2 in hooks:
                 h2.remove()
+            if moe:          # experts that saw no calibration token inherit their siblings' maximum
+                from auto_round_amd.quantizer import set_amax_for_uncalibrated_experts
+
+                n_filled.append(set_amax_for_uncalibrated_experts(blk))
             update_block_global_scale_if_needed(blk)
         tr.tune_block(blk, xin, fp_out, others, iters=iters, batch_size=bs, forward=_fwd, input_ids=ids, alg_ext=alg_ext)
         q_in = forward_all(blk, xin)
@@ -170,5 +176,7 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
     lin_ref = {n: p for n, p in q_ref.model.layers.named_modules() if isinstance(p, torch.nn.Linear)}
     lin_mine = {n: p for n, p in m.model.layers.named_modules() if isinstance(p, torch.nn.Linear)}
     assert set(lin_ref) == set(lin_mine) and len(lin_ref) >= 14
+    if isinstance(moe, tuple):
+        assert sum(n_filled) > 0, "the case is meant to contain experts without calibration tokens"
     for n, p1 in lin_ref.items():
         assert torch.equal(p1.weight.view(torch.int16), lin_mine[n].weight.view(torch.int16)), n
