@@ -139,3 +139,54 @@ def test_autoround_front_door_on_a_hf_mixtral_with_fused_experts(tmp_path, schem
     with torch.no_grad():
         logits = qmodel(input_ids=tokens[:2].cuda()).logits
     assert bool(torch.isfinite(logits).all())
+
+
+@pytest.mark.parametrize("kw", [dict(scheme="W4A16", group_size=32), dict(scheme="W2A16G32", enable_alg_ext=True),
+                                dict(scheme="NVFP4"), dict(scheme="W4A16", group_size=32, moe=True)],
+                         ids=["w4g32", "w2g32_alg_ext", "nvfp4", "mixtral_w4g32"])
+def test_front_door_follows_the_pinned_block_flow(kw):
+    """tests/pipeline_flow.py is pinned bit for bit against the reference's AutoRound.quantize() on CPU
+    (tests/test_pipeline_vs_reference.py).  Here the same flow runs on the GPU with the torch restatement as the engine, next
+    to the product's front door with the HIP engine: identical iteration-0 loss of every block (same inputs, same chaining,
+    same calibration statistics), matching final losses, and near-identical tuned weights."""
+    import copy
+
+    from auto_round_amd.autoround import AutoRound
+    from auto_round_amd.moe_unfuse import unfuse_moe_experts
+    from auto_round_amd.schemes import apply_scheme, resolve_scheme
+    from pipeline_flow import run_flow
+    from test_moe_unfuse import tiny_mixtral
+
+    kw = dict(kw)
+    moe = kw.pop("moe", False)
+    base = (tiny_mixtral(layers=2, hidden=128, ffn=256, experts=4).to(torch.bfloat16) if moe else tiny_llama(vocab=96)).cuda()
+    tokens = torch.randint(0, 96, (8, 32), generator=torch.Generator().manual_seed(4))
+    iters, bs = 4, 4
+    alg_ext = bool(kw.get("enable_alg_ext", False))
+
+    m_flow = copy.deepcopy(base)
+    if moe:
+        unfuse_moe_experts(m_flow)
+    for p in m_flow.parameters():
+        p.requires_grad_(False)
+    blocks = list(m_flow.model.layers)
+    sch = resolve_scheme(**{k: v for k, v in kw.items() if k != "enable_alg_ext"})
+    for b in blocks:
+        apply_scheme(b, sch)
+    m_flow.config._attn_implementation = "sdpa"
+    stats_flow, _ = run_flow(m_flow, blocks, tokens, sch, iters=iters, bs=bs, alg_ext=alg_ext, moe=bool(moe))
+
+    m_hip = copy.deepcopy(base)
+    ar = AutoRound(m_hip, None, iters=iters, nsamples=8, seqlen=32, batch_size=bs, dataset=tokens, **kw)
+    ar.config.sdpa_backend = "auto"             # same attention kernels as the flow above
+    ar.quantize()
+    for (i0, b0), rec in zip(stats_flow, ar.records):
+        st = rec["stats"]
+        assert abs(st["init_loss"] - i0) <= 5e-3 * i0, (rec["name"], st, i0)
+        assert abs(st["best_loss"] - b0) <= 5e-2 * b0, (rec["name"], st, b0)
+    lin_f = {n: p for n, p in m_flow.model.layers.named_modules() if isinstance(p, torch.nn.Linear)}
+    lin_h = {n.replace(".orig_layer", ""): p for n, p in m_hip.model.layers.named_modules() if isinstance(p, torch.nn.Linear)}
+    lin_f = {n.replace(".orig_layer", ""): p for n, p in lin_f.items()}
+    assert set(lin_f) == set(lin_h)
+    agree = [(lin_f[n].weight == lin_h[n].weight).float().mean().item() for n in lin_f]
+    assert np.mean(agree) > 0.97, (np.mean(agree), min(agree))

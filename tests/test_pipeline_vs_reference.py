@@ -11,7 +11,7 @@ import sys
 import pytest
 import torch
 
-from oracle import torch_ref as tr
+from pipeline_flow import run_flow
 
 REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
@@ -57,19 +57,12 @@ def _tiny_moe(experts=4, top_k=2):
     return MixtralForCausalLM(cfg).to(torch.bfloat16).eval()
 
 
-def _fwd(blk, x, others):
-    out = blk(x, **others)
-    return out[0] if isinstance(out, (tuple, list)) else out
-
-
 @pytest.mark.parametrize("kw", [dict(scheme="W4A16", group_size=32), dict(scheme="W2A16G32", sym=False), dict(scheme="MXFP4"),
                                 dict(scheme="W2A16G32", enable_alg_ext=True), dict(scheme="NVFP4", enable_alg_ext=True),
                                 dict(scheme="W4A16", group_size=32, moe=True), dict(scheme="NVFP4", moe=(24, 1))],
                          ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32",
                               "mixtral_nvfp4_idle_experts"])
 def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monkeypatch):
-    import transformers
-
     shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
     sys.dont_write_bytecode = True
     for p in (shim, REF):
@@ -105,78 +98,12 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
     sch = resolve_scheme(**{k: v for k, v in kw.items() if k != "enable_alg_ext"})
     for b in blocks:
         apply_scheme(b, sch)
-    captured, others = [], {}
-
-    class Stop(Exception):
-        pass
-
-    def hook(mod, args, kwargs):
-        captured.append(args[0].detach())
-        if not others:
-            for k, v in kwargs.items():
-                if k not in ("hidden_states", "past_key_values", "use_cache", "cache_position"):
-                    others[k] = tuple(x[:1] for x in v) if isinstance(v, tuple) else (v[:1] if isinstance(v, torch.Tensor) and v.dim() and v.shape[0] == bs else v)
-        raise Stop
-
-    h = blocks[0].register_forward_pre_hook(hook, with_kwargs=True)
-    with torch.no_grad():
-        for b0 in range(0, 8, bs):
-            try:
-                m(input_ids=tokens[b0:b0 + bs], use_cache=False)
-            except Stop:
-                pass
-    h.remove()
-    x0 = torch.cat(captured, 0)
-    # what the reference caches: its calibrator masks the last token in the 2-D attention mask, transformers turns that into a
-    # boolean [1,1,S,S] mask (causal AND key != last), and the input cache casts it to bf16
-    ref_mask = torch.tril(torch.ones(S, S))
-    ref_mask[:, -1] = 0
-    others["attention_mask"] = ref_mask.to(torch.bfloat16).reshape(1, 1, S, S)
-    # the reference concatenates its per-sample cache entries into batch-sized tensors; a broadcast [1, ...] mask takes another
-    # CPU SDPA path whose last-bit differences are enough to move the importance matrix of the algorithm extension
-    others = {k: (tuple(t.expand(bs, *t.shape[1:]).contiguous() for t in v) if isinstance(v, tuple) else
-                  (v.expand(bs, *v.shape[1:]).contiguous() if isinstance(v, torch.Tensor) and v.dim() and v.shape[0] == 1 else v))
-              for k, v in others.items()}
-    ids = tokens.clone()
-    ids[:, -1] = -100
-
-    @torch.no_grad()
-    def forward_all(blk, x):
-        outs = []
-        for b0 in range(0, x.shape[0], bs):
-            with torch.autocast("cpu", dtype=torch.bfloat16):
-                outs.append(_fwd(blk, x[b0:b0 + bs], others))
-        return torch.cat(outs, 0)
-
-    transformers.set_seed(42)
-    n_filled = []
-    fp_in, q_in = x0, None
-    for blk in blocks:
-        if alg_ext:          # the imatrix hooks fire during the reference (fp-input) forward
-            tr.collect_imatrix(blk, fp_in, others, batch_size=bs, forward=_fwd)
-        fp_out = forward_all(blk, fp_in)
-        xin = q_in if q_in is not None else fp_in
-        if str(sch.get("act_data_type", "")).startswith("nv_fp"):      # static activation scales + unified weight global scales
-            from auto_round_amd.quantizer import register_act_max_hooks
-            from auto_round_amd.wrapper import update_block_global_scale_if_needed
-
-            hooks = register_act_max_hooks(blk)                 # composer.py:430-436: collected on the quantised-input forward
-            forward_all(blk, xin)
-            for h2 in hooks:
-                h2.remove()
-            if moe:          # experts that saw no calibration token inherit their siblings' maximum
-                from auto_round_amd.quantizer import set_amax_for_uncalibrated_experts
-
-                n_filled.append(set_amax_for_uncalibrated_experts(blk))
-            update_block_global_scale_if_needed(blk)
-        tr.tune_block(blk, xin, fp_out, others, iters=iters, batch_size=bs, forward=_fwd, input_ids=ids, alg_ext=alg_ext)
-        q_in = forward_all(blk, xin)
-        fp_in = fp_out
+    _, n_filled = run_flow(m, blocks, tokens, sch, iters=iters, bs=bs, alg_ext=alg_ext, moe=bool(moe), reference_mask=True)
 
     lin_ref = {n: p for n, p in q_ref.model.layers.named_modules() if isinstance(p, torch.nn.Linear)}
     lin_mine = {n: p for n, p in m.model.layers.named_modules() if isinstance(p, torch.nn.Linear)}
     assert set(lin_ref) == set(lin_mine) and len(lin_ref) >= 14
     if isinstance(moe, tuple):
-        assert sum(n_filled) > 0, "the case is meant to contain experts without calibration tokens"
+        assert n_filled > 0, "the case is meant to contain experts without calibration tokens"
     for n, p1 in lin_ref.items():
         assert torch.equal(p1.weight.view(torch.int16), lin_mine[n].weight.view(torch.int16)), n
