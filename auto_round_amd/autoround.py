@@ -186,11 +186,16 @@ class AutoRound:
         return model, self.layer_config
 
     def _quantization_config(self, backend: str) -> dict:
-        qc = {k: self.scheme.get(k) for k in SCHEME_KEYS if self.scheme.get(k) is not None}
-        qc.update(quant_method="auto-round", packing_format=backend, iters=self.config.iters, nsamples=self.nsamples,
-                  seqlen=self.seqlen, batch_size=self.config.batch_size, enable_alg_ext=self.enable_alg_ext,
-                  enable_quanted_input=self.config.enable_quanted_input,
-                  block_name_to_quantize=os.path.commonprefix(self.block_names).rstrip("."), autoround_version="mi355x-0.1.0")
+        """Same keys as the reference writes for format "auto_round" (export_to_autoround/export.py:286-330 after
+        filter_quantization_config): scheme fields that differ from the 16-bit defaults, iters, block_name_to_quantize,
+        packing_format, quant_method, and per-layer deviations in extra_config."""
+        qc = {k: self.scheme.get(k) for k in ("bits", "group_size", "sym", "data_type")}
+        if (self.scheme.get("act_bits") or 16) <= 8:
+            qc.update({k: self.scheme.get(k) for k in ("act_bits", "act_data_type", "act_group_size", "act_sym", "act_dynamic")
+                       if self.scheme.get(k) is not None})
+        qc.update(quant_method="auto-round", packing_format=backend, iters=self.config.iters,
+                  block_name_to_quantize=os.path.commonprefix(self.block_names).rstrip("."), autoround_version="mi355x-0.1.0",
+                  static_kv_granularity="tensor", static_attention_granularity="tensor")
         extra = {n: {k: v for k, v in c.items() if c.get(k) != self.scheme.get(k) and v is not None}
                  for n, c in self.layer_config.items() if any(c.get(k) != self.scheme.get(k) for k in SCHEME_KEYS)}
         if extra:
@@ -234,6 +239,8 @@ class AutoRound:
         cfg["quantization_config"] = self._quantization_config(backend)
         with open(os.path.join(output_dir, "config.json"), "w") as f:
             json.dump(cfg, f, indent=2, default=str)
+        with open(os.path.join(output_dir, "quantization_config.json"), "w") as f:      # the reference writes both
+            json.dump(cfg["quantization_config"], f, indent=2, default=str)
         if self.tokenizer is not None and hasattr(self.tokenizer, "save_pretrained"):
             self.tokenizer.save_pretrained(output_dir)
         return index

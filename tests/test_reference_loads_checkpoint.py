@@ -89,3 +89,52 @@ def test_reference_inference_stack_loads_our_checkpoint(ck):
         assert torch.equal(w, torch.from_numpy(z[key]).view(torch.bfloat16)), n
     # ... while 4-bit ACTIVATION rounding makes the logits sensitive to the host's arithmetic (fp32 CPU qdq here vs bf16 GPU)
     assert np.abs(logits - z["logits"]).mean() <= 0.2 * scale
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("tag,kw", [("w4g32_sym", dict(scheme="W4A16", group_size=32)), ("nvfp4", dict(scheme="NVFP4"))])
+def test_checkpoint_structure_equals_a_reference_saved_checkpoint(tag, kw, tmp_path, monkeypatch):
+    """The reference quantises and SAVES the same architecture on CPU (format "auto_round"); our GPU-written fixture must
+    have exactly the same tensor names, dtypes and shapes and the same quantization_config keys / values (versions and the
+    run's iteration count aside)."""
+    from safetensors import safe_open
+
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, REF):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from auto_round import AutoRound
+
+    from test_gpu_autoround import tiny_llama
+    from test_pipeline_vs_reference import _Loader, _StubTokenizer
+
+    monkeypatch.chdir(tmp_path)
+    tokens = torch.randint(0, 64, (4, 16), generator=torch.Generator().manual_seed(1))
+    ar = AutoRound(tiny_llama(seed=3, vocab=64), tokenizer=_StubTokenizer(), iters=1, nsamples=4, seqlen=16, dataset=_Loader(tokens),
+                   device_map="cpu", batch_size=4, enable_torch_compile=False, **kw)
+    out = str(tmp_path / "ref")
+    ar.quantize_and_save(out, format="auto_round")
+    sub = [d for d in os.listdir(out) if os.path.isdir(os.path.join(out, d))]
+    out = os.path.join(out, sub[0]) if sub else out
+
+    def load(d):
+        t = {}
+        for f in os.listdir(d):
+            if f.endswith(".safetensors"):
+                with safe_open(os.path.join(d, f), "pt") as sf:
+                    for k in sf.keys():
+                        x = sf.get_tensor(k)
+                        t[k] = (x.dtype, tuple(x.shape))
+        return t
+
+    mine_dir = os.path.join(GOLDEN, f"tiny_ckpt_{tag}")
+    ref_t, my_t = load(out), load(mine_dir)
+    assert ref_t == my_t                                   # names, dtypes, shapes
+    ref_qc = json.load(open(os.path.join(out, "config.json")))["quantization_config"]
+    my_qc = json.load(open(os.path.join(mine_dir, "config.json")))["quantization_config"]
+    assert set(ref_qc) == set(my_qc), (sorted(set(ref_qc) ^ set(my_qc)))
+    for k in ref_qc:
+        if k not in ("autoround_version", "iters"):
+            assert ref_qc[k] == my_qc[k], k
+    assert os.path.exists(os.path.join(out, "quantization_config.json")) and os.path.exists(os.path.join(mine_dir, "quantization_config.json"))
