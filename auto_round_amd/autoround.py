@@ -229,10 +229,15 @@ class AutoRound:
                 ln = ln[:-len(".orig_layer")] if ln.endswith(".orig_layer") else ln
                 packed_prefixes.append(f"{name}.{ln}.")
         rest = {}
+        tied = bool(getattr(getattr(self.model, "config", None), "tie_word_embeddings", False))
+        emb = self.model.get_input_embeddings() if hasattr(self.model, "get_input_embeddings") else None
         for k, v in self.model.state_dict().items():
             k2 = k.replace(".orig_layer.", ".")
-            if not any(k2.startswith(p) for p in packed_prefixes):
-                rest[k2] = v.detach().to("cpu").contiguous()
+            if any(k2.startswith(p) for p in packed_prefixes):
+                continue
+            if tied and emb is not None and k2 == "lm_head.weight" and v.data_ptr() == emb.weight.data_ptr():
+                continue        # tied output embedding: stored once, like save_pretrained does
+            rest[k2] = v.detach().to("cpu").contiguous()
         writer.write(rest)
         index = writer.close()
         cfg = self.model.config.to_dict() if hasattr(self.model, "config") else {}

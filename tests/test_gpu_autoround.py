@@ -10,12 +10,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def tiny_llama(layers=2, hidden=128, ffn=256, heads=4, kv=2, vocab=512, seed=0):
+def tiny_llama(layers=2, hidden=128, ffn=256, heads=4, kv=2, vocab=512, seed=0, tie=False):
     from transformers import LlamaConfig, LlamaForCausalLM
 
     torch.manual_seed(seed)
     cfg = LlamaConfig(hidden_size=hidden, intermediate_size=ffn, num_attention_heads=heads, num_key_value_heads=kv,
-                      num_hidden_layers=layers, vocab_size=vocab, max_position_embeddings=256, tie_word_embeddings=False)
+                      num_hidden_layers=layers, vocab_size=vocab, max_position_embeddings=256, tie_word_embeddings=tie)
     cfg._attn_implementation = "sdpa"
     return LlamaForCausalLM(cfg).to(torch.bfloat16)
 
@@ -191,3 +191,17 @@ def test_front_door_follows_the_pinned_block_flow(kw):
     assert set(lin_f) == set(lin_h)
     agree = [(lin_f[n].weight == lin_h[n].weight).float().mean().item() for n in lin_f]
     assert np.mean(agree) > 0.97, (np.mean(agree), min(agree))
+
+
+def test_front_door_tied_embeddings_are_saved_once(tmp_path):
+    from safetensors import safe_open
+
+    from auto_round_amd.autoround import AutoRound
+
+    model = tiny_llama(layers=1, tie=True)
+    tokens = torch.randint(0, 512, (4, 16), generator=torch.Generator().manual_seed(2))
+    out = str(tmp_path / "tied")
+    AutoRound(model, None, scheme="W4A16", group_size=32, iters=1, nsamples=4, seqlen=16, batch_size=4, dataset=tokens).quantize_and_save(out)
+    with safe_open(os.path.join(out, "model.safetensors"), "pt") as f:
+        keys = set(f.keys())
+    assert "model.embed_tokens.weight" in keys and "lm_head.weight" not in keys
