@@ -202,6 +202,7 @@ class SignRoundConfig:
     # buffer once per iteration (RCCL): multi-GPU speed-up for ONE block, usable with quantised-input chaining where blocks
     # cannot be sharded.  The reference's counterpart is its experimental DDP mode (utils/distributed.py).
     data_parallel: bool = False
+    dp_overlap: bool = True              # dense blocks: per-layer gradient buckets all-reduced while the backward pass continues
 
     def __post_init__(self):
         if self.iters < 0:
@@ -353,10 +354,16 @@ class SignRoundQuantizer:
         sched_host = index_schedule if index_schedule is not None else (None if sched_dev is None else sched)
 
         dp_rank, dp_size = 0, 1
+        accum_cfg = cfg.gradient_accumulate_steps != 1     # with micro-batches a layer's gradient is only complete after the last one
+        self.last_dp_overlapped = False
         if cfg.data_parallel:
             from .sharding import dp_world, sync_block_gradients
 
             dp_rank, dp_size = dp_world()
+            if dp_size > 1 and cfg.dp_overlap and not accum_cfg:
+                from .sharding import enable_overlapped_sync
+
+                self.last_dp_overlapped = enable_overlapped_sync(block, arenas)
             if dp_size > 1 and (min(batch_size, global_bs) % dp_size or global_bs % min(batch_size, global_bs)):
                 raise ValueError(f"data_parallel: batch_size {batch_size} (global {global_bs}) must be divisible by the "
                                  f"{dp_size} ranks so that every rank weighs the same in the summed gradient")

@@ -161,6 +161,30 @@ def all_reduce_sum_(t: torch.Tensor, group=None, async_op: bool = False):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+def enable_overlapped_sync(block, arenas, group=None):
+    """Bucketed gradient all-reduce overlapped with the backward pass: every wrapped layer starts the SUM all-reduce of its own
+    slice of the arena's dWq buffer as soon as its weight-gradient GEMM has been issued (async on RCCL's stream), and
+    `sync_block_gradients` only waits for them.  Collectives must be issued in the same order on every rank, so this is only
+    enabled for blocks whose layers all run in every iteration in a data-independent order: it is refused (returns False) for
+    blocks with expert sub-modules, where participation depends on the routing of each rank's tokens."""
+    if any(".experts." in n or n.endswith(".experts") for n, _ in block.named_modules()):
+        return False
+    pending = []
+    for a in arenas:
+        a._dp_pending = pending
+        for lyr in a.layers:
+            flat = a.dWq[lyr._off:lyr._off + lyr.numel]
+
+            def start(flat=flat):
+                w = all_reduce_sum_(flat, group, async_op=True)
+                if w is not None:
+                    pending.append(w)
+
+            lyr._post_dw = start
+            lyr._dp_overlapped = True
+    return True
+
+
 def sync_block_gradients(arenas, total_loss: torch.Tensor, group=None, average_loss: bool = True):
     """What the reference's DDP / `_all_reduce_model_grads` does per iteration (utils/distributed.py:30-140), on this
     layout: ONE bucket per arena -- the block-wide dWq buffer (bf16, 2 B/weight instead of the reference's 4 B/weight of
@@ -171,6 +195,11 @@ def sync_block_gradients(arenas, total_loss: torch.Tensor, group=None, average_l
     if world == 1:
         return
     for a in arenas:
+        if getattr(a, "_dp_pending", None) is not None:      # per-layer buckets were started during the backward pass
+            for w in a._dp_pending:
+                w.wait()
+            a._dp_pending.clear()
+            continue
         for lyr in a.layers:
             if not lyr._dw_accum[0]:
                 lyr.weight_grad.zero_()

@@ -65,7 +65,8 @@ class _QLinearFn(torch.autograd.Function):
     first linear of a block sees the cached calibration activations)."""
 
     @staticmethod
-    def forward(ctx, x, token, wq, bias, dwq_out, accumulate):
+    def forward(ctx, x, token, wq, bias, dwq_out, accumulate, post_dw=None):
+        ctx.post_dw = post_dw
         ctx.x_dtype = x.dtype
         xc = x if x.dtype == wq.dtype else x.to(wq.dtype)
         ctx.save_for_backward(xc, wq)
@@ -87,12 +88,14 @@ class _QLinearFn(torch.autograd.Function):
         else:
             torch.mm(dy2.t(), x2, out=ctx.dwq_out)
             ctx.accumulate[0] = True
+        if ctx.post_dw is not None:       # data-parallel tuning: start this layer's gradient all-reduce now, so that it overlaps
+            ctx.post_dw()                 # with the backward pass of the layers upstream (sharding.enable_overlapped_sync)
         dx = None
         if ctx.x_needs_grad:
             dx = torch.mm(dy2, wq).reshape(xc.shape)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class _ActQdqFn(torch.autograd.Function):
@@ -507,7 +510,8 @@ class WrapperLinear(torch.nn.Module):
             a.qdq_forward()
         if self.enable_act_quant:
             x = act_fake_quant(x, self.orig_layer)
-        return _QLinearFn.apply(x, a.token, self.weight_q, self.orig_layer.bias, self.weight_grad, self._dw_accum)
+        return _QLinearFn.apply(x, a.token, self.weight_q, self.orig_layer.bias, self.weight_grad, self._dw_accum,
+                                getattr(self, "_post_dw", None))
 
     def unwrapper(self, best_params):
         """Bake the best parameters into the layer (reference: wrapper.py:345-468): weight <- qdq weight,

@@ -644,7 +644,7 @@ def test_static_activation_scale_calibration_nvfp4(quanted_input):
     assert not hasattr(wa0.orig_layer, "act_max") and ql.weight_packed.dtype == torch.uint8
 
 
-def _dp_worker(rank, world, port, out_path):
+def _dp_worker(rank, world, port, out_path, overlap=True):
     import torch.distributed as dist
 
     from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
@@ -656,8 +656,9 @@ def _dp_worker(rank, world, port, out_path):
         X, others = make_data(rope, cfg, N=16, S=16)
         Y = targets(layer, X, others)
         random.seed(21)
-        q = SignRoundQuantizer(SignRoundConfig(iters=3, batch_size=4, bits=4, data_parallel=True), device="cuda")
+        q = SignRoundQuantizer(SignRoundConfig(iters=3, batch_size=4, bits=4, data_parallel=True, dp_overlap=overlap), device="cuda")
         best = q.quantize_block(layer, X, others, Y, None, None)
+        assert q.last_dp_overlapped == overlap          # a dense block: per-layer buckets started from the backward pass
         if rank == 0:
             torch.save({"stats": q.last_stats, "weights": {n: m.weight.cpu() for n, m in linears(layer).items()},
                         "V": {n: b["value"].cpu() for n, b in best.items()}}, out_path)
@@ -666,7 +667,8 @@ def _dp_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_data_parallel_block_tuning_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("overlap", [True, False])
+def test_data_parallel_block_tuning_two_ranks_one_gpu(tmp_path, overlap):
     """data_parallel=True: two ranks (sharing this box's single GPU, gloo transport) each run half of every minibatch and
     all-reduce the block's dWq buffer once per iteration; the result follows the single-process run (identical iteration-0
     loss up to GEMM batch-split rounding, same trajectory statistics)."""
@@ -678,7 +680,7 @@ def test_data_parallel_block_tuning_two_ranks_one_gpu(tmp_path):
 
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, port, out, overlap), nprocs=2, join=True)
     dp = torch.load(out)
 
     layer, rope, cfg = make_layer("llama", 4, 32, True, seed=4)
