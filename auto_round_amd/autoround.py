@@ -23,7 +23,7 @@ import torch
 
 from .model_tuner import tune_blocks
 from .quantizer import SignRoundConfig, SignRoundQuantizer, SignRoundV2Quantizer
-from .schemes import SCHEME_KEYS, apply_scheme, resolve_scheme
+from .schemes import SCHEME_KEYS, apply_scheme, expand_layer_config, layer_pattern_regex, resolve_scheme
 from .shard_writer import ShardWriter
 from .wrapper import WrapperWALayer
 
@@ -153,7 +153,7 @@ class AutoRound:
         self.block_names = max(groups, key=len)
         blocks = [model.get_submodule(n) for n in self.block_names]
         for n, b in zip(self.block_names, blocks):
-            for ln, cfg in apply_scheme(b, self.scheme, layer_config=self.layer_config_in).items():
+            for ln, cfg in apply_scheme(b, self.scheme, layer_config=_block_layer_config(self.layer_config_in, n, b)).items():
                 self.layer_config[f"{n}.{ln}"] = cfg
         tokens = self._calibration_tokens()
         ids_for_mask = tokens.clone()
@@ -198,23 +198,88 @@ class AutoRound:
                   static_kv_granularity="tensor", static_attention_granularity="tensor")
         extra = {n: {k: v for k, v in c.items() if c.get(k) != self.scheme.get(k) and v is not None}
                  for n, c in self.layer_config.items() if any(c.get(k) != self.scheme.get(k) for k in SCHEME_KEYS)}
+        for pat, over in self._pattern_config().items():         # patterns are kept as such for loaders that re-apply them
+            extra[layer_pattern_regex(pat)] = {k: v for k, v in over.items() if v != self.scheme.get(k)}
         if extra:
             qc["extra_config"] = extra
         return qc
 
+    def _pattern_config(self) -> Dict[str, dict]:
+        """The user's `layer_config` entries that are patterns rather than layer names (the reference's `regex_config`,
+        compressors/layer_config/resolver.py:289-322)."""
+        return {k: dict(v) for k, v in (getattr(self, "layer_config_in", None) or {}).items() if k not in self.layer_config}
+
+    def _deviating_layers(self) -> Dict[str, dict]:
+        """Layers whose scheme differs from the model-wide one (export_to_autoround/utils.py:21-41 `check_neq_config`)."""
+        return {n: c for n, c in self.layer_config.items()
+                if any(c.get(k) not in (self.scheme.get(k), None) for k in SCHEME_KEYS)}
+
+    def _gptq_quantization_config(self) -> dict:
+        """format "auto_gptq" (export_to_autogptq/export.py:188-325): GPTQ's own keys, per-layer deviations as its
+        `dynamic` rules ("+:regex" = quantise with these settings, "-:regex" = leave in 16 bit)."""
+        import re
+
+        qc = {k: self.scheme.get(k) for k in ("bits", "group_size", "sym", "data_type")}
+        qc.update(iters=self.config.iters, autoround_version="mi355x-0.1.0", static_kv_granularity="tensor",
+                  static_attention_granularity="tensor", lm_head=False, provider="auto-round", quant_method="gptq",
+                  desc_act=False, true_sequential=False, damp_percent=0.01)
+        dynamic, patterns = {}, self._pattern_config()
+        rules = [(layer_pattern_regex(p), {**self.scheme, **over}) for p, over in patterns.items()]       # patterns first,
+        rules += [(f".*{re.escape(n)}.*", c) for n, c in self._deviating_layers().items()                 # then single layers
+                  if not any(re.search(p, n) for p in patterns)]                                          # they do not cover
+        for rx, c in rules:
+            if int(c.get("bits", 16)) < 16:
+                dynamic[f"+:{rx}"] = {k: c[k] for k in ("bits", "group_size", "sym")}
+            else:
+                dynamic[f"-:{rx}"] = {}
+        if dynamic:
+            qc["dynamic"] = dynamic
+        quantised, skipped = set(), set()
+        for bn in self.block_names:
+            for n, c in self.layer_config.items():
+                if n.startswith(bn + "."):                         # name inside its block
+                    (quantised if int(c.get("bits", 16)) <= 8 else skipped).add(n[len(bn) + 1:])
+        if skipped:                                                # export.py:267-288: only written for partially tuned blocks
+            qc["modules_in_block_to_quantize"] = [sorted(quantised)]
+        return qc
+
+    def _awq_quantization_config(self) -> dict:
+        """format "auto_awq" (export_to_awq/export.py:201-226): AutoAWQ's GEMM keys; layers left in 16 bit are listed."""
+        qc = {k: self.scheme.get(k) for k in ("bits", "group_size", "sym", "data_type")}
+        keep = [n for n, m in self.model.named_modules()            # linears outside the tuned blocks (lm_head, projectors)
+                if isinstance(m, torch.nn.Linear) and n not in self.layer_config
+                and not any(n.startswith(b + ".") for b in self.block_names)]
+        keep += [n for n, c in self.layer_config.items() if int(c.get("bits", 16)) > 8]
+        keep += [p for p, over in self._pattern_config().items() if int(over.get("bits", 0)) > 8]
+        qc.update(iters=self.config.iters, autoround_version="mi355x-0.1.0", static_kv_granularity="tensor",
+                  static_attention_granularity="tensor", provider="auto-round", quant_method="awq",
+                  to_quant_block_names=os.path.commonprefix(self.block_names).rstrip("."),
+                  zero_point=not bool(self.scheme["sym"]), version="gemm", modules_to_not_convert=keep)
+        return qc
+
     @torch.no_grad()
     def save_quantized(self, output_dir: str, format: str = "auto_round", max_shard_bytes: int = 5 * 1024 ** 3):
-        """Pack every tuned layer and write an `auto_round`-format checkpoint: safetensors shards (+ index), config.json
-        with `quantization_config`, tokenizer files when a tokenizer was given."""
-        if format not in ("auto_round", "auto_round:auto_gptq", "auto_round:auto_awq"):
-            raise NotImplementedError(f"format {format!r}: the MI355X path writes the auto_round checkpoint layout")
+        """Pack every tuned layer and write the checkpoint: safetensors shards (+ index), config.json with
+        `quantization_config`, tokenizer files when a tokenizer was given.  Formats: "auto_round" (default; optionally with
+        an explicit ":auto_gptq" / ":auto_awq" packing backend), and for INT schemes the plain "auto_gptq" and "auto_awq"
+        layouts (export/formats/backends/auto_gptq.py, auto_awq.py)."""
+        if format not in ("auto_round", "auto_round:auto_gptq", "auto_round:auto_awq", "auto_gptq", "auto_awq"):
+            raise NotImplementedError(f"format {format!r}: the MI355X path writes auto_round, auto_gptq and auto_awq checkpoints")
         if not self.quantized:
             raise RuntimeError("call quantize() first")
         from .export import pack_block
 
         sym, bits = bool(self.scheme["sym"]), int(self.scheme["bits"])
         int_scheme = str(self.scheme["data_type"]).startswith("int")
-        if not int_scheme:       # MXFP4 / NVFP4 checkpoints carry the llm_compressor tensor layout (export_to_nvfp_mx.py:178-179)
+        if format in ("auto_gptq", "auto_awq"):
+            # the same scheme checks as the reference's format classes (auto_gptq.py:44-57, auto_awq.py:33-46)
+            if not int_scheme or (self.scheme.get("act_bits") or 16) <= 8:
+                raise ValueError(f"{format} format supports weight-only INT schemes, got data_type={self.scheme['data_type']} "
+                                 f"act_bits={self.scheme.get('act_bits')}")
+            if format == "auto_awq" and any(int(c.get("bits", 16)) not in (4, 16) for c in self.layer_config.values()):
+                raise ValueError("auto_awq format supports W4A16 only (every tuned layer must be 4 bit)")
+            backend = format
+        elif not int_scheme:     # MXFP4 / NVFP4 checkpoints carry the llm_compressor tensor layout (export_to_nvfp_mx.py:178-179)
             backend = "auto_round:llm_compressor"
         else:                    # AutoRoundFormat's defaults (export/formats/backends/autoround.py:59-70)
             backend = format if ":" in format else ("auto_round:auto_gptq" if sym else
@@ -241,7 +306,14 @@ class AutoRound:
         writer.write(rest)
         index = writer.close()
         cfg = self.model.config.to_dict() if hasattr(self.model, "config") else {}
-        cfg["quantization_config"] = self._quantization_config(backend)
+        if format == "auto_gptq":
+            cfg["quantization_config"] = self._gptq_quantization_config()
+        elif format == "auto_awq":
+            cfg["quantization_config"] = self._awq_quantization_config()
+        else:
+            cfg["quantization_config"] = self._quantization_config(backend)
+        if format in ("auto_gptq", "auto_awq"):     # both exporters pin the advertised dtype to fp16 for the consumers' kernels
+            cfg["torch_dtype"] = "float16"          # (export_to_autogptq/export.py:314, export_to_awq/export.py:217-219)
         with open(os.path.join(output_dir, "config.json"), "w") as f:
             json.dump(cfg, f, indent=2, default=str)
         with open(os.path.join(output_dir, "quantization_config.json"), "w") as f:      # the reference writes both
@@ -254,6 +326,15 @@ class AutoRound:
         model, _ = self.quantize()
         self.save_quantized(output_dir, format=format, **kw)
         return model, output_dir
+
+
+def _block_layer_config(layer_config, block_name, block):
+    """The user's `layer_config` keys are full layer names or patterns over them; apply_scheme works on the names inside one
+    block, so resolve the keys on the full names (schemes.expand_layer_config) and strip the block prefix."""
+    if not layer_config:
+        return None
+    full = [f"{block_name}.{n}" for n, m in block.named_modules() if isinstance(m, torch.nn.Linear)]
+    return {n[len(block_name) + 1:]: over for n, over in expand_layer_config(full, layer_config).items()}
 
 
 def _first_sample(v, bs):

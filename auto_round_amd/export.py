@@ -23,7 +23,8 @@ class _QuantLinearInt(torch.nn.Module):
     ZP_OFF = 1
     QUANT_TYPE = "mi355x"
 
-    def __init__(self, bits, group_size, infeatures, outfeatures, bias=False, weight_dtype=torch.bfloat16, **kwargs):
+    def __init__(self, bits, group_size, infeatures, outfeatures, bias=False, weight_dtype=torch.bfloat16, g_idx=False,
+                 **kwargs):
         super().__init__()
         if bits not in (2, 3, 4, 8):
             raise NotImplementedError("Only 2,3,4,8 bits are supported.")
@@ -35,6 +36,8 @@ class _QuantLinearInt(torch.nn.Module):
         self.register_buffer("qweight", torch.zeros((infeatures // 32 * bits, outfeatures), dtype=torch.int32))
         self.register_buffer("qzeros", torch.zeros((ng, outfeatures // 32 * bits), dtype=torch.int32))
         self.register_buffer("scales", torch.zeros((ng, outfeatures), dtype=torch.float16))
+        if g_idx:      # the "auto_gptq" checkpoint layout carries the (trivial, no act-order) group index of every input channel
+            self.register_buffer("g_idx", (torch.arange(infeatures, dtype=torch.int64) // self.group_size).to(torch.int32))
         if bias:
             self.register_buffer("bias", torch.zeros((outfeatures,), dtype=torch.float16))
         else:
@@ -138,8 +141,8 @@ def dynamic_import_quant_linear_for_packing(backend: str, bits: int, group_size:
     """reference: export/export_to_autoround/export.py:56-95 -- which packer a backend string selects."""
     if "auto_round" in backend and "awq" not in backend and "gptq" not in backend:
         return QuantLinearPlain
-    if "auto_round" in backend and "gptq" in backend and "gptqmodel" not in backend:
-        return QuantLinearZP
+    if "gptq" in backend and "gptqmodel" not in backend:     # "auto_round:auto_gptq" and the plain "auto_gptq" format
+        return QuantLinearZP                                  # (export/utils.py:314-331 picks the same zp-1 packer for both)
     raise ValueError(f"unsupported backend for the MI355X packers: {backend}")
 
 
@@ -172,7 +175,8 @@ def pack_layer(layer: torch.nn.Linear, backend: str = "auto_round:auto_gptq", de
                 zp = int(zp.flatten()[0])
         return WQLinear_GEMM.from_linear(layer, bits, gs, scales=scale, zeros=zp, device=device)
     QL = dynamic_import_quant_linear_for_packing(backend, bits, gs, sym)
-    ql = QL(bits, gs, in_f, out_f, bias=layer.bias is not None, weight_dtype=layer.weight.dtype)
+    ql = QL(bits, gs, in_f, out_f, bias=layer.bias is not None, weight_dtype=layer.weight.dtype,
+            g_idx=not backend.startswith("auto_round"))       # export_to_autogptq/export.py:163
     zp = layer.zp
     if sym and isinstance(zp, torch.Tensor) and QL is QuantLinearPlain:
         zp = int(zp.flatten()[0])

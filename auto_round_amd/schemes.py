@@ -47,6 +47,44 @@ def resolve_scheme(scheme="W4A16", **overrides) -> dict:
     return cfg
 
 
+_REGEX_TOKENS = (".*", "^", "$", "|", "(", ")", "[", "]", "?", "+")
+
+
+def layer_pattern_regex(pattern: str) -> str:
+    """How a `layer_config` key that is not an exact layer name is read (reference: utils/common.py:813-867
+    `to_standard_regex`): a plain string matches as a substring (escaped, wrapped in `.*`); a string that already contains
+    regex tokens keeps them, has its bare dots escaped and is opened on the sides it does not anchor itself."""
+    import re
+
+    if not any(t in pattern for t in _REGEX_TOKENS):
+        return f".*{re.escape(pattern)}.*"
+    rx = re.sub(r"\.(\*?)", lambda m: ".*" if m.group(1) else "\\.", pattern)
+    if not rx.startswith(("^", ".*")):
+        rx = ".*" + rx
+    if not rx.endswith(("$", ".*")):
+        rx += ".*"
+    re.compile(rx)
+    return rx
+
+
+def expand_layer_config(layer_names: Iterable[str], layer_config: Optional[Dict[str, dict]]) -> Dict[str, dict]:
+    """-> {exact layer name: overrides}.  Exact names are taken as they are; every other key is a pattern searched in the
+    layer names (reference: compressors/layer_config/resolver.py:289-322)."""
+    import re
+
+    names = list(layer_names)
+    out: Dict[str, dict] = {}
+    for key, over in (layer_config or {}).items():
+        if key in names:
+            out.setdefault(key, {}).update(over)
+            continue
+        rx = re.compile(layer_pattern_regex(key))
+        for n in names:
+            if rx.search(n):
+                out.setdefault(n, {}).update(over)
+    return out
+
+
 def is_quantizable(module) -> bool:
     try:
         from transformers.pytorch_utils import Conv1D

@@ -11,7 +11,7 @@ from typing import Dict, Optional
 
 import torch
 
-_INT_KEYS = ("qweight", "qzeros", "scales", "bias")
+_INT_KEYS = ("qweight", "qzeros", "scales", "g_idx", "bias")
 _FP_KEYS = ("weight_packed", "weight_scale", "weight_global_scale", "input_global_scale", "bias")
 
 

@@ -1,0 +1,119 @@
+"""Host logic of the plain "auto_gptq" / "auto_awq" checkpoint formats and of `layer_config` key resolution: known answers,
+and -- where the reference tree is present -- the reference's own exporters run on CPU on the same tiny model."""
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from auto_round_amd.schemes import apply_scheme, expand_layer_config, layer_pattern_regex, resolve_scheme
+
+REF = "/root/reference"
+needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
+
+# pattern -> regex; the first four are the reference's documented examples (utils/common.py:823-831)
+KNOWN = {"model.embed_tokens": r".*model\.embed_tokens.*", "mlp.gate": r".*mlp\.gate.*", "mlp.gate$": r".*mlp\.gate$",
+         "mlp.*gate": r".*mlp.*gate.*", "model.layers.[0-3].mlp": r".*model\.layers\.[0-3]\.mlp.*",
+         "^model.layers.1.": r"^model\.layers\.1\..*", "q_proj|k_proj": r".*q_proj|k_proj.*", ".*down.*": r".*down.*",
+         "a.b.*c.d": r".*a\.b.*c\.d.*", "(q|k)_proj": r".*(q|k)_proj.*"}
+
+
+def _ref_on_path():
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, REF):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def test_layer_pattern_regex_known_answers():
+    for pat, rx in KNOWN.items():
+        assert layer_pattern_regex(pat) == rx, pat
+    with pytest.raises(Exception):
+        layer_pattern_regex("layers.(0")            # an invalid pattern is an error, not a silent non-match
+
+
+@needs_ref
+def test_layer_pattern_regex_equals_the_reference():
+    _ref_on_path()
+    from auto_round.utils import to_standard_regex
+
+    for pat in list(KNOWN) + ["down_proj", "x.y?z", "layers.1+.mlp", "model.layers.0.self_attn.q_proj", "experts.[0-9]+.w1$"]:
+        assert layer_pattern_regex(pat) == to_standard_regex(pat), pat
+
+
+def test_expand_layer_config_exact_names_and_patterns():
+    names = ["model.layers.0.mlp.down_proj", "model.layers.1.mlp.down_proj", "model.layers.1.self_attn.q_proj",
+             "model.layers.10.self_attn.q_proj"]
+    got = expand_layer_config(names, {"model.layers.0.mlp.down_proj": {"bits": 16}, "layers.1.self_attn": {"bits": 8},
+                                      "layers.[0-1].mlp": {"group_size": 64}, "nothing_like_this": {"bits": 2}})
+    assert got == {"model.layers.0.mlp.down_proj": {"bits": 16, "group_size": 64},
+                   "model.layers.1.mlp.down_proj": {"group_size": 64}, "model.layers.1.self_attn.q_proj": {"bits": 8}}
+    assert expand_layer_config(names, None) == {}
+
+
+def _shell(model, sym, layer_config, iters=1):
+    """An AutoRound facade object with the state `quantize()` leaves behind, without a GPU (the config builders are host code)."""
+    from auto_round_amd.autoround import AutoRound, _block_layer_config
+
+    ar = AutoRound.__new__(AutoRound)
+    ar.layer_config_in = layer_config
+    ar.model, ar.scheme, ar.config = model, resolve_scheme("W4A16", group_size=32, sym=sym), SimpleNamespace(iters=iters)
+    ar.block_names, ar.layer_config = [f"model.layers.{i}" for i in range(len(model.model.layers))], {}
+    for n in ar.block_names:
+        b = model.get_submodule(n)
+        for ln, cfg in apply_scheme(b, ar.scheme, layer_config=_block_layer_config(layer_config, n, b)).items():
+            ar.layer_config[f"{n}.{ln}"] = cfg
+    return ar
+
+
+def test_plain_format_configs_known_answers():
+    from test_gpu_autoround import tiny_llama
+
+    ar = _shell(tiny_llama(seed=3, vocab=64), True, None, iters=7)
+    g = ar._gptq_quantization_config()
+    assert g == {"bits": 4, "group_size": 32, "sym": True, "data_type": "int", "iters": 7, "autoround_version": g["autoround_version"],
+                 "static_kv_granularity": "tensor", "static_attention_granularity": "tensor", "lm_head": False,
+                 "provider": "auto-round", "quant_method": "gptq", "desc_act": False, "true_sequential": False, "damp_percent": 0.01}
+    a = _shell(tiny_llama(seed=3, vocab=64), False, {"mlp.up_proj": {"bits": 16}})._awq_quantization_config()
+    assert a["quant_method"] == "awq" and a["version"] == "gemm" and a["zero_point"] is True and a["to_quant_block_names"] == "model.layers"
+    assert a["modules_to_not_convert"] == ["lm_head", "model.layers.0.mlp.up_proj", "model.layers.1.mlp.up_proj",
+                                           "mlp.up_proj"]       # the pattern itself is listed too (export_to_awq/export.py:107-111)
+
+
+@needs_ref
+@pytest.mark.parametrize("fmt,sym,lc", [
+    ("auto_gptq", True, {"model.layers.0.mlp.down_proj": {"bits": 16}, "model.layers.1.self_attn.q_proj": {"bits": 8}}),
+    ("auto_gptq", True, {"model.layers.0.mlp.down_proj": {"bits": 16}, "k_proj": {"group_size": 64}, "layers.1.mlp": {"bits": 16}}),
+    ("auto_awq", False, {"model.layers.0.mlp.down_proj": {"bits": 16}}),
+    ("auto_awq", False, {"model.layers.0.mlp.down_proj": {"bits": 16}, "layers.1.mlp": {"bits": 16}}),
+    ("auto_round", True, {"model.layers.0.mlp.down_proj": {"bits": 16}, "model.layers.1.self_attn.q_proj": {"bits": 8},
+                          "k_proj": {"group_size": 64}})],
+    ids=["gptq_names", "gptq_patterns", "awq_names", "awq_patterns", "auto_round_patterns"])
+def test_plain_format_configs_equal_the_reference_export(fmt, sym, lc, tmp_path, monkeypatch):
+    _ref_on_path()
+    from auto_round import AutoRound
+
+    from test_gpu_autoround import tiny_llama
+    from test_pipeline_vs_reference import _Loader, _StubTokenizer
+
+    monkeypatch.chdir(tmp_path)
+    tokens = torch.randint(0, 64, (4, 16), generator=torch.Generator().manual_seed(1))
+    ar = AutoRound(tiny_llama(seed=3, vocab=64), tokenizer=_StubTokenizer(), iters=1, nsamples=4, seqlen=16, dataset=_Loader(tokens),
+                   device_map="cpu", batch_size=4, enable_torch_compile=False, scheme="W4A16", group_size=32, sym=sym,
+                   layer_config={k: dict(v) for k, v in lc.items()})
+    out = str(tmp_path / "ref")
+    ar.quantize_and_save(out, format=fmt)
+    sub = [d for d in os.listdir(out) if os.path.isdir(os.path.join(out, d))]
+    ref_qc = json.load(open(os.path.join(out, sub[0], "config.json") if sub else os.path.join(out, "config.json")))["quantization_config"]
+    mine = _shell(tiny_llama(seed=3, vocab=64), sym, lc)
+    my_qc = {"auto_gptq": mine._gptq_quantization_config, "auto_awq": mine._awq_quantization_config,
+             "auto_round": lambda: mine._quantization_config("auto_round:auto_gptq")}[fmt]()
+    assert set(ref_qc) == set(my_qc), sorted(set(ref_qc) ^ set(my_qc))
+    for k in ref_qc:
+        if k == "modules_to_not_convert":           # built from a set in the reference: order is not part of the format
+            assert sorted(ref_qc[k]) == sorted(my_qc[k])
+        elif k != "autoround_version":
+            assert ref_qc[k] == my_qc[k], k

@@ -205,3 +205,88 @@ def test_front_door_tied_embeddings_are_saved_once(tmp_path):
     with safe_open(os.path.join(out, "model.safetensors"), "pt") as f:
         keys = set(f.keys())
     assert "model.embed_tokens.weight" in keys and "lm_head.weight" not in keys
+
+
+def unpack_w4_awq(qweight, qzeros, scales, gs):
+    """AutoAWQ GEMM words ([in, out/8], nibble i of a word = output column 8*w + (0,2,4,6,1,3,5,7)[i], zero points stored
+    unchanged) -> fp32 weight [out, in]."""
+    order = torch.tensor([0, 2, 4, 6, 1, 3, 5, 7])
+    sh = torch.arange(0, 32, 4, dtype=torch.int32)
+
+    def cols(words):                                   # [rows, out/8] -> [rows, out]
+        nib = (words.unsqueeze(2) >> sh.view(1, 1, 8)) & 15
+        out = torch.empty_like(nib)
+        out[:, :, order] = nib
+        return out.reshape(words.shape[0], -1)
+
+    q, z = cols(qweight), cols(qzeros)
+    g = torch.arange(q.shape[0]) // gs
+    return ((q - z[g]).float() * scales.float()[g]).t()
+
+
+def _load_ckpt(out):
+    from safetensors import safe_open
+
+    tensors = {}
+    for fname in set(json.load(open(os.path.join(out, "model.safetensors.index.json")))["weight_map"].values()):
+        with safe_open(os.path.join(out, fname), "pt") as f:
+            for k in f.keys():
+                tensors[k] = f.get_tensor(k)
+    return tensors
+
+
+@pytest.mark.parametrize("fmt,sym", [("auto_gptq", True), ("auto_awq", False)])
+def test_front_door_writes_plain_gptq_and_awq_checkpoints(tmp_path, fmt, sym):
+    """format="auto_gptq" / "auto_awq" (export_to_autogptq/export.py, export_to_awq/export.py) with one layer left in 16 bit
+    by a full-name `layer_config` key and one selected by a pattern: tensors decode to the tuned weights, the configs carry
+    the consumers' keys."""
+    from auto_round_amd.autoround import AutoRound
+
+    tokens = torch.randint(0, 512, (8, 32), generator=torch.Generator().manual_seed(1))
+    lc = {"model.layers.0.mlp.down_proj": {"bits": 16}}
+    if fmt == "auto_gptq":
+        lc["layers.1.self_attn.q_proj"] = {"bits": 8}
+    ar = AutoRound(tiny_llama(), None, scheme="W4A16", group_size=32, sym=sym, iters=3, nsamples=8, seqlen=32, batch_size=4,
+                   dataset=tokens, layer_config=lc)
+    out = str(tmp_path / "ckpt")
+    qmodel, _ = ar.quantize_and_save(out, format=fmt)
+    assert ar.layer_config["model.layers.0.mlp.down_proj"]["bits"] == 16
+    cfg = json.load(open(os.path.join(out, "config.json")))
+    qc = cfg["quantization_config"]
+    assert cfg["torch_dtype"] == "float16" and qc["provider"] == "auto-round" and "packing_format" not in qc
+    t = _load_ckpt(out)
+    assert t["model.layers.0.mlp.down_proj.weight"].dtype == torch.bfloat16 and "model.layers.0.mlp.down_proj.qweight" not in t
+    if fmt == "auto_gptq":
+        assert qc["quant_method"] == "gptq" and qc["desc_act"] is False and qc["lm_head"] is False and qc["damp_percent"] == 0.01
+        assert qc["dynamic"] == {r"-:.*model\.layers\.0\.mlp\.down_proj.*": {},
+                                 r"+:.*layers\.1\.self_attn\.q_proj.*": {"bits": 8, "group_size": 32, "sym": True}}
+        assert qc["modules_in_block_to_quantize"] == [sorted(["mlp.down_proj", "mlp.gate_proj", "mlp.up_proj", "self_attn.k_proj",
+                                                               "self_attn.o_proj", "self_attn.q_proj", "self_attn.v_proj"])]
+        g = t["model.layers.0.self_attn.q_proj.g_idx"]
+        assert g.dtype == torch.int32 and torch.equal(g, (torch.arange(128) // 32).int())
+        q8 = t["model.layers.1.self_attn.q_proj.qweight"]
+        assert tuple(q8.shape) == (128 // 32 * 8, 128) and ar.layer_config["model.layers.1.self_attn.q_proj"]["bits"] == 8
+        unpack, names = unpack_w4_gptq, ("model.layers.0.self_attn.q_proj", "model.layers.1.mlp.down_proj")
+    else:
+        assert qc["quant_method"] == "awq" and qc["version"] == "gemm" and qc["zero_point"] is True
+        assert set(qc["modules_to_not_convert"]) == {"lm_head", "model.layers.0.mlp.down_proj"}
+        assert qc["to_quant_block_names"] == "model.layers" and "model.layers.0.self_attn.q_proj.g_idx" not in t
+        assert tuple(t["model.layers.0.self_attn.q_proj.qweight"].shape) == (128, 128 // 8)
+        unpack, names = unpack_w4_awq, ("model.layers.0.self_attn.q_proj", "model.layers.1.mlp.down_proj")
+    for base in names:
+        W = unpack(t[f"{base}.qweight"], t[f"{base}.qzeros"], t[f"{base}.scales"], 32)
+        assert torch.equal(W.to(torch.bfloat16).float(), qmodel.get_submodule(base).weight.detach().float().cpu()), base
+
+
+def test_front_door_plain_format_scheme_checks():
+    from auto_round_amd.autoround import AutoRound
+
+    tokens = torch.randint(0, 512, (4, 32), generator=torch.Generator().manual_seed(1))
+    ar = AutoRound(tiny_llama(), None, scheme="W2A16G32", iters=1, nsamples=4, seqlen=32, batch_size=4, dataset=tokens)
+    ar.quantize()
+    with pytest.raises(ValueError, match="W4A16 only"):
+        ar.save_quantized("/tmp/never_written", format="auto_awq")
+    ar = AutoRound(tiny_llama(), None, scheme="MXFP4", iters=1, nsamples=4, seqlen=32, batch_size=4, dataset=tokens)
+    ar.quantize()
+    with pytest.raises(ValueError, match="weight-only INT"):
+        ar.save_quantized("/tmp/never_written", format="auto_gptq")

@@ -13,16 +13,22 @@ from test_gpu_autoround import tiny_llama  # noqa: E402
 
 from auto_round_amd.autoround import AutoRound  # noqa: E402
 
-out_root = sys.argv[1]
+out_root, only = sys.argv[1], sys.argv[2:]          # optional tags: regenerate just those fixtures
 for tag, kw in (("w4g32_sym", dict(scheme="W4A16", group_size=32)), ("w2g32_asym", dict(scheme="W2A16G32", sym=False)),
                 ("w2g32_sym_algext", dict(scheme="W2A16G32", enable_alg_ext=True)), ("w3g32_sym", dict(scheme="W3A16", group_size=32)),
-                ("mxfp4", dict(scheme="MXFP4")), ("nvfp4", dict(scheme="NVFP4", enable_alg_ext=True))):
+                ("mxfp4", dict(scheme="MXFP4")), ("nvfp4", dict(scheme="NVFP4", enable_alg_ext=True)),
+                ("w4g32_sym_fmt_gptq", dict(scheme="W4A16", group_size=32, format="auto_gptq")),
+                ("w4g32_asym_fmt_awq", dict(scheme="W4A16", group_size=32, sym=False, format="auto_awq"))):
+    if only and tag not in only:
+        continue
+    kw = dict(kw)
+    fmt = kw.pop("format", "auto_round")
     model = tiny_llama(seed=3, vocab=64)
     g = torch.Generator().manual_seed(1)
     tokens = torch.randint(0, 64, (8, 32), generator=g)
     ar = AutoRound(model, None, iters=6, nsamples=8, seqlen=32, batch_size=4, dataset=tokens, **kw)
     out = os.path.join(out_root, f"tiny_ckpt_{tag}")
-    qmodel, _ = ar.quantize_and_save(out)
+    qmodel, _ = ar.quantize_and_save(out, format=fmt)
     with torch.no_grad():
         logits = qmodel(input_ids=tokens[:2].cuda()).logits.float().cpu().numpy()
     def lin(n):          # A4 schemes leave the activation-quant shell around the layer
