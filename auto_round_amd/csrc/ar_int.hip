@@ -50,8 +50,8 @@ __global__ __launch_bounds__(kTPB) void k_group_minmax(const void* __restrict__ 
             lo = lanes_min(lo, cpg);
             hi = lanes_max(hi, cpg);
             if (g < n_groups && (lane % cpg) == 0) {
-                if (wmin) store1<WDT>(wmin, g, fminf(lo, 0.f));
-                if (wmax) store1<WDT>(wmax, g, fmaxf(hi, 0.f));
+                if (wmin) store1<WDT>(wmin, g, lo > 0.f ? 0.f : lo);   // torch.clamp(max=0): a -0.0 extremum stays -0.0
+                if (wmax) store1<WDT>(wmax, g, hi < 0.f ? 0.f : hi);
                 const float am = fmaxf(-lo, hi);
                 if (absmax) absmax[g] = am;
                 tmax = fmaxf(tmax, am);
@@ -69,8 +69,8 @@ __global__ __launch_bounds__(kTPB) void k_group_minmax(const void* __restrict__ 
             lo = lanes_min(lo, kWave);
             hi = lanes_max(hi, kWave);
             if (lane == 0) {
-                if (wmin) store1<WDT>(wmin, g, fminf(lo, 0.f));
-                if (wmax) store1<WDT>(wmax, g, fmaxf(hi, 0.f));
+                if (wmin) store1<WDT>(wmin, g, lo > 0.f ? 0.f : lo);   // torch.clamp(max=0): a -0.0 extremum stays -0.0
+                if (wmax) store1<WDT>(wmax, g, hi < 0.f ? 0.f : hi);
                 const float am = fmaxf(-lo, hi);
                 if (absmax) absmax[g] = am;
                 tmax = fmaxf(tmax, am);

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import oracle as orc
+from random_cases import group_values
 
 REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
@@ -30,18 +31,7 @@ def _bits(t):
     return t.view(torch.int16).numpy().view(np.uint16).copy() if t.dtype in (torch.bfloat16, torch.float16) else t.float().numpy().copy()
 
 
-def _weights(rng, G, gs, dt):
-    """Per-group magnitudes log-uniform over nine decades plus the structural corner cases."""
-    mag = 10.0 ** rng.uniform(-7, 2, size=(G, 1))
-    w = rng.standard_normal((G, gs)) * mag
-    kinds = rng.integers(0, 10, size=G)
-    w[kinds == 0] = 0.0
-    w[kinds == 1] = np.abs(w[kinds == 1])
-    w[kinds == 2] = -np.abs(w[kinds == 2])
-    tie = kinds == 3
-    w[tie, 0] = -np.abs(w[tie]).max(axis=1)                       # |min| == |max|
-    w[tie, 1] = np.abs(w[tie]).max(axis=1)
-    return torch.from_numpy(w.astype(np.float32)).to(dt)
+_weights = group_values
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -122,3 +112,83 @@ def test_fp4_qdq_oracle_equals_the_reference_functions_on_random_cases(seed):
         Wq, exp, _ = quant_mx(W, bits=4, group_size=gs, v=V, max_scale=Ms, data_type="mx_fp")
         oWq = orc.qdq_mxfp4_fwd(Wb, V.numpy().reshape(-1), Ms.numpy(), G, gs, w_dt)[0]
     assert np.array_equal(oWq, _bits(Wq).reshape(-1)), f"nv={nv} G={G} w_dt={w_dt}"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_packers_equal_the_reference_quantlinears_on_random_cases(seed):
+    """qlinear_torch_zp / qlinear_torch `QuantLinear.pack` and the AWQ `WQLinear_GEMM.from_linear` on a random baked layer."""
+    _ref()
+    import auto_round_extension.torch.qlinear_torch as plain
+    import auto_round_extension.torch.qlinear_torch_zp as zpmod
+    from auto_round.data_type.int import quant_tensor_asym, quant_tensor_sym
+
+    rng = np.random.default_rng(3000 + seed)
+    bits = int(rng.choice([2, 3, 4, 8]))
+    gs = int(rng.choice([32, 64, 128]))
+    sym = bool(rng.integers(0, 2))
+    out_f, in_f = 32 * int(rng.integers(1, 5)), gs * int(rng.integers(1, 4)) * (2 if gs == 32 else 1)
+    if in_f % 32:
+        in_f *= 2
+    lin = torch.nn.Linear(in_f, out_f, bias=False)
+    W = _weights(rng, out_f * in_f // gs, gs, torch.bfloat16).reshape(out_f, in_f)
+    V = torch.from_numpy((rng.random((out_f * in_f // gs, gs)) - 0.5).astype(np.float32))
+    Wq, scale, zp = (quant_tensor_sym if sym else quant_tensor_asym)(W, bits=bits, group_size=gs, v=V)
+    lin.weight.data = Wq.detach().clone()
+    scale2d = scale.reshape(out_f, -1)
+    zp2d = zp.reshape(out_f, -1) if isinstance(zp, torch.Tensor) else zp
+    ozp = zp2d.float().numpy() if isinstance(zp2d, torch.Tensor) else float(zp2d)
+    Wb, sb = _bits(lin.weight.data).reshape(-1), _bits(scale2d).reshape(-1)
+    for mod, off in ((zpmod, 1), (plain, 0)):
+        ql = mod.QuantLinear(bits, gs, in_f, out_f, False)
+        ql.device = "cpu"
+        ql.pack(lin, scale2d.clone(), zp2d.clone() if isinstance(zp2d, torch.Tensor) else zp2d, None, device="cpu")
+        qw, qz, st = orc.pack_int(Wb, sb, ozp, out_f, in_f, gs, bits, orc.DT_BF16, orc.DT_F16, zp_off=off)
+        tag = f"bits={bits} gs={gs} sym={sym} {out_f}x{in_f} off={off}"
+        assert np.array_equal(qw, ql.qweight.numpy()), tag
+        assert np.array_equal(qz, ql.qzeros.numpy()), tag
+        assert np.array_equal(st, _bits(ql.scales)), tag
+    if bits == 4:
+        from auto_round.export.export_to_awq.utils import WQLinear_GEMM
+
+        z_awq = zp2d.t().contiguous().to(torch.float32) if isinstance(zp2d, torch.Tensor) else zp2d
+        aq = WQLinear_GEMM.from_linear(lin, bits, gs, scales=scale2d.t().contiguous(), zeros=z_awq, device="cpu")
+        qw, qz, st = orc.pack_awq(Wb, sb, ozp, out_f, in_f, gs)
+        assert np.array_equal(qw, aq.qweight.numpy()) and np.array_equal(qz, aq.qzeros.numpy()) and np.array_equal(st, _bits(aq.scales))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_int_activation_fake_quant_equals_the_reference_on_random_cases(seed):
+    """quant_tensor_sym / quant_tensor_asym on activations as `WrapperLinear._qdq_act` calls them (v = 0, 0-dim scales)."""
+    _ref()
+    from auto_round.data_type.int import quant_tensor_asym, quant_tensor_sym
+
+    rng = np.random.default_rng(4000 + seed)
+    bits = int(rng.choice([4, 8]))
+    hidden = int(rng.choice([128, 256, 384]))
+    gs = int(rng.choice([32, 128, -1]))
+    sym = bool(seed % 2)
+    dt = orc.DT_F16 if seed % 4 == 3 else orc.DT_BF16
+    g = hidden if gs == -1 else gs
+    T = int(rng.integers(3, 24))
+    x = _weights(rng, T * hidden // g, g, torch.float32).clamp(-3e4, 3e4).reshape(T, hidden).to(TD[dt]).requires_grad_(True)
+    one = torch.tensor(1.0)
+    xq, scale, zp = (quant_tensor_sym if sym else quant_tensor_asym)(
+        x, bits=bits, group_size=gs, v=0, min_scale=one.clone(), max_scale=one.clone(), scale_dtype=torch.float16, tensor_max=None,
+        q_scale_thresh=1e-5)
+    dy = torch.from_numpy((rng.standard_normal((T, hidden)) * 1e-2).astype(np.float32)).to(TD[dt])
+    xq.backward(dy)
+    xb, G = _bits(x).reshape(-1), T * hidden // g
+    tag = f"bits={bits} gs={gs} hidden={hidden} sym={sym} dt={dt} T={T}"
+    if sym:
+        oxq, os_ = orc.int_act_fwd(xb, G, g, bits, a_dt=dt)
+        odx = orc.int_act_bwd(_bits(dy).reshape(-1), xb, G, g, bits, a_dt=dt)
+    else:
+        oxq, os_, ozp = orc.int_act_asym_fwd(xb, G, g, bits, a_dt=dt)
+        assert np.array_equal(ozp, zp.detach().reshape(-1).float().numpy()), tag
+        odx = orc.int_act_asym_bwd(_bits(dy).reshape(-1), xb, G, g, bits, a_dt=dt)
+    assert np.array_equal(os_, _bits(scale.reshape(-1))), tag
+    assert np.array_equal(oxq, _bits(xq).reshape(-1)), tag
+    ref = _bits(x.grad).reshape(-1)
+    same = odx == ref
+    finite = np.isfinite(orc.from_bits(ref, TD[dt]).float().numpy())
+    assert same[finite].mean() >= (1.0 if sym else 0.998), (tag, float(same[finite].mean()))
