@@ -16,7 +16,6 @@ from __future__ import annotations
 
 import json
 import os
-import random
 from typing import Dict, List, Optional, Union
 
 import torch
@@ -25,7 +24,6 @@ from .model_tuner import tune_blocks
 from .quantizer import SignRoundConfig, SignRoundQuantizer, SignRoundV2Quantizer
 from .schemes import SCHEME_KEYS, apply_scheme, expand_layer_config, layer_pattern_regex, resolve_scheme
 from .shard_writer import ShardWriter
-from .wrapper import WrapperWALayer
 
 
 class _StopForward(Exception):

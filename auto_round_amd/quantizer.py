@@ -24,14 +24,14 @@ import functools
 import copy
 import inspect
 import random
-from dataclasses import dataclass, field
-from typing import Any, Callable, Dict, List, Optional, Sequence, Union
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Union
 
 import torch
 
 from . import ops
 from .sign_sgd import SignSGD
-from .wrapper import (SignRoundOptimizedWrapperLinear, WrapperLinear, _quantizable, check_to_quantized, unwrapper_block,
+from .wrapper import (SignRoundOptimizedWrapperLinear, _quantizable, check_to_quantized, unwrapper_block,
                       update_block_global_scale_if_needed, wrapper_block)
 
 FLT_MAX = float(torch.finfo(torch.float32).max)

@@ -22,7 +22,6 @@ Algorithm extension (enable_alg_ext / SignRoundV2), pinned by tests/golden/searc
 """
 from __future__ import annotations
 
-import copy
 import random
 from typing import Dict, List, Optional
 

@@ -10,7 +10,6 @@ import copy
 import json
 import math
 import os
-import random
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +17,7 @@ import torch
 import transformers
 
 from auto_round_amd.autoround import AutoRound
-from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer, stack_samples
+from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
 from oracle import torch_ref as tr
 
 

@@ -192,3 +192,86 @@ def test_int_activation_fake_quant_equals_the_reference_on_random_cases(seed):
     same = odx == ref
     finite = np.isfinite(orc.from_bits(ref, TD[dt]).float().numpy())
     assert same[finite].mean() >= (1.0 if sym else 0.998), (tag, float(same[finite].mean()))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_init_scale_searches_equal_the_reference_on_random_cases(seed):
+    """search_scales (+ the search_int threshold clamp) and the fp4 coefficient searches of the algorithm extension, with a
+    random importance matrix, on weights of ordinary magnitude (the searches compare fp32 loss sums, so near-ties between
+    two candidates may resolve differently; everything else must be identical)."""
+    _ref()
+    from auto_round.data_type.int import search_scales
+    from auto_round.data_type.mxfp import search_mx_scale
+    from auto_round.data_type.nvfp import search_nvfp4_scale
+    from auto_round.data_type.utils import reshape_imatrix_for_weight, search_optimized_init_scale
+
+    rng = np.random.default_rng(5000 + seed)
+    cols = int(rng.choice([128, 256, 384]))
+    rows = int(rng.integers(4, 24))
+    imatrix = torch.from_numpy(((rng.random(cols) * 4.0 + 0.01) ** 2 * 100.0).astype(np.float32))
+    imatrix[int(rng.integers(0, cols))] = 0.0
+    W = torch.from_numpy((rng.standard_normal((rows, cols)) * 10.0 ** rng.uniform(-3, 0)).astype(np.float32)).to(torch.bfloat16)
+    W[0, :32] = 0.0
+    Wb = _bits(W).reshape(-1)
+    if seed % 2:
+        nb, gs = [(4, 128), (2, 32), (3, 64), (8, 128)][seed // 2 % 4]
+        Wg = W.reshape(-1, gs)
+        qw = reshape_imatrix_for_weight(imatrix, Wg, gs)
+        raw_ref = _bits(search_scales(Wg, nb, qw).reshape(-1))
+        init_ref = _bits(search_optimized_init_scale(Wg, "int_sym", nb, qw, 1e-5).reshape(-1))
+        ones_ref = _bits(search_optimized_init_scale(Wg, "int_sym", nb, None, 1e-5).reshape(-1))
+        raw, init = orc.search_int_scale(Wb, Wg.shape[0], gs, nb, qw_row=imatrix.numpy(), groups_per_row=cols // gs)
+        _, ones = orc.search_int_scale(Wb, Wg.shape[0], gs, nb)
+        assert (raw == raw_ref).mean() >= 0.99 and (init == init_ref).mean() >= 0.99 and (ones == ones_ref).mean() >= 0.99, (nb, gs)
+    else:
+        nv = bool(seed // 2 % 2)
+        gs, mode = (16, 1) if nv else (32, 0)
+        Wg = W.reshape(-1, gs)
+        qw = reshape_imatrix_for_weight(imatrix, Wg, gs)
+        fn = search_nvfp4_scale if nv else search_mx_scale
+        gsc = orc.nvfp4_global_scale(Wb) if nv else 1.0
+        for q, row in ((qw, imatrix.numpy()), (torch.ones_like(Wg, dtype=torch.float32), None)):
+            ref = fn(Wg, 4, q).reshape(-1).float().numpy()
+            best = orc.search_fp4_scale(Wb, Wg.shape[0], gs, mode, qw_row=row, groups_per_row=cols // gs, global_scale=gsc)
+            assert (best == ref).mean() >= 0.99, (nv, float((best == ref).mean()))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_losses_equal_the_reference_on_random_cases(seed):
+    """SignRoundQuantizer._get_loss (plain / valid-token mask) and SignRoundV2Quantizer._get_loss (outlier-suppressed) with
+    their x1000 backward, on random bf16 / fp16 activations."""
+    _ref()
+    from types import SimpleNamespace
+
+    from auto_round.algorithms.quantization.sign_round.quantizer import SignRoundQuantizer as RefQ
+    from auto_round.algorithms.quantization.sign_roundv2.quantizer import SignRoundV2Quantizer as V2
+
+    rng = np.random.default_rng(6000 + seed)
+    dt = orc.DT_F16 if seed % 3 == 2 else orc.DT_BF16
+    B, S, H = int(rng.integers(1, 5)), int(rng.choice([16, 48, 64])), int(rng.choice([64, 128]))
+    pred = torch.from_numpy(rng.standard_normal((B, S, H)).astype(np.float32) * 10.0 ** rng.uniform(-2, 1)).to(TD[dt])
+    ref = (pred.float() + 0.05 * pred.float().abs().mean() * torch.from_numpy(rng.standard_normal((B, S, H)).astype(np.float32))).to(TD[dt])
+    mask = [torch.ones(1, S, dtype=torch.long) for _ in range(B)]
+    for m in mask:
+        m[0, -1] = 0
+        m[0, int(rng.integers(0, S - 1))] = 0
+    mflat = torch.cat(mask).reshape(-1).numpy().astype(np.uint8)
+    fake = SimpleNamespace(model_context=SimpleNamespace(amp=True, amp_dtype=TD[dt]))
+    for m, mo in ((None, None), (mask, mflat)):
+        p2 = pred.detach().clone().requires_grad_(True)
+        loss = RefQ._get_loss(fake, p2, ref, list(range(B)), torch.nn.MSELoss(), "cpu", m)
+        (loss * 1000).backward()
+        lo, d = orc.mse_fwd_bwd(_bits(pred).reshape(-1), _bits(ref).reshape(-1), act_dt=dt, token_mask=mo, row_len=H)
+        assert abs(lo - loss.item()) <= 2e-6 * abs(loss.item())
+        a, b = orc.from_bits(d, TD[dt]).float().numpy(), p2.grad.float().numpy().reshape(-1)
+        assert np.array_equal(a, b), (seed, m is None)
+    if B * S * H >= 4000:        # the reference's top-0.1% drop needs at least a handful of elements to drop
+        fake2 = SimpleNamespace(_use_outlier_suppressed_loss=True, amp=True, amp_dtype=TD[dt])
+        p2 = pred.detach().clone().requires_grad_(True)
+        loss = V2._get_loss(fake2, p2, ref, list(range(B)), torch.nn.MSELoss(), "cpu", None)
+        (loss * 1000).backward()
+        lo, d, dropped = orc.outlier_mse_fwd_bwd(_bits(pred).reshape(-1), _bits(ref).reshape(-1), act_dt=dt)
+        assert dropped == max(1, B * S * H // 1000)
+        assert abs(lo - loss.item()) <= 2e-3 * abs(loss.item())
+        a, b = orc.from_bits(d, TD[dt]).float().numpy(), p2.grad.float().numpy().reshape(-1)
+        assert (a != b).sum() <= 4 and (a == 0).sum() == (b == 0).sum()

@@ -1,4 +1,4 @@
-import torch, time, sys
+import torch
 import torch.nn.functional as F
 def bench(fn, iters=10):
     for _ in range(3): fn()
