@@ -290,3 +290,21 @@ def test_front_door_plain_format_scheme_checks():
     ar.quantize()
     with pytest.raises(ValueError, match="weight-only INT"):
         ar.save_quantized("/tmp/never_written", format="auto_gptq")
+
+
+@pytest.mark.parametrize("kw", [dict(scheme="W4A16", group_size=32), dict(scheme="W2A16G32", sym=False, enable_alg_ext=True),
+                                dict(scheme="MXFP4")], ids=["w4g32", "w2g32_asym_alg_ext", "mxfp4"])
+def test_two_identical_front_door_runs_give_identical_weights(kw):
+    """Run-to-run determinism, the property the reference's test_autoround_acc.py:26-62 checks of its CPU path (`out0.equal(out1)`):
+    same seed, same data -> bit-identical tuned model."""
+    from auto_round_amd.autoround import AutoRound
+
+    outs = []
+    for rep in range(2):
+        tokens = torch.randint(0, 512, (8, 32), generator=torch.Generator().manual_seed(1))
+        ar = AutoRound(tiny_llama(), None, iters=8, nsamples=8, seqlen=32, batch_size=4, dataset=tokens, **kw)
+        m, _ = ar.quantize()
+        outs.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    for n, p in outs[0].items():
+        q = outs[1][n]
+        assert torch.equal(p.view(torch.int16) if p.dtype == torch.bfloat16 else p, q.view(torch.int16) if q.dtype == torch.bfloat16 else q), n
