@@ -55,6 +55,18 @@ class AutoRound:
                  enable_minmax_tuning: bool = True, gradient_accumulate_steps: int = 1, not_use_best_mse: bool = False,
                  dynamic_max_gap: int = -1, layer_config: Optional[Dict[str, dict]] = None, device_map=0, seed: int = 42,
                  amp: bool = True, **kwargs):
+        # the reference's memory / compilation knobs change how it runs, not what it computes: accepted and ignored here
+        # (everything of one block is resident in HBM, the fused kernels stand where torch.compile would)
+        for k in ("low_gpu_mem_usage", "low_cpu_mem_usage", "enable_torch_compile"):
+            kwargs.pop(k, None)
+        if kwargs.pop("platform", "hf") != "hf":
+            raise NotImplementedError("only Hugging Face models (platform='hf') are handled")
+        legacy_device = kwargs.pop("device", None)           # autoround.py:753-757: deprecated alias of device_map
+        if legacy_device is not None and device_map in (None, 0):
+            device_map = legacy_device
+        alg = kwargs.pop("algorithm", None) or kwargs.pop("alg_configs", None)
+        if alg is not None and str(alg).lower().replace("_", "") not in ("signround", "autoround"):
+            raise NotImplementedError(f"algorithm {alg!r}: this path implements SignRound (and its extension, enable_alg_ext=True)")
         if kwargs:
             raise TypeError(f"arguments outside the MI355X hot path: {sorted(kwargs)} (use the reference with auto_round_amd.plugin)")
         self.model, self.tokenizer = model, tokenizer
@@ -68,6 +80,10 @@ class AutoRound:
                     self.scheme[k] = v
         self.nsamples, self.seqlen, self.seed = nsamples, seqlen, seed
         self.dataset = dataset
+        if isinstance(device_map, str) and device_map.strip().isdigit():
+            device_map = int(device_map)
+        if device_map in (None, "auto", "cuda"):
+            device_map = 0
         self.device = torch.device("cuda", device_map) if isinstance(device_map, int) else torch.device(device_map)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError(f"AutoRound (MI355X path) needs a HIP device, got device_map={device_map!r} with "

@@ -88,7 +88,8 @@ def test_autoround_front_door_argument_errors():
     with pytest.raises(ValueError):
         AutoRound(model, None, scheme="FP8_STATIC", dataset=torch.zeros(1, 8, dtype=torch.long))
     with pytest.raises(TypeError):
-        AutoRound(model, None, low_gpu_mem_usage=True)
+        AutoRound(model, None, quant_lm_head=True)
+    AutoRound(model, None, low_gpu_mem_usage=True, enable_torch_compile=False, device="cuda:0")     # result-neutral knobs are accepted
     with pytest.raises(RuntimeError):
         AutoRound(model, None, dataset=torch.zeros(1, 8, dtype=torch.long)).save_quantized("/tmp/never")
 

@@ -82,6 +82,18 @@ def test_front_door_fails_loudly_without_a_hip_device():
         AutoRound(torch.nn.Linear(32, 32), None, dataset=torch.zeros(1, 8, dtype=torch.long))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         AutoRound(torch.nn.Linear(32, 32), None, device_map="cpu", dataset=torch.zeros(1, 8, dtype=torch.long))
+    # the reference's memory / compile knobs, its legacy `device` alias and an explicit SignRound request are accepted
+    # (the call gets as far as the device check); anything that would change the computation is refused up front
+    for extra in (dict(low_gpu_mem_usage=True, enable_torch_compile=False, low_cpu_mem_usage=True), dict(device="cuda:0"),
+                  dict(device_map="auto"), dict(device_map="0"), dict(algorithm="sign_round"), dict(platform="hf")):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            AutoRound(torch.nn.Linear(32, 32), None, dataset=torch.zeros(1, 8, dtype=torch.long), **extra)
+    with pytest.raises(NotImplementedError, match="SignRound"):
+        AutoRound(torch.nn.Linear(32, 32), None, algorithm="awq")
+    with pytest.raises(NotImplementedError, match="platform"):
+        AutoRound(torch.nn.Linear(32, 32), None, platform="model_scope")
+    with pytest.raises(TypeError, match="outside the MI355X hot path"):
+        AutoRound(torch.nn.Linear(32, 32), None, quant_lm_head=True)
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
