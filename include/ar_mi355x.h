@@ -65,7 +65,8 @@ int ar_qdq_int_fwd(const void* W, const float* V, const void* wmin, const void* 
                    int sym, int w_dt, int s_dt, float q_thresh, float lo_bound, float hi_bound, ar_stream_t stream);
 
 /* ---- INT fake-quant backward (unfused; for step-level parity tests) ------------------------------------------
- * replaces: torch autograd through the forward above.  dV [n_groups*gs], dmin/dmax
+ * replaces: torch autograd through quant_tensor_sym / quant_tensor_asym (auto_round/data_type/int.py:165-298; SURVEY
+ * 8-a12, App. A.3).  dV [n_groups*gs], dmin/dmax
  * [n_groups] fp32; any of the three may be NULL. */
 int ar_qdq_int_bwd(const void* dWq, const void* W, const float* V, const void* wmin, const void* wmax,
                    const float* min_s, const float* max_s, float* dV, float* dmin, float* dmax, int64_t n_groups,
@@ -191,6 +192,8 @@ int ar_qdq_fp4_fwd(const void* X, const float* V, const float* absmax, const flo
 /* init_scale_dev (optional, fp32 [n_groups]) replaces the scalar init_scale per group: the searched init scale of the
  * reference's algorithm extension (SignRoundOptimizedWrapperLinear, sign_roundv2/quantizer.py:101-126). */
 /* fused backward + sign-SGD for the fp4 weight path (V and max_scale); same contract as ar_qdq_int_bwd_sgd.
+ * replaces: torch autograd through quant_mx / nv_fp4 (auto_round/data_type/mxfp.py:233-291, nvfp.py:83-98) followed by
+ * SignSGD.step (algorithms/quantization/sign_round/sign_sgd.py:356-389).
  * dV_out/dmax_out (optional) additionally export the raw gradients for parity tests (then no update is applied
  * when lr_v_dev == NULL). */
 int ar_qdq_fp4_bwd_sgd(const void* dXq, const void* X, float* V, const float* absmax, float* max_s, float init_scale,

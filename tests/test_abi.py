@@ -103,3 +103,16 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libar_oracle" not in txt, f
+
+
+def test_every_entry_point_cites_its_reference_interface_and_is_documented():
+    """Each declaration in the header is preceded by a comment citing the reference file it replaces (or says it is binding
+    hygiene), and INTEGRATION.md's table names every exported symbol."""
+    src = open(HEADER).read()
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    for name in header_functions():
+        assert name in doc, f"{name} missing from INTEGRATION.md"
+        decl = re.search(r"\b(?:int64_t|int|const char\*)\s+" + name + r"\s*\(", src)
+        head = src[:decl.start()]
+        last_comment = head[head.rfind("/*"):]
+        assert re.search(r"\.py|hygiene|version|return code|scratch|workspace", last_comment), f"{name}: no reference citation in its header comment"
