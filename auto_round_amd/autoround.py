@@ -272,11 +272,18 @@ class AutoRound:
         return qc
 
     @torch.no_grad()
-    def save_quantized(self, output_dir: str, format: str = "auto_round", max_shard_bytes: int = 5 * 1024 ** 3):
+    def save_quantized(self, output_dir: str, format: str = "auto_round", inplace: bool = True,
+                       max_shard_bytes: int = 5 * 1024 ** 3, **kwargs):
         """Pack every tuned layer and write the checkpoint: safetensors shards (+ index), config.json with
         `quantization_config`, tokenizer files when a tokenizer was given.  Formats: "auto_round" (default; optionally with
         an explicit ":auto_gptq" / ":auto_awq" packing backend), and for INT schemes the plain "auto_gptq" and "auto_awq"
         layouts (export/formats/backends/auto_gptq.py, auto_awq.py)."""
+        # `inplace` (compressors/base.py save_quantized) only says whether the reference may splice its packed modules into
+        # the caller's model; the tensors written are the same, and this writer never alters the model
+        if kwargs.pop("safe_serialization", True) is not True:
+            raise NotImplementedError("checkpoints are written as safetensors")
+        if kwargs:
+            raise TypeError(f"save_quantized: unsupported arguments {sorted(kwargs)}")
         if format not in ("auto_round", "auto_round:auto_gptq", "auto_round:auto_awq", "auto_gptq", "auto_awq"):
             raise NotImplementedError(f"format {format!r}: the MI355X path writes auto_round, auto_gptq and auto_awq checkpoints")
         if not self.quantized:
@@ -336,9 +343,9 @@ class AutoRound:
             self.tokenizer.save_pretrained(output_dir)
         return index
 
-    def quantize_and_save(self, output_dir: str = "tmp_autoround", format: str = "auto_round", **kw):
+    def quantize_and_save(self, output_dir: str = "tmp_autoround", format: str = "auto_round", inplace: bool = True, **kw):
         model, _ = self.quantize()
-        self.save_quantized(output_dir, format=format, **kw)
+        self.save_quantized(output_dir, format=format, inplace=inplace, **kw)
         return model, output_dir
 
 
