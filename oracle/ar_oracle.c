@@ -249,7 +249,9 @@ void oracle_qdq_int_fwd(const void* W, const float* V, const void* wmin, const v
 
 /* ------------------------------------------------------------------------------------------
  * INT fake-quant backward, restating what torch autograd computes for the forward above, op by
- * op and dtype by dtype:
+ * op and dtype by dtype.
+ * reference: autograd through auto_round/data_type/int.py:165-238 (quant_tensor_sym), :241-298 (quant_tensor_asym) and
+ *            round_ste (auto_round/data_type/utils.py:314); the clamp bounds of WrapperLinear._qdq_weight (auto_round/wrapper.py:256-259):
  *   g        = float(dWq)                                     (.to(W.dtype) backward)
  *   e_k      = g_k * s                                        (MulBackward, other side)
  *   inside_k = lo_q <= r_k (+zp) <= hi_q (inclusive)          (ClampBackward)
@@ -612,7 +614,8 @@ void oracle_pack_fp4(const void* W, const void* scale, float global_scale, int64
     }
 }
 
-/* small utilities exported for the dtype-helper tests */
+/* small utilities exported for the dtype-helper tests: torch's own .to(bfloat16/float16/float8_e4m3fn) casts, which every
+ * reference function above goes through (known answers: the reference's test/unit/test_cpu/data_type/test_nvfp.py:52-64) */
 uint16_t oracle_f32_to_bf16(float f) { return f32_to_bf16_bits(f); }
 uint16_t oracle_f32_to_f16(float f) { return f32_to_f16_bits(f); }
 float oracle_f16_to_f32(uint16_t h) { return f16_bits_to_f32(h); }

@@ -35,7 +35,8 @@ def _ste(fn, x):
 
 def qdq_int(W2d, bits, gs, sym, v, min_scale, max_scale, wmin, wmax, scale_dtype=torch.float16, thresh=1e-5):
     """Fake-quant of a [out, in] weight with per-group scales; differentiable w.r.t. v, min_scale, max_scale.
-    Returns (Wq [out,in] in W dtype, scale [G,1], zp (int for sym, [G,1] tensor for asym))."""
+    Returns (Wq [out,in] in W dtype, scale [G,1], zp (int for sym, [G,1] tensor for asym)).
+    reference: auto_round/data_type/int.py:165-238 (quant_tensor_sym), :241-298 (quant_tensor_asym)"""
     out_f, in_f = W2d.shape
     pad = (-in_f) % gs          # zero-pad every row to a multiple of gs (data_type/utils.py:52-56), cut again at the end
     Wg = (F.pad(W2d, (0, pad)) if pad else W2d).reshape(-1, gs)
@@ -131,6 +132,7 @@ def _recip_eps(t):
 
 
 def int_search_grid(bits, ratio=0.75):
+    """reference: the candidate grid of search_scales, auto_round/data_type/int.py:40-59"""
     nmax = 2 ** (bits - 1)
     if bits == 2:
         n, step = 90, 0.01
@@ -143,7 +145,8 @@ def int_search_grid(bits, ratio=0.75):
 
 def search_int_scale(Wg, bits, qw=None, thresh=1e-5):
     """Per-group symmetric scale minimising the importance-weighted rounding error over the reference's grid of
-    numerators around nmax; everything in Wg's dtype.  Returns the clamped init scale [G, 1]."""
+    numerators around nmax; everything in Wg's dtype.  Returns the clamped init scale [G, 1].
+    reference: search_scales + search_int, auto_round/data_type/int.py:24-86, data_type/utils.py:203-209"""
     nmax, grid = int_search_grid(bits)
     idx = Wg.abs().argmax(dim=-1, keepdim=True)
     rg = _recip_eps(torch.take_along_dim(Wg, idx, dim=-1))
@@ -183,14 +186,16 @@ def _search_coeff(qdq_at, X32, cands, qw):
 
 
 def search_mx_coeff(Wg, qw=None):
-    """MXFP4: which of the coefficients 1, 0.5, 2 on the group max gives the smallest weighted error -> [G, 1] fp32."""
+    """MXFP4: which of the coefficients 1, 0.5, 2 on the group max gives the smallest weighted error -> [G, 1] fp32.
+    reference: search_mx_scale, auto_round/data_type/mxfp.py:103-170"""
     X32 = Wg.to(torch.float32)
     ones = torch.ones(Wg.shape[0], device=Wg.device)
     return _search_coeff(lambda c: qdq_mxfp4(X32, Wg.shape[-1], 0, ones * c)[0], X32, (1.0, 0.5, 2.0), qw)
 
 
 def search_nv_coeff(Wg, qw=None):
-    """NVFP4: coefficient in {1.0, 0.50 .. 1.51} on the group max (global scale = the tensor's own) -> [G, 1] fp32."""
+    """NVFP4: coefficient in {1.0, 0.50 .. 1.51} on the group max (global scale = the tensor's own) -> [G, 1] fp32.
+    reference: search_nvfp4_scale, auto_round/data_type/nvfp.py:329-386"""
     X32 = Wg.to(torch.float32)
     gsc = nvfp4_global_scale(X32)
     ones = torch.ones(Wg.shape[0], device=Wg.device)
@@ -200,7 +205,8 @@ def search_nv_coeff(Wg, qw=None):
 
 def outlier_loss(pred, ref, token_mask=None):
     """mean(((|pred-ref| in fp32) * token_mask * keep)^2), keep = all but the max(1, n/1000) largest |pred-ref| ranked in
-    the activation dtype (ties at the k-th value: whatever torch.topk picks)."""
+    the activation dtype (ties at the k-th value: whatever torch.topk picks).
+    reference: SignRoundV2Quantizer._get_loss, algorithms/quantization/sign_roundv2/quantizer.py:362-399"""
     d = (pred - ref).abs().view(-1)
     k = max(1, int(d.numel() / 1000))
     keep = torch.ones_like(d, dtype=torch.bool)
@@ -214,7 +220,8 @@ def outlier_loss(pred, ref, token_mask=None):
 @torch.no_grad()
 def collect_imatrix(block, inputs, input_others, batch_size=8, forward=None, amp_dtype=torch.bfloat16, amp=True):
     """Run the fp block over all samples and leave `imatrix` = sum over tokens of x^2 (fp32 [in]) on every layer that
-    will be quantised."""
+    will be quantised.
+    reference: the imatrix forward hooks, algorithms/quantization/sign_roundv2/quantizer.py:401-428"""
     def hook(m, inp, out):
         x = inp[0] if isinstance(inp, (tuple, list)) else inp
         sq = (x.reshape(-1, x.shape[-1]).to(torch.float32) ** 2).sum(dim=0)
@@ -230,6 +237,7 @@ def collect_imatrix(block, inputs, input_others, batch_size=8, forward=None, amp
 
 
 def nvfp4_global_scale(t):
+    """reference: calculate_gparam, auto_round/data_type/nvfp.py:56-64"""
     return 448.0 * 6.0 * _recip0(t.to(torch.float32).abs().max())
 
 
@@ -286,7 +294,8 @@ def act_fake_quant(x, layer):
 
 
 class RefWrapperLinear(torch.nn.Module):
-    """Plain-torch tuning wrapper around an nn.Linear carrying bits/group_size/sym/scale_dtype attributes."""
+    """Plain-torch tuning wrapper around an nn.Linear carrying bits/group_size/sym/scale_dtype attributes.
+    reference: WrapperLinear, auto_round/wrapper.py:139-293 (parameters, _qdq_weight), :517-565 (forward), :345-468 (unwrapper)"""
 
     def __init__(self, layer: torch.nn.Linear, enable_minmax_tuning=True):
         super().__init__()
@@ -359,7 +368,8 @@ class RefWrapperLinear(torch.nn.Module):
 
 class RefOptWrapperLinear(RefWrapperLinear):
     """Algorithm-extension wrapper: searched init scale (weighted by the layer's `imatrix`, consumed here), max_scale
-    tunes a coefficient on it within (0, 2), min_scale takes no part.  Symmetric int / mx_fp4 / nv_fp4."""
+    tunes a coefficient on it within (0, 2), min_scale takes no part.  Symmetric int / mx_fp4 / nv_fp4.
+    reference: SignRoundOptimizedWrapperLinear, algorithms/quantization/sign_roundv2/quantizer.py:101-161"""
 
     bounds = (0.0, 2.0)
 
@@ -411,6 +421,7 @@ class RefOptWrapperLinear(RefWrapperLinear):
 
 
 class RefWALayer(torch.nn.Module):
+    """reference: WrapperWALayer, auto_round/wrapper.py:568-612 (activation fake-quant shell left around a tuned layer)"""
     def __init__(self, layer):
         super().__init__()
         self.orig_layer = layer
@@ -420,6 +431,7 @@ class RefWALayer(torch.nn.Module):
 
 
 def wrap_block(block, enable_minmax_tuning=True, wrapper_cls=None) -> List[str]:
+    """reference: wrapper_block, auto_round/wrapper.py:774-828"""
     wrapper_cls = wrapper_cls or RefWrapperLinear
     names = []
     for n, m in list(block.named_modules()):
@@ -434,6 +446,7 @@ def wrap_block(block, enable_minmax_tuning=True, wrapper_cls=None) -> List[str]:
 
 
 def unwrap_block(block, best):
+    """reference: unwrapper_block, auto_round/wrapper.py:861-878"""
     for n, m in list(block.named_modules()):
         if isinstance(m, RefWrapperLinear):
             parent = block
@@ -445,6 +458,7 @@ def unwrap_block(block, best):
 
 @torch.no_grad()
 def sign_sgd_step(params, lr: float):
+    """reference: SignSGD._single_tensor_sgd, algorithms/quantization/sign_round/sign_sgd.py:356-389"""
     for p in params:
         if p.grad is not None:
             p.add_(torch.sign(p.grad), alpha=-lr)
@@ -452,7 +466,8 @@ def sign_sgd_step(params, lr: float):
 
 def linear_lr_stream(lr0: float, iters: int) -> List[float]:
     """The fp32 learning rates LinearLR(1.0 -> 0.0, total_iters=iters) hands to the optimizer, by running the real
-    torch scheduler on a dummy parameter (values are pinned by tests/golden/step_*.npz `lr_stream`)."""
+    torch scheduler on a dummy parameter (values are pinned by tests/golden/step_*.npz `lr_stream`).
+    reference: LinearLR(start_factor=1, end_factor=0, total_iters=iters), sign_round/quantizer.py:419-429"""
     p = torch.nn.Parameter(torch.zeros(1))
     opt = torch.optim.SGD([{"params": [p], "lr": torch.tensor(lr0)}], lr=lr0)
     sch = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=0.0, total_iters=iters)
@@ -485,7 +500,8 @@ def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others:
                lr=None, enable_minmax_tuning=True, amp_dtype=torch.bfloat16, forward=None, record=None,
                max_iters_to_run=None, input_ids=None, amp=True, alg_ext=False):
     """The reference's quantize_block loop in plain torch.  inputs/targets: [N, S, H].  Returns best_params and
-    leaves the block unwrapped with baked weights.  `forward(block, x, others)` defaults to block(x, **others)[0]."""
+    leaves the block unwrapped with baked weights.  `forward(block, x, others)` defaults to block(x, **others)[0].
+    reference: SignRoundQuantizer.quantize_block, algorithms/quantization/sign_round/quantizer.py:311-552"""
     use_outlier_loss = False
     wrapper_cls = RefWrapperLinear
     if alg_ext:     # SignRoundV2Quantizer.prepare_run: optimized wrapper for sym int/mx/nv; outlier loss for <4 bits / A4
