@@ -48,6 +48,10 @@ def get_block_names(model) -> List[List[str]]:
 
 
 class AutoRound:
+    """The reference's entry object for this path: `AutoRound(model, tokenizer, scheme=..., iters=..., ...)` with `quantize()`,
+    `save_quantized()`, `quantize_and_save()` (auto_round/autoround.py:732-793, compressors/base.py quantize / save_quantized /
+    quantize_and_save:1926-1990); arguments keep the reference's names, meaning and defaults."""
+
     def __init__(self, model, tokenizer=None, scheme: Union[str, dict] = "W4A16", *, bits=None, group_size=None, sym=None,
                  act_bits=None, act_group_size=None, act_sym=None, act_dynamic=None, act_data_type=None,
                  iters: int = 200, lr=None, minmax_lr=None, nsamples: int = 128, seqlen: int = 2048, batch_size: int = 8,

@@ -107,6 +107,9 @@ class WQLinear_GEMM(torch.nn.Module):
 
 
 class QuantLinearFP4(torch.nn.Module):
+    """reference: export/export_to_autoround/qlinear_fp.py:141-265 (`QuantLinear.pack`, `_pack_fp4_to_uint8`): MXFP4 / NVFP4 nibbles
+    in `weight_packed`, e8m0 / e4m3 `weight_scale`, NVFP4 `weight_global_scale` / `input_global_scale`."""
+
     def __init__(self, bits, group_size, infeatures, outfeatures, bias=False, data_type="mx_fp", **kwargs):
         super().__init__()
         if bits != 4:

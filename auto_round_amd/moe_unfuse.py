@@ -48,7 +48,8 @@ def _linear_loop_forward(self, hidden_states: torch.Tensor, top_k_index: torch.T
 
 @torch.no_grad()
 def unfuse_moe_experts(model: nn.Module) -> List[str]:
-    """Unfuse every standard fused-experts module under `model` in place.  Returns the names of the converted modules."""
+    """Unfuse every standard fused-experts module under `model` in place.  Returns the names of the converted modules.
+    reference: auto_round/modeling/fused_moe/moe_experts_interface.py ("linear_loop" experts)."""
     done = []
     for name, m in list(model.named_modules()):
         if not _is_fused_experts(m):

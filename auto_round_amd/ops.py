@@ -2,6 +2,20 @@
 and the CURRENT torch HIP stream to `libar_mi355x.so`, and returns.  No arithmetic happens in Python.
 
 PyTorch is plumbing only (device memory, streams); the kernels are the product.
+
+Which reference interface each wrapper stands for (paths relative to the auto-round tree; the C entry point of the same name
+in include/ar_mi355x.h carries the same citation):
+  group_minmax / group_absmax      weight_min/max of WrapperLinear._init_tuning_params_and_quant_func   auto_round/wrapper.py:154-164
+  qdq_int_fwd / qdq_int_bwd        quant_tensor_sym / quant_tensor_asym and their autograd              auto_round/data_type/int.py:165-298
+  sign_sgd_ / qdq_int_bwd_sgd_     SignSGD._single_tensor_sgd (+ collect_best_params)                   sign_round/sign_sgd.py:356-389, compressors/utils.py:205-217
+  mse_loss_fwd_bwd                 _get_loss + (loss * 1000).backward()                                 sign_round/quantizer.py:127-158,789-803
+  outlier_mse_loss_fwd_bwd         SignRoundV2Quantizer._get_loss                                       sign_roundv2/quantizer.py:362-399
+  best_loss_update                 best-loss bookkeeping                                                sign_round/quantizer.py:508-521
+  gather_rows                      minibatch gather of the cached activations                           algorithms/block_runner.py:368-422
+  pack_int / pack_awq / pack_fp4   QuantLinear.pack, WQLinear_GEMM.from_linear, qlinear_fp pack         auto_round_extension/torch/qlinear_torch[_zp].py, export/export_to_awq/utils.py:139-274, export/export_to_autoround/qlinear_fp.py:141-265
+  qdq_fp4_fwd / qdq_fp4_bwd_sgd_   quant_mx / nv_fp4 (+ autograd + SignSGD)                             data_type/mxfp.py:233-291, data_type/nvfp.py:56-98
+  fp4_act_bwd, qdq_int_act_fwd, int_act_bwd   WrapperLinear._qdq_act and its autograd                   auto_round/wrapper.py:295-321
+  search_int_scale / search_fp4_scale          search_scales, search_mx_scale, search_nvfp4_scale       data_type/int.py:24-86, mxfp.py:103-170, nvfp.py:329-386
 """
 from __future__ import annotations
 

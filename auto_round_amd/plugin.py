@@ -18,7 +18,8 @@ MI355XSignRoundQuantizer = None
 
 
 def register():
-    """Idempotent.  Raises ImportError when auto_round is not importable."""
+    """Idempotent.  Raises ImportError when auto_round is not importable.  Uses the reference's own registries:
+    `register_pipeline_member` / `register_algorithm` (auto_round/algorithms/registry.py:205-235,312-327)."""
     global MI355XSignRoundConfig, MI355XSignRoundQuantizer
     if MI355XSignRoundQuantizer is not None:
         return MI355XSignRoundConfig, MI355XSignRoundQuantizer

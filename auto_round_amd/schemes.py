@@ -32,7 +32,8 @@ SCHEME_KEYS = ("bits", "group_size", "sym", "data_type", "act_bits", "act_data_t
 
 
 def resolve_scheme(scheme="W4A16", **overrides) -> dict:
-    """Preset name (or a dict with the same keys) + explicit overrides (`bits=`, `group_size=`, `sym=`, ...; None = keep)."""
+    """Preset name (or a dict with the same keys) + explicit overrides (`bits=`, `group_size=`, `sym=`, ...; None = keep);
+    reference: PRESET_SCHEMES and scheme resolution, auto_round/schemes.py:538-832."""
     if isinstance(scheme, str):
         if scheme.upper() not in PRESET_SCHEMES:
             raise ValueError(f"scheme {scheme!r}: the MI355X path implements {sorted(PRESET_SCHEMES)}")

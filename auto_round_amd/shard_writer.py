@@ -26,6 +26,9 @@ def packed_state(prefix: str, module: torch.nn.Module) -> Dict[str, torch.Tensor
 
 
 class ShardWriter:
+    """reference: ShardWriter (auto_round/compressors/shard_writer.py:37): size-bounded safetensors shards written while the
+    run is still tuning later blocks, `model.safetensors.index.json` on close."""
+
     def __init__(self, out_dir: str, max_shard_bytes: int = 5 * 1024 ** 3, metadata: Optional[dict] = None):
         self.out_dir = out_dir
         self.max_shard_bytes = int(max_shard_bytes)

@@ -22,6 +22,9 @@ from . import ops
 
 
 class SignSGD(Optimizer):
+    """reference: SignSGD (algorithms/quantization/sign_round/sign_sgd.py:128; `step` :255-306) with `_single_tensor_sgd` (:356-389):
+    `param.add_(sign(grad), alpha=-lr)` per parameter group; here one fused backward + update launch per arena."""
+
     def __init__(self, params, lr=None, momentum=0, dampening=0, weight_decay=0, nesterov=False, *, maximize=False,
                  foreach=None, differentiable=False, arenas=None, fused=None):
         if lr is None:

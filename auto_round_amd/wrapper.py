@@ -144,7 +144,8 @@ class _IntActQdqFn(torch.autograd.Function):
 
 
 def act_fake_quant(x: torch.Tensor, layer) -> torch.Tensor:
-    """Activation fake-quant as configured on `layer` (act_bits / act_data_type / act_group_size / act_max)."""
+    """Activation fake-quant as configured on `layer` (act_bits / act_data_type / act_group_size / act_max); reference:
+    WrapperLinear._qdq_act (auto_round/wrapper.py:295-321) and WrapperWALayer.forward (:568-612)."""
     adt = str(getattr(layer, "act_data_type", ""))
     gs = getattr(layer, "act_group_size", 0)
     gs = int(gs) if gs is not None else 0
@@ -187,7 +188,9 @@ class WrapperWALayer(torch.nn.Module):
 
 
 class BlockArena:
-    """Block-wide flat HBM buffers for all layers that share (bits, group_size, sym, data_type, dtypes)."""
+    """Block-wide flat HBM buffers for all layers that share (bits, group_size, sym, data_type, dtypes): the storage behind
+    the per-layer `value` / `min_scale` / `max_scale` Parameters and `weight_min` / `weight_max` buffers the reference allocates
+    one WrapperLinear at a time (auto_round/wrapper.py:139-242)."""
 
     def __init__(self, key, device):
         (self.data_type, self.bits, self.gs, self.sym, self.w_dtype, self.scale_dtype, self.bounds, self.optimized) = key
