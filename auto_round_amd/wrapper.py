@@ -345,7 +345,8 @@ class BlockArena:
 
 
 class WrapperLinear(torch.nn.Module):
-    """Mirror of auto_round.wrapper.WrapperLinear (wrapper.py:62-565) for INT weight-only schemes.
+    """Mirror of auto_round.wrapper.WrapperLinear (wrapper.py:62-565): INT (W2/W3/W4/W8 sym + asym), MXFP4 and NVFP4 weights,
+    optional activation fake-quant (MXFP4 / NVFP4 / dynamic INT) in front of the GEMM.
 
     The wrapped layer must carry the scheme attributes the reference's `apply_plan_to_model` sets: `bits`,
     `group_size`, `sym`, `data_type`, `scale_dtype`, `act_bits` (compressors/layer_config/resolver.py:482-497).
