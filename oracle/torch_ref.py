@@ -293,6 +293,14 @@ def act_fake_quant(x, layer):
     raise NotImplementedError(adt)
 
 
+def _is_conv1d(m) -> bool:
+    try:
+        from transformers.pytorch_utils import Conv1D
+    except Exception:  # pragma: no cover
+        return False
+    return isinstance(m, Conv1D)
+
+
 class RefWrapperLinear(torch.nn.Module):
     """Plain-torch tuning wrapper around an nn.Linear carrying bits/group_size/sym/scale_dtype attributes.
     reference: WrapperLinear, auto_round/wrapper.py:139-293 (parameters, _qdq_weight), :517-565 (forward), :345-468 (unwrapper)"""
@@ -300,14 +308,16 @@ class RefWrapperLinear(torch.nn.Module):
     def __init__(self, layer: torch.nn.Linear, enable_minmax_tuning=True):
         super().__init__()
         self.orig_layer = layer
+        self.conv1d = _is_conv1d(layer)          # transformers' Conv1D keeps its weight as [in, out] (wrapper.py:150-151)
         self.bits, self.sym = int(layer.bits), bool(layer.sym)
         self.data_type = str(getattr(layer, "data_type", "int"))
         self.act_quant = int(getattr(layer, "act_bits", 16)) <= 8
         gs = int(layer.group_size)
-        self.gs = layer.in_features if (gs == -1 or layer.in_features < gs) else gs
+        W = layer.weight.data.t() if self.conv1d else layer.weight.data
+        in_features = W.shape[1]
+        self.gs = in_features if (gs == -1 or in_features < gs) else gs
         self.scale_dtype = getattr(layer, "scale_dtype", torch.float16)
         self.thresh = 1e-8 if self.scale_dtype == torch.float32 else 1e-5
-        W = layer.weight.data
         pad = (-W.shape[1]) % self.gs
         Wg = (F.pad(W, (0, pad)) if pad else W).reshape(-1, self.gs)
         self.wmin = torch.clamp(Wg.min(1)[0], max=0)
@@ -328,6 +338,10 @@ class RefWrapperLinear(torch.nn.Module):
         mx = self.max_scale if mx is None else mx
         mn.data.clamp_(0, 1)
         mx.data.clamp_(0, 1)
+        if self.conv1d:          # quantise the [out, in] view, hand back the stored orientation (wrapper.py:263-264, :291-292)
+            wq, s, zp = qdq_int(self.orig_layer.weight.t(), self.bits, self.gs, self.sym, v, mn, mx, self.wmin, self.wmax,
+                                self.scale_dtype, self.thresh)
+            return wq.t(), s, zp
         W = self.orig_layer.weight
         if self.data_type.startswith("mx_fp"):
             wq, se = qdq_mxfp4(W, self.gs, v, mx)
@@ -347,6 +361,9 @@ class RefWrapperLinear(torch.nn.Module):
         wq, _, _ = self.qdq()
         if self.act_quant:
             x = act_fake_quant(x, self.orig_layer)
+        if self.conv1d:          # conv1d_forward (wrapper.py:501-515)
+            out = torch.addmm(self.orig_layer.bias, x.view(-1, x.size(-1)), wq)
+            return out.view(*x.size()[:-1], self.orig_layer.nf)
         return F.linear(x, wq, self.orig_layer.bias)
 
     def unwrap(self, best: Optional[Dict[str, torch.Tensor]]):
@@ -358,7 +375,7 @@ class RefWrapperLinear(torch.nn.Module):
         with torch.no_grad():
             wq, s, zp = self.qdq(v, mn, mx)
             self.orig_layer.weight.data.copy_(wq)
-        out_f = self.orig_layer.weight.shape[0]
+        out_f = self.orig_layer.weight.shape[1] if self.conv1d else self.orig_layer.weight.shape[0]
         self.orig_layer.scale = s.reshape(out_f, -1).cpu()
         self.orig_layer.zp = zp.reshape(out_f, -1).cpu() if isinstance(zp, torch.Tensor) else zp
         if self.act_quant:
@@ -435,7 +452,7 @@ def wrap_block(block, enable_minmax_tuning=True, wrapper_cls=None) -> List[str]:
     wrapper_cls = wrapper_cls or RefWrapperLinear
     names = []
     for n, m in list(block.named_modules()):
-        if isinstance(m, torch.nn.Linear) and int(getattr(m, "bits", 16)) < 16:
+        if (isinstance(m, torch.nn.Linear) or _is_conv1d(m)) and int(getattr(m, "bits", 16)) < 16:
             parent = block
             parts = n.split(".")
             for p in parts[:-1]:

@@ -46,6 +46,33 @@ def _tiny():
     return LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
 
 
+def _tiny_opt():
+    """The north-star's model family (OPT: learned positions, biases on every projection, ReLU MLP, model.decoder.layers)."""
+    from transformers import OPTConfig, OPTForCausalLM
+
+    torch.manual_seed(0)
+    cfg = OPTConfig(hidden_size=64, ffn_dim=128, num_attention_heads=4, num_hidden_layers=2, vocab_size=64,
+                    max_position_embeddings=32, word_embed_proj_dim=64)
+    cfg._attn_implementation = "sdpa"
+    return OPTForCausalLM(cfg).to(torch.bfloat16).eval()
+
+
+def _tiny_gpt2():
+    """GPT-2: Conv1D projections (weights stored [in, out]), fused qkv, transformer.h."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    torch.manual_seed(0)
+    cfg = GPT2Config(n_embd=64, n_head=4, n_layer=2, n_inner=128, vocab_size=64, n_positions=32)
+    cfg._attn_implementation = "sdpa"
+    return GPT2LMHeadModel(cfg).to(torch.bfloat16).eval()
+
+
+def _layers(model):
+    if hasattr(model, "transformer"):
+        return model.transformer.h
+    return model.model.decoder.layers if hasattr(model.model, "decoder") else model.model.layers
+
+
 def _tiny_moe(experts=4, top_k=2):
     from transformers import MixtralConfig, MixtralForCausalLM
 
@@ -59,9 +86,11 @@ def _tiny_moe(experts=4, top_k=2):
 
 @pytest.mark.parametrize("kw", [dict(scheme="W4A16", group_size=32), dict(scheme="W2A16G32", sym=False), dict(scheme="MXFP4"),
                                 dict(scheme="W2A16G32", enable_alg_ext=True), dict(scheme="NVFP4", enable_alg_ext=True),
-                                dict(scheme="W4A16", group_size=32, moe=True), dict(scheme="NVFP4", moe=(24, 1))],
+                                dict(scheme="W4A16", group_size=32, moe=True), dict(scheme="NVFP4", moe=(24, 1)),
+                                dict(scheme="W4A16", group_size=32, arch="opt"), dict(scheme="W2A16G32", sym=False, arch="opt"),
+                                dict(scheme="W4A16", group_size=32, arch="gpt2")],
                          ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32",
-                              "mixtral_nvfp4_idle_experts"])
+                              "mixtral_nvfp4_idle_experts", "opt_w4g32", "opt_w2g32_asym", "gpt2_conv1d_w4g32"])
 def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monkeypatch):
     shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
     sys.dont_write_bytecode = True
@@ -75,7 +104,8 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
     monkeypatch.chdir(tmp_path)                      # the reference writes ./ar_work_space
     kw = dict(kw)
     moe = kw.pop("moe", False)
-    base = (_tiny_moe(*moe) if isinstance(moe, tuple) else _tiny_moe()) if moe else _tiny()
+    arch = kw.pop("arch", "llama")
+    base = (_tiny_moe(*moe) if isinstance(moe, tuple) else _tiny_moe()) if moe else ({"opt": _tiny_opt, "gpt2": _tiny_gpt2, "llama": _tiny}[arch]())
     tokens = torch.randint(0, 64, (8, 16), generator=torch.Generator().manual_seed(1))
     iters, bs, S = 3, 4, 16
 
@@ -93,16 +123,18 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
         assert len(unfuse_moe_experts(m)) == 2
     for p in m.parameters():
         p.requires_grad_(False)
-    blocks = list(m.model.layers)
+    blocks = list(_layers(m))
     alg_ext = bool(kw.get("enable_alg_ext", False))
     sch = resolve_scheme(**{k: v for k, v in kw.items() if k != "enable_alg_ext"})
     for b in blocks:
         apply_scheme(b, sch)
     _, n_filled = run_flow(m, blocks, tokens, sch, iters=iters, bs=bs, alg_ext=alg_ext, moe=bool(moe), reference_mask=True)
 
-    lin_ref = {n: p for n, p in q_ref.model.layers.named_modules() if isinstance(p, torch.nn.Linear)}
-    lin_mine = {n: p for n, p in m.model.layers.named_modules() if isinstance(p, torch.nn.Linear)}
-    assert set(lin_ref) == set(lin_mine) and len(lin_ref) >= 14
+    from transformers.pytorch_utils import Conv1D
+
+    lin_ref = {n: p for n, p in _layers(q_ref).named_modules() if isinstance(p, (torch.nn.Linear, Conv1D))}
+    lin_mine = {n: p for n, p in _layers(m).named_modules() if isinstance(p, (torch.nn.Linear, Conv1D))}
+    assert set(lin_ref) == set(lin_mine) and len(lin_ref) >= 8
     if isinstance(moe, tuple):
         assert n_filled > 0, "the case is meant to contain experts without calibration tokens"
     for n, p1 in lin_ref.items():
