@@ -67,6 +67,25 @@ def _tiny_gpt2():
     return GPT2LMHeadModel(cfg).to(torch.bfloat16).eval()
 
 
+def _tiny_hf(kind):
+    """Other decoder families through the same flow: Qwen2 (q/k/v biases), Qwen3 (q/k norms), Qwen3-MoE (fused 3-D experts)."""
+    import transformers as T
+
+    torch.manual_seed(0)
+    common = dict(hidden_size=64, intermediate_size=128, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=2,
+                  vocab_size=64, max_position_embeddings=32, tie_word_embeddings=False)
+    if kind == "qwen2":
+        cfg, cls = T.Qwen2Config(**common), T.Qwen2ForCausalLM
+    elif kind == "qwen3":
+        cfg, cls = T.Qwen3Config(head_dim=16, **common), T.Qwen3ForCausalLM
+    else:
+        cfg = T.Qwen3MoeConfig(head_dim=16, moe_intermediate_size=64, num_experts=4, num_experts_per_tok=2, decoder_sparse_step=1,
+                               mlp_only_layers=[], **common)
+        cls = T.Qwen3MoeForCausalLM
+    cfg._attn_implementation = "sdpa"
+    return cls(cfg).to(torch.bfloat16).eval()
+
+
 def _layers(model):
     if hasattr(model, "transformer"):
         return model.transformer.h
@@ -88,9 +107,10 @@ def _tiny_moe(experts=4, top_k=2):
                                 dict(scheme="W2A16G32", enable_alg_ext=True), dict(scheme="NVFP4", enable_alg_ext=True),
                                 dict(scheme="W4A16", group_size=32, moe=True), dict(scheme="NVFP4", moe=(24, 1)),
                                 dict(scheme="W4A16", group_size=32, arch="opt"), dict(scheme="W2A16G32", sym=False, arch="opt"),
-                                dict(scheme="W4A16", group_size=32, arch="gpt2")],
+                                dict(scheme="W4A16", group_size=32, arch="gpt2"), dict(scheme="W4A16", group_size=32, arch="qwen2"),
+                                dict(scheme="W4A16", group_size=32, arch="qwen3"), dict(scheme="W4A16", group_size=32, arch="qwen3_moe", moe_arch=True)],
                          ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32",
-                              "mixtral_nvfp4_idle_experts", "opt_w4g32", "opt_w2g32_asym", "gpt2_conv1d_w4g32"])
+                              "mixtral_nvfp4_idle_experts", "opt_w4g32", "opt_w2g32_asym", "gpt2_conv1d_w4g32", "qwen2_w4g32", "qwen3_w4g32", "qwen3_moe_w4g32"])
 def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monkeypatch):
     shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
     sys.dont_write_bytecode = True
@@ -105,7 +125,11 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
     kw = dict(kw)
     moe = kw.pop("moe", False)
     arch = kw.pop("arch", "llama")
-    base = (_tiny_moe(*moe) if isinstance(moe, tuple) else _tiny_moe()) if moe else ({"opt": _tiny_opt, "gpt2": _tiny_gpt2, "llama": _tiny}[arch]())
+    moe = moe or kw.pop("moe_arch", False)
+    if arch in ("qwen2", "qwen3", "qwen3_moe"):
+        base = _tiny_hf(arch)
+    else:
+        base = (_tiny_moe(*moe) if isinstance(moe, tuple) else _tiny_moe()) if moe else ({"opt": _tiny_opt, "gpt2": _tiny_gpt2, "llama": _tiny}[arch]())
     tokens = torch.randint(0, 64, (8, 16), generator=torch.Generator().manual_seed(1))
     iters, bs, S = 3, 4, 16
 
