@@ -108,9 +108,11 @@ def _tiny_moe(experts=4, top_k=2):
                                 dict(scheme="W4A16", group_size=32, moe=True), dict(scheme="NVFP4", moe=(24, 1)),
                                 dict(scheme="W4A16", group_size=32, arch="opt"), dict(scheme="W2A16G32", sym=False, arch="opt"),
                                 dict(scheme="W4A16", group_size=32, arch="gpt2"), dict(scheme="W4A16", group_size=32, arch="qwen2"),
-                                dict(scheme="W4A16", group_size=32, arch="qwen3"), dict(scheme="W4A16", group_size=32, arch="qwen3_moe", moe_arch=True)],
+                                dict(scheme="W4A16", group_size=32, arch="qwen3"), dict(scheme="W4A16", group_size=32, arch="qwen3_moe", moe_arch=True),
+                                dict(scheme="W4A16", group_size=32, act_bits=8), dict(scheme="INT8"), dict(scheme="W3A16", group_size=32),
+                                dict(scheme="W8A16", group_size=32)],
                          ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32",
-                              "mixtral_nvfp4_idle_experts", "opt_w4g32", "opt_w2g32_asym", "gpt2_conv1d_w4g32", "qwen2_w4g32", "qwen3_w4g32", "qwen3_moe_w4g32"])
+                              "mixtral_nvfp4_idle_experts", "opt_w4g32", "opt_w2g32_asym", "gpt2_conv1d_w4g32", "qwen2_w4g32", "qwen3_w4g32", "qwen3_moe_w4g32", "w4a8_int_act", "int8_w8a8", "w3g32", "w8g32"])
 def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monkeypatch):
     shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
     sys.dont_write_bytecode = True
@@ -150,6 +152,10 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
     blocks = list(_layers(m))
     alg_ext = bool(kw.get("enable_alg_ext", False))
     sch = resolve_scheme(**{k: v for k, v in kw.items() if k != "enable_alg_ext"})
+    if (sch.get("act_bits") or 16) <= 8:      # unset activation fields follow the weights', as in the product's front door
+        for k, v in (("act_data_type", sch["data_type"]), ("act_sym", sch["sym"]), ("act_dynamic", True), ("act_group_size", sch["group_size"])):
+            if sch.get(k) is None:
+                sch[k] = v
     for b in blocks:
         apply_scheme(b, sch)
     _, n_filled = run_flow(m, blocks, tokens, sch, iters=iters, bs=bs, alg_ext=alg_ext, moe=bool(moe), reference_mask=True)
