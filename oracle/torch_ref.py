@@ -515,7 +515,8 @@ class Sampler:
 
 def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others: dict, *, iters=200, batch_size=8,
                lr=None, enable_minmax_tuning=True, amp_dtype=torch.bfloat16, forward=None, record=None,
-               max_iters_to_run=None, input_ids=None, amp=True, alg_ext=False):
+               max_iters_to_run=None, input_ids=None, amp=True, alg_ext=False, gradient_accumulate_steps=1, minmax_lr=None,
+               not_use_best_mse=False, dynamic_max_gap=-1):
     """The reference's quantize_block loop in plain torch.  inputs/targets: [N, S, H].  Returns best_params and
     leaves the block unwrapped with baked weights.  `forward(block, x, others)` defaults to block(x, **others)[0].
     reference: SignRoundQuantizer.quantize_block, algorithms/quantization/sign_round/quantizer.py:311-552"""
@@ -530,11 +531,18 @@ def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others:
     wrappers = {n: m for n, m in block.named_modules() if isinstance(m, RefWrapperLinear)}
     lr0 = lr if lr is not None else 1.0 / iters
     lrs = linear_lr_stream(lr0, iters)
-    params = [p for w in wrappers.values() for p in w.params.values()]
-    sampler = Sampler(inputs.shape[0], min(batch_size, inputs.shape[0]))
+    lrs_mm = lrs if minmax_lr is None else linear_lr_stream(minmax_lr, iters)     # minmax_lr defaults to lr (config.py:110-140)
+    params_v = [p for w in wrappers.values() for k, p in w.params.items() if k == "value"]
+    params_mm = [p for w in wrappers.values() for k, p in w.params.items() if k != "value"]
+    params = params_v + params_mm
+    # micro-batches: the sampler draws global batches of batch_size * gradient_accumulate_steps, the loss becomes a SUM that is
+    # normalised for reporting only, the gradient accumulates over the micro-batches (quantizer.py:436-452, :470-500)
+    accum = gradient_accumulate_steps != 1
+    global_bs = min(inputs.shape[0], batch_size * gradient_accumulate_steps)
+    sampler = Sampler(inputs.shape[0], global_bs)
     dev_type = inputs.device.type
     best_loss, best, last_best = float(torch.finfo(torch.float32).max), {}, 0
-    mse = torch.nn.MSELoss()
+    mse = torch.nn.MSELoss(reduction="sum" if accum else "mean")
     losses = []
     run = iters if max_iters_to_run is None else min(iters, max_iters_to_run)
     vmask = None
@@ -544,31 +552,45 @@ def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others:
         if not bool(vm.all()):
             vmask = vm.to(inputs.device)
     for i in range(run):
-        idx = sampler.next_batch()
-        x = inputs[idx]
-        ref = targets[idx]
-        with torch.autocast(device_type=dev_type, dtype=amp_dtype, enabled=amp):
-            out = forward(block, x, input_others) if forward else block(x, **input_others)
-            if isinstance(out, (tuple, list)):
-                out = out[0]
-        if use_outlier_loss:
-            loss = outlier_loss(out, ref.to(out.dtype), None if vmask is None else vmask[idx].unsqueeze(-1))
-            total = loss.item() / (1 if vmask is None else max(1, int(torch.count_nonzero(vmask[idx]).item())))
-        elif vmask is not None:
-            m = vmask[idx].unsqueeze(-1)
-            loss = mse((out * m).to(torch.float32), (ref * m).to(torch.float32))
-            total = loss.item() / max(1, int(torch.count_nonzero(vmask[idx]).item()))
-        else:
-            loss = mse(out.to(torch.float32), ref.to(torch.float32))
-            total = loss.item()
-        (loss * 1000).backward()
+        gidx = sampler.next_batch()
+        num_elm = 1
+        if vmask is not None:
+            num_elm = int(torch.count_nonzero(vmask[gidx]).item())
+        elif accum:
+            num_elm = global_bs * inputs[0].numel()
+        total = 0.0
+        for b0 in range(0, len(gidx), batch_size):
+            idx = gidx[b0:b0 + batch_size]
+            x = inputs[idx]
+            ref = targets[idx]
+            with torch.autocast(device_type=dev_type, dtype=amp_dtype, enabled=amp):
+                out = forward(block, x, input_others) if forward else block(x, **input_others)
+                if isinstance(out, (tuple, list)):
+                    out = out[0]
+            if use_outlier_loss:
+                loss = outlier_loss(out, ref.to(out.dtype), None if vmask is None else vmask[idx].unsqueeze(-1))
+            elif vmask is not None:
+                m = vmask[idx].unsqueeze(-1)
+                loss = mse((out * m).to(torch.float32), (ref * m).to(torch.float32))
+            else:
+                loss = mse(out.to(torch.float32), ref.to(torch.float32))
+            num_elm = 1 if num_elm <= 0 else num_elm
+            total += loss.item() / num_elm
+            (loss * 1000).backward()
         losses.append(total)
         if total < best_loss:
-            best_loss, last_best = total, i
+            best_loss = total
+            if not not_use_best_mse:
+                last_best = i
+                best = {n: {k: p.data.clone() for k, p in w.params.items()} for n, w in wrappers.items()}
+        if not_use_best_mse and i == iters - 1:        # the parameters as they stand BEFORE the last step (quantizer.py:513-514)
             best = {n: {k: p.data.clone() for k, p in w.params.items()} for n, w in wrappers.items()}
         if record is not None:
             record(i, wrappers, total)
-        sign_sgd_step(params, lrs[i])
+        if not not_use_best_mse and 0 < dynamic_max_gap <= i - last_best:
+            break
+        sign_sgd_step(params_v, lrs[i])
+        sign_sgd_step(params_mm, lrs_mm[i])
         for p in params:
             p.grad = None
     unwrap_block(block, best)

@@ -23,7 +23,8 @@ def reference_cached_mask(S, device="cpu"):
     return m.to(torch.bfloat16).reshape(1, 1, S, S)
 
 
-def run_flow(model, blocks, tokens, scheme, *, iters, bs, alg_ext=False, moe=False, reference_mask=False, seed=42):
+def run_flow(model, blocks, tokens, scheme, *, iters, bs, alg_ext=False, moe=False, reference_mask=False, seed=42,
+             quanted_input=True, tune_kw=None):
     """Tunes `blocks` of `model` in place (scheme attributes must already be on the linears).  Returns per-block
     (init_loss, best_loss) and the number of MoE layers whose act_max had to be filled in."""
     import transformers
@@ -81,7 +82,7 @@ def run_flow(model, blocks, tokens, scheme, *, iters, bs, alg_ext=False, moe=Fal
         if alg_ext:          # the imatrix hooks fire during the reference (fp-input) forward
             tr.collect_imatrix(blk, fp_in, others, batch_size=bs, forward=fwd)
         fp_out = forward_all(blk, fp_in)
-        xin = q_in if q_in is not None else fp_in
+        xin = q_in if (q_in is not None and quanted_input) else fp_in
         if str(scheme.get("act_data_type", "")).startswith("nv_fp"):   # static activation scales + unified weight global scales
             hooks = register_act_max_hooks(blk)                 # composer.py:430-436: collected on the quantised-input forward
             forward_all(blk, xin)
@@ -90,8 +91,10 @@ def run_flow(model, blocks, tokens, scheme, *, iters, bs, alg_ext=False, moe=Fal
             if moe:          # experts that saw no calibration token inherit their siblings' maximum
                 n_filled += set_amax_for_uncalibrated_experts(blk)
             update_block_global_scale_if_needed(blk)
-        _, info = tr.tune_block(blk, xin, fp_out, others, iters=iters, batch_size=bs, forward=fwd, input_ids=ids, alg_ext=alg_ext)
+        _, info = tr.tune_block(blk, xin, fp_out, others, iters=iters, batch_size=bs, forward=fwd, input_ids=ids, alg_ext=alg_ext,
+                                **(tune_kw or {}))
         stats.append((info["losses"][0], info["best_loss"]))
-        q_in = forward_all(blk, xin)
+        if quanted_input:        # composer.py:476-481: the next block is tuned on this block's quantised output
+            q_in = forward_all(blk, xin)
         fp_in = fp_out
     return stats, n_filled

@@ -110,9 +110,16 @@ def _tiny_moe(experts=4, top_k=2):
                                 dict(scheme="W4A16", group_size=32, arch="gpt2"), dict(scheme="W4A16", group_size=32, arch="qwen2"),
                                 dict(scheme="W4A16", group_size=32, arch="qwen3"), dict(scheme="W4A16", group_size=32, arch="qwen3_moe", moe_arch=True),
                                 dict(scheme="W4A16", group_size=32, act_bits=8), dict(scheme="INT8"), dict(scheme="W3A16", group_size=32),
-                                dict(scheme="W8A16", group_size=32)],
+                                dict(scheme="W8A16", group_size=32),
+                                dict(scheme="W4A16", group_size=32, gradient_accumulate_steps=2),
+                                dict(scheme="W4A16", group_size=32, not_use_best_mse=True),
+                                dict(scheme="W4A16", group_size=32, enable_minmax_tuning=False),
+                                dict(scheme="W4A16", group_size=32, enable_quanted_input=False),
+                                dict(scheme="W2A16G32", lr=5e-3, minmax_lr=2e-3),
+                                dict(scheme="W2A16G32", iters=6, dynamic_max_gap=1)],
                          ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32",
-                              "mixtral_nvfp4_idle_experts", "opt_w4g32", "opt_w2g32_asym", "gpt2_conv1d_w4g32", "qwen2_w4g32", "qwen3_w4g32", "qwen3_moe_w4g32", "w4a8_int_act", "int8_w8a8", "w3g32", "w8g32"])
+                              "mixtral_nvfp4_idle_experts", "opt_w4g32", "opt_w2g32_asym", "gpt2_conv1d_w4g32", "qwen2_w4g32", "qwen3_w4g32", "qwen3_moe_w4g32", "w4a8_int_act", "int8_w8a8", "w3g32", "w8g32", "grad_accumulate_2", "last_iterate",
+                              "no_minmax_tuning", "fp_input_chain", "explicit_lrs", "early_stop"])
 def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monkeypatch):
     shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
     sys.dont_write_bytecode = True
@@ -133,12 +140,17 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
     else:
         base = (_tiny_moe(*moe) if isinstance(moe, tuple) else _tiny_moe()) if moe else ({"opt": _tiny_opt, "gpt2": _tiny_gpt2, "llama": _tiny}[arch]())
     tokens = torch.randint(0, 64, (8, 16), generator=torch.Generator().manual_seed(1))
-    iters, bs, S = 3, 4, 16
+    iters, bs, S = kw.pop("iters", 3), 4, 16
+    loop_kw = {k: kw.pop(k) for k in ("gradient_accumulate_steps", "not_use_best_mse", "enable_minmax_tuning", "lr", "minmax_lr",
+                                      "dynamic_max_gap") if k in kw}
+    quanted_input = kw.pop("enable_quanted_input", True)
+    if loop_kw.get("gradient_accumulate_steps", 1) != 1:
+        bs = 2                                       # 2 micro-batches of 2 = the same global batch of 4
 
     # --- the reference, front door to tuned weights
     m_ref = copy.deepcopy(base)
     ar = AutoRound(m_ref, tokenizer=_StubTokenizer(), iters=iters, nsamples=8, seqlen=S, dataset=_Loader(tokens), device_map="cpu",
-                   batch_size=bs, enable_torch_compile=False, **kw)
+                   batch_size=bs, enable_torch_compile=False, enable_quanted_input=quanted_input, **loop_kw, **kw)
     q_ref, _ = ar.quantize()
 
     # --- the same flow with the restatement
@@ -158,7 +170,8 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
                 sch[k] = v
     for b in blocks:
         apply_scheme(b, sch)
-    _, n_filled = run_flow(m, blocks, tokens, sch, iters=iters, bs=bs, alg_ext=alg_ext, moe=bool(moe), reference_mask=True)
+    _, n_filled = run_flow(m, blocks, tokens, sch, iters=iters, bs=bs, alg_ext=alg_ext, moe=bool(moe), reference_mask=True,
+                           quanted_input=quanted_input, tune_kw=loop_kw)
 
     from transformers.pytorch_utils import Conv1D
 
