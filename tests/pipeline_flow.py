@@ -11,6 +11,12 @@ from oracle import torch_ref as tr
 
 
 def fwd(blk, x, others):
+    n = others.get("_materialise_rows")
+    if n:        # reference-mask mode: every shared tensor is materialised at the batch's own row count (see run_flow)
+        rows = x.shape[0]
+        others = {k: (tuple(t.expand(rows, *t.shape[1:]).contiguous() for t in v) if isinstance(v, tuple) else
+                      (v.expand(rows, *v.shape[1:]).contiguous() if isinstance(v, torch.Tensor) and v.dim() and v.shape[0] == 1 else v))
+                  for k, v in others.items() if k != "_materialise_rows"}
     out = blk(x, **others)
     return out[0] if isinstance(out, (tuple, list)) else out
 
@@ -59,11 +65,10 @@ def run_flow(model, blocks, tokens, scheme, *, iters, bs, alg_ext=False, moe=Fal
     x0 = torch.cat(captured, 0)
     if reference_mask:
         others["attention_mask"] = reference_cached_mask(S, device)
-        # the reference concatenates its per-sample cache entries into batch-sized tensors; a broadcast [1, ...] mask takes
-        # another CPU SDPA path whose last-bit differences are enough to move the algorithm extension's importance matrix
-        others = {k: (tuple(t.expand(bs, *t.shape[1:]).contiguous() for t in v) if isinstance(v, tuple) else
-                      (v.expand(bs, *v.shape[1:]).contiguous() if isinstance(v, torch.Tensor) and v.dim() and v.shape[0] == 1 else v))
-                  for k, v in others.items()}
+        # the reference concatenates its per-sample cache entries into tensors with one row per sample of the batch; a broadcast
+        # [1, ...] mask takes another CPU SDPA path whose last-bit differences are enough to move the algorithm extension's
+        # importance matrix -> fwd() materialises the shared tensors per call (ragged last batches included)
+        others["_materialise_rows"] = True
     ids = tokens.clone()
     ids[:, -1] = -100
 
