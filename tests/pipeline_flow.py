@@ -83,6 +83,18 @@ def run_flow(model, blocks, tokens, scheme, *, iters, bs, alg_ext=False, moe=Fal
     transformers.set_seed(seed)
     stats, n_filled = [], 0
     fp_in, q_in = x0, None
+    tr.RefWALayer.follow_reference_ignored_act_max = bool(reference_mask)      # see the note on RefWALayer
+    try:
+        return _run_blocks(blocks, fp_in, q_in, others, scheme, iters, bs, alg_ext, moe, quanted_input, tune_kw, ids, forward_all,
+                           stats, n_filled)
+    finally:
+        tr.RefWALayer.follow_reference_ignored_act_max = False
+
+
+def _run_blocks(blocks, fp_in, q_in, others, scheme, iters, bs, alg_ext, moe, quanted_input, tune_kw, ids, forward_all, stats, n_filled):
+    from auto_round_amd.quantizer import register_act_max_hooks, set_amax_for_uncalibrated_experts
+    from auto_round_amd.wrapper import update_block_global_scale_if_needed
+
     for blk in blocks:
         if alg_ext:          # the imatrix hooks fire during the reference (fp-input) forward
             tr.collect_imatrix(blk, fp_in, others, batch_size=bs, forward=fwd)

@@ -193,3 +193,88 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
         assert n_filled > 0, "the case is meant to contain experts without calibration tokens"
     for n, p1 in lin_ref.items():
         assert torch.equal(p1.weight.view(torch.int16), lin_mine[n].weight.view(torch.int16)), n
+
+
+@pytest.mark.parametrize("kw", [dict(scheme="W4A16", group_size=32), dict(scheme="W2A16G32", sym=False), dict(scheme="W4A16", group_size=32, sym=False),
+                                dict(scheme="W3A16", group_size=32), dict(scheme="MXFP4"), dict(scheme="NVFP4")],
+                         ids=["w4g32_sym_gptq_words", "w2g32_asym_plain_words", "w4g32_asym_awq_words", "w3g32_sym", "mxfp4_nibbles",
+                              "nvfp4_nibbles_and_scales"])
+def test_reference_checkpoint_tensors_equal_the_oracle_packers_on_the_restated_flow(kw, tmp_path, monkeypatch):
+    """North-star: "quantized integer weights and packed buffers must match the reference bit-exactly on the same seed/inputs".
+    The reference tunes AND saves (format auto_round) on CPU; the restated flow tunes the same model and the C oracle's packers
+    -- the ones the HIP packers are held to on the GPU -- pack it: every packed tensor of every block layer is identical."""
+    import numpy as np
+    from safetensors import safe_open
+
+    from oracle import oracle as orc
+
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, REF):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from auto_round import AutoRound
+
+    from auto_round_amd.schemes import apply_scheme, resolve_scheme
+
+    monkeypatch.chdir(tmp_path)
+    base = _tiny()
+    tokens = torch.randint(0, 64, (8, 16), generator=torch.Generator().manual_seed(1))
+    iters, bs, S = 3, 4, 16
+    ar = AutoRound(copy.deepcopy(base), tokenizer=_StubTokenizer(), iters=iters, nsamples=8, seqlen=S, dataset=_Loader(tokens),
+                   device_map="cpu", batch_size=bs, enable_torch_compile=False, **kw)
+    out = str(tmp_path / "ref")
+    ar.quantize_and_save(out, format="auto_round")
+    sub = [d for d in os.listdir(out) if os.path.isdir(os.path.join(out, d))]
+    out = os.path.join(out, sub[0]) if sub else out
+    ref_t = {}
+    for f in os.listdir(out):
+        if f.endswith(".safetensors"):
+            with safe_open(os.path.join(out, f), "pt") as sf:
+                for k in sf.keys():
+                    ref_t[k] = sf.get_tensor(k)
+
+    m = copy.deepcopy(base)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    sch = resolve_scheme(**kw)
+    blocks = list(m.model.layers)
+    for b in blocks:
+        apply_scheme(b, sch)
+    run_flow(m, blocks, tokens, sch, iters=iters, bs=bs, reference_mask=True)
+
+    bits_, gs, sym, mx = int(sch["bits"]), int(sch["group_size"]), bool(sch["sym"]), str(sch["data_type"]).startswith("mx")
+    nv = str(sch["data_type"]).startswith("nv")
+    n_checked = 0
+    for name, lin in m.named_modules():
+        if not (isinstance(lin, torch.nn.Linear) and hasattr(lin, "scale") and name.startswith("model.layers")):
+            continue
+        name = name.replace(".orig_layer", "")          # A4 schemes leave the activation-quant shell around the layer
+        out_f, in_f = lin.weight.shape
+        Wb = orc.to_bits(lin.weight.data).reshape(-1)
+        if mx:
+            packed, sb = orc.pack_fp4(Wb, orc.to_bits(lin.scale.to(lin.weight.dtype)).reshape(-1), out_f, in_f, gs, 0)
+            assert np.array_equal(packed, ref_t[f"{name}.weight_packed"].numpy()), name
+            assert np.array_equal(sb, ref_t[f"{name}.weight_scale"].numpy().reshape(sb.shape)), name
+        elif nv:      # e4m3 group scales, the (q/k/v- and gate/up-unified) global scale and the static input scale from act_max
+            gsc = float(lin.weight_global_scale)
+            packed, sb = orc.pack_fp4(Wb, lin.scale.float().numpy().reshape(-1), out_f, in_f, gs, 1, global_scale=gsc)
+            assert np.array_equal(packed, ref_t[f"{name}.weight_packed"].numpy()), name
+            assert np.array_equal(sb, ref_t[f"{name}.weight_scale"].view(torch.uint8).numpy().reshape(sb.shape)), name
+            assert np.float32(gsc) == ref_t[f"{name}.weight_global_scale"].float().numpy().reshape(-1)[0], name
+            amax = np.float32(torch.as_tensor(lin.act_max).float().abs().max().item())
+            assert np.float32(448.0 * 6.0) * (np.float32(1.0) / amax) == ref_t[f"{name}.input_global_scale"].float().numpy().reshape(-1)[0], name
+        else:
+            sb = orc.to_bits(lin.scale).reshape(-1)
+            zp = float(lin.zp) if not isinstance(lin.zp, torch.Tensor) else lin.zp.float().numpy()
+            if sym:                                   # backend auto_round:auto_gptq -> the zp-1 packer
+                qw, qz, st = orc.pack_int(Wb, sb, zp, out_f, in_f, gs, bits_, zp_off=1)
+            elif bits_ == 4:                          # W4 asym -> AWQ GEMM container
+                qw, qz, st = orc.pack_awq(Wb, sb, zp, out_f, in_f, gs)
+            else:                                     # other asym -> the plain packer
+                qw, qz, st = orc.pack_int(Wb, sb, zp, out_f, in_f, gs, bits_, zp_off=0)
+            assert np.array_equal(qw, ref_t[f"{name}.qweight"].numpy()), name
+            assert np.array_equal(qz, ref_t[f"{name}.qzeros"].numpy()), name
+            assert np.array_equal(st, orc.to_bits(ref_t[f"{name}.scales"])), name
+        n_checked += 1
+    assert n_checked == 14
