@@ -196,9 +196,11 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
 
 
 @pytest.mark.parametrize("kw", [dict(scheme="W4A16", group_size=32), dict(scheme="W2A16G32", sym=False), dict(scheme="W4A16", group_size=32, sym=False),
-                                dict(scheme="W3A16", group_size=32), dict(scheme="MXFP4"), dict(scheme="NVFP4")],
+                                dict(scheme="W3A16", group_size=32), dict(scheme="MXFP4"), dict(scheme="NVFP4"),
+                                dict(scheme="W4A16", group_size=32, format="auto_gptq"), dict(scheme="W4A16", group_size=32, sym=False, format="auto_awq"),
+                                dict(scheme="W2A16G32", enable_alg_ext=True)],
                          ids=["w4g32_sym_gptq_words", "w2g32_asym_plain_words", "w4g32_asym_awq_words", "w3g32_sym", "mxfp4_nibbles",
-                              "nvfp4_nibbles_and_scales"])
+                              "nvfp4_nibbles_and_scales", "format_auto_gptq", "format_auto_awq", "w2g32_alg_ext"])
 def test_reference_checkpoint_tensors_equal_the_oracle_packers_on_the_restated_flow(kw, tmp_path, monkeypatch):
     """North-star: "quantized integer weights and packed buffers must match the reference bit-exactly on the same seed/inputs".
     The reference tunes AND saves (format auto_round) on CPU; the restated flow tunes the same model and the C oracle's packers
@@ -218,13 +220,15 @@ def test_reference_checkpoint_tensors_equal_the_oracle_packers_on_the_restated_f
     from auto_round_amd.schemes import apply_scheme, resolve_scheme
 
     monkeypatch.chdir(tmp_path)
+    kw = dict(kw)
+    fmt, alg_ext = kw.pop("format", "auto_round"), bool(kw.get("enable_alg_ext", False))
     base = _tiny()
     tokens = torch.randint(0, 64, (8, 16), generator=torch.Generator().manual_seed(1))
     iters, bs, S = 3, 4, 16
     ar = AutoRound(copy.deepcopy(base), tokenizer=_StubTokenizer(), iters=iters, nsamples=8, seqlen=S, dataset=_Loader(tokens),
                    device_map="cpu", batch_size=bs, enable_torch_compile=False, **kw)
     out = str(tmp_path / "ref")
-    ar.quantize_and_save(out, format="auto_round")
+    ar.quantize_and_save(out, format=fmt)
     sub = [d for d in os.listdir(out) if os.path.isdir(os.path.join(out, d))]
     out = os.path.join(out, sub[0]) if sub else out
     ref_t = {}
@@ -237,11 +241,11 @@ def test_reference_checkpoint_tensors_equal_the_oracle_packers_on_the_restated_f
     m = copy.deepcopy(base)
     for p in m.parameters():
         p.requires_grad_(False)
-    sch = resolve_scheme(**kw)
+    sch = resolve_scheme(**{k: v for k, v in kw.items() if k != "enable_alg_ext"})
     blocks = list(m.model.layers)
     for b in blocks:
         apply_scheme(b, sch)
-    run_flow(m, blocks, tokens, sch, iters=iters, bs=bs, reference_mask=True)
+    run_flow(m, blocks, tokens, sch, iters=iters, bs=bs, reference_mask=True, alg_ext=alg_ext)
 
     bits_, gs, sym, mx = int(sch["bits"]), int(sch["group_size"]), bool(sch["sym"]), str(sch["data_type"]).startswith("mx")
     nv = str(sch["data_type"]).startswith("nv")
@@ -267,8 +271,10 @@ def test_reference_checkpoint_tensors_equal_the_oracle_packers_on_the_restated_f
         else:
             sb = orc.to_bits(lin.scale).reshape(-1)
             zp = float(lin.zp) if not isinstance(lin.zp, torch.Tensor) else lin.zp.float().numpy()
-            if sym:                                   # backend auto_round:auto_gptq -> the zp-1 packer
+            if sym or fmt == "auto_gptq":             # backend auto_round:auto_gptq / format auto_gptq -> the zp-1 packer
                 qw, qz, st = orc.pack_int(Wb, sb, zp, out_f, in_f, gs, bits_, zp_off=1)
+                if fmt == "auto_gptq":
+                    assert np.array_equal(ref_t[f"{name}.g_idx"].numpy(), np.arange(in_f, dtype=np.int32) // gs), name
             elif bits_ == 4:                          # W4 asym -> AWQ GEMM container
                 qw, qz, st = orc.pack_awq(Wb, sb, zp, out_f, in_f, gs)
             else:                                     # other asym -> the plain packer
