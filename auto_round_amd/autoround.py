@@ -174,17 +174,7 @@ class AutoRound:
             for ln, cfg in apply_scheme(b, self.scheme, layer_config=_block_layer_config(self.layer_config_in, n, b)).items():
                 self.layer_config[f"{n}.{ln}"] = cfg
         tokens = self._calibration_tokens()
-        ids_for_mask = tokens.clone()
-        pad = getattr(self.tokenizer, "pad_token_id", None)
-        if pad is not None:
-            ids_for_mask[ids_for_mask == pad] = -100
-        else:                                   # llm.py:352-358: without a pad id, trailing repeats of the last token count as padding
-            for b in range(ids_for_mask.shape[0]):
-                last, j = tokens[b, -1], tokens.shape[1] - 2
-                while j >= 0 and tokens[b, j] == last:
-                    ids_for_mask[b, j] = -100
-                    j -= 1
-        ids_for_mask[:, -1] = -100              # llm.py:341-360: pads and the last position do not enter the loss
+        ids_for_mask = loss_mask_ids(tokens, getattr(self.tokenizer, "pad_token_id", None))
         # grouped-query "sdpa" attention would silently run on the 2x slower flash kernels (attention.py)
         cfg_obj, old_attn = getattr(model, "config", None), None
         if self.config.sdpa_backend == "efficient" and getattr(cfg_obj, "_attn_implementation", None) == "sdpa":
@@ -351,6 +341,23 @@ class AutoRound:
         model, _ = self.quantize()
         self.save_quantized(output_dir, format=format, inplace=inplace, **kw)
         return model, output_dir
+
+
+def loss_mask_ids(tokens: torch.Tensor, pad_token_id=None) -> torch.Tensor:
+    """Token ids with -100 where a position must not enter the loss (reference: calibration/llm.py:341-360): pad tokens --
+    matched by `pad_token_id`, or, without one, the trailing repeats of a sample's last token -- and every sample's last
+    position (no next-token target)."""
+    ids = tokens.clone()
+    if pad_token_id is not None:
+        ids[ids == pad_token_id] = -100
+    else:
+        for b in range(ids.shape[0]):
+            last, j = tokens[b, -1], tokens.shape[1] - 2
+            while j >= 0 and tokens[b, j] == last:
+                ids[b, j] = -100
+                j -= 1
+    ids[:, -1] = -100
+    return ids
 
 
 def _block_layer_config(layer_config, block_name, block):

@@ -30,7 +30,7 @@ def reference_cached_mask(S, device="cpu"):
 
 
 def run_flow(model, blocks, tokens, scheme, *, iters, bs, alg_ext=False, moe=False, reference_mask=False, seed=42,
-             quanted_input=True, tune_kw=None):
+             quanted_input=True, tune_kw=None, pad_token_id=None):
     """Tunes `blocks` of `model` in place (scheme attributes must already be on the linears).  Returns per-block
     (init_loss, best_loss) and the number of MoE layers whose act_max had to be filled in."""
     import transformers
@@ -69,8 +69,9 @@ def run_flow(model, blocks, tokens, scheme, *, iters, bs, alg_ext=False, moe=Fal
         # [1, ...] mask takes another CPU SDPA path whose last-bit differences are enough to move the algorithm extension's
         # importance matrix -> fwd() materialises the shared tensors per call (ragged last batches included)
         others["_materialise_rows"] = True
-    ids = tokens.clone()
-    ids[:, -1] = -100
+    from auto_round_amd.autoround import loss_mask_ids
+
+    ids = loss_mask_ids(tokens, pad_token_id)       # the product's own rule for which positions enter the loss
 
     @torch.no_grad()
     def forward_all(blk, x):

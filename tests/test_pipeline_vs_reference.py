@@ -121,11 +121,14 @@ def _tiny_moe(experts=4, top_k=2):
                                                                                   "q_proj": {"bits": 8}, "layers.1.mlp": {"group_size": 64}}),
                                 dict(scheme="W4A16", group_size=32, nsamples=6, iters=5),
                                 dict(scheme="W4A16", group_size=32, nsamples=3),
-                                dict(scheme="W4A16", group_size=32, seed=7)],
+                                dict(scheme="W4A16", group_size=32, seed=7),
+                                dict(scheme="W4A16", group_size=32, trailing_repeats=True),
+                                dict(scheme="W4A16", group_size=32, trailing_repeats=True, pad_token_id=3)],
                          ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32",
                               "mixtral_nvfp4_idle_experts", "opt_w4g32", "opt_w2g32_asym", "gpt2_conv1d_w4g32", "qwen2_w4g32", "qwen3_w4g32", "qwen3_moe_w4g32", "w4a8_int_act", "int8_w8a8", "w3g32", "w8g32", "grad_accumulate_2", "last_iterate",
                               "no_minmax_tuning", "fp_input_chain", "explicit_lrs", "early_stop", "mixed_layer_config",
-                              "ragged_last_batch", "fewer_samples_than_batch", "other_seed"])
+                              "ragged_last_batch", "fewer_samples_than_batch", "other_seed", "trailing_repeats_count_as_padding",
+                              "pad_token_id_masks_pads"])
 def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monkeypatch):
     shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
     sys.dont_write_bytecode = True
@@ -147,6 +150,12 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
         base = (_tiny_moe(*moe) if isinstance(moe, tuple) else _tiny_moe()) if moe else ({"opt": _tiny_opt, "gpt2": _tiny_gpt2, "llama": _tiny}[arch]())
     nsamples, seed, layer_config = kw.pop("nsamples", 8), kw.pop("seed", 42), kw.pop("layer_config", None)
     tokens = torch.randint(0, 64, (nsamples, 16), generator=torch.Generator().manual_seed(1))
+    pad_token_id = kw.pop("pad_token_id", None)
+    if kw.pop("trailing_repeats", False):        # samples that end in a run of one token, and a few pad ids in the middle
+        tokens[1, -5:] = tokens[1, -1]
+        tokens[4, -2:] = tokens[4, -1]
+        tokens[6, :] = 3
+        tokens[2, 4], tokens[5, 9] = 3, 3
     iters, bs, S = kw.pop("iters", 3), 4, 16
     loop_kw = {k: kw.pop(k) for k in ("gradient_accumulate_steps", "not_use_best_mse", "enable_minmax_tuning", "lr", "minmax_lr",
                                       "dynamic_max_gap") if k in kw}
@@ -156,7 +165,9 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
 
     # --- the reference, front door to tuned weights
     m_ref = copy.deepcopy(base)
-    ar = AutoRound(m_ref, tokenizer=_StubTokenizer(), iters=iters, nsamples=nsamples, seqlen=S, dataset=_Loader(tokens), device_map="cpu",
+    tok = _StubTokenizer()
+    tok.pad_token_id = pad_token_id
+    ar = AutoRound(m_ref, tokenizer=tok, iters=iters, nsamples=nsamples, seqlen=S, dataset=_Loader(tokens), device_map="cpu",
                    batch_size=bs, enable_torch_compile=False, enable_quanted_input=quanted_input, seed=seed,
                    layer_config=None if layer_config is None else {k: dict(v) for k, v in layer_config.items()}, **loop_kw, **kw)
     q_ref, _ = ar.quantize()
@@ -182,7 +193,7 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
         name = f"{'model.layers' if hasattr(m, 'model') and not hasattr(m.model, 'decoder') else 'blocks'}.{i}"
         apply_scheme(b, sch, layer_config=_block_layer_config(layer_config, name, b))
     _, n_filled = run_flow(m, blocks, tokens, sch, iters=iters, bs=bs, alg_ext=alg_ext, moe=bool(moe), reference_mask=True,
-                           quanted_input=quanted_input, tune_kw=loop_kw, seed=seed)
+                           quanted_input=quanted_input, tune_kw=loop_kw, seed=seed, pad_token_id=pad_token_id)
 
     from transformers.pytorch_utils import Conv1D
 

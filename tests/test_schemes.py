@@ -163,3 +163,15 @@ def test_host_helpers_equal_the_reference_helpers():
             assert torch.equal(a.weight_global_scale.reshape(-1).float(), b.weight_global_scale.reshape(-1).float()), n
     qa, ka, va = blk_a.self_attn.q_proj, blk_a.self_attn.k_proj, blk_a.self_attn.v_proj
     assert float(qa.weight_global_scale) == float(ka.weight_global_scale) == float(va.weight_global_scale)
+
+
+def test_loss_mask_ids_known_answers():
+    """Which positions enter the loss (reference: calibration/llm.py:341-360): pads by id, or trailing repeats of the last token when
+    the tokenizer has no pad id; always without the last position."""
+    from auto_round_amd.autoround import loss_mask_ids
+
+    t = torch.tensor([[5, 6, 7, 7, 7], [1, 2, 3, 4, 5], [9, 9, 9, 9, 9], [0, 3, 0, 2, 0]])
+    assert loss_mask_ids(t).tolist() == [[5, 6, -100, -100, -100], [1, 2, 3, 4, -100], [-100] * 5, [0, 3, 0, 2, -100]]
+    assert loss_mask_ids(t, pad_token_id=0).tolist() == [[5, 6, 7, 7, -100], [1, 2, 3, 4, -100], [9, 9, 9, 9, -100],
+                                                         [-100, 3, -100, 2, -100]]
+    assert t[0, 2] == 7                                  # the input is left alone
