@@ -69,6 +69,7 @@ def register():
             q_cls = SignRoundV2Quantizer if getattr(self, "enable_alg_ext", False) else SignRoundQuantizer
             q = q_cls(cfg, device=device_manager.device)
             best = q.quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=input_ids)
+            adopt_act_quant_shells(block, device_manager.device)
             st = q.last_stats
             try:
                 from auto_round.logger import logger
@@ -86,6 +87,32 @@ def register():
     _Quantizer.__name__ = "MI355XSignRoundQuantizer"
     MI355XSignRoundConfig, MI355XSignRoundQuantizer = _Config, _Quantizer
     return _Config, _Quantizer
+
+
+def adopt_act_quant_shells(block, device="cpu") -> int:
+    """After an activation-quantised block (MXFP4 / NVFP4 / W4A8 ...) is tuned, the reference expects ITS `WrapperWALayer` around every
+    tuned layer: its exporters unwrap exactly that class (`export_to_nvfp_mx.pack_layer`, export_to_autoround/export_to_nvfp_mx.py:
+    60-70) and its quantised-output forward calls `orig_layer.act_quant_func`.  Swap this package's shells for the reference's and give
+    the layers the attributes the reference's own unwrapper leaves behind (wrapper.py:432-468).  Returns the number of shells swapped."""
+    import torch
+    from auto_round.data_type.utils import get_quant_func
+    from auto_round.wrapper import WrapperWALayer as _RefShell
+
+    from .wrapper import WrapperWALayer, _set_module
+
+    n_swapped = 0
+    for name, m in list(block.named_modules()):
+        if not isinstance(m, WrapperWALayer):
+            continue
+        layer = m.orig_layer
+        layer.act_quant_func, layer.act_data_type = get_quant_func(layer.act_data_type, layer.act_bits, layer.act_sym,
+                                                                   disable_opt_rtn=True, iters=getattr(layer, "iters", 200))
+        sdt = getattr(layer, "scale_dtype", torch.float16)
+        layer.q_scale_thresh = 1e-8 if sdt == torch.float32 else 1e-5
+        layer.act_min_scale, layer.act_max_scale = torch.tensor(1.0), torch.tensor(1.0)
+        _set_module(block, name, _RefShell(layer, enable_torch_compile=False, device=device))
+        n_swapped += 1
+    return n_swapped
 
 
 def packing_quant_linear(backend: str, bits: int, group_size: int, sym: bool):

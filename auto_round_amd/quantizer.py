@@ -102,6 +102,48 @@ def stack_samples(samples: Union[torch.Tensor, Sequence[torch.Tensor]], device) 
     return torch.cat([s.to(device) for s in samples], dim=0).contiguous()
 
 
+SHARED_CACHE_KEYS = ("position_ids", "cache_position", "position_embeddings", "cu_seqlens")      # utils/common.py:676
+
+
+def _to_device(v, device):
+    if isinstance(v, torch.Tensor):
+        return v.to(device)
+    if isinstance(v, tuple):
+        return tuple(_to_device(t, device) for t in v)
+    return v
+
+
+def normalize_input_others(input_others, nsamples: int, device, shared_keys=SHARED_CACHE_KEYS):
+    """-> (shared, per_sample).  The reference's front door hands `input_others` over the way its input cache stores them
+    (algorithms/block_runner.py:368-422 `_select_batch`): the shared keys as a list of which the first entry serves every
+    batch, every other tensor-valued key as a list with one [1, ...] entry per calibration sample that it concatenates per
+    minibatch.  Here the per-sample entries become ONE resident [N, ...] tensor per key (rows are gathered per minibatch by
+    index); a key whose entries are all equal -- the usual fixed-seqlen case: one mask for every sample -- keeps a single
+    broadcastable row and costs nothing per iteration.  A dict without list values (the standalone front door) is returned
+    as it is."""
+    if not input_others or not any(isinstance(v, list) for k, v in input_others.items() if k != "positional_inputs"):
+        return input_others, {}
+    shared, per_sample = {}, {}
+    for k, v in input_others.items():
+        if k == "positional_inputs":
+            shared[k] = v
+        elif k in shared_keys:
+            shared[k] = _to_device(v[0] if isinstance(v, list) and len(v) else (None if isinstance(v, list) else v), device)
+        elif isinstance(v, list) and len(v) == nsamples and all(isinstance(t, torch.Tensor) for t in v):
+            rows = torch.cat([t.to(device) for t in v], dim=0).contiguous()
+            if rows.shape[0] != nsamples:
+                raise ValueError(f"input_others[{k!r}]: expected one row per calibration sample, got {tuple(rows.shape)}")
+            if nsamples > 1 and bool((rows == rows[:1]).all()):
+                shared[k] = rows[:1]
+            else:
+                per_sample[k] = rows
+        elif isinstance(v, list):
+            shared[k] = _to_device(v[0], device) if len(v) == 1 else v
+        else:
+            shared[k] = _to_device(v, device)
+    return shared, per_sample
+
+
 def check_need_act_calibration(act_dynamic, act_data_type=None, act_bits=16) -> bool:
     """reference: compressors/utils.py:186-202 -- static activation quantisation needs an `act_max` per layer."""
     if act_bits is None or act_bits > 8:
@@ -295,6 +337,8 @@ class SignRoundQuantizer:
         X = stack_samples(active_inputs, device)
         Y = stack_samples(fp_outputs, device)
         nsamples = X.shape[0]
+        # the reference's per-sample lists (plugin mode) -> resident tensors; the standalone front door's dict passes through
+        input_others, per_sample_others = normalize_input_others(input_others, nsamples, device)
 
         quantized_names, unquantized_names = self.wrapper_block(
             block, cfg.enable_minmax_tuning, cfg.enable_norm_bias_tuning, enable_torch_compile=False, device=device,
@@ -397,7 +441,10 @@ class SignRoundQuantizer:
                 nb = idx.numel()
                 x = ops.gather_rows(X, idx, out=xb[:nb])
                 ref = ops.gather_rows(Y, idx, out=yb[:nb])
-                pred = self.block_forward(block, x, input_others)
+                others_b = input_others
+                if per_sample_others:       # rows of this minibatch, like the reference's per-batch concatenation
+                    others_b = {**input_others, **{k: t.index_select(0, idx) for k, t in per_sample_others.items()}}
+                pred = self.block_forward(block, x, others_b)
                 pred_c = pred if pred.is_contiguous() else pred.contiguous()
                 if dpred is None or dpred.shape != pred_c.shape or dpred.dtype != pred_c.dtype:
                     dpred = torch.empty_like(pred_c)
