@@ -24,9 +24,10 @@ from oracle import torch_ref as tr  # noqa: E402
 from pipeline_flow import run_flow  # noqa: E402
 from test_pipeline_vs_reference import _Loader, _StubTokenizer  # noqa: E402
 
-iters, nsamples, seqlen, bs = int(os.environ.get("ITERS", 8)), 16, 512, 8
+iters, nsamples, seqlen, bs = (int(os.environ.get("ITERS", 8)), int(os.environ.get("NSAMPLES", 16)), int(os.environ.get("SEQLEN", 512)), 8)
+layers = int(os.environ.get("LAYERS", 2))          # ITERS=200 NSAMPLES=128 SEQLEN=2048 LAYERS=1 = one block of BASELINE configs[0]
 torch.manual_seed(0)
-cfg = OPTConfig(hidden_size=768, ffn_dim=3072, num_attention_heads=12, num_hidden_layers=2, vocab_size=50272, max_position_embeddings=2048)
+cfg = OPTConfig(hidden_size=768, ffn_dim=3072, num_attention_heads=12, num_hidden_layers=layers, vocab_size=50272, max_position_embeddings=2048)
 cfg._attn_implementation = "sdpa"
 base = OPTForCausalLM(cfg).to(torch.bfloat16).eval()
 tokens = torch.randint(0, 50272, (nsamples, seqlen), generator=torch.Generator().manual_seed(1))
@@ -73,8 +74,9 @@ def timed_tb(*a, **k):
 
 tr.tune_block = timed_tb
 run_flow(m, blocks, tokens, sch, iters=iters, bs=bs, reference_mask=True)
-out = dict(model="OPT-125M-shaped, 2 blocks (hidden 768, ffn 3072, 12 heads), W4G128 sym", nsamples=nsamples, seqlen=seqlen, batch_size=bs,
+out = dict(model=f"OPT-125M-shaped, {layers} block(s) (hidden 768, ffn 3072, 12 heads), W4G128 sym", nsamples=nsamples, seqlen=seqlen, batch_size=bs,
            iters=iters, threads=torch.get_num_threads(),
-           reference_tuning_s_per_iter=spent["ref"] / (2 * iters), port_tuning_s_per_iter=spent["port"] / (2 * iters),
+           reference_tuning_s_per_iter=spent["ref"] / (layers * iters), port_tuning_s_per_iter=spent["port"] / (layers * iters),
+           reference_tuning_s_per_block=spent["ref"] / layers, port_tuning_s_per_block=spent["port"] / layers,
            port_over_reference=spent["port"] / spent["ref"])
 print(json.dumps(out))
