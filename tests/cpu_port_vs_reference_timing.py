@@ -12,7 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.dont_write_bytecode = True
-for p in (os.path.join(ROOT, "oracle", "ref_shim"), "/root/reference", os.path.join(ROOT, "tests"), ROOT):
+for p in (os.path.join(ROOT, "oracle", "ref_shim"), "/root/reference", os.path.join(ROOT, "tests"), ROOT):     # (lives under tests/: only tests may use oracle/)
     sys.path.insert(0, p)
 
 from transformers import OPTConfig, OPTForCausalLM  # noqa: E402
