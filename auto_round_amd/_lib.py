@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -51,6 +51,9 @@ SIGNATURES = {
     "ar_search_fp4_scale": (c_int, [P, P, P, L, P, P, I, P, L, I, I, I, P]),
     "ar_fp4_act_bwd": (c_int, [P, P, P, P, L, I, I, I, P]),
     "ar_pack_fp4": (c_int, [P, P, P, L, L, I, I, I, P, P, P]),
+    "ar_profile_enable": (c_int, [I]),
+    "ar_profile_reset": (c_int, []),
+    "ar_profile_read": (c_int, [I, L, P, P, P]),
 }
 
 _lib = None

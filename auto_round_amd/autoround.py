@@ -22,7 +22,7 @@ import torch
 
 from .model_tuner import tune_blocks
 from .quantizer import SignRoundConfig, SignRoundQuantizer, SignRoundV2Quantizer
-from .schemes import SCHEME_KEYS, apply_scheme, expand_layer_config, layer_pattern_regex, resolve_scheme
+from .schemes import SCHEME_KEYS, apply_scheme, expand_layer_config, is_quantizable, layer_pattern_regex, resolve_scheme
 from .shard_writer import ShardWriter
 
 
@@ -255,7 +255,7 @@ class AutoRound:
         """format "auto_awq" (export_to_awq/export.py:201-226): AutoAWQ's GEMM keys; layers left in 16 bit are listed."""
         qc = {k: self.scheme.get(k) for k in ("bits", "group_size", "sym", "data_type")}
         keep = [n for n, m in self.model.named_modules()            # linears outside the tuned blocks (lm_head, projectors)
-                if isinstance(m, torch.nn.Linear) and n not in self.layer_config
+                if is_quantizable(m) and n not in self.layer_config
                 and not any(n.startswith(b + ".") for b in self.block_names)]
         keep += [n for n, c in self.layer_config.items() if int(c.get("bits", 16)) > 8]
         keep += [p for p, over in self._pattern_config().items() if int(over.get("bits", 0)) > 8]
@@ -365,7 +365,7 @@ def _block_layer_config(layer_config, block_name, block):
     block, so resolve the keys on the full names (schemes.expand_layer_config) and strip the block prefix."""
     if not layer_config:
         return None
-    full = [f"{block_name}.{n}" for n, m in block.named_modules() if isinstance(m, torch.nn.Linear)]
+    full = [f"{block_name}.{n}" for n, m in block.named_modules() if is_quantizable(m)]      # nn.Linear and Conv1D (GPT-2)
     return {n[len(block_name) + 1:]: over for n, over in expand_layer_config(full, layer_config).items()}
 
 

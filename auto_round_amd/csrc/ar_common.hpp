@@ -2,6 +2,7 @@
 // per-group scale arithmetic).  CDNA4 only: 64-wide wavefronts are assumed everywhere.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "ar_mi355x.h"
@@ -264,5 +265,22 @@ __device__ __forceinline__ void group_scale(const IntCfg& c, float wmin, float w
 
 // error plumbing for the C ABI
 inline int launch_status() { return (int)hipGetLastError(); }
+
+// ---- optional per-launch device timing of the hot kernels (ar_profile_*, csrc/ar_prof.hip) ---------------------------
+// When profiling is on, a hot launch goes through hipExtLaunchKernelGGL with a start/stop event pair: the events carry the
+// dispatch's OWN begin/end timestamps (what rocprofv3 --kernel-trace reports), unlike an event bracket recorded around
+// the launch, whose marker packets cost more than an 11 us kernel.  Off (the default): the plain launch, zero overhead.
+bool prof_on();
+void prof_events(int kernel_id, int64_t units, hipEvent_t* start, hipEvent_t* stop);
+#define AR_LAUNCH_PROF(KID, UNITS, KERNEL, GRID, BLOCK, LDS, ST, ...)                                                    \
+    do {                                                                                                               \
+        if (ar::prof_on()) {                                                                                           \
+            hipEvent_t e0_, e1_;                                                                                       \
+            ar::prof_events((KID), (int64_t)(UNITS), &e0_, &e1_);                                                      \
+            hipExtLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), (LDS), (ST), e0_, e1_, 0, __VA_ARGS__);             \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), (LDS), (ST), __VA_ARGS__);                             \
+        }                                                                                                              \
+    } while (0)
 
 }  // namespace ar

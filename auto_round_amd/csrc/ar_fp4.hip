@@ -263,10 +263,10 @@ extern "C" int ar_qdq_fp4_fwd(const void* X, const float* V, const float* absmax
     do {                                                                                                             \
         if (mode == 0) {                                                                                             \
             if (act) hipLaunchKernelGGL((k_fp4_fwd<DT, AR_FP4_ACT_UNROLL, 0, true>), grid, kTPB, 0, st, a);          \
-            else hipLaunchKernelGGL((k_fp4_fwd<DT, AR_FP4_FWD_UNROLL, 0, false>), grid, kTPB, 0, st, a);             \
+            else AR_LAUNCH_PROF(AR_PROF_FP4_FWD, n_groups, (k_fp4_fwd<DT, AR_FP4_FWD_UNROLL, 0, false>), grid, kTPB, 0, st, a); \
         } else {                                                                                                     \
             if (act) hipLaunchKernelGGL((k_fp4_fwd<DT, AR_FP4_ACT_UNROLL, 1, true>), grid, kTPB, 0, st, a);          \
-            else hipLaunchKernelGGL((k_fp4_fwd<DT, AR_FP4_FWD_UNROLL, 1, false>), grid, kTPB, 0, st, a);             \
+            else AR_LAUNCH_PROF(AR_PROF_FP4_FWD, n_groups, (k_fp4_fwd<DT, AR_FP4_FWD_UNROLL, 1, false>), grid, kTPB, 0, st, a); \
         }                                                                                                            \
     } while (0)
     switch (x_dt) {
@@ -460,8 +460,8 @@ extern "C" int ar_qdq_fp4_bwd_sgd(const void* dXq, const void* X, float* V, cons
     hipStream_t st = (hipStream_t)stream;
 #define AR_BWD(DT)                                                                                                   \
     do {                                                                                                             \
-        if (mode == 0) hipLaunchKernelGGL((k_fp4_bwd<DT, AR_FP4_BWD_UNROLL, 0>), grid, kTPB, 0, st, a);              \
-        else hipLaunchKernelGGL((k_fp4_bwd<DT, AR_FP4_BWD_UNROLL, 1>), grid, kTPB, 0, st, a);                        \
+        if (mode == 0) AR_LAUNCH_PROF(AR_PROF_FP4_BWD, n_groups, (k_fp4_bwd<DT, AR_FP4_BWD_UNROLL, 0>), grid, kTPB, 0, st, a); \
+        else AR_LAUNCH_PROF(AR_PROF_FP4_BWD, n_groups, (k_fp4_bwd<DT, AR_FP4_BWD_UNROLL, 1>), grid, kTPB, 0, st, a); \
     } while (0)
     switch (x_dt) {
         case AR_DT_BF16: AR_BWD(AR_DT_BF16); break;

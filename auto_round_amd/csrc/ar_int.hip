@@ -813,20 +813,20 @@ extern "C" int ar_qdq_int_fwd(const void* W, const float* V, const void* wmin, c
         // measured (tools/kbench.py): the forward is HBM-bound either way (group 128: equal, group 32: the generic one is
         // 1.7 % faster), the fused backward gains 4-9 % -- so only group 128 takes the specialised forward
         if (w_dt == AR_DT_BF16 && !same16 && a.cfg.sym == 1 && s_dt == AR_DT_F16 && a.cpg == 16) {
-            hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_FWD_UNROLL, 16>), fgrid, kTPB, 0, st, a);
+            AR_LAUNCH_PROF(AR_PROF_INT_FWD, a.n_groups, (k_int_fwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_FWD_UNROLL, 16>), fgrid, kTPB, 0, st, a);
             return launch_status();
         }
 #endif
         switch (w_dt) {
             case AR_DT_BF16:
-                if (same16) hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_BF16, AR_DT_BF16, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
-                else hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                if (same16) AR_LAUNCH_PROF(AR_PROF_INT_FWD, a.n_groups, (k_int_fwd_flat<AR_DT_BF16, AR_DT_BF16, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                else AR_LAUNCH_PROF(AR_PROF_INT_FWD, a.n_groups, (k_int_fwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
                 break;
             case AR_DT_F16:
-                if (same16) hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_F16, AR_DT_F16, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
-                else hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_F16, AR_DT_F32, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                if (same16) AR_LAUNCH_PROF(AR_PROF_INT_FWD, a.n_groups, (k_int_fwd_flat<AR_DT_F16, AR_DT_F16, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                else AR_LAUNCH_PROF(AR_PROF_INT_FWD, a.n_groups, (k_int_fwd_flat<AR_DT_F16, AR_DT_F32, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a);
                 break;
-            default: hipLaunchKernelGGL((k_int_fwd_flat<AR_DT_F32, AR_DT_F32, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a); break;
+            default: AR_LAUNCH_PROF(AR_PROF_INT_FWD, a.n_groups, (k_int_fwd_flat<AR_DT_F32, AR_DT_F32, AR_FLAT_FWD_UNROLL>), fgrid, kTPB, 0, st, a); break;
         }
         return launch_status();
     }
@@ -879,21 +879,21 @@ static int launch_int_bwd(BwdArgs& a, int gs, int bits, int sym, int w_dt, int s
         const int fgrid = grid_for_tiles((a.n_groups * a.cpg + kTPB * AR_FLAT_BWD_UNROLL - 1) / (kTPB * AR_FLAT_BWD_UNROLL));
 #if AR_INT_SPEC
         if (w_dt == AR_DT_BF16 && !same16 && a.cfg.sym == 1 && s_dt == AR_DT_F16 && (a.cpg == 16 || a.cpg == 4)) {
-            if (a.cpg == 16) hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL, 16>), fgrid, kTPB, 0, st, a);
-            else hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL, 4>), fgrid, kTPB, 0, st, a);
+            if (a.cpg == 16) AR_LAUNCH_PROF(AR_PROF_INT_BWD, a.n_groups, (k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL, 16>), fgrid, kTPB, 0, st, a);
+            else AR_LAUNCH_PROF(AR_PROF_INT_BWD, a.n_groups, (k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL, 4>), fgrid, kTPB, 0, st, a);
             return launch_status();
         }
 #endif
         switch (w_dt) {
             case AR_DT_BF16:
-                if (same16) hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_BF16, AR_DT_BF16, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
-                else hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                if (same16) AR_LAUNCH_PROF(AR_PROF_INT_BWD, a.n_groups, (k_int_bwd_flat<AR_DT_BF16, AR_DT_BF16, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                else AR_LAUNCH_PROF(AR_PROF_INT_BWD, a.n_groups, (k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
                 break;
             case AR_DT_F16:
-                if (same16) hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_F16, AR_DT_F16, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
-                else hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_F16, AR_DT_F32, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                if (same16) AR_LAUNCH_PROF(AR_PROF_INT_BWD, a.n_groups, (k_int_bwd_flat<AR_DT_F16, AR_DT_F16, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
+                else AR_LAUNCH_PROF(AR_PROF_INT_BWD, a.n_groups, (k_int_bwd_flat<AR_DT_F16, AR_DT_F32, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a);
                 break;
-            default: hipLaunchKernelGGL((k_int_bwd_flat<AR_DT_F32, AR_DT_F32, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a); break;
+            default: AR_LAUNCH_PROF(AR_PROF_INT_BWD, a.n_groups, (k_int_bwd_flat<AR_DT_F32, AR_DT_F32, AR_FLAT_BWD_UNROLL>), fgrid, kTPB, 0, st, a); break;
         }
         return launch_status();
     }

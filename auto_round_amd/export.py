@@ -140,6 +140,14 @@ class QuantLinearFP4(torch.nn.Module):
             self.bias = linear.bias.detach().to(torch.float16)
 
 
+def _is_conv1d(m) -> bool:
+    try:
+        from transformers.pytorch_utils import Conv1D
+    except Exception:  # pragma: no cover
+        return False
+    return isinstance(m, Conv1D)
+
+
 def dynamic_import_quant_linear_for_packing(backend: str, bits: int, group_size: int, sym: bool, act_bits: int = 16):
     """reference: export/export_to_autoround/export.py:56-95 -- which packer a backend string selects."""
     if "auto_round" in backend and "awq" not in backend and "gptq" not in backend:
@@ -153,8 +161,13 @@ def pack_layer(layer: torch.nn.Linear, backend: str = "auto_round:auto_gptq", de
     """reference: export/export_to_autoround/export.py:143-239 for one already-unwrapped layer carrying
     `scale` / `zp`.  Returns the packed QuantLinear (does not splice it into a model)."""
     bits, gs, sym = int(layer.bits), int(layer.group_size), bool(layer.sym)
-    out_f, in_f = layer.weight.shape
+    conv1d = _is_conv1d(layer)
+    # transformers' Conv1D (GPT-2) stores its weight [in, out]; the packers work on [out, in] like the reference's exporters
+    # (export_to_autoround/export.py:200-205 takes in/out features from the transposed shape, QuantLinear.pack transposes)
+    in_f, out_f = (layer.weight.shape if conv1d else layer.weight.shape[::-1])
     dt = str(getattr(layer, "data_type", "int"))
+    if conv1d and (dt.startswith(("mx_fp", "nv_fp")) or "awq" in backend):
+        raise NotImplementedError("Conv1D layers are packed in the auto_round / auto_gptq INT layouts only")
     if dt.startswith("mx_fp") or dt.startswith("nv_fp"):      # export_to_nvfp_mx.pack_layer -> qlinear_fp.QuantLinear.pack
         # the llm_compressor ("compressed-tensors" nvfp4/mxfp4-pack-quantized) exporter packs through the same
         # QuantLinear and only adds the static input scale (export_to_llmcompressor/export_to_fp.py:68-131)
@@ -193,7 +206,7 @@ def pack_block(block, backend: Optional[str] = None) -> Dict[str, torch.nn.Modul
     other asym -> auto_round (export/formats/backends/autoround.py:59-70)."""
     out = {}
     for n, m in block.named_modules():
-        if isinstance(m, torch.nn.Linear) and hasattr(m, "scale") and int(getattr(m, "bits", 16)) < 16:
+        if (isinstance(m, torch.nn.Linear) or _is_conv1d(m)) and hasattr(m, "scale") and int(getattr(m, "bits", 16)) < 16:
             be = backend or ("auto_round:auto_gptq" if m.sym else ("auto_round:auto_awq" if int(m.bits) == 4 else "auto_round"))
             out[n] = pack_layer(m, be)
     return out

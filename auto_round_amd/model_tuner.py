@@ -46,11 +46,13 @@ def tune_blocks(blocks: Sequence[torch.nn.Module], block0_inputs, input_others: 
 
 
 def tune_blocks_sharded(blocks, block0_inputs, input_others, quantizer, seed: int = 42, policy: str = "round_robin",
-                        group=None):
-    """Multi-GPU form: requires enable_quanted_input=False (blocks are only independent on the fp chain)."""
+                        group=None, input_ids=None):
+    """Multi-GPU form: requires enable_quanted_input=False (blocks are only independent on the fp chain).  Every owned block
+    goes through the same pre-tuning calibration and loss mask as `tune_blocks` (sharding.tune_sharded)."""
     from . import sharding
 
     if quantizer.config.enable_quanted_input:
         raise ValueError("block sharding needs enable_quanted_input=False: with quantised-input chaining block k+1 "
                          "depends on the tuned block k (SURVEY 8e) -- run replicas instead")
-    return sharding.tune_sharded(blocks, block0_inputs, input_others, quantizer, seed=seed, policy=policy, group=group)
+    return sharding.tune_sharded(blocks, block0_inputs, input_others, quantizer, seed=seed, policy=policy, group=group,
+                                 input_ids=input_ids)

@@ -38,19 +38,39 @@ def dt_code(dtype: torch.dtype) -> int:
 
 def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
+        _devs_seen.clear()
         raise _lib.Mi355xLibraryError(
             f"{name} is on {t.device}: the MI355X path only runs on a HIP device and has no CPU fallback")
     if not t.is_contiguous():
+        _devs_seen.clear()
         raise ValueError(f"{name} must be contiguous")
     return t
 
 
+_devs_seen: list = []     # device index of every tensor handed to the launch being assembled (checked by _launch)
+
+
 def _p(t: Optional[torch.Tensor], name: str = "tensor"):
-    return None if t is None else _dev(t, name).data_ptr()
+    if t is None:
+        return None
+    _devs_seen.append(_dev(t, name).device.index)
+    return t.data_ptr()
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _launch(entry: str, *args):
+    """One C-ABI call on the stream of the device that OWNS the tensors (not whatever device happens to be current):
+    every pointer of a launch must live on one HIP device; if that device is not the current one the call runs under a
+    device guard, so `SignRoundQuantizer(device="cuda:1")` works while cuda:0 is current."""
+    devs = set(_devs_seen)
+    _devs_seen.clear()
+    if len(devs) != 1:
+        raise _lib.Mi355xLibraryError(f"{entry}: tensors live on HIP devices {sorted(devs)}; one launch needs one device")
+    (dev,) = devs
+    fn = getattr(load(), entry)
+    if dev == torch.cuda.current_device():
+        return check(fn(*args, torch.cuda.current_stream().cuda_stream), entry)
+    with torch.cuda.device(dev):
+        return check(fn(*args, torch.cuda.current_stream(dev).cuda_stream), entry)
 
 
 def group_minmax(W: torch.Tensor, gs: int):
@@ -58,7 +78,7 @@ def group_minmax(W: torch.Tensor, gs: int):
     G = W.numel() // gs
     wmin = torch.empty(G, dtype=W.dtype, device=W.device)
     wmax = torch.empty(G, dtype=W.dtype, device=W.device)
-    check(load().ar_group_minmax(_p(W, "W"), _p(wmin), _p(wmax), G, gs, dt_code(W.dtype), _stream()), "ar_group_minmax")
+    _launch("ar_group_minmax", _p(W, "W"), _p(wmin), _p(wmax), G, gs, dt_code(W.dtype))
     return wmin, wmax
 
 
@@ -66,7 +86,7 @@ def group_absmax(W: torch.Tensor, gs: int, want_tensor_max: bool = False, want_g
     G = W.numel() // gs
     am = torch.empty(G, dtype=torch.float32, device=W.device) if want_groups else None
     tm = torch.zeros(1, dtype=torch.float32, device=W.device) if want_tensor_max else None
-    check(load().ar_group_absmax(_p(W, "W"), _p(am), _p(tm), G, gs, dt_code(W.dtype), _stream()), "ar_group_absmax")
+    _launch("ar_group_absmax", _p(W, "W"), _p(am), _p(tm), G, gs, dt_code(W.dtype))
     return am, tm
 
 
@@ -77,10 +97,9 @@ def qdq_int_fwd(W, V, wmin, wmax, min_s, max_s, *, gs, bits, sym, scale_dtype=to
     Wq = out if out is not None else torch.empty_like(W)
     scale = torch.empty(G, dtype=scale_dtype, device=W.device) if want_scale else None
     zp = torch.empty(G, dtype=torch.float32, device=W.device) if want_scale else None
-    check(load().ar_qdq_int_fwd(_p(W, "W"), _p(V, "V"), _p(wmin, "wmin"), _p(wmax, "wmax"), _p(min_s, "min_scale"),
+    _launch("ar_qdq_int_fwd", _p(W, "W"), _p(V, "V"), _p(wmin, "wmin"), _p(wmax, "wmax"), _p(min_s, "min_scale"),
                                 _p(max_s, "max_scale"), _p(Wq, "Wq"), _p(scale), _p(zp), G, gs, bits, int(sym),
-                                dt_code(W.dtype), dt_code(scale_dtype), q_thresh, bounds[0], bounds[1], _stream()),
-          "ar_qdq_int_fwd")
+                                dt_code(W.dtype), dt_code(scale_dtype), q_thresh, bounds[0], bounds[1])
     return (Wq, scale, zp) if want_scale else Wq
 
 
@@ -91,14 +110,14 @@ def qdq_int_bwd(dWq, W, V, wmin, wmax, min_s, max_s, *, gs, bits, sym, scale_dty
     dV = torch.empty(W.numel(), dtype=torch.float32, device=W.device)
     dmin = torch.empty(G, dtype=torch.float32, device=W.device)
     dmax = torch.empty(G, dtype=torch.float32, device=W.device)
-    check(load().ar_qdq_int_bwd(_p(dWq, "dWq"), _p(W, "W"), _p(V, "V"), _p(wmin), _p(wmax), _p(min_s), _p(max_s), _p(dV),
+    _launch("ar_qdq_int_bwd", _p(dWq, "dWq"), _p(W, "W"), _p(V, "V"), _p(wmin), _p(wmax), _p(min_s), _p(max_s), _p(dV),
                                 _p(dmin), _p(dmax), G, gs, bits, int(sym), dt_code(W.dtype), dt_code(scale_dtype),
-                                q_thresh, bounds[0], bounds[1], _stream()), "ar_qdq_int_bwd")
+                                q_thresh, bounds[0], bounds[1])
     return dV, dmin, dmax
 
 
 def sign_sgd_(p: torch.Tensor, g: torch.Tensor, lr_dev: torch.Tensor):
-    check(load().ar_sign_sgd(_p(p, "param"), _p(g, "grad"), p.numel(), _p(lr_dev, "lr"), _stream()), "ar_sign_sgd")
+    _launch("ar_sign_sgd", _p(p, "param"), _p(g, "grad"), p.numel(), _p(lr_dev, "lr"))
     return p
 
 
@@ -107,11 +126,10 @@ def qdq_int_bwd_sgd_(dWq, W, V, wmin, wmax, min_s, max_s, *, gs, bits, sym, lr_v
                      best_min=None, best_max=None, Wq_next=None):
     """Fused backward + sign-SGD (in place on V, min_s, max_s) [+ snapshot] [+ next forward]."""
     G = W.numel() // gs
-    check(load().ar_qdq_int_bwd_sgd(_p(dWq, "dWq"), _p(W, "W"), _p(V, "V"), _p(wmin), _p(wmax), _p(min_s), _p(max_s), G,
+    _launch("ar_qdq_int_bwd_sgd", _p(dWq, "dWq"), _p(W, "W"), _p(V, "V"), _p(wmin), _p(wmax), _p(min_s), _p(max_s), G,
                                     gs, bits, int(sym), dt_code(W.dtype), dt_code(scale_dtype), q_thresh, bounds[0],
                                     bounds[1], _p(lr_v, "lr_v"), _p(lr_mm, "lr_mm"), int(tune_minmax),
-                                    _p(snapshot_flag), _p(best_V), _p(best_min), _p(best_max), _p(Wq_next), _stream()),
-          "ar_qdq_int_bwd_sgd")
+                                    _p(snapshot_flag), _p(best_V), _p(best_min), _p(best_max), _p(Wq_next))
 
 
 _mse_ws = {}
@@ -134,10 +152,9 @@ def mse_loss_fwd_bwd(pred, ref, *, dpred=None, loss_out=None, loss_accum=None, a
         dpred = torch.empty_like(pred)
     if loss_out is None:
         loss_out = torch.empty(1, dtype=torch.float32, device=pred.device)
-    check(load().ar_mse_loss_fwd_bwd(_p(pred, "pred"), _p(ref, "ref"), _p(dpred), _p(loss_out), _p(loss_accum),
+    _launch("ar_mse_loss_fwd_bwd", _p(pred, "pred"), _p(ref, "ref"), _p(dpred), _p(loss_out), _p(loss_accum),
                                      accum_scale, pred.numel(), dt_code(pred.dtype), grad_scale, _p(token_mask, "token_mask"),
-                                     pred.shape[-1] if token_mask is not None else 0, _p(mse_workspace(pred.device)),
-                                     _stream()), "ar_mse_loss_fwd_bwd")
+                                     pred.shape[-1] if token_mask is not None else 0, _p(mse_workspace(pred.device)))
     return loss_out, dpred
 
 
@@ -159,15 +176,14 @@ def outlier_mse_loss_fwd_bwd(pred, ref, *, topk=None, dpred=None, loss_out=None,
     if ws is None:
         ws = torch.empty(load().ar_outlier_loss_workspace_bytes(), dtype=torch.uint8, device=pred.device)
         _ol_ws[key] = ws
-    check(load().ar_outlier_mse_loss_fwd_bwd(_p(pred, "pred"), _p(ref, "ref"), _p(dpred), _p(loss_out), _p(loss_accum),
+    _launch("ar_outlier_mse_loss_fwd_bwd", _p(pred, "pred"), _p(ref, "ref"), _p(dpred), _p(loss_out), _p(loss_accum),
                                              accum_scale, n, dt_code(pred.dtype), grad_scale, _p(token_mask),
-                                             pred.shape[-1] if token_mask is not None else 0, topk, _p(ws), _stream()),
-          "ar_outlier_mse_loss_fwd_bwd")
+                                             pred.shape[-1] if token_mask is not None else 0, topk, _p(ws))
     return loss_out, dpred
 
 
 def best_loss_update(total_loss, state, istate, it: int):
-    check(load().ar_best_loss_update(_p(total_loss), _p(state), _p(istate), it, _stream()), "ar_best_loss_update")
+    _launch("ar_best_loss_update", _p(total_loss), _p(state), _p(istate), it)
 
 
 def gather_rows(src: torch.Tensor, idx_dev: torch.Tensor, out: Optional[torch.Tensor] = None):
@@ -178,8 +194,7 @@ def gather_rows(src: torch.Tensor, idx_dev: torch.Tensor, out: Optional[torch.Te
         out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     if idx_dev.dtype != torch.int64:
         raise TypeError("idx must be int64")
-    check(load().ar_gather_rows(_p(src, "src"), _p(idx_dev, "idx"), _p(out, "out"), n, row_bytes, _stream()),
-          "ar_gather_rows")
+    _launch("ar_gather_rows", _p(src, "src"), _p(idx_dev, "idx"), _p(out, "out"), n, row_bytes)
     return out
 
 
@@ -195,9 +210,8 @@ def pack_int(Wq2d: torch.Tensor, scale2d: torch.Tensor, zp, *, gs, bits, zp_off=
         zt, zs = zp.to(device=dev, dtype=torch.float32).contiguous(), 0.0
     else:
         zt, zs = None, float(zp)
-    check(load().ar_pack_int(_p(Wq2d, "Wq"), _p(scale2d, "scale"), _p(zt), zs, out_f, in_f, gs, bits, dt_code(Wq2d.dtype),
-                             dt_code(scale2d.dtype), zp_off, _p(qweight), _p(qzeros), _p(scales_t), _stream()),
-          "ar_pack_int")
+    _launch("ar_pack_int", _p(Wq2d, "Wq"), _p(scale2d, "scale"), _p(zt), zs, out_f, in_f, gs, bits, dt_code(Wq2d.dtype),
+                             dt_code(scale2d.dtype), zp_off, _p(qweight), _p(qzeros), _p(scales_t))
     return qweight, qzeros, scales_t
 
 
@@ -212,8 +226,8 @@ def pack_awq(Wq2d: torch.Tensor, scale2d: torch.Tensor, zp, *, gs):
         zt, zs = zp.to(device=dev, dtype=torch.float32).contiguous(), 0.0
     else:
         zt, zs = None, float(zp)
-    check(load().ar_pack_awq(_p(Wq2d, "Wq"), _p(scale2d, "scale"), _p(zt), zs, out_f, in_f, gs, dt_code(Wq2d.dtype),
-                             dt_code(scale2d.dtype), _p(qweight), _p(qzeros), _p(scales_t), _stream()), "ar_pack_awq")
+    _launch("ar_pack_awq", _p(Wq2d, "Wq"), _p(scale2d, "scale"), _p(zt), zs, out_f, in_f, gs, dt_code(Wq2d.dtype),
+                             dt_code(scale2d.dtype), _p(qweight), _p(qzeros), _p(scales_t))
     return qweight, qzeros, scales_t
 
 
@@ -224,8 +238,8 @@ def qdq_fp4_fwd(X, V, absmax, max_s, *, mode, gs, init_scale=1.0, global_scale=N
     scale = None
     if want_scale:
         scale = torch.empty(G, dtype=X.dtype if mode == 0 else torch.float32, device=X.device)
-    check(load().ar_qdq_fp4_fwd(_p(X, "X"), _p(V), _p(absmax), _p(max_s), init_scale, _p(init_scale_dev), _p(global_scale), _p(Xq), _p(scale),
-                                G, gs, mode, dt_code(X.dtype), bounds[0], bounds[1], _stream()), "ar_qdq_fp4_fwd")
+    _launch("ar_qdq_fp4_fwd", _p(X, "X"), _p(V), _p(absmax), _p(max_s), init_scale, _p(init_scale_dev), _p(global_scale), _p(Xq), _p(scale),
+                                G, gs, mode, dt_code(X.dtype), bounds[0], bounds[1])
     return (Xq, scale) if want_scale else Xq
 
 
@@ -236,10 +250,10 @@ def qdq_fp4_bwd_sgd_(dXq, X, V, absmax, max_s, *, mode, gs, init_scale=1.0, glob
     G = X.numel() // gs
     dV = torch.empty(X.numel(), dtype=torch.float32, device=X.device) if want_grads else None
     dmax = torch.empty(G, dtype=torch.float32, device=X.device) if want_grads else None
-    check(load().ar_qdq_fp4_bwd_sgd(_p(dXq, "dXq"), _p(X, "X"), _p(V), _p(absmax, "absmax"), _p(max_s), init_scale,
+    _launch("ar_qdq_fp4_bwd_sgd", _p(dXq, "dXq"), _p(X, "X"), _p(V), _p(absmax, "absmax"), _p(max_s), init_scale,
                                     _p(init_scale_dev), _p(global_scale), G, gs, mode, dt_code(X.dtype), bounds[0], bounds[1], _p(lr_v),
                                     _p(lr_mm), int(tune_minmax), _p(snapshot_flag), _p(best_V), _p(best_max), _p(dV),
-                                    _p(dmax), _stream()), "ar_qdq_fp4_bwd_sgd")
+                                    _p(dmax))
     return (dV, dmax) if want_grads else None
 
 
@@ -255,9 +269,9 @@ def search_fp4_scale(X, absmax, candidates, *, mode, gs, qw_row=None, groups_per
     """Per-group init-scale search over `candidates` (fp32 device tensor, evaluated in order). -> fp32 [numel/gs]"""
     G = X.numel() // gs
     best = torch.empty(G, dtype=torch.float32, device=X.device)
-    check(load().ar_search_fp4_scale(_p(X, "X"), _p(absmax, "absmax"), _p(qw_row), groups_per_row, _p(global_scale),
+    _launch("ar_search_fp4_scale", _p(X, "X"), _p(absmax, "absmax"), _p(qw_row), groups_per_row, _p(global_scale),
                                      _p(candidates, "candidates"), candidates.numel(), _p(best), G, gs, mode,
-                                     dt_code(X.dtype), _stream()), "ar_search_fp4_scale")
+                                     dt_code(X.dtype))
     return best
 
 
@@ -288,8 +302,8 @@ def search_int_scale(X, *, gs, bits, qw_row=None, groups_per_row=0, q_thresh=1e-
         _int_cand[key] = cand
     init = torch.empty(G, dtype=X.dtype, device=X.device)
     raw = torch.empty(G, dtype=X.dtype, device=X.device) if want_raw else None
-    check(load().ar_search_int_scale(_p(X, "X"), _p(qw_row), groups_per_row, _p(cand), cand.numel(), _p(raw), _p(init), G, gs,
-                                     bits, dt_code(X.dtype), q_thresh, _stream()), "ar_search_int_scale")
+    _launch("ar_search_int_scale", _p(X, "X"), _p(qw_row), groups_per_row, _p(cand), cand.numel(), _p(raw), _p(init), G, gs,
+                                     bits, dt_code(X.dtype), q_thresh)
     return (raw, init) if want_raw else init
 
 
@@ -298,24 +312,22 @@ def qdq_int_act_fwd(X, *, gs, bits, sym=True, scale_dtype=torch.float16, q_thres
     G = X.numel() // gs
     Xq = out if out is not None else torch.empty_like(X)
     scale = torch.empty(G, dtype=scale_dtype, device=X.device) if want_scale else None
-    check(load().ar_qdq_int_act_fwd(_p(X, "X"), _p(Xq), _p(scale), G, gs, bits, int(bool(sym)), dt_code(X.dtype), dt_code(scale_dtype), q_thresh,
-                                    _stream()), "ar_qdq_int_act_fwd")
+    _launch("ar_qdq_int_act_fwd", _p(X, "X"), _p(Xq), _p(scale), G, gs, bits, int(bool(sym)), dt_code(X.dtype), dt_code(scale_dtype), q_thresh)
     return (Xq, scale) if want_scale else Xq
 
 
 def int_act_bwd(dXq, X, *, gs, bits, sym=True, scale_dtype=torch.float16, q_thresh=1e-5, out=None):
     G = X.numel() // gs
     dX = out if out is not None else torch.empty_like(X)
-    check(load().ar_int_act_bwd(_p(dXq, "dXq"), _p(X, "X"), _p(dX), G, gs, bits, int(bool(sym)), dt_code(X.dtype), dt_code(scale_dtype), q_thresh,
-                                _stream()), "ar_int_act_bwd")
+    _launch("ar_int_act_bwd", _p(dXq, "dXq"), _p(X, "X"), _p(dX), G, gs, bits, int(bool(sym)), dt_code(X.dtype), dt_code(scale_dtype), q_thresh)
     return dX
 
 
 def fp4_act_bwd(dXq, X, *, mode, gs, global_scale=None, out=None):
     """Gradient of the dynamic activation fake-quant w.r.t. its input (same dtype/shape as X)."""
     dX = out if out is not None else torch.empty_like(X)
-    check(load().ar_fp4_act_bwd(_p(dXq, "dXq"), _p(X, "X"), _p(dX), _p(global_scale), X.numel() // gs, gs, mode,
-                                dt_code(X.dtype), _stream()), "ar_fp4_act_bwd")
+    _launch("ar_fp4_act_bwd", _p(dXq, "dXq"), _p(X, "X"), _p(dX), _p(global_scale), X.numel() // gs, gs, mode,
+                                dt_code(X.dtype))
     return dX
 
 
@@ -323,6 +335,30 @@ def pack_fp4(Wq2d, scale, *, mode, gs, global_scale=None):
     out_f, in_f = Wq2d.shape
     packed = torch.empty((out_f, in_f // 2), dtype=torch.uint8, device=Wq2d.device)
     sb = torch.empty((out_f, in_f // gs), dtype=torch.uint8, device=Wq2d.device)
-    check(load().ar_pack_fp4(_p(Wq2d, "Wq"), _p(scale, "scale"), _p(global_scale), out_f, in_f, gs, mode,
-                             dt_code(Wq2d.dtype), _p(packed), _p(sb), _stream()), "ar_pack_fp4")
+    _launch("ar_pack_fp4", _p(Wq2d, "Wq"), _p(scale, "scale"), _p(global_scale), out_f, in_f, gs, mode,
+                             dt_code(Wq2d.dtype), _p(packed), _p(sb))
     return packed, sb
+
+
+# ---- optional device-side timing of the hot kernels (ar_profile_*; bench.py and tools only) ----------------------------
+PROF_INT_FWD, PROF_INT_BWD, PROF_FP4_FWD, PROF_FP4_BWD, PROF_GEMM_DW, PROF_NORM, PROF_SWIGLU, PROF_ROPE = range(8)
+
+
+def profile_enable(on: bool = True) -> bool:
+    """Attach start/stop events to every hot-kernel dispatch from now on (off by default).  -> previous state"""
+    return bool(load().ar_profile_enable(int(bool(on))))
+
+
+def profile_reset() -> None:
+    check(load().ar_profile_reset(), "ar_profile_reset")
+
+
+def profile_read(kernel_id: int, min_units: int = 0):
+    """-> (total_ms, min_ms, launches) over the recorded launches of `kernel_id` that processed >= min_units units
+    (synchronises on the recorded events)."""
+    import ctypes
+
+    tot, mn, cnt = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int64(0)
+    check(load().ar_profile_read(kernel_id, int(min_units), ctypes.byref(tot), ctypes.byref(mn), ctypes.byref(cnt)),
+          "ar_profile_read")
+    return tot.value, mn.value, cnt.value

@@ -245,6 +245,12 @@ class SignRoundConfig:
     # cannot be sharded.  The reference's counterpart is its experimental DDP mode (utils/distributed.py).
     data_parallel: bool = False
     dp_overlap: bool = True              # dense blocks: per-layer gradient buckets all-reduced while the backward pass continues
+    # Run supported decoder blocks (Llama family: RMSNorm, rotary embedding, SwiGLU MLP, weight-only schemes) through the fused
+    # HIP block path (auto_round_amd/fused_block.py) instead of transformers' module code -- the MI355X counterpart of the
+    # reference's torch.compile(block_forward) (utils/device.py:112-122, compressors/base.py:1177-1179).  Same arithmetic per op,
+    # different bf16 rounding points inside the block (trajectory-level parity, like the reference's compiled path); blocks it
+    # does not cover silently keep the generic path.  Off by default for the same reason enable_torch_compile is.
+    fused_block: bool = False
 
     def __post_init__(self):
         if self.iters < 0:
@@ -331,6 +337,13 @@ class SignRoundQuantizer:
     # ------------------------------------------------------------------------------------------------------------------
     def quantize_block(self, block, fp_inputs, input_others, fp_outputs, q_inputs=None, block_ctx=None, input_ids=None,
                        **kwargs) -> dict:
+        # the whole block is tuned with the quantizer's device current: torch's ops take the device from their tensors, the
+        # C-ABI launches take the stream of their tensors' device (ops._launch) -- both agree for any `device=`
+        with torch.cuda.device(self.device):
+            return self._quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs)
+
+    def _quantize_block(self, block, fp_inputs, input_others, fp_outputs, q_inputs=None, block_ctx=None, input_ids=None,
+                        **kwargs) -> dict:
         cfg = self.config
         device = self.device
         active_inputs = q_inputs if (q_inputs is not None and cfg.enable_quanted_input) else fp_inputs
@@ -465,6 +478,11 @@ class SignRoundQuantizer:
                 if 0 < cfg.dynamic_max_gap <= i - last_best:
                     last_iter = i
                     break
+            if not track_best and i == cfg.iters - 1:
+                # not_use_best_mse: the reference snapshots the parameters at the last iteration BEFORE its optimizer step
+                # (sign_round/quantizer.py:513-514), so that step never reaches the baked weights -- do not take it
+                optimizer.zero_grad()
+                break
             optimizer.step()
             optimizer.zero_grad()
             lr_schedule.step()
@@ -526,17 +544,14 @@ class SignRoundQuantizer:
             outs.append(self.block_forward(block, inputs[b0:b0 + bs], input_others))
         return torch.cat(outs, dim=0)
 
-    def compress_block(self, block, fp_inputs, input_others, q_inputs=None, block_ctx=None, input_ids=None):
-        """reference: AlgorithmComposer.compress_block (composer.py:360-483):
-        (3) reference forward with the fp weights, (4) quantize_block, (6) forward of the quantised block to produce
-        the next block's quantised input.  -> (fp_outputs [N,S,H], q_outputs [N,S,H] or None, best_params)"""
-        device = self.device
-        X = stack_samples(fp_inputs, device)
+    def calibrate_block(self, block, X: torch.Tensor, input_others, Xq: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Everything the composer does for a block BEFORE tuning it (composer.py:423-451): NVFP4 global scales (unified over
+        q/k/v, gate/up, w1/w3), the scheme-dependent per-block setup, the reference forward with the fp weights under the
+        calibration hooks (imatrix of the algorithm extension; act_max of statically activation-quantised layers -- taken from
+        the fp-input forward, or, with quantised-input chaining, from one extra forward on the quantised input) and act_max for
+        experts that saw no token.  -> fp_outputs [N, S, H].  Shared by `compress_block` and the block-sharded path."""
         update_block_global_scale_if_needed(block)      # composer.py:438-451 (NVFP4 only; no-op otherwise)
         self.prepare_block(block)
-        Xq = stack_samples(q_inputs, device) if (q_inputs is not None and self.config.enable_quanted_input) else None
-        # calibration hooks (composer.py:284-299, :423-436): act_max of statically activation-quantised layers is taken
-        # from the fp-input forward, or -- with quantised-input chaining -- from one extra forward on the quantised input
         need_q = bool(self.config.enable_quanted_input)
         handles = ([] if need_q else register_act_max_hooks(block)) + self.register_fp_input_forward_hooks(block)
         try:
@@ -553,10 +568,21 @@ class SignRoundQuantizer:
                     for h in handles:
                         h.remove()
         set_amax_for_uncalibrated_experts(block)                  # composer.py:438-451
-        best = self.quantize_block(block, X, input_others, fp_out, Xq, block_ctx, input_ids=input_ids)
-        q_out = None
-        if self.config.enable_quanted_input:
-            q_out = self.forward_all(block, Xq if Xq is not None else X, input_others)
+        return fp_out
+
+    def compress_block(self, block, fp_inputs, input_others, q_inputs=None, block_ctx=None, input_ids=None):
+        """reference: AlgorithmComposer.compress_block (composer.py:360-483):
+        (3) reference forward with the fp weights, (4) quantize_block, (6) forward of the quantised block to produce
+        the next block's quantised input.  -> (fp_outputs [N,S,H], q_outputs [N,S,H] or None, best_params)"""
+        device = self.device
+        with torch.cuda.device(device):
+            X = stack_samples(fp_inputs, device)
+            Xq = stack_samples(q_inputs, device) if (q_inputs is not None and self.config.enable_quanted_input) else None
+            fp_out = self.calibrate_block(block, X, input_others, Xq)
+            best = self.quantize_block(block, X, input_others, fp_out, Xq, block_ctx, input_ids=input_ids)
+            q_out = None
+            if self.config.enable_quanted_input:
+                q_out = self.forward_all(block, Xq if Xq is not None else X, input_others)
         return fp_out, q_out, best
 
 
@@ -627,8 +653,9 @@ class SignRoundV2Quantizer(SignRoundQuantizer):
 
     def quantize_block(self, block, fp_inputs, input_others, fp_outputs, q_inputs=None, block_ctx=None, input_ids=None,
                        **kwargs) -> dict:
-        if self._scheme is None:          # quantize_block called directly (without compress_block)
-            self.prepare_block(block)
+        # always derived from THIS block's scheme attributes (cheap, idempotent): quantize_block may be called directly, or --
+        # block-sharded runs -- long after the calibration forward of the same block, with other blocks prepared in between
+        self.prepare_block(block)
         try:
             return super().quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs)
         finally:

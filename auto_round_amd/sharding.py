@@ -108,19 +108,85 @@ def relay_fp_chain(blocks: Sequence[Optional[torch.nn.Module]], x0: torch.Tensor
 
 
 def tune_sharded(blocks: Sequence[Optional[torch.nn.Module]], x0: torch.Tensor, input_others: dict, quantizer,
-                 seed: int = 42, policy: str = "round_robin", group=None) -> Dict[int, dict]:
+                 seed: int = 42, policy: str = "round_robin", group=None, input_ids=None, pipelined: bool = True,
+                 on_block_done: Optional[Callable] = None) -> Dict[int, dict]:
     """Shard `blocks` over the ranks and tune the local ones against the fp chain.  Every rank must pass the same
-    x0 buffer shape; rank `src=0` holds the data.  Returns {block index: stats/best_params} for local blocks."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    x0 buffer shape; rank `src=0` holds the data.  Returns {block index: stats/best_params} for local blocks.
+
+    The relay forward of a block IS its calibration forward (`quantizer.calibrate_block`: NVFP4 global-scale unification,
+    act_max hooks + fill-in for idle experts, imatrix hooks of the algorithm extension), and the loss mask (`input_ids`)
+    reaches `quantize_block`, so a sharded block is prepared and tuned exactly like the sequential `compress_block` does
+    with `enable_quanted_input=False`.
+
+    pipelined (default): every rank walks ITS blocks in order -- receive the block's input from the previous owner, run the
+    calibration forward, hand the output to the next owner with an asynchronous send, tune -- so that the fp sweep of the
+    blocks downstream runs on the other GPUs while this one tunes.  With round-robin ownership rank r's next input arrives
+    (N-1 forwards later) while it is still tuning, and its receive was posted before the tuning started, so neither the sweep
+    nor the transfers sit on the critical path: after the pipeline has filled (rank r idles r forwards once), a round of N
+    blocks costs one forward + one tuning run per GPU.  pipelined=False keeps the two-phase form (whole sweep first, then all
+    tuning), whose sweep is a serial prefix of n_blocks forwards.  Both give bit-identical blocks (same inputs, same schedule)."""
     n = len(blocks)
-    broadcast_calibration(x0, 0, group)
     cfg = quantizer.config
+    if cfg.enable_quanted_input:
+        raise ValueError("block sharding tunes every block against the fp activation chain: set enable_quanted_input=False "
+                         "(with quantised-input chaining blocks are sequential; use data_parallel=True instead)")
+    broadcast_calibration(x0, 0, group)
     scheds = replay_index_schedules(seed, n, x0.shape[0], cfg.batch_size, cfg.iters, cfg.gradient_accumulate_steps)
-    pairs = relay_fp_chain(blocks, x0, lambda b, x: quantizer.forward_all(b, x, input_others), policy, group)
     out = {}
-    for k, (xin, yout) in pairs.items():
-        best = quantizer.quantize_block(blocks[k], xin, input_others, yout, None, None, index_schedule=scheds[k])
+
+    def tune(k, xin, yout):
+        best = quantizer.quantize_block(blocks[k], xin, input_others, yout, None, None, input_ids=input_ids,
+                                        index_schedule=scheds[k])
         out[k] = {"best_params": best, "stats": dict(quantizer.last_stats)}
+        if on_block_done is not None:
+            on_block_done(k, blocks[k], out[k])
+
+    if not pipelined:
+        pairs = relay_fp_chain(blocks, x0, lambda b, x: quantizer.calibrate_block(b, x, input_others), policy, group)
+        for k, (xin, yout) in pairs.items():
+            tune(k, xin, yout)
+        return out
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = [k for k in range(n) if owner_of(k, n, world, policy) == rank]
+    pending_recv: Dict[int, tuple] = {}
+    sends = []
+
+    def post_recv(k):
+        """Post the receive of block k's input (if it comes from another rank) ahead of time."""
+        if k is None or k == 0 or k in pending_recv:
+            return
+        src = owner_of(k - 1, n, world, policy)
+        if src != rank:
+            buf = torch.empty_like(x0)
+            pending_recv[k] = (buf, dist.irecv(buf, src=src, group=group))
+
+    carried = None                                  # output of my previous block when I also own the next one
+    if mine:
+        post_recv(mine[0])
+    for i, k in enumerate(mine):
+        if k == 0:
+            xin = x0
+        elif k in pending_recv:
+            buf, work = pending_recv.pop(k)
+            work.wait()
+            xin = buf
+        else:
+            xin = carried
+        yout = quantizer.calibrate_block(blocks[k], xin, input_others)
+        carried = None
+        if k + 1 < n:
+            nxt = owner_of(k + 1, n, world, policy)
+            if nxt != rank:
+                sends.append((yout, dist.isend(yout.contiguous(), dst=nxt, group=group)))
+            else:
+                carried = yout
+        post_recv(mine[i + 1] if i + 1 < len(mine) else None)      # arrives while this block is being tuned
+        tune(k, xin, yout)
+        sends = [(t, w) for t, w in sends if not w.is_completed()]
+    for _, w in sends:
+        w.wait()
     return out
 
 

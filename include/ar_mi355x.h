@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 8
+#define AR_ABI_VERSION 9
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -228,6 +228,19 @@ int ar_fp4_act_bwd(const void* dXq, const void* X, void* dX, const float* global
  * (e8m0 for mode 0, e4m3fn for mode 1). */
 int ar_pack_fp4(const void* Wq, const void* scale, const float* global_scale_dev, int64_t out_f, int64_t in_f, int gs,
                 int mode, int w_dt, uint8_t* packed, uint8_t* scale_bytes, ar_stream_t stream);
+
+/* ---- optional device-side timing of the hot kernels (bench.py / tools; OFF by default) --------------------------
+ * binding hygiene / measurement, no reference counterpart (the reference times blocks on the host,
+ * compressors/orchestrator.py:792-794).  While enabled, each profiled launch carries a start/stop event pair on the dispatch
+ * itself (hipExtLaunchKernelGGL): ar_profile_read() sums the kernels' own durations -- the figure rocprofv3 --kernel-trace
+ * reports -- over the recorded launches of `kernel_id` that processed at least `min_units` units (groups for the quant
+ * kernels, output elements for the GEMM), so that bench.py's live roofline fraction is honest for an 11 us kernel too.
+ * These three calls are the only ones that allocate (events) or synchronise (read / reset). */
+enum { AR_PROF_INT_FWD = 0, AR_PROF_INT_BWD = 1, AR_PROF_FP4_FWD = 2, AR_PROF_FP4_BWD = 3, AR_PROF_GEMM_DW = 4,
+       AR_PROF_NORM = 5, AR_PROF_SWIGLU = 6, AR_PROF_ROPE = 7 };
+int ar_profile_enable(int on);
+int ar_profile_reset(void);
+int ar_profile_read(int kernel_id, int64_t min_units, double* total_ms, double* min_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

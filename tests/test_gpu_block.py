@@ -118,8 +118,9 @@ def test_first_step_is_bit_exact_vs_torch_ref():
     blk_m = copy.deepcopy(layer)
     random.seed(5)
     q = SignRoundQuantizer(SignRoundConfig(iters=200, batch_size=4, bits=4, not_use_best_mse=True), device="cuda")
-    # run exactly one iteration by limiting iters through a custom scheduler-free config copy
-    q.config.iters = 1
+    # exactly ONE applied step: with not_use_best_mse the parameters are snapshotted at the last iteration BEFORE its
+    # optimizer step (reference sign_round/quantizer.py:513-514), so two iterations leave the state after step 0
+    q.config.iters = 2
     q.config.lr = 1.0 / 200
     q.config.minmax_lr = 1.0 / 200
     q.config.lr_is_auto = False

@@ -54,7 +54,7 @@ class _FakeQuantizer:
     """Stands in for SignRoundQuantizer in the CPU test: same surface tune_sharded uses."""
 
     class _Cfg:
-        batch_size, iters, gradient_accumulate_steps = 2, 6, 1
+        batch_size, iters, gradient_accumulate_steps, enable_quanted_input = 2, 6, 1, False
 
     def __init__(self):
         self.config = self._Cfg()
@@ -64,8 +64,16 @@ class _FakeQuantizer:
         with torch.no_grad():
             return torch.cat([block(x[i:i + 2]) for i in range(0, x.shape[0], 2)])
 
-    def quantize_block(self, block, xin, others, yout, q_inputs, ctx, index_schedule=None):
-        self.last_stats = {"sched_sum": int(np.array(index_schedule).sum()), "in_sum": float(xin.sum()), "out_sum": float(yout.sum())}
+    calibrated = None
+
+    def calibrate_block(self, block, x, others):          # the relay's forward IS the block's calibration forward
+        self.calibrated = (self.calibrated or 0) + 1
+        return self.forward_all(block, x, others)
+
+    def quantize_block(self, block, xin, others, yout, q_inputs, ctx, input_ids=None, index_schedule=None):
+        assert input_ids == "ids"                         # the loss mask reaches the sharded blocks
+        self.last_stats = {"sched_sum": int(np.array(index_schedule).sum()), "in_sum": float(xin.sum()), "out_sum": float(yout.sum()),
+                           "calibrated": self.calibrated}
         return {"dummy": torch.tensor(float(len(index_schedule)))}
 
 
@@ -82,7 +90,7 @@ def _worker(rank, world, port, tmp):
             x0.copy_(torch.randn(N, 4, H, generator=torch.Generator().manual_seed(7)))
         q = _FakeQuantizer()
         mine = [b if sh.owner_of(k, n_blocks, world) == rank else None for k, b in enumerate(blocks)]
-        res = sh.tune_sharded(mine, x0, {}, q, seed=42)
+        res = sh.tune_sharded(mine, x0, {}, q, seed=42, input_ids="ids")
         # sequential ground truth
         xs = [torch.randn(N, 4, H, generator=torch.Generator().manual_seed(7))]
         for b in blocks:
@@ -93,6 +101,14 @@ def _worker(rank, world, port, tmp):
             assert abs(r["stats"]["in_sum"] - float(xs[k].sum())) < 1e-4, (rank, k)
             assert abs(r["stats"]["out_sum"] - float(xs[k + 1].sum())) < 1e-4, (rank, k)
             assert r["stats"]["sched_sum"] == int(np.array(sched[k]).sum())
+            # every owned block went through calibrate_block before it was tuned (pipelined: one by one, in block order)
+            assert r["stats"]["calibrated"] == sorted(res).index(k) + 1, (rank, k, r["stats"])
+        # the two-phase form (whole sweep first) gives the same pairs and schedules
+        q2 = _FakeQuantizer()
+        res2 = sh.tune_sharded(mine, x0.clone() if rank == 0 else torch.zeros_like(x0), {}, q2, seed=42, input_ids="ids", pipelined=False)
+        for k, r in res.items():
+            assert res2[k]["stats"]["in_sum"] == r["stats"]["in_sum"] and res2[k]["stats"]["sched_sum"] == r["stats"]["sched_sum"]
+            assert res2[k]["stats"]["calibrated"] == len(res)
         merged = sh.gather_results({k: v["stats"] for k, v in res.items()}, dst=0)
         if rank == 0:
             assert sorted(merged) == list(range(n_blocks))
