@@ -51,6 +51,8 @@ SIGNATURES = {
     "ar_search_fp4_scale": (c_int, [P, P, P, L, P, P, I, P, L, I, I, I, P]),
     "ar_fp4_act_bwd": (c_int, [P, P, P, P, L, I, I, I, P]),
     "ar_pack_fp4": (c_int, [P, P, P, L, L, I, I, I, P, P, P]),
+    "ar_gemm_dw": (c_int, [P, P, P, L, L, L, L, L, L, I, P]),
+    "ar_gemm_dw_config": (c_int, [I, I]),
     "ar_profile_enable": (c_int, [I]),
     "ar_profile_reset": (c_int, []),
     "ar_profile_read": (c_int, [I, L, P, P, P]),

@@ -1,0 +1,255 @@
+// ar_gemm.hip -- hand-written MFMA weight-gradient GEMM for gfx950:  dW[M,N] = dY^T X  with dY [K,M], X [K,N] row-major bf16.
+//
+// replaces: the autograd backward of F.linear(x, weight_q) w.r.t. weight_q inside WrapperLinear.forward
+//           (auto_round/wrapper.py:528-556) -- torch.mm(dY.t(), X), a "TN" GEMM whose two operands are both strided in the
+//           reduction dimension (tokens).  hipBLASLt runs it at ~1.0 PFLOP/s on MI355X (MT256x256x32, 47 % MFMA utilisation);
+//           it is 27 % of a Llama-3-8B tuning iteration (profiles/r01_llama8b_block_kernel_stats.csv).
+//
+// Design (CDNA4-first):
+//   * 256x256 output tile per 512-thread workgroup (8 waves = 2 per SIMD), wave tile 64(m) x 128(n), v_mfma_f32_32x32x16_bf16
+//     computing the TRANSPOSED tile (a-operand = X fragment, b-operand = dY fragment): every lane then owns, for ONE output
+//     row m, runs of 4 consecutive n -- 8-byte stores, and a quant group (128 consecutive n of one row) lives in one lane
+//     pair, which is what the fused backward + sign-SGD epilogue wants.
+//   * both operands are K-strided in memory, so tiles are staged [k][256] exactly as they lie in HBM (each k-row is one
+//     coalesced 512-byte piece) by LDS-DMA (global_load_lds, 16 B per lane, no staging VGPRs) and the MFMA fragments are read
+//     with ds_read_b64_tr_b16 -- the hardware 4x4 transposing LDS read -- instead of transposing in registers.
+//   * the LDS image is XOR-swizzled on the 16-byte chunk index, chunk ^= (k & 3) << 2 (applied to the per-lane SOURCE address of
+//     the DMA and to the read address; the DMA destination stays lane-linear), so the four k-rows a transposing read touches
+//     fall on disjoint bank ranges.
+//   * K is consumed in units of 16 (one MFMA K-step; 16 KB of LDS per unit for both operands) through a ring of 8 units with
+//     6 units of DMA in flight; counted s_waitcnt vmcnt(8) -- never 0 -- and raw s_barrier keep the DMA in flight across
+//     barriers.  The two waves of a SIMD run half a period apart (waves 4-7 take one extra barrier up front): while one is in
+//     its 8-MFMA cluster the other issues its 12 fragment reads and 2 DMA pieces, so the matrix pipe always has a taker.
+//   * XCD-aware tile order: each XCD (own L2) works on 2x8-tile patches, two patches of one column band at a time, so the 32
+//     concurrent workgroups of an XCD share 8 X panels and 4 dY panels per K-unit instead of fetching 64.
+#include "ar_common.hpp"
+
+namespace ar {
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+constexpr int GB = 256;                       // block tile edge (M and N)
+constexpr int GU = 16;                        // k per unit
+constexpr int GR = 8;                         // ring size in units
+constexpr int GD = 6;                         // units of DMA in flight
+constexpr int ROWB = GB * 2;                  // bytes per staged k-row
+constexpr int PIECE = GU * ROWB;              // 8192: one operand's piece of a unit
+constexpr int UNIT = 2 * PIECE;               // 16384
+constexpr int GEMM_LDS = GR * UNIT;           // 131072
+constexpr int GTHREADS = 512;
+
+struct GemmArgs {
+    const uint16_t* Y;   // dY [K, M]  (ldy)
+    const uint16_t* X;   // X  [K, N]  (ldx)
+    uint16_t* W;         // dW [M, N]  (ldw)
+    int M, N, K;
+    int64_t ldy, ldx, ldw;
+    int accumulate;      // dW += (torch addmm_ semantics: fp32 sum of the old bf16 value and the fp32 accumulator, rounded once)
+    int tiles_m, tiles_n, order;
+};
+
+__device__ __forceinline__ void tile_of_block(const GemmArgs& a, int bid, int& tm, int& tn) {
+    const int nwg = a.tiles_m * a.tiles_n;
+    if (a.order == 2 && (a.tiles_m % 2 == 0) && (a.tiles_n % 8 == 0) && ((nwg / 16) % 8 == 0)) {
+        const int x = bid & 7, s = bid >> 3, t = s >> 4, j = s & 15;
+        const int pn = a.tiles_n >> 3;
+        const int p = x + 8 * t;
+        tm = (p / pn) * 2 + (j >> 3);
+        tn = (p % pn) * 8 + (j & 7);
+        return;
+    }
+    int id = bid;
+    if (a.order >= 1 && nwg % 8 == 0) id = (bid & 7) * (nwg >> 3) + (bid >> 3);      // contiguous chunk per XCD
+    tm = id / a.tiles_n;
+    tn = id % a.tiles_n;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// SEM selects which (k-row, 4-column piece) a lane of a 16-lane group hands to the transposing read: 1 = row i>>2, piece i&3 --
+// the hardware's rule, pinned on the GPU by tools/mfma_probe (profiles/r02_mfma_probe.json: within a 16-lane group, lane L
+// receives element L%4 of the 8-byte pieces supplied by lanes L/4, L/4+4, L/4+8, L/4+12); 2 = row i&3, piece i>>2 (kept as the
+// negative control of tools/gemm_dw_probe.py).
+template <int SEM>
+__global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wm = wave & 3, wn = wave >> 2;
+    int tm, tn;
+    tile_of_block(a, blockIdx.x, tm, tn);
+    const int64_t m0 = (int64_t)tm * GB, n0 = (int64_t)tn * GB;
+    const int U = a.K / GU;
+
+    // ---- DMA source pointers: this wave moves k-rows {2*wave, 2*wave+1} of each operand's piece; lane -> (row, physical chunk)
+    const int drow = 2 * wave + (lane >> 5);
+    const int pchunk = lane & 31;
+    const int lchunk = pchunk ^ ((drow & 3) << 2);
+    const uint16_t* srcP = a.X + (int64_t)drow * a.ldx + n0 + lchunk * 8;
+    const uint16_t* srcQ = a.Y + (int64_t)drow * a.ldy + m0 + lchunk * 8;
+    const int64_t stepP = (int64_t)GU * a.ldx, stepQ = (int64_t)GU * a.ldy;
+    const int dstoff = 2 * wave * ROWB;       // wave-uniform byte offset inside a piece
+
+    // ---- fragment read offsets (bytes inside a unit)
+    const int q = lane >> 4, i = lane & 15, g = q >> 1;
+    const int rowsel = (SEM == 2) ? (i & 3) : (i >> 2);
+    const int piece = (SEM == 2) ? (i >> 2) : (i & 3);
+    const int rowoff = (8 * g + rowsel) * ROWB + (piece & 1) * 8;
+    int offP[4], offQ[2];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int chunk = wn * 16 + ni * 4 + (q & 1) * 2 + (piece >> 1);
+        offP[ni] = rowoff + ((chunk ^ (rowsel << 2)) << 4);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int chunk = wm * 8 + mi * 4 + (q & 1) * 2 + (piece >> 1);
+        offQ[mi] = PIECE + rowoff + ((chunk ^ (rowsel << 2)) << 4);
+    }
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto issue = [&](int v) {      // DMA of unit v (clamped: the last D issues of the loop re-stage the final unit, never read)
+        const int vv = v < U ? v : U - 1;
+        uint8_t* dst = lds + (v & (GR - 1)) * UNIT + dstoff;
+        __builtin_amdgcn_global_load_lds((const void*)(srcP + vv * stepP), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(srcQ + vv * stepQ), (__attribute__((address_space(3))) void*)(dst + PIECE), 16, 0, 0);
+    };
+    // Fragment reads are issued as inline asm on purpose: to hipcc an LDS-DMA in flight is a pending store to "some LDS", so
+    // it puts s_waitcnt vmcnt(0) in front of the first LDS read it can see after a global_load_lds -- which would drain the
+    // 6-unit DMA pipeline every unit.  The asm reads are invisible to that pass; ordering against the DMA is provided by the
+    // counted vmcnt + barrier protocol above, and the MFMAs wait for their operands with an explicit counted lgkmcnt (LDS
+    // reads return in order: lgkmcnt(12) leaves exactly the 12 reads of the NEXT unit's prefetch outstanding).
+    auto rd = [&](uint32_t addr, s16x4_t& lo, s16x4_t& hi) {
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                     : "=&v"(lo), "=&v"(hi)
+                     : "v"(addr), "n"(4 * ROWB)
+                     : "memory");
+    };
+    struct Frags { s16x4_t plo[4], phi[4], qlo[2], qhi[2]; };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    auto read_frags = [&](int v, Frags& f) {
+        const uint32_t base = lds0 + (uint32_t)((v & (GR - 1)) * UNIT);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) rd(base + offQ[mi], f.qlo[mi], f.qhi[mi]);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) rd(base + offP[ni], f.plo[ni], f.phi[ni]);
+    };
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    auto cat = [](const s16x4_t& lo, const s16x4_t& hi) -> bf16x8_t {
+        return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto mma = [&](const Frags& f) {
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat(f.plo[ni], f.phi[ni]), cat(f.qlo[mi], f.qhi[mi]), acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue
+#pragma unroll
+    for (int v = 0; v < GD; ++v) issue(v);
+    wait_vm<(GD - 2) * 2>();
+    bar();
+    Frags fa, fb;
+    read_frags(0, fa);
+    if (grp == 1) bar();
+
+    // ---- main loop: two units per trip (static register sets)
+    for (int u = 0; u < U; u += 2) {
+        read_frags(u + 1, fb);
+        issue(u + GD);
+        wait_vm<(GD - 2) * 2>();
+        bar();
+        mma(fa);
+        bar();
+        read_frags(u + 2, fa);
+        issue(u + 1 + GD);
+        wait_vm<(GD - 2) * 2>();
+        bar();
+        mma(fb);
+        bar();
+    }
+    if (grp == 0) bar();
+    wait_vm<0>();          // no LDS-DMA may outlive the workgroup's LDS allocation
+
+    // ---- epilogue: lane owns row m = m0 + wm*64 + mi*32 + (lane&31); n = n0 + wn*128 + ni*32 + 8*t + 4*(lane>>5) + r
+    const int h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 32 + (lane & 31);
+        uint16_t* rowp = a.W + m * a.ldw + n0 + wn * 128 + 4 * h;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint16_t* p = rowp + ni * 32 + 8 * t;
+                float v0 = acc[mi][ni][4 * t + 0], v1 = acc[mi][ni][4 * t + 1], v2 = acc[mi][ni][4 * t + 2], v3 = acc[mi][ni][4 * t + 3];
+                if (a.accumulate) {
+                    const uint2 old = *reinterpret_cast<const uint2*>(p);
+                    v0 += bf16_lo(old.x); v1 += bf16_hi(old.x); v2 += bf16_lo(old.y); v3 += bf16_hi(old.y);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(p) = o;
+            }
+        }
+    }
+}
+
+static int g_gemm_sem = 1, g_gemm_order = 2;    // rule 1 is what the hardware does (profiles/r02_mfma_probe.json)
+
+}  // namespace ar
+
+using namespace ar;
+
+extern "C" int ar_gemm_dw_config(int sem, int order) {      // experiment knobs (tools/gemm_dw_probe.py); -1 keeps a value
+    if (sem == 1 || sem == 2) g_gemm_sem = sem;
+    if (order >= 0 && order <= 2) g_gemm_order = order;
+    return g_gemm_sem * 10 + g_gemm_order;
+}
+
+extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
+                          int64_t ldw, int accumulate, ar_stream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return AR_OK;
+    if (M % GB || N % GB || K % (2 * GU) || K < GD * GU || (ldy % 8) || (ldx % 8) || (ldw % 4)) return AR_ERR_UNSUPPORTED;
+    if (((uintptr_t)dY | (uintptr_t)X) & 15 || ((uintptr_t)dW & 7)) return AR_ERR_UNSUPPORTED;
+    GemmArgs a;
+    a.Y = (const uint16_t*)dY; a.X = (const uint16_t*)X; a.W = (uint16_t*)dW;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = accumulate;
+    a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = g_gemm_order;
+    const int grid = a.tiles_m * a.tiles_n;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_dw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    if (g_gemm_sem == 1) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw<1>), grid, GTHREADS, GEMM_LDS, st, a);
+    else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw<2>), grid, GTHREADS, GEMM_LDS, st, a);
+    return launch_status();
+}

@@ -47,6 +47,9 @@ def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+import contextlib as _contextlib
+
+_NULLCTX = _contextlib.nullcontext()
 _devs_seen: list = []     # device index of every tensor handed to the launch being assembled (checked by _launch)
 
 
@@ -338,6 +341,36 @@ def pack_fp4(Wq2d, scale, *, mode, gs, global_scale=None):
     _launch("ar_pack_fp4", _p(Wq2d, "Wq"), _p(scale, "scale"), _p(global_scale), out_f, in_f, gs, mode,
                              dt_code(Wq2d.dtype), _p(packed), _p(sb))
     return packed, sb
+
+
+def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> bool:
+    """out[M,N] (+)= dY2d[K,M]^T @ X2d[K,N] through the hand-written MFMA kernel (bf16, fp32 accumulate).  Operands may be
+    column slices of wider row-major buffers (unit inner stride).  -> False when the shape / alignment is outside what the
+    kernel takes (the caller then keeps the library GEMM); raises on a failed launch."""
+    if dY2d.dtype != torch.bfloat16 or X2d.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
+        return False
+    if dY2d.dim() != 2 or X2d.dim() != 2 or out.dim() != 2 or dY2d.stride(1) != 1 or X2d.stride(1) != 1 or out.stride(1) != 1:
+        return False
+    K, M = dY2d.shape
+    N = X2d.shape[1]
+    if X2d.shape[0] != K or tuple(out.shape) != (M, N):
+        raise ValueError("gemm_dw: shape mismatch")
+    for t in (dY2d, X2d, out):
+        if not t.is_cuda:
+            raise _lib.Mi355xLibraryError("gemm_dw: the MI355X path only runs on a HIP device and has no CPU fallback")
+        _devs_seen.append(t.device.index)
+    devs = set(_devs_seen)
+    _devs_seen.clear()
+    if len(devs) != 1:
+        raise _lib.Mi355xLibraryError("gemm_dw: tensors live on different HIP devices")
+    (dev,) = devs
+    with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
+        rc = load().ar_gemm_dw(dY2d.data_ptr(), X2d.data_ptr(), out.data_ptr(), M, N, K, dY2d.stride(0), X2d.stride(0), out.stride(0),
+                               int(bool(accumulate)), torch.cuda.current_stream(dev).cuda_stream)
+    if rc == _lib.AR_ERR_UNSUPPORTED:
+        return False
+    check(rc, "ar_gemm_dw")
+    return True
 
 
 # ---- optional device-side timing of the hot kernels (ar_profile_*; bench.py and tools only) ----------------------------

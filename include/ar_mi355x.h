@@ -229,6 +229,19 @@ int ar_fp4_act_bwd(const void* dXq, const void* X, void* dX, const float* global
 int ar_pack_fp4(const void* Wq, const void* scale, const float* global_scale_dev, int64_t out_f, int64_t in_f, int gs,
                 int mode, int w_dt, uint8_t* packed, uint8_t* scale_bytes, ar_stream_t stream);
 
+/* ---- weight-gradient GEMM (hand-written MFMA, gfx950) -------------------------------------------------------------
+ * replaces: the autograd backward of F.linear(x, weight_q) with respect to weight_q inside WrapperLinear.forward
+ *           (auto_round/wrapper.py:528-556): dW[M,N] = dY^T X, dY [K,M] and X [K,N] row-major bf16 (leading dimensions in
+ *           elements), fp32 accumulation, one rounding to bf16; accumulate != 0 adds the previous bf16 dW before rounding
+ *           (torch addmm_, the gradient-accumulation case).  M, N multiples of 256, K a multiple of 32 and >= 96; operands
+ *           16-byte aligned, ldy/ldx multiples of 8, ldw a multiple of 4; anything else returns AR_ERR_UNSUPPORTED and the
+ *           caller keeps the library GEMM.  Needs 128 KB of dynamic LDS per workgroup. */
+int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
+               int64_t ldw, int accumulate, ar_stream_t stream);
+/* experiment knobs of the kernel above for tools/gemm_dw_probe.py (binding hygiene; -1 keeps a value): sem = lane->piece rule
+ * of the transposing LDS read (1 | 2), order = tile order (0 identity, 1 XCD chunks, 2 XCD 2x8 patches).  Returns sem*10+order. */
+int ar_gemm_dw_config(int sem, int order);
+
 /* ---- optional device-side timing of the hot kernels (bench.py / tools; OFF by default) --------------------------
  * binding hygiene / measurement, no reference counterpart (the reference times blocks on the host,
  * compressors/orchestrator.py:792-794).  While enabled, each profiled launch carries a start/stop event pair on the dispatch

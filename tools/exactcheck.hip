@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #define AR_FASTDIV 1
 #define AR_HW_BF16 1
@@ -73,8 +74,63 @@ __global__ void check_bf16(unsigned long long* out) {
     atomicAdd(out, bad);
 }
 
+// (3) MXFP4 shared exponent: floorf(log2f(x)) as the fp4 kernels evaluate it (csrc/ar_fp4.hip fp4_group_scale) against the host
+//     libm (glibc log2f -- what the C oracle and the CPU goldens use) for every float within +-8 ulp of every power of two
+//     2^k, k in [-149, 127] (the only inputs where a 1-ulp difference between two libms can move the floor), and for 2^24
+//     pseudo-random positive floats.
+__global__ void eval_floor_log2(const float* x, float* y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = floorf(log2f(x[i]));
+}
+
+#include <math.h>
+#include <vector>
+static void check_log2() {
+    std::vector<float> xs;
+    for (int k = -149; k <= 127; ++k) {
+        const float p = ldexpf(1.0f, k);
+        uint32_t b; memcpy(&b, &p, 4);
+        for (int d = -8; d <= 8; ++d) {
+            const int64_t bb = (int64_t)b + d;
+            if (bb <= 0 || bb >= 0x7f800000ll) continue;
+            const uint32_t u = (uint32_t)bb; float f; memcpy(&f, &u, 4);
+            xs.push_back(f);
+        }
+    }
+    const size_t n_edge = xs.size();
+    uint64_t h = 0x1234567ull;
+    for (int i = 0; i < (1 << 24); ++i) {
+        h = h * 6364136223846793005ull + 1442695040888963407ull;
+        uint32_t u = (uint32_t)(h >> 33) % 0x7f800000u;
+        if (u == 0) u = 1;
+        float f; memcpy(&f, &u, 4);
+        xs.push_back(f);
+    }
+    float *dx, *dy;
+    hipMalloc(&dx, xs.size() * 4); hipMalloc(&dy, xs.size() * 4);
+    hipMemcpy(dx, xs.data(), xs.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(eval_floor_log2, (unsigned)((xs.size() + 255) / 256), 256, 0, 0, dx, dy, (int)xs.size());
+    std::vector<float> ys(xs.size());
+    hipMemcpy(ys.data(), dy, xs.size() * 4, hipMemcpyDeviceToHost);
+    unsigned long long bad_edge = 0, bad_rand = 0, bad_vs_exponent = 0;
+    for (size_t i = 0; i < xs.size(); ++i) {
+        const float host = floorf(log2f(xs[i]));
+        if (host != ys[i]) {
+            if (i < n_edge) { if (bad_edge < 8) printf("{\"log2_mismatch\": {\"x_bits\": %u, \"gpu\": %g, \"host\": %g}}\n", *(uint32_t*)&xs[i], ys[i], host); ++bad_edge; }
+            else ++bad_rand;
+        }
+        int e; frexpf(xs[i], &e);
+        if (i < n_edge && ys[i] != (float)(e - 1)) ++bad_vs_exponent;      // informational: where floor(log2f) != exponent field
+    }
+    printf("{\"check\": \"floorf(log2f(x)) GPU (ocml) vs host (glibc)\", \"edge_inputs\": %zu, \"edge_mismatch\": %llu, "
+           "\"random_inputs\": %d, \"random_mismatch\": %llu, \"edge_inputs_where_gpu_floor_differs_from_exponent_field\": %llu}\n",
+           n_edge, bad_edge, 1 << 24, bad_rand, bad_vs_exponent);
+    hipFree(dx); hipFree(dy);
+}
+
 int main() {
     unsigned long long *d, h[4];
+    check_log2();
     hipMalloc(&d, sizeof(h));
     for (int wdt = 0; wdt < 2; ++wdt) {
         hipMemset(d, 0, sizeof(h));
