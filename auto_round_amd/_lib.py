@@ -51,6 +51,12 @@ SIGNATURES = {
     "ar_search_fp4_scale": (c_int, [P, P, P, L, P, P, I, P, L, I, I, I, P]),
     "ar_fp4_act_bwd": (c_int, [P, P, P, P, L, I, I, I, P]),
     "ar_pack_fp4": (c_int, [P, P, P, L, L, I, I, I, P, P, P]),
+    "ar_rmsnorm_fwd": (c_int, [P, P, P, P, L, I, F, I, P]),
+    "ar_rmsnorm_bwd": (c_int, [P, P, P, P, P, P, L, I, I, P]),
+    "ar_swiglu_fwd": (c_int, [P, L, P, L, L, I, P]),
+    "ar_swiglu_bwd": (c_int, [P, P, L, L, L, I, P]),
+    "ar_rope_fwd": (c_int, [P, L, P, P, L, P, P, P, L, L, I, I, I, I, P]),
+    "ar_rope_bwd": (c_int, [P, P, P, P, P, L, P, L, L, L, I, I, I, I, P]),
     "ar_gemm_dw": (c_int, [P, P, P, L, L, L, L, L, L, I, P]),
     "ar_gemm_dw_config": (c_int, [I, I]),
     "ar_profile_enable": (c_int, [I]),

@@ -1,0 +1,337 @@
+// ar_block.hip -- the elementwise / normalisation work of a Llama-family decoder block as fused HBM-bound kernels.
+//
+// replaces (for the duration of the tuning loop): what the reference gets from torch.compile(block_forward)
+// (auto_round/utils/device.py:112-122, compressors/base.py:1177-1179, "about 20 %") on the block code transformers runs eagerly:
+//   LlamaRMSNorm.forward, apply_rotary_pos_emb + repeat_kv, act_fn(gate) * up and their autograd backwards
+//   (transformers/models/llama/modeling_llama.py).  On MI355X these were ~90 launches and 20 % of a Llama-3-8B tuning iteration
+//   (profiles/r01_llama8b_block_kernel_stats.csv); here they are six streaming kernels, 16-byte accesses, one pass each.
+//
+// Forward kernels round where the eager module code rounds (so the fused forward tracks transformers' bf16 forward closely);
+// backward kernels evaluate the exact fp32 derivative and round once.  All tensors are token-major: [tokens, features].
+#include "ar_common.hpp"
+
+namespace ar {
+
+// ---- RMSNorm ------------------------------------------------------------------------------------------------------------
+// y = w * dt(x * rsqrt(mean(x^2) + eps))     (LlamaRMSNorm.forward: fp32 statistics, one rounding to the activation dtype,
+// then the product with the weight rounded again).  One wave per row, the row stays in registers (MAXC chunks of 8 per lane).
+template <int DT, int MAXC>
+__global__ __launch_bounds__(kTPB) void k_rmsnorm_fwd(const void* __restrict__ x, const void* __restrict__ w, void* __restrict__ y,
+                                                       float* __restrict__ rstd_out, int64_t rows, int hidden, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kTPB / kWave) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = hidden / kEPT;
+    Raw8<DT> rx[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * kWave;
+        if (ch < nch) {
+            rx[c] = load8_raw<DT>(x, row * hidden + (int64_t)ch * kEPT);
+            float v[8];
+            unpack8<DT>(rx[c], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+        }
+    }
+    ss = lanes_sum(ss, kWave);
+    const float rstd = 1.0f / __builtin_sqrtf(ss / (float)hidden + eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * kWave;
+        if (ch < nch) {
+            float v[8], wv[8], o[8];
+            unpack8<DT>(rx[c], v);
+            unpack8<DT>(load8_raw<DT>(w, (int64_t)ch * kEPT), wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = wv[j] * round_to<DT>(v[j] * rstd);
+            store8<DT>(y, row * hidden + (int64_t)ch * kEPT, o);
+        }
+    }
+}
+
+// dx = rstd * (g - xhat * mean(g * xhat)) [+ dres],  g = dy * w,  xhat = x * rstd        (exact derivative, fp32, one rounding)
+template <int DT, int MAXC>
+__global__ __launch_bounds__(kTPB) void k_rmsnorm_bwd(const void* __restrict__ dy, const void* __restrict__ x, const void* __restrict__ w,
+                                                       const float* __restrict__ rstd_in, const void* __restrict__ dres,
+                                                       void* __restrict__ dx, int64_t rows, int hidden) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kTPB / kWave) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = hidden / kEPT;
+    const float rstd = rstd_in[row];
+    Raw8<DT> rx[MAXC], rg[MAXC];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * kWave;
+        if (ch < nch) {
+            rx[c] = load8_raw<DT>(x, row * hidden + (int64_t)ch * kEPT);
+            rg[c] = load8_raw<DT>(dy, row * hidden + (int64_t)ch * kEPT);
+            float xv[8], gv[8], wv[8];
+            unpack8<DT>(rx[c], xv);
+            unpack8<DT>(rg[c], gv);
+            unpack8<DT>(load8_raw<DT>(w, (int64_t)ch * kEPT), wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += (gv[j] * wv[j]) * (xv[j] * rstd);
+        }
+    }
+    dot = lanes_sum(dot, kWave) / (float)hidden;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * kWave;
+        if (ch < nch) {
+            float xv[8], gv[8], wv[8], o[8];
+            unpack8<DT>(rx[c], xv);
+            unpack8<DT>(rg[c], gv);
+            unpack8<DT>(load8_raw<DT>(w, (int64_t)ch * kEPT), wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = rstd * (gv[j] * wv[j] - (xv[j] * rstd) * dot);
+            if (dres) {
+                float rv[8];
+                unpack8<DT>(load8_raw<DT>(dres, row * hidden + (int64_t)ch * kEPT), rv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += rv[j];
+            }
+            store8<DT>(dx, row * hidden + (int64_t)ch * kEPT, o);
+        }
+    }
+}
+
+// ---- SwiGLU -------------------------------------------------------------------------------------------------------------
+// a = dt(dt(silu(g)) * u), g = gu[:, :F], u = gu[:, F:2F]       (LlamaMLP.forward: act_fn(gate_proj(x)) * up_proj(x))
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+template <int DT>
+__global__ __launch_bounds__(kTPB) void k_swiglu_fwd(const void* __restrict__ gu, int64_t ld, void* __restrict__ a, int64_t rows, int64_t F) {
+    const int64_t cpr = F / kEPT;
+    const int64_t idx = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+    if (idx >= rows * cpr) return;
+    const int64_t r = idx / cpr, c = idx - r * cpr;
+    float g[8], u[8], o[8];
+    unpack8<DT>(load8_raw<DT>(gu, r * ld + c * kEPT), g);
+    unpack8<DT>(load8_raw<DT>(gu, r * ld + F + c * kEPT), u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = round_to<DT>(silu_f(g[j])) * u[j];
+    store8<DT>(a, r * F + c * kEPT, o);
+}
+
+// in place on gu: (g, u) <- (dg, du) with dg = da * u * silu'(g), du = da * silu(g); silu'(g) = s * (1 + g * (1 - s)), s = sigmoid(g)
+template <int DT>
+__global__ __launch_bounds__(kTPB) void k_swiglu_bwd(const void* __restrict__ da, void* __restrict__ gu, int64_t ld, int64_t rows, int64_t F) {
+    const int64_t cpr = F / kEPT;
+    const int64_t idx = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+    if (idx >= rows * cpr) return;
+    const int64_t r = idx / cpr, c = idx - r * cpr;
+    float g[8], u[8], d[8], dg[8], du[8];
+    unpack8<DT>(load8_raw<DT>(gu, r * ld + c * kEPT), g);
+    unpack8<DT>(load8_raw<DT>(gu, r * ld + F + c * kEPT), u);
+    unpack8<DT>(load8_raw<DT>(da, r * F + c * kEPT), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float s = 1.0f / (1.0f + expf(-g[j]));
+        dg[j] = d[j] * u[j] * (s * (1.0f + g[j] * (1.0f - s)));
+        du[j] = d[j] * (g[j] * s);
+    }
+    store8<DT>(gu, r * ld + c * kEPT, dg);
+    store8<DT>(gu, r * ld + F + c * kEPT, du);
+}
+
+// ---- rotary embedding + grouped-query head repeat -------------------------------------------------------------------------
+// qkv [T, (hq + 2 hkv) * d] (ld) -> q [T, hq*d], k [T, hq*d], v [T, hq*d] with every kv head written hq/hkv times (what repeat_kv
+// materialises for the SDPA kernels).  x_embed = dt(dt(x*cos) + dt(rotate_half(x)*sin))   (apply_rotary_pos_emb, each op rounded).
+// One lane handles the chunk pair (i, i + d/2) of one head of one token.
+template <int DT>
+__global__ __launch_bounds__(kTPB) void k_rope_fwd(const void* __restrict__ qkv, int64_t ld, const void* __restrict__ cs, const void* __restrict__ sn,
+                                                    int64_t cs_bstride, void* __restrict__ q, void* __restrict__ k, void* __restrict__ v,
+                                                    int64_t tokens, int64_t seq, int hq, int hkv, int d) {
+    const int ppl = d / (2 * kEPT);                         // chunk pairs per head
+    const int heads = hq + 2 * hkv;
+    const int64_t idx = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+    if (idx >= tokens * heads * ppl) return;
+    const int p = (int)(idx % ppl);
+    const int head = (int)((idx / ppl) % heads);
+    const int64_t t = idx / ((int64_t)ppl * heads);
+    const int64_t src = t * ld + (int64_t)head * d + p * kEPT;
+    float lo[8], hi[8], olo[8], ohi[8];
+    unpack8<DT>(load8_raw<DT>(qkv, src), lo);
+    unpack8<DT>(load8_raw<DT>(qkv, src + d / 2), hi);
+    const int rep = hq / hkv;
+    if (head < hq + hkv) {
+        const int64_t b = t / seq, s = t - b * seq;
+        const int64_t co = b * cs_bstride + s * d + p * kEPT;
+        float cl[8], ch[8], sl[8], sh[8];
+        unpack8<DT>(load8_raw<DT>(cs, co), cl);
+        unpack8<DT>(load8_raw<DT>(cs, co + d / 2), ch);
+        unpack8<DT>(load8_raw<DT>(sn, co), sl);
+        unpack8<DT>(load8_raw<DT>(sn, co + d / 2), sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            olo[j] = round_to<DT>(lo[j] * cl[j]) + round_to<DT>(-hi[j] * sl[j]);       // rotate_half: first half takes -x[d/2:]
+            ohi[j] = round_to<DT>(hi[j] * ch[j]) + round_to<DT>(lo[j] * sh[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { olo[j] = lo[j]; ohi[j] = hi[j]; }
+    }
+    const int64_t orow = t * (int64_t)hq * d;
+    if (head < hq) {
+        store8<DT>(q, orow + (int64_t)head * d + p * kEPT, olo);
+        store8<DT>(q, orow + (int64_t)head * d + p * kEPT + d / 2, ohi);
+    } else {
+        void* dst = head < hq + hkv ? k : v;
+        const int kvh = head < hq + hkv ? head - hq : head - hq - hkv;
+        for (int r = 0; r < rep; ++r) {
+            const int64_t o = orow + (int64_t)(kvh * rep + r) * d + p * kEPT;
+            store8<DT>(dst, o, olo);
+            store8<DT>(dst, o + d / 2, ohi);
+        }
+    }
+}
+
+// backward: dq, dk, dv [T, hq*d] (gradients of the repeated heads) -> dqkv [T, (hq + 2 hkv) * d] (ld): sums over the hq/hkv copies,
+// then the transpose of the rotation: dx_lo = dy_lo*cos_lo + dy_hi*sin_hi ; dx_hi = dy_hi*cos_hi - dy_lo*sin_lo.
+template <int DT>
+__global__ __launch_bounds__(kTPB) void k_rope_bwd(const void* __restrict__ dq, const void* __restrict__ dk, const void* __restrict__ dv,
+                                                    const void* __restrict__ cs, const void* __restrict__ sn, int64_t cs_bstride,
+                                                    void* __restrict__ dqkv, int64_t ld, int64_t tokens, int64_t seq, int hq, int hkv, int d) {
+    const int ppl = d / (2 * kEPT);
+    const int heads = hq + 2 * hkv;
+    const int64_t idx = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+    if (idx >= tokens * heads * ppl) return;
+    const int p = (int)(idx % ppl);
+    const int head = (int)((idx / ppl) % heads);
+    const int64_t t = idx / ((int64_t)ppl * heads);
+    const int rep = hq / hkv;
+    const int64_t irow = t * (int64_t)hq * d;
+    float lo[8], hi[8];
+    if (head < hq) {
+        unpack8<DT>(load8_raw<DT>(dq, irow + (int64_t)head * d + p * kEPT), lo);
+        unpack8<DT>(load8_raw<DT>(dq, irow + (int64_t)head * d + p * kEPT + d / 2), hi);
+    } else {
+        const void* srcp = head < hq + hkv ? dk : dv;
+        const int kvh = head < hq + hkv ? head - hq : head - hq - hkv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { lo[j] = 0.f; hi[j] = 0.f; }
+        for (int r = 0; r < rep; ++r) {
+            float a[8], b[8];
+            const int64_t o = irow + (int64_t)(kvh * rep + r) * d + p * kEPT;
+            unpack8<DT>(load8_raw<DT>(srcp, o), a);
+            unpack8<DT>(load8_raw<DT>(srcp, o + d / 2), b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { lo[j] += a[j]; hi[j] += b[j]; }
+        }
+    }
+    float olo[8], ohi[8];
+    if (head < hq + hkv) {
+        const int64_t b = t / seq, s = t - b * seq;
+        const int64_t co = b * cs_bstride + s * d + p * kEPT;
+        float cl[8], ch[8], sl[8], sh[8];
+        unpack8<DT>(load8_raw<DT>(cs, co), cl);
+        unpack8<DT>(load8_raw<DT>(cs, co + d / 2), ch);
+        unpack8<DT>(load8_raw<DT>(sn, co), sl);
+        unpack8<DT>(load8_raw<DT>(sn, co + d / 2), sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            olo[j] = lo[j] * cl[j] + hi[j] * sh[j];
+            ohi[j] = hi[j] * ch[j] - lo[j] * sl[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { olo[j] = lo[j]; ohi[j] = hi[j]; }
+    }
+    const int64_t dst = t * ld + (int64_t)head * d + p * kEPT;
+    store8<DT>(dqkv, dst, olo);
+    store8<DT>(dqkv, dst + d / 2, ohi);
+}
+
+static inline int grid1d(int64_t n) { return (int)((n + kTPB - 1) / kTPB); }
+
+}  // namespace ar
+
+using namespace ar;
+
+#define AR_DT_SWITCH2(dt, CALL)                    \
+    switch (dt) {                                  \
+        case AR_DT_BF16: CALL(AR_DT_BF16); break;  \
+        case AR_DT_F16: CALL(AR_DT_F16); break;    \
+        default: return AR_ERR_UNSUPPORTED;        \
+    }
+
+extern "C" int ar_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd_out, int64_t rows, int hidden, float eps, int dt,
+                              ar_stream_t stream) {
+    if (rows <= 0) return AR_OK;
+    if (hidden <= 0 || hidden % kEPT || hidden > 16 * kWave * kEPT) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)((rows + 3) / 4);
+    const bool small = hidden <= 8 * kWave * kEPT;
+#define AR_CALL(DT)                                                                                                              \
+    if (small) AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_rmsnorm_fwd<DT, 8>), grid, kTPB, 0, st, x, w, y, rstd_out, rows, hidden, eps); \
+    else AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_rmsnorm_fwd<DT, 16>), grid, kTPB, 0, st, x, w, y, rstd_out, rows, hidden, eps)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx,
+                              int64_t rows, int hidden, int dt, ar_stream_t stream) {
+    if (rows <= 0) return AR_OK;
+    if (hidden <= 0 || hidden % kEPT || hidden > 16 * kWave * kEPT || !rstd) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)((rows + 3) / 4);
+    const bool small = hidden <= 8 * kWave * kEPT;
+#define AR_CALL(DT)                                                                                                              \
+    if (small) AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_rmsnorm_bwd<DT, 8>), grid, kTPB, 0, st, dy, x, w, rstd, dres, dx, rows, hidden); \
+    else AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_rmsnorm_bwd<DT, 16>), grid, kTPB, 0, st, dy, x, w, rstd, dres, dx, rows, hidden)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_swiglu_fwd(const void* gu, int64_t ld, void* a, int64_t rows, int64_t F, int dt, ar_stream_t stream) {
+    if (rows <= 0 || F <= 0) return AR_OK;
+    if (F % kEPT || ld % kEPT || ld < 2 * F) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d(rows * (F / kEPT));
+#define AR_CALL(DT) AR_LAUNCH_PROF(AR_PROF_SWIGLU, rows, (k_swiglu_fwd<DT>), grid, kTPB, 0, st, gu, ld, a, rows, F)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_swiglu_bwd(const void* da, void* gu, int64_t ld, int64_t rows, int64_t F, int dt, ar_stream_t stream) {
+    if (rows <= 0 || F <= 0) return AR_OK;
+    if (F % kEPT || ld % kEPT || ld < 2 * F) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d(rows * (F / kEPT));
+#define AR_CALL(DT) AR_LAUNCH_PROF(AR_PROF_SWIGLU, rows, (k_swiglu_bwd<DT>), grid, kTPB, 0, st, da, gu, ld, rows, F)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_rope_fwd(const void* qkv, int64_t ld, const void* cos, const void* sin, int64_t cs_batch_stride, void* q, void* k,
+                           void* v, int64_t tokens, int64_t seq, int hq, int hkv, int d, int dt, ar_stream_t stream) {
+    if (tokens <= 0) return AR_OK;
+    if (d % (2 * kEPT) || hkv <= 0 || hq % hkv || ld % kEPT || seq <= 0 || tokens % seq) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d(tokens * (hq + 2 * hkv) * (d / (2 * kEPT)));
+#define AR_CALL(DT) AR_LAUNCH_PROF(AR_PROF_ROPE, tokens, (k_rope_fwd<DT>), grid, kTPB, 0, st, qkv, ld, cos, sin, cs_batch_stride, q, k, v, tokens, seq, hq, hkv, d)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_rope_bwd(const void* dq, const void* dk, const void* dv, const void* cos, const void* sin, int64_t cs_batch_stride,
+                           void* dqkv, int64_t ld, int64_t tokens, int64_t seq, int hq, int hkv, int d, int dt, ar_stream_t stream) {
+    if (tokens <= 0) return AR_OK;
+    if (d % (2 * kEPT) || hkv <= 0 || hq % hkv || ld % kEPT || seq <= 0 || tokens % seq) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d(tokens * (hq + 2 * hkv) * (d / (2 * kEPT)));
+#define AR_CALL(DT) AR_LAUNCH_PROF(AR_PROF_ROPE, tokens, (k_rope_bwd<DT>), grid, kTPB, 0, st, dq, dk, dv, cos, sin, cs_batch_stride, dqkv, ld, tokens, seq, hq, hkv, d)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}

@@ -1,0 +1,265 @@
+"""Fused tuning-time forward / backward of a Llama-family decoder block (RMSNorm -> q/k/v -> rotary -> SDPA -> o -> residual ->
+RMSNorm -> SwiGLU MLP -> residual) on MI355X.
+
+The reference speeds the same code up with `torch.compile(block_forward)` (auto_round/utils/device.py:112-122,
+compressors/base.py:1177-1179: "about 20 %"); here the block is written once, by hand, for the one thing the tuning loop does with
+it -- forward on a cached minibatch, backward to the fake-quant weights only:
+
+  * the elementwise / normalisation work (20 % of a Llama-3-8B iteration as ~90 eager launches) is six HIP kernels
+    (csrc/ar_block.hip: RMSNorm fwd/bwd, rotary + GQA head repeat fwd/bwd, SwiGLU fwd/bwd), token-major, no transposes;
+  * q/k/v run as ONE GEMM against the arena's contiguous [q;k;v] slice of the fake-quant weights, gate/up likewise; the two
+    residual adds ride in the GEMM epilogue (addmm);
+  * the block input needs no gradient, so nothing upstream of q/k/v is differentiated; weight gradients are written straight
+    into the arena's dWq slices (merged for q/k/v and gate/up) by the hand-written MFMA kernel (csrc/ar_gemm.hip) where its
+    shape constraints hold and it wins, by hipBLASLt otherwise;
+  * attention stays on PyTorch's SDPA (its backward through a local autograd graph).
+
+Same arithmetic per op as the module code, but different bf16 rounding points (fused residual epilogue, fp32 backward of the
+elementwise ops, merged GEMMs): parity with the generic path is trajectory-level, exactly like the reference's compiled path,
+which is why `SignRoundConfig.fused_block` is opt-in.  Blocks this file does not recognise keep the generic path silently.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _is_rmsnorm(m) -> bool:
+    return (type(m).__name__.endswith("RMSNorm") and hasattr(m, "weight") and hasattr(m, "variance_epsilon")
+            and getattr(m, "bias", None) is None)
+
+
+def _is_silu(act) -> bool:
+    return "silu" in type(act).__name__.lower() or act is F.silu
+
+
+class FusedLlamaBlock:
+    """Built per block after `wrapper_block`; `forward(x)` returns the block output connected to autograd through the arena's
+    dummy token, its backward fills the arena's dWq buffer."""
+
+    def __init__(self):
+        self.use_mfma_dw = True
+
+    # -- recognition ----------------------------------------------------------------------------------------------------
+    @classmethod
+    def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True) -> Optional["FusedLlamaBlock"]:
+        from .wrapper import WrapperLinear
+
+        try:
+            n1, n2, attn, mlp = block.input_layernorm, block.post_attention_layernorm, block.self_attn, block.mlp
+            proj = [attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj]
+        except AttributeError:
+            return None
+        if len(arenas) != 1 or not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not _is_silu(getattr(mlp, "act_fn", None)):
+            return None
+        if any(hasattr(attn, a) and not isinstance(getattr(attn, a), torch.nn.Identity) for a in ("q_norm", "k_norm")):
+            return None                                                    # Qwen3-style per-head norms: generic path
+        if getattr(attn, "sliding_window", None) is not None:
+            return None
+        if not all(isinstance(p, WrapperLinear) for p in proj):
+            return None
+        arena = arenas[0]
+        if any(p.arena is not arena or p.enable_act_quant or p.padded or p.is_conv1d for p in proj):
+            return None
+        q, k, v, o, g, u, d = proj
+        if arena.w_dtype not in (torch.bfloat16, torch.float16) or arena.w_dtype != amp_dtype:
+            return None
+        if not (k._off == q._off + q.numel and v._off == k._off + k.numel and u._off == g._off + g.numel):
+            return None
+        if not (q.in_features == k.in_features == v.in_features and g.in_features == u.in_features
+                and g.out_features == u.out_features and k.out_features == v.out_features):
+            return None
+        others = dict(input_others or {})
+        pe = others.get("position_embeddings")
+        if not (isinstance(pe, (tuple, list)) and len(pe) == 2) or others.get("past_key_values") is not None:
+            return None
+        hd = int(getattr(attn, "head_dim", 0))
+        if hd <= 0 or hd % 16 or q.out_features % hd or k.out_features % hd:
+            return None
+        hq, hkv = q.out_features // hd, k.out_features // hd
+        if hq % hkv or o.in_features != hq * hd or (g.out_features % 8) or (q.in_features % 8):
+            return None
+        qkv_bias = [p.orig_layer.bias for p in (q, k, v)]
+        if any(b is not None for b in qkv_bias) and not all(b is not None for b in qkv_bias):
+            return None
+        gu_bias = [p.orig_layer.bias for p in (g, u)]
+        if any(b is not None for b in gu_bias) and not all(b is not None for b in gu_bias):
+            return None
+
+        self = cls()
+        self.block, self.arena, self.attn = block, arena, attn
+        self.layers = dict(q=q, k=k, v=v, o=o, g=g, u=u, d=d)
+        self.w1, self.eps1 = n1.weight, float(n1.variance_epsilon)
+        self.w2, self.eps2 = n2.weight, float(n2.variance_epsilon)
+        self.hq, self.hkv, self.hd = hq, hkv, hd
+        self.H, self.Fdim = q.in_features, g.out_features
+        self.scaling = getattr(attn, "scaling", None)
+        self.dtype = arena.w_dtype
+        self.sdpa_ctx = sdpa_ctx
+        self.use_mfma_dw = bool(use_mfma_dw)
+
+        def view(first, last_numel_sum, rows, cols, buf):
+            return buf[first._off:first._off + last_numel_sum].view(rows, cols)
+
+        nqkv = q.numel + k.numel + v.numel
+        self.Wqkv = view(q, nqkv, (hq + 2 * hkv) * hd, self.H, arena.Wq)
+        self.dWqkv = view(q, nqkv, (hq + 2 * hkv) * hd, self.H, arena.dWq)
+        self.Wo, self.dWo = o.weight_q, o.weight_grad
+        self.Wgu = view(g, g.numel + u.numel, 2 * self.Fdim, self.H, arena.Wq)
+        self.dWgu = view(g, g.numel + u.numel, 2 * self.Fdim, self.H, arena.dWq)
+        self.Wd, self.dWd = d.weight_q, d.weight_grad
+        dt = self.dtype
+        self.b_qkv = torch.cat([b.to(dt) for b in qkv_bias]) if qkv_bias[0] is not None else None
+        self.b_gu = torch.cat([b.to(dt) for b in gu_bias]) if gu_bias[0] is not None else None
+        self.b_o = None if o.orig_layer.bias is None else o.orig_layer.bias.to(dt)
+        self.b_d = None if d.orig_layer.bias is None else d.orig_layer.bias.to(dt)
+        return self
+
+    # -- pieces ---------------------------------------------------------------------------------------------------------
+    def _cos_sin(self, others, B, S):
+        cos, sin = others["position_embeddings"]
+        cos, sin = cos.to(self.dtype), sin.to(self.dtype)
+        if cos.dim() == 2:
+            cos, sin = cos.unsqueeze(0), sin.unsqueeze(0)
+        if cos.shape[0] not in (1, B) or cos.shape[1] != S or cos.shape[2] != self.hd:
+            raise ValueError(f"position_embeddings of shape {tuple(cos.shape)} do not fit a [{B}, {S}] batch with head_dim {self.hd}")
+        return cos.contiguous(), sin.contiguous()
+
+    def _attention(self, q2d, k2d, v2d, mask, B, S, grad: bool):
+        hq, hd = self.hq, self.hd
+
+        def heads(t):
+            return t.view(B, S, hq, hd).transpose(1, 2)
+
+        import contextlib
+
+        ctx = self.sdpa_ctx() if self.sdpa_ctx is not None else contextlib.nullcontext()
+        if mask is not None and mask.dim() == 4:
+            mask = mask[:, :, :, :S]
+        with ctx:
+            if grad:
+                with torch.enable_grad():
+                    ql, kl, vl = (heads(t).detach().requires_grad_(True) for t in (q2d, k2d, v2d))
+                    out = F.scaled_dot_product_attention(ql, kl, vl, attn_mask=mask, dropout_p=0.0, scale=self.scaling,
+                                                         is_causal=mask is None and S > 1)
+                return out, (ql, kl, vl)
+            out = F.scaled_dot_product_attention(heads(q2d), heads(k2d), heads(v2d), attn_mask=mask, dropout_p=0.0,
+                                                 scale=self.scaling, is_causal=mask is None and S > 1)
+            return out, None
+
+    @staticmethod
+    def _linear_residual(res2d, a2d, W, bias):
+        """res + a @ W^T (+ bias): the residual add rides in the GEMM epilogue (one rounding)."""
+        if bias is None:
+            return torch.addmm(res2d, a2d, W.t())
+        return torch.addmm(res2d + bias, a2d, W.t())
+
+    def _dw(self, dY2d, X2d, out2d, layers):
+        """out (+)= dY^T X into the arena; `layers` are the wrapped layers whose slices `out2d` covers."""
+        acc = layers[0]._dw_accum[0]
+        done = False
+        if self.use_mfma_dw and out2d.is_contiguous() and mfma_dw_pays(out2d.shape[0], out2d.shape[1], dY2d.shape[0]):
+            done = ops.gemm_dw(dY2d, X2d, out2d, accumulate=acc)
+        if not done:
+            if acc:
+                out2d.addmm_(dY2d.t(), X2d)
+            else:
+                torch.mm(dY2d.t(), X2d, out=out2d)
+        for lyr in layers:
+            lyr._dw_accum[0] = True
+            post = getattr(lyr, "_post_dw", None)
+            if post is not None:
+                post()
+
+    # -- the two directions -----------------------------------------------------------------------------------------------
+    def forward(self, x, input_others):
+        a = self.arena
+        if not a.wq_fresh:
+            a.qdq_forward()
+        return _FusedBlockFn.apply(x, a.token, self, input_others)
+
+    @torch.no_grad()
+    def forward_nograd(self, x, input_others):
+        return self._forward_impl(x, input_others, None)
+
+    def _forward_impl(self, x, others, ctx):
+        B, S, H = x.shape
+        T = B * S
+        L = self.layers
+        x2d = x.reshape(T, H)
+        if x2d.dtype != self.dtype:
+            x2d = x2d.to(self.dtype)
+        x2d = x2d.contiguous()
+        cos, sin = self._cos_sin(others, B, S)
+        mask = others.get("attention_mask")
+        h1, _ = ops.rmsnorm_fwd(x2d, self.w1, self.eps1, want_rstd=False)
+        qkv = F.linear(h1, self.Wqkv, self.b_qkv)
+        q2d, k2d, v2d = ops.rope_fwd(qkv, cos, sin, B, S, self.hq, self.hkv, self.hd)
+        del qkv
+        attn, leaves = self._attention(q2d, k2d, v2d, mask, B, S, grad=ctx is not None)
+        attn2d = attn.detach().transpose(1, 2).reshape(T, self.hq * self.hd)
+        x2 = self._linear_residual(x2d, attn2d, self.Wo, self.b_o)
+        h2, rstd2 = ops.rmsnorm_fwd(x2, self.w2, self.eps2, want_rstd=ctx is not None)
+        gu = F.linear(h2, self.Wgu, self.b_gu)
+        act = ops.swiglu_fwd(gu, self.Fdim)
+        y = self._linear_residual(x2, act, self.Wd, self.b_d)
+        if ctx is not None:
+            ctx.saved = dict(h1=h1, attn=attn, leaves=leaves, attn2d=attn2d, x2=x2, rstd2=rstd2, h2=h2, gu=gu, act=act, cos=cos, sin=sin,
+                             B=B, S=S)
+        return y.view(B, S, H)
+
+    def _backward_impl(self, ctx, dy):
+        s = ctx.saved
+        ctx.saved = None
+        B, S = s["B"], s["S"]
+        T = B * S
+        L = self.layers
+        dy2d = dy.reshape(T, self.H)
+        if dy2d.dtype != self.dtype:
+            dy2d = dy2d.to(self.dtype)
+        dy2d = dy2d.contiguous()
+        # MLP
+        self._dw(dy2d, s.pop("act"), self.dWd, [L["d"]])
+        da = torch.mm(dy2d, self.Wd)
+        dgu = ops.swiglu_bwd_(da, s.pop("gu"), self.Fdim)
+        del da
+        self._dw(dgu, s.pop("h2"), self.dWgu, [L["g"], L["u"]])
+        dh2 = torch.mm(dgu, self.Wgu)
+        del dgu
+        dx2 = ops.rmsnorm_bwd(dh2, s.pop("x2"), self.w2, s.pop("rstd2"), dres=dy2d, out=dh2)
+        # attention
+        self._dw(dx2, s.pop("attn2d"), self.dWo, [L["o"]])
+        dattn = torch.mm(dx2, self.Wo)
+        del dx2
+        attn, leaves = s.pop("attn"), s.pop("leaves")
+        dq, dk, dv = torch.autograd.grad(attn, leaves, dattn.view(B, S, self.hq, self.hd).transpose(1, 2))
+        del attn, leaves, dattn
+
+        def tok(t):
+            return t.transpose(1, 2).contiguous().view(T, self.hq * self.hd)
+
+        dqkv = ops.rope_bwd(tok(dq), tok(dk), tok(dv), s["cos"], s["sin"], B, S, self.hq, self.hkv, self.hd)
+        del dq, dk, dv
+        self._dw(dqkv, s.pop("h1"), self.dWqkv, [L["q"], L["k"], L["v"]])
+
+
+def mfma_dw_pays(M: int, N: int, K: int) -> bool:
+    """Where the hand-written weight-gradient GEMM beats hipBLASLt on MI355X (tools/gemm_dw_probe.py, profiles/r02_gemm_dw_*):
+    256x256 tiles that fill the 256 CUs at least once, deep K."""
+    return M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and K >= 2048 and (M // 256) * (N // 256) >= 224
+
+
+class _FusedBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, token, fb, others):
+        ctx.fb = fb
+        return fb._forward_impl(x, others, ctx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ctx.fb._backward_impl(ctx, dy)
+        return None, None, None, None

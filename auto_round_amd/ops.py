@@ -343,6 +343,59 @@ def pack_fp4(Wq2d, scale, *, mode, gs, global_scale=None):
     return packed, sb
 
 
+def rmsnorm_fwd(x2d, weight, eps, want_rstd=True):
+    """-> (y [rows, H], rstd [rows] fp32 or None)"""
+    rows, H = x2d.shape
+    y = torch.empty_like(x2d)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device) if want_rstd else None
+    _launch("ar_rmsnorm_fwd", _p(x2d, "x"), _p(weight, "weight"), _p(y), _p(rstd), rows, H, float(eps), dt_code(x2d.dtype))
+    return y, rstd
+
+
+def rmsnorm_bwd(dy2d, x2d, weight, rstd, dres=None, out=None):
+    """dx = d rmsnorm / dx applied to dy (+ dres) -> [rows, H]"""
+    rows, H = x2d.shape
+    dx = out if out is not None else torch.empty_like(x2d)
+    _launch("ar_rmsnorm_bwd", _p(dy2d, "dy"), _p(x2d, "x"), _p(weight, "weight"), _p(rstd, "rstd"), _p(dres), _p(dx), rows, H,
+            dt_code(x2d.dtype))
+    return dx
+
+
+def swiglu_fwd(gu2d, F_):
+    """gu2d [rows, >= 2F] (row stride = its stride(0)) -> a [rows, F] = silu(gu[:, :F]) * gu[:, F:2F]"""
+    rows = gu2d.shape[0]
+    a = torch.empty((rows, F_), dtype=gu2d.dtype, device=gu2d.device)
+    _launch("ar_swiglu_fwd", _p(gu2d, "gu"), gu2d.stride(0), _p(a), rows, F_, dt_code(gu2d.dtype))
+    return a
+
+
+def swiglu_bwd_(da2d, gu2d, F_):
+    """in place: gu2d <- (d gate, d up)"""
+    _launch("ar_swiglu_bwd", _p(da2d, "da"), _p(gu2d, "gu"), gu2d.stride(0), gu2d.shape[0], F_, dt_code(gu2d.dtype))
+    return gu2d
+
+
+def rope_fwd(qkv2d, cos, sin, batch, seq, hq, hkv, d):
+    """qkv2d [tokens, (hq+2hkv)*d] -> q, k, v [tokens, hq*d] (rotary on q/k, kv heads repeated hq/hkv times)"""
+    tokens = qkv2d.shape[0]
+    q = torch.empty((tokens, hq * d), dtype=qkv2d.dtype, device=qkv2d.device)
+    k = torch.empty_like(q)
+    v = torch.empty_like(q)
+    bstride = 0 if cos.shape[0] == 1 else cos.stride(0)
+    _launch("ar_rope_fwd", _p(qkv2d, "qkv"), qkv2d.stride(0), _p(cos, "cos"), _p(sin, "sin"), bstride, _p(q), _p(k), _p(v), tokens, seq,
+            hq, hkv, d, dt_code(qkv2d.dtype))
+    return q, k, v
+
+
+def rope_bwd(dq2d, dk2d, dv2d, cos, sin, batch, seq, hq, hkv, d, out=None):
+    tokens = dq2d.shape[0]
+    dqkv = out if out is not None else torch.empty((tokens, (hq + 2 * hkv) * d), dtype=dq2d.dtype, device=dq2d.device)
+    bstride = 0 if cos.shape[0] == 1 else cos.stride(0)
+    _launch("ar_rope_bwd", _p(dq2d, "dq"), _p(dk2d, "dk"), _p(dv2d, "dv"), _p(cos, "cos"), _p(sin, "sin"), bstride, _p(dqkv), dqkv.stride(0),
+            tokens, seq, hq, hkv, d, dt_code(dq2d.dtype))
+    return dqkv
+
+
 def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> bool:
     """out[M,N] (+)= dY2d[K,M]^T @ X2d[K,N] through the hand-written MFMA kernel (bf16, fp32 accumulate).  Operands may be
     column slices of wider row-major buffers (unit inner stride).  -> False when the shape / alignment is outside what the

@@ -251,6 +251,10 @@ class SignRoundConfig:
     # different bf16 rounding points inside the block (trajectory-level parity, like the reference's compiled path); blocks it
     # does not cover silently keep the generic path.  Off by default for the same reason enable_torch_compile is.
     fused_block: bool = False
+    # Weight-gradient GEMMs (dY^T X, 27 % of a Llama-3-8B iteration through hipBLASLt) on the hand-written MFMA kernel
+    # (csrc/ar_gemm.hip) for the shapes where it wins (fused_block.mfma_dw_pays); another GEMM engine = another fp32 summation
+    # order, so -- like fused_block -- opt-in.  The front door's enable_torch_compile=True switches both on.
+    mfma_dw_gemm: bool = False
 
     def __post_init__(self):
         if self.iters < 0:
@@ -297,6 +301,7 @@ class SignRoundQuantizer:
         if c.momentum not in (0, 0.0, None):
             raise NotImplementedError("momentum != 0 is outside the MI355X hot path")
         self.last_stats: Dict[str, Any] = {}
+        self.last_fused_block = False
 
     # convenience accessors with the reference's attribute names
     @property
@@ -360,6 +365,16 @@ class SignRoundQuantizer:
         if not arenas or cfg.iters <= 0:
             unwrapper_block(block, {})
             return {}
+        for a in arenas:
+            for lyr in a.layers:
+                lyr._mfma_dw = bool(cfg.mfma_dw_gemm)
+        fused = None
+        if cfg.fused_block and cfg.amp:
+            from .fused_block import FusedLlamaBlock
+
+            fused = FusedLlamaBlock.try_build(block, arenas, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx,
+                                              use_mfma_dw=cfg.mfma_dw_gemm)
+        self.last_fused_block = fused is not None
 
         # one (round, minmax) pair of param groups per arena; lr by the arena's bit-width (quantizer.py:374-417)
         groups = []
@@ -457,7 +472,7 @@ class SignRoundQuantizer:
                 others_b = input_others
                 if per_sample_others:       # rows of this minibatch, like the reference's per-batch concatenation
                     others_b = {**input_others, **{k: t.index_select(0, idx) for k, t in per_sample_others.items()}}
-                pred = self.block_forward(block, x, others_b)
+                pred = fused.forward(x, others_b) if fused is not None else self.block_forward(block, x, others_b)
                 pred_c = pred if pred.is_contiguous() else pred.contiguous()
                 if dpred is None or dpred.shape != pred_c.shape or dpred.dtype != pred_c.dtype:
                     dpred = torch.empty_like(pred_c)

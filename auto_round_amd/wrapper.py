@@ -65,8 +65,9 @@ class _QLinearFn(torch.autograd.Function):
     first linear of a block sees the cached calibration activations)."""
 
     @staticmethod
-    def forward(ctx, x, token, wq, bias, dwq_out, accumulate, post_dw=None):
+    def forward(ctx, x, token, wq, bias, dwq_out, accumulate, post_dw=None, mfma_dw=False):
         ctx.post_dw = post_dw
+        ctx.mfma_dw = mfma_dw
         ctx.x_dtype = x.dtype
         xc = x if x.dtype == wq.dtype else x.to(wq.dtype)
         ctx.save_for_backward(xc, wq)
@@ -83,7 +84,16 @@ class _QLinearFn(torch.autograd.Function):
             dy2 = dy2.to(wq.dtype)
         x2 = xc.reshape(-1, xc.shape[-1])
         # dWq[out,in] = dY^T X  -- MFMA GEMM straight into the arena (no autograd accumulation buffers)
-        if ctx.accumulate[0]:
+        done = False
+        if ctx.mfma_dw and ctx.dwq_out.is_contiguous():      # hand-written MFMA kernel where its shape constraints hold and it wins
+            from .fused_block import mfma_dw_pays
+
+            if mfma_dw_pays(ctx.dwq_out.shape[0], ctx.dwq_out.shape[1], x2.shape[0]):
+                done = ops.gemm_dw(dy2 if dy2.is_contiguous() else dy2.contiguous(), x2 if x2.is_contiguous() else x2.contiguous(),
+                                   ctx.dwq_out, accumulate=ctx.accumulate[0])
+        if done:
+            ctx.accumulate[0] = True
+        elif ctx.accumulate[0]:
             ctx.dwq_out.addmm_(dy2.t(), x2)
         else:
             torch.mm(dy2.t(), x2, out=ctx.dwq_out)
@@ -95,7 +105,7 @@ class _QLinearFn(torch.autograd.Function):
             dx = torch.mm(dy2, wq).reshape(xc.shape)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 class _ActQdqFn(torch.autograd.Function):
@@ -515,7 +525,7 @@ class WrapperLinear(torch.nn.Module):
         if self.enable_act_quant:
             x = act_fake_quant(x, self.orig_layer)
         return _QLinearFn.apply(x, a.token, self.weight_q, self.orig_layer.bias, self.weight_grad, self._dw_accum,
-                                getattr(self, "_post_dw", None))
+                                getattr(self, "_post_dw", None), getattr(self, "_mfma_dw", False))
 
     def unwrapper(self, best_params):
         """Bake the best parameters into the layer (reference: wrapper.py:345-468): weight <- qdq weight,

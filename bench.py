@@ -268,6 +268,7 @@ class Bench:
         kw = {}
         if fused_block is not None:
             kw["fused_block"] = fused_block
+            kw["mfma_dw_gemm"] = fused_block
         self.qcfg = SignRoundConfig(iters=args.iters, batch_size=args.batch_size, bits=self.bits,
                                     fuse_next_forward=fuse_next_forward, sdpa_backend=args.sdpa, data_parallel=dp,
                                     enable_quanted_input=quanted_input, **kw)

@@ -229,6 +229,31 @@ int ar_fp4_act_bwd(const void* dXq, const void* X, void* dX, const float* global
 int ar_pack_fp4(const void* Wq, const void* scale, const float* global_scale_dev, int64_t out_f, int64_t in_f, int gs,
                 int mode, int w_dt, uint8_t* packed, uint8_t* scale_bytes, ar_stream_t stream);
 
+/* ---- fused elementwise / normalisation kernels of a Llama-family decoder block (tuning-time block forward/backward) ------
+ * replace, for the duration of the tuning loop, what the reference gets from torch.compile(block_forward)
+ * (auto_round/utils/device.py:112-122, compressors/base.py:1177-1179) on the module code transformers runs eagerly
+ * (transformers/models/llama/modeling_llama.py: LlamaRMSNorm.forward, apply_rotary_pos_emb + repeat_kv, LlamaMLP.forward) and
+ * their autograd backwards.  Token-major tensors [rows, features], dt = AR_DT_BF16 | AR_DT_F16.  Forward kernels round where
+ * the eager modules round; backward kernels evaluate the exact fp32 derivative and round once.
+ *   ar_rmsnorm_fwd   y = w * dt(x * rsqrt(mean(x^2) + eps)); rstd_out [rows] fp32 optional
+ *   ar_rmsnorm_bwd   dx = rstd * (dy*w - xhat * mean(dy*w*xhat)) (+ dres: the residual branch's gradient, fused add)
+ *   ar_swiglu_fwd    a [rows, F] = dt(silu(g)) * u with g = gu[:, :F], u = gu[:, F:2F], gu row stride ld
+ *   ar_swiglu_bwd    in place on gu: (g, u) <- (d g, d u) given da
+ *   ar_rope_fwd      qkv [tokens, (hq + 2 hkv) * d] (ld) -> q, k, v [tokens, hq * d]: rotary embedding on q and k (cos / sin
+ *                    [batch or 1, seq, d], cs_batch_stride elements between batches, 0 to broadcast), every kv head written
+ *                    hq / hkv times (repeat_kv)
+ *   ar_rope_bwd      dq, dk, dv [tokens, hq * d] -> dqkv (ld): sums the repeated heads, applies the transposed rotation */
+int ar_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd_out, int64_t rows, int hidden, float eps, int dt,
+                   ar_stream_t stream);
+int ar_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx, int64_t rows,
+                   int hidden, int dt, ar_stream_t stream);
+int ar_swiglu_fwd(const void* gu, int64_t ld, void* a, int64_t rows, int64_t F, int dt, ar_stream_t stream);
+int ar_swiglu_bwd(const void* da, void* gu, int64_t ld, int64_t rows, int64_t F, int dt, ar_stream_t stream);
+int ar_rope_fwd(const void* qkv, int64_t ld, const void* cos, const void* sin, int64_t cs_batch_stride, void* q, void* k, void* v,
+                int64_t tokens, int64_t seq, int hq, int hkv, int d, int dt, ar_stream_t stream);
+int ar_rope_bwd(const void* dq, const void* dk, const void* dv, const void* cos, const void* sin, int64_t cs_batch_stride,
+                void* dqkv, int64_t ld, int64_t tokens, int64_t seq, int hq, int hkv, int d, int dt, ar_stream_t stream);
+
 /* ---- weight-gradient GEMM (hand-written MFMA, gfx950) -------------------------------------------------------------
  * replaces: the autograd backward of F.linear(x, weight_q) with respect to weight_q inside WrapperLinear.forward
  *           (auto_round/wrapper.py:528-556): dW[M,N] = dY^T X, dY [K,M] and X [K,N] row-major bf16 (leading dimensions in

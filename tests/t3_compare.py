@@ -45,13 +45,41 @@ def _layers(model):
     return L(model)
 
 
+class _HipLossTrace:
+    """Per-iteration loss of the HIP engine: `ops.best_loss_update(total_loss, ...)` sees every iteration's accumulated loss on
+    the device; the probe copies it out (one sync per iteration -- test only)."""
+
+    def __init__(self):
+        self.blocks = []
+
+    def install(self):
+        import auto_round_amd.ops as ops
+        import auto_round_amd.quantizer as product
+
+        self._ops, self._orig = ops, ops.best_loss_update
+        trace = self
+
+        def spy(total_loss, state, istate, it):
+            if it == 0:
+                trace.blocks.append([])
+            trace.blocks[-1].append(float(total_loss.item()))
+            return trace._orig(total_loss, state, istate, it)
+
+        ops.best_loss_update = spy
+        return self
+
+    def remove(self):
+        self._ops.best_loss_update = self._orig
+
+
 class _LossProbe:
     """Records, per quantize_block call of the reference's quantizer classes, the first minibatch loss divided by the
     valid-token count -- the reference's `init_loss` (sign_round/quantizer.py:477-497), which it only logs with 6 decimals."""
 
     def __init__(self):
         self.init_losses, self._armed, self._num = [], False, 1
-        self._undo = []
+        self.traces = []            # per block: every minibatch loss / valid-token count, in order
+        self._undo, self._depth = [], 0
 
     def install(self):
         from auto_round.algorithms.quantization.sign_round.quantizer import SignRoundQuantizer as R
@@ -66,6 +94,7 @@ class _LossProbe:
 
             def quantize_block(self, *a, **k):
                 probe._armed, probe._num = True, 1
+                probe.traces.append([])
                 return orig(self, *a, **k)
 
             cls.quantize_block = quantize_block
@@ -77,10 +106,18 @@ class _LossProbe:
                 return
 
             def _get_loss(self, *a, **k):
-                loss = orig(self, *a, **k)
-                if probe._armed and type(self).__dict__.get("_get_loss") is _get_loss:
-                    probe._armed = False
-                    probe.init_losses.append(float(loss.item()) / max(probe._num, 1))
+                probe._depth += 1                       # the V2 class defers to the base class: record the outermost call only
+                try:
+                    loss = orig(self, *a, **k)
+                finally:
+                    probe._depth -= 1
+                if probe._depth == 0:
+                    val = float(loss.item()) / max(probe._num, 1)
+                    if probe._armed:
+                        probe._armed = False
+                        probe.init_losses.append(val)
+                    if probe.traces:
+                        probe.traces[-1].append(val)
                 return loss
 
             cls._get_loss = _get_loss
@@ -90,8 +127,7 @@ class _LossProbe:
 
         def _get_non_zero_cnt(self, tensor, indices):
             n = orig_cnt(self, tensor, indices)
-            if probe._armed:
-                probe._num = n
+            probe._num = n
             return n
 
         R._get_non_zero_cnt = _get_non_zero_cnt
@@ -150,6 +186,7 @@ def run_case(name, iters=20, nsamples=16, seqlen=32, batch_size=4, seed=42, devi
         finally:
             probe.remove()
         hip_stats = []
+        hip_trace = _HipLossTrace().install()
         orig_qb = product.SignRoundQuantizer.quantize_block
 
         def spy(self, *a, **k):
@@ -162,6 +199,7 @@ def run_case(name, iters=20, nsamples=16, seqlen=32, batch_size=4, seed=42, devi
             q_hip, _ = AutoRound(copy.deepcopy(base), alg_configs=Cfg(iters=iters), **common).quantize()
         finally:
             product.SignRoundQuantizer.quantize_block = orig_qb
+            hip_trace.remove()
     finally:
         os.chdir(cwd)
 
@@ -206,6 +244,15 @@ def run_case(name, iters=20, nsamples=16, seqlen=32, batch_size=4, seed=42, devi
     rec["frac_identical_scale_zp_where_codes_agree"] = (same_sz / n_sz) if n_sz else None
     rel = [abs(a - b) / max(abs(a), 1e-30) for a, b in zip(rec["init_loss_ref"], rec["init_loss_hip"])]
     rec["init_loss_max_rel_diff"] = max(rel) if rel else None
+    # where do the two engines' loss trajectories part?  (iteration of the first relative difference > 1e-4, per block; None =
+    # never within the run).  Immediate = a systematic difference; late = sign-SGD chaos seeded by a near-zero gradient.
+    first = []
+    for tr_ref, tr_hip in zip(probe.traces, hip_trace.blocks):
+        n = min(len(tr_ref), len(tr_hip))
+        f = next((i for i in range(n) if abs(tr_ref[i] - tr_hip[i]) > 1e-4 * max(abs(tr_ref[i]), 1e-30)), None)
+        first.append(f)
+    rec["loss_trajectory_first_divergence_iter"] = first
+    rec["loss_trajectory_len"] = [min(len(a), len(b)) for a, b in zip(probe.traces, hip_trace.blocks)]
     return rec
 
 

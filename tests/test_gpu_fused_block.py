@@ -1,0 +1,236 @@
+"""The fused Llama-family block path (auto_round_amd/fused_block.py, csrc/ar_block.hip, csrc/ar_gemm.hip) on the GPU:
+every kernel against a plain PyTorch fp32 reference of the same op (and bit for bit against transformers' eager module where
+the kernel mirrors its rounding points), the whole block against transformers' LlamaDecoderLayer, and the tuning loop with
+`fused_block=True` against the generic path (trajectory-level parity, like the reference's torch.compile path)."""
+import copy
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda")
+
+
+def _rand(*shape, scale=1.0, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(_dev())
+
+
+@pytest.mark.parametrize("H", [256, 4096, 3072, 8192])
+def test_rmsnorm_fwd_bwd_vs_fp32_torch_and_the_eager_module(H):
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+
+    from auto_round_amd import ops
+
+    T = 64
+    x, w = _rand(T, H, seed=1), (1.0 + 0.1 * _rand(H, seed=2).float()).to(torch.bfloat16)
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-5)
+    xf = x.float()
+    rstd_ref = torch.rsqrt(xf.pow(2).mean(-1) + 1e-5)
+    assert torch.allclose(rstd, rstd_ref, rtol=2e-6, atol=0)
+    mod = LlamaRMSNorm(H, eps=1e-5).to(_dev()).to(torch.bfloat16)
+    mod.weight.data.copy_(w)
+    y_mod = mod(x)
+    # same rounding points as the module: identical up to the (fp32) reduction order of the variance
+    assert (y == y_mod).float().mean().item() > 0.999
+    assert torch.allclose(y.float(), y_mod.float(), rtol=1e-2, atol=1e-3)
+    # backward against autograd of the fp32 formula (+ the fused residual-gradient add)
+    dy, dres = _rand(T, H, seed=3), _rand(T, H, seed=4)
+    xr = xf.clone().requires_grad_(True)
+    yr = w.float() * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5))
+    (gx,) = torch.autograd.grad(yr, xr, dy.float())
+    dx = ops.rmsnorm_bwd(dy, x, w, rstd, dres=dres)
+    ref = gx + dres.float()
+    assert torch.allclose(dx.float(), ref, rtol=2e-2, atol=2e-2)
+    assert (dx.float() - ref).abs().mean().item() < 4e-3 * ref.abs().mean().item() + 1e-6
+    dx2 = ops.rmsnorm_bwd(dy.clone(), x, w, rstd, dres=None)
+    assert torch.allclose(dx2.float(), gx, rtol=2e-2, atol=2e-2)
+
+
+def test_swiglu_fwd_bwd_vs_torch():
+    from auto_round_amd import ops
+
+    T, Fd = 96, 1024
+    gu = _rand(T, 2 * Fd, seed=5, scale=2.0)
+    a = ops.swiglu_fwd(gu, Fd)
+    g, u = gu[:, :Fd], gu[:, Fd:]
+    assert torch.equal(a, torch.nn.functional.silu(g) * u)            # bit for bit what LlamaMLP computes
+    da = _rand(T, Fd, seed=6)
+    gr, ur = g.float().clone().requires_grad_(True), u.float().clone().requires_grad_(True)
+    out = torch.nn.functional.silu(gr) * ur
+    dg_ref, du_ref = torch.autograd.grad(out, (gr, ur), da.float())
+    res = ops.swiglu_bwd_(da, gu.clone(), Fd)
+    assert torch.allclose(res[:, :Fd].float(), dg_ref, rtol=1e-2, atol=1e-2)
+    assert torch.allclose(res[:, Fd:].float(), du_ref, rtol=1e-2, atol=1e-2)
+    # a wider buffer (row stride > 2F)
+    wide = _rand(T, 2 * Fd + 64, seed=7)
+    assert torch.equal(ops.swiglu_fwd(wide, Fd), torch.nn.functional.silu(wide[:, :Fd]) * wide[:, Fd:2 * Fd])
+
+
+@pytest.mark.parametrize("hq,hkv,d,batched_cos", [(8, 2, 64, False), (4, 4, 128, True), (32, 8, 128, False)])
+def test_rope_fwd_bwd_vs_transformers(hq, hkv, d, batched_cos):
+    from transformers.models.llama.modeling_llama import apply_rotary_pos_emb, repeat_kv
+
+    from auto_round_amd import ops
+
+    B, S = 2, 16
+    T = B * S
+    qkv = _rand(T, (hq + 2 * hkv) * d, seed=8)
+    pos = torch.arange(S, device=_dev()).float()
+    inv = 1.0 / (10000 ** (torch.arange(0, d, 2, device=_dev()).float() / d))
+    fr = torch.outer(pos, inv)
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos()[None].to(torch.bfloat16), emb.sin()[None].to(torch.bfloat16)
+    if batched_cos:
+        cos, sin = cos.repeat(B, 1, 1).contiguous(), (sin.repeat(B, 1, 1) * 0.5).to(torch.bfloat16).contiguous()
+    q, k, v = ops.rope_fwd(qkv, cos, sin, B, S, hq, hkv, d)
+    q4 = qkv[:, :hq * d].view(B, S, hq, d).transpose(1, 2)
+    k4 = qkv[:, hq * d:(hq + hkv) * d].view(B, S, hkv, d).transpose(1, 2)
+    v4 = qkv[:, (hq + hkv) * d:].view(B, S, hkv, d).transpose(1, 2)
+    qe, ke = apply_rotary_pos_emb(q4, k4, cos, sin)
+    rep = hq // hkv
+    assert torch.equal(q.view(B, S, hq, d).transpose(1, 2), qe)                        # bit for bit the eager module code
+    assert torch.equal(k.view(B, S, hq, d).transpose(1, 2), repeat_kv(ke, rep))
+    assert torch.equal(v.view(B, S, hq, d).transpose(1, 2), repeat_kv(v4, rep))
+    # backward vs autograd of the fp32 formula through rotary + repeat
+    dq, dk, dv = _rand(T, hq * d, seed=9), _rand(T, hq * d, seed=10), _rand(T, hq * d, seed=11)
+    xr = qkv.float().clone().requires_grad_(True)
+    q4r = xr[:, :hq * d].view(B, S, hq, d).transpose(1, 2)
+    k4r = xr[:, hq * d:(hq + hkv) * d].view(B, S, hkv, d).transpose(1, 2)
+    v4r = xr[:, (hq + hkv) * d:].view(B, S, hkv, d).transpose(1, 2)
+    qer, ker = apply_rotary_pos_emb(q4r, k4r, cos.float(), sin.float())
+    outs = (qer, repeat_kv(ker, rep), repeat_kv(v4r, rep))
+    grads = [t.float().view(B, S, hq, d).transpose(1, 2) for t in (dq, dk, dv)]
+    (gx,) = torch.autograd.grad(outs, xr, grads)
+    dqkv = ops.rope_bwd(dq, dk, dv, cos, sin, B, S, hq, hkv, d)
+    assert torch.allclose(dqkv.float(), gx, rtol=2e-2, atol=3e-2)
+    assert (dqkv.float() - gx).abs().mean().item() < 4e-3 * gx.abs().mean().item()
+
+
+@pytest.mark.parametrize("K,M,N", [(128, 256, 256), (256, 512, 256), (1024, 256, 768)])
+def test_gemm_dw_vs_fp32_reference_including_strides_and_accumulation(K, M, N):
+    from auto_round_amd import ops
+
+    big_y, big_x = _rand(K, M + 256, seed=12), _rand(K, N + 128, seed=13)
+    dY, X = big_y[:, 128:128 + M], big_x[:, 64:64 + N]
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=_dev())
+    assert ops.gemm_dw(dY, X, out)
+    ref = dY.float().t() @ X.float()
+    assert (out == ref.to(torch.bfloat16)).float().mean().item() > 0.995           # fp32 accumulation, one rounding
+    assert torch.allclose(out.float(), ref, rtol=1e-2, atol=1e-2)
+    old = _rand(M, N, seed=14)
+    out2 = old.clone()
+    assert ops.gemm_dw(dY, X, out2, accumulate=True)
+    assert torch.allclose(out2.float(), old.float() + ref, rtol=1e-2, atol=2e-2)
+    # shapes outside the kernel's constraints are refused, not mangled
+    assert ops.gemm_dw(dY[:, :M - 8], X, torch.empty(M - 8, N, dtype=torch.bfloat16, device=_dev())) is False
+
+
+def _llama_layer(hidden=256, ffn=512, heads=4, kv_heads=2, seed=0, bits=4, gs=32):
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaDecoderLayer, LlamaRotaryEmbedding
+
+    torch.manual_seed(seed)
+    cfg = LlamaConfig(hidden_size=hidden, intermediate_size=ffn, num_attention_heads=heads, num_key_value_heads=kv_heads,
+                      num_hidden_layers=1, vocab_size=256, max_position_embeddings=256)
+    cfg._attn_implementation = "sdpa"
+    layer = LlamaDecoderLayer(cfg, 0).to(torch.bfloat16).eval().to(_dev())
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.bits, m.group_size, m.sym, m.data_type, m.scale_dtype, m.act_bits = bits, gs, True, "int", torch.float16, 16
+    rope = LlamaRotaryEmbedding(cfg).to(_dev())
+    return layer, rope, cfg
+
+
+def _data(rope, cfg, N=8, S=32, seed=1):
+    X = _rand(N, S, cfg.hidden_size, seed=seed)
+    pos = torch.arange(S, device=_dev()).unsqueeze(0)
+    cos, sin = rope(X[:1], pos)
+    return X, {"position_embeddings": (cos, sin), "attention_mask": None, "position_ids": pos}
+
+
+def test_fused_block_forward_and_weight_gradients_match_the_module_path():
+    from auto_round_amd.fused_block import FusedLlamaBlock
+    from auto_round_amd.quantizer import block_forward
+    from auto_round_amd.wrapper import unwrapper_block, wrapper_block
+
+    layer, rope, cfg = _llama_layer()
+    X, others = _data(rope, cfg, N=4, S=64)
+    blk = copy.deepcopy(layer)
+    wrapper_block(blk, True, False, device="cuda")
+    arenas = blk._ar_arenas
+    fb = FusedLlamaBlock.try_build(blk, arenas, others, torch.bfloat16)
+    assert fb is not None, "a transformers LlamaDecoderLayer must be recognised"
+    # generic path: module code under autocast
+    pred_m = block_forward(blk, X, others, amp=True, amp_dtype=torch.bfloat16)
+    dpred = _rand(*pred_m.shape, seed=3, scale=0.1)
+    pred_m.backward(dpred)
+    dW_m = arenas[0].dWq.clone()
+    for lyr in arenas[0].layers:
+        lyr._dw_accum[0] = False
+    arenas[0].dWq.zero_()
+    pred_f = fb.forward(X, others)
+    pred_f.backward(dpred)
+    dW_f = arenas[0].dWq.clone()
+    assert all(lyr._dw_accum[0] for lyr in arenas[0].layers)
+    scale = pred_m.float().abs().mean().item()
+    assert (pred_f.float() - pred_m.float()).abs().max().item() < 0.05 * scale + 0.05        # bf16 rounding points only
+    assert (pred_f.float() - pred_m.float()).abs().mean().item() < 5e-3 * scale
+    gs = dW_m.float().abs().mean().item()
+    assert (dW_f.float() - dW_m.float()).abs().mean().item() < 2e-2 * gs
+    cosine = torch.nn.functional.cosine_similarity(dW_f.float(), dW_m.float(), dim=0).item()
+    assert cosine > 0.999, cosine
+    unwrapper_block(blk, {})
+
+
+def test_blocks_the_fused_path_does_not_cover_keep_the_generic_path():
+    from auto_round_amd.fused_block import FusedLlamaBlock
+    from auto_round_amd.wrapper import unwrapper_block, wrapper_block
+
+    layer, rope, cfg = _llama_layer()
+    X, others = _data(rope, cfg)
+    blk = copy.deepcopy(layer)
+    blk.mlp.down_proj.act_bits = 8                       # an activation-quantised layer
+    blk.mlp.down_proj.act_data_type, blk.mlp.down_proj.act_group_size, blk.mlp.down_proj.act_sym, blk.mlp.down_proj.act_dynamic = "int", 32, True, True
+    wrapper_block(blk, True, False, device="cuda")
+    assert FusedLlamaBlock.try_build(blk, blk._ar_arenas, others, torch.bfloat16) is None
+    unwrapper_block(blk, {})
+    blk = copy.deepcopy(layer)
+    wrapper_block(blk, True, False, device="cuda")
+    assert FusedLlamaBlock.try_build(blk, blk._ar_arenas, {"attention_mask": None}, torch.bfloat16) is None      # no rotary inputs
+    assert FusedLlamaBlock.try_build(torch.nn.Sequential(), [], others, torch.bfloat16) is None
+    unwrapper_block(blk, {})
+
+
+@pytest.mark.parametrize("bits,gs", [(4, 32), (2, 32)])
+def test_tuning_with_the_fused_block_tracks_the_generic_path(bits, gs):
+    """Trajectory-level parity (what the reference's compiled block_forward is held to): same iteration-0 loss, the same
+    learning, nearly all tuned weights identical after a short run."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    layer, rope, cfg = _llama_layer(bits=bits, gs=gs)
+    X, others = _data(rope, cfg, N=16, S=32)
+    res = {}
+    for fused in (False, True):
+        blk = copy.deepcopy(layer)
+        random.seed(7)
+        q = SignRoundQuantizer(SignRoundConfig(iters=20, batch_size=4, bits=bits, lr=5e-3, minmax_lr=5e-3, fused_block=fused,
+                                               mfma_dw_gemm=fused), device="cuda")
+        fp_out, q_out, best = q.compress_block(blk, X, others)
+        assert q.last_fused_block is fused
+        res[fused] = (q.last_stats, {n: m.weight.detach().clone() for n, m in blk.named_modules() if isinstance(m, torch.nn.Linear)}, q_out)
+    sg, sf = res[False][0], res[True][0]
+    assert abs(sg["init_loss"] - sf["init_loss"]) <= 2e-2 * sg["init_loss"], (sg, sf)
+    assert sf["best_loss"] < 0.9 * sf["init_loss"] and abs(sg["best_loss"] - sf["best_loss"]) <= 0.15 * sg["best_loss"], (sg, sf)
+    tot = same = 0
+    for n, w in res[False][1].items():
+        tot += w.numel()
+        same += int((w == res[True][1][n]).sum())
+    assert same / tot > 0.90, same / tot
+    assert (res[False][2].float() - res[True][2].float()).abs().mean().item() < 2e-2 * res[False][2].float().abs().mean().item()

@@ -30,7 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="q_o,gate_up,down,qkv_merged,kv")
     ap.add_argument("--K", type=int, default=16384)
-    ap.add_argument("--variants", default="2:2,2:1,2:0,1:2")       # sem:order
+    ap.add_argument("--variants", default="v0:2,v1_staggered:2,v1_lockstep:2,v1_staggered:1,v1_staggered:0")       # kernel:order
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
@@ -49,31 +49,25 @@ def main():
         err = (out.float() - ref).abs().max().item()
         exact = (out == ref.to(torch.bfloat16)).float().mean().item()
         print(json.dumps({"check": "small", "sem": sem, "took_kernel": ok, "max_abs_err": err, "frac_equal_to_rounded_fp32": exact}), flush=True)
-    best_sem = None
-    for sem in (1, 2):
-        lib.ar_gemm_dw_config(sem, 2)
-        out = torch.empty(512, 256, dtype=torch.bfloat16, device=dev)
-        dY = torch.randn(256, 512, device=dev).to(torch.bfloat16)
-        X = torch.randn(256, 256, device=dev).to(torch.bfloat16)
-        ops.gemm_dw(dY, X, out)
-        if (out.float() - dY.float().t() @ X.float()).abs().max().item() < 0.5:
-            best_sem = sem
-    print(json.dumps({"correct_sem": best_sem}), flush=True)
-    if best_sem is None:
-        return
-    # accumulate + strided operands (column slices of wider buffers), multi-tile, all three tile orders
-    for order in (0, 1, 2):
-        lib.ar_gemm_dw_config(best_sem, order)
-        K, M, N = 512, 1024, 2048
-        big_y = torch.randn(K, M + 512, device=dev).to(torch.bfloat16)
-        big_x = torch.randn(K, N + 256, device=dev).to(torch.bfloat16)
-        dY, X = big_y[:, 256:256 + M], big_x[:, 256:256 + N]
-        out = torch.randn(M, N, device=dev).to(torch.bfloat16)
-        old = out.clone()
-        assert ops.gemm_dw(dY, X, out, accumulate=True)
-        ref = (old.float() + dY.float().t() @ X.float())
-        err = ((out.float() - ref).abs() / (ref.abs() + 1.0)).max().item()
-        print(json.dumps({"check": "strided+accumulate", "order": order, "max_rel_err": err}), flush=True)
+    lib.ar_gemm_dw_config(1, 2)
+    KERNELS = {"v0": 10, "v1_staggered": 11, "v1_lockstep": 12}
+    # accumulate + strided operands (column slices of wider buffers), multi-tile, all tile orders, every kernel
+    for kname, code in KERNELS.items():
+        for order in (0, 1, 2):
+            lib.ar_gemm_dw_config(code, order)
+            K, M, N = 512, 1024, 2048
+            big_y = torch.randn(K, M + 512, device=dev).to(torch.bfloat16)
+            big_x = torch.randn(K, N + 256, device=dev).to(torch.bfloat16)
+            dY, X = big_y[:, 256:256 + M], big_x[:, 256:256 + N]
+            out = torch.randn(M, N, device=dev).to(torch.bfloat16)
+            old = out.clone()
+            assert ops.gemm_dw(dY, X, out, accumulate=True)
+            ref = (old.float() + dY.float().t() @ X.float())
+            exact = (out == ref.to(torch.bfloat16)).float().mean().item()
+            err = ((out.float() - ref).abs() / (ref.abs() + 1.0)).max().item()
+            print(json.dumps({"check": "strided+accumulate", "kernel": kname, "order": order, "max_rel_err": err,
+                              "frac_equal_to_rounded_fp32": exact}), flush=True)
+    wanted = [v for v in args.variants.split(",")]
     for name in args.shapes.split(","):
         M, N = SHAPES[name]
         K = args.K
@@ -82,35 +76,33 @@ def main():
         out_t = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         out_k = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         flops = 2.0 * M * N * K
-        variants = [tuple(int(x) for x in v.split(":")) for v in args.variants.split(",") if int(v.split(":")[0]) == best_sem or v.startswith(str(best_sem))]
-        variants = [(best_sem, o) for o in sorted({v[1] for v in variants})]
 
         def lib_mm():
             torch.mm(dY.t(), X, out=out_t)
 
         fns = {"hipblaslt": lib_mm}
-        for sem, order in variants:
-            def f(sem=sem, order=order):
-                lib.ar_gemm_dw_config(sem, order)
+        for v in wanted:
+            kname, order = v.split(":")
+            def f(code=KERNELS[kname], order=int(order)):
+                lib.ar_gemm_dw_config(code, order)
                 ops.gemm_dw(dY, X, out_k)
-            fns[f"mfma_sem{sem}_order{order}"] = f
-        for f in fns.values():       # warm-up
+            fns[f"mfma_{kname}_order{order}"] = f
+        diffs = {}
+        for k, f in fns.items():       # warm-up + agreement with the library product
             f()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            if k != "hipblaslt":
+                diffs[k] = ((out_k.float() - out_t.float()).abs().max().item(), (out_k == out_t).float().mean().item())
         times = {k: [] for k in fns}
         for _ in range(args.rounds):  # interleaved rounds
             for k, f in fns.items():
                 times[k].append(timed(f, args.reps))
-        lib_mm()
-        fns[f"mfma_sem{best_sem}_order2"]() if f"mfma_sem{best_sem}_order2" in fns else None
-        torch.cuda.synchronize()
-        diff = (out_k.float() - out_t.float()).abs().max().item()
         scale = out_t.float().abs().mean().item()
         for k, ts in times.items():
             ms = sorted(ts)[len(ts) // 2]
             print(json.dumps({"shape": name, "M": M, "N": N, "K": K, "impl": k, "ms_median": ms, "ms_min": min(ts),
-                              "pflops": flops / ms / 1e12, "max_abs_diff_vs_hipblaslt": diff if k != "hipblaslt" else 0.0,
-                              "mean_abs_out": scale}), flush=True)
+                              "pflops": flops / ms / 1e12, "max_abs_diff_vs_hipblaslt": diffs.get(k, (0.0, 1.0))[0],
+                              "frac_bit_equal_to_hipblaslt": diffs.get(k, (0.0, 1.0))[1], "mean_abs_out": scale}), flush=True)
 
 
 if __name__ == "__main__":
