@@ -372,7 +372,310 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw2(GemmArgs a) {
     }
 }
 
-static int g_gemm_kernel = 1;     // 0: v0 (k_gemm_dw)  1: v1 staggered  2: v1 lockstep
+
+template <int ABL>
+__global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw2_abl(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wm = wave & 3, wn = wave >> 2;
+    int tm, tn;
+    tile_of_block(a, blockIdx.x, tm, tn);
+    const int64_t m0 = (int64_t)tm * GB, n0 = (int64_t)tn * GB;
+    const int U = a.K / GU;                        // k16 units; K % 128 == 0 (checked by the host)
+
+    const int drow = 2 * wave + (lane >> 5);
+    const int lchunk = (lane & 31) ^ ((drow & 3) << 2);
+    const uint16_t* srcP = a.X + (int64_t)drow * a.ldx + n0 + lchunk * 8;
+    const uint16_t* srcQ = a.Y + (int64_t)drow * a.ldy + m0 + lchunk * 8;
+    const int64_t stepP = (int64_t)GU * a.ldx, stepQ = (int64_t)GU * a.ldy;     // elements per unit
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    const uint32_t dmabase = lds0 + 2 * wave * ROWB;                            // wave-uniform
+
+    const int q = lane >> 4, i = lane & 15, g = q >> 1;
+    const int rowsel = i >> 2, piece = i & 3;                                     // hardware rule of ds_read_b64_tr_b16
+    const int rowoff = (8 * g + rowsel) * ROWB + (piece & 1) * 8;
+    uint32_t aP[2][4], aQ[2][2];                                                  // [64 KB half][tile]
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int chunk = wn * 16 + ni * 4 + (q & 1) * 2 + (piece >> 1);
+        aP[0][ni] = lds0 + rowoff + ((chunk ^ (rowsel << 2)) << 4);
+        aP[1][ni] = aP[0][ni] + 65536;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int chunk = wm * 8 + mi * 4 + (q & 1) * 2 + (piece >> 1);
+        aQ[0][mi] = lds0 + PIECE + rowoff + ((chunk ^ (rowsel << 2)) << 4);
+        aQ[1][mi] = aQ[0][mi] + 65536;
+    }
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    int vnext = 0;                                 // next unit to stage
+    auto issue_unit = [&](int slot_unit) {         // slot_unit: 0..7 compile-time after unrolling
+        __builtin_amdgcn_global_load_lds((const void*)srcP, (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)srcQ, (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
+        ++vnext;
+        const bool more = vnext < U;               // past the end the pointers stay on the last unit (staged again, never read)
+        srcP += more ? stepP : 0;
+        srcQ += more ? stepQ : 0;
+    };
+    struct Pair { s16x4_t plo[2][4], phi[2][4], qlo[2][2], qhi[2][2]; };
+#define AR_RD(LO, HI, ADDR, OFF)                                                                                        \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                           \
+                 : "=&v"(LO), "=&v"(HI)                                                                                 \
+                 : "v"(ADDR), "n"(OFF), "n"((OFF) + 4 * ROWB)                                                            \
+                 : "memory")
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    auto cat = [](const s16x4_t& lo, const s16x4_t& hi) -> bf16x8_t {
+        return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Pair f;
+    // one phase on pair slot S (0..3): L part then M part
+#define AR_PHASE(S)                                                                                                     \
+    do {                                                                                                                \
+        constexpr int H = (S) >> 1;                      /* which 64 KB half */                                          \
+        constexpr int O = ((S) & 1) * 2 * UNIT;          /* offset inside the half */                                    \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                                 \
+            if (ABL >= 2) { if (u == 0 && (S) == 0) { AR_RD(f.qlo[k][0], f.qhi[k][0], aQ[0][0], 0); AR_RD(f.qlo[k][1], f.qhi[k][1], aQ[0][1], 0); \
+                AR_RD(f.plo[k][0], f.phi[k][0], aP[0][0], 0); AR_RD(f.plo[k][1], f.phi[k][1], aP[0][1], 0);              \
+                AR_RD(f.plo[k][2], f.phi[k][2], aP[0][2], 0); AR_RD(f.plo[k][3], f.phi[k][3], aP[0][3], 0); } }          \
+            else if (k == 0) {                                                                                               \
+                AR_RD(f.qlo[0][0], f.qhi[0][0], aQ[H][0], O); AR_RD(f.qlo[0][1], f.qhi[0][1], aQ[H][1], O);             \
+                AR_RD(f.plo[0][0], f.phi[0][0], aP[H][0], O); AR_RD(f.plo[0][1], f.phi[0][1], aP[H][1], O);             \
+                AR_RD(f.plo[0][2], f.phi[0][2], aP[H][2], O); AR_RD(f.plo[0][3], f.phi[0][3], aP[H][3], O);             \
+            } else {                                                                                                    \
+                AR_RD(f.qlo[1][0], f.qhi[1][0], aQ[H][0], O + UNIT); AR_RD(f.qlo[1][1], f.qhi[1][1], aQ[H][1], O + UNIT); \
+                AR_RD(f.plo[1][0], f.phi[1][0], aP[H][0], O + UNIT); AR_RD(f.plo[1][1], f.phi[1][1], aP[H][1], O + UNIT); \
+                AR_RD(f.plo[1][2], f.phi[1][2], aP[H][2], O + UNIT); AR_RD(f.plo[1][3], f.phi[1][3], aP[H][3], O + UNIT); \
+            }                                                                                                           \
+        }                                                                                                               \
+        if (ABL == 0) { issue_unit((((S) + 3) & 3) * 2); issue_unit((((S) + 3) & 3) * 2 + 1);                           \
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+        if (ABL < 3) bar();                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                                   \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                            \
+                _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                        \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat(f.plo[k][ni], f.phi[k][ni]),              \
+                                                                          cat(f.qlo[k][mi], f.qhi[k][mi]), acc[mi][ni], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        if (ABL < 3) bar();                                                                                             \
+    } while (0)
+
+    // ---- prologue: pairs 0, 1, 2 in flight; pair 0 landed for everybody
+#pragma unroll
+    for (int v = 0; v < 6; ++v) issue_unit(v);
+    wait_vm<8>();
+    bar();
+    if ((ABL < 3) && grp == 1) bar();
+    for (int u = 0; u < U; u += 8) {
+        AR_PHASE(0);
+        AR_PHASE(1);
+        AR_PHASE(2);
+        AR_PHASE(3);
+    }
+    if ((ABL < 3) && grp == 0) bar();
+    wait_vm<0>();
+#undef AR_PHASE
+#undef AR_RD
+
+    const int h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 32 + (lane & 31);
+        uint16_t* rowp = a.W + m * a.ldw + n0 + wn * 128 + 4 * h;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint16_t* p = rowp + ni * 32 + 8 * t;
+                float v0 = acc[mi][ni][4 * t + 0], v1 = acc[mi][ni][4 * t + 1], v2 = acc[mi][ni][4 * t + 2], v3 = acc[mi][ni][4 * t + 3];
+                if (a.accumulate) {
+                    const uint2 old = *reinterpret_cast<const uint2*>(p);
+                    v0 += bf16_lo(old.x); v1 += bf16_hi(old.x); v2 += bf16_lo(old.y); v3 += bf16_hi(old.y);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(p) = o;
+            }
+        }
+    }
+}
+
+
+// (v2 -- v1 with half of the fragment reads moved into the MFMA cluster so that both waves of a SIMD feed the LDS pipe all the
+//  time -- measured equal to v1 within noise on every shape, profiles/r02_gemm_dw_v2_split_reads_no_gain.jsonl, and was removed.)
+
+// ---- v3: v1 with the DMA pieces issued from inside the MFMA cluster (copy of the v1 setup) --------------------------------
+template <bool STAGGER>
+__global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wm = wave & 3, wn = wave >> 2;
+    int tm, tn;
+    tile_of_block(a, blockIdx.x, tm, tn);
+    const int64_t m0 = (int64_t)tm * GB, n0 = (int64_t)tn * GB;
+    const int U = a.K / GU;                        // k16 units; K % 128 == 0 (checked by the host)
+
+    const int drow = 2 * wave + (lane >> 5);
+    const int lchunk = (lane & 31) ^ ((drow & 3) << 2);
+    const uint16_t* srcP = a.X + (int64_t)drow * a.ldx + n0 + lchunk * 8;
+    const uint16_t* srcQ = a.Y + (int64_t)drow * a.ldy + m0 + lchunk * 8;
+    const int64_t stepP = (int64_t)GU * a.ldx, stepQ = (int64_t)GU * a.ldy;     // elements per unit
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    const uint32_t dmabase = lds0 + 2 * wave * ROWB;                            // wave-uniform
+
+    const int q = lane >> 4, i = lane & 15, g = q >> 1;
+    const int rowsel = i >> 2, piece = i & 3;                                     // hardware rule of ds_read_b64_tr_b16
+    const int rowoff = (8 * g + rowsel) * ROWB + (piece & 1) * 8;
+    uint32_t aP[2][4], aQ[2][2];                                                  // [64 KB half][tile]
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int chunk = wn * 16 + ni * 4 + (q & 1) * 2 + (piece >> 1);
+        aP[0][ni] = lds0 + rowoff + ((chunk ^ (rowsel << 2)) << 4);
+        aP[1][ni] = aP[0][ni] + 65536;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int chunk = wm * 8 + mi * 4 + (q & 1) * 2 + (piece >> 1);
+        aQ[0][mi] = lds0 + PIECE + rowoff + ((chunk ^ (rowsel << 2)) << 4);
+        aQ[1][mi] = aQ[0][mi] + 65536;
+    }
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    int vnext = 0;                                 // next unit to stage
+    auto issue_unit = [&](int slot_unit) {         // slot_unit: 0..7 compile-time after unrolling
+        __builtin_amdgcn_global_load_lds((const void*)srcP, (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)srcQ, (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
+        ++vnext;
+        const bool more = vnext < U;               // past the end the pointers stay on the last unit (staged again, never read)
+        srcP += more ? stepP : 0;
+        srcQ += more ? stepQ : 0;
+    };
+    struct Pair { s16x4_t plo[2][4], phi[2][4], qlo[2][2], qhi[2][2]; };
+#define AR_RD(LO, HI, ADDR, OFF)                                                                                        \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                           \
+                 : "=&v"(LO), "=&v"(HI)                                                                                 \
+                 : "v"(ADDR), "n"(OFF), "n"((OFF) + 4 * ROWB)                                                            \
+                 : "memory")
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    auto cat = [](const s16x4_t& lo, const s16x4_t& hi) -> bf16x8_t {
+        return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Pair f;
+    // one phase on pair slot S (0..3): L part then M part
+    auto issue_p = [&](int slot_unit) {
+        __builtin_amdgcn_global_load_lds((const void*)srcP, (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
+    };
+    auto issue_q = [&](int slot_unit) {
+        __builtin_amdgcn_global_load_lds((const void*)srcQ, (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
+        ++vnext;
+        const bool more = vnext < U;
+        srcP += more ? stepP : 0;
+        srcQ += more ? stepQ : 0;
+    };
+#define AR_MMA(K, MI, NI) acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat(f.plo[K][NI], f.phi[K][NI]), cat(f.qlo[K][MI], f.qhi[K][MI]), acc[MI][NI], 0, 0, 0)
+#define AR_PIN() __builtin_amdgcn_sched_barrier(0)
+    // L part: the 24 fragment reads of this pair, then wait for them and for the wave's own DMA of the NEXT pair; M part: 16 MFMAs
+    // with the 4 DMA pieces of pair S+3 issued in between (an LDS-DMA piece costs ~60 issue cycles among bare MFMAs but
+    // 100-185 inside a phase that also carries the fragment reads -- in v1 the four of them made the L part longer than the
+    // partner's MFMA cluster: the no-DMA ablation of v1 ran 18-23 % faster, profiles/r02_gemm_dw_ablation.jsonl)
+#define AR_PHASE(S)                                                                                                     \
+    do {                                                                                                                \
+        constexpr int H = (S) >> 1;                                                                                     \
+        constexpr int O = ((S) & 1) * 2 * UNIT;                                                                         \
+        constexpr int DU = (((S) + 3) & 3) * 2;                                                                         \
+        AR_RD(f.qlo[0][0], f.qhi[0][0], aQ[H][0], O); AR_RD(f.qlo[0][1], f.qhi[0][1], aQ[H][1], O);                     \
+        AR_RD(f.plo[0][0], f.phi[0][0], aP[H][0], O); AR_RD(f.plo[0][1], f.phi[0][1], aP[H][1], O);                     \
+        AR_RD(f.plo[0][2], f.phi[0][2], aP[H][2], O); AR_RD(f.plo[0][3], f.phi[0][3], aP[H][3], O);                     \
+        AR_RD(f.qlo[1][0], f.qhi[1][0], aQ[H][0], O + UNIT); AR_RD(f.qlo[1][1], f.qhi[1][1], aQ[H][1], O + UNIT);       \
+        AR_RD(f.plo[1][0], f.phi[1][0], aP[H][0], O + UNIT); AR_RD(f.plo[1][1], f.phi[1][1], aP[H][1], O + UNIT);       \
+        AR_RD(f.plo[1][2], f.phi[1][2], aP[H][2], O + UNIT); AR_RD(f.plo[1][3], f.phi[1][3], aP[H][3], O + UNIT);       \
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        bar();                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        AR_MMA(0, 0, 0); AR_MMA(0, 0, 1); AR_PIN(); issue_p(DU); AR_PIN();                                              \
+        AR_MMA(0, 0, 2); AR_MMA(0, 0, 3); AR_MMA(0, 1, 0); AR_MMA(0, 1, 1); AR_PIN(); issue_q(DU); AR_PIN();            \
+        AR_MMA(0, 1, 2); AR_MMA(0, 1, 3); AR_MMA(1, 0, 0); AR_MMA(1, 0, 1); AR_PIN(); issue_p(DU + 1); AR_PIN();        \
+        AR_MMA(1, 0, 2); AR_MMA(1, 0, 3); AR_MMA(1, 1, 0); AR_MMA(1, 1, 1); AR_PIN(); issue_q(DU + 1); AR_PIN();        \
+        AR_MMA(1, 1, 2); AR_MMA(1, 1, 3);                                                                               \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        bar();                                                                                                          \
+    } while (0)
+
+    // ---- prologue: pairs 0, 1, 2 in flight; pair 0 landed for everybody
+#pragma unroll
+    for (int v = 0; v < 6; ++v) issue_unit(v);
+    wait_vm<8>();
+    bar();
+    if (STAGGER && grp == 1) bar();
+    for (int u = 0; u < U; u += 8) {
+        AR_PHASE(0);
+        AR_PHASE(1);
+        AR_PHASE(2);
+        AR_PHASE(3);
+    }
+    if (STAGGER && grp == 0) bar();
+    wait_vm<0>();
+#undef AR_PHASE
+#undef AR_RD
+#undef AR_MMA
+#undef AR_PIN
+
+    const int h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 32 + (lane & 31);
+        uint16_t* rowp = a.W + m * a.ldw + n0 + wn * 128 + 4 * h;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint16_t* p = rowp + ni * 32 + 8 * t;
+                float v0 = acc[mi][ni][4 * t + 0], v1 = acc[mi][ni][4 * t + 1], v2 = acc[mi][ni][4 * t + 2], v3 = acc[mi][ni][4 * t + 3];
+                if (a.accumulate) {
+                    const uint2 old = *reinterpret_cast<const uint2*>(p);
+                    v0 += bf16_lo(old.x); v1 += bf16_hi(old.x); v2 += bf16_lo(old.y); v3 += bf16_hi(old.y);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(p) = o;
+            }
+        }
+    }
+}
+
+
+
+static int g_gemm_kernel = 7;     // 0: v0  1: v1 staggered  2: v1 lockstep  3: v2 (split reads)  4-6: timing ablations  7: v3 (DMA in the MFMA cluster)
 static int g_gemm_sem = 1, g_gemm_order = 2;    // rule 1 is what the hardware does (profiles/r02_mfma_probe.json)
 
 }  // namespace ar
@@ -381,7 +684,7 @@ using namespace ar;
 
 extern "C" int ar_gemm_dw_config(int sem, int order) {      // experiment knobs (tools/gemm_dw_probe.py); -1 keeps a value
     if (sem == 1 || sem == 2) g_gemm_sem = sem;                 // v0 only: lane->piece rule (2 = negative control)
-    if (sem >= 10 && sem <= 12) g_gemm_kernel = sem - 10;       // 10: v0, 11: v1 staggered, 12: v1 lockstep
+    if (sem >= 10 && sem <= 17) g_gemm_kernel = sem - 10;       // 10: v0, 11: v1 staggered, 12: v1 lockstep, 13: v2 staggered
     if (order >= 0 && order <= 2) g_gemm_order = order;
     return g_gemm_kernel * 100 + g_gemm_sem * 10 + g_gemm_order;
 }
@@ -407,6 +710,21 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
         attr_done = true;
     }
     if (g_gemm_kernel >= 1 && K % 128 == 0 && K >= 256) {
+        if (g_gemm_kernel == 7) {
+            static bool a4 = false;
+            if (!a4) { (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS); a4 = true; }
+            AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true>), grid, GTHREADS, GEMM_LDS, st, a);
+            return launch_status();
+        }
+        if (g_gemm_kernel >= 4) {      // timing ablations (tools/gemm_dw_probe.py --ablate); outputs are not a product
+            (void)hipFuncSetAttribute((const void*)k_gemm_dw2_abl<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+            (void)hipFuncSetAttribute((const void*)k_gemm_dw2_abl<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+            (void)hipFuncSetAttribute((const void*)k_gemm_dw2_abl<3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+            if (g_gemm_kernel == 4) hipLaunchKernelGGL((k_gemm_dw2_abl<1>), grid, GTHREADS, GEMM_LDS, st, a);
+            else if (g_gemm_kernel == 5) hipLaunchKernelGGL((k_gemm_dw2_abl<2>), grid, GTHREADS, GEMM_LDS, st, a);
+            else hipLaunchKernelGGL((k_gemm_dw2_abl<3>), grid, GTHREADS, GEMM_LDS, st, a);
+            return launch_status();
+        }
         if (g_gemm_kernel == 1) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw2<true>), grid, GTHREADS, GEMM_LDS, st, a);
         else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw2<false>), grid, GTHREADS, GEMM_LDS, st, a);
         return launch_status();

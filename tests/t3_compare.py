@@ -256,6 +256,103 @@ def run_case(name, iters=20, nsamples=16, seqlen=32, batch_size=4, seed=42, devi
     return rec
 
 
+def _sharded_worker(rank, world, port, out_path, iters, nsamples, seqlen, batch_size):
+    """One of `world` ranks sharing cuda:0 over gloo: run the REFERENCE front door (fp-chain mode) to get its tuned weights and
+    the exact block-0 inputs it hands to quantize_block, then tune the same blocks with `sharding.tune_sharded` (HIP engine,
+    broadcast + pipelined relay + per-block schedule replay) and compare on rank 0."""
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    joined = False
+    try:
+        import_reference()
+        from auto_round import AutoRound
+        from auto_round.algorithms.quantization.sign_round.quantizer import SignRoundQuantizer as R
+        from test_pipeline_vs_reference import _Loader, _StubTokenizer
+
+        from auto_round_amd import sharding as sh
+        from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer, normalize_input_others, stack_samples
+        from auto_round_amd.schemes import apply_scheme, resolve_scheme
+
+        base = _model("llama")
+        tokens = torch.randint(0, 64, (nsamples, seqlen), generator=torch.Generator().manual_seed(1))
+        captured = {}
+        orig = R.quantize_block
+
+        def spy(self, block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=None, **kw):
+            if "x0" not in captured:
+                captured.update(x0=[t.detach().clone() for t in fp_inputs], others=input_others, ids=input_ids)
+            return orig(self, block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=input_ids, **kw)
+
+        import tempfile
+
+        cwd = os.getcwd()
+        os.chdir(tempfile.mkdtemp(prefix=f"t3s{rank}_"))
+        R.quantize_block = spy
+        try:
+            q_ref, _ = AutoRound(copy.deepcopy(base), iters=iters, tokenizer=_StubTokenizer(), nsamples=nsamples, seqlen=seqlen,
+                                 dataset=_Loader(tokens), device_map=0, batch_size=batch_size, enable_torch_compile=False, seed=42,
+                                 scheme="W4A16", group_size=32, enable_quanted_input=False).quantize()
+        finally:
+            R.quantize_block = orig
+            os.chdir(cwd)
+        # the reference switches to its experimental DDP mode as soon as torch.distributed is initialised
+        # (utils/distributed.py): it must run BEFORE this process joins the group
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        joined = True
+        m = copy.deepcopy(base).to("cuda")
+        for p in m.parameters():
+            p.requires_grad_(False)
+        blocks = list(m.model.layers)
+        sch = resolve_scheme(scheme="W4A16", group_size=32)
+        for b in blocks:
+            apply_scheme(b, sch)
+        X = stack_samples(captured["x0"], "cuda")
+        if rank != 0:
+            X = torch.zeros_like(X)                       # only rank 0 holds the calibration activations; the broadcast delivers them
+        shared, per_sample = normalize_input_others(captured["others"], nsamples, "cuda")
+        assert not per_sample
+        q = SignRoundQuantizer(SignRoundConfig(iters=iters, batch_size=batch_size, bits=4, enable_quanted_input=False), device="cuda")
+        mine = [b if sh.owner_of(k, len(blocks), world) == rank else None for k, b in enumerate(blocks)]
+        local = sh.tune_sharded(mine, X, shared, q, seed=42, input_ids=captured["ids"])
+        payload = {k: {"stats": v["stats"], "weights": {n: mod.weight.detach().cpu() for n, mod in blocks[k].named_modules()
+                                                         if isinstance(mod, torch.nn.Linear)}} for k, v in local.items()}
+        merged = sh.gather_results(payload)
+        if rank == 0:
+            tot = same = 0
+            for k, rec in merged.items():
+                ref_lin = {n: mod for n, mod in q_ref.model.layers[k].named_modules() if isinstance(mod, torch.nn.Linear)}
+                for n, w in rec["weights"].items():
+                    a, b = ref_lin[n].weight.detach().cpu().view(torch.int16), w.view(torch.int16)
+                    tot += a.numel()
+                    same += int((a == b).sum())
+            out = {"case": "llama_w4g32_fp_chain_sharded_2_ranks", "ranks": world, "blocks": sorted(merged), "weights": tot,
+                   "frac_identical_weights": same / tot, "init_loss_hip": [merged[k]["stats"]["init_loss"] for k in sorted(merged)],
+                   "owners": {k: sh.owner_of(k, len(blocks), world) for k in sorted(merged)}}
+            with open(out_path, "w") as f:
+                json.dump(out, f)
+        dist.barrier()
+    finally:
+        if joined:
+            dist.destroy_process_group()
+
+
+def run_sharded_case(iters=20, nsamples=16, seqlen=32, batch_size=4, world=2):
+    import socket
+    import tempfile
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = os.path.join(tempfile.mkdtemp(prefix="t3s_"), "sharded.json")
+    mp.spawn(_sharded_worker, args=(world, port, out, iters, nsamples, seqlen, batch_size), nprocs=world, join=True)
+    with open(out) as f:
+        return json.load(f)
+
+
 def main():
     import argparse
 
@@ -276,6 +373,14 @@ def main():
             r = {"case": c, "error": repr(e), "trace": traceback.format_exc()[-1500:]}
         recs.append(r)
         print(json.dumps(r), flush=True)
+    try:
+        r = run_sharded_case(iters=args.iters)
+    except Exception as e:
+        import traceback
+
+        r = {"case": "llama_w4g32_fp_chain_sharded_2_ranks", "error": repr(e), "trace": traceback.format_exc()[-1500:]}
+    recs.append(r)
+    print(json.dumps(r), flush=True)
     if args.out:
         with open(args.out, "w") as f:
             json.dump({"what": "reference AutoRound(...).quantize() on cuda:0 vs the same front door with the auto_round_amd plugin "

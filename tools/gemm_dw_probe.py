@@ -30,7 +30,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="q_o,gate_up,down,qkv_merged,kv")
     ap.add_argument("--K", type=int, default=16384)
-    ap.add_argument("--variants", default="v0:2,v1_staggered:2,v1_lockstep:2,v1_staggered:1,v1_staggered:0")       # kernel:order
+    ap.add_argument("--variants", default="v1_staggered:2,v3:2")       # kernel:order
+    ap.add_argument("--ablate", action="store_true", help="also time the v1 ablations (no DMA / no reads / MFMA only): garbage outputs")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
@@ -50,10 +51,11 @@ def main():
         exact = (out == ref.to(torch.bfloat16)).float().mean().item()
         print(json.dumps({"check": "small", "sem": sem, "took_kernel": ok, "max_abs_err": err, "frac_equal_to_rounded_fp32": exact}), flush=True)
     lib.ar_gemm_dw_config(1, 2)
-    KERNELS = {"v0": 10, "v1_staggered": 11, "v1_lockstep": 12}
+    KERNELS = {"v0": 10, "v1_staggered": 11, "v1_lockstep": 12, "v3": 17}
+    ABLATIONS = {"abl_no_dma": 14, "abl_no_dma_no_reads": 15, "abl_mfma_only": 16}
     # accumulate + strided operands (column slices of wider buffers), multi-tile, all tile orders, every kernel
-    for kname, code in KERNELS.items():
-        for order in (0, 1, 2):
+    for kname, code in list(KERNELS.items()):
+        for order in (2,):
             lib.ar_gemm_dw_config(code, order)
             K, M, N = 512, 1024, 2048
             big_y = torch.randn(K, M + 512, device=dev).to(torch.bfloat16)
@@ -68,6 +70,9 @@ def main():
             print(json.dumps({"check": "strided+accumulate", "kernel": kname, "order": order, "max_rel_err": err,
                               "frac_equal_to_rounded_fp32": exact}), flush=True)
     wanted = [v for v in args.variants.split(",")]
+    if args.ablate:
+        KERNELS = dict(KERNELS, **ABLATIONS)
+        wanted += [f"{k}:2" for k in ABLATIONS]
     for name in args.shapes.split(","):
         M, N = SHAPES[name]
         K = args.K
