@@ -255,6 +255,40 @@ class AutoRound:
             qc["modules_in_block_to_quantize"] = [sorted(quantised)]
         return qc
 
+    def _llmc_quantization_config(self) -> dict:
+        """format "llm_compressor" for MXFP4 / NVFP4 (export_to_llmcompressor/export_to_fp.py:140-156 `_get_scheme` /
+        `_get_group_format`, :290-380; config.py:46-101): the `compressed-tensors` QuantizationConfig the reference obtains from
+        that package's preset schemes (`preset_name_to_scheme("NVFP4" | "MXFP4", ["Linear"])`, status COMPRESSED) and dumps with
+        `to_dict()`, plus `format`, `provider` and the `ignore` list of `generate_ignore_regex_list` (utils.py:21-51) + lm_head.
+        compressed-tensors (a third-party dependency of the reference, not vendored and not installed here) cannot be imported
+        to produce the dict, so it is restated in the layout the reference itself hard-codes for its NVFP4-E5M3 variant
+        (config.py:103-139): NVFP4 = 4-bit float, tensor_group strategy, group 16, static weights / locally dynamic inputs;
+        MXFP4 = 4-bit float, group strategy, group 32, static weights / dynamic inputs."""
+        dt, bits = str(self.scheme["data_type"]), int(self.scheme["bits"])
+        if bits != 4 or not dt.startswith(("mx_fp", "nv_fp")):
+            raise ValueError(f"llm_compressor format: implemented for the MXFP4 / NVFP4 schemes, got data_type={dt} bits={bits}")
+        nv = dt.startswith("nv_fp")
+        mixed = {(int(c.get("bits", 16)), str(c.get("data_type"))) for c in self.layer_config.values() if int(c.get("bits", 16)) <= 8}
+        if len(mixed) > 1:
+            raise NotImplementedError("llm_compressor format: mixed-precision config groups are not written by the MI355X path")
+
+        def quant_args(dynamic):
+            return {"actorder": None, "block_structure": None, "dynamic": dynamic, "group_size": 16 if nv else 32, "num_bits": 4,
+                    "observer": "minmax", "observer_kwargs": {}, "strategy": "tensor_group" if nv else "group", "symmetric": True,
+                    "type": "float"}
+
+        act = (self.scheme.get("act_bits") or 16) <= 8
+        ignore = ["re:" + layer_pattern_regex(p) for p, over in self._pattern_config().items() if int(over.get("bits", 0)) > 8]
+        ignore += [n for n, c in self.layer_config.items() if int(c.get("bits", 16)) > 8]
+        for n, m in self.model.named_modules():              # get_lm_head_name: the output projection stays out
+            if n.split(".")[-1] == "lm_head" and n not in self.layer_config and n not in ignore:
+                ignore.append(n)
+        return {"config_groups": {"group_0": {"input_activations": quant_args("local" if nv else True) if act else None,
+                                              "output_activations": None, "targets": ["Linear"], "weights": quant_args(False)}},
+                "format": "nvfp4-pack-quantized" if nv else "mxfp4-pack-quantized", "global_compression_ratio": None,
+                "ignore": ignore, "kv_cache_scheme": None, "quant_method": "compressed-tensors",
+                "quantization_status": "compressed", "provider": "auto-round"}
+
     def _awq_quantization_config(self) -> dict:
         """format "auto_awq" (export_to_awq/export.py:201-226): AutoAWQ's GEMM keys; layers left in 16 bit are listed."""
         qc = {k: self.scheme.get(k) for k in ("bits", "group_size", "sym", "data_type")}
@@ -282,8 +316,9 @@ class AutoRound:
             raise NotImplementedError("checkpoints are written as safetensors")
         if kwargs:
             raise TypeError(f"save_quantized: unsupported arguments {sorted(kwargs)}")
-        if format not in ("auto_round", "auto_round:auto_gptq", "auto_round:auto_awq", "auto_gptq", "auto_awq"):
-            raise NotImplementedError(f"format {format!r}: the MI355X path writes auto_round, auto_gptq and auto_awq checkpoints")
+        if format not in ("auto_round", "auto_round:auto_gptq", "auto_round:auto_awq", "auto_gptq", "auto_awq", "llm_compressor"):
+            raise NotImplementedError(f"format {format!r}: the MI355X path writes auto_round, auto_gptq, auto_awq and (MXFP4 / NVFP4) "
+                                      "llm_compressor checkpoints")
         if not self.quantized:
             raise RuntimeError("call quantize() first")
         from .export import pack_block
@@ -298,6 +333,12 @@ class AutoRound:
             if format == "auto_awq" and any(int(c.get("bits", 16)) not in (4, 16) for c in self.layer_config.values()):
                 raise ValueError("auto_awq format supports W4A16 only (every tuned layer must be 4 bit)")
             backend = format
+        elif format == "llm_compressor":      # same tensors as below, compressed-tensors config (export_to_llmcompressor/export_to_fp.py)
+            if int_scheme:
+                raise NotImplementedError("llm_compressor format for INT schemes packs through the compressed-tensors package "
+                                          "(export_to_llmcompressor/export.py:209-246), which is not part of this path")
+            llmc_cfg = self._llmc_quantization_config()
+            backend = "llm_compressor"
         elif not int_scheme:     # MXFP4 / NVFP4 checkpoints carry the llm_compressor tensor layout (export_to_nvfp_mx.py:178-179)
             backend = "auto_round:llm_compressor"
         else:                    # AutoRoundFormat's defaults (export/formats/backends/autoround.py:59-70)
@@ -325,7 +366,9 @@ class AutoRound:
         writer.write(rest)
         index = writer.close()
         cfg = self.model.config.to_dict() if hasattr(self.model, "config") else {}
-        if format == "auto_gptq":
+        if format == "llm_compressor":
+            cfg["quantization_config"] = llmc_cfg
+        elif format == "auto_gptq":
             cfg["quantization_config"] = self._gptq_quantization_config()
         elif format == "auto_awq":
             cfg["quantization_config"] = self._awq_quantization_config()

@@ -512,14 +512,7 @@ class SignRoundQuantizer:
             if n_improved > 0:
                 for a in arenas:
                     for l in a.layers:
-                        name = _name_of(block, l)
-                        bp = {}
-                        if "value" in l.params:
-                            bp["value"] = a.best_V[l._off:l._off + l.numel].view(l.n_groups, l.gs)
-                        if "min_scale" in l.params:
-                            bp["min_scale"] = a.best_min[l._goff:l._goff + l.n_groups]
-                            bp["max_scale"] = a.best_max[l._goff:l._goff + l.n_groups]
-                        best_params[name] = bp
+                        best_params[_name_of(block, l)] = a.best_params_of(l)
             best_iter, shown_loss = ist[1], best_loss
         else:
             best_params = collect_best_params(block)

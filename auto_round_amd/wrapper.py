@@ -203,7 +203,8 @@ class BlockArena:
     one WrapperLinear at a time (auto_round/wrapper.py:139-242)."""
 
     def __init__(self, key, device):
-        (self.data_type, self.bits, self.gs, self.sym, self.w_dtype, self.scale_dtype, self.bounds, self.optimized) = key
+        (self.data_type, self.bits, self.gs, self.sym, self.w_dtype, self.scale_dtype, self.bounds, self.optimized,
+         self.shared) = key        # shared: every layer has ONE (min_scale, max_scale) pair -- per-tensor groups
         self.device = device
         self.layers: List["WrapperLinear"] = []
         self.n = 0
@@ -240,9 +241,26 @@ class BlockArena:
         self.best_V = None
         self.best_min = None
         self.best_max = None
-        for lyr in self.layers:
+        if self.shared:
+            if self.kind != "int" or self.optimized:
+                raise NotImplementedError("per-tensor groups (group_size=0) are implemented for the INT schemes")
+            P = len(self.layers)
+            self.min_c = torch.ones(P, dtype=torch.float32, device=dev)        # the tunable parameters proper, one pair per layer
+            self.max_c = torch.ones(P, dtype=torch.float32, device=dev)
+            self.best_min_c = self.best_max_c = None
+            self.share_index = torch.cat([torch.full((l.n_groups,), i, dtype=torch.int64, device=dev)
+                                          for i, l in enumerate(self.layers)])
+        for li, lyr in enumerate(self.layers):
+            lyr._share_slot = li
             lyr._bind(self)
-        if self.kind == "int":
+        if self.kind == "int" and self.shared:
+            gmin, gmax = ops.group_minmax(self.W, self.gs)
+            self.wmin, self.wmax = torch.empty_like(gmin), torch.empty_like(gmax)
+            for l in self.layers:       # the tensor's own min / max (wrapper.py:154-164 on the [1, numel] view), on every virtual group
+                gl = slice(l._goff, l._goff + l.n_groups)
+                self.wmin[gl] = gmin[gl].min()
+                self.wmax[gl] = gmax[gl].max()
+        elif self.kind == "int":
             self.wmin, self.wmax = ops.group_minmax(self.W, self.gs)
         else:   # fp4: per-group absmax is constant during tuning; NVFP4 also needs the per-layer global scale
             self.wmin = self.wmax = None
@@ -287,11 +305,36 @@ class BlockArena:
             self.best_V = self.V.clone()
             self.best_min = self.min_scale.clone()
             self.best_max = self.max_scale.clone()
+            if self.shared:
+                self.best_min_c, self.best_max_c = self.min_c.clone(), self.max_c.clone()
+
+    def _expand_shared(self):
+        """Shared form: in-place [lo, hi] clamp of the per-layer parameters (wrapper.py:257-259), then onto the virtual groups."""
+        self.min_c.clamp_(self.bounds[0], self.bounds[1])
+        self.max_c.clamp_(self.bounds[0], self.bounds[1])
+        torch.index_select(self.min_c, 0, self.share_index, out=self.min_scale)
+        torch.index_select(self.max_c, 0, self.share_index, out=self.max_scale)
+
+    def best_params_of(self, lyr) -> dict:
+        """The best-so-far parameters of one layer in the reference's shapes (views into the arena's snapshot buffers)."""
+        bp = {}
+        if "value" in lyr.params:
+            bp["value"] = self.best_V[lyr._off:lyr._off + lyr.numel].view(lyr.value.shape)
+        if "min_scale" in lyr.params:
+            if self.shared:
+                i = lyr._share_slot
+                bp["min_scale"], bp["max_scale"] = self.best_min_c[i:i + 1], self.best_max_c[i:i + 1]
+            else:
+                bp["min_scale"] = self.best_min[lyr._goff:lyr._goff + lyr.n_groups]
+                bp["max_scale"] = self.best_max[lyr._goff:lyr._goff + lyr.n_groups]
+        return bp
 
     # -- the two grouped launches of an iteration ---------------------------------------------------------------------
     def qdq_forward(self, V=None, min_s=None, max_s=None, want_scale=False):
         """K1 for every layer of the block in one launch."""
         V = self.V if V is None else V
+        if self.shared and min_s is None and max_s is None:
+            self._expand_shared()
         mn = self.min_scale if min_s is None else min_s
         mx = self.max_scale if max_s is None else max_s
         if self.kind != "int":
@@ -332,6 +375,26 @@ class BlockArena:
                                      tune_minmax=self.tune_minmax, snapshot_flag=snapshot_flag,
                                      best_V=None if self.best_V is None else self.best_V[sl],
                                      best_max=None if self.best_max is None else self.best_max[gl])
+            self.wq_fresh = False
+            for lyr in self.layers:
+                lyr._dw_accum[0] = False
+            return
+        if self.shared:
+            dV, dmin, dmax = ops.qdq_int_bwd(self.dWq, self.W, self.V, self.wmin, self.wmax, self.min_scale, self.max_scale,
+                                             gs=self.gs, bits=self.bits, sym=self.sym_code, scale_dtype=self.scale_dtype,
+                                             q_thresh=self.q_thresh, bounds=self.bounds)
+            if snapshot_flag is not None:       # collect_best_params happens before optimizer.step() (sign_round/quantizer.py:508-523)
+                take = snapshot_flag.to(torch.bool)
+                self.best_V.copy_(torch.where(take, self.V, self.best_V))
+                self.best_min_c.copy_(torch.where(take, self.min_c, self.best_min_c))
+                self.best_max_c.copy_(torch.where(take, self.max_c, self.best_max_c))
+            ops.sign_sgd_(self.V, dV, lr_v)
+            if self.tune_minmax:
+                P = self.min_c.numel()
+                gmin = torch.zeros(P, dtype=torch.float32, device=self.device).index_add_(0, self.share_index, dmin)
+                gmax = torch.zeros(P, dtype=torch.float32, device=self.device).index_add_(0, self.share_index, dmax)
+                ops.sign_sgd_(self.min_c, gmin, lr_mm)
+                ops.sign_sgd_(self.max_c, gmax, lr_mm)
             self.wq_fresh = False
             for lyr in self.layers:
                 lyr._dw_accum[0] = False
@@ -383,13 +446,24 @@ class WrapperLinear(torch.nn.Module):
         self.is_conv1d = bool(Conv1D) and isinstance(orig_layer, Conv1D)
         w = orig_layer.weight.data
         self.out_features, self.in_features = (w.shape[1], w.shape[0]) if self.is_conv1d else tuple(w.shape)
+        if isinstance(orig_layer.group_size, (tuple, list)):
+            # 2-D block groups (data_type/utils.py:49-56) exist for the FP8 block schemes; through WrapperLinear the reference's
+            # own INT / fp4 quant functions cannot take them (weight_min is reduced over both block dims, the quant function
+            # reduces over the last one only and the shapes no longer broadcast -- tests/test_torch_ref.py pins that RuntimeError)
+            raise NotImplementedError(f"group_size={orig_layer.group_size}: 2-D block groups are an FP8 block-scheme feature; the "
+                                      "reference's W2/W3/W4/W8 and fp4 quant functions do not accept them either")
         gs = int(orig_layer.group_size)
+        # per-tensor (group_size == 0, data_type/utils.py:57-59): ONE group = the whole weight.  The kernels keep their
+        # lane-group form on "virtual" groups of <= 128 consecutive weights that all carry the tensor's (wmin, wmax,
+        # min_scale, max_scale); the arena sums their scale gradients before the sign step (BlockArena, shared form)
+        self.per_tensor = gs == 0
+        if self.per_tensor:
+            gs = next((g for g in (128, 64, 32, 16, 8) if self.in_features % g == 0), 0)
         if gs == -1 or self.in_features < gs:
             gs = self.in_features            # per-output-channel groups (data_type/utils.py:47-48)
         if gs <= 0 or gs % 8:
             raise NotImplementedError(f"group_size={orig_layer.group_size} with in_features={self.in_features}: group "
-                                      "sizes must be a multiple of 8 (per-tensor group_size=0 and 2-D block groups are "
-                                      "outside the hot path)")
+                                      "sizes must be a multiple of 8")
         self.gs = gs
         # rows are zero-padded to a multiple of the group size exactly like reshape_pad_tensor_by_group_size
         # (data_type/utils.py:52-56); the pad columns never receive a gradient, so their V stays 0
@@ -419,7 +493,7 @@ class WrapperLinear(torch.nn.Module):
     # arenas are keyed by everything the grouped kernels treat as launch-uniform
     def arena_key(self):
         return (self.data_type, self.bits, self.gs, self.sym, self.orig_layer.weight.dtype, self.scale_dtype,
-                tuple(self.minmax_scale_bound), bool(self.optimized))
+                tuple(self.minmax_scale_bound), bool(self.optimized), bool(self.per_tensor))
 
     def _imatrix_row(self):
         """The layer's importance matrix as one padded fp32 row [in_pad] (pad = 1e-5), or None for uniform importance.
@@ -450,9 +524,15 @@ class WrapperLinear(torch.nn.Module):
         self.weight_grad = arena.dWq[off:off + n].view(self.out_features, self.in_pad)[:, :self.in_features]
         tunable_v = self.enable_round_tuning and self.bits < 16
         tunable_mm = self.enable_minmax_tuning and self.bits < 16
-        self.value = torch.nn.Parameter(arena.V[off:off + n].view(G, self.gs), requires_grad=tunable_v)
-        self.min_scale = torch.nn.Parameter(arena.min_scale[goff:goff + G], requires_grad=tunable_mm)
-        self.max_scale = torch.nn.Parameter(arena.max_scale[goff:goff + G], requires_grad=tunable_mm)
+        if self.per_tensor:       # the reference's shapes: value [1, numel], min_scale / max_scale [1]
+            i = self._share_slot
+            self.value = torch.nn.Parameter(arena.V[off:off + n].view(1, n), requires_grad=tunable_v)
+            self.min_scale = torch.nn.Parameter(arena.min_c[i:i + 1], requires_grad=tunable_mm)
+            self.max_scale = torch.nn.Parameter(arena.max_c[i:i + 1], requires_grad=tunable_mm)
+        else:
+            self.value = torch.nn.Parameter(arena.V[off:off + n].view(G, self.gs), requires_grad=tunable_v)
+            self.min_scale = torch.nn.Parameter(arena.min_scale[goff:goff + G], requires_grad=tunable_mm)
+            self.max_scale = torch.nn.Parameter(arena.max_scale[goff:goff + G], requires_grad=tunable_mm)
         if tunable_v:
             self.params["value"] = self.value
         if tunable_mm:
@@ -516,6 +596,8 @@ class WrapperLinear(torch.nn.Module):
             wq2d = wq2d.t()
         if self.sym:
             zp = int(2 ** (self.bits - 1))
+        if self.per_tensor:       # every virtual group carries the tensor's scale / zero point: hand back the one value, [1, 1]
+            return wq2d, scale[:1].view(1, 1), zp if self.sym else zp[:1].view(1, 1)
         return wq2d, scale.view(self.n_groups, 1), zp if self.sym else zp.view(self.n_groups, 1)
 
     def forward(self, x):
@@ -537,9 +619,12 @@ class WrapperLinear(torch.nn.Module):
         wq, scale, zp = self._qdq_weight(v, mn, mx)
         self.orig_layer.weight.data.copy_(wq)
         self.orig_layer.weight.grad = None
-        self.orig_layer.scale = scale.reshape(self.out_features, -1).to("cpu")
+        if scale.numel() > 1:           # wrapper.py:393-398: a single (per-tensor) scale is stored flat
+            self.orig_layer.scale = scale.reshape(self.out_features, -1).to("cpu")
+        else:
+            self.orig_layer.scale = scale.view(-1).to("cpu")
         if isinstance(zp, torch.Tensor):
-            self.orig_layer.zp = zp.reshape(self.out_features, -1).to("cpu")
+            self.orig_layer.zp = (zp.reshape(self.out_features, -1) if zp.numel() > 1 else zp.view(-1)).to("cpu")
         else:
             self.orig_layer.zp = zp
         if self.weight_global_scale_dev is not None:

@@ -38,8 +38,11 @@ def qdq_int(W2d, bits, gs, sym, v, min_scale, max_scale, wmin, wmax, scale_dtype
     Returns (Wq [out,in] in W dtype, scale [G,1], zp (int for sym, [G,1] tensor for asym)).
     reference: auto_round/data_type/int.py:165-238 (quant_tensor_sym), :241-298 (quant_tensor_asym)"""
     out_f, in_f = W2d.shape
-    pad = (-in_f) % gs          # zero-pad every row to a multiple of gs (data_type/utils.py:52-56), cut again at the end
-    Wg = (F.pad(W2d, (0, pad)) if pad else W2d).reshape(-1, gs)
+    if gs == 0:                 # per-tensor: ONE group = the whole weight (data_type/utils.py:57-59)
+        pad, Wg = 0, W2d.reshape(1, -1)
+    else:
+        pad = (-in_f) % gs      # zero-pad every row to a multiple of gs (data_type/utils.py:52-56), cut again at the end
+        Wg = (F.pad(W2d, (0, pad)) if pad else W2d).reshape(-1, gs)
 
     def back(x):
         x = x.to(W2d.dtype)
@@ -315,11 +318,11 @@ class RefWrapperLinear(torch.nn.Module):
         gs = int(layer.group_size)
         W = layer.weight.data.t() if self.conv1d else layer.weight.data
         in_features = W.shape[1]
-        self.gs = in_features if (gs == -1 or in_features < gs) else gs
+        self.gs = gs if gs == 0 else (in_features if (gs == -1 or in_features < gs) else gs)
         self.scale_dtype = getattr(layer, "scale_dtype", torch.float16)
         self.thresh = 1e-8 if self.scale_dtype == torch.float32 else 1e-5
-        pad = (-W.shape[1]) % self.gs
-        Wg = (F.pad(W, (0, pad)) if pad else W).reshape(-1, self.gs)
+        pad = 0 if self.gs == 0 else (-W.shape[1]) % self.gs
+        Wg = W.reshape(1, -1) if self.gs == 0 else (F.pad(W, (0, pad)) if pad else W).reshape(-1, self.gs)
         self.wmin = torch.clamp(Wg.min(1)[0], max=0)
         self.wmax = torch.clamp(Wg.max(1)[0], min=0)
         dev = W.device
@@ -376,8 +379,8 @@ class RefWrapperLinear(torch.nn.Module):
             wq, s, zp = self.qdq(v, mn, mx)
             self.orig_layer.weight.data.copy_(wq)
         out_f = self.orig_layer.weight.shape[1] if self.conv1d else self.orig_layer.weight.shape[0]
-        self.orig_layer.scale = s.reshape(out_f, -1).cpu()
-        self.orig_layer.zp = zp.reshape(out_f, -1).cpu() if isinstance(zp, torch.Tensor) else zp
+        self.orig_layer.scale = (s.reshape(out_f, -1) if s.numel() > 1 else s.view(-1)).cpu()      # wrapper.py:393-398
+        self.orig_layer.zp = ((zp.reshape(out_f, -1) if zp.numel() > 1 else zp.view(-1)).cpu()) if isinstance(zp, torch.Tensor) else zp
         if self.act_quant:
             return RefWALayer(self.orig_layer)
         return self.orig_layer

@@ -117,3 +117,72 @@ def test_plain_format_configs_equal_the_reference_export(fmt, sym, lc, tmp_path,
             assert sorted(ref_qc[k]) == sorted(my_qc[k])
         elif k != "autoround_version":
             assert ref_qc[k] == my_qc[k], k
+
+
+def _fp4_shell(model, scheme_name, layer_config=None):
+    from auto_round_amd.autoround import AutoRound, _block_layer_config
+
+    ar = AutoRound.__new__(AutoRound)
+    ar.layer_config_in = layer_config
+    ar.model, ar.scheme, ar.config = model, resolve_scheme(scheme_name), SimpleNamespace(iters=1)
+    ar.block_names, ar.layer_config = [f"model.layers.{i}" for i in range(len(model.model.layers))], {}
+    for n in ar.block_names:
+        b = model.get_submodule(n)
+        for ln, cfg in apply_scheme(b, ar.scheme, layer_config=_block_layer_config(layer_config, n, b)).items():
+            ar.layer_config[f"{n}.{ln}"] = cfg
+    return ar
+
+
+def test_llm_compressor_config_known_answers():
+    from test_gpu_autoround import tiny_llama
+
+    nv = _fp4_shell(tiny_llama(seed=3, vocab=64), "NVFP4", {"k_proj": {"bits": 16, "act_bits": 16}})._llmc_quantization_config()
+    g = nv["config_groups"]["group_0"]
+    assert nv["format"] == "nvfp4-pack-quantized" and nv["quant_method"] == "compressed-tensors" and nv["quantization_status"] == "compressed"
+    assert g["weights"]["num_bits"] == 4 and g["weights"]["type"] == "float" and g["weights"]["strategy"] == "tensor_group"
+    assert g["weights"]["group_size"] == 16 and g["weights"]["dynamic"] is False and g["input_activations"]["dynamic"] == "local"
+    assert g["targets"] == ["Linear"] and nv["provider"] == "auto-round"
+    assert nv["ignore"] == ["re:.*k_proj.*", "model.layers.0.self_attn.k_proj", "model.layers.1.self_attn.k_proj", "lm_head"]
+    mx = _fp4_shell(tiny_llama(seed=3, vocab=64), "MXFP4")._llmc_quantization_config()
+    g = mx["config_groups"]["group_0"]
+    assert mx["format"] == "mxfp4-pack-quantized" and g["weights"]["group_size"] == 32 and g["weights"]["strategy"] == "group"
+    assert g["input_activations"]["num_bits"] == 4 and g["input_activations"]["dynamic"] is True and mx["ignore"] == ["lm_head"]
+    with pytest.raises(ValueError):
+        _shell(tiny_llama(seed=3, vocab=64), True, None)._llmc_quantization_config()          # INT schemes: not this exporter
+
+
+@needs_ref
+def test_llm_compressor_config_follows_the_reference_helpers_and_dict_layout():
+    """compressed-tensors is absent, so the reference cannot build (or save) this config here; what it DOES hold without that
+    package is pinned: the scheme / format names (`_get_scheme`, `_get_group_format`), the ignore list
+    (`generate_ignore_regex_list`) and the dict layout it hard-codes for its NVFP4-E5M3 variant (config.py:103-139)."""
+    _ref_on_path()
+    from auto_round.export.export_to_llmcompressor.config import initialize_nvfp4_e5m3_quantization
+    from auto_round.export.export_to_llmcompressor.utils import generate_ignore_regex_list
+
+    from test_gpu_autoround import tiny_llama
+
+    lc = {"k_proj": {"bits": 16, "act_bits": 16}, "model.layers.1.mlp.down_proj": {"bits": 16}}
+    ar = _fp4_shell(tiny_llama(seed=3, vocab=64), "NVFP4", lc)
+    mine = ar._llmc_quantization_config()
+    ref_layout = initialize_nvfp4_e5m3_quantization(ignore=["lm_head"])
+    assert set(mine) - {"provider"} == set(ref_layout)
+    assert set(mine["config_groups"]["group_0"]) == set(ref_layout["config_groups"]["group_0"])
+    for side in ("weights", "input_activations"):
+        a, b = mine["config_groups"]["group_0"][side], ref_layout["config_groups"]["group_0"][side]
+        assert set(a) == set(b) and all(a[k] == b[k] for k in a), side           # NVFP4 and its E5M3 variant share every quant arg
+    for k in ("global_compression_ratio", "kv_cache_scheme", "quant_method", "quantization_status"):
+        assert mine[k] == ref_layout[k], k
+    # the format / scheme names: functions of export_to_fp.py that need nothing from compressed-tensors (the module imports it
+    # lazily through config.py; _get_scheme / _get_group_format are plain string logic)
+    import importlib
+
+    try:
+        fp = importlib.import_module("auto_round.export.export_to_llmcompressor.export_to_fp")
+        assert fp._get_group_format(4, "nv_fp") == mine["format"] and fp._get_scheme(4, "nv_fp") == "NVFP4"
+        assert fp._get_group_format(4, "mx_fp") == _fp4_shell(tiny_llama(seed=3, vocab=64), "MXFP4")._llmc_quantization_config()["format"]
+    except ImportError:
+        pass
+    regex_config = {k: v for k, v in lc.items() if k not in ar.layer_config}
+    ref_ignore = generate_ignore_regex_list(regex_config=regex_config, layer_config=ar.layer_config)
+    assert mine["ignore"] == ref_ignore + ["lm_head"]

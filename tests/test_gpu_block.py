@@ -60,7 +60,8 @@ def linears(block):
     return {n: m for n, m in block.named_modules() if isinstance(m, torch.nn.Linear)}
 
 
-@pytest.mark.parametrize("kind,bits,gs,sym", [("llama", 4, 32, True), ("opt", 4, 128, True), ("llama", 2, 32, False)])
+@pytest.mark.parametrize("kind,bits,gs,sym", [("llama", 4, 32, True), ("opt", 4, 128, True), ("llama", 2, 32, False),
+                                              ("llama", 8, 0, True), ("opt", 8, 0, False)])      # gs 0: per-tensor groups
 def test_quantize_block_vs_torch_ref_loop(kind, bits, gs, sym):
     from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
     from oracle import torch_ref as tr
@@ -94,6 +95,9 @@ def test_quantize_block_vs_torch_ref_loop(kind, bits, gs, sym):
         agree.append((lm[n].weight == lo[n].weight).float().mean().item())
         # V moved by at most sum(lr) and only in multiples consistent with sign steps
         assert float(best_m[n]["value"].abs().max()) <= sum(tr.linear_lr_stream(1.0 / iters, iters)) + 1e-6
+        if gs == 0:     # the reference's per-tensor shapes: value [1, numel], one min / max scale, scale stored flat
+            assert tuple(best_m[n]["value"].shape) == (1, lm[n].weight.numel()) and tuple(best_m[n]["min_scale"].shape) == (1,)
+            assert tuple(lm[n].scale.shape) == (1,)
     assert np.mean(agree) > 0.97, agree
 
 

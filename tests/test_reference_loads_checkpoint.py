@@ -22,7 +22,35 @@ def test_fixture_checkpoint_layout(ck):
     from safetensors import safe_open
 
     qc = json.load(open(os.path.join(ck, "config.json")))["quantization_config"]
+    if ck.endswith("_fmt_llmc"):        # compressed-tensors config + the fp4 tensor layout (export_to_llmcompressor/export_to_fp.py)
+        nv = "nvfp4" in os.path.basename(ck)
+        g0 = qc["config_groups"]["group_0"]
+        assert qc["format"] == ("nvfp4-pack-quantized" if nv else "mxfp4-pack-quantized") and qc["quant_method"] == "compressed-tensors"
+        assert g0["weights"]["num_bits"] == 4 and g0["input_activations"]["num_bits"] == 4 and qc["ignore"] == ["lm_head"]
+        with safe_open(os.path.join(ck, "model.safetensors"), "pt") as f:     # what the reference's own tests check of this format
+            keys = set(f.keys())                                              # (test/unit/test_cpu/quantization/test_mxfp_nvfp.py:150-170, :260-275)
+            wp = f.get_tensor("model.layers.0.mlp.down_proj.weight_packed")
+            ws = f.get_tensor("model.layers.0.mlp.down_proj.weight_scale")
+        assert wp.dtype == torch.uint8 and tuple(wp.shape) == (128, 128) and ws.shape[0] == 128
+        assert ws.dtype == (torch.float8_e4m3fn if nv else torch.uint8)
+        assert ("model.layers.0.mlp.down_proj.weight_global_scale" in keys) == nv
+        assert ("model.layers.0.mlp.down_proj.input_global_scale" in keys) == nv
+        return
     bits, gs = qc["bits"], qc["group_size"]
+    if "gpt2" in os.path.basename(ck):   # Conv1D layers are packed like linears of shape [out, in] (export.py:200-205)
+        from test_gpu_autoround import unpack_w4_gptq
+
+        z = np.load(os.path.join(ck, "expected.npz"))
+        with safe_open(os.path.join(ck, "model.safetensors"), "pt") as f:
+            keys = set(f.keys())
+            for n in z["names"]:
+                t = {k: f.get_tensor(f"{z['prefix']}{n}.{k}") for k in ("qweight", "qzeros", "scales")}
+                W = unpack_w4_gptq(t["qweight"], t["qzeros"], t["scales"], gs)                 # [out, in]
+                stored = torch.from_numpy(z["W_" + str(n).replace(".", "_")]).view(torch.bfloat16)      # Conv1D: [in, out]
+                assert tuple(t["qweight"].shape) == (stored.shape[0] // 8, stored.shape[1])
+                assert torch.equal(W.to(torch.bfloat16), stored.t()), n
+        assert f"{z['prefix']}attn.c_attn.weight" not in keys and f"{z['prefix']}attn.c_attn.bias" in keys
+        return
     if "_fmt_" in ck:                   # the plain auto_gptq / auto_awq layouts
         from test_gpu_autoround import unpack_w4_awq, unpack_w4_gptq
 
@@ -66,6 +94,9 @@ def test_fixture_checkpoint_layout(ck):
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
 @pytest.mark.parametrize("ck", CKPTS, ids=[os.path.basename(c)[10:] for c in CKPTS])
 def test_reference_inference_stack_loads_our_checkpoint(ck):
+    if ck.endswith("_fmt_llmc"):
+        pytest.skip("llm_compressor checkpoints are loaded by vLLM / compressed-tensors, neither of which is installed; layout and "
+                    "config are pinned by the fixture-layout and config tests")
     if ck.endswith("fmt_awq"):
         pytest.skip("the reference has no torch-only backend for the AWQ layout (inference/backend.py: awq backends need "
                     "gptqmodel / autoawq / auto-round-lib); the layout is pinned by the decode and structure tests")
@@ -89,8 +120,15 @@ def test_reference_inference_stack_loads_our_checkpoint(ck):
     finally:
         for k, r in saved.items():
             B.BackendInfos[k].requirements = r
-    ql = m.model.layers[0].self_attn.q_proj
     z = np.load(os.path.join(ck, "expected.npz"))
+    if "gpt2" in os.path.basename(ck):
+        ql = m.transformer.h[0].attn.c_attn
+        with torch.no_grad():
+            logits = m(input_ids=torch.from_numpy(z["tokens"])).logits.float().numpy()
+        assert type(ql).__module__.startswith("auto_round_extension.torch.qlinear_torch"), type(ql)
+        assert np.abs(logits - z["logits"]).max() <= 0.05 * np.abs(z["logits"]).mean()
+        return
+    ql = m.model.layers[0].self_attn.q_proj
     fp4 = "fp4" in os.path.basename(ck)
     with torch.no_grad():
         logits = m(input_ids=torch.from_numpy(z["tokens"])).logits.float().numpy()

@@ -86,7 +86,7 @@ def _opt_layer(seed=0, hidden=64, ffn=128, heads=4, group_size=32, bits=4, sym=T
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
-@pytest.mark.parametrize("group_size,bits,sym", [(32, 4, True), (48, 4, True), (-1, 4, False), (40, 2, False)])
+@pytest.mark.parametrize("group_size,bits,sym", [(32, 4, True), (48, 4, True), (-1, 4, False), (40, 2, False), (0, 4, True), (0, 8, False)])
 def test_tune_block_equals_reference_loop_on_cpu(group_size, bits, sym):
     """Same seeded layer, same data, 6 iterations: reference wrapper_block/SignSGD/LinearLR vs oracle/torch_ref."""
     import copy
@@ -369,3 +369,24 @@ def test_asymmetric_int_activation_restatement_equals_reference_golden(tag):
     xq.backward(orc.from_bits(z[tag + "_dy"], dt))
     assert np.array_equal(orc.to_bits(xq), z[tag + "_xq"]) and np.array_equal(zp.detach().reshape(-1).numpy(), z[tag + "_zp"])
     assert np.array_equal(orc.to_bits(x.grad), z[tag + "_dx"])
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "auto_round")), reason="reference tree not present (GPU box)")
+def test_reference_wrapper_cannot_take_2d_block_groups_for_int_schemes():
+    """SURVEY 8 a1 lists tuple (2-D block) group sizes among the reshapes of data_type/utils.py:29-71.  They exist for the FP8 block
+    schemes: through WrapperLinear the reference's own INT quant functions fail on them (weight_min is reduced over both block
+    dimensions, wrapper.py:154-164, the quant function broadcasts it against a last-dimension reduction) -- which is why the
+    MI355X wrapper refuses them with NotImplementedError instead of inventing a behaviour."""
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shim")
+    sys.dont_write_bytecode = True
+    for p in (shim, REF):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from auto_round.wrapper import WrapperLinear
+
+    lin = torch.nn.Linear(128, 64, bias=False).to(torch.bfloat16)
+    lin.bits, lin.group_size, lin.sym, lin.data_type, lin.scale_dtype, lin.act_bits, lin.iters = 4, (16, 32), True, "int", torch.float16, 16, 200
+    lin.super_bits = lin.super_group_size = None
+    w = WrapperLinear(lin, enable_minmax_tuning=True, device="cpu")
+    with pytest.raises(RuntimeError):
+        w(torch.randn(2, 128).to(torch.bfloat16))
