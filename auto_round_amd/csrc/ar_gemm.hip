@@ -48,6 +48,8 @@ struct GemmArgs {
     int64_t ldy, ldx, ldw;
     int accumulate;      // dW += (torch addmm_ semantics: fp32 sum of the old bf16 value and the fp32 accumulator, rounded once)
     int tiles_m, tiles_n, order;
+    float* ws;           // split-K: fp32 partial tiles [nsplit][M][N] (caller-owned scratch), reduced in a fixed order afterwards
+    int nsplit;
 };
 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& a, int bid, int& tm, int& tn) {
@@ -521,21 +523,37 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw2_abl(GemmArgs a) {
 //  time -- measured equal to v1 within noise on every shape, profiles/r02_gemm_dw_v2_split_reads_no_gain.jsonl, and was removed.)
 
 // ---- v3: v1 with the DMA pieces issued from inside the MFMA cluster (copy of the v1 setup) --------------------------------
-template <bool STAGGER>
+// SPLITK: few output tiles but a deep K (OPT-125M's 768x768 weight against 16384 tokens is 9 tiles): the grid is tiles x nsplit,
+// every workgroup reduces its own K slice (a whole number of 128-row chunks) into an fp32 partial tile in caller-owned scratch,
+// and k_splitk_reduce sums the slices in slice order (deterministic: no float atomics) into the bf16 result.
+template <bool STAGGER, bool SPLITK = false>
 __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wm = wave & 3, wn = wave >> 2;
     int tm, tn;
-    tile_of_block(a, blockIdx.x, tm, tn);
+    int sp = 0;
+    int64_t krow0 = 0;
+    int U = a.K / GU;                              // k16 units; K % 128 == 0 (checked by the host)
+    if (SPLITK) {
+        sp = blockIdx.x % a.nsplit;
+        const int tile = blockIdx.x / a.nsplit;
+        tm = tile / a.tiles_n;
+        tn = tile % a.tiles_n;
+        const int chunks = a.K / 128;
+        const int c0 = (int)((int64_t)chunks * sp / a.nsplit), c1 = (int)((int64_t)chunks * (sp + 1) / a.nsplit);
+        krow0 = (int64_t)c0 * 128;
+        U = (c1 - c0) * 8;
+    } else {
+        tile_of_block(a, blockIdx.x, tm, tn);
+    }
     const int64_t m0 = (int64_t)tm * GB, n0 = (int64_t)tn * GB;
-    const int U = a.K / GU;                        // k16 units; K % 128 == 0 (checked by the host)
 
     const int drow = 2 * wave + (lane >> 5);
     const int lchunk = (lane & 31) ^ ((drow & 3) << 2);
-    const uint16_t* srcP = a.X + (int64_t)drow * a.ldx + n0 + lchunk * 8;
-    const uint16_t* srcQ = a.Y + (int64_t)drow * a.ldy + m0 + lchunk * 8;
+    const uint16_t* srcP = a.X + (krow0 + drow) * a.ldx + n0 + lchunk * 8;
+    const uint16_t* srcQ = a.Y + (krow0 + drow) * a.ldy + m0 + lchunk * 8;
     const int64_t stepP = (int64_t)GU * a.ldx, stepQ = (int64_t)GU * a.ldy;     // elements per unit
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
     const uint32_t dmabase = lds0 + 2 * wave * ROWB;                            // wave-uniform
@@ -650,6 +668,21 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
 #undef AR_PIN
 
     const int h = lane >> 5;
+    if (SPLITK) {
+        float* wsp = a.ws + (int64_t)sp * a.M * a.N;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int64_t m = m0 + wm * 64 + mi * 32 + (lane & 31);
+            float* rowp = wsp + m * a.N + n0 + wn * 128 + 4 * h;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    st16f(rowp + ni * 32 + 8 * t, make_float4(acc[mi][ni][4 * t + 0], acc[mi][ni][4 * t + 1], acc[mi][ni][4 * t + 2],
+                                                              acc[mi][ni][4 * t + 3]));
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int64_t m = m0 + wm * 64 + mi * 32 + (lane & 31);
@@ -673,7 +706,30 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     }
 }
 
-
+// sum of the split-K slices in slice order (+ the previous bf16 value when accumulating), one rounding to bf16
+__global__ __launch_bounds__(kTPB) void k_splitk_reduce(const float* __restrict__ ws, int nsplit, int64_t M, int64_t N, uint16_t* __restrict__ W,
+                                                         int64_t ldw, int accumulate) {
+    const int64_t cpr = N / kEPT;
+    const int64_t idx = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+    if (idx >= M * cpr) return;
+    const int64_t m = idx / cpr, c = idx - m * cpr;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        float p[8];
+        unpack_f8(load8_f32(ws, ((int64_t)s * M + m) * N + c * kEPT), p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += p[j];
+    }
+    if (accumulate) {
+        float o[8];
+        unpack8<AR_DT_BF16>(load8_raw<AR_DT_BF16>(W, m * ldw + c * kEPT), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += o[j];
+    }
+    store8<AR_DT_BF16>(W, m * ldw + c * kEPT, v);
+}
 
 static int g_gemm_kernel = 7;     // 0: v0  1: v1 staggered  2: v1 lockstep  3: v2 (split reads)  4-6: timing ablations  7: v3 (DMA in the MFMA cluster)
 static int g_gemm_sem = 1, g_gemm_order = 2;    // rule 1 is what the hardware does (profiles/r02_mfma_probe.json)
@@ -689,12 +745,28 @@ extern "C" int ar_gemm_dw_config(int sem, int order) {      // experiment knobs 
     return g_gemm_kernel * 100 + g_gemm_sem * 10 + g_gemm_order;
 }
 
+// split-K plan: only when the 256x256 tiles cannot fill the 256 CUs once and K is deep enough for slices of >= 512 rows
+static int splitk_plan(int64_t M, int64_t N, int64_t K) {
+    if (M % GB || N % GB || K % 128) return 1;
+    const int64_t tiles = (M / GB) * (N / GB);
+    if (tiles >= 192 || K < 1024) return 1;
+    int64_t ns = (256 + tiles - 1) / tiles;
+    if (ns > K / 512) ns = K / 512;
+    return ns < 2 ? 1 : (int)ns;
+}
+
+extern "C" int64_t ar_gemm_dw_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    const int ns = splitk_plan(M, N, K);
+    return ns > 1 ? (int64_t)ns * M * N * 4 : 0;
+}
+
 extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
-                          int64_t ldw, int accumulate, ar_stream_t stream) {
+                          int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, ar_stream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return AR_OK;
     if (M % GB || N % GB || K % (2 * GU) || K < GD * GU || (ldy % 8) || (ldx % 8) || (ldw % 4)) return AR_ERR_UNSUPPORTED;
     if (((uintptr_t)dY | (uintptr_t)X) & 15 || ((uintptr_t)dW & 7)) return AR_ERR_UNSUPPORTED;
     GemmArgs a;
+    a.ws = nullptr; a.nsplit = 1;
     a.Y = (const uint16_t*)dY; a.X = (const uint16_t*)X; a.W = (uint16_t*)dW;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = accumulate;
     a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = g_gemm_order;
@@ -709,10 +781,22 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    if (g_gemm_kernel >= 1 && K % 128 == 0 && K >= 256) {
+    if (g_gemm_kernel >= 1 && K % 128 == 0 && K >= 128) {
         if (g_gemm_kernel == 7) {
             static bool a4 = false;
-            if (!a4) { (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS); a4 = true; }
+            if (!a4) {
+                (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+                (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+                a4 = true;
+            }
+            const int ns = splitk_plan(M, N, K);
+            if (ns > 1 && workspace && workspace_bytes >= (int64_t)ns * M * N * 4 && (ldw % 8) == 0 && !((uintptr_t)dW & 15)) {
+                a.ws = (float*)workspace; a.nsplit = ns;
+                AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, true>), grid * ns, GTHREADS, GEMM_LDS, st, a);
+                const int rgrid = (int)((M * (N / kEPT) + kTPB - 1) / kTPB);
+                hipLaunchKernelGGL(k_splitk_reduce, rgrid, kTPB, 0, st, a.ws, ns, M, N, a.W, ldw, accumulate);
+                return launch_status();
+            }
             AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true>), grid, GTHREADS, GEMM_LDS, st, a);
             return launch_status();
         }

@@ -396,6 +396,9 @@ def rope_bwd(dq2d, dk2d, dv2d, cos, sin, batch, seq, hq, hkv, d, out=None):
     return dqkv
 
 
+_gemm_ws: dict = {}
+
+
 def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> bool:
     """out[M,N] (+)= dY2d[K,M]^T @ X2d[K,N] through the hand-written MFMA kernel (bf16, fp32 accumulate).  Operands may be
     column slices of wider row-major buffers (unit inner stride).  -> False when the shape / alignment is outside what the
@@ -417,9 +420,17 @@ def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate
     if len(devs) != 1:
         raise _lib.Mi355xLibraryError("gemm_dw: tensors live on different HIP devices")
     (dev,) = devs
+    ws_bytes = load().ar_gemm_dw_workspace_bytes(M, N, K)
+    ws = None
+    if ws_bytes > 0:                # split-K partial tiles: one growing scratch buffer per device, reused by every call
+        ws = _gemm_ws.get(dev)
+        if ws is None or ws.numel() < ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=f"cuda:{dev}")
+            _gemm_ws[dev] = ws
     with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
         rc = load().ar_gemm_dw(dY2d.data_ptr(), X2d.data_ptr(), out.data_ptr(), M, N, K, dY2d.stride(0), X2d.stride(0), out.stride(0),
-                               int(bool(accumulate)), torch.cuda.current_stream(dev).cuda_stream)
+                               int(bool(accumulate)), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
+                               torch.cuda.current_stream(dev).cuda_stream)
     if rc == _lib.AR_ERR_UNSUPPORTED:
         return False
     check(rc, "ar_gemm_dw")

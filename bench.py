@@ -146,18 +146,18 @@ def make_others(rope, seqlen, device, x1):
 def cpu_baseline(w, bits, gs, sym, seqlen, batch_size, iters, timed=5, extrapolate=True):
     """oracle/torch_ref (the pinned torch restatement of the reference loop) on the host cores, bounded sample.
 
-    extrapolate=True (big blocks): `timed` iterations at batch 1 of the real sequence length, and `timed` passes of the
-    batch-independent part alone (fake-quant forward + its autograd backward for every layer); per-iteration time at the real
-    batch B = t_q + B * (t_b1 - t_q) (GEMM / attention / elementwise work is linear in tokens; the fake-quant part does not
-    depend on the batch).  extrapolate=False (small blocks): `timed` iterations at the real batch, no model.
-    Medians are used; the spread (max-min over median) of the timed iterations is reported."""
+    extrapolate=True (big blocks): `timed` tuning iterations at batch 1 and `timed` at batch 2 of the real sequence length; the
+    per-iteration time at the real batch B is t(1) + (B - 1) * (t(2) - t(1)) -- the marginal cost of one more sample (GEMM,
+    attention and elementwise work are linear in tokens; the fake-quant forward/backward, weight casts and optimizer step do not
+    depend on the batch and sit in t(1)).  extrapolate=False (small blocks): `timed` iterations at the real batch, no model.
+    Medians are used; the spread (max - min over median) of each timed series is reported."""
     from oracle import torch_ref as tr
 
     torch.manual_seed(0)
     layer, rope, cfg, n_w = build_block(w, bits, gs, sym, "cpu", seed=0)
     S, H = seqlen, w["hidden"]
-    b_run = 1 if extrapolate else batch_size
-    X = torch.randn(b_run, S, H).to(torch.bfloat16)
+    b_max = 2 if extrapolate else batch_size
+    X = torch.randn(b_max, S, H).to(torch.bfloat16)
     others = make_others(rope, S, "cpu", X[:1])
 
     def fwd(blk, x, o):
@@ -169,52 +169,50 @@ def cpu_baseline(w, bits, gs, sym, seqlen, batch_size, iters, timed=5, extrapola
     params = [p for wr in wrappers for p in wr.params.values()]
     mse = torch.nn.MSELoss()
 
-    def one_iter():
+    def one_iter(b):
+        x = X[:b]
         with torch.autocast("cpu", dtype=torch.bfloat16):
-            out = fwd(layer, X, others)
-        loss = mse(out.float(), X.float())
+            out = fwd(layer, x, others)
+        loss = mse(out.float(), x.float())
         (loss * 1000).backward()
         tr.sign_sgd_step(params, 0.005)
         for p in params:
             p.grad = None
         return loss.item()
 
-    def quant_only():
-        for wr in wrappers:                       # fake-quant forward + autograd backward of every layer, no block forward
-            wq = wr.qdq()[0]
-            wq.backward(torch.ones_like(wq))
-        for p in params:
-            p.grad = None
-
-    def timeit(fn, n):
+    def series(b, n):
         ts = []
         for _ in range(n):
             t0 = time.perf_counter()
-            fn()
+            one_iter(b)
             ts.append(time.perf_counter() - t0)
         return ts
 
-    t_warm = timeit(one_iter, 1 if extrapolate else 2)[0]
-    t_it = timeit(one_iter, timed)
-    med = statistics.median(t_it)
-    rec = {"unit": "blocks/s", "cores": torch.get_num_threads(), "kind": "port", "timed_iterations": timed,
-           "iter_s": [round(t, 4) for t in t_it], "iter_spread": (max(t_it) - min(t_it)) / med, "warmup_iter_s": t_warm}
+    def spread(ts):
+        return (max(ts) - min(ts)) / statistics.median(ts)
+
+    rec = {"unit": "blocks/s", "cores": torch.get_num_threads(), "kind": "port", "timed_iterations_per_batch_size": timed}
     if extrapolate:
-        timeit(quant_only, 1)
-        t_q = statistics.median(timeit(quant_only, timed))
-        t_q = min(t_q, med)
-        t_iter = t_q + batch_size * (med - t_q)
-        rec["quant_only_s"] = t_q
+        t_warm = series(1, 1)[0]
+        t1, t2 = series(1, timed), series(2, timed)
+        m1, m2 = statistics.median(t1), statistics.median(t2)
+        slope = max(m2 - m1, 0.0)
+        t_iter = m1 + slope * (batch_size - 1)
+        rec.update(batch1_iter_s=[round(t, 3) for t in t1], batch2_iter_s=[round(t, 3) for t in t2], batch1_spread=spread(t1),
+                   batch2_spread=spread(t2), warmup_iter_s=t_warm)
         rec["sample"] = (f"oracle/torch_ref.py (torch restatement of the reference loop) on CPU, same block shapes: 1 warm-up + {timed} "
-                         f"timed tuning iterations at batch 1x{S} (median {med:.2f}s, spread {rec['iter_spread']:.1%}) and {timed} "
-                         f"passes of the batch-independent fake-quant forward+backward alone (median {t_q:.2f}s); per-iteration "
-                         f"time at batch {batch_size} = t_q + {batch_size}*(t_b1 - t_q) = {t_iter:.2f}s, x {iters} iters; fp/q-output "
-                         f"forwards and packing not included (favours the CPU)")
+                         f"timed tuning iterations at batch 1x{S} (median {m1:.2f}s, spread {spread(t1):.1%}) and {timed} at batch "
+                         f"2x{S} (median {m2:.2f}s, spread {spread(t2):.1%}); per-iteration time at batch {batch_size} = t(1) + "
+                         f"{batch_size - 1}*(t(2)-t(1)) = {t_iter:.2f}s, x {iters} iters; fp/q-output forwards and packing not "
+                         f"included (favours the CPU)")
     else:
-        t_iter = med
-        rec["sample"] = (f"oracle/torch_ref.py (torch restatement of the reference loop) on CPU, same block shapes: 1 warm-up + {timed} "
-                         f"timed tuning iterations at the real batch {batch_size}x{S} (median {med:.3f}s, spread "
-                         f"{rec['iter_spread']:.1%}) x {iters} iters; fp/q-output forwards and packing not included")
+        t_warm = series(batch_size, 2)[0]
+        tb = series(batch_size, timed)
+        t_iter = statistics.median(tb)
+        rec.update(iter_s=[round(t, 4) for t in tb], iter_spread=spread(tb), warmup_iter_s=t_warm)
+        rec["sample"] = (f"oracle/torch_ref.py (torch restatement of the reference loop) on CPU, same block shapes: 2 warm-up + {timed} "
+                         f"timed tuning iterations at the real batch {batch_size}x{S} (median {t_iter:.3f}s, spread {spread(tb):.1%}) "
+                         f"x {iters} iters; fp/q-output forwards and packing not included")
     rec["sec_per_iter_at_batch"] = t_iter
     rec["value"] = 1.0 / (iters * t_iter)
     return rec

@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 9
+#define AR_ABI_VERSION 10
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -262,7 +262,11 @@ int ar_rope_bwd(const void* dq, const void* dk, const void* dv, const void* cos,
  *           16-byte aligned, ldy/ldx multiples of 8, ldw a multiple of 4; anything else returns AR_ERR_UNSUPPORTED and the
  *           caller keeps the library GEMM.  Needs 128 KB of dynamic LDS per workgroup. */
 int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
-               int64_t ldw, int accumulate, ar_stream_t stream);
+               int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, ar_stream_t stream);
+/* caller-owned scratch ar_gemm_dw wants for (M, N, K) (the library never allocates): 0 when the output tiles alone fill the
+ * chip; otherwise the fp32 partial tiles of its split-K form (few tiles, deep K -- e.g. OPT-125M's 768x768 weight against 16384
+ * tokens), which are summed in slice order, i.e. deterministically.  Without the workspace the call still works, unsplit. */
+int64_t ar_gemm_dw_workspace_bytes(int64_t M, int64_t N, int64_t K);
 /* experiment knobs of the kernel above for tools/gemm_dw_probe.py (binding hygiene; -1 keeps a value): sem = lane->piece rule
  * of the transposing LDS read (1 | 2), order = tile order (0 identity, 1 XCD chunks, 2 XCD 2x8 patches).  Returns sem*10+order. */
 int ar_gemm_dw_config(int sem, int order);

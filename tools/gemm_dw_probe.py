@@ -13,7 +13,7 @@ from auto_round_amd import ops  # noqa: E402
 from auto_round_amd._lib import load  # noqa: E402
 
 SHAPES = {"gate_up": (14336, 4096), "down": (4096, 14336), "q_o": (4096, 4096), "qkv_merged": (6144, 4096),
-          "gate_up_merged": (28672, 4096), "kv": (1024, 4096), "opt_fc1": (3072, 768), "opt_qkv": (768, 768)}
+          "gate_up_merged": (28672, 4096), "kv": (1024, 4096), "opt_fc1": (3072, 768), "opt_fc2": (768, 3072), "opt_qkv": (768, 768)}
 
 
 def timed(fn, reps):
