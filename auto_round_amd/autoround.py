@@ -58,7 +58,7 @@ class AutoRound:
                  dataset=None, enable_alg_ext: bool = False, enable_quanted_input: bool = True,
                  enable_minmax_tuning: bool = True, gradient_accumulate_steps: int = 1, not_use_best_mse: bool = False,
                  dynamic_max_gap: int = -1, layer_config: Optional[Dict[str, dict]] = None, device_map=0, seed: int = 42,
-                 amp: bool = True, **kwargs):
+                 amp: bool = True, momentum: float = 0.0, **kwargs):
         # the reference's memory knobs change how it runs, not what it computes: accepted and ignored here (everything of one block
         # is resident in HBM).  enable_torch_compile (compressors/base.py:1177-1179: compiled block_forward, "about 20 %") selects its
         # MI355X counterpart: the fused HIP block path and the hand-written MFMA weight-gradient GEMM -- same trade as the
@@ -102,7 +102,7 @@ class AutoRound:
         self.config = SignRoundConfig(iters=iters, lr=lr, minmax_lr=minmax_lr, batch_size=batch_size, bits=self.scheme["bits"],
                                       enable_minmax_tuning=enable_minmax_tuning, enable_quanted_input=enable_quanted_input,
                                       gradient_accumulate_steps=gradient_accumulate_steps, not_use_best_mse=not_use_best_mse,
-                                      dynamic_max_gap=dynamic_max_gap, amp=amp, amp_dtype=amp_dtype, fused_block=fused,
+                                      dynamic_max_gap=dynamic_max_gap, amp=amp, amp_dtype=amp_dtype, momentum=momentum, fused_block=fused,
                                       mfma_dw_gemm=fused)
         self.layer_config_in = layer_config
         self.layer_config: Dict[str, dict] = {}

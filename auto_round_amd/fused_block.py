@@ -119,6 +119,63 @@ class FusedLlamaBlock:
         self.b_d = None if d.orig_layer.bias is None else d.orig_layer.bias.to(dt)
         return self
 
+    @classmethod
+    def try_build_plain(cls, block, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None) -> Optional["FusedLlamaBlock"]:
+        """The no-grad form for an UNWRAPPED block (plain nn.Linear layers): the reference forward that produces the block's
+        targets and the quantised-output forward that feeds the next block (composer.py steps 3 and 6) run through the same
+        fused kernels as the tuning-time forward.  The q/k/v and gate/up weights are concatenated once per call (a copy of the
+        block's weights against 128 samples of forward work).  Refused (None) when any projection carries forward hooks -- the
+        calibration hooks (act_max, imatrix) must see the module calls -- or an activation-quant shell."""
+        try:
+            n1, n2, attn, mlp = block.input_layernorm, block.post_attention_layernorm, block.self_attn, block.mlp
+            proj = [attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj]
+        except AttributeError:
+            return None
+        if not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not _is_silu(getattr(mlp, "act_fn", None)):
+            return None
+        if any(hasattr(attn, a) and not isinstance(getattr(attn, a), torch.nn.Identity) for a in ("q_norm", "k_norm")):
+            return None
+        if getattr(attn, "sliding_window", None) is not None:
+            return None
+        if not all(type(p) is torch.nn.Linear for p in proj):
+            return None
+        if any(p._forward_hooks or p._forward_pre_hooks for p in proj + [attn, mlp, n1, n2, block]):
+            return None
+        q, k, v, o, g, u, d = proj
+        if any(p.weight.dtype != amp_dtype or p.weight.device.type != "cuda" for p in proj) or amp_dtype not in (torch.bfloat16, torch.float16):
+            return None
+        others = dict(input_others or {})
+        pe = others.get("position_embeddings")
+        if not (isinstance(pe, (tuple, list)) and len(pe) == 2) or others.get("past_key_values") is not None:
+            return None
+        hd = int(getattr(attn, "head_dim", 0))
+        if hd <= 0 or hd % 16 or q.out_features % hd or k.out_features % hd or k.out_features != v.out_features:
+            return None
+        hq, hkv = q.out_features // hd, k.out_features // hd
+        if hq % hkv or o.in_features != hq * hd or (g.out_features % 8) or (q.in_features % 8) or g.out_features != u.out_features:
+            return None
+        for grp in ((q, k, v), (g, u)):
+            b = [p.bias for p in grp]
+            if any(x is not None for x in b) and not all(x is not None for x in b):
+                return None
+        self = cls()
+        self.block, self.arena, self.attn, self.layers = block, None, attn, {}
+        self.w1, self.eps1 = n1.weight, float(n1.variance_epsilon)
+        self.w2, self.eps2 = n2.weight, float(n2.variance_epsilon)
+        self.hq, self.hkv, self.hd = hq, hkv, hd
+        self.H, self.Fdim = q.in_features, g.out_features
+        self.scaling = getattr(attn, "scaling", None)
+        self.dtype = amp_dtype
+        self.sdpa_ctx = sdpa_ctx
+        self.Wqkv = torch.cat([q.weight, k.weight, v.weight], dim=0)
+        self.Wgu = torch.cat([g.weight, u.weight], dim=0)
+        self.Wo, self.Wd = o.weight, d.weight
+        self.b_qkv = None if q.bias is None else torch.cat([q.bias, k.bias, v.bias]).to(amp_dtype)
+        self.b_gu = None if g.bias is None else torch.cat([g.bias, u.bias]).to(amp_dtype)
+        self.b_o = None if o.bias is None else o.bias.to(amp_dtype)
+        self.b_d = None if d.bias is None else d.bias.to(amp_dtype)
+        return self
+
     # -- pieces ---------------------------------------------------------------------------------------------------------
     def _cos_sin(self, others, B, S):
         cos, sin = others["position_embeddings"]

@@ -59,7 +59,7 @@ def register():
             cfg = SignRoundConfig(
                 iters=self.iters, lr=None if getattr(c, "lr_is_auto", False) else self.lr,
                 minmax_lr=None if getattr(c, "minmax_lr_is_auto", False) else self.minmax_lr,
-                lr_scheduler=self.lr_scheduler, enable_minmax_tuning=self.enable_minmax_tuning,
+                lr_scheduler=self.lr_scheduler, momentum=getattr(self, "momentum", 0.0) or 0.0, enable_minmax_tuning=self.enable_minmax_tuning,
                 enable_norm_bias_tuning=self.enable_norm_bias_tuning,
                 gradient_accumulate_steps=self.gradient_accumulate_steps, not_use_best_mse=self.not_use_best_mse,
                 dynamic_max_gap=self.dynamic_max_gap, enable_quanted_input=self.enable_quanted_input,

@@ -298,8 +298,6 @@ class SignRoundQuantizer:
         c = self.config
         if c.enable_norm_bias_tuning:
             raise NotImplementedError("enable_norm_bias_tuning is outside the MI355X hot path")
-        if c.momentum not in (0, 0.0, None):
-            raise NotImplementedError("momentum != 0 is outside the MI355X hot path")
         self.last_stats: Dict[str, Any] = {}
         self.last_fused_block = False
 
@@ -388,7 +386,7 @@ class SignRoundQuantizer:
                 for l in a.layers:
                     mm += [p for k, p in l.params.items() if "min" in k or "max" in k]
                 groups.append({"params": mm, "lr": torch.tensor(layer_mm), "kind": "minmax", "arena": ai})
-        optimizer = self.optimizer(groups, lr=torch.tensor(cfg.lr), weight_decay=0, arenas=arenas)
+        optimizer = self.optimizer(groups, lr=torch.tensor(cfg.lr), weight_decay=0, arenas=arenas, momentum=cfg.momentum or 0.0)
         optimizer.fuse_next_fwd = cfg.fuse_next_forward
         if cfg.lr_scheduler is None:
             lr_schedule = torch.optim.lr_scheduler.LinearLR(optimizer, start_factor=1.0, end_factor=0.0,
@@ -547,9 +545,15 @@ class SignRoundQuantizer:
     def forward_all(self, block, inputs: torch.Tensor, input_others, batch_size: Optional[int] = None) -> torch.Tensor:
         """No-grad forward of every cached sample in minibatches -> [N, S, H] (composer.py steps 3 and 6)."""
         bs = batch_size or self.config.batch_size
+        fb = None
+        if self.config.fused_block and self.config.amp and isinstance(input_others, dict):
+            from .fused_block import FusedLlamaBlock
+
+            fb = FusedLlamaBlock.try_build_plain(block, input_others, self.config.amp_dtype, sdpa_ctx=self._sdpa_ctx)
         outs = []
         for b0 in range(0, inputs.shape[0], bs):
-            outs.append(self.block_forward(block, inputs[b0:b0 + bs], input_others))
+            x = inputs[b0:b0 + bs]
+            outs.append(fb.forward_nograd(x, input_others) if fb is not None else self.block_forward(block, x, input_others))
         return torch.cat(outs, dim=0)
 
     def calibrate_block(self, block, X: torch.Tensor, input_others, Xq: Optional[torch.Tensor] = None) -> torch.Tensor:

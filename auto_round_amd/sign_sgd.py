@@ -10,8 +10,9 @@ SURVEY App. A.4).  Two execution modes:
 * unfused (`fused=False`, or plain tensors with `.grad` set): one `ar_sign_sgd` launch per parameter, the literal
   restatement used by the step-level parity tests.
 
-weight_decay / momentum / nesterov of the reference are not on the named hot path (weight_decay=0, momentum=0 in
-SignRoundConfig) and raise if requested.
+momentum (0 by default) takes the unfused route -- gradients materialised by `ar_qdq_int_bwd`, running buffers, `ar_sign_sgd` --
+because the sign is then taken of the buffer; weight_decay is always 0 in the reference's quantizer and nesterov / dampening are
+never set by it: they raise if requested.
 """
 from __future__ import annotations
 
@@ -29,11 +30,13 @@ class SignSGD(Optimizer):
                  foreach=None, differentiable=False, arenas=None, fused=None):
         if lr is None:
             raise ValueError("lr is required")
-        if momentum not in (0, None) or weight_decay != 0 or nesterov or maximize:
-            raise NotImplementedError("SignSGD on MI355X implements the hot-path configuration: momentum=0, "
-                                      "weight_decay=0, nesterov=False, maximize=False")
-        defaults = dict(lr=lr, momentum=0, dampening=dampening, weight_decay=0, nesterov=False, maximize=False,
+        if weight_decay != 0 or nesterov or maximize or dampening != 0:
+            raise NotImplementedError("SignSGD on MI355X implements what the reference's quantizer can ask for: weight_decay=0 "
+                                      "(sign_round/quantizer.py:422), dampening=0, nesterov=False, maximize=False")
+        momentum = float(momentum or 0.0)
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=0, nesterov=False, maximize=False,
                         foreach=foreach, differentiable=differentiable)
+        self.momentum = momentum
         super().__init__(params, defaults)
         self.arenas = list(arenas) if arenas else []
         self.fused = bool(self.arenas) if fused is None else fused
@@ -75,8 +78,10 @@ class SignSGD(Optimizer):
             for a in self.arenas:
                 lr_v, lr_mm = self._arena_lrs(a)
                 a.backward_step(self._lr_tensor(("v", id(a)), lr_v, a.device), self._lr_tensor(("mm", id(a)), lr_mm, a.device),
-                                snapshot_flag=self.snapshot_flag, fuse_next_fwd=self.fuse_next_fwd)
+                                snapshot_flag=self.snapshot_flag, fuse_next_fwd=self.fuse_next_fwd, momentum=self.momentum)
             return loss
+        if self.momentum:
+            raise NotImplementedError("momentum is implemented on the arena path (quantize_block)")
         for gi, group in enumerate(self.param_groups):
             lr = group["lr"]
             for pi, p in enumerate(group["params"]):

@@ -485,11 +485,21 @@ def unwrap_block(block, best):
 
 
 @torch.no_grad()
-def sign_sgd_step(params, lr: float):
-    """reference: SignSGD._single_tensor_sgd, algorithms/quantization/sign_round/sign_sgd.py:356-389"""
+def sign_sgd_step(params, lr: float, momentum: float = 0.0, state: Optional[dict] = None):
+    """reference: SignSGD._single_tensor_sgd, algorithms/quantization/sign_round/sign_sgd.py:356-389 (weight_decay 0, dampening 0,
+    no nesterov): with momentum the sign is taken of the running buffer, which starts as a copy of the first gradient."""
     for p in params:
-        if p.grad is not None:
-            p.add_(torch.sign(p.grad), alpha=-lr)
+        if p.grad is None:
+            continue
+        d = p.grad
+        if momentum:
+            buf = state.get(id(p))
+            if buf is None:
+                buf = state[id(p)] = d.detach().clone()
+            else:
+                buf.mul_(momentum).add_(d, alpha=1.0)
+            d = buf
+        p.add_(torch.sign(d), alpha=-lr)
 
 
 def linear_lr_stream(lr0: float, iters: int) -> List[float]:
@@ -527,7 +537,7 @@ class Sampler:
 def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others: dict, *, iters=200, batch_size=8,
                lr=None, enable_minmax_tuning=True, amp_dtype=torch.bfloat16, forward=None, record=None,
                max_iters_to_run=None, input_ids=None, amp=True, alg_ext=False, gradient_accumulate_steps=1, minmax_lr=None,
-               not_use_best_mse=False, dynamic_max_gap=-1):
+               not_use_best_mse=False, dynamic_max_gap=-1, momentum=0.0):
     """The reference's quantize_block loop in plain torch.  inputs/targets: [N, S, H].  Returns best_params and
     leaves the block unwrapped with baked weights.  `forward(block, x, others)` defaults to block(x, **others)[0].
     reference: SignRoundQuantizer.quantize_block, algorithms/quantization/sign_round/quantizer.py:311-552"""
@@ -545,6 +555,7 @@ def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others:
     lrs_mm = lrs if minmax_lr is None else linear_lr_stream(minmax_lr, iters)     # minmax_lr defaults to lr (config.py:110-140)
     params_v = [p for w in wrappers.values() for k, p in w.params.items() if k == "value"]
     params_mm = [p for w in wrappers.values() for k, p in w.params.items() if k != "value"]
+    mom_state: dict = {}
     params = params_v + params_mm
     # micro-batches: the sampler draws global batches of batch_size * gradient_accumulate_steps, the loss becomes a SUM that is
     # normalised for reporting only, the gradient accumulates over the micro-batches (quantizer.py:436-452, :470-500)
@@ -600,8 +611,8 @@ def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others:
             record(i, wrappers, total)
         if not not_use_best_mse and 0 < dynamic_max_gap <= i - last_best:
             break
-        sign_sgd_step(params_v, lrs[i])
-        sign_sgd_step(params_mm, lrs_mm[i])
+        sign_sgd_step(params_v, lrs[i], momentum, mom_state)
+        sign_sgd_step(params_mm, lrs_mm[i], momentum, mom_state)
         for p in params:
             p.grad = None
     unwrap_block(block, best)

@@ -896,3 +896,32 @@ def test_block_sharding_two_ranks_equals_the_sequential_run(tmp_path):
         assert abs(sharded[k]["stats"]["init_loss"] - recs[k]["stats"]["init_loss"]) <= 1e-6 * recs[k]["stats"]["init_loss"], k
         for n, m in linears(blocks[k]).items():
             assert torch.equal(sharded[k]["weights"][n], m.weight.cpu()), (k, n)
+
+
+@pytest.mark.parametrize("kind,bits,gs,sym,scheme", [("llama", 4, 32, True, None), ("llama", 2, 32, False, None), ("llama", 4, 32, True, "MXFP4_W")])
+def test_momentum_takes_the_unfused_route_and_tracks_the_torch_restatement(kind, bits, gs, sym, scheme):
+    """SignSGD momentum (sign_sgd.py:356-389, off by default): running buffers over materialised gradients."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from oracle import torch_ref as tr
+
+    layer, rope, cfg = make_layer(kind, bits, gs, sym)
+    if scheme is not None:
+        from auto_round_amd.testing.moe import set_scheme
+
+        set_scheme(layer, scheme)
+    X, others = make_data(rope, cfg)
+    Y = targets(layer, X, others)
+    iters, bs = 6, 4
+    blk_o = copy.deepcopy(layer)
+    random.seed(13)
+    best_o, info = tr.tune_block(blk_o, X, Y, others, iters=iters, batch_size=bs, forward=fwd, momentum=0.9)
+    blk_m = copy.deepcopy(layer)
+    random.seed(13)
+    q = SignRoundQuantizer(SignRoundConfig(iters=iters, batch_size=bs, bits=bits, momentum=0.9), device="cuda")
+    q.quantize_block(blk_m, X, others, Y, None, None)
+    st = q.last_stats
+    assert abs(st["init_loss"] - info["losses"][0]) <= 2e-3 * info["losses"][0], (st, info["losses"])
+    assert abs(st["best_loss"] - info["best_loss"]) <= 5e-2 * info["best_loss"], (st, info)
+    lo, lm = linears(blk_o), linears(blk_m)
+    agree = [(lm[n].weight == lo[n].weight).float().mean().item() for n in lo]
+    assert np.mean(agree) > 0.95, agree

@@ -237,3 +237,28 @@ def test_tuning_with_the_fused_block_tracks_the_generic_path(bits, gs):
     # fixed is the learning (losses above) and the block's quantised output (below)
     assert same / tot > 0.45, same / tot
     assert (res[False][2].float() - res[True][2].float()).abs().mean().item() < 2e-2 * res[False][2].float().abs().mean().item()
+
+
+def test_fused_nograd_forward_of_an_unwrapped_block_and_its_fallback_under_hooks():
+    """The reference forward (targets) and the quantised-output forward run through the fused kernels too; with calibration
+    hooks on the projections the module path is kept so that the hooks fire."""
+    from auto_round_amd.fused_block import FusedLlamaBlock
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    layer, rope, cfg = _llama_layer()
+    X, others = _data(rope, cfg, N=8, S=64)
+    qf = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=4, bits=4, fused_block=True), device="cuda")
+    qm = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=4, bits=4, fused_block=False), device="cuda")
+    assert FusedLlamaBlock.try_build_plain(layer, others, torch.bfloat16) is not None
+    out_f, out_m = qf.forward_all(layer, X, others), qm.forward_all(layer, X, others)
+    scale = out_m.float().abs().mean().item()
+    assert out_f.shape == out_m.shape and (out_f.float() - out_m.float()).abs().mean().item() < 5e-3 * scale
+    assert (out_f.float() - out_m.float()).abs().max().item() < 0.05 * scale + 0.05
+    seen = []
+    h = layer.mlp.down_proj.register_forward_hook(lambda m, i, o: seen.append(1))
+    try:
+        assert FusedLlamaBlock.try_build_plain(layer, others, torch.bfloat16) is None
+        out_h = qf.forward_all(layer, X, others)
+    finally:
+        h.remove()
+    assert len(seen) == 2 and torch.equal(out_h, out_m)

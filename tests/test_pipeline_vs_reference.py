@@ -116,6 +116,8 @@ def _tiny_moe(experts=4, top_k=2):
                                 dict(scheme="W4A16", group_size=32, enable_minmax_tuning=False),
                                 dict(scheme="W4A16", group_size=32, enable_quanted_input=False),
                                 dict(scheme="W2A16G32", lr=5e-3, minmax_lr=2e-3),
+                                dict(scheme="W4A16", group_size=32, momentum=0.9, iters=6),
+                                dict(scheme="W8A16", group_size=0, iters=4),
                                 dict(scheme="W2A16G32", iters=6, dynamic_max_gap=1),
                                 dict(scheme="W4A16", group_size=32, layer_config={"model.layers.0.mlp.down_proj": {"bits": 16},
                                                                                   "q_proj": {"bits": 8}, "layers.1.mlp": {"group_size": 64}}),
@@ -126,7 +128,7 @@ def _tiny_moe(experts=4, top_k=2):
                                 dict(scheme="W4A16", group_size=32, trailing_repeats=True, pad_token_id=3)],
                          ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32",
                               "mixtral_nvfp4_idle_experts", "opt_w4g32", "opt_w2g32_asym", "gpt2_conv1d_w4g32", "qwen2_w4g32", "qwen3_w4g32", "qwen3_moe_w4g32", "w4a8_int_act", "int8_w8a8", "w3g32", "w8g32", "grad_accumulate_2", "last_iterate",
-                              "no_minmax_tuning", "fp_input_chain", "explicit_lrs", "early_stop", "mixed_layer_config",
+                              "no_minmax_tuning", "fp_input_chain", "explicit_lrs", "momentum_0.9", "per_tensor_groups", "early_stop", "mixed_layer_config",
                               "ragged_last_batch", "fewer_samples_than_batch", "other_seed", "trailing_repeats_count_as_padding",
                               "pad_token_id_masks_pads"])
 def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monkeypatch):
@@ -158,7 +160,7 @@ def test_block_by_block_pipeline_equals_reference_front_door(kw, tmp_path, monke
         tokens[2, 4], tokens[5, 9] = 3, 3
     iters, bs, S = kw.pop("iters", 3), 4, 16
     loop_kw = {k: kw.pop(k) for k in ("gradient_accumulate_steps", "not_use_best_mse", "enable_minmax_tuning", "lr", "minmax_lr",
-                                      "dynamic_max_gap") if k in kw}
+                                      "dynamic_max_gap", "momentum") if k in kw}
     quanted_input = kw.pop("enable_quanted_input", True)
     if loop_kw.get("gradient_accumulate_steps", 1) != 1:
         bs = 2                                       # 2 micro-batches of 2 = the same global batch of 4

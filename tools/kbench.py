@@ -73,6 +73,30 @@ def main():
         res[f"int8_act_g{ags}_fwd_GBps"] = 4 * n / t / 1e6
         t = timeit(lambda: ops.int_act_bwd(dWq, W, gs=ags, bits=8, out=Wq))
         res[f"int8_act_g{ags}_bwd_GBps"] = 6 * n / t / 1e6
+    # fused block kernels at the Llama-3-8B minibatch (8 x 2048 tokens, hidden 4096, ffn 14336, 32/8 heads of 128)
+    del V, dWq, Wq
+    T, H, Fd, hq, hkv, d = 16384, 4096, 14336, 32, 8, 128
+    x = torch.randn(T, H, generator=g, device="cuda").to(torch.bfloat16)
+    wn = torch.ones(H, device="cuda", dtype=torch.bfloat16)
+    t = timeit(lambda: ops.rmsnorm_fwd(x, wn, 1e-5))
+    res["rmsnorm_fwd_GBps"] = 4 * T * H / t / 1e6
+    y, rstd = ops.rmsnorm_fwd(x, wn, 1e-5)
+    t = timeit(lambda: ops.rmsnorm_bwd(y, x, wn, rstd, dres=x, out=y))
+    res["rmsnorm_bwd_add_GBps"] = 8 * T * H / t / 1e6
+    gu = torch.randn(T, 2 * Fd, generator=g, device="cuda").to(torch.bfloat16)
+    t = timeit(lambda: ops.swiglu_fwd(gu, Fd))
+    res["swiglu_fwd_GBps"] = 6 * T * Fd / t / 1e6
+    da = ops.swiglu_fwd(gu, Fd)
+    t = timeit(lambda: ops.swiglu_bwd_(da, gu, Fd))
+    res["swiglu_bwd_GBps"] = 10 * T * Fd / t / 1e6
+    del gu, da
+    qkv = torch.randn(T, (hq + 2 * hkv) * d, generator=g, device="cuda").to(torch.bfloat16)
+    cs = torch.randn(1, 2048, d, generator=g, device="cuda").to(torch.bfloat16)
+    t = timeit(lambda: ops.rope_fwd(qkv, cs, cs, 8, 2048, hq, hkv, d))
+    res["rope_fwd_GBps"] = 2 * T * d * ((hq + 2 * hkv) + 3 * hq) / t / 1e6
+    q, k, v = ops.rope_fwd(qkv, cs, cs, 8, 2048, hq, hkv, d)
+    t = timeit(lambda: ops.rope_bwd(q, k, v, cs, cs, 8, 2048, hq, hkv, d, out=qkv))
+    res["rope_bwd_GBps"] = 2 * T * d * ((hq + 2 * hkv) + 3 * hq) / t / 1e6
     print(json.dumps({k: round(v, 3) for k, v in res.items()}))
 
 
