@@ -224,7 +224,7 @@ def test_tuning_with_the_fused_block_tracks_the_generic_path(bits, gs):
                                                mfma_dw_gemm=fused), device="cuda")
         fp_out, q_out, best = q.compress_block(blk, X, others)
         assert q.last_fused_block is fused
-        res[fused] = (q.last_stats, {n: m.weight.detach().clone() for n, m in blk.named_modules() if isinstance(m, torch.nn.Linear)}, q_out)
+        res[fused] = (q.last_stats, {n: m.weight.detach().clone() for n, m in blk.named_modules() if isinstance(m, torch.nn.Linear)}, q_out, fp_out)
     sg, sf = res[False][0], res[True][0]
     assert abs(sg["init_loss"] - sf["init_loss"]) <= 2e-2 * sg["init_loss"], (sg, sf)
     assert sf["best_loss"] < 0.9 * sf["init_loss"] and abs(sg["best_loss"] - sf["best_loss"]) <= 0.15 * sg["best_loss"], (sg, sf)
@@ -236,7 +236,13 @@ def test_tuning_with_the_fused_block_tracks_the_generic_path(bits, gs):
     # sign step amplifies that: after 20 iterations roughly 60-80 % of the baked weights are still bit-identical; what is held
     # fixed is the learning (losses above) and the block's quantised output (below)
     assert same / tot > 0.45, same / tot
-    assert (res[False][2].float() - res[True][2].float()).abs().mean().item() < 2e-2 * res[False][2].float().abs().mean().item()
+    # the two quantised blocks sit at the same distance from the fp block (that distance IS the quantisation error, several
+    # percent of the output at 2 bits) and no further from each other than that
+    err_g = (res[False][2].float() - res[False][3].float()).abs().mean().item()
+    err_f = (res[True][2].float() - res[True][3].float()).abs().mean().item()
+    assert abs(err_f - err_g) <= 0.15 * err_g, (err_f, err_g)
+    assert (res[False][2].float() - res[True][2].float()).abs().mean().item() <= 1.2 * err_g
+    assert (res[False][3].float() - res[True][3].float()).abs().mean().item() < 5e-3 * res[False][3].float().abs().mean().item()      # fp targets
 
 
 def test_fused_nograd_forward_of_an_unwrapped_block_and_its_fallback_under_hooks():
