@@ -28,8 +28,24 @@ __device__ __forceinline__ float f16_to_f32(uint32_t h) {
 __device__ __forceinline__ uint32_t f32_to_f16(float f) {
     return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);   // v_cvt_f16_f32, RNE
 }
+// two fp32 -> packed bf16x2 with the gfx950 conversion instruction (v_cvt_pk_bf16_f32: RNE, NaN quieted); verified
+// against the integer RNE formula over all 2^32 inputs by tools/exactcheck (profiles/r01_exactcheck.json).
+#ifndef AR_HW_BF16
+#define AR_HW_BF16 1
+#endif
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#if AR_HW_BF16
+    f32x2_t v; v.x = lo; v.y = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+#else
+    return f32_to_bf16(lo) | (f32_to_bf16(hi) << 16);
+#endif
+}
+
 template <int DT> __device__ __forceinline__ float round_to(float v) {
-    if constexpr (DT == AR_DT_BF16) return __uint_as_float(f32_to_bf16(v) << 16);
+    if constexpr (DT == AR_DT_BF16) return __uint_as_float(pack_bf16x2(v, v) & 0xffff0000u);      // 2 instructions (software RNE: 7)
     else if constexpr (DT == AR_DT_F16) return f16_to_f32(f32_to_f16(v));
     else return v;
 }
@@ -128,22 +144,6 @@ template <int DT> __device__ __forceinline__ void unpack8(const Raw8<DT>& r, flo
         o[6] = f16_to_f32(r.q.w & 0xffffu); o[7] = f16_to_f32(r.q.w >> 16);
     }
 }
-// two fp32 -> packed bf16x2 with the gfx950 conversion instruction (v_cvt_pk_bf16_f32: RNE, NaN quieted); verified
-// against the integer RNE formula over all 2^32 inputs by tools/exactcheck (profiles/r01_exactcheck.json).
-#ifndef AR_HW_BF16
-#define AR_HW_BF16 1
-#endif
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-#if AR_HW_BF16
-    f32x2_t v; v.x = lo; v.y = hi;
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-#else
-    return f32_to_bf16(lo) | (f32_to_bf16(hi) << 16);
-#endif
-}
-
 // ---- exact division by a per-group scale in 3 instructions --------------------------------------------------------
 // y = 1/s is the correctly rounded reciprocal (one IEEE division per lane per chunk, shared by its 8 elements); then
 //     q0 = w*y ; r = fma(-q0, s, w) (exact residual) ; q = fma(r, y, q0)
@@ -215,6 +215,40 @@ __device__ __forceinline__ float lanes_min(float v, int width) {
     for (int m = width >> 1; m > 0; m >>= 1) v = fminf(v, __shfl_xor(v, m, kWave));
     return v;
 }
+
+// ---- lane-group butterflies on DPP (no LDS crossbar): after the two quad permutes every quad is uniform, row_half_mirror then
+// swaps the two quads of an 8-lane half and row_mirror the two halves of a 16-lane row; 32 / 64 lanes finish through ds_bpermute.
+// One VOP2 instruction with the DPP operand per step; written as inline asm because the compiler's own form of it is
+// mov + mov_dpp + canonicalise + op.  `s_nop 1` covers the two wait states between a VALU write of the source and its DPP read.
+#define AR_DPP_STEP(OPC, CTRL, V)                                                                                  \
+    asm volatile("s_nop 1\n\t" OPC "_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(V) : "v"(V))
+#define AR_GROUP_REDUCE(T, NAME, OPC, OP)                                                                         \
+    template <int W> __device__ __forceinline__ T NAME(T v) {                                                     \
+        if constexpr (W >= 2) AR_DPP_STEP(OPC, "quad_perm:[1,0,3,2]", v);                                         \
+        if constexpr (W >= 4) AR_DPP_STEP(OPC, "quad_perm:[2,3,0,1]", v);                                         \
+        if constexpr (W >= 8) AR_DPP_STEP(OPC, "row_half_mirror", v);                                             \
+        if constexpr (W >= 16) AR_DPP_STEP(OPC, "row_mirror", v);                                                 \
+        if constexpr (W >= 32) { const T o = __shfl_xor(v, 16, kWave); v = OP(v, o); }                            \
+        if constexpr (W >= 64) { const T o = __shfl_xor(v, 32, kWave); v = OP(v, o); }                            \
+        return v;                                                                                                 \
+    }
+__device__ __forceinline__ float op_min(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float op_max(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float op_add(float a, float b) { return a + b; }
+__device__ __forceinline__ int op_imin(int a, int b) { return a < b ? a : b; }
+AR_GROUP_REDUCE(float, group_min, "v_min_f32", op_min)
+AR_GROUP_REDUCE(float, group_max, "v_max_f32", op_max)
+AR_GROUP_REDUCE(float, group_sum, "v_add_f32", op_add)
+AR_GROUP_REDUCE(int, group_imin, "v_min_i32", op_imin)
+// sum over 2 or 4 lanes in the order of the shuffle butterfly it replaces (stride 2, then 1): bit-identical sums
+template <int W> __device__ __forceinline__ float group_sum_desc(float v) {
+    static_assert(W == 1 || W == 2 || W == 4, "quad permutes only");
+    if constexpr (W >= 4) AR_DPP_STEP("v_add_f32", "quad_perm:[2,3,0,1]", v);
+    if constexpr (W >= 2) AR_DPP_STEP("v_add_f32", "quad_perm:[1,0,3,2]", v);
+    return v;
+}
+#undef AR_GROUP_REDUCE
+#undef AR_DPP_STEP
 
 // ---- per-group INT scale / zero-point (runs once per group, off the streaming path) -----------------------------
 // Mirrors auto_round/data_type/int.py:221-227 (sym) and :283-293 (asym) with the dtype choreography of

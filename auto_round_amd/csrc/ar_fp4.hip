@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kTPB) void k_fp4_fwd(const Fp4Args a0) {
                     for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(x[k]));
                 }
             }
-            if (!a.absmax) amax = lanes_max(amax, cpg);
+            if (!a.absmax) amax = group_max<cpg>(amax);
             if (!ok[u]) continue;
             const int64_t g = c / cpg;
             const float Ms = a.max_s ? clamp3(msr[u], a.lo, a.hi) : 1.0f;
@@ -414,8 +414,8 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a0) {
                     store8_f32(a.V, c * kEPT, vn);
                 }
             }
-            s_gq = lanes_sum(s_gq, cpg);
-            s_dvw = lanes_sum(s_dvw, cpg);
+            s_gq = group_sum_desc<cpg>(s_gq);
+            s_dvw = group_sum_desc<cpg>(s_dvw);
             if (ok && (c % cpg) == 0) {
                 float dMs;
                 if (a.mode == 0) {
@@ -518,9 +518,9 @@ __global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ d
 #pragma unroll
             for (int k = 0; k < 8; ++k) { gg[k] = 0.f; x[k] = 0.f; }
         }
-        const float amax = lanes_max(lmax, cpg);
+        const float amax = group_max<cpg>(lmax);
         const int my_pos = ((int)(c % cpg)) * kEPT + lk;
-        const int kstar = lanes_min_i((ok && lmax == amax) ? my_pos : 0x7fffffff, cpg);   // first index attaining the max
+        const int kstar = group_imin<cpg>((ok && lmax == amax) ? my_pos : 0x7fffffff);   // first index attaining the max
         float s_gq = 0.f, s_dvw = 0.f;
         float sc = 1.f, rsc = 1.f, m = amax, se_un = 0.f, s_pre = 0.f, r = 0.f;
         if (mode == 0) {
@@ -559,8 +559,8 @@ __global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ d
                 s_dvw += dxp * x[k];
             }
         }
-        s_gq = lanes_sum(s_gq, cpg);
-        s_dvw = lanes_sum(s_dvw, cpg);
+        s_gq = group_sum_desc<cpg>(s_gq);
+        s_dvw = group_sum_desc<cpg>(s_dvw);
         if (!ok) continue;
         float extra;
         if (mode == 0) {

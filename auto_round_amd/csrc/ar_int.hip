@@ -91,6 +91,57 @@ __global__ __launch_bounds__(kTPB) void k_group_minmax(const void* __restrict__ 
     }
 }
 
+// Lane-group form with the group width as a template parameter (DPP butterflies) and U chunks per lane in flight: U
+// independent loads issued before the first use -- the one-load-per-wave form above is latency-bound (3.5 TB/s on 2 B/element).
+template <int WDT, int CPG, int U>
+__global__ __launch_bounds__(kTPB) void k_group_minmax_lg(const void* __restrict__ W, void* __restrict__ wmin,
+                                                          void* __restrict__ wmax, float* __restrict__ absmax,
+                                                          float* __restrict__ tensor_absmax, int64_t n_groups) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t total = n_groups * CPG;                       // chunks
+    const int64_t stride = (int64_t)gridDim.x * kTPB;
+    float tmax = 0.f;
+    for (int64_t c0 = (int64_t)blockIdx.x * kTPB + threadIdx.x; c0 - threadIdx.x < total; c0 += stride * U) {
+        Raw8<WDT> r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = c0 + u * stride;
+            r[u] = load8_raw<WDT>(W, (c < total ? c : 0) * kEPT);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c = c0 + u * stride;
+            float v[8];
+            unpack8<WDT>(r[u], v);
+            float lo = v[0], hi = v[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) { lo = __builtin_fminf(lo, v[k]); hi = __builtin_fmaxf(hi, v[k]); }
+            if (c >= total) { lo = INFINITY; hi = -INFINITY; }
+            lo = group_min<CPG>(lo);
+            hi = group_max<CPG>(hi);
+            if (c < total && (lane & (CPG - 1)) == 0) {
+                const int64_t g = c / CPG;
+                if (wmin) store1<WDT>(wmin, g, lo > 0.f ? 0.f : lo);   // torch.clamp(max=0): a -0.0 extremum stays -0.0
+                if (wmax) store1<WDT>(wmax, g, hi < 0.f ? 0.f : hi);
+                const float am = fmaxf(-lo, hi);
+                if (absmax) absmax[g] = am;
+                tmax = fmaxf(tmax, am);
+            }
+        }
+    }
+    if (tensor_absmax) {    // wave -> workgroup -> ONE atomic per workgroup (the grid is capped for this case on the host)
+        __shared__ float wmaxs[kTPB / kWave];
+        tmax = lanes_max(tmax, kWave);
+        if (lane == 0) wmaxs[threadIdx.x / kWave] = tmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = wmaxs[0];
+            for (int w = 1; w < kTPB / kWave; ++w) m = fmaxf(m, wmaxs[w]);
+            if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(tensor_absmax), __float_as_uint(m));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
@@ -715,12 +766,48 @@ static inline bool fill_cfg(IntCfg& c, float& qlo, float& qhi, int bits, int sym
 
 using namespace ar;
 
+// lane groups (power-of-two chunks per group up to a wave): the templated kernel, four loads per lane in flight
+template <int WDT>
+static bool launch_minmax_lg(const void* W, void* wmin, void* wmax, float* absmax, float* tensor_absmax, int64_t n_groups, int cpg,
+                             hipStream_t st) {
+    constexpr int U = 4;
+    const int64_t chunks = n_groups * cpg;
+    int64_t blocks = (chunks + (int64_t)kTPB * U - 1) / ((int64_t)kTPB * U);
+    if (blocks < 1) blocks = 1;
+    if (tensor_absmax && blocks > 256 * 8) blocks = 256 * 8;    // grid-stride: at most 2048 atomics on the global max
+    if (blocks > (1 << 22)) blocks = 1 << 22;
+    const int grid = (int)blocks;
+#define AR_MM(C) hipLaunchKernelGGL((k_group_minmax_lg<WDT, C, U>), grid, kTPB, 0, st, W, wmin, wmax, absmax, tensor_absmax, n_groups)
+    switch (cpg) {
+        case 1: AR_MM(1); break;
+        case 2: AR_MM(2); break;
+        case 4: AR_MM(4); break;
+        case 8: AR_MM(8); break;
+        case 16: AR_MM(16); break;
+        case 32: AR_MM(32); break;
+        case 64: AR_MM(64); break;
+        default: return false;
+    }
+#undef AR_MM
+    return true;
+}
+static bool launch_minmax_lg(const void* W, void* wmin, void* wmax, float* absmax, float* tensor_absmax, int64_t n_groups, int cpg,
+                             int w_dt, hipStream_t st) {
+    switch (w_dt) {
+        case AR_DT_BF16: return launch_minmax_lg<AR_DT_BF16>(W, wmin, wmax, absmax, tensor_absmax, n_groups, cpg, st);
+        case AR_DT_F16: return launch_minmax_lg<AR_DT_F16>(W, wmin, wmax, absmax, tensor_absmax, n_groups, cpg, st);
+        case AR_DT_F32: return launch_minmax_lg<AR_DT_F32>(W, wmin, wmax, absmax, tensor_absmax, n_groups, cpg, st);
+        default: return false;
+    }
+}
+
 extern "C" int ar_group_minmax(const void* W, void* wmin, void* wmax, int64_t n_groups, int gs, int w_dt,
                                ar_stream_t stream) {
     if (gs <= 0 || gs % kEPT || n_groups < 0) return AR_ERR_UNSUPPORTED;
     if (n_groups == 0) return AR_OK;
     const int cpg = gs / kEPT;
     const bool lane_groups = cpg <= kWave && ilog2_exact(cpg) >= 0;
+    if (lane_groups && launch_minmax_lg(W, wmin, wmax, nullptr, nullptr, n_groups, cpg, w_dt, (hipStream_t)stream)) return launch_status();
     const int64_t waves = lane_groups ? (n_groups + (kWave / cpg) - 1) / (kWave / cpg) : n_groups;
     const int grid = grid_for_tiles((waves + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
@@ -739,6 +826,7 @@ extern "C" int ar_group_absmax(const void* W, float* absmax, float* tensor_absma
     if (n_groups == 0) return AR_OK;
     const int cpg = gs / kEPT;
     const bool lane_groups = cpg <= kWave && ilog2_exact(cpg) >= 0;
+    if (lane_groups && launch_minmax_lg(W, nullptr, nullptr, absmax, tensor_absmax, n_groups, cpg, w_dt, (hipStream_t)stream)) return launch_status();
     const int64_t waves = lane_groups ? (n_groups + (kWave / cpg) - 1) / (kWave / cpg) : n_groups;
     int grid = grid_for_tiles((waves + 3) / 4);
     if (tensor_absmax && grid > 256 * 8) grid = 256 * 8;   // grid-stride: at most 2048 atomics on the global max

@@ -67,8 +67,9 @@ def main():
         res[f"{name}fp4_act_fwd_GBps"] = 4 * n / t / 1e6
         t = timeit(lambda: ops.fp4_act_bwd(dWq, W, mode=mode, gs=fgs, global_scale=gsc, out=Wq))
         res[f"{name}fp4_act_bwd_GBps"] = 6 * n / t / 1e6
-    # dynamic symmetric int8 activation fake-quant: group 32 / 128 (lane groups) and per-token 4096 (wave per group)
-    for ags in (32, 128, 4096):
+    # dynamic symmetric int8 activation fake-quant: group 32 / 128 (lane groups) and per-token 4096 / 14336 (a wave / a
+    # workgroup per group, the group parked in LDS); n = 218,103,808 is a multiple of all four
+    for ags in (32, 128, 4096, 14336):
         t = timeit(lambda: ops.qdq_int_act_fwd(W, gs=ags, bits=8, out=Wq))
         res[f"int8_act_g{ags}_fwd_GBps"] = 4 * n / t / 1e6
         t = timeit(lambda: ops.int_act_bwd(dWq, W, gs=ags, bits=8, out=Wq))
