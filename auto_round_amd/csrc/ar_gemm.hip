@@ -706,6 +706,229 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     }
 }
 
+// ---- v4: four waves, one per SIMD, 128 x 128 per wave; operands staged through registers -------------------------------------
+// What v3 taught (profiles/r02_gemm_dw_ablation.jsonl, r02_gemm_dw_pmc.json): with eight waves the fragment reads move 6 KB of LDS
+// per wave and K-step of 16 for 64x128 of output, and every LDS-DMA piece issued among the MFMAs stalls its wave for 60-185 issue
+// cycles -- the no-DMA ablation ran 15-20 % faster.  hipBLASLt's NT kernels (forward GEMMs, 1.5 PFLOP/s here) use the other
+// classical shape: 4 waves x (128 x 128), i.e. 8 KB of fragments per K-step for twice the output, 256 accumulator registers per
+// lane (the unified 512-entry file makes that one wave per SIMD), and plain global loads into registers followed by ds_write.
+// v4 is that shape for the TN problem: same [k][256] swizzled LDS image and transposing fragment reads as v0-v3; a K-unit of 16 per
+// phase = 16 MFMAs (512 matrix-pipe cycles) that shadow the 16 fragment reads of the next unit, the 4 ds_write_b128 of unit +3
+// and the 4 global_load_dwordx4 of unit +3+L (L units = 16*L registers of loads in flight); one s_barrier every second phase.
+// Result (profiles/r02_gemm_dw_v4_vs_v3.jsonl): bit-identical output, 1.19-1.33 PFLOP/s against v3's 1.23-1.36 on the same shapes,
+// so v3 stays the default and v4 is reachable only through ar_gemm_dw_config(18 | 19) for tools/gemm_dw_probe.py.  Its timing
+// ablations (r02_gemm_dw_v4_ablation.json) are the useful part: MFMAs + barriers alone 1.6-2.0 PFLOP/s (the matrix pipe at the
+// clock the chip sustains), without the LDS stores 1.45-1.55, without the loads 1.22-1.36, without the fragment reads 1.25-1.7 --
+// with one wave per SIMD every cycle another instruction holds the issue port beyond an MFMA's 32 is lost, and the VGPR->LDS
+// store path (13 cycles per ds_write_b128, shared by a SIMD pair) is the largest such item; v3's second wave per SIMD hides it.
+template <int L, bool SPLITK>
+__global__ __launch_bounds__(256, 1) void k_gemm_dw5(GemmArgs a) {
+    static_assert(8 % L == 0, "the load ring must divide the unroll of 8 phases");
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    int tm, tn, sp = 0;
+    int64_t krow0 = 0;
+    int U = a.K / GU;                              // K % 128 == 0 (host)
+    if (SPLITK) {
+        sp = blockIdx.x % a.nsplit;
+        const int tile = blockIdx.x / a.nsplit;
+        tm = tile / a.tiles_n;
+        tn = tile % a.tiles_n;
+        const int chunks = a.K / 128;
+        const int c0 = (int)((int64_t)chunks * sp / a.nsplit), c1 = (int)((int64_t)chunks * (sp + 1) / a.nsplit);
+        krow0 = (int64_t)c0 * 128;
+        U = (c1 - c0) * 8;
+    } else {
+        tile_of_block(a, blockIdx.x, tm, tn);
+    }
+    const int64_t m0 = (int64_t)tm * GB, n0 = (int64_t)tn * GB;
+
+    // ---- staging: this wave moves k-rows 4w .. 4w+3 of each operand's piece, two rows per 16-byte-per-lane instruction
+    const uint16_t* srcP[2];
+    const uint16_t* srcQ[2];
+    int dstoff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 4 * wave + 2 * j + (lane >> 5);
+        const int pchunk = lane & 31;
+        const int lchunk = pchunk ^ ((r & 3) << 2);
+        srcP[j] = a.X + (krow0 + r) * a.ldx + n0 + lchunk * 8;
+        srcQ[j] = a.Y + (krow0 + r) * a.ldy + m0 + lchunk * 8;
+        dstoff[j] = r * ROWB + pchunk * 16;
+    }
+    const int64_t stepP = (int64_t)GU * a.ldx, stepQ = (int64_t)GU * a.ldy;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+
+    // ---- fragment read addresses (ds_read_b64_tr_b16: lane i of a 16-lane group supplies k-row i>>2, 8-byte piece i&3)
+    const int q = lane >> 4, i = lane & 15, g = q >> 1;
+    const int rowsel = i >> 2, piece = i & 3;
+    const int rowoff = (8 * g + rowsel) * ROWB + (piece & 1) * 8;
+    uint32_t aP[2][4], aQ[2][4];                   // [64 KB half of the ring][tile]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int cp = wn * 16 + t * 4 + (q & 1) * 2 + (piece >> 1);
+        const int cq = wm * 16 + t * 4 + (q & 1) * 2 + (piece >> 1);
+        aP[0][t] = lds0 + rowoff + ((cp ^ (rowsel << 2)) << 4);
+        aQ[0][t] = lds0 + PIECE + rowoff + ((cq ^ (rowsel << 2)) << 4);
+        aP[1][t] = aP[0][t] + 65536;
+        aQ[1][t] = aQ[0][t] + 65536;
+    }
+
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    struct Frag { s16x4_t plo[4], phi[4], qlo[4], qhi[4]; };
+    Frag F[2];
+    u32x4_t G[L][4];                                 // loads in flight: [unit % L][P rows j=0,1 | Q rows j=0,1]; constant indices only
+    int vnext = 0;                                 // next unit to load
+#define AR_LOAD_UNIT(GS)                                                                                                \
+    do {                                                                                                                \
+        G[GS][0] = *reinterpret_cast<const u32x4_t*>(srcP[0]);                                                            \
+        G[GS][1] = *reinterpret_cast<const u32x4_t*>(srcP[1]);                                                            \
+        G[GS][2] = *reinterpret_cast<const u32x4_t*>(srcQ[0]);                                                            \
+        G[GS][3] = *reinterpret_cast<const u32x4_t*>(srcQ[1]);                                                            \
+        ++vnext;                                                                                                        \
+        const bool more = vnext < U;       /* past the end the pointers stay on the last unit (staged again, never read) */ \
+        srcP[0] += more ? stepP : 0; srcP[1] += more ? stepP : 0;                                                       \
+        srcQ[0] += more ? stepQ : 0; srcQ[1] += more ? stepQ : 0;                                                       \
+    } while (0)
+#define AR_STORE_UNIT(SL, GS)                                                                                           \
+    do {                                                                                                                \
+        uint8_t* base_ = lds + (SL) * UNIT;                                                                             \
+        *reinterpret_cast<u32x4_t*>(base_ + dstoff[0]) = G[GS][0];                                                        \
+        *reinterpret_cast<u32x4_t*>(base_ + dstoff[1]) = G[GS][1];                                                        \
+        *reinterpret_cast<u32x4_t*>(base_ + PIECE + dstoff[0]) = G[GS][2];                                                \
+        *reinterpret_cast<u32x4_t*>(base_ + PIECE + dstoff[1]) = G[GS][3];                                                \
+    } while (0)
+#define AR_RD5(LO, HI, ADDR, OFF)                                                                                       \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                           \
+                 : "=&v"(LO), "=&v"(HI)                                                                                 \
+                 : "v"(ADDR), "n"(OFF), "n"((OFF) + 4 * ROWB)                                                            \
+                 : "memory")
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    auto cat = [](const s16x4_t& lo, const s16x4_t& hi) -> bf16x8_t {
+        return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+#define AR_PIN5() __builtin_amdgcn_sched_barrier(0)
+#define AR_MMA5(FB, MI, NI)                                                                                             \
+    acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat(F[FB].plo[NI], F[FB].phi[NI]), cat(F[FB].qlo[MI], F[FB].qhi[MI]), \
+                                                          acc[MI][NI], 0, 0, 0)
+    // fragment reads of the unit in ring slot SL into F[NB], tile T of P / of Q
+#define AR_RDP(NB, SL, T) AR_RD5(F[NB].plo[T], F[NB].phi[T], aP[(SL) >> 2][T], ((SL) & 3) * UNIT)
+#define AR_RDQ(NB, SL, T) AR_RD5(F[NB].qlo[T], F[NB].qhi[T], aQ[(SL) >> 2][T], ((SL) & 3) * UNIT)
+    // one phase: S = unit index mod 8 (compile time).  MFMAs of unit S from F[S&1]; reads of unit S+1; stores of unit S+3; loads of
+    // unit S+3+L.  The stores sit late in the phase: their loads were issued L phases ago.
+#define AR_ST1(SL, GS, J) *reinterpret_cast<u32x4_t*>(lds + (SL) * UNIT + ((J) >> 1) * PIECE + dstoff[(J) & 1]) = G[GS][J]
+#define AR_LD1P(GS, J) G[GS][J] = *reinterpret_cast<const u32x4_t*>(srcP[J])
+#define AR_LD1Q(GS, J) G[GS][2 + (J)] = *reinterpret_cast<const u32x4_t*>(srcQ[J])
+#define AR_ADVANCE()                                                                                                    \
+    do {                                                                                                                \
+        ++vnext;                                                                                                        \
+        const bool more = vnext < U;                                                                                    \
+        srcP[0] += more ? stepP : 0; srcP[1] += more ? stepP : 0;                                                       \
+        srcQ[0] += more ? stepQ : 0; srcQ[1] += more ? stepQ : 0;                                                       \
+    } while (0)
+    // every MFMA is followed by at most ~25 issue cycles of other work (the matrix pipe is busy 32): three fragment reads, or two
+    // and a store, or one load -- a single wave per SIMD has nobody to cover a longer gap
+    // The stores sit in the second half of the phase, between the loads: measured best of the placements tried (stores first:
+    // -12 %; the two waves of a store-path half in opposite halves of the phase: the duplicated loop body halved the rate).
+#define AR_PHASE5(S, EARLY)                                                                                             \
+    do {                                                                                                                \
+        constexpr int FB = (S) & 1, NB = FB ^ 1, SR = ((S) + 1) & 7, SW = ((S) + 3) & 7, GS = ((S) + 3) % L;             \
+        AR_MMA5(FB, 0, 0); AR_PIN5(); AR_RDQ(NB, SR, 0); if (EARLY) AR_ST1(SW, GS, 0); AR_PIN5();                        \
+        AR_MMA5(FB, 0, 1); AR_PIN5(); AR_RDP(NB, SR, 0); AR_PIN5();                                                      \
+        AR_MMA5(FB, 0, 2); AR_PIN5(); AR_RDP(NB, SR, 1); if (EARLY) AR_ST1(SW, GS, 1); AR_PIN5();                        \
+        AR_MMA5(FB, 0, 3); AR_PIN5(); AR_RDQ(NB, SR, 1); AR_PIN5();                                                      \
+        AR_MMA5(FB, 1, 0); AR_PIN5(); AR_RDP(NB, SR, 2); if (EARLY) AR_ST1(SW, GS, 2); AR_PIN5();                        \
+        AR_MMA5(FB, 1, 1); AR_PIN5(); AR_RDP(NB, SR, 3); AR_PIN5();                                                      \
+        AR_MMA5(FB, 1, 2); AR_PIN5(); AR_RDQ(NB, SR, 2); if (EARLY) AR_ST1(SW, GS, 3); AR_PIN5();                        \
+        AR_MMA5(FB, 1, 3); AR_PIN5(); AR_RDQ(NB, SR, 3); AR_PIN5();                                                      \
+        AR_MMA5(FB, 2, 0); AR_PIN5(); if (!(EARLY)) AR_ST1(SW, GS, 0); AR_PIN5();                                        \
+        AR_MMA5(FB, 2, 1); AR_PIN5(); AR_LD1P(GS, 0); AR_PIN5();                                                         \
+        AR_MMA5(FB, 2, 2); AR_PIN5(); if (!(EARLY)) AR_ST1(SW, GS, 1); AR_PIN5();                                        \
+        AR_MMA5(FB, 2, 3); AR_PIN5(); AR_LD1P(GS, 1); AR_PIN5();                                                         \
+        AR_MMA5(FB, 3, 0); AR_PIN5(); if (!(EARLY)) AR_ST1(SW, GS, 2); AR_PIN5();                                        \
+        AR_MMA5(FB, 3, 1); AR_PIN5(); AR_LD1Q(GS, 0); AR_PIN5();                                                         \
+        AR_MMA5(FB, 3, 2); AR_PIN5(); if (!(EARLY)) AR_ST1(SW, GS, 3); AR_PIN5();                                        \
+        AR_MMA5(FB, 3, 3); AR_PIN5(); AR_LD1Q(GS, 1); AR_ADVANCE(); AR_PIN5();                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+        if (((S) & 1) == 1) { AR_PIN5(); __builtin_amdgcn_s_barrier(); AR_PIN5(); }                                      \
+    } while (0)
+
+    // ---- prologue: units 0..2 into LDS, units 3..3+L-1 in flight, fragments of unit 0 in F[0]
+    AR_LOAD_UNIT(0); AR_STORE_UNIT(0, 0);
+    AR_LOAD_UNIT(1); AR_STORE_UNIT(1, 1);
+    AR_LOAD_UNIT(2); AR_STORE_UNIT(2, 2);
+    AR_LOAD_UNIT(3 % L); AR_LOAD_UNIT(4 % L); AR_LOAD_UNIT(5 % L); AR_LOAD_UNIT(6 % L);
+    if constexpr (L == 8) { AR_LOAD_UNIT(7); AR_LOAD_UNIT(0); AR_LOAD_UNIT(1); AR_LOAD_UNIT(2); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AR_PIN5(); __builtin_amdgcn_s_barrier(); AR_PIN5();
+    AR_RDQ(0, 0, 0); AR_RDQ(0, 0, 1); AR_RDQ(0, 0, 2); AR_RDQ(0, 0, 3);
+    AR_RDP(0, 0, 0); AR_RDP(0, 0, 1); AR_RDP(0, 0, 2); AR_RDP(0, 0, 3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int u = 0; u < U; u += 8) {
+        AR_PHASE5(0, false); AR_PHASE5(1, false); AR_PHASE5(2, false); AR_PHASE5(3, false);
+        AR_PHASE5(4, false); AR_PHASE5(5, false); AR_PHASE5(6, false); AR_PHASE5(7, false);
+    }
+#undef AR_PHASE5
+#undef AR_RDP
+#undef AR_RDQ
+#undef AR_MMA5
+#undef AR_PIN5
+#undef AR_RD5
+#undef AR_LOAD_UNIT
+#undef AR_STORE_UNIT
+#undef AR_ST1
+#undef AR_LD1P
+#undef AR_LD1Q
+#undef AR_ADVANCE
+
+    const int h = lane >> 5;
+    if (SPLITK) {
+        float* wsp = a.ws + (int64_t)sp * a.M * a.N;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int64_t m = m0 + wm * 128 + mi * 32 + (lane & 31);
+            float* rowp = wsp + m * a.N + n0 + wn * 128 + 4 * h;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    st16f(rowp + ni * 32 + 8 * t, make_float4(acc[mi][ni][4 * t + 0], acc[mi][ni][4 * t + 1], acc[mi][ni][4 * t + 2],
+                                                              acc[mi][ni][4 * t + 3]));
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m0 + wm * 128 + mi * 32 + (lane & 31);
+        uint16_t* rowp = a.W + m * a.ldw + n0 + wn * 128 + 4 * h;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint16_t* p = rowp + ni * 32 + 8 * t;
+                float v0 = acc[mi][ni][4 * t + 0], v1 = acc[mi][ni][4 * t + 1], v2 = acc[mi][ni][4 * t + 2], v3 = acc[mi][ni][4 * t + 3];
+                if (a.accumulate) {
+                    const uint2 old = *reinterpret_cast<const uint2*>(p);
+                    v0 += bf16_lo(old.x); v1 += bf16_hi(old.x); v2 += bf16_lo(old.y); v3 += bf16_hi(old.y);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(p) = o;
+            }
+        }
+    }
+}
+
 // sum of the split-K slices in slice order (+ the previous bf16 value when accumulating), one rounding to bf16
 __global__ __launch_bounds__(kTPB) void k_splitk_reduce(const float* __restrict__ ws, int nsplit, int64_t M, int64_t N, uint16_t* __restrict__ W,
                                                          int64_t ldw, int accumulate) {
@@ -740,7 +963,7 @@ using namespace ar;
 
 extern "C" int ar_gemm_dw_config(int sem, int order) {      // experiment knobs (tools/gemm_dw_probe.py); -1 keeps a value
     if (sem == 1 || sem == 2) g_gemm_sem = sem;                 // v0 only: lane->piece rule (2 = negative control)
-    if (sem >= 10 && sem <= 17) g_gemm_kernel = sem - 10;       // 10: v0, 11: v1 staggered, 12: v1 lockstep, 13: v2 staggered
+    if (sem >= 10 && sem <= 19) g_gemm_kernel = sem - 10;       // ..., 17: v3, 18: v4 (4 loads units in flight), 19: v4 (8)       // 10: v0, 11: v1 staggered, 12: v1 lockstep, 13: v2 staggered
     if (order >= 0 && order <= 2) g_gemm_order = order;
     return g_gemm_kernel * 100 + g_gemm_sem * 10 + g_gemm_order;
 }
@@ -780,6 +1003,17 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_dw2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
+    }
+    if (g_gemm_kernel >= 8 && K % 128 == 0 && K >= 128) {
+        static bool a5 = false;
+        if (!a5) {
+            (void)hipFuncSetAttribute((const void*)k_gemm_dw5<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+            (void)hipFuncSetAttribute((const void*)k_gemm_dw5<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+            a5 = true;
+        }
+        if (g_gemm_kernel == 8) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw5<4, false>), grid, 256, GEMM_LDS, st, a);
+        else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw5<8, false>), grid, 256, GEMM_LDS, st, a);
+        return launch_status();
     }
     if (g_gemm_kernel >= 1 && K % 128 == 0 && K >= 128) {
         if (g_gemm_kernel == 7) {

@@ -51,7 +51,7 @@ def main():
         exact = (out == ref.to(torch.bfloat16)).float().mean().item()
         print(json.dumps({"check": "small", "sem": sem, "took_kernel": ok, "max_abs_err": err, "frac_equal_to_rounded_fp32": exact}), flush=True)
     lib.ar_gemm_dw_config(1, 2)
-    KERNELS = {"v0": 10, "v1_staggered": 11, "v1_lockstep": 12, "v3": 17}
+    KERNELS = {"v0": 10, "v1_staggered": 11, "v1_lockstep": 12, "v3": 17, "v4_l4": 18, "v4_l8": 19}
     ABLATIONS = {"abl_no_dma": 14, "abl_no_dma_no_reads": 15, "abl_mfma_only": 16}
     # accumulate + strided operands (column slices of wider buffers), multi-tile, all tile orders, every kernel
     for kname, code in list(KERNELS.items()):
