@@ -59,7 +59,7 @@ WORKLOADS = {
                             desc="Mixtral-8x7B decoder block as transformers builds it (MixtralDecoderLayer; fused 3-D expert "
                                  "parameters unfused by auto_round_amd.moe_unfuse; BASELINE.json configs[4])"),
 }
-SCHEMES = ("W4A16", "W2A16G32", "MXFP4", "NVFP4", "MXFP4_W", "NVFP4_W")
+SCHEMES = ("W4A16", "W2A16G32", "MXFP4", "NVFP4", "MXFP4_W", "NVFP4_W", "INT8", "INT4")     # INT8 / INT4: per-row weights, per-token activations
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -319,7 +319,10 @@ class Bench:
         """Live K1 / K2 figures from the device-side events recorded during the timed region."""
         from auto_round_amd import ops
 
-        n_w, G, w = self.n_w, self.n_w // self.gs, self.w
+        n_w, w = self.n_w, self.w
+        # groups per block: per-row presets (group_size -1: INT8 / INT4) have one group per output row
+        G = sum(m.weight.numel() // (int(m.group_size) if int(m.group_size) > 0 else m.weight.shape[-1])
+                for m in self.layer.modules() if isinstance(m, torch.nn.Linear) and getattr(m, "bits", 16) < 16) or 1
         out = {}
         nv = self.fp4 and self.scheme.startswith("NVFP4")
         launches_per_pass = (4 + 3 * w.get("experts", 0) if w["family"] in ("moe", "moe_hf") else 7) if nv else 1
@@ -446,7 +449,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        w, n_w, G, N, S = b.w, b.n_w, b.n_w // b.gs, b.N, b.S
+        w, n_w, G, N, S = b.w, b.n_w, (b.n_w // b.gs if b.gs > 0 else b.n_w // b.H), b.N, b.S
         default_cfg = (args.scheme is None and b.bits == 4 and b.gs == 128 and b.sym and args.iters == 200
                        and N == 128 and S == 2048)
         # the description names the BASELINE config only when the run really is that config
