@@ -526,7 +526,10 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw2_abl(GemmArgs a) {
 // SPLITK: few output tiles but a deep K (OPT-125M's 768x768 weight against 16384 tokens is 9 tiles): the grid is tiles x nsplit,
 // every workgroup reduces its own K slice (a whole number of 128-row chunks) into an fp32 partial tile in caller-owned scratch,
 // and k_splitk_reduce sums the slices in slice order (deterministic: no float atomics) into the bf16 result.
-template <bool STAGGER, bool SPLITK = false>
+// TAIL: K is not a multiple of 128 (an expert's share of the tokens in a MoE block): the last 128-row chunk is completed with
+// zeros -- every lane of the LDS-DMA supplies its own source address, so rows past K simply read a 512-byte row of zeros.
+__device__ __attribute__((aligned(512))) uint16_t g_zero_row[256];
+template <bool STAGGER, bool SPLITK = false, bool TAIL = false>
 __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -535,13 +538,13 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     int tm, tn;
     int sp = 0;
     int64_t krow0 = 0;
-    int U = a.K / GU;                              // k16 units; K % 128 == 0 (checked by the host)
+    int U = (a.K + 127) / 128 * 8;                 // k16 units, whole 128-row chunks (without TAIL the host guarantees K % 128 == 0)
     if (SPLITK) {
         sp = blockIdx.x % a.nsplit;
         const int tile = blockIdx.x / a.nsplit;
         tm = tile / a.tiles_n;
         tn = tile % a.tiles_n;
-        const int chunks = a.K / 128;
+        const int chunks = (a.K + 127) / 128;
         const int c0 = (int)((int64_t)chunks * sp / a.nsplit), c1 = (int)((int64_t)chunks * (sp + 1) / a.nsplit);
         krow0 = (int64_t)c0 * 128;
         U = (c1 - c0) * 8;
@@ -557,6 +560,8 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     const int64_t stepP = (int64_t)GU * a.ldx, stepQ = (int64_t)GU * a.ldy;     // elements per unit
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
     const uint32_t dmabase = lds0 + 2 * wave * ROWB;                            // wave-uniform
+    const uint16_t* zsrc = g_zero_row + (lane & 31) * 8;                        // TAIL: this lane's 16 bytes of a zero row
+    int64_t vrow = krow0 + drow;                                                // TAIL: absolute k-row of the next unit's piece
 
     const int q = lane >> 4, i = lane & 15, g = q >> 1;
     const int rowsel = i >> 2, piece = i & 3;                                     // hardware rule of ds_read_b64_tr_b16
@@ -585,9 +590,11 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
 
     int vnext = 0;                                 // next unit to stage
     auto issue_unit = [&](int slot_unit) {         // slot_unit: 0..7 compile-time after unrolling
-        __builtin_amdgcn_global_load_lds((const void*)srcP, (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void*)srcQ, (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
+        const bool real = !TAIL || vrow < a.K;
+        __builtin_amdgcn_global_load_lds((const void*)(real ? srcP : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(real ? srcQ : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
         ++vnext;
+        vrow += GU;
         const bool more = vnext < U;               // past the end the pointers stay on the last unit (staged again, never read)
         srcP += more ? stepP : 0;
         srcQ += more ? stepQ : 0;
@@ -610,11 +617,14 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     Pair f;
     // one phase on pair slot S (0..3): L part then M part
     auto issue_p = [&](int slot_unit) {
-        __builtin_amdgcn_global_load_lds((const void*)srcP, (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
+        const bool real = !TAIL || vrow < a.K;
+        __builtin_amdgcn_global_load_lds((const void*)(real ? srcP : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
     };
     auto issue_q = [&](int slot_unit) {
-        __builtin_amdgcn_global_load_lds((const void*)srcQ, (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
+        const bool real = !TAIL || vrow < a.K;
+        __builtin_amdgcn_global_load_lds((const void*)(real ? srcQ : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
         ++vnext;
+        vrow += GU;
         const bool more = vnext < U;
         srcP += more ? stepP : 0;
         srcQ += more ? stepQ : 0;
@@ -970,7 +980,7 @@ extern "C" int ar_gemm_dw_config(int sem, int order) {      // experiment knobs 
 
 // split-K plan: only when the 256x256 tiles cannot fill the 256 CUs once and K is deep enough for slices of >= 512 rows
 static int splitk_plan(int64_t M, int64_t N, int64_t K) {
-    if (M % GB || N % GB || K % 128) return 1;
+    if (M % GB || N % GB) return 1;
     const int64_t tiles = (M / GB) * (N / GB);
     if (tiles >= 192 || K < 1024) return 1;
     int64_t ns = (256 + tiles - 1) / tiles;
@@ -986,7 +996,8 @@ extern "C" int64_t ar_gemm_dw_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
                           int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, ar_stream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return AR_OK;
-    if (M % GB || N % GB || K % (2 * GU) || K < GD * GU || (ldy % 8) || (ldx % 8) || (ldw % 4)) return AR_ERR_UNSUPPORTED;
+    if (M % GB || N % GB || K < GD * GU || (ldy % 8) || (ldx % 8) || (ldw % 4)) return AR_ERR_UNSUPPORTED;
+    if (K % 128 && g_gemm_kernel != 7) return AR_ERR_UNSUPPORTED;       // only the default kernel completes a ragged K with zeros
     if (((uintptr_t)dY | (uintptr_t)X) & 15 || ((uintptr_t)dW & 7)) return AR_ERR_UNSUPPORTED;
     GemmArgs a;
     a.ws = nullptr; a.nsplit = 1;
@@ -1015,23 +1026,27 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
         else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw5<8, false>), grid, 256, GEMM_LDS, st, a);
         return launch_status();
     }
-    if (g_gemm_kernel >= 1 && K % 128 == 0 && K >= 128) {
+    if (g_gemm_kernel >= 1 && (K % 128 == 0 || g_gemm_kernel == 7) && K >= 128) {
         if (g_gemm_kernel == 7) {
             static bool a4 = false;
             if (!a4) {
                 (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
                 (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+                (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+                (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
                 a4 = true;
             }
             const int ns = splitk_plan(M, N, K);
             if (ns > 1 && workspace && workspace_bytes >= (int64_t)ns * M * N * 4 && (ldw % 8) == 0 && !((uintptr_t)dW & 15)) {
                 a.ws = (float*)workspace; a.nsplit = ns;
-                AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, true>), grid * ns, GTHREADS, GEMM_LDS, st, a);
+                if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, true, true>), grid * ns, GTHREADS, GEMM_LDS, st, a);
+                else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, true>), grid * ns, GTHREADS, GEMM_LDS, st, a);
                 const int rgrid = (int)((M * (N / kEPT) + kTPB - 1) / kTPB);
                 hipLaunchKernelGGL(k_splitk_reduce, rgrid, kTPB, 0, st, a.ws, ns, M, N, a.W, ldw, accumulate);
                 return launch_status();
             }
-            AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true>), grid, GTHREADS, GEMM_LDS, st, a);
+            if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, true>), grid, GTHREADS, GEMM_LDS, st, a);
+            else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true>), grid, GTHREADS, GEMM_LDS, st, a);
             return launch_status();
         }
         if (g_gemm_kernel >= 4) {      // timing ablations (tools/gemm_dw_probe.py --ablate); outputs are not a product

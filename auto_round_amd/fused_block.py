@@ -307,8 +307,9 @@ class FusedLlamaBlock:
 def mfma_dw_pays(M: int, N: int, K: int) -> bool:
     """Where the hand-written weight-gradient GEMM beats hipBLASLt on MI355X (tools/gemm_dw_probe.py, profiles/r02_gemm_dw_*):
     256x256 tiles that fill the 256 CUs at least once, deep K."""
-    # (few tiles x deep K go through the kernel's deterministic split-K form: OPT-125M's 768x768 / 3072x768 weights, k/v projections)
-    return M % 256 == 0 and N % 256 == 0 and K % 128 == 0 and K >= 2048
+    # (few tiles x deep K go through the kernel's deterministic split-K form: OPT-125M's 768x768 / 3072x768 weights, k/v projections;
+    #  a K that is not a multiple of 128 -- an expert's share of the tokens -- is completed with zero rows inside the kernel)
+    return M % 256 == 0 and N % 256 == 0 and K >= 2048
 
 
 class _FusedBlockFn(torch.autograd.Function):

@@ -90,9 +90,9 @@ def build_block(w, bits, gs, sym, device, seed, attn="sdpa", scheme=None):
         with torch.device(device):
             layer = MixtralDecoderLayer(cfg, 0).to(torch.bfloat16)
             rope = MixtralRotaryEmbedding(cfg)
-        for p in layer.parameters():                        # torch.empty expert parameters: give them a weight-like scale
-            if p.dim() == 3:
-                p.data.normal_(0.0, 0.02)
+        for n, p in layer.named_parameters():               # torch.empty parameters (fused experts, router): weight-like values.
+            if p.dim() == 3 or (p.dim() == 2 and p.shape[0] == w["experts"]):   # an all-zero router would send every token to
+                p.data.normal_(0.0, 0.02)                                      # experts 0 and 1; a random one spreads them
         layer.eval()
         for p in layer.parameters():
             p.requires_grad_(False)

@@ -258,7 +258,7 @@ int ar_rope_bwd(const void* dq, const void* dk, const void* dv, const void* cos,
  * replaces: the autograd backward of F.linear(x, weight_q) with respect to weight_q inside WrapperLinear.forward
  *           (auto_round/wrapper.py:528-556): dW[M,N] = dY^T X, dY [K,M] and X [K,N] row-major bf16 (leading dimensions in
  *           elements), fp32 accumulation, one rounding to bf16; accumulate != 0 adds the previous bf16 dW before rounding
- *           (torch addmm_, the gradient-accumulation case).  M, N multiples of 256, K a multiple of 32 and >= 96; operands
+ *           (torch addmm_, the gradient-accumulation case).  M, N multiples of 256, K >= 96 (a K that is not a multiple of 128 is completed with zero rows); operands
  *           16-byte aligned, ldy/ldx multiples of 8, ldw a multiple of 4; anything else returns AR_ERR_UNSUPPORTED and the
  *           caller keeps the library GEMM.  Needs 128 KB of dynamic LDS per workgroup. */
 int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,

@@ -111,7 +111,8 @@ def test_rope_fwd_bwd_vs_transformers(hq, hkv, d, batched_cos):
     assert (dqkv.float() - gx).abs().mean().item() < 4e-3 * gx.abs().mean().item()
 
 
-@pytest.mark.parametrize("K,M,N", [(128, 256, 256), (256, 512, 256), (1024, 256, 768)])
+@pytest.mark.parametrize("K,M,N", [(128, 256, 256), (256, 512, 256), (1024, 256, 768), (1000, 256, 256), (4100, 512, 256),
+                                   (2057, 2048, 2048)])       # ragged K: completed with zero rows (MoE experts); with and without split-K
 def test_gemm_dw_vs_fp32_reference_including_strides_and_accumulation(K, M, N):
     from auto_round_amd import ops
 
