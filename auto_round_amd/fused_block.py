@@ -194,6 +194,13 @@ class FusedLlamaBlock:
 
         import contextlib
 
+        if mask is None and S > 1 and getattr(self, "flash_fwd", True):
+            # hand-written causal flash-attention forward (csrc/ar_attn.hip; head size 128, S % 128 == 0); it returns the rows'
+            # log-sum-exp in the form the library's attention backward consumes, so the backward stays torch's
+            res = ops.attn_fwd(q2d, k2d, v2d, B, S, hq, hd, scale=self.scaling)
+            if res is not None:
+                out2d, lse = res
+                return heads(out2d), (("flash", q2d, k2d, v2d, out2d, lse) if grad else None)
         ctx = self.sdpa_ctx() if self.sdpa_ctx is not None else contextlib.nullcontext()
         if mask is not None and mask.dim() == 4:
             mask = mask[:, :, :, :S]
@@ -293,7 +300,15 @@ class FusedLlamaBlock:
         dattn = torch.mm(dx2, self.Wo)
         del dx2
         attn, leaves = s.pop("attn"), s.pop("leaves")
-        dq, dk, dv = torch.autograd.grad(attn, leaves, dattn.view(B, S, self.hq, self.hd).transpose(1, 2))
+        dattn4 = dattn.view(B, S, self.hq, self.hd).transpose(1, 2)
+        if isinstance(leaves[0], str):      # forward was ar_attn_fwd: (tag, q2d, k2d, v2d, out2d, lse)
+            _, q2d, k2d, v2d, out2d, lse = leaves
+            h4 = lambda t: t.view(B, S, self.hq, self.hd).transpose(1, 2)
+            z = torch.zeros((), dtype=torch.int64)
+            dq, dk, dv, _ = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
+                dattn4, h4(q2d), h4(k2d), h4(v2d), None, h4(out2d), lse, z, z, 0.0, (True, True, True, False), True, scale=self.scaling)
+        else:
+            dq, dk, dv = torch.autograd.grad(attn, leaves, dattn4)
         del attn, leaves, dattn
 
         def tok(t):

@@ -396,6 +396,32 @@ def rope_bwd(dq2d, dk2d, dv2d, cos, sin, batch, seq, hq, hkv, d, out=None):
     return dqkv
 
 
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq: int, heads: int, head_dim: int, scale=None):
+    """Causal attention forward on token-major operands q / k / v [batch * seq, heads * head_dim] (bf16, K / V already repeated to
+    `heads`): -> (out [batch * seq, heads * head_dim], lse [batch, heads, seq] fp32), or None when the kernel does not take the
+    shape (head size other than 128, seq not a multiple of 128) -- the caller then keeps torch's SDPA."""
+    if q.dtype != torch.bfloat16 or head_dim != 128 or seq % 128 or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+        return None
+    out = torch.empty_like(q)
+    lse = torch.empty((batch, heads, seq), dtype=torch.float32, device=q.device)
+    sc = float(scale) if scale is not None else head_dim ** -0.5
+    devs = set()
+    for t in (q, k, v):
+        if not t.is_cuda:
+            raise _lib.Mi355xLibraryError("attn_fwd: the MI355X path only runs on a HIP device and has no CPU fallback")
+        devs.add(t.device.index)
+    if len(devs) != 1:
+        raise _lib.Mi355xLibraryError("attn_fwd: tensors live on different HIP devices")
+    (dev,) = devs
+    with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
+        rc = load().ar_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), batch, seq, heads, head_dim,
+                                sc, 1, torch.cuda.current_stream(dev).cuda_stream)
+    if rc == _lib.AR_ERR_UNSUPPORTED:
+        return None
+    check(rc, "ar_attn_fwd")
+    return out, lse
+
+
 _gemm_ws: dict = {}
 
 

@@ -255,6 +255,9 @@ class SignRoundConfig:
     # (csrc/ar_gemm.hip) for the shapes where it wins (fused_block.mfma_dw_pays); another GEMM engine = another fp32 summation
     # order, so -- like fused_block -- opt-in.  The front door's enable_torch_compile=True switches both on.
     mfma_dw_gemm: bool = False
+    # Inside the fused block: the causal attention forward on the hand-written flash-attention kernel (csrc/ar_attn.hip) instead of
+    # torch's SDPA (AOTriton); the backward stays the library's, fed with this kernel's output and log-sum-exp rows.
+    flash_attention: bool = True
 
     def __post_init__(self):
         if self.iters < 0:
@@ -372,6 +375,8 @@ class SignRoundQuantizer:
 
             fused = FusedLlamaBlock.try_build(block, arenas, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx,
                                               use_mfma_dw=cfg.mfma_dw_gemm)
+            if fused is not None:
+                fused.flash_fwd = bool(cfg.flash_attention)
         self.last_fused_block = fused is not None
 
         # one (round, minmax) pair of param groups per arena; lr by the arena's bit-width (quantizer.py:374-417)
@@ -550,6 +555,8 @@ class SignRoundQuantizer:
             from .fused_block import FusedLlamaBlock
 
             fb = FusedLlamaBlock.try_build_plain(block, input_others, self.config.amp_dtype, sdpa_ctx=self._sdpa_ctx)
+            if fb is not None:
+                fb.flash_fwd = bool(self.config.flash_attention)
         outs = []
         for b0 in range(0, inputs.shape[0], bs):
             x = inputs[b0:b0 + bs]

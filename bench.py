@@ -267,6 +267,7 @@ class Bench:
         if fused_block is not None:
             kw["fused_block"] = fused_block
             kw["mfma_dw_gemm"] = fused_block
+        kw["flash_attention"] = not getattr(args, "no_flash_attn", False)
         self.qcfg = SignRoundConfig(iters=args.iters, batch_size=args.batch_size, bits=self.bits,
                                     fuse_next_forward=fuse_next_forward, sdpa_backend=args.sdpa, data_parallel=dp,
                                     enable_quanted_input=quanted_input, **kw)
@@ -383,6 +384,7 @@ def main():
                          "buffer per iteration (strong scaling; for quantised-input chaining). Default N>1 mode: block sharding")
     ap.add_argument("--alg-ext", action="store_true",
                     help="tune with the algorithm extension (SignRoundV2: imatrix, searched init scales, outlier loss)")
+    ap.add_argument("--no-flash-attn", action="store_true", help="fused block: keep torch's SDPA forward instead of csrc/ar_attn.hip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the opt125m and variants objects")
@@ -469,7 +471,7 @@ def main():
             "data": "synthetic: random-init weights of the named architecture, N(0,1) bf16 hidden states",
             "config": {"workload": workload_desc, "scheme": args.scheme or "int", "bits": b.bits, "group_size": b.gs, "sym": b.sym,
                        "iters": args.iters, "nsamples": N, "seqlen": S, "batch_size": args.batch_size,
-                       "weights_per_block": n_w, "groups_per_block": G, "includes_packing": True,
+                       "weights_per_block": n_w, "groups_per_block": G, "includes_packing": True, "flash_attention": bool(b.qcfg.flash_attention and b.qcfg.fused_block),
                        "fuse_next_forward": bool(args.fuse_next_forward), "fused_block": bool(getattr(b.quantizer, "last_fused_block", False)),
                        "sdpa_backend": args.sdpa, "alg_ext": bool(args.alg_ext),
                        "parallelism": (f"data-parallel inside the block x{world}" if dp else

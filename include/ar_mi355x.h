@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 10
+#define AR_ABI_VERSION 11
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -270,6 +270,17 @@ int64_t ar_gemm_dw_workspace_bytes(int64_t M, int64_t N, int64_t K);
 /* experiment knobs of the kernel above for tools/gemm_dw_probe.py (binding hygiene; -1 keeps a value): sem = lane->piece rule
  * of the transposing LDS read (1 | 2), order = tile order (0 identity, 1 XCD chunks, 2 XCD 2x8 patches).  Returns sem*10+order. */
 int ar_gemm_dw_config(int sem, int order);
+
+/* ---- causal attention forward (hand-written MFMA flash attention, gfx950) ------------------------------------------
+ * replaces: the attention forward of the decoder block inside the tuning loop -- transformers' sdpa_attention_forward
+ *           (transformers/integrations/sdpa_attention.py: torch scaled_dot_product_attention(q, k, v, is_causal=True)), which the
+ *           reference reaches through block_forward (auto_round/utils/model.py block_forward, compressors/base.py:1177-1179).
+ *           Q, K, V, O: [B, S, H, D] token-major bf16 (K / V already repeated to H heads), D = 128, S a multiple of 128;
+ *           LSE [B, H, S] fp32 = natural-log row sums of the scaled scores, the form
+ *           aten::_scaled_dot_product_efficient_attention_backward consumes.  scale = 1/sqrt(D) for the stock models.
+ *           Anything else (no causal mask, other head sizes) returns AR_ERR_UNSUPPORTED and the caller keeps torch's SDPA. */
+int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
+                float scale, int causal, ar_stream_t stream);
 
 /* ---- optional device-side timing of the hot kernels (bench.py / tools; OFF by default) --------------------------
  * binding hygiene / measurement, no reference counterpart (the reference times blocks on the host,

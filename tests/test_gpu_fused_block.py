@@ -269,3 +269,38 @@ def test_fused_nograd_forward_of_an_unwrapped_block_and_its_fallback_under_hooks
     finally:
         h.remove()
     assert len(seen) == 2 and torch.equal(out_h, out_m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S,H", [(1, 128, 2), (2, 512, 4), (1, 2048, 3)])
+def test_attention_forward_vs_torch_sdpa(B, S, H):
+    """The hand-written causal flash-attention forward against torch's SDPA on the same token-major operands: output within bf16
+    rounding of an fp32 softmax(QK^T)V, log-sum-exp rows equal to torch's to fp32 precision, and the library backward fed with this
+    kernel's (out, lse) returns the gradients it returns for its own forward."""
+    import math
+
+    from auto_round_amd import ops
+
+    D = 128
+    q, k, v = (_rand(B * S, H * D, seed=21 + i) for i in range(3))
+    res = ops.attn_fwd(q, k, v, B, S, H, D)
+    assert res is not None
+    out, lse = res
+    q4, k4, v4 = (t.view(B, S, H, D).transpose(1, 2) for t in (q, k, v))
+    ref_o, ref_lse, seed, off = torch.ops.aten._scaled_dot_product_efficient_attention(q4, k4, v4, None, True, 0.0, True)
+    sc = (q4.float() @ k4.float().transpose(-1, -2)) / math.sqrt(D)
+    sc = sc.masked_fill(~torch.ones(S, S, device=q.device, dtype=torch.bool).tril(), float("-inf"))
+    exact = torch.softmax(sc, -1) @ v4.float()
+    mine = out.view(B, S, H, D).transpose(1, 2).float()
+    assert torch.allclose(lse, torch.logsumexp(sc, -1), rtol=0, atol=2e-5)
+    assert torch.allclose(lse, ref_lse[..., :S], rtol=0, atol=2e-5)
+    assert (mine - exact).abs().max().item() <= 1.5 * (ref_o.float() - exact).abs().max().item() + 1e-3
+    assert (mine - exact).abs().mean().item() <= 1.2 * (ref_o.float() - exact).abs().mean().item() + 1e-5
+    do = _rand(B * S, H * D, seed=30).view(B, S, H, D).transpose(1, 2)
+    z = torch.zeros((), dtype=torch.int64)
+    g_ref = torch.ops.aten._scaled_dot_product_efficient_attention_backward(do, q4, k4, v4, None, ref_o, ref_lse, seed, off, 0.0,
+                                                                            (True, True, True, False), True)
+    g_mine = torch.ops.aten._scaled_dot_product_efficient_attention_backward(do, q4, k4, v4, None, out.view(B, S, H, D).transpose(1, 2),
+                                                                             lse, z, z, 0.0, (True, True, True, False), True)
+    for a, b in zip(g_mine[:3], g_ref[:3]):
+        assert (a.float() - b.float()).abs().max().item() <= 2e-2 * b.float().abs().max().item() + 1e-3
