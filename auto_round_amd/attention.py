@@ -15,6 +15,26 @@ import torch.nn.functional as F
 NAME = "mi355x_sdpa"
 
 
+def efficient_backward_ok(seq: int) -> bool:
+    """torch 2.10 + ROCm 7.2: the backward of the "efficient" SDPA kernels (aiter fmha_bwd behind AOTriton) returns wrong
+    gradients (relative error ~1, NaNs) for token-major [B, S, H, D] operands when S % 256 == 128 and S > 128 (384, 640, 896, ...);
+    contiguous [B, H, S, D] operands and every other length checked are right, and so are the "flash" and "math" backends
+    (measured against fp32 autograd: tools/sdpa_backward_check.py, profiles/r02_sdpa_backward_check.json).  Callers route those
+    lengths to the flash kernels."""
+    return seq <= 128 or seq % 256 != 128
+
+
+def backend_order(prefer: str, seq=None):
+    from torch.nn.attention import SDPBackend
+
+    if prefer == "math":
+        return [SDPBackend.MATH]
+    if prefer == "flash" or (seq is not None and not efficient_backward_ok(int(seq))):
+        return [SDPBackend.FLASH_ATTENTION, SDPBackend.MATH] if prefer != "flash" else [SDPBackend.FLASH_ATTENTION,
+                                                                                       SDPBackend.EFFICIENT_ATTENTION, SDPBackend.MATH]
+    return [SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH]
+
+
 def _repeat_kv(x: torch.Tensor, n_rep: int) -> torch.Tensor:
     if n_rep == 1:
         return x
@@ -32,7 +52,7 @@ def mi355x_sdpa_attention(module, query, key, value, attention_mask=None, dropou
         attention_mask = attention_mask[:, :, :, : key.shape[-2]]
     if is_causal is None:
         is_causal = query.shape[2] > 1 and attention_mask is None and getattr(module, "is_causal", True)
-    order = [SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH]
+    order = backend_order("efficient", query.shape[2])
     with sdpa_kernel(order, set_priority=True):
         out = F.scaled_dot_product_attention(query, key, value, attn_mask=attention_mask, dropout_p=dropout,
                                              scale=scaling, is_causal=bool(is_causal))

@@ -30,7 +30,6 @@ typedef short as16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 abf16x8_t __attribute__((ext_vector_type(8)));
 typedef float af32x16_t __attribute__((ext_vector_type(16)));
 
-constexpr int AQ = 128;              // queries per workgroup
 constexpr int AK = 64;               // keys per tile
 constexpr int AD = 128;              // head dimension
 constexpr int AROW = AD * 2;         // bytes per staged key / value row
@@ -51,7 +50,13 @@ struct AttnArgs {
     float scale_log2e;                                             // softmax scale * log2(e)
 };
 
-__global__ __launch_bounds__(256, 2) void k_attn_fwd_d128(AttnArgs a) {
+// WAVES waves of 32 queries per workgroup: 8 (256 queries, 512 threads) halves the K / V staging per wave and per query against 4 --
+// the LDS-DMA issue is the largest non-MFMA cost of the kernel (ablations in DESIGN.md) -- and is used whenever S % 256 == 0.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
+    constexpr int AQ = 32 * WAVES;       // queries per workgroup
+    constexpr int RPW = AK / WAVES;      // tile rows staged per wave (16 or 8), 4 per DMA instruction
+    constexpr int NP = RPW / 4;
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,21 +93,21 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_d128(AttnArgs a) {
     }
 
     // ---- DMA: a tile is 64 rows of 256 B; one instruction moves 4 rows (lane -> row 4 p + (lane >> 4), physical chunk lane & 15).
-    // wave w moves rows 16 w .. 16 w + 15 of the K tile and of the V tile: 4 + 4 instructions per tile.  Per-lane element offsets
+    // wave w moves rows RPW w .. RPW w + RPW - 1 of the K tile and of the V tile.  Per-lane element offsets
     // are fixed; the tile base pointers are uniform and advance by 64 rows per tile.
     const int drow = lane >> 4, pchunk = lane & 15;
-    uint32_t doff[4];
+    uint32_t doff[NP];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int r = 16 * wave + 4 * p + drow;                    // row inside the tile
+    for (int p = 0; p < NP; ++p) {
+        const int r = RPW * wave + 4 * p + drow;                   // row inside the tile
         doff[p] = (uint32_t)(r * row_stride + (pchunk ^ attn_swz(r)) * 8);
     }
     auto issue_tile = [&](int kt, int buf) {
         const uint16_t* Kt = Kb + (int64_t)kt * AK * row_stride;   // uniform
         const uint16_t* Vt = Vb + (int64_t)kt * AK * row_stride;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const uint32_t dst = lds0 + buf * ABUF + (16 * wave + 4 * p) * AROW;      // wave-uniform
+        for (int p = 0; p < NP; ++p) {
+            const uint32_t dst = lds0 + buf * ABUF + (RPW * wave + 4 * p) * AROW;     // wave-uniform
             __builtin_amdgcn_global_load_lds((const void*)(Kt + doff[p]), (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const void*)(Vt + doff[p]), (__attribute__((address_space(3))) void*)(uintptr_t)(dst + ATILE), 16, 0, 0);
         }
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_d128(AttnArgs a) {
         }
     };
 
-    const int n_kt = 2 * qt + 2;                                          // key tiles up to the diagonal: always an even number
+    const int n_kt = (q0 + AQ) / AK;                                      // key tiles up to the diagonal: always an even number
     issue_tile(0, 0);
     for (int kt = 0; kt < n_kt; kt += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -286,7 +291,7 @@ using namespace ar;
 
 extern "C" int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H,
                            int64_t D, float scale, int causal, ar_stream_t stream) {
-    if (D != AD || !causal || S % AQ || B <= 0 || H <= 0 || S <= 0) return AR_ERR_UNSUPPORTED;
+    if (D != AD || !causal || S % 128 || B <= 0 || H <= 0 || S <= 0) return AR_ERR_UNSUPPORTED;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return AR_ERR_UNSUPPORTED;
     AttnArgs a;
     a.Q = (const uint16_t*)Q; a.K = (const uint16_t*)K; a.V = (const uint16_t*)V; a.O = (uint16_t*)O; a.LSE = LSE;
@@ -294,10 +299,11 @@ extern "C" int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O,
     a.scale_log2e = scale * 1.4426950408889634f;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_attn_fwd_d128, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
+        (void)hipFuncSetAttribute((const void*)k_attn_fwd_d128<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
+        (void)hipFuncSetAttribute((const void*)k_attn_fwd_d128<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
         attr = true;
     }
-    const int64_t grid = B * H * (S / AQ);
-    hipLaunchKernelGGL(k_attn_fwd_d128, (int)grid, 256, ATTN_LDS, (hipStream_t)stream, a);
+    if (S % 256 == 0) hipLaunchKernelGGL(k_attn_fwd_d128<8>, (int)(B * H * (S / 256)), 512, ATTN_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_attn_fwd_d128<4>, (int)(B * H * (S / 128)), 256, ATTN_LDS, (hipStream_t)stream, a);
     return launch_status();
 }

@@ -194,14 +194,16 @@ class FusedLlamaBlock:
 
         import contextlib
 
-        if mask is None and S > 1 and getattr(self, "flash_fwd", True):
+        from .attention import efficient_backward_ok
+
+        if mask is None and S > 1 and getattr(self, "flash_fwd", True) and efficient_backward_ok(S):
             # hand-written causal flash-attention forward (csrc/ar_attn.hip; head size 128, S % 128 == 0); it returns the rows'
             # log-sum-exp in the form the library's attention backward consumes, so the backward stays torch's
             res = ops.attn_fwd(q2d, k2d, v2d, B, S, hq, hd, scale=self.scaling)
             if res is not None:
                 out2d, lse = res
                 return heads(out2d), (("flash", q2d, k2d, v2d, out2d, lse) if grad else None)
-        ctx = self.sdpa_ctx() if self.sdpa_ctx is not None else contextlib.nullcontext()
+        ctx = self.sdpa_ctx(S) if self.sdpa_ctx is not None else contextlib.nullcontext()
         if mask is not None and mask.dim() == 4:
             mask = mask[:, :, :, :S]
         with ctx:

@@ -322,22 +322,24 @@ class SignRoundQuantizer:
     @property
     def gradient_accumulate_steps(self): return self.config.gradient_accumulate_steps
 
-    def _sdpa_ctx(self):
+    def _sdpa_ctx(self, seq=None):
+        """SDPA backend priority for one attention call of `seq` tokens (attention.backend_order: the efficient kernels first,
+        except for the lengths where their backward is wrong in this torch build)."""
         pref = getattr(self.config, "sdpa_backend", "auto")
         if pref == "auto":
             return contextlib.nullcontext()
-        from torch.nn.attention import SDPBackend, sdpa_kernel
+        from torch.nn.attention import sdpa_kernel
 
-        order = {"efficient": [SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH],
-                 "flash": [SDPBackend.FLASH_ATTENTION, SDPBackend.EFFICIENT_ATTENTION, SDPBackend.MATH],
-                 "math": [SDPBackend.MATH]}[pref]
+        from .attention import backend_order
+
+        order = backend_order(pref, seq)
         try:
             return sdpa_kernel(order, set_priority=True)
         except TypeError:  # pragma: no cover  (older torch without set_priority)
             return sdpa_kernel(order)
 
     def block_forward(self, block, x, input_others):
-        with self._sdpa_ctx():
+        with self._sdpa_ctx(x.shape[1] if x.dim() == 3 else None):
             return block_forward(block, x, input_others, amp=self.config.amp, amp_dtype=self.config.amp_dtype)
 
     # ------------------------------------------------------------------------------------------------------------------
