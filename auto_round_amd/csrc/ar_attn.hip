@@ -42,6 +42,20 @@ constexpr int ATTN_LDS = 2 * ABUF;   // double buffered: 64 KB
 // both land on disjoint banks
 __device__ __forceinline__ int attn_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
+// value of the other lane half (lane ^ 32) combined with this one, without touching LDS: v_permlane32_swap hands every lane both
+// halves' values.  (A ds_bpermute here would make the compiler drain the LDS-DMA of the next tile -- vmcnt(0) -- in front of it.)
+// (inline asm: the two-result builtin returned the first result twice with this compiler -- probed on the GPU)
+__device__ __forceinline__ float halves_max(float x) {
+    float lo = x, hi = x;
+    asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 4" : "+v"(lo), "+v"(hi));      // lo <- {x[0:31], x[0:31]}, hi <- {x[32:63], x[32:63]}
+    return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float halves_sum(float x) {
+    float lo = x, hi = x;
+    asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 4" : "+v"(lo), "+v"(hi));
+    return lo + hi;
+}
+
 struct AttnArgs {
     const uint16_t* Q; const uint16_t* K; const uint16_t* V;    // [B, S, H, D] token-major
     uint16_t* O;                                                   // [B, S, H, D]
@@ -102,15 +116,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
         const int r = RPW * wave + 4 * p + drow;                   // row inside the tile
         doff[p] = (uint32_t)(r * row_stride + (pchunk ^ attn_swz(r)) * 8);
     }
+    // piece j of 2 NP: K rows (j < NP) or V rows of this wave
+    auto issue_piece = [&](int kt, int buf, int j) {
+        const int p = j % NP;
+        const uint16_t* T = (j < NP ? Kb : Vb) + (int64_t)kt * AK * row_stride;      // uniform
+        const uint32_t dst = lds0 + buf * ABUF + (j < NP ? 0 : ATILE) + (RPW * wave + 4 * p) * AROW;     // wave-uniform
+        __builtin_amdgcn_global_load_lds((const void*)(T + doff[p]), (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
+    };
     auto issue_tile = [&](int kt, int buf) {
-        const uint16_t* Kt = Kb + (int64_t)kt * AK * row_stride;   // uniform
-        const uint16_t* Vt = Vb + (int64_t)kt * AK * row_stride;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const uint32_t dst = lds0 + buf * ABUF + (RPW * wave + 4 * p) * AROW;     // wave-uniform
-            __builtin_amdgcn_global_load_lds((const void*)(Kt + doff[p]), (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void*)(Vt + doff[p]), (__attribute__((address_space(3))) void*)(uintptr_t)(dst + ATILE), 16, 0, 0);
-        }
+        for (int j = 0; j < 2 * NP; ++j) issue_piece(kt, buf, j);
     };
 
     // ---- fragment read addresses: one register per k-step (K) / per d-tile (V^T, low and high key rows); buffer, key sub-tile and
@@ -149,7 +164,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
         asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"                        \
                      : "=&v"(vlo[(ST) & 1][dt]), "=&v"(vhi[(ST) & 1][dt])                                                \
                      : "v"(vAlo[dt]), "v"(vAhi[dt]), "n"(BUF * ABUF + ATILE + (ST) * 16 * AROW) : "memory");
-    // one key tile from LDS buffer BUF (compile time)
+    // one key tile from LDS buffer BUF (compile time).  (Issuing the next tile's DMA pieces between the MFMAs of the S^T product
+    // instead of up front was tried: their 64-bit addresses stay live across the loop and the kernel spills.)
     auto tile = [&](auto bufc, int kt) {
         constexpr int BUF = decltype(bufc)::value;
         const int k0 = kt * AK;
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        mx = halves_max(mx);
         const float m_new = fmaxf(m_run, mx * a.scale_log2e);             // finite: key 0 is visible to every query
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // raw v_exp_f32: arguments <= 0
         float psum = 0.f;
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
 #undef AR_VREAD
 #undef AR_PINA
     // ---- normalise and store: lane = query, registers = d (runs of 4 consecutive d -> 8-byte stores)
-    const float l_tot = l_run + __shfl_xor(l_run, 32, kWave);
+    const float l_tot = halves_sum(l_run);
     const float inv = 1.0f / l_tot;
     uint16_t* orow = a.O + ((int64_t)(b * a.S + myq) * a.H + head) * AD;
 #pragma unroll
