@@ -54,7 +54,7 @@ class FusedLlamaBlock:
             proj = [attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj]
         except AttributeError:
             return None
-        if len(arenas) != 1 or not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not _is_silu(getattr(mlp, "act_fn", None)):
+        if not arenas or not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not _is_silu(getattr(mlp, "act_fn", None)):
             return None
         if any(hasattr(attn, a) and not isinstance(getattr(attn, a), torch.nn.Identity) for a in ("q_norm", "k_norm")):
             return None                                                    # Qwen3-style per-head norms: generic path
@@ -62,10 +62,26 @@ class FusedLlamaBlock:
             return None
         if not all(isinstance(p, WrapperLinear) for p in proj):
             return None
-        arena = arenas[0]
-        if any(p.arena is not arena or p.enable_act_quant or p.padded or p.is_conv1d for p in proj):
-            return None
         q, k, v, o, g, u, d = proj
+        # layers of one scheme and group size share an arena; the merged projections need theirs contiguous in ONE arena each
+        # (per-row presets such as INT8 put down_proj, with its own row length, in a second arena)
+        if any(p.padded or p.is_conv1d or not any(p.arena is a for a in arenas) for p in proj):
+            return None
+        if not (q.arena is k.arena is v.arena and g.arena is u.arena):
+            return None
+        if len({a.w_dtype for a in arenas}) != 1:
+            return None
+        arena = q.arena
+        # dynamic activation fake-quant (INT8 / INT4 / W4A8 presets, MXFP4): one plan per GEMM input; the merged projections must
+        # agree on theirs.  NVFP4's per-layer static activation scale keeps the module path.
+        from .wrapper import act_quant_plan
+
+        try:
+            plans = [act_quant_plan(p.orig_layer, p.in_features) if p.enable_act_quant else None for p in proj]
+        except NotImplementedError:
+            return None
+        if any(pl is not None and pl[0] == "nv" for pl in plans) or not (plans[0] == plans[1] == plans[2]) or plans[4] != plans[5]:
+            return None
         if arena.w_dtype not in (torch.bfloat16, torch.float16) or arena.w_dtype != amp_dtype:
             return None
         if not (k._off == q._off + q.numel and v._off == k._off + k.numel and u._off == g._off + g.numel):
@@ -91,7 +107,7 @@ class FusedLlamaBlock:
             return None
 
         self = cls()
-        self.block, self.arena, self.attn = block, arena, attn
+        self.block, self.arena, self.arenas, self.attn = block, arena, list(arenas), attn
         self.layers = dict(q=q, k=k, v=v, o=o, g=g, u=u, d=d)
         self.w1, self.eps1 = n1.weight, float(n1.variance_epsilon)
         self.w2, self.eps2 = n2.weight, float(n2.variance_epsilon)
@@ -101,6 +117,7 @@ class FusedLlamaBlock:
         self.dtype = arena.w_dtype
         self.sdpa_ctx = sdpa_ctx
         self.use_mfma_dw = bool(use_mfma_dw)
+        self.aq = dict(qkv=plans[0], o=plans[3], gu=plans[4], d=plans[6])
 
         def view(first, last_numel_sum, rows, cols, buf):
             return buf[first._off:first._off + last_numel_sum].view(rows, cols)
@@ -109,8 +126,8 @@ class FusedLlamaBlock:
         self.Wqkv = view(q, nqkv, (hq + 2 * hkv) * hd, self.H, arena.Wq)
         self.dWqkv = view(q, nqkv, (hq + 2 * hkv) * hd, self.H, arena.dWq)
         self.Wo, self.dWo = o.weight_q, o.weight_grad
-        self.Wgu = view(g, g.numel + u.numel, 2 * self.Fdim, self.H, arena.Wq)
-        self.dWgu = view(g, g.numel + u.numel, 2 * self.Fdim, self.H, arena.dWq)
+        self.Wgu = view(g, g.numel + u.numel, 2 * self.Fdim, self.H, g.arena.Wq)
+        self.dWgu = view(g, g.numel + u.numel, 2 * self.Fdim, self.H, g.arena.dWq)
         self.Wd, self.dWd = d.weight_q, d.weight_grad
         dt = self.dtype
         self.b_qkv = torch.cat([b.to(dt) for b in qkv_bias]) if qkv_bias[0] is not None else None
@@ -160,6 +177,7 @@ class FusedLlamaBlock:
                 return None
         self = cls()
         self.block, self.arena, self.attn, self.layers = block, None, attn, {}
+        self.aq = dict(qkv=None, o=None, gu=None, d=None)
         self.w1, self.eps1 = n1.weight, float(n1.variance_epsilon)
         self.w2, self.eps2 = n2.weight, float(n2.variance_epsilon)
         self.hq, self.hkv, self.hd = hq, hkv, hd
@@ -243,10 +261,10 @@ class FusedLlamaBlock:
 
     # -- the two directions -----------------------------------------------------------------------------------------------
     def forward(self, x, input_others):
-        a = self.arena
-        if not a.wq_fresh:
-            a.qdq_forward()
-        return _FusedBlockFn.apply(x, a.token, self, input_others)
+        for a in self.arenas:
+            if not a.wq_fresh:
+                a.qdq_forward()
+        return _FusedBlockFn.apply(x, self.arena.token, self, input_others)
 
     @torch.no_grad()
     def forward_nograd(self, x, input_others):
@@ -262,20 +280,31 @@ class FusedLlamaBlock:
         x2d = x2d.contiguous()
         cos, sin = self._cos_sin(others, B, S)
         mask = others.get("attention_mask")
+        from .wrapper import act_quant_fwd_raw
+
+        aq = self.aq
+
+        def fq(t, plan):        # the GEMM's input: fake-quantised activations where the scheme has them
+            return t if plan is None else act_quant_fwd_raw(t, plan)
+
         h1, _ = ops.rmsnorm_fwd(x2d, self.w1, self.eps1, want_rstd=False)
+        h1 = fq(h1, aq["qkv"])                       # (the block input needs no gradient: only the quantised form is kept)
         qkv = F.linear(h1, self.Wqkv, self.b_qkv)
         q2d, k2d, v2d = ops.rope_fwd(qkv, cos, sin, B, S, self.hq, self.hkv, self.hd)
         del qkv
         attn, leaves = self._attention(q2d, k2d, v2d, mask, B, S, grad=ctx is not None)
         attn2d = attn.detach().transpose(1, 2).reshape(T, self.hq * self.hd)
-        x2 = self._linear_residual(x2d, attn2d, self.Wo, self.b_o)
+        attn_in = fq(attn2d, aq["o"])
+        x2 = self._linear_residual(x2d, attn_in, self.Wo, self.b_o)
         h2, rstd2 = ops.rmsnorm_fwd(x2, self.w2, self.eps2, want_rstd=ctx is not None)
-        gu = F.linear(h2, self.Wgu, self.b_gu)
+        h2_in = fq(h2, aq["gu"])
+        gu = F.linear(h2_in, self.Wgu, self.b_gu)
         act = ops.swiglu_fwd(gu, self.Fdim)
-        y = self._linear_residual(x2, act, self.Wd, self.b_d)
+        act_in = fq(act, aq["d"])
+        y = self._linear_residual(x2, act_in, self.Wd, self.b_d)
         if ctx is not None:
-            ctx.saved = dict(h1=h1, attn=attn, leaves=leaves, attn2d=attn2d, x2=x2, rstd2=rstd2, h2=h2, gu=gu, act=act, cos=cos, sin=sin,
-                             B=B, S=S)
+            ctx.saved = dict(h1=h1, attn=attn, leaves=leaves, attn2d=attn2d, attn_in=attn_in, x2=x2, rstd2=rstd2, h2=h2, h2_in=h2_in,
+                             gu=gu, act=act, act_in=act_in, cos=cos, sin=sin, B=B, S=S)
         return y.view(B, S, H)
 
     def _backward_impl(self, ctx, dy):
@@ -288,18 +317,25 @@ class FusedLlamaBlock:
         if dy2d.dtype != self.dtype:
             dy2d = dy2d.to(self.dtype)
         dy2d = dy2d.contiguous()
+        from .wrapper import act_quant_bwd_raw
+
+        aq = self.aq
+
+        def bq(g, x, plan):     # gradient w.r.t. the quantised activation -> gradient w.r.t. the activation
+            return g if plan is None else act_quant_bwd_raw(g, x, plan)
+
         # MLP
-        self._dw(dy2d, s.pop("act"), self.dWd, [L["d"]])
-        da = torch.mm(dy2d, self.Wd)
+        self._dw(dy2d, s.pop("act_in"), self.dWd, [L["d"]])
+        da = bq(torch.mm(dy2d, self.Wd), s.pop("act"), aq["d"])
         dgu = ops.swiglu_bwd_(da, s.pop("gu"), self.Fdim)
         del da
-        self._dw(dgu, s.pop("h2"), self.dWgu, [L["g"], L["u"]])
-        dh2 = torch.mm(dgu, self.Wgu)
+        self._dw(dgu, s.pop("h2_in"), self.dWgu, [L["g"], L["u"]])
+        dh2 = bq(torch.mm(dgu, self.Wgu), s.pop("h2"), aq["gu"])
         del dgu
         dx2 = ops.rmsnorm_bwd(dh2, s.pop("x2"), self.w2, s.pop("rstd2"), dres=dy2d, out=dh2)
         # attention
-        self._dw(dx2, s.pop("attn2d"), self.dWo, [L["o"]])
-        dattn = torch.mm(dx2, self.Wo)
+        self._dw(dx2, s.pop("attn_in"), self.dWo, [L["o"]])
+        dattn = bq(torch.mm(dx2, self.Wo), s.pop("attn2d"), aq["o"])
         del dx2
         attn, leaves = s.pop("attn"), s.pop("leaves")
         dattn4 = dattn.view(B, S, self.hq, self.hd).transpose(1, 2)

@@ -153,9 +153,12 @@ class _IntActQdqFn(torch.autograd.Function):
         return dx.view(xc.shape), None, None, None, None, None
 
 
-def act_fake_quant(x: torch.Tensor, layer) -> torch.Tensor:
-    """Activation fake-quant as configured on `layer` (act_bits / act_data_type / act_group_size / act_max); reference:
-    WrapperLinear._qdq_act (auto_round/wrapper.py:295-321) and WrapperWALayer.forward (:568-612)."""
+def act_quant_plan(layer, hidden: int):
+    """The activation fake-quant configured on `layer` (act_bits / act_data_type / act_group_size / act_sym) for inputs of last
+    dimension `hidden`, as a hashable tuple: ("int", bits, group, scale_dtype, thresh, sym) | ("mx",) | ("nv",), or None when the
+    layer's activations stay in 16 bit.  reference: WrapperLinear._qdq_act (auto_round/wrapper.py:295-321)."""
+    if int(getattr(layer, "act_bits", 16) or 16) > 8:
+        return None
     adt = str(getattr(layer, "act_data_type", ""))
     gs = getattr(layer, "act_group_size", 0)
     gs = int(gs) if gs is not None else 0
@@ -163,25 +166,57 @@ def act_fake_quant(x: torch.Tensor, layer) -> torch.Tensor:
         if getattr(layer, "act_dynamic", True) is False:
             raise NotImplementedError("int activation fake-quant implements the dynamic case (static act_max scales: NVFP4 only)")
         asym = getattr(layer, "act_sym", True) is False
-        h = x.shape[-1]
-        g = h if (gs in (-1, 0) or h < gs) else gs          # data_type/utils.py:47-48
-        if g % 8 or h % g:
-            raise NotImplementedError(f"act_group_size={gs} with hidden size {h}: groups must be a multiple of 8 that divides it")
+        g = hidden if (gs in (-1, 0) or hidden < gs) else gs          # data_type/utils.py:47-48
+        if g % 8 or hidden % g:
+            raise NotImplementedError(f"act_group_size={gs} with hidden size {hidden}: groups must be a multiple of 8 that divides it")
         sdt = getattr(layer, "scale_dtype", torch.float16) or torch.float16
-        return _IntActQdqFn.apply(x, int(layer.act_bits), g, sdt, 1e-8 if sdt == torch.float32 else 1e-5, not asym)
-    if int(getattr(layer, "act_bits", 16)) != 4 or x.shape[-1] % max(gs, 1):
+        return ("int", int(layer.act_bits), g, sdt, 1e-8 if sdt == torch.float32 else 1e-5, not asym)
+    if int(getattr(layer, "act_bits", 16)) != 4 or hidden % max(gs, 1):
         raise NotImplementedError("activation fake-quant implements MXFP4 (gs 32) / NVFP4 (gs 16) and dynamic symmetric int")
     if is_mx_fp(adt) and gs == 32:
-        return _ActQdqFn.apply(x, 0, 32, None)
+        return ("mx",)
     if is_nv_fp(adt) and gs == 16:
-        act_max = getattr(layer, "act_max", None)
-        if act_max is None:     # nv_fp4_with_static_gs falls back to the tensor's own max (nvfp.py:107-108)
-            _, tmax = ops.group_absmax(x.detach().contiguous().view(-1), 16, want_tensor_max=True, want_groups=False)
-        else:
-            tmax = torch.as_tensor(act_max, dtype=torch.float32, device=x.device).abs().max().reshape(1)
-        gscale = torch.where(tmax == 0, torch.zeros_like(tmax), (448.0 * 6.0) * (1.0 / tmax))
-        return _ActQdqFn.apply(x, 1, 16, gscale.contiguous())
+        return ("nv",)
     raise NotImplementedError(f"act_data_type={adt} with act_group_size={gs}")
+
+
+def act_quant_fwd_raw(x: torch.Tensor, plan):
+    """Kernel-level forward of a dynamic plan ("int" / "mx"; no autograd): contiguous x -> fake-quantised x."""
+    if plan[0] == "int":
+        _, bits, g, sdt, thresh, sym = plan
+        return ops.qdq_int_act_fwd(x.view(-1), gs=g, bits=bits, sym=sym, scale_dtype=sdt, q_thresh=thresh).view(x.shape)
+    assert plan[0] == "mx"
+    return ops.qdq_fp4_fwd(x.view(-1), None, None, None, mode=0, gs=32, global_scale=None).view(x.shape)
+
+
+def act_quant_bwd_raw(dy: torch.Tensor, x: torch.Tensor, plan, out=None):
+    """Kernel-level input gradient of a dynamic plan: (gradient w.r.t. the quantised activation, the activation) -> gradient."""
+    if plan[0] == "int":
+        _, bits, g, sdt, thresh, sym = plan
+        return ops.int_act_bwd(dy.view(-1), x.view(-1), gs=g, bits=bits, sym=sym, scale_dtype=sdt, q_thresh=thresh,
+                               out=None if out is None else out.view(-1)).view(x.shape)
+    assert plan[0] == "mx"
+    return ops.fp4_act_bwd(dy.view(-1), x.view(-1), mode=0, gs=32, global_scale=None, out=None if out is None else out.view(-1)).view(x.shape)
+
+
+def act_fake_quant(x: torch.Tensor, layer) -> torch.Tensor:
+    """Activation fake-quant as configured on `layer` (act_bits / act_data_type / act_group_size / act_max); reference:
+    WrapperLinear._qdq_act (auto_round/wrapper.py:295-321) and WrapperWALayer.forward (:568-612)."""
+    plan = act_quant_plan(layer, x.shape[-1])
+    if plan is None:
+        raise NotImplementedError("activation fake-quant implements MXFP4 (gs 32) / NVFP4 (gs 16) and dynamic symmetric int")
+    if plan[0] == "int":
+        _, bits, g, sdt, thresh, sym = plan
+        return _IntActQdqFn.apply(x, bits, g, sdt, thresh, sym)
+    if plan[0] == "mx":
+        return _ActQdqFn.apply(x, 0, 32, None)
+    act_max = getattr(layer, "act_max", None)
+    if act_max is None:     # nv_fp4_with_static_gs falls back to the tensor's own max (nvfp.py:107-108)
+        _, tmax = ops.group_absmax(x.detach().contiguous().view(-1), 16, want_tensor_max=True, want_groups=False)
+    else:
+        tmax = torch.as_tensor(act_max, dtype=torch.float32, device=x.device).abs().max().reshape(1)
+    gscale = torch.where(tmax == 0, torch.zeros_like(tmax), (448.0 * 6.0) * (1.0 / tmax))
+    return _ActQdqFn.apply(x, 1, 16, gscale.contiguous())
 
 
 class WrapperWALayer(torch.nn.Module):

@@ -190,6 +190,78 @@ def test_fused_block_forward_and_weight_gradients_match_the_module_path():
     unwrapper_block(blk, {})
 
 
+def _set_int_act(layer, bits=8, gs=32, sym=True, only=None):
+    for n, m in layer.named_modules():
+        if isinstance(m, torch.nn.Linear) and (only is None or n.endswith(only)):
+            m.act_bits, m.act_data_type, m.act_group_size, m.act_sym, m.act_dynamic = bits, "int", gs, sym, True
+
+
+@pytest.mark.parametrize("act_gs,act_sym", [(32, True), (-1, True), (64, False)])
+def test_fused_block_with_activation_fake_quant_matches_the_module_path(act_gs, act_sym):
+    """W4A8-style schemes (dynamic INT activations, per group or per token): the fused path quantises each GEMM input with the same
+    kernels the wrapped layers call, so forward and weight gradients match the module path to bf16 rounding points."""
+    from auto_round_amd.fused_block import FusedLlamaBlock
+    from auto_round_amd.quantizer import block_forward
+    from auto_round_amd.wrapper import unwrapper_block, wrapper_block
+
+    layer, rope, cfg = _llama_layer()
+    _set_int_act(layer, 8, act_gs, act_sym)
+    X, others = _data(rope, cfg, N=4, S=64)
+    blk = copy.deepcopy(layer)
+    wrapper_block(blk, True, False, device="cuda")
+    arenas = blk._ar_arenas
+    fb = FusedLlamaBlock.try_build(blk, arenas, others, torch.bfloat16)
+    assert fb is not None and all(v is not None for v in fb.aq.values())
+    pred_m = block_forward(blk, X, others, amp=True, amp_dtype=torch.bfloat16)
+    dpred = _rand(*pred_m.shape, seed=3, scale=0.1)
+    pred_m.backward(dpred)
+    dW_m = arenas[0].dWq.clone()
+    for lyr in arenas[0].layers:
+        lyr._dw_accum[0] = False
+    arenas[0].dWq.zero_()
+    pred_f = fb.forward(X, others)
+    pred_f.backward(dpred)
+    dW_f = arenas[0].dWq.clone()
+    scale = pred_m.float().abs().mean().item()
+    assert (pred_f.float() - pred_m.float()).abs().mean().item() < 1e-2 * scale
+    cosine = torch.nn.functional.cosine_similarity(dW_f.float(), dW_m.float(), dim=0).item()
+    assert cosine > 0.995, cosine
+    unwrapper_block(blk, {})
+
+
+def test_fused_block_with_per_row_weights_in_two_arenas():
+    """The reference's INT8 preset: per-row weight groups (group_size -1) put down_proj -- a different row length -- in its own
+    arena, per-token int8 activations on every GEMM input; the fused path takes both."""
+    from auto_round_amd.fused_block import FusedLlamaBlock
+    from auto_round_amd.quantizer import block_forward
+    from auto_round_amd.wrapper import unwrapper_block, wrapper_block
+
+    layer, rope, cfg = _llama_layer(bits=8, gs=-1)
+    _set_int_act(layer, 8, -1, True)
+    X, others = _data(rope, cfg, N=4, S=64)
+    blk = copy.deepcopy(layer)
+    wrapper_block(blk, True, False, device="cuda")
+    arenas = blk._ar_arenas
+    assert len(arenas) == 2
+    fb = FusedLlamaBlock.try_build(blk, arenas, others, torch.bfloat16)
+    assert fb is not None
+    pred_m = block_forward(blk, X, others, amp=True, amp_dtype=torch.bfloat16)
+    dpred = _rand(*pred_m.shape, seed=3, scale=0.1)
+    pred_m.backward(dpred)
+    dW_m = [a.dWq.clone() for a in arenas]
+    for a in arenas:
+        for lyr in a.layers:
+            lyr._dw_accum[0] = False
+        a.dWq.zero_()
+    pred_f = fb.forward(X, others)
+    pred_f.backward(dpred)
+    scale = pred_m.float().abs().mean().item()
+    assert (pred_f.float() - pred_m.float()).abs().mean().item() < 1e-2 * scale
+    for a, ref in zip(arenas, dW_m):
+        assert torch.nn.functional.cosine_similarity(a.dWq.float(), ref.float(), dim=0).item() > 0.995
+    unwrapper_block(blk, {})
+
+
 def test_blocks_the_fused_path_does_not_cover_keep_the_generic_path():
     from auto_round_amd.fused_block import FusedLlamaBlock
     from auto_round_amd.wrapper import unwrapper_block, wrapper_block
@@ -197,8 +269,7 @@ def test_blocks_the_fused_path_does_not_cover_keep_the_generic_path():
     layer, rope, cfg = _llama_layer()
     X, others = _data(rope, cfg)
     blk = copy.deepcopy(layer)
-    blk.mlp.down_proj.act_bits = 8                       # an activation-quantised layer
-    blk.mlp.down_proj.act_data_type, blk.mlp.down_proj.act_group_size, blk.mlp.down_proj.act_sym, blk.mlp.down_proj.act_dynamic = "int", 32, True, True
+    _set_int_act(blk, 8, 32, True, only="k_proj")        # q / k / v disagree about their (shared) input: no merged projection
     wrapper_block(blk, True, False, device="cuda")
     assert FusedLlamaBlock.try_build(blk, blk._ar_arenas, others, torch.bfloat16) is None
     unwrapper_block(blk, {})
