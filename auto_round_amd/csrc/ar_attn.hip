@@ -313,11 +313,10 @@ extern "C" int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O,
     a.Q = (const uint16_t*)Q; a.K = (const uint16_t*)K; a.V = (const uint16_t*)V; a.O = (uint16_t*)O; a.LSE = LSE;
     a.B = (int)B; a.S = (int)S; a.H = (int)H;
     a.scale_log2e = scale * 1.4426950408889634f;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)k_attn_fwd_d128<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
         (void)hipFuncSetAttribute((const void*)k_attn_fwd_d128<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
-        attr = true;
     }
     if (S % 256 == 0) hipLaunchKernelGGL(k_attn_fwd_d128<8>, (int)(B * H * (S / 256)), 512, ATTN_LDS, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_attn_fwd_d128<4>, (int)(B * H * (S / 128)), 256, ATTN_LDS, (hipStream_t)stream, a);

@@ -9,6 +9,19 @@
 
 namespace ar {
 
+// true exactly once per (call site, HIP device): function attributes such as the dynamic-LDS limit are per device, and a process
+// may drive more than one (SignRoundQuantizer(device="cuda:1") after work on cuda:0)
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 constexpr int kWave = 64;   // CDNA wavefront
 constexpr int kTPB = 256;   // threads per workgroup (4 waves, one per SIMD)
 constexpr int kEPT = 8;     // elements per lane per chunk: 16 B of bf16/f16, 32 B of fp32

@@ -1006,21 +1006,19 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
     a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = g_gemm_order;
     const int grid = a.tiles_m * a.tiles_n;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.first()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_dw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_dw2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm_dw2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
     if (g_gemm_kernel >= 8 && K % 128 == 0 && K >= 128) {
-        static bool a5 = false;
-        if (!a5) {
+        static PerDeviceOnce a5;
+        if (a5.first()) {
             (void)hipFuncSetAttribute((const void*)k_gemm_dw5<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
             (void)hipFuncSetAttribute((const void*)k_gemm_dw5<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-            a5 = true;
         }
         if (g_gemm_kernel == 8) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw5<4, false>), grid, 256, GEMM_LDS, st, a);
         else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw5<8, false>), grid, 256, GEMM_LDS, st, a);
@@ -1028,13 +1026,12 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
     }
     if (g_gemm_kernel >= 1 && (K % 128 == 0 || g_gemm_kernel == 7) && K >= 128) {
         if (g_gemm_kernel == 7) {
-            static bool a4 = false;
-            if (!a4) {
+            static PerDeviceOnce a4;
+            if (a4.first()) {
                 (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
                 (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
                 (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
                 (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-                a4 = true;
             }
             const int ns = splitk_plan(M, N, K);
             if (ns > 1 && workspace && workspace_bytes >= (int64_t)ns * M * N * 4 && (ldw % 8) == 0 && !((uintptr_t)dW & 15)) {
