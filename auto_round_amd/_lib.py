@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -53,6 +53,8 @@ SIGNATURES = {
     "ar_pack_fp4": (c_int, [P, P, P, L, L, I, I, I, P, P, P]),
     "ar_rmsnorm_fwd": (c_int, [P, P, P, P, L, I, F, I, P]),
     "ar_rmsnorm_bwd": (c_int, [P, P, P, P, P, P, L, I, I, P]),
+    "ar_layernorm_fwd": (c_int, [P, P, P, P, P, P, L, I, F, I, P]),
+    "ar_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, L, I, I, P]),
     "ar_swiglu_fwd": (c_int, [P, L, P, L, L, I, P]),
     "ar_swiglu_bwd": (c_int, [P, P, L, L, L, I, P]),
     "ar_rope_fwd": (c_int, [P, L, P, P, L, P, P, P, L, L, I, I, I, I, P]),

@@ -100,6 +100,117 @@ __global__ __launch_bounds__(kTPB) void k_rmsnorm_bwd(const void* __restrict__ d
     }
 }
 
+// ---- LayerNorm (OPT / GPT-style blocks) ---------------------------------------------------------------------------------------
+// y = dt(((x - mean) * rstd) * w + b)       (nn.LayerNorm under autocast runs in fp32 on the upcast input and the next Linear rounds
+// its input once: transformers/models/opt/modeling_opt.py OPTDecoderLayer.self_attn_layer_norm / final_layer_norm).  Two passes over
+// the row in registers (mean, then the centred sum of squares); one wave per row.
+template <int DT, int MAXC>
+__global__ __launch_bounds__(kTPB) void k_layernorm_fwd(const void* __restrict__ x, const void* __restrict__ w, const void* __restrict__ b,
+                                                         void* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         int64_t rows, int hidden, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kTPB / kWave) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = hidden / kEPT;
+    Raw8<DT> rx[MAXC];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * kWave;
+        if (ch < nch) {
+            rx[c] = load8_raw<DT>(x, row * hidden + (int64_t)ch * kEPT);
+            float v[8];
+            unpack8<DT>(rx[c], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[j];
+        }
+    }
+    const float mean = lanes_sum(sum, kWave) / (float)hidden;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (lane + c * kWave < nch) {
+            float v[8];
+            unpack8<DT>(rx[c], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += (v[j] - mean) * (v[j] - mean);
+        }
+    }
+    const float rstd = 1.0f / __builtin_sqrtf(lanes_sum(ss, kWave) / (float)hidden + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * kWave;
+        if (ch < nch) {
+            float v[8], wv[8], bv[8], o[8];
+            unpack8<DT>(rx[c], v);
+            unpack8<DT>(load8_raw<DT>(w, (int64_t)ch * kEPT), wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+            if (b) unpack8<DT>(load8_raw<DT>(b, (int64_t)ch * kEPT), bv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = ((v[j] - mean) * rstd) * wv[j] + bv[j];
+            store8<DT>(y, row * hidden + (int64_t)ch * kEPT, o);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * w,  xhat = (x - mean) * rstd     (exact derivative, fp32)
+template <int DT, int MAXC>
+__global__ __launch_bounds__(kTPB) void k_layernorm_bwd(const void* __restrict__ dy, const void* __restrict__ x, const void* __restrict__ w,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         const void* __restrict__ dres, void* __restrict__ dx, int64_t rows, int hidden) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kTPB / kWave) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = hidden / kEPT;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    Raw8<DT> rx[MAXC], rg[MAXC];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * kWave;
+        if (ch < nch) {
+            rx[c] = load8_raw<DT>(x, row * hidden + (int64_t)ch * kEPT);
+            rg[c] = load8_raw<DT>(dy, row * hidden + (int64_t)ch * kEPT);
+            float xv[8], gv[8], wv[8];
+            unpack8<DT>(rx[c], xv);
+            unpack8<DT>(rg[c], gv);
+            unpack8<DT>(load8_raw<DT>(w, (int64_t)ch * kEPT), wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = gv[j] * wv[j];
+                sg += g;
+                sgx += g * ((xv[j] - mean) * rstd);
+            }
+        }
+    }
+    sg = lanes_sum(sg, kWave) / (float)hidden;
+    sgx = lanes_sum(sgx, kWave) / (float)hidden;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + c * kWave;
+        if (ch < nch) {
+            float xv[8], gv[8], wv[8], o[8];
+            unpack8<DT>(rx[c], xv);
+            unpack8<DT>(rg[c], gv);
+            unpack8<DT>(load8_raw<DT>(w, (int64_t)ch * kEPT), wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = rstd * (gv[j] * wv[j] - sg - ((xv[j] - mean) * rstd) * sgx);
+            if (dres) {
+                float rv[8];
+                unpack8<DT>(load8_raw<DT>(dres, row * hidden + (int64_t)ch * kEPT), rv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += rv[j];
+            }
+            store8<DT>(dx, row * hidden + (int64_t)ch * kEPT, o);
+        }
+    }
+}
+
 // ---- SwiGLU -------------------------------------------------------------------------------------------------------------
 // a = dt(dt(silu(g)) * u), g = gu[:, :F], u = gu[:, F:2F]       (LlamaMLP.forward: act_fn(gate_proj(x)) * up_proj(x))
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
@@ -285,6 +396,36 @@ extern "C" int ar_rmsnorm_bwd(const void* dy, const void* x, const void* w, cons
 #define AR_CALL(DT)                                                                                                              \
     if (small) AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_rmsnorm_bwd<DT, 8>), grid, kTPB, 0, st, dy, x, w, rstd, dres, dx, rows, hidden); \
     else AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_rmsnorm_bwd<DT, 16>), grid, kTPB, 0, st, dy, x, w, rstd, dres, dx, rows, hidden)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean_out, float* rstd_out, int64_t rows,
+                                int hidden, float eps, int dt, ar_stream_t stream) {
+    if (rows <= 0) return AR_OK;
+    if (hidden <= 0 || hidden % kEPT || hidden > 16 * kWave * kEPT || !w) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)((rows + 3) / 4);
+    const bool small = hidden <= 8 * kWave * kEPT;
+#define AR_CALL(DT)                                                                                                              \
+    if (small) AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_fwd<DT, 8>), grid, kTPB, 0, st, x, w, b, y, mean_out, rstd_out, rows, hidden, eps); \
+    else AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_fwd<DT, 16>), grid, kTPB, 0, st, x, w, b, y, mean_out, rstd_out, rows, hidden, eps)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const void* dres,
+                                void* dx, int64_t rows, int hidden, int dt, ar_stream_t stream) {
+    if (rows <= 0) return AR_OK;
+    if (hidden <= 0 || hidden % kEPT || hidden > 16 * kWave * kEPT || !mean || !rstd || !w) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)((rows + 3) / 4);
+    const bool small = hidden <= 8 * kWave * kEPT;
+#define AR_CALL(DT)                                                                                                              \
+    if (small) AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_bwd<DT, 8>), grid, kTPB, 0, st, dy, x, w, mean, rstd, dres, dx, rows, hidden); \
+    else AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_bwd<DT, 16>), grid, kTPB, 0, st, dy, x, w, mean, rstd, dres, dx, rows, hidden)
     AR_DT_SWITCH2(dt, AR_CALL)
 #undef AR_CALL
     return launch_status();

@@ -1,5 +1,6 @@
 """Fused tuning-time forward / backward of a Llama-family decoder block (RMSNorm -> q/k/v -> rotary -> SDPA -> o -> residual ->
-RMSNorm -> SwiGLU MLP -> residual) on MI355X.
+RMSNorm -> SwiGLU MLP -> residual) and of an OPT-family one (LayerNorm -> q/k/v + bias -> SDPA -> out_proj -> residual -> LayerNorm
+-> fc1 -> ReLU -> fc2 -> residual; `FusedOPTBlock`) on MI355X.
 
 The reference speeds the same code up with `torch.compile(block_forward)` (auto_round/utils/device.py:112-122,
 compressors/base.py:1177-1179: "about 20 %"); here the block is written once, by hand, for the one thing the tuning loop does with
@@ -12,7 +13,7 @@ it -- forward on a cached minibatch, backward to the fake-quant weights only:
   * the block input needs no gradient, so nothing upstream of q/k/v is differentiated; weight gradients are written straight
     into the arena's dWq slices (merged for q/k/v and gate/up) by the hand-written MFMA kernel (csrc/ar_gemm.hip) where its
     shape constraints hold and it wins, by hipBLASLt otherwise;
-  * attention stays on PyTorch's SDPA (its backward through a local autograd graph).
+  * the causal attention forward is csrc/ar_attn.hip at head size 128 (PyTorch's SDPA otherwise); the backward is the library's.
 
 Same arithmetic per op as the module code, but different bf16 rounding points (fused residual epilogue, fp32 backward of the
 elementwise ops, merged GEMMs): parity with the generic path is trajectory-level, exactly like the reference's compiled path,
@@ -355,6 +356,246 @@ class FusedLlamaBlock:
         dqkv = ops.rope_bwd(tok(dq), tok(dk), tok(dv), s["cos"], s["sin"], B, S, self.hq, self.hkv, self.hd)
         del dq, dk, dv
         self._dw(dqkv, s.pop("h1"), self.dWqkv, [L["q"], L["k"], L["v"]])
+
+
+class FusedOPTBlock(FusedLlamaBlock):
+    """The same treatment for OPT-style decoder blocks (transformers/models/opt/modeling_opt.py OPTDecoderLayer with
+    do_layer_norm_before: LayerNorm -> q/k/v (+bias, q scaled) -> causal attention -> out_proj + residual -> LayerNorm -> fc1 ->
+    ReLU -> fc2 + residual).  LayerNorm forward / backward are csrc/ar_block.hip kernels (the module path runs them in fp32 with
+    two dtype conversions around each), q/k/v run as one GEMM, the residual adds ride in the GEMM epilogues, weight gradients go
+    straight into the arena through the MFMA kernel.  BASELINE configs[0] (OPT-125M) is this block."""
+
+    @staticmethod
+    def _parts(block):
+        try:
+            attn = block.self_attn
+            return (block.self_attn_layer_norm, block.final_layer_norm, attn,
+                    [attn.q_proj, attn.k_proj, attn.v_proj, attn.out_proj, block.fc1, block.fc2])
+        except AttributeError:
+            return None
+
+    @staticmethod
+    def _shape_ok(block, n1, n2, attn, q, k, v, o, f1, f2):
+        if not (isinstance(n1, torch.nn.LayerNorm) and isinstance(n2, torch.nn.LayerNorm)) or not getattr(block, "do_layer_norm_before", False):
+            return None
+        if n1.weight is None or n2.weight is None or not isinstance(getattr(block, "activation_fn", None), torch.nn.ReLU):
+            return None
+        if float(getattr(block, "dropout", 0.0) or 0.0) != 0.0 and block.training:
+            return None
+        hd = int(getattr(attn, "head_dim", 0))
+        H = q.in_features
+        if hd <= 0 or hd % 16 or H % hd or not (q.out_features == k.out_features == v.out_features == H == o.in_features == o.out_features):
+            return None
+        if not (k.in_features == v.in_features == H == f1.in_features == f2.out_features and f1.out_features == f2.in_features) or H % 8 or f1.out_features % 8:
+            return None
+        return hd
+
+    @classmethod
+    def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True) -> Optional["FusedOPTBlock"]:
+        from .wrapper import WrapperLinear, act_quant_plan
+
+        parts = cls._parts(block)
+        if parts is None or not arenas:
+            return None
+        n1, n2, attn, proj = parts
+        if not all(isinstance(p, WrapperLinear) for p in proj):
+            return None
+        q, k, v, o, f1, f2 = proj
+        hd = cls._shape_ok(block, n1, n2, attn, q, k, v, o, f1, f2)
+        if hd is None:
+            return None
+        if any(p.padded or p.is_conv1d or not any(p.arena is a for a in arenas) for p in proj) or not (q.arena is k.arena is v.arena):
+            return None
+        if len({a.w_dtype for a in arenas}) != 1 or q.arena.w_dtype != amp_dtype or amp_dtype not in (torch.bfloat16, torch.float16):
+            return None
+        # OPTAttention declares k_proj, v_proj, q_proj in that order, and the arena follows declaration order: the merged GEMM
+        # takes the three in whatever order they sit in the arena
+        trio = sorted([("q", q), ("k", k), ("v", v)], key=lambda t: t[1]._off)
+        if not (trio[1][1]._off == trio[0][1]._off + trio[0][1].numel and trio[2][1]._off == trio[1][1]._off + trio[1][1].numel):
+            return None
+        others = dict(input_others or {})
+        if others.get("past_key_values") is not None:
+            return None
+        qkv_bias = [t[1].orig_layer.bias for t in trio]
+        if any(b is not None for b in qkv_bias) and not all(b is not None for b in qkv_bias):
+            return None
+        try:
+            plans = [act_quant_plan(p.orig_layer, p.in_features) if p.enable_act_quant else None for p in proj]
+        except NotImplementedError:
+            return None
+        if any(pl is not None and pl[0] == "nv" for pl in plans) or not (plans[0] == plans[1] == plans[2]):
+            return None
+        self = cls()
+        arena = q.arena
+        self.block, self.arena, self.arenas, self.attn = block, arena, list(arenas), attn
+        self.layers = dict(q=q, k=k, v=v, o=o, f1=f1, f2=f2)
+        self.n1, self.n2 = n1, n2
+        self.hq = self.hkv = q.out_features // hd
+        self.hd, self.H, self.Fdim = hd, q.in_features, f1.out_features
+        self.qscale = float(getattr(attn, "scaling", hd ** -0.5))
+        self.scaling = 1.0                     # OPTAttention scales q itself and calls the attention with scaling = 1
+        self.dtype = arena.w_dtype
+        self.sdpa_ctx = sdpa_ctx
+        self.use_mfma_dw = bool(use_mfma_dw)
+        self.aq = dict(qkv=plans[0], o=plans[3], f1=plans[4], f2=plans[5])
+        n, first = q.numel + k.numel + v.numel, trio[0][1]._off
+        self.order = [t[0] for t in trio]
+        self.trio = [t[1] for t in trio]
+        self.Wqkv = arena.Wq[first:first + n].view(3 * self.H, self.H)
+        self.dWqkv = arena.dWq[first:first + n].view(3 * self.H, self.H)
+        self.Wo, self.dWo = o.weight_q, o.weight_grad
+        self.W1, self.dW1 = f1.weight_q, f1.weight_grad
+        self.W2, self.dW2 = f2.weight_q, f2.weight_grad
+        dt = self.dtype
+        self.b_qkv = torch.cat([b.to(dt) for b in qkv_bias]) if qkv_bias[0] is not None else None
+        self.b_o, self.b_1, self.b_2 = (None if p.orig_layer.bias is None else p.orig_layer.bias.to(dt) for p in (o, f1, f2))
+        return self
+
+    @classmethod
+    def try_build_plain(cls, block, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None) -> Optional["FusedOPTBlock"]:
+        parts = cls._parts(block)
+        if parts is None:
+            return None
+        n1, n2, attn, proj = parts
+        if not all(type(p) is torch.nn.Linear for p in proj):
+            return None
+        q, k, v, o, f1, f2 = proj
+        hd = cls._shape_ok(block, n1, n2, attn, q, k, v, o, f1, f2)
+        if hd is None or any(p._forward_hooks or p._forward_pre_hooks for p in proj + [attn, n1, n2, block]):
+            return None
+        if any(p.weight.dtype != amp_dtype or p.weight.device.type != "cuda" for p in proj) or amp_dtype not in (torch.bfloat16, torch.float16):
+            return None
+        if (input_others or {}).get("past_key_values") is not None:
+            return None
+        b = [p.bias for p in (q, k, v)]
+        if any(x is not None for x in b) and not all(x is not None for x in b):
+            return None
+        self = cls()
+        self.block, self.arena, self.arenas, self.attn, self.layers = block, None, [], attn, {}
+        self.n1, self.n2 = n1, n2
+        self.hq = self.hkv = q.out_features // hd
+        self.hd, self.H, self.Fdim = hd, q.in_features, f1.out_features
+        self.qscale = float(getattr(attn, "scaling", hd ** -0.5))
+        self.scaling = 1.0
+        self.dtype = amp_dtype
+        self.sdpa_ctx = sdpa_ctx
+        self.aq = dict(qkv=None, o=None, f1=None, f2=None)
+        self.order = ["q", "k", "v"]
+        self.Wqkv = torch.cat([q.weight, k.weight, v.weight], dim=0)
+        self.Wo, self.W1, self.W2 = o.weight, f1.weight, f2.weight
+        self.b_qkv = None if q.bias is None else torch.cat([q.bias, k.bias, v.bias]).to(amp_dtype)
+        self.b_o, self.b_1, self.b_2 = (None if p.bias is None else p.bias.to(amp_dtype) for p in (o, f1, f2))
+        return self
+
+    def _ln(self, n, x2d, want_stats):
+        dt = self.dtype
+        return ops.layernorm_fwd(x2d, n.weight.to(dt), None if n.bias is None else n.bias.to(dt), float(n.eps), want_stats=want_stats)
+
+    def _forward_impl(self, x, others, ctx):
+        from .wrapper import act_quant_fwd_raw
+
+        B, S, H = x.shape
+        T = B * S
+        aq = self.aq
+
+        def fq(t, plan):
+            return t if plan is None else act_quant_fwd_raw(t, plan)
+
+        x2d = x.reshape(T, H)
+        if x2d.dtype != self.dtype:
+            x2d = x2d.to(self.dtype)
+        x2d = x2d.contiguous()
+        mask = others.get("attention_mask")
+        h1, _, _ = self._ln(self.n1, x2d, False)
+        h1 = fq(h1, aq["qkv"])
+        qkv = F.linear(h1, self.Wqkv, self.b_qkv)
+        at = {n: i * H for i, n in enumerate(self.order)}
+        q2d = qkv[:, at["q"]:at["q"] + H] * self.qscale     # OPTAttention: q_proj(x) * scaling, in the activation dtype
+        k2d, v2d = qkv[:, at["k"]:at["k"] + H].contiguous(), qkv[:, at["v"]:at["v"] + H].contiguous()
+        del qkv
+        attn, leaves = self._attention(q2d, k2d, v2d, mask, B, S, grad=ctx is not None)
+        attn2d = attn.detach().transpose(1, 2).reshape(T, H)
+        attn_in = fq(attn2d, aq["o"])
+        x2 = self._linear_residual(x2d, attn_in, self.Wo, self.b_o)
+        h2, mean2, rstd2 = self._ln(self.n2, x2, ctx is not None)
+        h2_in = fq(h2, aq["f1"])
+        a = torch.relu_(F.linear(h2_in, self.W1, self.b_1))
+        a_in = fq(a, aq["f2"])
+        y = self._linear_residual(x2, a_in, self.W2, self.b_2)
+        if ctx is not None:
+            ctx.saved = dict(h1=h1, attn=attn, leaves=leaves, attn2d=attn2d, attn_in=attn_in, x2=x2, mean2=mean2, rstd2=rstd2, h2=h2,
+                             h2_in=h2_in, a=a, a_in=a_in, B=B, S=S)
+        return y.view(B, S, H)
+
+    def _backward_impl(self, ctx, dy):
+        from .wrapper import act_quant_bwd_raw
+
+        s = ctx.saved
+        ctx.saved = None
+        B, S = s["B"], s["S"]
+        T, H = B * S, self.H
+        L, aq = self.layers, self.aq
+
+        def bq(g, x, plan):
+            return g if plan is None else act_quant_bwd_raw(g, x, plan)
+
+        dy2d = dy.reshape(T, H)
+        if dy2d.dtype != self.dtype:
+            dy2d = dy2d.to(self.dtype)
+        dy2d = dy2d.contiguous()
+        # MLP
+        self._dw(dy2d, s.pop("a_in"), self.dW2, [L["f2"]])
+        a = s.pop("a")
+        da = bq(torch.mm(dy2d, self.W2), a, aq["f2"])
+        df = torch.ops.aten.threshold_backward(da, a, 0)     # ReLU
+        del da, a
+        self._dw(df, s.pop("h2_in"), self.dW1, [L["f1"]])
+        dh2 = bq(torch.mm(df, self.W1), s.pop("h2"), aq["f1"])
+        del df
+        dt = self.dtype
+        dx2 = ops.layernorm_bwd(dh2, s.pop("x2"), self.n2.weight.to(dt), s.pop("mean2"), s.pop("rstd2"), dres=dy2d, out=dh2)
+        # attention
+        self._dw(dx2, s.pop("attn_in"), self.dWo, [L["o"]])
+        dattn = bq(torch.mm(dx2, self.Wo), s.pop("attn2d"), aq["o"])
+        del dx2
+        attn, leaves = s.pop("attn"), s.pop("leaves")
+        dattn4 = dattn.view(B, S, self.hq, self.hd).transpose(1, 2)
+        if isinstance(leaves[0], str):
+            _, q2d, k2d, v2d, out2d, lse = leaves
+            h4 = lambda t: t.view(B, S, self.hq, self.hd).transpose(1, 2)
+            z = torch.zeros((), dtype=torch.int64)
+            dq, dk, dv, _ = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
+                dattn4, h4(q2d), h4(k2d), h4(v2d), None, h4(out2d), lse, z, z, 0.0, (True, True, True, False), True, scale=self.scaling)
+        else:
+            dq, dk, dv = torch.autograd.grad(attn, leaves, dattn4)
+        del attn, leaves, dattn
+        dqkv = torch.empty(T, 3 * H, dtype=self.dtype, device=dy2d.device)
+        grads = dict(q=dq, k=dk, v=dv)
+        for i, n in enumerate(self.order):
+            dst = dqkv[:, i * H:(i + 1) * H].view(B, S, self.hq, self.hd)
+            if n == "q":
+                torch.mul(grads[n].transpose(1, 2), self.qscale, out=dst)
+            else:
+                dst.copy_(grads[n].transpose(1, 2))
+        del dq, dk, dv, grads
+        self._dw(dqkv, s.pop("h1"), self.dWqkv, self.trio)
+
+
+def build_fused_block(block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True):
+    """The fused form of a wrapped block, whichever family recognises it (None: the generic module path)."""
+    for cls in (FusedLlamaBlock, FusedOPTBlock):
+        fb = cls.try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=use_mfma_dw)
+        if fb is not None:
+            return fb
+    return None
+
+
+def build_fused_block_plain(block, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None):
+    for cls in (FusedLlamaBlock, FusedOPTBlock):
+        fb = cls.try_build_plain(block, input_others, amp_dtype, sdpa_ctx=sdpa_ctx)
+        if fb is not None:
+            return fb
+    return None
 
 
 def mfma_dw_pays(M: int, N: int, K: int) -> bool:

@@ -361,6 +361,26 @@ def rmsnorm_bwd(dy2d, x2d, weight, rstd, dres=None, out=None):
     return dx
 
 
+def layernorm_fwd(x2d, weight, bias, eps, want_stats=True):
+    """-> (y [rows, H], mean [rows] fp32, rstd [rows] fp32) (stats None unless wanted)"""
+    rows, H = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device) if want_stats else None
+    _launch("ar_layernorm_fwd", _p(x2d, "x"), _p(weight, "weight"), _p(bias), _p(y), _p(mean), _p(rstd), rows, H, float(eps),
+            dt_code(x2d.dtype))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2d, x2d, weight, mean, rstd, dres=None, out=None):
+    """dx = d layernorm / dx applied to dy (+ dres) -> [rows, H]"""
+    rows, H = x2d.shape
+    dx = out if out is not None else torch.empty_like(x2d)
+    _launch("ar_layernorm_bwd", _p(dy2d, "dy"), _p(x2d, "x"), _p(weight, "weight"), _p(mean, "mean"), _p(rstd, "rstd"), _p(dres), _p(dx),
+            rows, H, dt_code(x2d.dtype))
+    return dx
+
+
 def swiglu_fwd(gu2d, F_):
     """gu2d [rows, >= 2F] (row stride = its stride(0)) -> a [rows, F] = silu(gu[:, :F]) * gu[:, F:2F]"""
     rows = gu2d.shape[0]

@@ -245,7 +245,7 @@ class SignRoundConfig:
     # cannot be sharded.  The reference's counterpart is its experimental DDP mode (utils/distributed.py).
     data_parallel: bool = False
     dp_overlap: bool = True              # dense blocks: per-layer gradient buckets all-reduced while the backward pass continues
-    # Run supported decoder blocks (Llama family: RMSNorm, rotary embedding, SwiGLU MLP, weight-only schemes) through the fused
+    # Run supported decoder blocks (Llama family: RMSNorm, rotary embedding, SwiGLU MLP; OPT family: LayerNorm, ReLU MLP) through the fused
     # HIP block path (auto_round_amd/fused_block.py) instead of transformers' module code -- the MI355X counterpart of the
     # reference's torch.compile(block_forward) (utils/device.py:112-122, compressors/base.py:1177-1179).  Same arithmetic per op,
     # different bf16 rounding points inside the block (trajectory-level parity, like the reference's compiled path); blocks it
@@ -373,10 +373,9 @@ class SignRoundQuantizer:
                 lyr._mfma_dw = bool(cfg.mfma_dw_gemm)
         fused = None
         if cfg.fused_block and cfg.amp:
-            from .fused_block import FusedLlamaBlock
+            from .fused_block import build_fused_block
 
-            fused = FusedLlamaBlock.try_build(block, arenas, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx,
-                                              use_mfma_dw=cfg.mfma_dw_gemm)
+            fused = build_fused_block(block, arenas, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx, use_mfma_dw=cfg.mfma_dw_gemm)
             if fused is not None:
                 fused.flash_fwd = bool(cfg.flash_attention)
         self.last_fused_block = fused is not None
@@ -554,9 +553,9 @@ class SignRoundQuantizer:
         bs = batch_size or self.config.batch_size
         fb = None
         if self.config.fused_block and self.config.amp and isinstance(input_others, dict):
-            from .fused_block import FusedLlamaBlock
+            from .fused_block import build_fused_block_plain
 
-            fb = FusedLlamaBlock.try_build_plain(block, input_others, self.config.amp_dtype, sdpa_ctx=self._sdpa_ctx)
+            fb = build_fused_block_plain(block, input_others, self.config.amp_dtype, sdpa_ctx=self._sdpa_ctx)
             if fb is not None:
                 fb.flash_fwd = bool(self.config.flash_attention)
         outs = []

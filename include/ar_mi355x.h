@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 11
+#define AR_ABI_VERSION 12
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -247,6 +247,14 @@ int ar_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd_out, int64
                    ar_stream_t stream);
 int ar_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx, int64_t rows,
                    int hidden, int dt, ar_stream_t stream);
+
+/* LayerNorm of OPT / GPT-style blocks (weight and bias, fp32 statistics, one rounding): nn.LayerNorm as transformers'
+ * OPTDecoderLayer calls it (modeling_opt.py: self_attn_layer_norm / final_layer_norm) and its autograd backward w.r.t. the input
+ * (+ an optional residual gradient); mean / rstd [rows] fp32 are written by the forward and read by the backward. */
+int ar_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean_out, float* rstd_out, int64_t rows, int hidden,
+                     float eps, int dt, ar_stream_t stream);
+int ar_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const void* dres, void* dx,
+                     int64_t rows, int hidden, int dt, ar_stream_t stream);
 int ar_swiglu_fwd(const void* gu, int64_t ld, void* a, int64_t rows, int64_t F, int dt, ar_stream_t stream);
 int ar_swiglu_bwd(const void* da, void* gu, int64_t ld, int64_t rows, int64_t F, int dt, ar_stream_t stream);
 int ar_rope_fwd(const void* qkv, int64_t ld, const void* cos, const void* sin, int64_t cs_batch_stride, void* q, void* k, void* v,

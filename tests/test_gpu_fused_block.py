@@ -407,3 +407,143 @@ def test_attention_path_avoids_the_broken_efficient_backward(S):
     for a, b in zip(g, exact):
         assert (a.float() - b).abs().max().item() <= 3e-2 * b.abs().max().item() + 1e-3
     assert str(backend_order("efficient", S)[0]).endswith("FLASH_ATTENTION")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# OPT-style blocks (LayerNorm, biased projections, ReLU MLP): BASELINE configs[0]'s block family
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,dt,bias", [(768, torch.bfloat16, True), (256, torch.float16, True), (4096, torch.bfloat16, False),
+                                       (2048, torch.bfloat16, True), (8192, torch.bfloat16, True)])
+def test_layernorm_fwd_bwd_vs_fp32_torch(H, dt, bias):
+    from auto_round_amd import ops
+
+    T = 70
+    x = _rand(T, H, seed=1, scale=1.5, dtype=dt) + 0.3
+    w = (1.0 + 0.1 * _rand(H, seed=2).float()).to(dt)
+    b = (0.1 * _rand(H, seed=5).float()).to(dt) if bias else None
+    y, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-5)
+    xf = x.float()
+    ref = torch.nn.functional.layer_norm(xf, (H,), w.float(), None if b is None else b.float(), 1e-5)
+    assert torch.allclose(mean, xf.mean(-1), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rstd, torch.rsqrt(xf.var(-1, unbiased=False) + 1e-5), rtol=1e-5, atol=0)
+    assert torch.equal(y, ref.to(dt)) or (y == ref.to(dt)).float().mean().item() > 0.995      # one rounding, at the store
+    assert torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2)
+    y2, m2, r2 = ops.layernorm_fwd(x, w, b, 1e-5, want_stats=False)
+    assert torch.equal(y2, y) and m2 is None and r2 is None
+    dy, dres = _rand(T, H, seed=3, dtype=dt), _rand(T, H, seed=4, dtype=dt)
+    xr = xf.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (H,), w.float(), None, 1e-5)
+    (gx,) = torch.autograd.grad(yr, xr, dy.float())
+    dx = ops.layernorm_bwd(dy, x, w, mean, rstd, dres=dres)
+    want = gx + dres.float()
+    assert torch.allclose(dx.float(), want, rtol=2e-2, atol=2e-2)
+    assert (dx.float() - want).abs().mean().item() < 4e-3 * want.abs().mean().item() + 1e-6
+    dx2 = ops.layernorm_bwd(dy.clone(), x, w, mean, rstd)
+    assert torch.allclose(dx2.float(), gx, rtol=2e-2, atol=2e-2)
+    buf = dy.clone()
+    dx3 = ops.layernorm_bwd(buf, x, w, mean, rstd, dres=dres, out=buf)      # in place over dy, as the block's backward uses it
+    assert dx3.data_ptr() == buf.data_ptr() and torch.equal(dx3, dx)
+
+
+def _opt_layer(hidden=256, ffn=512, heads=4, seed=0, bits=4, gs=32, bias=True):
+    from transformers import OPTConfig
+    from transformers.models.opt.modeling_opt import OPTDecoderLayer
+
+    torch.manual_seed(seed)
+    cfg = OPTConfig(hidden_size=hidden, ffn_dim=ffn, num_attention_heads=heads, num_hidden_layers=1, vocab_size=256,
+                    max_position_embeddings=256, word_embed_proj_dim=hidden, enable_bias=bias)
+    cfg._attn_implementation = "sdpa"
+    layer = OPTDecoderLayer(cfg).to(torch.bfloat16).eval().to(_dev())
+    with torch.no_grad():       # non-trivial LayerNorm affine and biases
+        for n, p in layer.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(0.05 * torch.randn_like(p.float()))
+            elif "layer_norm.weight" in n:
+                p.copy_(1.0 + 0.1 * torch.randn_like(p.float()))
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.bits, m.group_size, m.sym, m.data_type, m.scale_dtype, m.act_bits = bits, gs, True, "int", torch.float16, 16
+    return layer, cfg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bias,act", [(True, None), (False, None), (True, (8, 32, True))])
+def test_fused_opt_block_forward_and_weight_gradients_match_the_module_path(bias, act):
+    from auto_round_amd.fused_block import FusedOPTBlock, build_fused_block
+    from auto_round_amd.quantizer import block_forward
+    from auto_round_amd.wrapper import unwrapper_block, wrapper_block
+
+    layer, cfg = _opt_layer(bias=bias)
+    X, others = _rand(4, 64, cfg.hidden_size, seed=1), {}
+    blk = copy.deepcopy(layer)
+    if act is not None:
+        _set_int_act(blk, *act)
+    wrapper_block(blk, True, False, device="cuda")
+    arenas = blk._ar_arenas
+    fb = build_fused_block(blk, arenas, others, torch.bfloat16)
+    assert isinstance(fb, FusedOPTBlock), "a transformers OPTDecoderLayer must be recognised"
+    pred_m = block_forward(blk, X, others, amp=True, amp_dtype=torch.bfloat16)
+    dpred = _rand(*pred_m.shape, seed=3, scale=0.1)
+    pred_m.backward(dpred)
+    dW_m = [a.dWq.clone() for a in arenas]
+    for a in arenas:
+        for lyr in a.layers:
+            lyr._dw_accum[0] = False
+        a.dWq.zero_()
+    pred_f = fb.forward(X, others)
+    pred_f.backward(dpred)
+    assert all(lyr._dw_accum[0] for a in arenas for lyr in a.layers)
+    scale = pred_m.float().abs().mean().item()
+    assert pred_f.shape == pred_m.shape
+    assert (pred_f.float() - pred_m.float()).abs().max().item() < 0.05 * scale + 0.05
+    assert (pred_f.float() - pred_m.float()).abs().mean().item() < 5e-3 * scale
+    for a, m in zip(arenas, dW_m):
+        gsz = m.float().abs().mean().item()
+        assert (a.dWq.float() - m.float()).abs().mean().item() < (2e-2 if act is None else 6e-2) * gsz
+        cosine = torch.nn.functional.cosine_similarity(a.dWq.float(), m.float(), dim=0).item()
+        assert cosine > (0.999 if act is None else 0.995), cosine
+    unwrapper_block(blk, {})
+
+
+@pytest.mark.gpu
+def test_opt_blocks_the_fused_path_does_not_cover():
+    from auto_round_amd.fused_block import build_fused_block, build_fused_block_plain
+    from auto_round_amd.wrapper import unwrapper_block, wrapper_block
+
+    layer, cfg = _opt_layer()
+    blk = copy.deepcopy(layer)
+    blk.do_layer_norm_before = False                       # OPT-350m's post-norm form keeps the module path
+    wrapper_block(blk, True, False, device="cuda")
+    assert build_fused_block(blk, blk._ar_arenas, {}, torch.bfloat16) is None
+    unwrapper_block(blk, {})
+    blk = copy.deepcopy(layer)
+    blk.activation_fn = torch.nn.GELU()
+    assert build_fused_block_plain(blk, {}, torch.bfloat16) is None
+    assert build_fused_block_plain(layer, {}, torch.bfloat16) is not None
+
+
+@pytest.mark.gpu
+def test_tuning_an_opt_block_with_the_fused_path_tracks_the_generic_path():
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    layer, cfg = _opt_layer(bits=4, gs=32)
+    X, others = _rand(16, 32, cfg.hidden_size, seed=1), {}
+    res = {}
+    for fused in (False, True):
+        blk = copy.deepcopy(layer)
+        random.seed(7)
+        q = SignRoundQuantizer(SignRoundConfig(iters=20, batch_size=4, bits=4, lr=5e-3, minmax_lr=5e-3, fused_block=fused,
+                                               mfma_dw_gemm=fused), device="cuda")
+        fp_out, q_out, best = q.compress_block(blk, X, others)
+        assert q.last_fused_block is fused
+        res[fused] = (q.last_stats, q_out, fp_out)
+    sg, sf = res[False][0], res[True][0]
+    assert abs(sg["init_loss"] - sf["init_loss"]) <= 2e-2 * sg["init_loss"], (sg, sf)
+    assert sf["best_loss"] < 0.9 * sf["init_loss"] and abs(sg["best_loss"] - sf["best_loss"]) <= 0.15 * sg["best_loss"], (sg, sf)
+    err_g = (res[False][1].float() - res[False][2].float()).abs().mean().item()
+    err_f = (res[True][1].float() - res[True][2].float()).abs().mean().item()
+    assert abs(err_f - err_g) <= 0.15 * err_g, (err_f, err_g)
+    assert (res[False][1].float() - res[True][1].float()).abs().mean().item() <= 1.2 * err_g
+    assert (res[False][2].float() - res[True][2].float()).abs().mean().item() < 5e-3 * res[False][2].float().abs().mean().item()
