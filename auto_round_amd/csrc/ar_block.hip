@@ -358,6 +358,42 @@ __global__ __launch_bounds__(kTPB) void k_rope_bwd(const void* __restrict__ dq, 
     store8<DT>(dqkv, dst + d / 2, ohi);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 2-byte matrix transpose dst[c, r] = src[r, c] (rows, cols multiples of 64): a 64 x 64 tile through LDS.  Loads are 16 B per lane
+// (eight lanes cover 128 B of a source row), stores likewise (eight lanes cover 128 B of a destination row); the LDS row pitch of
+// 33 words keeps the column gather at two lanes per bank.  The fused block keeps W^T next to W so that the input-gradient GEMM
+// dX = dY W runs in the library's fast layout (both operands contiguous along the reduction).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kTrTile = 64, kTrPitch = 66;      // pitch in 2-byte elements
+
+__global__ __launch_bounds__(kTPB) void k_transpose16(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t rows, int64_t cols,
+                                                       int tiles_c) {
+    __shared__ uint32_t lds[kTrTile * kTrPitch / 2];
+    const int64_t tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+    const int64_t r0 = tr * kTrTile, c0 = tc * kTrTile;
+    const uint16_t* l16 = reinterpret_cast<const uint16_t*>(lds);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int idx = threadIdx.x + p * kTPB, r = idx >> 3, cc = idx & 7;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + (r0 + r) * cols + c0 + cc * 8);
+        uint32_t* w = lds + (r * kTrPitch + cc * 8) / 2;
+        w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int idx = threadIdx.x + p * kTPB, oc = idx >> 3, rr = idx & 7;
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = l16[(rr * 8 + 2 * j) * kTrPitch + oc], hi = l16[(rr * 8 + 2 * j + 1) * kTrPitch + oc];
+            o[j] = lo | (hi << 16);
+        }
+        const u32x4_t v = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<u32x4_t*>(dst + (c0 + oc) * rows + r0 + rr * 8) = v;
+    }
+}
+
 static inline int grid1d(int64_t n) { return (int)((n + kTPB - 1) / kTPB); }
 
 }  // namespace ar
@@ -428,6 +464,15 @@ extern "C" int ar_layernorm_bwd(const void* dy, const void* x, const void* w, co
     else AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_bwd<DT, 16>), grid, kTPB, 0, st, dy, x, w, mean, rstd, dres, dx, rows, hidden)
     AR_DT_SWITCH2(dt, AR_CALL)
 #undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_transpose16(const void* src, void* dst, int64_t rows, int64_t cols, ar_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return AR_OK;
+    if (rows % kTrTile || cols % kTrTile || !src || !dst || (rows / kTrTile) * (cols / kTrTile) > 0x7fffffffLL) return AR_ERR_UNSUPPORTED;
+    const int tiles_c = (int)(cols / kTrTile);
+    hipLaunchKernelGGL(k_transpose16, (unsigned)((rows / kTrTile) * tiles_c), kTPB, 0, (hipStream_t)stream, (const uint16_t*)src,
+                       (uint16_t*)dst, rows, cols, tiles_c);
     return launch_status();
 }
 

@@ -44,10 +44,12 @@ class FusedLlamaBlock:
 
     def __init__(self):
         self.use_mfma_dw = True
+        self._tn = None
 
     # -- recognition ----------------------------------------------------------------------------------------------------
     @classmethod
-    def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True) -> Optional["FusedLlamaBlock"]:
+    def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True,
+                  tn_dx_gemm=True) -> Optional["FusedLlamaBlock"]:
         from .wrapper import WrapperLinear
 
         try:
@@ -135,7 +137,28 @@ class FusedLlamaBlock:
         self.b_gu = torch.cat([b.to(dt) for b in gu_bias]) if gu_bias[0] is not None else None
         self.b_o = None if o.orig_layer.bias is None else o.orig_layer.bias.to(dt)
         self.b_d = None if d.orig_layer.bias is None else d.orig_layer.bias.to(dt)
+        self._tn = None
+        self.set_tn_dx(tn_dx_gemm)
         return self
+
+    def set_tn_dx(self, on: bool):
+        """Keep W^T next to the o / gate-up / down weights (refreshed by one transpose kernel each per iteration) so that the three
+        input-gradient GEMMs dX = dY W run with both operands contiguous along the reduction -- the layout the library's tuned
+        kernel covers (1.52-1.58 PFLOP/s against 1.02-1.35 for the K-strided form on the Llama-3-8B shapes,
+        profiles/r02_dx_gemm_layout_probe.json).  Costs one extra copy of those weights in HBM."""
+        self._tn = None
+        if not on or self.arena is None:
+            return
+        ws = (self.Wo, self.Wgu, self.Wd)
+        if any(w.shape[0] % 64 or w.shape[1] % 64 or not w.is_contiguous() for w in ws) or min(min(w.shape) for w in ws) < 1024:
+            return
+        self._tn = [torch.empty((w.shape[1], w.shape[0]), dtype=w.dtype, device=w.device) for w in ws]
+
+    def _dx(self, dY2d, W, slot):
+        """dY @ W through the transposed copy when there is one"""
+        if self._tn is not None:
+            return torch.mm(dY2d, self._tn[slot].t())
+        return torch.mm(dY2d, W)
 
     @classmethod
     def try_build_plain(cls, block, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None) -> Optional["FusedLlamaBlock"]:
@@ -178,6 +201,7 @@ class FusedLlamaBlock:
                 return None
         self = cls()
         self.block, self.arena, self.attn, self.layers = block, None, attn, {}
+        self._tn = None
         self.aq = dict(qkv=None, o=None, gu=None, d=None)
         self.w1, self.eps1 = n1.weight, float(n1.variance_epsilon)
         self.w2, self.eps2 = n2.weight, float(n2.variance_epsilon)
@@ -237,11 +261,12 @@ class FusedLlamaBlock:
             return out, None
 
     @staticmethod
-    def _linear_residual(res2d, a2d, W, bias):
-        """res + a @ W^T (+ bias): the residual add rides in the GEMM epilogue (one rounding)."""
+    def _linear_residual(res2d, a2d, W, bias, inplace=False):
+        """res + a @ W^T (+ bias): the residual add rides in the GEMM epilogue (one rounding).  torch's out-of-place addmm first
+        copies `res` into the result; inplace=True accumulates into `res` itself."""
         if bias is None:
-            return torch.addmm(res2d, a2d, W.t())
-        return torch.addmm(res2d + bias, a2d, W.t())
+            return res2d.addmm_(a2d, W.t()) if inplace else torch.addmm(res2d, a2d, W.t())
+        return (res2d.add_(bias) if inplace else res2d + bias).addmm_(a2d, W.t())
 
     def _dw(self, dY2d, X2d, out2d, layers):
         """out (+)= dY^T X into the arena; `layers` are the wrapped layers whose slices `out2d` covers."""
@@ -261,11 +286,17 @@ class FusedLlamaBlock:
                 post()
 
     # -- the two directions -----------------------------------------------------------------------------------------------
-    def forward(self, x, input_others):
+    def forward(self, x, input_others, donate_input=False):
+        """donate_input: the caller's `x` is scratch (the tuning loop's gathered minibatch) and may be overwritten -- the first
+        residual GEMM then accumulates into it in place instead of into a copy of it."""
         for a in self.arenas:
             if not a.wq_fresh:
                 a.qdq_forward()
-        return _FusedBlockFn.apply(x, self.arena.token, self, input_others)
+        self._donated = bool(donate_input)
+        try:
+            return _FusedBlockFn.apply(x, self.arena.token, self, input_others)
+        finally:
+            self._donated = False
 
     @torch.no_grad()
     def forward_nograd(self, x, input_others):
@@ -288,6 +319,9 @@ class FusedLlamaBlock:
         def fq(t, plan):        # the GEMM's input: fake-quantised activations where the scheme has them
             return t if plan is None else act_quant_fwd_raw(t, plan)
 
+        if ctx is not None and self._tn is not None:
+            for w, wt in zip((self.Wo, self.Wgu, self.Wd), self._tn):
+                ops.transpose16(w, out=wt)
         h1, _ = ops.rmsnorm_fwd(x2d, self.w1, self.eps1, want_rstd=False)
         h1 = fq(h1, aq["qkv"])                       # (the block input needs no gradient: only the quantised form is kept)
         qkv = F.linear(h1, self.Wqkv, self.b_qkv)
@@ -296,7 +330,7 @@ class FusedLlamaBlock:
         attn, leaves = self._attention(q2d, k2d, v2d, mask, B, S, grad=ctx is not None)
         attn2d = attn.detach().transpose(1, 2).reshape(T, self.hq * self.hd)
         attn_in = fq(attn2d, aq["o"])
-        x2 = self._linear_residual(x2d, attn_in, self.Wo, self.b_o)
+        x2 = self._linear_residual(x2d, attn_in, self.Wo, self.b_o, inplace=ctx is not None and getattr(self, "_donated", False))
         h2, rstd2 = ops.rmsnorm_fwd(x2, self.w2, self.eps2, want_rstd=ctx is not None)
         h2_in = fq(h2, aq["gu"])
         gu = F.linear(h2_in, self.Wgu, self.b_gu)
@@ -327,16 +361,16 @@ class FusedLlamaBlock:
 
         # MLP
         self._dw(dy2d, s.pop("act_in"), self.dWd, [L["d"]])
-        da = bq(torch.mm(dy2d, self.Wd), s.pop("act"), aq["d"])
+        da = bq(self._dx(dy2d, self.Wd, 2), s.pop("act"), aq["d"])
         dgu = ops.swiglu_bwd_(da, s.pop("gu"), self.Fdim)
         del da
         self._dw(dgu, s.pop("h2_in"), self.dWgu, [L["g"], L["u"]])
-        dh2 = bq(torch.mm(dgu, self.Wgu), s.pop("h2"), aq["gu"])
+        dh2 = bq(self._dx(dgu, self.Wgu, 1), s.pop("h2"), aq["gu"])
         del dgu
         dx2 = ops.rmsnorm_bwd(dh2, s.pop("x2"), self.w2, s.pop("rstd2"), dres=dy2d, out=dh2)
         # attention
         self._dw(dx2, s.pop("attn_in"), self.dWo, [L["o"]])
-        dattn = bq(torch.mm(dx2, self.Wo), s.pop("attn2d"), aq["o"])
+        dattn = bq(self._dx(dx2, self.Wo, 0), s.pop("attn2d"), aq["o"])
         del dx2
         attn, leaves = s.pop("attn"), s.pop("leaves")
         dattn4 = dattn.view(B, S, self.hq, self.hd).transpose(1, 2)
@@ -516,7 +550,7 @@ class FusedOPTBlock(FusedLlamaBlock):
         attn, leaves = self._attention(q2d, k2d, v2d, mask, B, S, grad=ctx is not None)
         attn2d = attn.detach().transpose(1, 2).reshape(T, H)
         attn_in = fq(attn2d, aq["o"])
-        x2 = self._linear_residual(x2d, attn_in, self.Wo, self.b_o)
+        x2 = self._linear_residual(x2d, attn_in, self.Wo, self.b_o, inplace=ctx is not None and getattr(self, "_donated", False))
         h2, mean2, rstd2 = self._ln(self.n2, x2, ctx is not None)
         h2_in = fq(h2, aq["f1"])
         a = torch.relu_(F.linear(h2_in, self.W1, self.b_1))
@@ -581,13 +615,12 @@ class FusedOPTBlock(FusedLlamaBlock):
         self._dw(dqkv, s.pop("h1"), self.dWqkv, self.trio)
 
 
-def build_fused_block(block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True):
+def build_fused_block(block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True, tn_dx_gemm=True):
     """The fused form of a wrapped block, whichever family recognises it (None: the generic module path)."""
-    for cls in (FusedLlamaBlock, FusedOPTBlock):
-        fb = cls.try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=use_mfma_dw)
-        if fb is not None:
-            return fb
-    return None
+    fb = FusedLlamaBlock.try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=use_mfma_dw, tn_dx_gemm=tn_dx_gemm)
+    if fb is None:
+        fb = FusedOPTBlock.try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=use_mfma_dw)
+    return fb
 
 
 def build_fused_block_plain(block, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None):

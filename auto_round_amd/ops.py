@@ -381,6 +381,16 @@ def layernorm_bwd(dy2d, x2d, weight, mean, rstd, dres=None, out=None):
     return dx
 
 
+def transpose16(src2d, out=None):
+    """[R, C] bf16 / fp16 (contiguous, R and C multiples of 64) -> [C, R]; None when the shape is not covered"""
+    R, C = src2d.shape
+    if R % 64 or C % 64 or src2d.element_size() != 2 or not src2d.is_contiguous():
+        return None
+    dst = out if out is not None else torch.empty((C, R), dtype=src2d.dtype, device=src2d.device)
+    _launch("ar_transpose16", _p(src2d, "src"), _p(dst, "dst"), R, C)
+    return dst
+
+
 def swiglu_fwd(gu2d, F_):
     """gu2d [rows, >= 2F] (row stride = its stride(0)) -> a [rows, F] = silu(gu[:, :F]) * gu[:, F:2F]"""
     rows = gu2d.shape[0]

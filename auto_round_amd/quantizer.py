@@ -258,6 +258,10 @@ class SignRoundConfig:
     # Inside the fused block: the causal attention forward on the hand-written flash-attention kernel (csrc/ar_attn.hip) instead of
     # torch's SDPA (AOTriton); the backward stays the library's, fed with this kernel's output and log-sum-exp rows.
     flash_attention: bool = True
+    # Inside the fused block: the input-gradient GEMMs dX = dY W of o / gate-up / down read a transposed copy of the fake-quant
+    # weights (one csrc/ar_block.hip transpose per weight per iteration) -- both operands contiguous along the reduction is the
+    # layout hipBLASLt's tuned gfx950 kernel covers (fused_block.FusedLlamaBlock.set_tn_dx).
+    tn_dx_gemm: bool = True
 
     def __post_init__(self):
         if self.iters < 0:
@@ -375,7 +379,8 @@ class SignRoundQuantizer:
         if cfg.fused_block and cfg.amp:
             from .fused_block import build_fused_block
 
-            fused = build_fused_block(block, arenas, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx, use_mfma_dw=cfg.mfma_dw_gemm)
+            fused = build_fused_block(block, arenas, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx, use_mfma_dw=cfg.mfma_dw_gemm,
+                                      tn_dx_gemm=cfg.tn_dx_gemm)
             if fused is not None:
                 fused.flash_fwd = bool(cfg.flash_attention)
         self.last_fused_block = fused is not None
@@ -476,7 +481,7 @@ class SignRoundQuantizer:
                 others_b = input_others
                 if per_sample_others:       # rows of this minibatch, like the reference's per-batch concatenation
                     others_b = {**input_others, **{k: t.index_select(0, idx) for k, t in per_sample_others.items()}}
-                pred = fused.forward(x, others_b) if fused is not None else self.block_forward(block, x, others_b)
+                pred = fused.forward(x, others_b, donate_input=True) if fused is not None else self.block_forward(block, x, others_b)      # x: scratch rows
                 pred_c = pred if pred.is_contiguous() else pred.contiguous()
                 if dpred is None or dpred.shape != pred_c.shape or dpred.dtype != pred_c.dtype:
                     dpred = torch.empty_like(pred_c)

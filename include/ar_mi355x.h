@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 12
+#define AR_ABI_VERSION 13
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -255,6 +255,10 @@ int ar_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float
                      float eps, int dt, ar_stream_t stream);
 int ar_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const void* dres, void* dx,
                      int64_t rows, int hidden, int dt, ar_stream_t stream);
+/* dst[c, r] = src[r, c] for 2-byte elements (bf16 / fp16 bit patterns), rows and cols multiples of 64.  The fused block keeps a
+ * transposed copy of each fake-quant weight so that the input-gradient GEMM of F.linear (auto_round/wrapper.py:528-556, autograd's
+ * dX = dY W) runs with both operands contiguous along the reduction. */
+int ar_transpose16(const void* src, void* dst, int64_t rows, int64_t cols, ar_stream_t stream);
 int ar_swiglu_fwd(const void* gu, int64_t ld, void* a, int64_t rows, int64_t F, int dt, ar_stream_t stream);
 int ar_swiglu_bwd(const void* da, void* gu, int64_t ld, int64_t rows, int64_t F, int dt, ar_stream_t stream);
 int ar_rope_fwd(const void* qkv, int64_t ld, const void* cos, const void* sin, int64_t cs_batch_stride, void* q, void* k, void* v,

@@ -547,3 +547,54 @@ def test_tuning_an_opt_block_with_the_fused_path_tracks_the_generic_path():
     assert abs(err_f - err_g) <= 0.15 * err_g, (err_f, err_g)
     assert (res[False][1].float() - res[True][1].float()).abs().mean().item() <= 1.2 * err_g
     assert (res[False][2].float() - res[True][2].float()).abs().mean().item() < 5e-3 * res[False][2].float().abs().mean().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,C,dt", [(64, 64, torch.bfloat16), (256, 1024, torch.float16), (4096, 1088, torch.bfloat16)])
+def test_transpose16_is_exact(R, C, dt):
+    from auto_round_amd import ops
+
+    x = _rand(R, C, seed=R + C, dtype=dt)
+    y = ops.transpose16(x)
+    assert y.shape == (C, R) and torch.equal(y, x.t().contiguous())
+    out = torch.empty(C, R, dtype=dt, device=_dev())
+    assert ops.transpose16(x, out=out) is out and torch.equal(out, y)
+    assert ops.transpose16(x[:, :32].contiguous()) is None and ops.transpose16(x.t()) is None      # shapes / strides it refuses
+
+
+@pytest.mark.gpu
+def test_fused_block_input_gradient_gemms_through_the_transposed_weights():
+    """tn_dx_gemm only changes which GEMM kernel computes dX = dY W: weight gradients agree with the K-strided form to GEMM
+    rounding, and the transposed copies follow the weights from iteration to iteration."""
+    from auto_round_amd.fused_block import FusedLlamaBlock
+    from auto_round_amd.wrapper import unwrapper_block, wrapper_block
+
+    layer, rope, cfg = _llama_layer(hidden=1024, ffn=2048, heads=8, kv_heads=4, gs=128)
+    X, others = _data(rope, cfg, N=2, S=64)
+    blk = copy.deepcopy(layer)
+    wrapper_block(blk, True, False, device="cuda")
+    arenas = blk._ar_arenas
+    fb = FusedLlamaBlock.try_build(blk, arenas, others, torch.bfloat16, tn_dx_gemm=True)
+    assert fb is not None and fb._tn is not None and [tuple(t.shape) for t in fb._tn] == [(1024, 1024), (1024, 4096), (2048, 1024)]
+    dpred = _rand(2, 64, 1024, seed=3, scale=0.1)
+    grads = {}
+    for tn in (True, False):
+        fb.set_tn_dx(tn)
+        for a in arenas:
+            for lyr in a.layers:
+                lyr._dw_accum[0] = False
+            a.dWq.zero_()
+        fb.forward(X, others).backward(dpred)
+        grads[tn] = arenas[0].dWq.clone()
+        if tn:
+            assert torch.equal(fb._tn[0], fb.Wo.t()) and torch.equal(fb._tn[1], fb.Wgu.t()) and torch.equal(fb._tn[2], fb.Wd.t())
+    ref = grads[False].float()
+    assert (grads[True].float() - ref).abs().mean().item() < 1e-2 * ref.abs().mean().item()
+    assert torch.nn.functional.cosine_similarity(grads[True].float(), ref, dim=0).item() > 0.9999
+    # a small block keeps the plain form (the copies would cost more than they save)
+    small, rope_s, cfg_s = _llama_layer()
+    blk_s = copy.deepcopy(small)
+    wrapper_block(blk_s, True, False, device="cuda")
+    assert FusedLlamaBlock.try_build(blk_s, blk_s._ar_arenas, _data(rope_s, cfg_s)[1], torch.bfloat16)._tn is None
+    unwrapper_block(blk, {})
+    unwrapper_block(blk_s, {})
