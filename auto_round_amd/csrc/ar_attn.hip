@@ -1,4 +1,4 @@
-// ar_attn.hip -- causal flash-attention forward for gfx950 (head dimension 128, bf16), token-major operands.
+// ar_attn.hip -- causal flash-attention forward for gfx950 (head dimension 128 or 64, bf16), token-major operands.
 //
 // replaces: the attention forward of the decoder block inside the tuning loop -- transformers' sdpa_attention_forward
 //           (transformers/integrations/sdpa_attention.py) -> torch scaled_dot_product_attention, which on ROCm 7.2 / torch 2.10 is
@@ -31,16 +31,18 @@ typedef __bf16 abf16x8_t __attribute__((ext_vector_type(8)));
 typedef float af32x16_t __attribute__((ext_vector_type(16)));
 
 constexpr int AK = 64;               // keys per tile
-constexpr int AD = 128;              // head dimension
-constexpr int AROW = AD * 2;         // bytes per staged key / value row
-constexpr int ATILE = AK * AROW;     // 16 KB: one operand's tile
-constexpr int ABUF = 2 * ATILE;      // K tile + V tile
-constexpr int ATTN_LDS = 2 * ABUF;   // double buffered: 64 KB
 
-// LDS swizzle of a staged row r: the 16-byte chunk index is XORed with the row's low four bits, bit pairs swapped -- 16 rows of a
-// ds_read_b128 group (distinct r & 15) and the 4 consecutive rows of a transposing read (distinct r & 3 -> distinct 64-byte blocks)
-// both land on disjoint banks
-__device__ __forceinline__ int attn_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+// LDS swizzle of a staged row r: the 16-byte chunk index is XORed with bits of the row number so that the 16 rows of a
+// ds_read_b128 group and the 4 consecutive rows of a transposing read both land on disjoint banks (256 B of banks per pass).
+//   256-byte rows (D = 128): every row starts on bank 0 -> the row's low four bits, bit pairs swapped (distinct r & 15 for the
+//     b128 group; distinct r & 3 in the top two bits = distinct 64-byte blocks for the transposing read);
+//   128-byte rows (D = 64): rows alternate between the two halves of the banks, eight chunks per row -> three bits of r >> 1,
+//     rotated so that r and r + 2 (same half) differ in the top bit (the transposing read covers four chunks of each row).
+template <int D>
+__device__ __forceinline__ int attn_swz(int r) {
+    if constexpr (D == 128) return ((r & 3) << 2) | ((r >> 2) & 3);
+    else return (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+}
 
 // value of the other lane half (lane ^ 32) combined with this one, without touching LDS: v_permlane32_swap hands every lane both
 // halves' values.  (A ds_bpermute here would make the compiler drain the LDS-DMA of the next tile -- vmcnt(0) -- in front of it.)
@@ -66,11 +68,19 @@ struct AttnArgs {
 
 // WAVES waves of 32 queries per workgroup: 8 (256 queries, 512 threads) halves the K / V staging per wave and per query against 4 --
 // the LDS-DMA issue is the largest non-MFMA cost of the kernel (ablations in DESIGN.md) -- and is used whenever S % 256 == 0.
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
+template <int WAVES, int AD>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd(AttnArgs a) {
+    constexpr int AROW = AD * 2;         // bytes per staged key / value row
+    constexpr int ATILE = AK * AROW;     // one operand's tile (16 KB at D = 128)
+    constexpr int ABUF = 2 * ATILE;      // K tile + V tile; two of them (double buffering) are the kernel's LDS
+    constexpr int NKS = AD / 16;         // k-steps of the S^T product
+    constexpr int ND = AD / 32;          // d-tiles of O^T
     constexpr int AQ = 32 * WAVES;       // queries per workgroup
-    constexpr int RPW = AK / WAVES;      // tile rows staged per wave (16 or 8), 4 per DMA instruction
-    constexpr int NP = RPW / 4;
+    constexpr int RPW = AK / WAVES;      // tile rows staged per wave (16 or 8)
+    constexpr int RPI = 1024 / AROW;     // rows per DMA instruction (64 lanes x 16 B): 4 or 8
+    constexpr int CPR = AROW / 16;       // 16-byte chunks per row
+    constexpr int NP = RPW / RPI;
+    static_assert(NP >= 1, "a wave stages at least one DMA instruction per operand");
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,28 +109,28 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
 
     // ---- Q^T fragments (b-operand: n = query = lane & 31, k = d = 16 ks + 8 h .. +7), kept for the whole kernel
     const int myq = q0 + 32 * wave + lq;
-    abf16x8_t qf[8];
+    abf16x8_t qf[NKS];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
         const uint4 r = *reinterpret_cast<const uint4*>(Qb + (int64_t)myq * row_stride + 16 * ks + 8 * h);
         qf[ks] = __builtin_bit_cast(abf16x8_t, r);
     }
 
-    // ---- DMA: a tile is 64 rows of 256 B; one instruction moves 4 rows (lane -> row 4 p + (lane >> 4), physical chunk lane & 15).
-    // wave w moves rows RPW w .. RPW w + RPW - 1 of the K tile and of the V tile.  Per-lane element offsets
+    // ---- DMA: a tile is 64 rows of AROW bytes; one instruction moves RPI rows (lane -> row RPI p + lane / CPR, physical chunk
+    // lane % CPR).  wave w moves rows RPW w .. RPW w + RPW - 1 of the K tile and of the V tile.  Per-lane element offsets
     // are fixed; the tile base pointers are uniform and advance by 64 rows per tile.
-    const int drow = lane >> 4, pchunk = lane & 15;
+    const int drow = lane / CPR, pchunk = lane % CPR;
     uint32_t doff[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int r = RPW * wave + 4 * p + drow;                   // row inside the tile
-        doff[p] = (uint32_t)(r * row_stride + (pchunk ^ attn_swz(r)) * 8);
+        const int r = RPW * wave + RPI * p + drow;                 // row inside the tile
+        doff[p] = (uint32_t)(r * row_stride + (pchunk ^ attn_swz<AD>(r)) * 8);
     }
     // piece j of 2 NP: K rows (j < NP) or V rows of this wave
     auto issue_piece = [&](int kt, int buf, int j) {
         const int p = j % NP;
         const uint16_t* T = (j < NP ? Kb : Vb) + (int64_t)kt * AK * row_stride;      // uniform
-        const uint32_t dst = lds0 + buf * ABUF + (j < NP ? 0 : ATILE) + (RPW * wave + 4 * p) * AROW;     // wave-uniform
+        const uint32_t dst = lds0 + buf * ABUF + (j < NP ? 0 : ATILE) + (RPW * wave + RPI * p) * AROW;   // wave-uniform
         __builtin_amdgcn_global_load_lds((const void*)(T + doff[p]), (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
     };
     auto issue_tile = [&](int kt, int buf) {
@@ -131,25 +141,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
     // ---- fragment read addresses: one register per k-step (K) / per d-tile (V^T, low and high key rows); buffer, key sub-tile and
     // 16-key step are immediate offsets of the read instructions (the swizzle of a row does not depend on them)
     // K (a-operand of S^T): m = key = 32 t + lq, k = d = 16 ks + 8 h .. +7 -> 16-byte chunk 2 ks + h of row key
-    uint32_t kA[8];
+    uint32_t kA[NKS];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kA[ks] = lds0 + lq * AROW + ((uint32_t)((2 * ks + h) ^ attn_swz(lq)) << 4);
+    for (int ks = 0; ks < NKS; ++ks) kA[ks] = lds0 + lq * AROW + ((uint32_t)((2 * ks + h) ^ attn_swz<AD>(lq)) << 4);
     // V^T (a-operand of O^T): m = d = 32 dt + (lane & 31), k = keys; lane group g = lane >> 4 supplies rows 16 st + 4 h + (i >> 2)
     // (+ 8 for the second half) and the 8-byte piece (i & 3) of the 16 columns 32 dt + 16 (g & 1) ..
     const int gi = lane & 15, gg = lane >> 4;
     const int vrow = 4 * h + (gi >> 2);
     const int vcol0 = 16 * (gg & 1) + 4 * (gi & 3);
-    uint32_t vAlo[4], vAhi[4];
+    uint32_t vAlo[ND], vAhi[ND];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int dt = 0; dt < ND; ++dt) {
         const int col = 32 * dt + vcol0;
-        vAlo[dt] = lds0 + vrow * AROW + ((uint32_t)((col >> 3) ^ attn_swz(vrow)) << 4) + (col & 7) * 2;
-        vAhi[dt] = lds0 + (vrow + 8) * AROW + ((uint32_t)((col >> 3) ^ attn_swz(vrow + 8)) << 4) + (col & 7) * 2;
+        vAlo[dt] = lds0 + vrow * AROW + ((uint32_t)((col >> 3) ^ attn_swz<AD>(vrow)) << 4) + (col & 7) * 2;
+        vAhi[dt] = lds0 + (vrow + 8) * AROW + ((uint32_t)((col >> 3) ^ attn_swz<AD>(vrow + 8)) << 4) + (col & 7) * 2;
     }
 
-    af32x16_t o[4];
+    af32x16_t o[ND];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
 #define AR_PINA() __builtin_amdgcn_sched_barrier(0)
 #define AR_KREAD(KS, T) if (!(AR_ATTN_ABL & 4)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(kf[(KS) & 3][T]) : "v"(kA[KS]), "n"(BUF * ABUF + (T) * 32 * AROW) : "memory")
 #define AR_VREAD(ST)                                                                                                     \
-    _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) if (!(AR_ATTN_ABL & 4))                                             \
+    _Pragma("unroll") for (int dt = 0; dt < ND; ++dt) if (!(AR_ATTN_ABL & 4))                                            \
         asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"                        \
                      : "=&v"(vlo[(ST) & 1][dt]), "=&v"(vhi[(ST) & 1][dt])                                                \
                      : "v"(vAlo[dt]), "v"(vAhi[dt]), "n"(BUF * ABUF + ATILE + (ST) * 16 * AROW) : "memory");
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
     auto tile = [&](auto bufc, int kt) {
         constexpr int BUF = decltype(bufc)::value;
         const int k0 = kt * AK;
-        // ---- S^T = K Q^T: 2 key sub-tiles x 8 k-steps; a ring of 4 k-steps of fragments, 6 reads in flight ahead of the MFMAs.
+        // ---- S^T = K Q^T: 2 key sub-tiles x NKS k-steps; a ring of 4 k-steps of fragments, 6 reads in flight ahead of the MFMAs.
         // A wait is tied to the registers it releases ("+v"): nothing else would keep the MFMAs behind it.
         af32x16_t s[2];
 #pragma unroll
@@ -179,11 +189,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
         u32x4_t kf[4][2];
         AR_KREAD(0, 0); AR_KREAD(0, 1); AR_KREAD(1, 0); AR_KREAD(1, 1); AR_KREAD(2, 0); AR_KREAD(2, 1);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            if (ks + 3 < 8) { AR_KREAD(ks + 3, 0); AR_KREAD(ks + 3, 1); }
-            if (ks <= 4) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(kf[ks & 3][0]), "+v"(kf[ks & 3][1])::"memory");
-            else if (ks == 5) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kf[ks & 3][0]), "+v"(kf[ks & 3][1])::"memory");
-            else if (ks == 6) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kf[ks & 3][0]), "+v"(kf[ks & 3][1])::"memory");
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 3 < NKS) { AR_KREAD(ks + 3, 0); AR_KREAD(ks + 3, 1); }
+            const int ahead = (ks + 3 < NKS ? ks + 3 : NKS - 1) - ks;         // k-steps of reads issued behind this one's
+            if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(kf[ks & 3][0]), "+v"(kf[ks & 3][1])::"memory");
+            else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(kf[ks & 3][0]), "+v"(kf[ks & 3][1])::"memory");
+            else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kf[ks & 3][0]), "+v"(kf[ks & 3][1])::"memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[ks & 3][0]), "+v"(kf[ks & 3][1])::"memory");
             if (!(AR_ATTN_ABL & 8)) {
             s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8_t, kf[ks & 3][0]), qf[ks], s[0], 0, 0, 0);
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
             AR_PINA();
         }
         // the V^T fragments of the first 32 keys do not depend on the softmax: their reads fly under it
-        as16x4_t vlo[2][4], vhi[2][4];
+        as16x4_t vlo[2][ND], vhi[2][ND];
         AR_VREAD(0)
         AR_VREAD(1)
         AR_PINA();
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
             typedef float af32x2 __attribute__((ext_vector_type(2)));
             const af32x2 a2 = {alpha, alpha};
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const af32x2 v = af32x2{o[dt][r], o[dt][r + 1]} * a2;
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
         }
         }
         AR_PINA();
-        // ---- O^T += V^T P^T: 4 k-steps of 16 keys (sub-tile t, half s2) x 4 d-tiles; two steps of fragments in flight
+        // ---- O^T += V^T P^T: 4 k-steps of 16 keys (sub-tile t, half s2) x ND d-tiles; two steps of fragments in flight
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const int t = st >> 1, s2 = st & 1;
@@ -252,15 +263,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
                 pb[e] = (short)(w & 0xffffu);
                 pb[e + 1] = (short)(w >> 16);
             }
-            if (st < 3) {
-                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vlo[st & 1][0]), "+v"(vhi[st & 1][0]), "+v"(vlo[st & 1][1]), "+v"(vhi[st & 1][1]),
-                             "+v"(vlo[st & 1][2]), "+v"(vhi[st & 1][2]), "+v"(vlo[st & 1][3]), "+v"(vhi[st & 1][3])::"memory");
+            // (the next step's 2 ND reads may stay in flight, except behind the last step)
+            if constexpr (ND == 4) {
+                if (st < 3) {
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vlo[st & 1][0]), "+v"(vhi[st & 1][0]), "+v"(vlo[st & 1][1]), "+v"(vhi[st & 1][1]),
+                                 "+v"(vlo[st & 1][2]), "+v"(vhi[st & 1][2]), "+v"(vlo[st & 1][3]), "+v"(vhi[st & 1][3])::"memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[st & 1][0]), "+v"(vhi[st & 1][0]), "+v"(vlo[st & 1][1]), "+v"(vhi[st & 1][1]),
+                                 "+v"(vlo[st & 1][2]), "+v"(vhi[st & 1][2]), "+v"(vlo[st & 1][3]), "+v"(vhi[st & 1][3])::"memory");
+                }
             } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[st & 1][0]), "+v"(vhi[st & 1][0]), "+v"(vlo[st & 1][1]), "+v"(vhi[st & 1][1]),
-                             "+v"(vlo[st & 1][2]), "+v"(vhi[st & 1][2]), "+v"(vlo[st & 1][3]), "+v"(vhi[st & 1][3])::"memory");
+                if (st < 3) {
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vlo[st & 1][0]), "+v"(vhi[st & 1][0]), "+v"(vlo[st & 1][1]), "+v"(vhi[st & 1][1])::"memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[st & 1][0]), "+v"(vhi[st & 1][0]), "+v"(vlo[st & 1][1]), "+v"(vhi[st & 1][1])::"memory");
+                }
             }
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < ND; ++dt) {
                 const as16x8_t va = __builtin_shufflevector(vlo[st & 1][dt], vhi[st & 1][dt], 0, 1, 2, 3, 4, 5, 6, 7);
                 if (!(AR_ATTN_ABL & 8)) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8_t, va), __builtin_bit_cast(abf16x8_t, pb),
                                                                 o[dt], 0, 0, 0);
@@ -290,7 +310,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd_d128(AttnArgs a) {
     const float inv = 1.0f / l_tot;
     uint16_t* orow = a.O + ((int64_t)(b * a.S + myq) * a.H + head) * AD;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint2 w;
@@ -307,18 +327,25 @@ using namespace ar;
 
 extern "C" int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H,
                            int64_t D, float scale, int causal, ar_stream_t stream) {
-    if (D != AD || !causal || S % 128 || B <= 0 || H <= 0 || S <= 0) return AR_ERR_UNSUPPORTED;
+    if ((D != 128 && D != 64) || !causal || S % 128 || B <= 0 || H <= 0 || S <= 0) return AR_ERR_UNSUPPORTED;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return AR_ERR_UNSUPPORTED;
     AttnArgs a;
     a.Q = (const uint16_t*)Q; a.K = (const uint16_t*)K; a.V = (const uint16_t*)V; a.O = (uint16_t*)O; a.LSE = LSE;
     a.B = (int)B; a.S = (int)S; a.H = (int)H;
     a.scale_log2e = scale * 1.4426950408889634f;
+    constexpr int LDS128 = 4 * AK * 128 * 2, LDS64 = 4 * AK * 64 * 2;      // 2 buffers x (K tile + V tile)
     static PerDeviceOnce attr;
     if (attr.first()) {
-        (void)hipFuncSetAttribute((const void*)k_attn_fwd_d128<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
-        (void)hipFuncSetAttribute((const void*)k_attn_fwd_d128<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
+        (void)hipFuncSetAttribute((const void*)k_attn_fwd<4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+        (void)hipFuncSetAttribute((const void*)k_attn_fwd<8, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
     }
-    if (S % 256 == 0) hipLaunchKernelGGL(k_attn_fwd_d128<8>, (int)(B * H * (S / 256)), 512, ATTN_LDS, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_attn_fwd_d128<4>, (int)(B * H * (S / 128)), 256, ATTN_LDS, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 128) {
+        if (S % 256 == 0) hipLaunchKernelGGL((k_attn_fwd<8, 128>), (int)(B * H * (S / 256)), 512, LDS128, st, a);
+        else hipLaunchKernelGGL((k_attn_fwd<4, 128>), (int)(B * H * (S / 128)), 256, LDS128, st, a);
+    } else {
+        if (S % 256 == 0) hipLaunchKernelGGL((k_attn_fwd<8, 64>), (int)(B * H * (S / 256)), 512, LDS64, st, a);
+        else hipLaunchKernelGGL((k_attn_fwd<4, 64>), (int)(B * H * (S / 128)), 256, LDS64, st, a);
+    }
     return launch_status();
 }

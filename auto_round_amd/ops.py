@@ -429,8 +429,8 @@ def rope_bwd(dq2d, dk2d, dv2d, cos, sin, batch, seq, hq, hkv, d, out=None):
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq: int, heads: int, head_dim: int, scale=None):
     """Causal attention forward on token-major operands q / k / v [batch * seq, heads * head_dim] (bf16, K / V already repeated to
     `heads`): -> (out [batch * seq, heads * head_dim], lse [batch, heads, seq] fp32), or None when the kernel does not take the
-    shape (head size other than 128, seq not a multiple of 128) -- the caller then keeps torch's SDPA."""
-    if q.dtype != torch.bfloat16 or head_dim != 128 or seq % 128 or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+    shape (head size other than 128 / 64, seq not a multiple of 128) -- the caller then keeps torch's SDPA."""
+    if q.dtype != torch.bfloat16 or head_dim not in (128, 64) or seq % 128 or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
         return None
     out = torch.empty_like(q)
     lse = torch.empty((batch, heads, seq), dtype=torch.float32, device=q.device)

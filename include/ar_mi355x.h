@@ -287,7 +287,7 @@ int ar_gemm_dw_config(int sem, int order);
  * replaces: the attention forward of the decoder block inside the tuning loop -- transformers' sdpa_attention_forward
  *           (transformers/integrations/sdpa_attention.py: torch scaled_dot_product_attention(q, k, v, is_causal=True)), which the
  *           reference reaches through block_forward (auto_round/utils/model.py block_forward, compressors/base.py:1177-1179).
- *           Q, K, V, O: [B, S, H, D] token-major bf16 (K / V already repeated to H heads), D = 128, S a multiple of 128;
+ *           Q, K, V, O: [B, S, H, D] token-major bf16 (K / V already repeated to H heads), D = 128 or 64, S a multiple of 128;
  *           LSE [B, H, S] fp32 = natural-log row sums of the scaled scores, the form
  *           aten::_scaled_dot_product_efficient_attention_backward consumes.  scale = 1/sqrt(D) for the stock models.
  *           Anything else (no causal mask, other head sizes) returns AR_ERR_UNSUPPORTED and the caller keeps torch's SDPA. */

@@ -343,8 +343,9 @@ def test_fused_nograd_forward_of_an_unwrapped_block_and_its_fallback_under_hooks
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,S,H", [(1, 128, 2), (2, 512, 4), (1, 2048, 3), (2, 1024, 8), (1, 768, 8)])      # 4- and 8-wave forms
-def test_attention_forward_vs_torch_sdpa(B, S, H):
+@pytest.mark.parametrize("B,S,H,D", [(1, 128, 2, 128), (2, 512, 4, 128), (1, 2048, 3, 128), (2, 1024, 8, 128), (1, 768, 8, 128),      # 4- and 8-wave forms
+                                     (1, 128, 3, 64), (2, 512, 4, 64), (1, 2048, 12, 64), (2, 1024, 8, 64), (1, 768, 5, 64)])
+def test_attention_forward_vs_torch_sdpa(B, S, H, D):
     """The hand-written causal flash-attention forward against torch's SDPA on the same token-major operands: output within bf16
     rounding of an fp32 softmax(QK^T)V, log-sum-exp rows equal to torch's to fp32 precision, and the library backward fed with this
     kernel's (out, lse) returns the gradients it returns for its own forward."""
@@ -352,7 +353,6 @@ def test_attention_forward_vs_torch_sdpa(B, S, H):
 
     from auto_round_amd import ops
 
-    D = 128
     q, k, v = (_rand(B * S, H * D, seed=21 + i) for i in range(3))
     res = ops.attn_fwd(q, k, v, B, S, H, D)
     assert res is not None
