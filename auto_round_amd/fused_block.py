@@ -149,10 +149,20 @@ class FusedLlamaBlock:
         self._tn = None
         if not on or self.arena is None:
             return
-        ws = (self.Wo, self.Wgu, self.Wd)
-        if any(w.shape[0] % 64 or w.shape[1] % 64 or not w.is_contiguous() for w in ws) or min(min(w.shape) for w in ws) < 1024:
+        ws = self._dx_weights()
+        if any(w.shape[0] % 64 or w.shape[1] % 64 or not w.is_contiguous() for w in ws) or min(min(w.shape) for w in ws) < self._tn_min_dim:
             return
         self._tn = [torch.empty((w.shape[1], w.shape[0]), dtype=w.dtype, device=w.device) for w in ws]
+
+    _tn_min_dim = 1024
+
+    def _dx_weights(self):
+        return (self.Wo, self.Wgu, self.Wd)
+
+    def _refresh_tn(self):
+        if self._tn is not None:
+            for w, wt in zip(self._dx_weights(), self._tn):
+                ops.transpose16(w, out=wt)
 
     def _dx(self, dY2d, W, slot):
         """dY @ W through the transposed copy when there is one"""
@@ -319,9 +329,8 @@ class FusedLlamaBlock:
         def fq(t, plan):        # the GEMM's input: fake-quantised activations where the scheme has them
             return t if plan is None else act_quant_fwd_raw(t, plan)
 
-        if ctx is not None and self._tn is not None:
-            for w, wt in zip((self.Wo, self.Wgu, self.Wd), self._tn):
-                ops.transpose16(w, out=wt)
+        if ctx is not None:
+            self._refresh_tn()
         h1, _ = ops.rmsnorm_fwd(x2d, self.w1, self.eps1, want_rstd=False)
         h1 = fq(h1, aq["qkv"])                       # (the block input needs no gradient: only the quantised form is kept)
         qkv = F.linear(h1, self.Wqkv, self.b_qkv)
@@ -425,7 +434,8 @@ class FusedOPTBlock(FusedLlamaBlock):
         return hd
 
     @classmethod
-    def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True) -> Optional["FusedOPTBlock"]:
+    def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True,
+                  tn_dx_gemm=True) -> Optional["FusedOPTBlock"]:
         from .wrapper import WrapperLinear, act_quant_plan
 
         parts = cls._parts(block)
@@ -483,7 +493,11 @@ class FusedOPTBlock(FusedLlamaBlock):
         dt = self.dtype
         self.b_qkv = torch.cat([b.to(dt) for b in qkv_bias]) if qkv_bias[0] is not None else None
         self.b_o, self.b_1, self.b_2 = (None if p.orig_layer.bias is None else p.orig_layer.bias.to(dt) for p in (o, f1, f2))
+        self.set_tn_dx(tn_dx_gemm)
         return self
+
+    def _dx_weights(self):          # (OPT-125M's 768-wide weights stay below _tn_min_dim: no gain measured there)
+        return (self.Wo, self.W1, self.W2)
 
     @classmethod
     def try_build_plain(cls, block, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None) -> Optional["FusedOPTBlock"]:
@@ -540,6 +554,8 @@ class FusedOPTBlock(FusedLlamaBlock):
             x2d = x2d.to(self.dtype)
         x2d = x2d.contiguous()
         mask = others.get("attention_mask")
+        if ctx is not None:
+            self._refresh_tn()
         h1, _, _ = self._ln(self.n1, x2d, False)
         h1 = fq(h1, aq["qkv"])
         qkv = F.linear(h1, self.Wqkv, self.b_qkv)
@@ -553,7 +569,7 @@ class FusedOPTBlock(FusedLlamaBlock):
         x2 = self._linear_residual(x2d, attn_in, self.Wo, self.b_o, inplace=ctx is not None and getattr(self, "_donated", False))
         h2, mean2, rstd2 = self._ln(self.n2, x2, ctx is not None)
         h2_in = fq(h2, aq["f1"])
-        a = torch.relu_(F.linear(h2_in, self.W1, self.b_1))
+        a = torch.relu_(F.linear(h2_in, self.W1, self.b_1))     # (bias + ReLU as a GEMM epilogue, torch._addmm_activation: no gain measured)
         a_in = fq(a, aq["f2"])
         y = self._linear_residual(x2, a_in, self.W2, self.b_2)
         if ctx is not None:
@@ -580,17 +596,17 @@ class FusedOPTBlock(FusedLlamaBlock):
         # MLP
         self._dw(dy2d, s.pop("a_in"), self.dW2, [L["f2"]])
         a = s.pop("a")
-        da = bq(torch.mm(dy2d, self.W2), a, aq["f2"])
+        da = bq(self._dx(dy2d, self.W2, 2), a, aq["f2"])
         df = torch.ops.aten.threshold_backward(da, a, 0)     # ReLU
         del da, a
         self._dw(df, s.pop("h2_in"), self.dW1, [L["f1"]])
-        dh2 = bq(torch.mm(df, self.W1), s.pop("h2"), aq["f1"])
+        dh2 = bq(self._dx(df, self.W1, 1), s.pop("h2"), aq["f1"])
         del df
         dt = self.dtype
         dx2 = ops.layernorm_bwd(dh2, s.pop("x2"), self.n2.weight.to(dt), s.pop("mean2"), s.pop("rstd2"), dres=dy2d, out=dh2)
         # attention
         self._dw(dx2, s.pop("attn_in"), self.dWo, [L["o"]])
-        dattn = bq(torch.mm(dx2, self.Wo), s.pop("attn2d"), aq["o"])
+        dattn = bq(self._dx(dx2, self.Wo, 0), s.pop("attn2d"), aq["o"])
         del dx2
         attn, leaves = s.pop("attn"), s.pop("leaves")
         dattn4 = dattn.view(B, S, self.hq, self.hd).transpose(1, 2)
@@ -619,7 +635,7 @@ def build_fused_block(block, arenas, input_others, amp_dtype=torch.bfloat16, sdp
     """The fused form of a wrapped block, whichever family recognises it (None: the generic module path)."""
     fb = FusedLlamaBlock.try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=use_mfma_dw, tn_dx_gemm=tn_dx_gemm)
     if fb is None:
-        fb = FusedOPTBlock.try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=use_mfma_dw)
+        fb = FusedOPTBlock.try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=use_mfma_dw, tn_dx_gemm=tn_dx_gemm)
     return fb
 
 
