@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -58,6 +58,8 @@ SIGNATURES = {
     "ar_swiglu_fwd": (c_int, [P, L, P, L, L, I, P]),
     "ar_swiglu_bwd": (c_int, [P, P, L, L, L, I, P]),
     "ar_rope_fwd": (c_int, [P, L, P, P, L, P, P, P, L, L, I, I, I, I, P]),
+    "ar_headnorm_fwd": (c_int, [P, P, P, P, P, L, L, I, I, I, F, I, P]),
+    "ar_headnorm_bwd": (c_int, [P, P, P, P, P, L, L, I, I, I, I, P]),
     "ar_transpose16": (c_int, [P, P, L, L, P]),
     "ar_rope_bwd": (c_int, [P, P, P, P, P, L, P, L, L, L, I, I, I, I, P]),
     "ar_gemm_dw": (c_int, [P, P, P, L, L, L, L, L, L, I, P, L, P]),

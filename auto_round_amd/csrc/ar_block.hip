@@ -100,6 +100,69 @@ __global__ __launch_bounds__(kTPB) void k_rmsnorm_bwd(const void* __restrict__ d
     }
 }
 
+// ---- per-head RMSNorm of q and k (Qwen3-style q_norm / k_norm) -----------------------------------------------------------------
+// qkv [tokens, ld]: heads 0 .. hq-1 are queries, hq .. hq+hkv-1 keys, the rest values; every query / key head (d elements) is
+// normalised on its own with the weight wq / wk [d] (Qwen3RMSNorm = LlamaRMSNorm on the last dimension), values are copied.
+// L = d / 8 lanes own one head (8 elements each), 64 / L heads per wave; the sum of squares is a DPP reduction inside the lane group.
+template <int DT, int L>
+__global__ __launch_bounds__(kTPB) void k_headnorm_fwd(const void* __restrict__ qkv, const void* __restrict__ wq, const void* __restrict__ wk,
+                                                        void* __restrict__ out, float* __restrict__ rstd_out, int64_t tokens, int64_t ld, int hq,
+                                                        int hkv, float eps) {
+    constexpr int D = L * kEPT;
+    const int heads = hq + 2 * hkv, nh = hq + hkv;
+    const int64_t item = ((int64_t)blockIdx.x * kTPB + threadIdx.x) / L;       // (token, head)
+    const int sub = threadIdx.x % L;
+    if (item >= tokens * heads) return;
+    const int64_t t = item / heads;
+    const int head = (int)(item % heads);
+    const int64_t at = t * ld + (int64_t)head * D + sub * kEPT;
+    const Raw8<DT> rx = load8_raw<DT>(qkv, at);
+    if (head >= nh) {                                                           // value head: copied (whole lane groups take this branch)
+        *reinterpret_cast<uint4*>(static_cast<uint16_t*>(out) + at) = rx.q;
+        return;
+    }
+    float v[8], wv[8], o[8];
+    unpack8<DT>(rx, v);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+    ss = group_sum<L>(ss);
+    const float rstd = 1.0f / __builtin_sqrtf(ss / (float)D + eps);
+    if (sub == 0 && rstd_out) rstd_out[t * nh + head] = rstd;
+    unpack8<DT>(load8_raw<DT>(head < hq ? wq : wk, (int64_t)sub * kEPT), wv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = wv[j] * round_to<DT>(v[j] * rstd);
+    store8<DT>(out, at, o);
+}
+
+// in place on the gradient: dqkv <- d(raw qkv) for the query / key heads (exact derivative of the norm, fp32, one rounding); value
+// heads are left as they are
+template <int DT, int L>
+__global__ __launch_bounds__(kTPB) void k_headnorm_bwd(void* __restrict__ dqkv, const void* __restrict__ qkv, const void* __restrict__ wq,
+                                                        const void* __restrict__ wk, const float* __restrict__ rstd_in, int64_t tokens,
+                                                        int64_t ld, int hq, int hkv) {
+    constexpr int D = L * kEPT;
+    const int nh = hq + hkv;
+    const int64_t item = ((int64_t)blockIdx.x * kTPB + threadIdx.x) / L;       // (token, query-or-key head)
+    const int sub = threadIdx.x % L;
+    if (item >= tokens * nh) return;
+    const int64_t t = item / nh;
+    const int head = (int)(item % nh);
+    const int64_t at = t * ld + (int64_t)head * D + sub * kEPT;
+    const float rstd = rstd_in[item];
+    float xv[8], gv[8], wv[8], o[8];
+    unpack8<DT>(load8_raw<DT>(qkv, at), xv);
+    unpack8<DT>(load8_raw<DT>(dqkv, at), gv);
+    unpack8<DT>(load8_raw<DT>(head < hq ? wq : wk, (int64_t)sub * kEPT), wv);
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dot += (gv[j] * wv[j]) * (xv[j] * rstd);
+    dot = group_sum<L>(dot) / (float)D;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = rstd * (gv[j] * wv[j] - (xv[j] * rstd) * dot);
+    store8<DT>(dqkv, at, o);
+}
+
 // ---- LayerNorm (OPT / GPT-style blocks) ---------------------------------------------------------------------------------------
 // y = dt(((x - mean) * rstd) * w + b)       (nn.LayerNorm under autocast runs in fp32 on the upcast input and the next Linear rounds
 // its input once: transformers/models/opt/modeling_opt.py OPTDecoderLayer.self_attn_layer_norm / final_layer_norm).  Two passes over
@@ -434,6 +497,38 @@ extern "C" int ar_rmsnorm_bwd(const void* dy, const void* x, const void* w, cons
     else AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_rmsnorm_bwd<DT, 16>), grid, kTPB, 0, st, dy, x, w, rstd, dres, dx, rows, hidden)
     AR_DT_SWITCH2(dt, AR_CALL)
 #undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_headnorm_fwd(const void* qkv, const void* wq, const void* wk, void* out, float* rstd_out, int64_t tokens, int64_t ld,
+                               int hq, int hkv, int d, float eps, int dt, ar_stream_t stream) {
+    if (tokens <= 0) return AR_OK;
+    const int L = d / kEPT;
+    if (d % kEPT || !(L == 8 || L == 16 || L == 32 || L == 64) || hq <= 0 || hkv <= 0 || ld % kEPT || ld < (int64_t)(hq + 2 * hkv) * d || !wq || !wk)
+        return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d(tokens * (hq + 2 * hkv) * L);
+#define AR_CALL_L(DT, LL) hipLaunchKernelGGL((k_headnorm_fwd<DT, LL>), grid, kTPB, 0, st, qkv, wq, wk, out, rstd_out, tokens, ld, hq, hkv, eps)
+#define AR_CALL(DT) switch (L) { case 8: AR_CALL_L(DT, 8); break; case 16: AR_CALL_L(DT, 16); break; case 32: AR_CALL_L(DT, 32); break; default: AR_CALL_L(DT, 64); }
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+#undef AR_CALL_L
+    return launch_status();
+}
+
+extern "C" int ar_headnorm_bwd(void* dqkv, const void* qkv, const void* wq, const void* wk, const float* rstd, int64_t tokens, int64_t ld,
+                               int hq, int hkv, int d, int dt, ar_stream_t stream) {
+    if (tokens <= 0) return AR_OK;
+    const int L = d / kEPT;
+    if (d % kEPT || !(L == 8 || L == 16 || L == 32 || L == 64) || hq <= 0 || hkv <= 0 || ld % kEPT || ld < (int64_t)(hq + 2 * hkv) * d || !wq || !wk || !rstd)
+        return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d(tokens * (hq + hkv) * L);
+#define AR_CALL_L(DT, LL) hipLaunchKernelGGL((k_headnorm_bwd<DT, LL>), grid, kTPB, 0, st, dqkv, qkv, wq, wk, rstd, tokens, ld, hq, hkv)
+#define AR_CALL(DT) switch (L) { case 8: AR_CALL_L(DT, 8); break; case 16: AR_CALL_L(DT, 16); break; case 32: AR_CALL_L(DT, 32); break; default: AR_CALL_L(DT, 64); }
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+#undef AR_CALL_L
     return launch_status();
 }
 

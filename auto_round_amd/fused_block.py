@@ -1,5 +1,5 @@
-"""Fused tuning-time forward / backward of a Llama-family decoder block (RMSNorm -> q/k/v -> rotary -> SDPA -> o -> residual ->
-RMSNorm -> SwiGLU MLP -> residual) and of an OPT-family one (LayerNorm -> q/k/v + bias -> SDPA -> out_proj -> residual -> LayerNorm
+"""Fused tuning-time forward / backward of a Llama-family decoder block (RMSNorm -> q/k/v [-> per-head q / k RMSNorm, Qwen3] ->
+rotary -> SDPA -> o -> residual -> RMSNorm -> SwiGLU MLP -> residual) and of an OPT-family one (LayerNorm -> q/k/v + bias -> SDPA -> out_proj -> residual -> LayerNorm
 -> fc1 -> ReLU -> fc2 -> residual; `FusedOPTBlock`) on MI355X.
 
 The reference speeds the same code up with `torch.compile(block_forward)` (auto_round/utils/device.py:112-122,
@@ -34,6 +34,19 @@ def _is_rmsnorm(m) -> bool:
             and getattr(m, "bias", None) is None)
 
 
+def _qk_norm(attn, hd):
+    """(wq, wk, eps) of Qwen3-style per-head q_norm / k_norm, None when the block has none, False when it has something else"""
+    qn, kn = getattr(attn, "q_norm", None), getattr(attn, "k_norm", None)
+    absent = [m is None or isinstance(m, torch.nn.Identity) for m in (qn, kn)]
+    if all(absent):
+        return None
+    if any(absent) or not (_is_rmsnorm(qn) and _is_rmsnorm(kn)) or hd not in (64, 128, 256, 512):
+        return False
+    if tuple(qn.weight.shape) != (hd,) or tuple(kn.weight.shape) != (hd,) or qn.variance_epsilon != kn.variance_epsilon:
+        return False
+    return qn.weight, kn.weight, float(qn.variance_epsilon)
+
+
 def _is_silu(act) -> bool:
     return "silu" in type(act).__name__.lower() or act is F.silu
 
@@ -45,6 +58,7 @@ class FusedLlamaBlock:
     def __init__(self):
         self.use_mfma_dw = True
         self._tn = None
+        self.qk_norm = None
 
     # -- recognition ----------------------------------------------------------------------------------------------------
     @classmethod
@@ -59,8 +73,6 @@ class FusedLlamaBlock:
             return None
         if not arenas or not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not _is_silu(getattr(mlp, "act_fn", None)):
             return None
-        if any(hasattr(attn, a) and not isinstance(getattr(attn, a), torch.nn.Identity) for a in ("q_norm", "k_norm")):
-            return None                                                    # Qwen3-style per-head norms: generic path
         if getattr(attn, "sliding_window", None) is not None:
             return None
         if not all(isinstance(p, WrapperLinear) for p in proj):
@@ -102,6 +114,9 @@ class FusedLlamaBlock:
         hq, hkv = q.out_features // hd, k.out_features // hd
         if hq % hkv or o.in_features != hq * hd or (g.out_features % 8) or (q.in_features % 8):
             return None
+        qk_norm = _qk_norm(attn, hd)
+        if qk_norm is False:
+            return None
         qkv_bias = [p.orig_layer.bias for p in (q, k, v)]
         if any(b is not None for b in qkv_bias) and not all(b is not None for b in qkv_bias):
             return None
@@ -115,6 +130,7 @@ class FusedLlamaBlock:
         self.w1, self.eps1 = n1.weight, float(n1.variance_epsilon)
         self.w2, self.eps2 = n2.weight, float(n2.variance_epsilon)
         self.hq, self.hkv, self.hd = hq, hkv, hd
+        self.qk_norm = qk_norm
         self.H, self.Fdim = q.in_features, g.out_features
         self.scaling = getattr(attn, "scaling", None)
         self.dtype = arena.w_dtype
@@ -184,8 +200,6 @@ class FusedLlamaBlock:
             return None
         if not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not _is_silu(getattr(mlp, "act_fn", None)):
             return None
-        if any(hasattr(attn, a) and not isinstance(getattr(attn, a), torch.nn.Identity) for a in ("q_norm", "k_norm")):
-            return None
         if getattr(attn, "sliding_window", None) is not None:
             return None
         if not all(type(p) is torch.nn.Linear for p in proj):
@@ -205,6 +219,9 @@ class FusedLlamaBlock:
         hq, hkv = q.out_features // hd, k.out_features // hd
         if hq % hkv or o.in_features != hq * hd or (g.out_features % 8) or (q.in_features % 8) or g.out_features != u.out_features:
             return None
+        qk_norm = _qk_norm(attn, hd)
+        if qk_norm is False or any(m is not None and (m._forward_hooks or m._forward_pre_hooks) for m in (getattr(attn, "q_norm", None), getattr(attn, "k_norm", None))):
+            return None
         for grp in ((q, k, v), (g, u)):
             b = [p.bias for p in grp]
             if any(x is not None for x in b) and not all(x is not None for x in b):
@@ -216,6 +233,7 @@ class FusedLlamaBlock:
         self.w1, self.eps1 = n1.weight, float(n1.variance_epsilon)
         self.w2, self.eps2 = n2.weight, float(n2.variance_epsilon)
         self.hq, self.hkv, self.hd = hq, hkv, hd
+        self.qk_norm = qk_norm
         self.H, self.Fdim = q.in_features, g.out_features
         self.scaling = getattr(attn, "scaling", None)
         self.dtype = amp_dtype
@@ -334,6 +352,11 @@ class FusedLlamaBlock:
         h1, _ = ops.rmsnorm_fwd(x2d, self.w1, self.eps1, want_rstd=False)
         h1 = fq(h1, aq["qkv"])                       # (the block input needs no gradient: only the quantised form is kept)
         qkv = F.linear(h1, self.Wqkv, self.b_qkv)
+        qkv_raw = rstd_qk = None
+        if self.qk_norm is not None:                 # Qwen3: RMSNorm of every query / key head before the rotation
+            wq, wk, eps_qk = self.qk_norm
+            qkv_raw = qkv
+            qkv, rstd_qk = ops.headnorm_fwd(qkv_raw, wq.to(self.dtype), wk.to(self.dtype), self.hq, self.hkv, self.hd, eps_qk)
         q2d, k2d, v2d = ops.rope_fwd(qkv, cos, sin, B, S, self.hq, self.hkv, self.hd)
         del qkv
         attn, leaves = self._attention(q2d, k2d, v2d, mask, B, S, grad=ctx is not None)
@@ -348,7 +371,7 @@ class FusedLlamaBlock:
         y = self._linear_residual(x2, act_in, self.Wd, self.b_d)
         if ctx is not None:
             ctx.saved = dict(h1=h1, attn=attn, leaves=leaves, attn2d=attn2d, attn_in=attn_in, x2=x2, rstd2=rstd2, h2=h2, h2_in=h2_in,
-                             gu=gu, act=act, act_in=act_in, cos=cos, sin=sin, B=B, S=S)
+                             gu=gu, act=act, act_in=act_in, cos=cos, sin=sin, B=B, S=S, qkv_raw=qkv_raw, rstd_qk=rstd_qk)
         return y.view(B, S, H)
 
     def _backward_impl(self, ctx, dy):
@@ -398,6 +421,9 @@ class FusedLlamaBlock:
 
         dqkv = ops.rope_bwd(tok(dq), tok(dk), tok(dv), s["cos"], s["sin"], B, S, self.hq, self.hkv, self.hd)
         del dq, dk, dv
+        if self.qk_norm is not None:
+            wq, wk, _ = self.qk_norm
+            ops.headnorm_bwd_(dqkv, s.pop("qkv_raw"), wq.to(self.dtype), wk.to(self.dtype), s.pop("rstd_qk"), self.hq, self.hkv, self.hd)
         self._dw(dqkv, s.pop("h1"), self.dWqkv, [L["q"], L["k"], L["v"]])
 
 

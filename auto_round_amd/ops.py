@@ -381,6 +381,23 @@ def layernorm_bwd(dy2d, x2d, weight, mean, rstd, dres=None, out=None):
     return dx
 
 
+def headnorm_fwd(qkv2d, wq, wk, hq, hkv, d, eps):
+    """q / k heads of qkv2d [tokens, (hq + 2 hkv) d] normalised per head (Qwen3 q_norm / k_norm), v copied -> (out, rstd [tokens, hq + hkv])"""
+    tokens = qkv2d.shape[0]
+    out = torch.empty_like(qkv2d)
+    rstd = torch.empty((tokens, hq + hkv), dtype=torch.float32, device=qkv2d.device)
+    _launch("ar_headnorm_fwd", _p(qkv2d, "qkv"), _p(wq, "wq"), _p(wk, "wk"), _p(out), _p(rstd), tokens, qkv2d.stride(0), hq, hkv, d, float(eps),
+            dt_code(qkv2d.dtype))
+    return out, rstd
+
+
+def headnorm_bwd_(dqkv2d, qkv2d, wq, wk, rstd, hq, hkv, d):
+    """in place: gradient w.r.t. the normalised q / k heads -> gradient w.r.t. the raw projection output"""
+    _launch("ar_headnorm_bwd", _p(dqkv2d, "dqkv"), _p(qkv2d, "qkv"), _p(wq, "wq"), _p(wk, "wk"), _p(rstd, "rstd"), dqkv2d.shape[0],
+            dqkv2d.stride(0), hq, hkv, d, dt_code(dqkv2d.dtype))
+    return dqkv2d
+
+
 def transpose16(src2d, out=None):
     """[R, C] bf16 / fp16 (contiguous, R and C multiples of 64) -> [C, R]; None when the shape is not covered"""
     R, C = src2d.shape

@@ -245,7 +245,7 @@ class SignRoundConfig:
     # cannot be sharded.  The reference's counterpart is its experimental DDP mode (utils/distributed.py).
     data_parallel: bool = False
     dp_overlap: bool = True              # dense blocks: per-layer gradient buckets all-reduced while the backward pass continues
-    # Run supported decoder blocks (Llama family: RMSNorm, rotary embedding, SwiGLU MLP; OPT family: LayerNorm, ReLU MLP) through the fused
+    # Run supported decoder blocks (Llama / Mistral / Qwen2 / Qwen3 family: RMSNorm, rotary embedding, SwiGLU MLP, optional q/k norms; OPT family: LayerNorm, ReLU MLP) through the fused
     # HIP block path (auto_round_amd/fused_block.py) instead of transformers' module code -- the MI355X counterpart of the
     # reference's torch.compile(block_forward) (utils/device.py:112-122, compressors/base.py:1177-1179).  Same arithmetic per op,
     # different bf16 rounding points inside the block (trajectory-level parity, like the reference's compiled path); blocks it

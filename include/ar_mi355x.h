@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 13
+#define AR_ABI_VERSION 14
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -255,6 +255,15 @@ int ar_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float
                      float eps, int dt, ar_stream_t stream);
 int ar_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, const void* dres, void* dx,
                      int64_t rows, int hidden, int dt, ar_stream_t stream);
+/* Per-head RMSNorm of the query and key heads of a merged projection output (Qwen3-style q_norm / k_norm:
+ * transformers/models/qwen3/modeling_qwen3.py Qwen3Attention.forward, `self.q_norm(self.q_proj(x).view(..., head_dim))`), as the
+ * reference reaches it through block_forward.  qkv / out [tokens, ld]: hq query heads, hkv key heads, hkv value heads of d
+ * elements (d in {64, 128, 256, 512}); wq / wk [d]; values are copied; rstd_out [tokens, hq + hkv] fp32.  The backward turns the
+ * gradient w.r.t. the normalised heads into the gradient w.r.t. the raw projection output in place (value heads untouched). */
+int ar_headnorm_fwd(const void* qkv, const void* wq, const void* wk, void* out, float* rstd_out, int64_t tokens, int64_t ld, int hq,
+                    int hkv, int d, float eps, int dt, ar_stream_t stream);
+int ar_headnorm_bwd(void* dqkv, const void* qkv, const void* wq, const void* wk, const float* rstd, int64_t tokens, int64_t ld, int hq,
+                    int hkv, int d, int dt, ar_stream_t stream);
 /* dst[c, r] = src[r, c] for 2-byte elements (bf16 / fp16 bit patterns), rows and cols multiples of 64.  The fused block keeps a
  * transposed copy of each fake-quant weight so that the input-gradient GEMM of F.linear (auto_round/wrapper.py:528-556, autograd's
  * dX = dY W) runs with both operands contiguous along the reduction. */

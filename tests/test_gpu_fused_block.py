@@ -598,3 +598,96 @@ def test_fused_block_input_gradient_gemms_through_the_transposed_weights():
     assert FusedLlamaBlock.try_build(blk_s, blk_s._ar_arenas, _data(rope_s, cfg_s)[1], torch.bfloat16)._tn is None
     unwrapper_block(blk, {})
     unwrapper_block(blk_s, {})
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Qwen3-style blocks: RMSNorm of every query / key head between the projection and the rotation
+@pytest.mark.gpu
+@pytest.mark.parametrize("hq,hkv,d,dt", [(4, 2, 64, torch.bfloat16), (8, 8, 128, torch.bfloat16), (2, 1, 256, torch.float16)])
+def test_headnorm_fwd_bwd_vs_fp32_torch(hq, hkv, d, dt):
+    from auto_round_amd import ops
+
+    T = 37
+    qkv = _rand(T, (hq + 2 * hkv) * d, seed=1, scale=2.0, dtype=dt)
+    wq, wk = ((1.0 + 0.2 * _rand(d, seed=s).float()).to(dt) for s in (2, 3))
+    out, rstd = ops.headnorm_fwd(qkv, wq, wk, hq, hkv, d, 1e-6)
+    x = qkv.float().view(T, hq + 2 * hkv, d)
+    r = torch.rsqrt(x[:, :hq + hkv].pow(2).mean(-1) + 1e-6)
+    assert torch.allclose(rstd, r, rtol=2e-6, atol=0)
+    w = torch.cat([wq.float().expand(hq, d), wk.float().expand(hkv, d)], 0)
+    ref = w * (x[:, :hq + hkv] * r.unsqueeze(-1)).to(dt).float()           # the module's two rounding points
+    o = out.view(T, hq + 2 * hkv, d)
+    assert torch.equal(o[:, hq + hkv:], qkv.view(T, -1, d)[:, hq + hkv:])   # values: copied
+    assert (o[:, :hq + hkv] == ref.to(dt)).float().mean().item() > 0.999
+    assert torch.allclose(o[:, :hq + hkv].float(), ref, rtol=1e-2, atol=1e-3)
+    # backward against autograd of the fp32 formula; the value heads' gradient passes through untouched
+    g = _rand(T, (hq + 2 * hkv) * d, seed=5, dtype=dt)
+    xr = x[:, :hq + hkv].clone().requires_grad_(True)
+    yr = w * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    (gx,) = torch.autograd.grad(yr, xr, g.float().view(T, -1, d)[:, :hq + hkv])
+    dq = ops.headnorm_bwd_(g.clone(), qkv, wq, wk, rstd, hq, hkv, d).view(T, -1, d)
+    assert torch.equal(dq[:, hq + hkv:], g.view(T, -1, d)[:, hq + hkv:])
+    assert torch.allclose(dq[:, :hq + hkv].float(), gx, rtol=2e-2, atol=2e-2)
+    assert (dq[:, :hq + hkv].float() - gx).abs().mean().item() < 4e-3 * gx.abs().mean().item() + 1e-6
+
+
+def _qwen3_layer(hidden=256, ffn=512, heads=4, kv_heads=2, head_dim=64, seed=0, bits=4, gs=32):
+    from transformers import Qwen3Config
+    from transformers.models.qwen3.modeling_qwen3 import Qwen3DecoderLayer, Qwen3RotaryEmbedding
+
+    torch.manual_seed(seed)
+    cfg = Qwen3Config(hidden_size=hidden, intermediate_size=ffn, num_attention_heads=heads, num_key_value_heads=kv_heads, head_dim=head_dim,
+                      num_hidden_layers=1, vocab_size=256, max_position_embeddings=256)
+    cfg._attn_implementation = "sdpa"
+    layer = Qwen3DecoderLayer(cfg, 0).to(torch.bfloat16).eval().to(_dev())
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            if "q_norm" in n or "k_norm" in n:
+                p.copy_(1.0 + 0.2 * torch.randn_like(p.float()))
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.bits, m.group_size, m.sym, m.data_type, m.scale_dtype, m.act_bits = bits, gs, True, "int", torch.float16, 16
+    return layer, Qwen3RotaryEmbedding(cfg).to(_dev()), cfg
+
+
+@pytest.mark.gpu
+def test_fused_block_with_per_head_qk_norms_matches_the_module_path():
+    from auto_round_amd.fused_block import FusedLlamaBlock
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer, block_forward
+    from auto_round_amd.wrapper import unwrapper_block, wrapper_block
+
+    layer, rope, cfg = _qwen3_layer()
+    X, others = _data(rope, cfg, N=4, S=64)
+    blk = copy.deepcopy(layer)
+    wrapper_block(blk, True, False, device="cuda")
+    arenas = blk._ar_arenas
+    fb = FusedLlamaBlock.try_build(blk, arenas, others, torch.bfloat16)
+    assert fb is not None and fb.qk_norm is not None, "a transformers Qwen3DecoderLayer must be recognised with its q / k norms"
+    pred_m = block_forward(blk, X, others, amp=True, amp_dtype=torch.bfloat16)
+    dpred = _rand(*pred_m.shape, seed=3, scale=0.1)
+    pred_m.backward(dpred)
+    dW_m = arenas[0].dWq.clone()
+    for lyr in arenas[0].layers:
+        lyr._dw_accum[0] = False
+    arenas[0].dWq.zero_()
+    pred_f = fb.forward(X, others)
+    pred_f.backward(dpred)
+    dW_f = arenas[0].dWq
+    scale = pred_m.float().abs().mean().item()
+    assert (pred_f.float() - pred_m.float()).abs().max().item() < 0.05 * scale + 0.05
+    assert (pred_f.float() - pred_m.float()).abs().mean().item() < 5e-3 * scale
+    assert (dW_f.float() - dW_m.float()).abs().mean().item() < 2e-2 * dW_m.float().abs().mean().item()
+    assert torch.nn.functional.cosine_similarity(dW_f.float(), dW_m.float(), dim=0).item() > 0.999
+    unwrapper_block(blk, {})
+    # the no-grad form for the unwrapped block (targets / quantised-output forwards)
+    qf = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=4, bits=4, fused_block=True), device="cuda")
+    qm = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=4, bits=4, fused_block=False), device="cuda")
+    assert FusedLlamaBlock.try_build_plain(layer, others, torch.bfloat16).qk_norm is not None
+    out_f, out_m = qf.forward_all(layer, X, others), qm.forward_all(layer, X, others)
+    assert (out_f.float() - out_m.float()).abs().mean().item() < 5e-3 * out_m.float().abs().mean().item()
+    # only one of the two norms: not this block's shape
+    odd = copy.deepcopy(layer)
+    odd.self_attn.k_norm = torch.nn.Identity()
+    assert FusedLlamaBlock.try_build_plain(odd, others, torch.bfloat16) is None
