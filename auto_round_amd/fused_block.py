@@ -73,8 +73,8 @@ class FusedLlamaBlock:
             return None
         if not arenas or not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not _is_silu(getattr(mlp, "act_fn", None)):
             return None
-        if getattr(attn, "sliding_window", None) is not None:
-            return None
+        # (a sliding window reaches the SDPA call only through `attention_mask` -- transformers' sdpa_attention_forward ignores the
+        # module's `sliding_window` -- and the mask is honoured below, so such blocks need nothing special)
         if not all(isinstance(p, WrapperLinear) for p in proj):
             return None
         q, k, v, o, g, u, d = proj
@@ -199,8 +199,6 @@ class FusedLlamaBlock:
         except AttributeError:
             return None
         if not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not _is_silu(getattr(mlp, "act_fn", None)):
-            return None
-        if getattr(attn, "sliding_window", None) is not None:
             return None
         if not all(type(p) is torch.nn.Linear for p in proj):
             return None

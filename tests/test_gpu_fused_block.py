@@ -691,3 +691,43 @@ def test_fused_block_with_per_head_qk_norms_matches_the_module_path():
     odd = copy.deepcopy(layer)
     odd.self_attn.k_norm = torch.nn.Identity()
     assert FusedLlamaBlock.try_build_plain(odd, others, torch.bfloat16) is None
+
+
+@pytest.mark.gpu
+def test_fused_block_honours_a_sliding_window_mask():
+    """Mistral-style blocks: the window lives in `attention_mask` (the SDPA interface ignores the module's `sliding_window`), which
+    the fused attention passes on exactly as the module path does."""
+    from transformers import MistralConfig
+    from transformers.models.mistral.modeling_mistral import MistralDecoderLayer, MistralRotaryEmbedding
+
+    from auto_round_amd.fused_block import FusedLlamaBlock
+    from auto_round_amd.quantizer import block_forward
+    from auto_round_amd.wrapper import unwrapper_block, wrapper_block
+
+    torch.manual_seed(0)
+    cfg = MistralConfig(hidden_size=256, intermediate_size=512, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=1,
+                        vocab_size=256, max_position_embeddings=256, sliding_window=16)
+    cfg._attn_implementation = "sdpa"
+    layer = MistralDecoderLayer(cfg, 0).to(torch.bfloat16).eval().to(_dev())
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    for m in layer.modules():
+        if isinstance(m, torch.nn.Linear):
+            m.bits, m.group_size, m.sym, m.data_type, m.scale_dtype, m.act_bits = 4, 32, True, "int", torch.float16, 16
+    S = 64
+    X, others = _data(MistralRotaryEmbedding(cfg).to(_dev()), cfg, N=4, S=S)
+    i = torch.arange(S, device=_dev())
+    keep = (i[None, :] <= i[:, None]) & (i[None, :] > i[:, None] - 16)
+    others["attention_mask"] = torch.zeros(S, S, device=_dev(), dtype=torch.bfloat16).masked_fill(~keep, float("-inf"))[None, None]
+    blk = copy.deepcopy(layer)
+    wrapper_block(blk, True, False, device="cuda")
+    fb = FusedLlamaBlock.try_build(blk, blk._ar_arenas, others, torch.bfloat16)
+    assert fb is not None
+    with torch.no_grad():
+        pred_m = block_forward(blk, X, others, amp=True, amp_dtype=torch.bfloat16)
+        causal = block_forward(blk, X, {**others, "attention_mask": None}, amp=True, amp_dtype=torch.bfloat16)
+    pred_f = fb.forward(X, others)
+    scale = pred_m.float().abs().mean().item()
+    assert (pred_f.float() - pred_m.float()).abs().mean().item() < 5e-3 * scale
+    assert (causal.float() - pred_m.float()).abs().mean().item() > 2e-2 * scale        # the window matters on this input
+    unwrapper_block(blk, {})
