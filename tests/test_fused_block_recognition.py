@@ -1,0 +1,88 @@
+"""Host logic of auto_round_amd/fused_block.py that needs no GPU: which decoder blocks the fused path recognises and which it
+leaves to the generic module path (the reference's counterpart, torch.compile(block_forward), takes every block:
+auto_round/utils/device.py:112-122), and that nothing is built on a CPU block."""
+import pytest
+import torch
+
+from auto_round_amd.fused_block import (FusedLlamaBlock, FusedOPTBlock, _is_rmsnorm, _is_silu, _qk_norm, build_fused_block,
+                                        build_fused_block_plain, mfma_dw_pays)
+
+
+def _qwen3(head_dim=64):
+    from transformers import Qwen3Config
+    from transformers.models.qwen3.modeling_qwen3 import Qwen3DecoderLayer
+
+    cfg = Qwen3Config(hidden_size=128, intermediate_size=256, num_attention_heads=2, num_key_value_heads=1, head_dim=head_dim,
+                      num_hidden_layers=1, vocab_size=64, max_position_embeddings=64)
+    return Qwen3DecoderLayer(cfg, 0)
+
+
+def _llama():
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaDecoderLayer
+
+    cfg = LlamaConfig(hidden_size=128, intermediate_size=256, num_attention_heads=2, num_key_value_heads=1, num_hidden_layers=1,
+                      vocab_size=64, max_position_embeddings=64)
+    return LlamaDecoderLayer(cfg, 0)
+
+
+def _opt(**kw):
+    from transformers import OPTConfig
+    from transformers.models.opt.modeling_opt import OPTDecoderLayer
+
+    cfg = OPTConfig(hidden_size=128, ffn_dim=256, num_attention_heads=2, num_hidden_layers=1, vocab_size=64, max_position_embeddings=64,
+                    word_embed_proj_dim=128, **kw)
+    return OPTDecoderLayer(cfg).eval()
+
+
+def test_per_head_qk_norms_are_recognised_only_in_the_qwen3_form():
+    blk = _qwen3()
+    wq, wk, eps = _qk_norm(blk.self_attn, 64)
+    assert wq is blk.self_attn.q_norm.weight and wk is blk.self_attn.k_norm.weight and eps == blk.self_attn.q_norm.variance_epsilon
+    assert _qk_norm(_llama().self_attn, 64) is None                       # no norms: plain Llama form
+    assert _qk_norm(blk.self_attn, 48) is False                           # a head size the kernel does not take
+    blk.self_attn.k_norm = torch.nn.Identity()
+    assert _qk_norm(blk.self_attn, 64) is False                           # only one of the two
+    blk = _qwen3()
+    blk.self_attn.q_norm = torch.nn.LayerNorm(64)
+    assert _qk_norm(blk.self_attn, 64) is False                           # another kind of norm
+    blk = _qwen3()
+    blk.self_attn.k_norm.variance_epsilon = 1e-3
+    assert _qk_norm(blk.self_attn, 64) is False                           # two epsilons: one kernel argument
+
+
+def test_norm_and_activation_predicates():
+    blk = _llama()
+    assert _is_rmsnorm(blk.input_layernorm) and not _is_rmsnorm(torch.nn.LayerNorm(8)) and not _is_rmsnorm(torch.nn.Identity())
+    assert _is_silu(blk.mlp.act_fn) and _is_silu(torch.nn.functional.silu) and not _is_silu(torch.nn.ReLU())
+
+
+def test_opt_blocks_shape_check():
+    blk = _opt()
+    n1, n2, attn, proj = FusedOPTBlock._parts(blk)
+    assert FusedOPTBlock._shape_ok(blk, n1, n2, attn, *proj) == 64
+    post = _opt(do_layer_norm_before=False)                               # OPT-350m's post-norm form
+    assert FusedOPTBlock._shape_ok(post, *FusedOPTBlock._parts(post)[:3], *FusedOPTBlock._parts(post)[3]) is None
+    gelu = _opt(activation_function="gelu")
+    assert FusedOPTBlock._shape_ok(gelu, *FusedOPTBlock._parts(gelu)[:3], *FusedOPTBlock._parts(gelu)[3]) is None
+    drop = _opt(dropout=0.1).train()                                      # dropout only matters in training mode
+    assert FusedOPTBlock._shape_ok(drop, *FusedOPTBlock._parts(drop)[:3], *FusedOPTBlock._parts(drop)[3]) is None
+    assert FusedOPTBlock._shape_ok(drop.eval(), *FusedOPTBlock._parts(drop)[:3], *FusedOPTBlock._parts(drop)[3]) == 64
+    assert FusedOPTBlock._parts(_llama()) is None
+
+
+def test_nothing_is_built_for_cpu_or_unwrapped_blocks():
+    """The fused path is a GPU path with no fallback arithmetic of its own: an unwrapped block, a block without arenas, CPU weights
+    and blocks of unknown shape all return None and the caller keeps the module path."""
+    for blk in (_llama(), _qwen3(), _opt(), torch.nn.Sequential(torch.nn.Linear(4, 4))):
+        assert build_fused_block(blk, [], {}, torch.bfloat16) is None
+        assert build_fused_block(blk, [object()], {}, torch.bfloat16) is None            # not wrapped: plain nn.Linear projections
+        assert build_fused_block_plain(blk.to(torch.bfloat16), {"position_embeddings": (torch.zeros(1, 4, 64), torch.zeros(1, 4, 64))},
+                                       torch.bfloat16) is None                             # CPU weights
+    assert FusedLlamaBlock.try_build_plain(_llama().to(torch.bfloat16), {}, torch.bfloat16) is None
+
+
+@pytest.mark.parametrize("M,N,K,want", [(4096, 4096, 16384, True), (768, 768, 16384, True), (4096, 4096, 1024, False),
+                                        (4000, 4096, 16384, False), (4096, 1000, 16384, False)])
+def test_the_mfma_weight_gradient_gemm_is_used_where_its_tiles_fit(M, N, K, want):
+    assert mfma_dw_pays(M, N, K) is want
