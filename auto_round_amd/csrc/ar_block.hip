@@ -538,11 +538,13 @@ extern "C" int ar_layernorm_fwd(const void* x, const void* w, const void* b, voi
     if (hidden <= 0 || hidden % kEPT || hidden > 16 * kWave * kEPT || !w) return AR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)((rows + 3) / 4);
-    const bool small = hidden <= 8 * kWave * kEPT;
-#define AR_CALL(DT)                                                                                                              \
-    if (small) AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_fwd<DT, 8>), grid, kTPB, 0, st, x, w, b, y, mean_out, rstd_out, rows, hidden, eps); \
-    else AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_fwd<DT, 16>), grid, kTPB, 0, st, x, w, b, y, mean_out, rstd_out, rows, hidden, eps)
+    // chunks of 8 per lane the row needs (2, 4, 8 or 16): the smallest instantiation keeps the register count, hence the number of
+    // rows in flight per CU, where a short row (OPT-125M: 768) needs it -- the kernel is a chain of dependent latencies
+    const int maxc = hidden <= 2 * kWave * kEPT ? 2 : hidden <= 4 * kWave * kEPT ? 4 : hidden <= 8 * kWave * kEPT ? 8 : 16;
+#define AR_CALL_C(DT, C) AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_fwd<DT, C>), grid, kTPB, 0, st, x, w, b, y, mean_out, rstd_out, rows, hidden, eps)
+#define AR_CALL(DT) switch (maxc) { case 2: AR_CALL_C(DT, 2); break; case 4: AR_CALL_C(DT, 4); break; case 8: AR_CALL_C(DT, 8); break; default: AR_CALL_C(DT, 16); }
     AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL_C
 #undef AR_CALL
     return launch_status();
 }
@@ -553,11 +555,11 @@ extern "C" int ar_layernorm_bwd(const void* dy, const void* x, const void* w, co
     if (hidden <= 0 || hidden % kEPT || hidden > 16 * kWave * kEPT || !mean || !rstd || !w) return AR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)((rows + 3) / 4);
-    const bool small = hidden <= 8 * kWave * kEPT;
-#define AR_CALL(DT)                                                                                                              \
-    if (small) AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_bwd<DT, 8>), grid, kTPB, 0, st, dy, x, w, mean, rstd, dres, dx, rows, hidden); \
-    else AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_bwd<DT, 16>), grid, kTPB, 0, st, dy, x, w, mean, rstd, dres, dx, rows, hidden)
+    const int maxc = hidden <= 2 * kWave * kEPT ? 2 : hidden <= 4 * kWave * kEPT ? 4 : hidden <= 8 * kWave * kEPT ? 8 : 16;
+#define AR_CALL_C(DT, C) AR_LAUNCH_PROF(AR_PROF_NORM, rows, (k_layernorm_bwd<DT, C>), grid, kTPB, 0, st, dy, x, w, mean, rstd, dres, dx, rows, hidden)
+#define AR_CALL(DT) switch (maxc) { case 2: AR_CALL_C(DT, 2); break; case 4: AR_CALL_C(DT, 4); break; case 8: AR_CALL_C(DT, 8); break; default: AR_CALL_C(DT, 16); }
     AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL_C
 #undef AR_CALL
     return launch_status();
 }

@@ -98,6 +98,34 @@ def main():
     q, k, v = ops.rope_fwd(qkv, cs, cs, 8, 2048, hq, hkv, d)
     t = timeit(lambda: ops.rope_bwd(q, k, v, cs, cs, 8, 2048, hq, hkv, d, out=qkv))
     res["rope_bwd_GBps"] = 2 * T * d * ((hq + 2 * hkv) + 3 * hq) / t / 1e6
+    # round-2 additions: per-head q / k norm (Qwen3 form of the same projection), LayerNorm (hidden 4096 and OPT-125M's 768),
+    # the 2-byte transpose of the merged gate / up weight, the attention forward at both head sizes
+    wh = torch.ones(d, device="cuda", dtype=torch.bfloat16)
+    t = timeit(lambda: ops.headnorm_fwd(qkv, wh, wh, hq, hkv, d, 1e-6))
+    res["headnorm_fwd_GBps"] = 4 * T * (hq + 2 * hkv) * d / t / 1e6
+    _, hr = ops.headnorm_fwd(qkv, wh, wh, hq, hkv, d, 1e-6)
+    dq_ = torch.randn_like(qkv)
+    t = timeit(lambda: ops.headnorm_bwd_(dq_, qkv, wh, wh, hr, hq, hkv, d))
+    res["headnorm_bwd_GBps"] = 6 * T * (hq + hkv) * d / t / 1e6
+    del dq_, hr
+    for Hn in (4096, 768):
+        xl = torch.randn(T, Hn, generator=g, device="cuda").to(torch.bfloat16)
+        wl = torch.ones(Hn, device="cuda", dtype=torch.bfloat16)
+        t = timeit(lambda: ops.layernorm_fwd(xl, wl, wl, 1e-5))
+        res[f"layernorm_h{Hn}_fwd_GBps"] = 4 * T * Hn / t / 1e6
+        yl, mean, rs = ops.layernorm_fwd(xl, wl, wl, 1e-5)
+        t = timeit(lambda: ops.layernorm_bwd(yl, xl, wl, mean, rs, dres=xl, out=yl))
+        res[f"layernorm_h{Hn}_bwd_add_GBps"] = 8 * T * Hn / t / 1e6
+    Wt_src = torch.randn(2 * Fd, H, generator=g, device="cuda").to(torch.bfloat16)
+    Wt_dst = torch.empty(H, 2 * Fd, device="cuda", dtype=torch.bfloat16)
+    t = timeit(lambda: ops.transpose16(Wt_src, out=Wt_dst))
+    res["transpose16_GBps"] = 4 * 2 * Fd * H / t / 1e6
+    del Wt_src, Wt_dst
+    for heads, hd in ((32, 128), (12, 64)):
+        qa, ka, va = (torch.randn(T, heads * hd, generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
+        t = timeit(lambda: ops.attn_fwd(qa, ka, va, 8, 2048, heads, hd))
+        res[f"attn_fwd_h{heads}_d{hd}_ms"] = t
+        res[f"attn_fwd_h{heads}_d{hd}_TFLOPs"] = 4 * 8 * heads * 2048 * 2048 * hd / 2 / t / 1e9      # causal: half the score matrix
     print(json.dumps({k: round(v, 3) for k, v in res.items()}))
 
 
