@@ -29,15 +29,25 @@ def _is_fused_experts(m: nn.Module) -> bool:
 
 def _linear_loop_forward(self, hidden_states: torch.Tensor, top_k_index: torch.Tensor, top_k_weights: torch.Tensor):
     """Same routing arithmetic as the fused implementation, one expert at a time through its nn.Linear children (which may be
-    tuning wrappers).  Experts that received no token are not called (their parameters get no gradient)."""
+    tuning wrappers).  Experts that received no token are not called (their parameters get no gradient).
+
+    The (token, slot) pairs are grouped by expert with ONE stable sort and one host read of the per-expert counts; each expert's
+    rows keep the order `torch.where(one_hot(top_k_index).permute(2, 1, 0)[e])` would give them (slot-major, then token) -- the
+    reference's order -- so every GEMM sees the same rows in the same places, without a device->host synchronisation per expert."""
     out = torch.zeros_like(hidden_states)
+    T, K = top_k_index.shape
     with torch.no_grad():
-        mask = torch.nn.functional.one_hot(top_k_index, num_classes=self.num_experts).permute(2, 1, 0)
-        hit = torch.greater(mask.sum(dim=(-1, -2)), 0).nonzero()[:, 0].tolist()
-    for e in hit:
-        if e >= self.num_experts:
+        flat = top_k_index.t().reshape(-1)                                  # index = slot * T + token
+        order = torch.argsort(flat, stable=True)
+        counts = torch.bincount(flat, minlength=self.num_experts).tolist()  # the one synchronisation
+    start = 0
+    for e, cnt in enumerate(counts):
+        if cnt == 0 or e >= self.num_experts:
+            start += cnt
             continue
-        pos, tok = torch.where(mask[e])
+        sel = order[start:start + cnt]
+        start += cnt
+        pos, tok = sel // T, sel % T
         ex = getattr(self, str(e))
         x = hidden_states[tok]
         h = self.act_fn(ex.gate_proj(x)) * ex.up_proj(x)

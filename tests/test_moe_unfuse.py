@@ -77,3 +77,44 @@ def test_unfusing_equals_the_reference_preparation():
     tok = torch.randint(0, 96, (2, 16), generator=torch.Generator().manual_seed(1))
     with torch.no_grad():
         assert torch.equal(a(input_ids=tok).logits, b(input_ids=tok).logits)
+
+
+def test_expert_grouping_keeps_the_reference_row_order():
+    """The loop groups (token, slot) pairs with one stable sort; every expert must see its rows in the order the reference's
+    `torch.where(one_hot(top_k_index).permute(2, 1, 0)[e])` yields (slot-major, then token), empty experts included -- the GEMM
+    row order is part of bit-for-bit parity.  Checked through the forward itself with recording experts."""
+    from auto_round_amd.moe_unfuse import _linear_loop_forward
+
+    class Rec(torch.nn.Module):
+        def __init__(self, log, e):
+            super().__init__()
+            self.log, self.e = log, e
+            self.gate_proj = self.up_proj = self.down_proj = self
+
+        def forward(self, x):
+            if x.shape[-1] == 4 and not self.log.get(("seen", self.e)):
+                self.log[("seen", self.e)] = True
+                self.log[self.e] = x[:, 0].clone()              # column 0 carries the token id
+            return x
+
+    g = torch.Generator().manual_seed(3)
+    for trial in range(20):
+        T, K, E = int(torch.randint(1, 33, (), generator=g)), 2, 6
+        idx = torch.stack([torch.randperm(E, generator=g)[:K] for _ in range(T)])
+        if trial % 3 == 0:
+            idx = idx.clamp(max=2)                               # experts 3..5 stay empty
+        log = {}
+        holder = torch.nn.Module()
+        holder.num_experts, holder.act_fn = E, torch.nn.Identity()
+        for e in range(E):
+            holder.add_module(str(e), Rec(log, e))
+        hidden = torch.zeros(T, 4)
+        hidden[:, 0] = torch.arange(T, dtype=torch.float32)
+        _linear_loop_forward(holder, hidden, idx, torch.ones(T, K))
+        mask = torch.nn.functional.one_hot(idx, num_classes=E).permute(2, 1, 0)
+        for e in range(E):
+            pos, tok = torch.where(mask[e])
+            if tok.numel() == 0:
+                assert e not in log                              # not called
+            else:
+                assert torch.equal(log[e], tok.float()), (trial, e)
