@@ -472,6 +472,7 @@ def main():
             "config": {"workload": workload_desc, "scheme": args.scheme or "int", "bits": b.bits, "group_size": b.gs, "sym": b.sym,
                        "iters": args.iters, "nsamples": N, "seqlen": S, "batch_size": args.batch_size,
                        "weights_per_block": n_w, "groups_per_block": G, "includes_packing": True, "flash_attention": bool(b.qcfg.flash_attention and b.qcfg.fused_block),
+                       "tn_dx_gemm": bool(b.qcfg.tn_dx_gemm and b.qcfg.fused_block), "mfma_dw_gemm": bool(b.qcfg.mfma_dw_gemm),
                        "fuse_next_forward": bool(args.fuse_next_forward), "fused_block": bool(getattr(b.quantizer, "last_fused_block", False)),
                        "sdpa_backend": args.sdpa, "alg_ext": bool(args.alg_ext),
                        "parallelism": (f"data-parallel inside the block x{world}" if dp else
