@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -42,7 +42,8 @@ SIGNATURES = {
     "ar_search_int_scale": (c_int, [P, P, L, P, I, P, P, L, I, I, I, F, P]),
     "ar_outlier_loss_workspace_bytes": (c_int64, []),
     "ar_outlier_mse_loss_fwd_bwd": (c_int, [P, P, P, P, P, F, L, I, F, P, L, L, P, P]),
-    "ar_best_loss_update": (c_int, [P, P, P, c_int32, P]),
+    "ar_best_loss_update": (c_int, [P, P, P, c_int32, P, P, P]),
+    "ar_iter_begin": (c_int, [P, P, I, P, P, I, I, P, P]),
     "ar_gather_rows": (c_int, [P, P, P, L, L, P]),
     "ar_pack_int": (c_int, [P, P, P, F, L, L, I, I, I, I, I, P, P, P, P]),
     "ar_pack_awq": (c_int, [P, P, P, F, L, L, I, I, I, P, P, P, P]),

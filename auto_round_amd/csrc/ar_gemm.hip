@@ -50,6 +50,8 @@ struct GemmArgs {
     int tiles_m, tiles_n, order;
     float* ws;           // split-K: fp32 partial tiles [nsplit][M][N] (caller-owned scratch), reduced in a fixed order afterwards
     int nsplit;
+    int tile0;           // > 0: split-K over the LAST tiles of the launch order only (tile0 = first of them); partial tiles are
+                         // then stored compactly, [tile - tile0][nsplit][256][256]
 };
 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& a, int bid, int& tm, int& tn) {
@@ -73,6 +75,10 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// The earlier generations (v0, v1, the timing ablations of v1, v4) are kept for tools/gemm_dw_probe.py only and are compiled only
+// with -DAR_GEMM_EXPERIMENTS (make EXTRA=-DAR_GEMM_EXPERIMENTS): the shipped library holds v3 alone, so nothing in a process can
+// switch the tuner's weight-gradient GEMM to another kernel.
+#ifdef AR_GEMM_EXPERIMENTS
 // SEM selects which (k-row, 4-column piece) a lane of a 16-lane group hands to the transposing read: 1 = row i>>2, piece i&3 --
 // the hardware's rule, pinned on the GPU by tools/mfma_probe (profiles/r02_mfma_probe.json: within a 16-lane group, lane L
 // receives element L%4 of the 8-byte pieces supplied by lanes L/4, L/4+4, L/4+8, L/4+12); 2 = row i&3, piece i>>2 (kept as the
@@ -519,6 +525,8 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw2_abl(GemmArgs a) {
 }
 
 
+#endif  // AR_GEMM_EXPERIMENTS
+
 // (v2 -- v1 with half of the fragment reads moved into the MFMA cluster so that both waves of a SIMD feed the LDS pipe all the
 //  time -- measured equal to v1 within noise on every shape, profiles/r02_gemm_dw_v2_split_reads_no_gain.jsonl, and was removed.)
 
@@ -542,8 +550,12 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     if (SPLITK) {
         sp = blockIdx.x % a.nsplit;
         const int tile = blockIdx.x / a.nsplit;
-        tm = tile / a.tiles_n;
-        tn = tile % a.tiles_n;
+        if (a.tile0 > 0) {
+            tile_of_block(a, a.tile0 + tile, tm, tn);      // the tail of the full launch's own tile order
+        } else {
+            tm = tile / a.tiles_n;
+            tn = tile % a.tiles_n;
+        }
         const int chunks = (a.K + 127) / 128;
         const int c0 = (int)((int64_t)chunks * sp / a.nsplit), c1 = (int)((int64_t)chunks * (sp + 1) / a.nsplit);
         krow0 = (int64_t)c0 * 128;
@@ -679,11 +691,13 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
 
     const int h = lane >> 5;
     if (SPLITK) {
-        float* wsp = a.ws + (int64_t)sp * a.M * a.N;
+        const bool compact = a.tile0 > 0;
+        float* wsp = compact ? a.ws + ((int64_t)(blockIdx.x / a.nsplit) * a.nsplit + sp) * (GB * GB) : a.ws + (int64_t)sp * a.M * a.N;
+        const int64_t wld = compact ? GB : a.N;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-            const int64_t m = m0 + wm * 64 + mi * 32 + (lane & 31);
-            float* rowp = wsp + m * a.N + n0 + wn * 128 + 4 * h;
+            const int64_t m = (compact ? 0 : m0) + wm * 64 + mi * 32 + (lane & 31);
+            float* rowp = wsp + m * wld + (compact ? 0 : n0) + wn * 128 + 4 * h;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -716,6 +730,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     }
 }
 
+#ifdef AR_GEMM_EXPERIMENTS
 // ---- v4: four waves, one per SIMD, 128 x 128 per wave; operands staged through registers -------------------------------------
 // What v3 taught (profiles/r02_gemm_dw_ablation.jsonl, r02_gemm_dw_pmc.json): with eight waves the fragment reads move 6 KB of LDS
 // per wave and K-step of 16 for 64x128 of output, and every LDS-DMA piece issued among the MFMAs stalls its wave for 60-185 issue
@@ -939,6 +954,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_dw5(GemmArgs a) {
     }
 }
 
+#endif  // AR_GEMM_EXPERIMENTS
+
 // sum of the split-K slices in slice order (+ the previous bf16 value when accumulating), one rounding to bf16
 __global__ __launch_bounds__(kTPB) void k_splitk_reduce(const float* __restrict__ ws, int nsplit, int64_t M, int64_t N, uint16_t* __restrict__ W,
                                                          int64_t ldw, int accumulate) {
@@ -964,7 +981,36 @@ __global__ __launch_bounds__(kTPB) void k_splitk_reduce(const float* __restrict_
     store8<AR_DT_BF16>(W, m * ldw + c * kEPT, v);
 }
 
+// the same for a hybrid launch: only the `ntail` last tiles of the launch order were split; their partial tiles lie compactly
+// [tile][nsplit][256][256].  32 workgroups per tile, one 16-byte piece of the result per lane.
+__global__ __launch_bounds__(kTPB) void k_splitk_reduce_tiles(GemmArgs a) {
+    const int t = blockIdx.x >> 5;
+    const int idx = (blockIdx.x & 31) * kTPB + threadIdx.x;          // 0 .. 8191: 256 rows x 32 pieces
+    const int ml = idx >> 5, c = idx & 31;
+    int tm, tn;
+    tile_of_block(a, a.tile0 + t, tm, tn);
+    const float* base = a.ws + (int64_t)t * a.nsplit * (GB * GB) + ml * GB + c * kEPT;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) {
+        float p[8];
+        unpack_f8(load8_f32(base, (int64_t)s * (GB * GB)), p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += p[j];
+    }
+    const int64_t off = ((int64_t)tm * GB + ml) * a.ldw + (int64_t)tn * GB + c * kEPT;
+    if (a.accumulate) {
+        float o[8];
+        unpack8<AR_DT_BF16>(load8_raw<AR_DT_BF16>(a.W, off), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += o[j];
+    }
+    store8<AR_DT_BF16>(a.W, off, v);
+}
+
 static int g_gemm_kernel = 7;     // 0: v0  1: v1 staggered  2: v1 lockstep  3: v2 (split reads)  4-6: timing ablations  7: v3 (DMA in the MFMA cluster)
+static int g_gemm_tail = 1;       // hybrid split of the last partial round (ar_gemm_dw_config(20 | 21) switches it for the A/B)
 static int g_gemm_sem = 1, g_gemm_order = 2;    // rule 1 is what the hardware does (profiles/r02_mfma_probe.json)
 
 }  // namespace ar
@@ -972,25 +1018,49 @@ static int g_gemm_sem = 1, g_gemm_order = 2;    // rule 1 is what the hardware d
 using namespace ar;
 
 extern "C" int ar_gemm_dw_config(int sem, int order) {      // experiment knobs (tools/gemm_dw_probe.py); -1 keeps a value
+#ifdef AR_GEMM_EXPERIMENTS
     if (sem == 1 || sem == 2) g_gemm_sem = sem;                 // v0 only: lane->piece rule (2 = negative control)
-    if (sem >= 10 && sem <= 19) g_gemm_kernel = sem - 10;       // ..., 17: v3, 18: v4 (4 loads units in flight), 19: v4 (8)       // 10: v0, 11: v1 staggered, 12: v1 lockstep, 13: v2 staggered
+    if (sem >= 10 && sem <= 19) g_gemm_kernel = sem - 10;       // 10: v0, 11: v1 staggered, 12: v1 lockstep, 14-16: ablations, 17: v3, 18 / 19: v4
+#endif
+    if (sem == 20 || sem == 21) g_gemm_tail = sem - 20;
     if (order >= 0 && order <= 2) g_gemm_order = order;
     return g_gemm_kernel * 100 + g_gemm_sem * 10 + g_gemm_order;
 }
 
-// split-K plan: only when the 256x256 tiles cannot fill the 256 CUs once and K is deep enough for slices of >= 512 rows
+// One 512-thread workgroup holds a CU (128 KB of LDS): 256 run at a time, and a launch of 256 r + t workgroups costs r + 1 rounds
+// however small t is.  The plan therefore never EXCEEDS a round: tiles x nsplit <= 256 (round 2 rounded the quotient up -- 288
+// workgroups for OPT-125M's 3072 x 768 weight, i.e. a second round for 32 of them).
+constexpr int kCUs = 256;
 static int splitk_plan(int64_t M, int64_t N, int64_t K) {
     if (M % GB || N % GB) return 1;
     const int64_t tiles = (M / GB) * (N / GB);
-    if (tiles >= 192 || K < 1024) return 1;
-    int64_t ns = (256 + tiles - 1) / tiles;
+    if (tiles > kCUs / 2 || K < 1024) return 1;
+    int64_t ns = kCUs / tiles;
     if (ns > K / 512) ns = K / 512;
     return ns < 2 ? 1 : (int)ns;
+}
+// Hybrid plan for many tiles: when the last round of the launch holds <= 128 tiles they are split along K so that the round is
+// full and 1 / nsplit as long (Llama-3-8B: the merged q/k/v weight is 384 tiles = 1.5 rounds, down_proj 896 = 3.5 rounds).
+// -> number of tail tiles (0: no hybrid), *ns = their split
+static int tail_plan(int64_t M, int64_t N, int64_t K, int* ns) {
+    *ns = 1;
+    if (M % GB || N % GB || K < 2048) return 0;
+    const int64_t tiles = (M / GB) * (N / GB);
+    const int r = (int)(tiles % kCUs);
+    if (tiles <= kCUs || r == 0 || r > kCUs / 2) return 0;
+    int64_t n = kCUs / r;
+    if (n > K / 1024) n = K / 1024;
+    if (n < 2) return 0;
+    *ns = (int)n;
+    return r;
 }
 
 extern "C" int64_t ar_gemm_dw_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     const int ns = splitk_plan(M, N, K);
-    return ns > 1 ? (int64_t)ns * M * N * 4 : 0;
+    if (ns > 1) return (int64_t)ns * M * N * 4;
+    int tns;
+    const int r = tail_plan(M, N, K, &tns);
+    return r ? (int64_t)r * tns * GB * GB * 4 : 0;
 }
 
 extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
@@ -1000,12 +1070,13 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
     if (K % 128 && g_gemm_kernel != 7) return AR_ERR_UNSUPPORTED;       // only the default kernel completes a ragged K with zeros
     if (((uintptr_t)dY | (uintptr_t)X) & 15 || ((uintptr_t)dW & 7)) return AR_ERR_UNSUPPORTED;
     GemmArgs a;
-    a.ws = nullptr; a.nsplit = 1;
+    a.ws = nullptr; a.nsplit = 1; a.tile0 = 0;
     a.Y = (const uint16_t*)dY; a.X = (const uint16_t*)X; a.W = (uint16_t*)dW;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = accumulate;
     a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = g_gemm_order;
     const int grid = a.tiles_m * a.tiles_n;
     hipStream_t st = (hipStream_t)stream;
+#ifdef AR_GEMM_EXPERIMENTS
     static PerDeviceOnce attr_done;
     if (attr_done.first()) {
         hipError_t e = hipFuncSetAttribute((const void*)k_gemm_dw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
@@ -1024,6 +1095,7 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
         else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw5<8, false>), grid, 256, GEMM_LDS, st, a);
         return launch_status();
     }
+#endif  // AR_GEMM_EXPERIMENTS
     if (g_gemm_kernel >= 1 && (K % 128 == 0 || g_gemm_kernel == 7) && K >= 128) {
         if (g_gemm_kernel == 7) {
             static PerDeviceOnce a4;
@@ -1042,10 +1114,21 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
                 hipLaunchKernelGGL(k_splitk_reduce, rgrid, kTPB, 0, st, a.ws, ns, M, N, a.W, ldw, accumulate);
                 return launch_status();
             }
+            int tns = 1;
+            const int rtail = (K % 128 == 0 && g_gemm_tail) ? tail_plan(M, N, K, &tns) : 0;
+            if (rtail && workspace && workspace_bytes >= (int64_t)rtail * tns * GB * GB * 4 && (ldw % 8) == 0 && !((uintptr_t)dW & 15)) {
+                // full rounds with the whole K, then the last (partial) round split along K, then its slices summed in order
+                AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true>), grid - rtail, GTHREADS, GEMM_LDS, st, a);
+                a.ws = (float*)workspace; a.nsplit = tns; a.tile0 = grid - rtail;
+                hipLaunchKernelGGL((k_gemm_dw4<true, true>), rtail * tns, GTHREADS, GEMM_LDS, st, a);
+                hipLaunchKernelGGL(k_splitk_reduce_tiles, rtail * 32, kTPB, 0, st, a);
+                return launch_status();
+            }
             if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, true>), grid, GTHREADS, GEMM_LDS, st, a);
             else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true>), grid, GTHREADS, GEMM_LDS, st, a);
             return launch_status();
         }
+#ifdef AR_GEMM_EXPERIMENTS
         if (g_gemm_kernel >= 4) {      // timing ablations (tools/gemm_dw_probe.py --ablate); outputs are not a product
             (void)hipFuncSetAttribute((const void*)k_gemm_dw2_abl<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
             (void)hipFuncSetAttribute((const void*)k_gemm_dw2_abl<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
@@ -1062,4 +1145,8 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
     if (g_gemm_sem == 1) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw<1>), grid, GTHREADS, GEMM_LDS, st, a);
     else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw<2>), grid, GTHREADS, GEMM_LDS, st, a);
     return launch_status();
+#else
+    }
+    return AR_ERR_UNSUPPORTED;      // K < 128
+#endif
 }

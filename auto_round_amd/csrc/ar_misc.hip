@@ -231,8 +231,9 @@ __global__ __launch_bounds__(kTPB) void k_outlier_mse(const void* __restrict__ p
 // ------------------------------------------------------------------------------------------------------------------
 // best-loss bookkeeping (one lane)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void k_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter) {
+__global__ void k_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter, int32_t* iter_dev, float* loss_hist) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (iter_dev) iter = *iter_dev;               // hipGraph replays: the iteration number lives on the device
     const float tl = *total_loss;
     if (iter == 0) state[1] = tl;
     state[2] = tl;
@@ -244,7 +245,19 @@ __global__ void k_best_loss_update(float* total_loss, float* state, int32_t* ist
     } else {
         istate[0] = 0;
     }
+    if (loss_hist) loss_hist[iter] = tl;
+    if (iter_dev) *iter_dev = iter + 1;
     *total_loss = 0.f;
+}
+
+// start of a tuning iteration whose host-side values come from device tables (one captured hipGraph replayed `iters` times):
+// this iteration's minibatch indices and learning rates are copied to the fixed addresses the captured kernels read
+__global__ void k_iter_begin(const int32_t* iter_dev, const int64_t* sched, int batch, int64_t* cur_idx, const float* lr_table,
+                             int n_lr, int iters, float* lr_out) {
+    const int it = *iter_dev;
+    if (it < 0 || it >= iters) return;
+    for (int j = threadIdx.x; j < batch; j += kWave) cur_idx[j] = sched[(int64_t)it * batch + j];
+    for (int j = threadIdx.x; j < n_lr; j += kWave) lr_out[j] = lr_table[(int64_t)j * iters + it];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -491,8 +504,17 @@ extern "C" int ar_outlier_mse_loss_fwd_bwd(const void* pred, const void* ref, vo
     return launch_status();
 }
 
-extern "C" int ar_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter, ar_stream_t stream) {
-    hipLaunchKernelGGL(k_best_loss_update, 1, kWave, 0, (hipStream_t)stream, total_loss, state, istate, iter);
+extern "C" int ar_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter, int32_t* iter_dev, float* loss_hist,
+                                   ar_stream_t stream) {
+    hipLaunchKernelGGL(k_best_loss_update, 1, kWave, 0, (hipStream_t)stream, total_loss, state, istate, iter, iter_dev, loss_hist);
+    return launch_status();
+}
+
+extern "C" int ar_iter_begin(const int32_t* iter_dev, const int64_t* sched, int batch, int64_t* cur_idx, const float* lr_table, int n_lr,
+                             int iters, float* lr_out, ar_stream_t stream) {
+    if (!iter_dev || batch < 0 || n_lr < 0 || iters <= 0 || (batch > 0 && (!sched || !cur_idx)) || (n_lr > 0 && (!lr_table || !lr_out)))
+        return AR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_iter_begin, 1, kWave, 0, (hipStream_t)stream, iter_dev, sched, batch, cur_idx, lr_table, n_lr, iters, lr_out);
     return launch_status();
 }
 

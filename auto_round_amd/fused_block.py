@@ -328,6 +328,27 @@ class FusedLlamaBlock:
     def forward_nograd(self, x, input_others):
         return self._forward_impl(x, input_others, None)
 
+    def forward_direct(self, x, input_others, donate_input=False):
+        """The tuning-time forward without an autograd node around it -> (y, ctx) for `backward_direct`: the same kernels in the same
+        order as `forward` + `.backward()`, as two plain calls (what a captured hipGraph of the iteration records)."""
+        import types
+
+        for a in self.arenas:
+            if not a.wq_fresh:
+                a.qdq_forward()
+        self._donated = bool(donate_input)
+        ctx = types.SimpleNamespace(saved=None)
+        try:
+            with torch.no_grad():
+                y = self._forward_impl(x, input_others, ctx)
+        finally:
+            self._donated = False
+        return y, ctx
+
+    def backward_direct(self, ctx, dy):
+        with torch.no_grad():
+            self._backward_impl(ctx, dy)
+
     def _forward_impl(self, x, others, ctx):
         B, S, H = x.shape
         T = B * S

@@ -185,8 +185,21 @@ def outlier_mse_loss_fwd_bwd(pred, ref, *, topk=None, dpred=None, loss_out=None,
     return loss_out, dpred
 
 
-def best_loss_update(total_loss, state, istate, it: int):
-    _launch("ar_best_loss_update", _p(total_loss), _p(state), _p(istate), it)
+def best_loss_update(total_loss, state, istate, it: int, iter_dev=None, loss_hist=None):
+    """iter_dev (int32 [1]): take the iteration number from the device and advance it (captured iterations);
+    loss_hist (fp32 [iters]): record this iteration's loss"""
+    _launch("ar_best_loss_update", _p(total_loss), _p(state), _p(istate), it, _p(iter_dev), _p(loss_hist))
+
+
+def iter_begin(iter_dev, sched, cur_idx, lr_table, lr_out, iters: int):
+    """cur_idx <- sched[*iter_dev], lr_out[k] <- lr_table[k, *iter_dev]: the host side of an iteration, from device tables"""
+    batch = cur_idx.numel()
+    n_lr = lr_out.numel()
+    if sched.dtype != torch.int64 or cur_idx.dtype != torch.int64 or iter_dev.dtype != torch.int32:
+        raise TypeError("iter_begin: sched / cur_idx int64, iter_dev int32")
+    if sched.numel() != iters * batch or lr_table.numel() != n_lr * iters or lr_table.dtype != torch.float32 or lr_out.dtype != torch.float32:
+        raise ValueError("iter_begin: table shapes do not match (iters, batch, n_lr)")
+    _launch("ar_iter_begin", _p(iter_dev, "iter_dev"), _p(sched, "sched"), batch, _p(cur_idx), _p(lr_table), n_lr, iters, _p(lr_out))
 
 
 def gather_rows(src: torch.Tensor, idx_dev: torch.Tensor, out: Optional[torch.Tensor] = None):

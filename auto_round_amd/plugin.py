@@ -30,7 +30,15 @@ def register():
 
     class _Config(_RefConfig):
         """Same fields as the reference SignRoundConfig; selects the MI355X quantizer.  Being a subclass it is not
-        coerced to the V2/Adam variants by normalize_algorithm_config (registry.py: `type(config) is SignRoundConfig`)."""
+        coerced to the V2/Adam variants by normalize_algorithm_config (registry.py: `type(config) is SignRoundConfig`).
+
+        One extra, MI355X-only key: `fused_block` (None = follow the front door's `enable_torch_compile`, the reference's switch
+        for its own compiled block forward; True / False = force the fused HIP block path and the MFMA weight-gradient GEMM on /
+        off)."""
+
+        def __init__(self, *, fused_block=None, **kwargs):
+            super().__init__(**kwargs)
+            self.fused_block = fused_block
 
     @register_pipeline_member(_Config)
     class _Quantizer(_RefQuantizer):
@@ -56,7 +64,11 @@ def register():
             from .quantizer import SignRoundConfig, SignRoundQuantizer, SignRoundV2Quantizer
 
             c = self._config
+            fused = getattr(c, "fused_block", None)
+            if fused is None:
+                fused = bool(getattr(getattr(self, "compress_context", None), "enable_torch_compile", False))
             cfg = SignRoundConfig(
+                fused_block=bool(fused), mfma_dw_gemm=bool(fused),
                 iters=self.iters, lr=None if getattr(c, "lr_is_auto", False) else self.lr,
                 minmax_lr=None if getattr(c, "minmax_lr_is_auto", False) else self.minmax_lr,
                 lr_scheduler=self.lr_scheduler, momentum=getattr(self, "momentum", 0.0) or 0.0, enable_minmax_tuning=self.enable_minmax_tuning,

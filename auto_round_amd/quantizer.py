@@ -262,6 +262,14 @@ class SignRoundConfig:
     # weights (one csrc/ar_block.hip transpose per weight per iteration) -- both operands contiguous along the reduction is the
     # layout hipBLASLt's tuned gfx950 kernel covers (fused_block.FusedLlamaBlock.set_tn_dx).
     tn_dx_gemm: bool = True
+    # One tuning iteration of a fused block as ONE captured hipGraph, replayed `iters` times: the minibatch indices, the learning
+    # rates and the iteration counter come from device tables (ar_iter_begin), the loss / best-loss bookkeeping already lives on
+    # the device, so nothing in the iteration needs the host.  For launch-bound blocks (OPT-125M: ~60 launches per 2 ms
+    # iteration).  None = automatic: blocks of up to `hip_graph_max_weights` quantised weights whose loop qualifies
+    # (_graph_eligible); True = whenever the loop qualifies; False = never.  Same kernels in the same order as the host-driven
+    # loop: results are bit-identical.
+    hip_graph: Optional[bool] = None
+    hip_graph_max_weights: int = 64 * 1024 * 1024
 
     def __post_init__(self):
         if self.iters < 0:
@@ -307,6 +315,7 @@ class SignRoundQuantizer:
             raise NotImplementedError("enable_norm_bias_tuning is outside the MI355X hot path")
         self.last_stats: Dict[str, Any] = {}
         self.last_fused_block = False
+        self.last_hip_graph = False
 
     # convenience accessors with the reference's attribute names
     @property
@@ -451,15 +460,57 @@ class SignRoundQuantizer:
         total_loss = torch.zeros(1, dtype=torch.float32, device=device)
         state = torch.tensor([FLT_MAX, 0.0, 0.0], dtype=torch.float32, device=device)
         istate = torch.zeros(4, dtype=torch.int32, device=device)
+        loss_hist = torch.zeros(max(cfg.iters, 1), dtype=torch.float32, device=device)     # per-iteration loss, read once at the end
         track_best = not cfg.not_use_best_mse
         if track_best:
             optimizer.snapshot_flag = istate[0:1]
         xb = torch.empty((min(batch_size, global_bs),) + tuple(X.shape[1:]), dtype=X.dtype, device=device)
         yb = torch.empty((min(batch_size, global_bs),) + tuple(Y.shape[1:]), dtype=Y.dtype, device=device)
-        dpred = None
+        scratch = {"dpred": None}
         last_iter = cfg.iters - 1
 
-        for i in range(cfg.iters):
+        def run_minibatches(gidx, num_elm, direct=False):
+            """forward / loss / backward of one iteration's minibatches; `gidx`: device int64 [global_bs] sample indices"""
+            for b0 in range(0, global_bs, batch_size):
+                idx = gidx[b0:b0 + batch_size]
+                if dp_size > 1:     # this rank's share of the minibatch; the summed gradient is the full-batch one
+                    idx = idx[dp_rank::dp_size].contiguous()
+                nb = idx.numel()
+                x = ops.gather_rows(X, idx, out=xb[:nb])
+                ref = ops.gather_rows(Y, idx, out=yb[:nb])
+                others_b = input_others
+                if per_sample_others:       # rows of this minibatch, like the reference's per-batch concatenation
+                    others_b = {**input_others, **{k: t.index_select(0, idx) for k, t in per_sample_others.items()}}
+                ctx = None
+                if direct:          # captured iterations: the fused block's own forward / backward, no autograd graph in between
+                    pred, ctx = fused.forward_direct(x, others_b, donate_input=True)
+                else:
+                    pred = fused.forward(x, others_b, donate_input=True) if fused is not None else self.block_forward(block, x, others_b)      # x: scratch rows
+                pred_c = pred if pred.is_contiguous() else pred.contiguous()
+                dpred = scratch["dpred"]
+                if dpred is None or dpred.shape != pred_c.shape or dpred.dtype != pred_c.dtype:
+                    dpred = scratch["dpred"] = torch.empty_like(pred_c)
+                n = pred_c.numel()
+                tmask = None
+                if mask_dev is not None:
+                    if mask_dev.shape[1] % 16 == 0:
+                        tmask = ops.gather_rows(mask_dev, idx, out=mb[:nb]).view(-1)
+                    else:
+                        tmask = mask_dev.index_select(0, idx).contiguous().view(-1)
+                self._loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred, total_loss, n, num_elm, accum, tmask)
+                if direct:
+                    fused.backward_direct(ctx, dpred)
+                else:
+                    pred_c.backward(dpred)
+
+        use_graph = self._graph_eligible(cfg, fused, arenas, early_stop, dp_size, accum, per_sample_others, valid_counts, sched_dev, track_best)
+        self.last_hip_graph = False
+        first_host_iter = 0
+        if use_graph:
+            first_host_iter = self._run_captured(cfg, optimizer, lr_schedule, arenas, sched_dev, global_bs, valid_counts, run_minibatches,
+                                                 total_loss, state, istate, loss_hist, device)
+
+        for i in range(first_host_iter, cfg.iters):
             if sched_dev is None:
                 host_idx = sampler.next_batch()
                 gidx = torch.tensor(host_idx, dtype=torch.int64).to(device)
@@ -471,32 +522,10 @@ class SignRoundQuantizer:
                 num_elm = max(1, sum(valid_counts[j] for j in host_idx))
             elif accum:
                 num_elm = global_bs * X[0].numel()
-            for b0 in range(0, global_bs, batch_size):
-                idx = gidx[b0:b0 + batch_size]
-                if dp_size > 1:     # this rank's share of the minibatch; the summed gradient is the full-batch one
-                    idx = idx[dp_rank::dp_size].contiguous()
-                nb = idx.numel()
-                x = ops.gather_rows(X, idx, out=xb[:nb])
-                ref = ops.gather_rows(Y, idx, out=yb[:nb])
-                others_b = input_others
-                if per_sample_others:       # rows of this minibatch, like the reference's per-batch concatenation
-                    others_b = {**input_others, **{k: t.index_select(0, idx) for k, t in per_sample_others.items()}}
-                pred = fused.forward(x, others_b, donate_input=True) if fused is not None else self.block_forward(block, x, others_b)      # x: scratch rows
-                pred_c = pred if pred.is_contiguous() else pred.contiguous()
-                if dpred is None or dpred.shape != pred_c.shape or dpred.dtype != pred_c.dtype:
-                    dpred = torch.empty_like(pred_c)
-                n = pred_c.numel()
-                tmask = None
-                if mask_dev is not None:
-                    if mask_dev.shape[1] % 16 == 0:
-                        tmask = ops.gather_rows(mask_dev, idx, out=mb[:nb]).view(-1)
-                    else:
-                        tmask = mask_dev.index_select(0, idx).contiguous().view(-1)
-                self._loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred, total_loss, n, num_elm, accum, tmask)
-                pred_c.backward(dpred)
+            run_minibatches(gidx, num_elm)
             if dp_size > 1:
                 sync_block_gradients(arenas, total_loss, average_loss=not accum)
-            ops.best_loss_update(total_loss, state, istate, i)
+            ops.best_loss_update(total_loss, state, istate, i, loss_hist=loss_hist)
             if early_stop:
                 last_best = int(istate[1].item())
                 if 0 < cfg.dynamic_max_gap <= i - last_best:
@@ -528,11 +557,91 @@ class SignRoundQuantizer:
             best_iter, shown_loss = cfg.iters, last_loss
         self.last_stats = dict(init_loss=init_loss, best_loss=best_loss, last_loss=last_loss, best_iter=best_iter,
                                iters_run=last_iter + 1, quantized=len(quantized_names),
-                               unquantized=len(unquantized_names), n_improved=n_improved)
+                               unquantized=len(unquantized_names), n_improved=n_improved, hip_graph=bool(self.last_hip_graph),
+                               loss_trace=loss_hist[:last_iter + 1].tolist())
         with torch.no_grad():
             unwrapper_block(block, best_params)
         # hand out independent copies: the arenas' best_* buffers are released with the block's wrappers
         return {n: {k: v.clone() for k, v in d.items()} for n, d in best_params.items()}
+
+    # -- one iteration as a captured hipGraph -------------------------------------------------------------------------------
+    @staticmethod
+    def _graph_eligible(cfg, fused, arenas, early_stop, dp_size, accum, per_sample_others, valid_counts, sched_dev, track_best) -> bool:
+        """The loop can run from device tables when nothing inside an iteration depends on the host: a fused block (its forward /
+        backward are plain kernel sequences), the whole index schedule drawn up front, best-parameter tracking on the device, a
+        valid-token count that is the same for every minibatch (it is a kernel ARGUMENT of the loss), no early stopping, no
+        micro-batches, no data-parallel exchange, no momentum buffers, no per-tensor (shared-parameter) arenas."""
+        if cfg.hip_graph is False or fused is None or not track_best or early_stop or dp_size > 1 or accum or per_sample_others:
+            return False
+        if sched_dev is None or cfg.iters < 3 or (cfg.momentum or 0.0) or any(a.shared for a in arenas):
+            return False
+        if valid_counts is not None and len(set(valid_counts)) != 1:
+            return False
+        if cfg.hip_graph is None and sum(a.n for a in arenas) > cfg.hip_graph_max_weights:
+            return False        # big blocks are GPU-bound (19 ms of kernels per Llama-3-8B iteration): nothing to gain
+        return True
+
+    def _run_captured(self, cfg, optimizer, lr_schedule, arenas, sched_dev, global_bs, valid_counts, run_minibatches, total_loss, state,
+                      istate, loss_hist, device) -> int:
+        """Iteration 0 eagerly through the device-table form (allocates every scratch buffer, sets the kernels' attributes, leaves
+        the Python-side freshness flags in their steady state), capture of ONE iteration, then iters - 1 replays.  -> the first
+        iteration the host-driven loop still has to run (== iters when everything was replayed)."""
+        import warnings
+
+        iters = cfg.iters
+        # the scheduler's learning-rate sequence, computed by the scheduler itself (chained fp32 recurrence of LinearLR on the
+        # 0-dim lr tensors, SURVEY App. A.4): value used by iteration i = value after i scheduler steps
+        rows = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(iters):
+                row = []
+                for a in arenas:
+                    lr_v, lr_mm = optimizer._arena_lrs(a)
+                    row += [float(lr_v), float(lr_mm)]
+                rows.append(row)
+                lr_schedule.step()
+        lr_table = torch.tensor(rows, dtype=torch.float32).t().contiguous().to(device)            # [2 * arenas, iters]
+        lr_out = torch.zeros(2 * len(arenas), dtype=torch.float32, device=device)
+        optimizer.lr_override = {id(a): (lr_out[2 * k:2 * k + 1], lr_out[2 * k + 1:2 * k + 2]) for k, a in enumerate(arenas)}
+        it_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        cur_idx = torch.empty(global_bs, dtype=torch.int64, device=device)
+        sched_flat = sched_dev.reshape(-1).contiguous()
+        num_elm = 1 if valid_counts is None else max(1, valid_counts[0] * global_bs)
+
+        def body():
+            ops.iter_begin(it_dev, sched_flat, cur_idx, lr_table, lr_out, iters)
+            run_minibatches(cur_idx, num_elm, direct=True)
+            ops.best_loss_update(total_loss, state, istate, 0, iter_dev=it_dev, loss_hist=loss_hist)
+            optimizer.step()
+
+        body()                                                          # iteration 0
+        flags = [(a, a.wq_fresh, [l._dw_accum[0] for l in a.layers]) for a in arenas]
+        prev_prof = ops.profile_enable(False)                           # per-dispatch event pairs cannot be captured
+        graph = None
+        try:
+            torch.cuda.synchronize(device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body()                                                  # recorded, not executed
+        except Exception as e:  # noqa: BLE001 -- any capture failure: the same body runs eagerly instead
+            graph = None
+            for a, fresh, acc in flags:
+                a.wq_fresh = fresh
+                for l, v in zip(a.layers, acc):
+                    l._dw_accum[0] = v
+            warnings.warn(f"hipGraph capture of the tuning iteration failed ({e!r}); running the iterations eagerly")
+        finally:
+            ops.profile_enable(prev_prof)
+        self.last_hip_graph = graph is not None
+        for _ in range(1, iters):
+            if graph is not None:
+                graph.replay()
+            else:
+                body()
+        optimizer.lr_override = None
+        self._last_graph = graph            # (kept until the next block: replays may still be in flight)
+        return iters
 
     def _loss_fwd_bwd(self, pred, ref, dpred, total_loss, n, num_elm, accum, tmask):
         """loss value into `total_loss` (+= loss/num_elm) and d(1000*loss)/dpred into `dpred`, one fused pass.

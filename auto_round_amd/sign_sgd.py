@@ -43,6 +43,7 @@ class SignSGD(Optimizer):
         self._lr_dev = {}
         self.snapshot_flag = None     # device int32[1]; set by the quantizer when best-param tracking is on
         self.fuse_next_fwd = True
+        self.lr_override = None       # {id(arena): (lr_v [1], lr_mm [1])}: device scalars filled by ar_iter_begin (captured iterations)
 
     def _lr_tensor(self, key, value, device):
         t = self._lr_dev.get(key)
@@ -76,9 +77,13 @@ class SignSGD(Optimizer):
         loss = closure() if closure is not None else None
         if self.fused:
             for a in self.arenas:
-                lr_v, lr_mm = self._arena_lrs(a)
-                a.backward_step(self._lr_tensor(("v", id(a)), lr_v, a.device), self._lr_tensor(("mm", id(a)), lr_mm, a.device),
-                                snapshot_flag=self.snapshot_flag, fuse_next_fwd=self.fuse_next_fwd, momentum=self.momentum)
+                if self.lr_override is not None:
+                    lr_v_dev, lr_mm_dev = self.lr_override[id(a)]
+                else:
+                    lr_v, lr_mm = self._arena_lrs(a)
+                    lr_v_dev, lr_mm_dev = self._lr_tensor(("v", id(a)), lr_v, a.device), self._lr_tensor(("mm", id(a)), lr_mm, a.device)
+                a.backward_step(lr_v_dev, lr_mm_dev, snapshot_flag=self.snapshot_flag, fuse_next_fwd=self.fuse_next_fwd,
+                                momentum=self.momentum)
             return loss
         if self.momentum:
             raise NotImplementedError("momentum is implemented on the arena path (quantize_block)")

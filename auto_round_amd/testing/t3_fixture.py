@@ -1,0 +1,230 @@
+"""End-to-end parity against a fixture that the REAL reference produced on an MI355X (VERDICT r02 "next round" item 1).
+
+`tests/t3_baseline_shapes.py` (builder side, reference tree staged) runs the reference's own front door
+`auto_round.AutoRound(...).quantize()` with its torch-eager SignRound quantizer on cuda:0 on ONE decoder block of OPT-125M's
+dimensions at the BASELINE configuration (W4 group_size=128 sym, 200 iterations, 128 x 2048 calibration tokens, batch 8, seed 42)
+and stores what came out -- the packed `qweight / qzeros / scales` of every layer through the reference's own
+`QuantLinear.pack`, the per-iteration loss trace, and checksums of the block's inputs and targets -- in
+`tests/golden/t3_opt125m_w4g128_ref_on_mi355x.npz`.
+
+This module is the reference-FREE half: it rebuilds the same seeded block and calibration tokens, reproduces the block inputs the
+way the reference's calibrator produces them (`calibration/llm.py:340-402`: attention mask with the last position cleared, the
+cached mask cast to the amp dtype by `calibration/inputs.py:100-107`), tunes the block with this package's engine (module path or
+fused path) and compares with the fixture.  Used by `tests/test_gpu_t3_fixture.py` (in the driver's `-m gpu` run, where no
+reference tree exists) and by `bench.py`'s `parity` object.  No oracle, no reference import."""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+FIXTURE = os.path.join(ROOT, "tests", "golden", "t3_opt125m_w4g128_ref_on_mi355x.npz")
+
+ARCHS = {
+    # BASELINE configs[0] / north-star target model: OPT-125M's decoder block
+    "opt125m": dict(family="opt", hidden=768, ffn=3072, heads=12, vocab=50272),
+    # BASELINE configs[1]: Llama-3-8B's decoder block (small vocabulary: embeddings are not on the path)
+    "llama8b": dict(family="llama", hidden=4096, ffn=14336, heads=32, kv=8, vocab=4096),
+}
+
+
+def build_model(arch: str):
+    """1-layer random-init causal LM of the named block dimensions, seeded on the CPU (deterministic across machines), bf16."""
+    a = ARCHS[arch]
+    torch.manual_seed(0)
+    if a["family"] == "opt":
+        from transformers import OPTConfig, OPTForCausalLM
+
+        cfg = OPTConfig(hidden_size=a["hidden"], ffn_dim=a["ffn"], num_attention_heads=a["heads"], num_hidden_layers=1,
+                        vocab_size=a["vocab"], max_position_embeddings=2048, word_embed_proj_dim=a["hidden"])
+        cfg._attn_implementation = "sdpa"
+        return OPTForCausalLM(cfg).to(torch.bfloat16).eval()
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(hidden_size=a["hidden"], intermediate_size=a["ffn"], num_attention_heads=a["heads"],
+                      num_key_value_heads=a["kv"], num_hidden_layers=1, vocab_size=a["vocab"], rope_theta=500000.0,
+                      max_position_embeddings=8192, tie_word_embeddings=False)
+    cfg._attn_implementation = "sdpa"
+    return LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+
+
+def decoder_blocks(model):
+    return model.model.decoder.layers if hasattr(model.model, "decoder") else model.model.layers
+
+
+def calib_tokens(arch: str, nsamples: int, seqlen: int) -> torch.Tensor:
+    return torch.randint(0, ARCHS[arch]["vocab"], (nsamples, seqlen), generator=torch.Generator().manual_seed(1))
+
+
+def sha(t: torch.Tensor) -> str:
+    """sha256 of a tensor's bytes (any dtype), independent of device and strides."""
+    c = t.detach().contiguous().cpu()
+    return hashlib.sha256(c.view(torch.uint8).numpy().tobytes() if c.dtype != torch.bool else c.numpy().tobytes()).hexdigest()
+
+
+class _Stop(Exception):
+    pass
+
+
+@torch.no_grad()
+def capture_block_inputs(model, block, tokens: torch.Tensor, device, amp_dtype=torch.bfloat16):
+    """(x0 [N, S, H], shared kwargs) of `block` on `tokens`, the way the reference's calibrator obtains them: one forward per
+    sample with `attention_mask = ones, last position 0` (calibration/llm.py:360-402), a pre-hook on the block records its input
+    and keyword arguments and stops the forward; tensors among the kwargs are then cast like the reference's input cache does
+    (calibration/inputs.py:100-107: half-precision tensors to the amp dtype; list entries -- the per-sample attention masks,
+    BOOLEAN with transformers >= 5 -- through `to_dtype`, i.e. a 0/1 additive bias from then on; integer tensors untouched)."""
+    captured, shared = [], {}
+
+    def hook(mod, args, kwargs):
+        hs = args[0] if args else kwargs["hidden_states"]
+        captured.append(hs.detach())
+        if not shared:
+            for k, v in kwargs.items():
+                if k in ("hidden_states", "past_key_values", "past_key_value", "use_cache", "cache_position"):
+                    continue
+                shared[k] = v
+        raise _Stop
+
+    h = block.register_forward_pre_hook(hook, with_kwargs=True)
+    try:
+        for i in range(tokens.shape[0]):
+            ids = tokens[i:i + 1].to(device)
+            am = torch.ones_like(ids)
+            am[:, -1] = 0
+            try:
+                model(ids, attention_mask=am, use_cache=False)
+            except _Stop:
+                pass
+    finally:
+        h.remove()
+
+    def cast(v):
+        if isinstance(v, torch.Tensor):
+            if v.dtype in (torch.int32, torch.int64):
+                return v
+            return v.to(amp_dtype) if (v.is_floating_point() or v.dtype == torch.bool) else v
+        if isinstance(v, (tuple, list)):
+            return type(v)(cast(x) for x in v)
+        return v
+
+    return torch.cat(captured, dim=0), {k: cast(v) for k, v in shared.items()}
+
+
+def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw: Optional[dict] = None, iters: int = 200,
+                      nsamples: int = 128, seqlen: int = 2048, batch_size: int = 8, fused: bool = False, alg_ext: bool = False,
+                      seed: int = 42, device="cuda:0", graph: Optional[bool] = None) -> dict:
+    """The plugin-mode flow without the reference around it: same seeded block, same block inputs, targets from the module-path
+    forward (what the reference's orchestrator hands to `quantize_block`), `transformers.set_seed(seed)` right before the block
+    (the reference's sampler then draws the same minibatches), then `SignRoundQuantizer.quantize_block` -- on the module path
+    (`fused=False`) or the fused block path with the MFMA weight-gradient GEMM (`fused=True`)."""
+    import transformers
+
+    from auto_round_amd.autoround import loss_mask_ids
+    from auto_round_amd.quantizer import BlockContext, SignRoundConfig, SignRoundQuantizer, SignRoundV2Quantizer
+    from auto_round_amd.schemes import apply_scheme, resolve_scheme
+
+    device = torch.device(device)
+    model = build_model(arch).to(device)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    tokens = calib_tokens(arch, nsamples, seqlen)
+    block = decoder_blocks(model)[0]
+    sch = resolve_scheme(scheme, **(scheme_kw or {}))
+    apply_scheme(block, sch)
+    x0, others = capture_block_inputs(model, block, tokens, device)
+    ids = loss_mask_ids(tokens, None)
+    q_cls = SignRoundV2Quantizer if alg_ext else SignRoundQuantizer
+    mod_cfg = SignRoundConfig(iters=iters, batch_size=batch_size, bits=sch["bits"], sdpa_backend="auto", fused_block=False)
+    q_mod = q_cls(mod_cfg, device=device)
+    with torch.cuda.device(device):
+        y = q_mod.calibrate_block(block, x0, others)              # module path: the targets the reference would hand over
+    kw = {} if graph is None else {"hip_graph": bool(graph)}
+    cfg = SignRoundConfig(iters=iters, batch_size=batch_size, bits=sch["bits"], sdpa_backend="auto", fused_block=bool(fused),
+                          mfma_dw_gemm=bool(fused), **kw)
+    q = q_cls(cfg, device=device)
+    transformers.set_seed(seed)
+    q.quantize_block(block, x0, others, y, None, BlockContext(0, 1, "0"), input_ids=ids)
+    torch.cuda.synchronize(device)
+    stats = dict(q.last_stats)
+    loss_trace = stats.pop("loss_trace", None)      # recorded on the device by ar_best_loss_update, one read per block
+    return dict(block=block, stats=stats, loss_trace=loss_trace, x_sha=sha(x0), y_sha=sha(y),
+                fused_block=bool(q.last_fused_block), hip_graph=bool(q.last_hip_graph), others_keys=sorted(others))
+
+
+def packed_layers(block) -> Dict[str, Dict[str, np.ndarray]]:
+    """name -> {qweight, qzeros, scales (fp16 bits)} through this package's HIP packers (the auto_round / zp-1 words for sym)."""
+    from auto_round_amd.export import pack_block
+
+    out = {}
+    for n, ql in pack_block(block).items():
+        out[n] = dict(qweight=ql.qweight.cpu().numpy(), qzeros=ql.qzeros.cpu().numpy(),
+                      scales=ql.scales.cpu().view(torch.int16).numpy())
+    return out
+
+
+def load_fixture(path: str = FIXTURE) -> dict:
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    layers = {}
+    for key in z.files:
+        if "::" in key:
+            name, what = key.split("::")
+            layers.setdefault(name, {})[what] = z[key]
+    return dict(meta=meta, layers=layers, loss_trace=z["loss_trace"])
+
+
+def _codes(qweight: np.ndarray, bits: int) -> np.ndarray:
+    """int32 words [in/32*bits, out] -> codes [in, out] (GPTQ order: code k of a word in bits [k*bits, (k+1)*bits))."""
+    per = 32 // bits
+    w = qweight.astype(np.uint32)
+    sh = (np.arange(per, dtype=np.uint32) * bits)[None, :, None]
+    return ((w[:, None, :] >> sh) & ((1 << bits) - 1)).reshape(-1, qweight.shape[1]).astype(np.uint8)
+
+
+def compare_with_fixture(packed: Dict[str, Dict[str, np.ndarray]], fix: dict) -> dict:
+    """Fractions of identical packed words / integer codes / scales / zero-point words against the reference-made fixture."""
+    bits = int(fix["meta"]["bits"])
+    tot_w = same_w = tot_c = same_c = tot_s = same_s = tot_z = same_z = 0
+    per_layer = {}
+    assert sorted(packed) == sorted(fix["layers"]), (sorted(packed), sorted(fix["layers"]))
+    for n, ref in fix["layers"].items():
+        mine = packed[n]
+        assert mine["qweight"].shape == ref["qweight"].shape and mine["scales"].shape == ref["scales"].shape, n
+        ew = mine["qweight"] == ref["qweight"]
+        ec = _codes(mine["qweight"], bits) == _codes(ref["qweight"], bits)
+        es = mine["scales"] == ref["scales"]
+        ez = mine["qzeros"] == ref["qzeros"]
+        tot_w += ew.size; same_w += int(ew.sum())
+        tot_c += ec.size; same_c += int(ec.sum())
+        tot_s += es.size; same_s += int(es.sum())
+        tot_z += ez.size; same_z += int(ez.sum())
+        per_layer[n] = float(ec.mean())
+    return dict(identical_words=same_w / tot_w, identical_codes=same_c / tot_c, identical_scales=same_s / tot_s,
+                identical_zero_words=same_z / tot_z, weights=tot_c, per_layer_identical_codes=per_layer)
+
+
+def trace_divergence(a, b, rel=1e-4):
+    """index of the first iteration whose losses differ by more than `rel` (None: never within the common length)"""
+    n = min(len(a), len(b))
+    return next((i for i in range(n) if abs(a[i] - b[i]) > rel * max(abs(a[i]), 1e-30)), None)
+
+
+def check_against_fixture(fused: bool, path: str = FIXTURE, graph: Optional[bool] = None) -> dict:
+    """Re-tune the fixture's block with this package and compare -> a flat record (what bench.py prints as `parity`)."""
+    fix = load_fixture(path)
+    m = fix["meta"]
+    r = tune_with_product(m["arch"], scheme=m["scheme"], iters=m["iters"], nsamples=m["nsamples"], seqlen=m["seqlen"],
+                          batch_size=m["batch_size"], fused=fused, seed=m["seed"], graph=graph)
+    cmp_ = compare_with_fixture(packed_layers(r["block"]), fix)
+    ref_trace = [float(x) for x in fix["loss_trace"]]
+    rec = dict(fused_block=r["fused_block"], hip_graph=r["hip_graph"], inputs_identical=(r["x_sha"] == m["x_sha"]), targets_identical=(r["y_sha"] == m["y_sha"]),
+               init_loss=r["stats"]["init_loss"], init_loss_ref=ref_trace[0], best_loss=r["stats"]["best_loss"],
+               best_loss_ref=min(ref_trace), best_loss_ratio=r["stats"]["best_loss"] / min(ref_trace),
+               best_iter=r["stats"]["best_iter"], best_iter_ref=int(np.argmin(ref_trace)),
+               first_divergence_iter=trace_divergence(ref_trace, r["loss_trace"]) if r["loss_trace"] else None, **cmp_)
+    return rec

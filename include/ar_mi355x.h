@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 14
+#define AR_ABI_VERSION 15
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -151,8 +151,23 @@ int ar_outlier_mse_loss_fwd_bwd(const void* pred, const void* ref, void* dpred, 
  * replaces: `if total_loss < best_loss: best_loss = total_loss; last_best_iter = i` (sign_round/quantizer.py:508-517)
  * state[0]=best_loss (init FLT_MAX) state[1]=init_loss state[2]=last total_loss ; istate[0]=snapshot flag
  * istate[1]=last_best_iter istate[2]=number of improvements (0 => the loss was never finite: keep RTN).
- * Also zeroes *total_loss for the next iteration. */
-int ar_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter, ar_stream_t stream);
+ * Also zeroes *total_loss for the next iteration.
+ * iter_dev (optional): the iteration number is read from *iter_dev instead of `iter` and *iter_dev is incremented afterwards --
+ * the form a captured hipGraph of one iteration needs.  loss_hist (optional, fp32 [iters]): loss_hist[iteration] = total loss,
+ * i.e. the per-iteration loss the reference only logs (`loss.item()` per batch, sign_round/quantizer.py:496) without a host
+ * synchronisation. */
+int ar_best_loss_update(float* total_loss, float* state, int32_t* istate, int32_t iter, int32_t* iter_dev, float* loss_hist,
+                        ar_stream_t stream);
+
+/* ---- start of a tuning iteration replayed from a hipGraph ------------------------------------------------------
+ * replaces: the host side of one loop iteration of SignRoundQuantizer.quantize_block -- `index_sampler.next_batch()`
+ *           (sign_round/quantizer.py:475, compressors/utils.py:388-438) and the learning rates `lr_schedule.step()` left in the
+ *           optimizer's param groups (sign_round/quantizer.py:805-821) -- for a loop whose iterations are ONE captured hipGraph:
+ * with it = *iter_dev:  cur_idx[j] = sched[it * batch + j] (j < batch);  lr_out[k] = lr_table[k * iters + it] (k < n_lr).
+ * The whole index schedule and the scheduler's learning-rate sequence are drawn / computed by the host before the loop and
+ * uploaded once; ar_best_loss_update(iter_dev=...) advances the counter at the end of the iteration. */
+int ar_iter_begin(const int32_t* iter_dev, const int64_t* sched, int batch, int64_t* cur_idx, const float* lr_table, int n_lr,
+                  int iters, float* lr_out, ar_stream_t stream);
 
 /* ---- calibration-activation gather ---------------------------------------------------------------------------
  * replaces: torch.cat([inputs[i] for i in indices]) in BlockForwardRunner._select_batch

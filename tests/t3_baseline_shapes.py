@@ -1,0 +1,397 @@
+"""T3 at the BASELINE configuration (VERDICT r02 "next round" item 1): the REAL reference on the MI355X against this package on
+real block dimensions, real group size, real iteration count.  Builder side only (needs the reference tree: /root/reference or the
+copy staged by tools/stage_reference.sh); the driver-side half is tests/test_gpu_t3_fixture.py on the fixture written here.
+
+Per case, on cuda:0, the reference's own front door `AutoRound(...).quantize()` runs
+  (ref)     with the reference's SignRound quantizer (torch eager on the GPU) -- the oracle; probes record the per-iteration loss,
+            the inputs / targets `quantize_block` received (checksums) and, per iteration, how many groups get a different SIGN for
+            d loss / d min_scale, d max_scale from `ar_qdq_int_bwd` than from torch autograd on the SAME operands (the weight
+            gradient autograd produced for the fake-quant weight, the reference's own parameters) -- the one quantity of the path
+            that is sign-exact rather than bit-exact, now measured at g128 on real shapes inside a real trajectory;
+  (module)  with the plugin, module path (`fused_block=False`): the HIP engine behind the reference's orchestrator;
+  (fused)   with the plugin, fused block path + MFMA weight-gradient GEMM (`fused_block=True`): what bench.py measures;
+  (alone)   reference-free: auto_round_amd.testing.t3_fixture.tune_with_product, module and fused -- the flow the driver-side
+            test runs; its block inputs / targets must hash to what the reference handed its own quantizer.
+Compared: identical tuned weights / integer codes / scales / zero points, loss traces and their first divergence.
+
+    python tests/t3_baseline_shapes.py --out profiles/r03_t3_baseline_shapes.json --fixture tests/golden/t3_opt125m_w4g128_ref_on_mi355x.npz
+"""
+import copy
+import gc
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from ref_tree import import_reference, reference_root  # noqa: E402
+
+BIG_CASES = {
+    # (a) BASELINE configs[0] / the north-star's target model at the full recipe
+    "opt125m_w4g128": dict(arch="opt125m", scheme="W4A16", kw={}, iters=200, nsamples=128, seqlen=2048, batch_size=8),
+    # (b) BASELINE configs[1] block dimensions, >= 50 iterations
+    "llama8b_w4g128": dict(arch="llama8b", scheme="W4A16", kw={}, iters=50, nsamples=32, seqlen=2048, batch_size=8),
+    # (c) BASELINE configs[2] scheme at real width
+    "llama8b_w2g32_asym_algext": dict(arch="llama8b", scheme="W2A16G32", kw=dict(sym=False, enable_alg_ext=True), iters=50,
+                                      nsamples=32, seqlen=2048, batch_size=8),
+}
+
+
+class _GradSignProbe:
+    """Inside the REFERENCE's tuning loop: after every backward, feed the reference's own operands to `ar_qdq_int_bwd` and compare
+    with what autograd left in `.grad`.  Operands per wrapped layer: dWq = the gradient autograd computed for the fake-quant weight
+    (retained on the tensor `_qdq_weight` returned), W, V, weight_min / weight_max, min_scale / max_scale (already clamped in place
+    by the forward).  Counted per iteration over all layers: groups, groups whose d min_scale / d max_scale SIGN differs, groups
+    whose value differs in any bit, elements of dV that differ in any bit.  Counts stay on the device until the end."""
+
+    def __init__(self):
+        self.rows, self._seen, self._undo = [], {}, []
+
+    def install(self):
+        import auto_round.wrapper as RW
+        from auto_round.algorithms.quantization.sign_round.quantizer import SignRoundQuantizer as R
+
+        import auto_round_amd.ops as ops
+
+        probe = self
+        orig_qdq = RW.WrapperLinear._qdq_weight
+        orig_step = R._step
+
+        def _qdq_weight(self, value, min_scale, max_scale):
+            wq, scale, zp = orig_qdq(self, value, min_scale, max_scale)
+            if (torch.is_grad_enabled() and isinstance(wq, torch.Tensor) and wq.requires_grad and type(self) is RW.WrapperLinear
+                    and str(self.data_type).startswith("int") and not isinstance(self.orig_layer.group_size, (tuple, list))):
+                wq.retain_grad()
+                probe._seen[id(self)] = (self, wq)
+            return wq, scale, zp
+
+        def _step(self, scaler, optimizer, lr_schedule):
+            acc = torch.zeros(6, dtype=torch.int64, device="cuda")
+            for w, wq in probe._seen.values():
+                g = wq.grad
+                if g is None or w.value.grad is None:
+                    continue
+                ol = w.orig_layer
+                gs = int(ol.group_size)
+                W = ol.weight.data
+                if gs <= 0 or W.shape[1] % gs or gs % 8:
+                    continue
+                V = w.value.data.reshape(-1).contiguous()
+                mn, mx = w.min_scale.data.reshape(-1).contiguous(), w.max_scale.data.reshape(-1).contiguous()
+                dV, dmin, dmax = ops.qdq_int_bwd(g.contiguous().view(-1), W.contiguous().view(-1), V,
+                                                 w.weight_min.reshape(-1).contiguous(), w.weight_max.reshape(-1).contiguous(), mn, mx,
+                                                 gs=gs, bits=int(ol.bits), sym=int(bool(ol.sym)), scale_dtype=ol.scale_dtype,
+                                                 q_thresh=float(w.q_scale_thresh), bounds=tuple(w.minmax_scale_bound))
+                rv = w.value.grad.reshape(-1)
+                acc[5] += (dV.view(torch.int32) != rv.view(torch.int32)).sum()
+                acc[0] += mn.numel()
+                if w.min_scale.grad is not None and w.max_scale.grad is not None:
+                    rmin, rmax = w.min_scale.grad.reshape(-1), w.max_scale.grad.reshape(-1)
+                    acc[1] += (torch.sign(dmin) != torch.sign(rmin)).sum()
+                    acc[2] += (torch.sign(dmax) != torch.sign(rmax)).sum()
+                    acc[3] += (dmin.view(torch.int32) != rmin.view(torch.int32)).sum()
+                    acc[4] += (dmax.view(torch.int32) != rmax.view(torch.int32)).sum()
+            probe._seen.clear()
+            probe.rows.append(acc)
+            return orig_step(self, scaler, optimizer, lr_schedule)
+
+        RW.WrapperLinear._qdq_weight = _qdq_weight
+        R._step = _step
+        self._undo = [(RW.WrapperLinear, "_qdq_weight", orig_qdq), (R, "_step", orig_step)]
+        return self
+
+    def remove(self):
+        for cls, name, orig in self._undo:
+            setattr(cls, name, orig)
+        self._undo = []
+
+    def summary(self):
+        if not self.rows:
+            return None
+        t = torch.stack(self.rows).cpu().numpy()
+        G, n_el = int(t[0, 0]), None
+        out = dict(iterations=int(t.shape[0]), groups_per_iteration=G,
+                   dmin_sign_diff_per_iter=[int(x) for x in t[:, 1]], dmax_sign_diff_per_iter=[int(x) for x in t[:, 2]],
+                   dmin_sign_diff_frac_max=float(t[:, 1].max() / max(G, 1)), dmax_sign_diff_frac_max=float(t[:, 2].max() / max(G, 1)),
+                   dmin_sign_diff_frac_mean=float(t[:, 1].mean() / max(G, 1)), dmax_sign_diff_frac_mean=float(t[:, 2].mean() / max(G, 1)),
+                   dmin_bits_diff_frac_mean=float(t[:, 3].mean() / max(G, 1)), dmax_bits_diff_frac_mean=float(t[:, 4].mean() / max(G, 1)),
+                   dV_bits_diff_total=int(t[:, 5].sum()))
+        return out
+
+
+class _InputSpy:
+    """What the reference's orchestrator hands to `quantize_block` (first call): checksums of the stacked inputs / targets, the
+    keys and shapes of input_others, the cached mask's values -- compared with the reference-free flow's."""
+
+    def __init__(self):
+        self.rec = None
+
+    def install(self):
+        from auto_round.algorithms.quantization.sign_round.quantizer import SignRoundQuantizer as R
+
+        from auto_round_amd.testing.t3_fixture import sha
+
+        spy = self
+        self._R, self._orig = R, R.quantize_block
+
+        def quantize_block(self, block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=None, **kw):
+            if spy.rec is None:
+                def stack(v):
+                    return v if isinstance(v, torch.Tensor) else torch.cat([t for t in v], dim=0)
+
+                def desc(v):
+                    if isinstance(v, torch.Tensor):
+                        return [str(v.dtype), list(v.shape)]
+                    if isinstance(v, (list, tuple)):
+                        return [type(v).__name__, len(v), desc(v[0]) if len(v) else None]
+                    return repr(v)[:40]
+
+                rec = dict(x_sha=sha(stack(fp_inputs)), y_sha=sha(stack(fp_outputs)), q_inputs=q_inputs is not None,
+                           others={k: desc(v) for k, v in (input_others or {}).items()})
+                am = (input_others or {}).get("attention_mask")
+                am0 = am[0] if isinstance(am, (list, tuple)) and len(am) else am
+                if isinstance(am0, torch.Tensor):
+                    rec["mask_sha"] = sha(am0[:1] if am0.dim() == 4 else am0)
+                    rec["mask_all_equal"] = bool(all(torch.equal(a, am[0]) for a in am)) if isinstance(am, (list, tuple)) else True
+                if input_ids is not None:
+                    ids = input_ids if isinstance(input_ids, torch.Tensor) else torch.cat([t.reshape(1, -1) for t in input_ids], 0)
+                    rec["ids_sha"] = sha(ids.to(torch.int64))
+                spy.rec = rec
+            return spy._orig(self, block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=input_ids, **kw)
+
+        R.quantize_block = quantize_block
+        return self
+
+    def remove(self):
+        self._R.quantize_block = self._orig
+
+
+def _tuned_layers(model):
+    from transformers.pytorch_utils import Conv1D
+
+    from auto_round_amd.testing.t3_fixture import decoder_blocks
+
+    out = {}
+    for n, p in decoder_blocks(model).named_modules():
+        if isinstance(p, (torch.nn.Linear, Conv1D)) and hasattr(p, "scale"):
+            out[n.replace(".orig_layer", "")] = p
+    return out
+
+
+def _decode(lin):
+    W = lin.weight.detach().float().cpu()
+    out_f, in_f = W.shape
+    s = lin.scale.float().reshape(out_f, -1)
+    gs = in_f // s.shape[1]
+    zp = lin.zp if isinstance(lin.zp, torch.Tensor) else torch.full_like(s, float(lin.zp))
+    zp = zp.float().reshape(out_f, -1)
+    q = torch.round(W.reshape(out_f, -1, gs) / s.unsqueeze(-1)) + zp.unsqueeze(-1)
+    return q, s, zp
+
+
+def compare_layers(La, Lb):
+    """identical tuned weights / integer codes / (scale, zp) where the codes agree, between two {name: tuned linear} maps"""
+    tot = same_w = same_q = same_sz = n_sz = 0
+    for n, a in La.items():
+        b = Lb[n]
+        wa, wb = a.weight.detach().cpu().view(torch.int16), b.weight.detach().cpu().view(torch.int16)
+        tot += wa.numel()
+        same_w += int((wa == wb).sum())
+        qa, s1, z1 = _decode(a)
+        qb, s2, z2 = _decode(b)
+        eq = qa == qb
+        same_q += int(eq.sum())
+        ge = eq.all(dim=-1)
+        n_sz += int(ge.sum())
+        same_sz += int(((s1 == s2) & (z1 == z2))[ge].sum())
+    return dict(weights=tot, identical_weights=same_w / tot, identical_codes=same_q / tot,
+                identical_scale_zp_where_codes_agree=(same_sz / n_sz) if n_sz else None)
+
+
+def _snapshot(model):
+    """CPU copies of what compare_layers reads, so the GPU model can be dropped between runs"""
+    class L:
+        pass
+
+    out = {}
+    for n, p in _tuned_layers(model).items():
+        o = L()
+        o.weight = p.weight.detach().cpu().clone()
+        o.scale = p.scale.detach().cpu().clone()
+        o.zp = p.zp.detach().cpu().clone() if isinstance(p.zp, torch.Tensor) else p.zp
+        o.bits, o.group_size, o.sym = int(p.bits), int(p.group_size), bool(p.sym)
+        o.bias = None if p.bias is None else p.bias.detach().cpu().clone()
+        out[n] = o
+    return out
+
+
+def _free():
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def write_fixture(path, case, layers, ref_trace, spy_rec, meta_extra):
+    """The reference-on-GPU result through the REFERENCE's own packer (auto_round_extension/torch/qlinear_torch_zp.QuantLinear.pack,
+    the auto_round format's W4-sym packer, export_to_autoround/export.py:206-228)."""
+    import auto_round_extension.torch.qlinear_torch_zp as zpmod
+
+    rec = {}
+    for n, o in layers.items():
+        out_f, in_f = o.weight.shape
+        lin = torch.nn.Linear(in_f, out_f, bias=o.bias is not None, dtype=o.weight.dtype)
+        lin.weight.data.copy_(o.weight)
+        if o.bias is not None:
+            lin.bias.data.copy_(o.bias)
+        ql = zpmod.QuantLinear(o.bits, o.group_size, in_f, out_f, o.bias is not None)
+        ql.device = "cpu"
+        z = o.zp.clone() if isinstance(o.zp, torch.Tensor) else o.zp
+        ql.pack(lin, o.scale.reshape(out_f, -1).clone(), z, None, device="cpu")
+        rec[f"{n}::qweight"] = ql.qweight.numpy().copy()
+        rec[f"{n}::qzeros"] = ql.qzeros.numpy().copy()
+        rec[f"{n}::scales"] = ql.scales.view(torch.int16).numpy().copy()
+    meta = dict(arch=case["arch"], scheme=case["scheme"], bits=4, iters=case["iters"], nsamples=case["nsamples"], seqlen=case["seqlen"],
+                batch_size=case["batch_size"], seed=42, x_sha=spy_rec["x_sha"], y_sha=spy_rec["y_sha"], **meta_extra)
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), loss_trace=np.asarray(ref_trace, dtype=np.float64), **rec)
+    return os.path.getsize(path)
+
+
+def run_big_case(name, fixture_path=None, skip_alone=False):
+    import_reference()
+    from auto_round import AutoRound
+    from t3_compare import _LossProbe
+    from test_pipeline_vs_reference import _Loader, _StubTokenizer
+
+    import auto_round_amd.plugin as plugin
+    import auto_round_amd.quantizer as product
+    from auto_round_amd.testing import t3_fixture as fx
+
+    case = BIG_CASES[name]
+    Cfg, _ = plugin.register()
+    base = fx.build_model(case["arch"])
+    tokens = fx.calib_tokens(case["arch"], case["nsamples"], case["seqlen"])
+    iters = case["iters"]
+    import tempfile
+
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp(prefix="t3b_"))
+    rec = {"case": name, **{k: case[k] for k in ("arch", "scheme", "iters", "nsamples", "seqlen", "batch_size")}, "scheme_kw": case["kw"]}
+    try:
+        common = dict(tokenizer=_StubTokenizer(), nsamples=case["nsamples"], seqlen=case["seqlen"], dataset=_Loader(tokens), device_map=0,
+                      batch_size=case["batch_size"], enable_torch_compile=False, seed=42, scheme=case["scheme"], **case["kw"])
+        # ---- (ref) the reference's own engine on the GPU, with probes
+        probe, gprobe, spy = _LossProbe().install(), _GradSignProbe().install(), _InputSpy().install()
+        t0 = time.perf_counter()
+        try:
+            q_ref, _ = AutoRound(copy.deepcopy(base), iters=iters, **common).quantize()
+        finally:
+            spy.remove(); gprobe.remove(); probe.remove()          # reverse order of installation
+        torch.cuda.synchronize()
+        rec["ref_wall_s"] = time.perf_counter() - t0
+        L_ref = _snapshot(q_ref)
+        del q_ref
+        _free()
+        ref_trace = probe.traces[0] if probe.traces else []
+        rec["ref"] = dict(init_loss=ref_trace[0] if ref_trace else None, best_loss=min(ref_trace) if ref_trace else None,
+                          best_iter=int(np.argmin(ref_trace)) if ref_trace else None, loss_trace=ref_trace, inputs=spy.rec)
+        rec["grad_sign_probe"] = gprobe.summary()
+
+        # ---- (module) / (fused): the plugin behind the same front door
+        for tag, fused in (("module", False), ("fused", True)):
+            stats = []
+            orig_qb = product.SignRoundQuantizer.quantize_block
+
+            def spy_qb(self, *a, **k):
+                out = orig_qb(self, *a, **k)
+                stats.append(dict(self.last_stats, fused_block=bool(self.last_fused_block)))
+                return out
+
+            product.SignRoundQuantizer.quantize_block = spy_qb
+            t0 = time.perf_counter()
+            try:
+                q_hip, _ = AutoRound(copy.deepcopy(base), alg_configs=Cfg(iters=iters, fused_block=fused), **common).quantize()
+            finally:
+                product.SignRoundQuantizer.quantize_block = orig_qb
+            torch.cuda.synchronize()
+            L_hip = _snapshot(q_hip)
+            del q_hip
+            _free()
+            st0 = dict(stats[0]) if stats else {}
+            tr = st0.pop("loss_trace", None) or []
+            r = dict(wall_s=time.perf_counter() - t0, engine_calls=len(stats), **st0, loss_trace=tr,
+                     first_divergence_iter=fx.trace_divergence(ref_trace, tr), same_layer_set=sorted(L_ref) == sorted(L_hip))
+            if ref_trace and tr:
+                r["init_loss_rel_diff"] = abs(ref_trace[0] - tr[0]) / max(abs(ref_trace[0]), 1e-30)
+                r["best_loss_ratio"] = min(tr) / min(ref_trace)
+            r.update(compare_layers(L_ref, L_hip))
+            rec[tag] = r
+            if tag == "module":
+                L_mod = L_hip
+            else:
+                rec["fused_vs_module"] = compare_layers(L_mod, L_hip)
+
+        # ---- (alone): the reference-free flow of the driver-side test
+        if not skip_alone:
+            for tag, fused in (("alone_module", False), ("alone_fused", True)):
+                a = fx.tune_with_product(case["arch"], scheme=case["scheme"], scheme_kw={k: v for k, v in case["kw"].items() if k != "enable_alg_ext"},
+                                         iters=iters, nsamples=case["nsamples"], seqlen=case["seqlen"], batch_size=case["batch_size"],
+                                         fused=fused, alg_ext=bool(case["kw"].get("enable_alg_ext")))
+
+                L_al = {}
+                for n, p in a["block"].named_modules():
+                    if isinstance(p, torch.nn.Linear) and hasattr(p, "scale"):
+                        L_al[n] = p
+                r = dict(stats=a["stats"], fused_block=a["fused_block"], hip_graph=a["hip_graph"], inputs_identical=a["x_sha"] == spy.rec["x_sha"],
+                         targets_identical=a["y_sha"] == spy.rec["y_sha"], others_keys=a["others_keys"],
+                         first_divergence_iter=fx.trace_divergence(ref_trace, a["loss_trace"] or []), loss_trace=a["loss_trace"])
+                r.update(compare_layers(L_ref, L_al))
+                rec[tag] = r
+                del a, L_al
+                _free()
+        if fixture_path:
+            sz = write_fixture(fixture_path, case, L_ref, ref_trace, spy.rec,
+                               dict(device=torch.cuda.get_device_name(0), torch=torch.__version__,
+                                    made_by="tests/t3_baseline_shapes.py: the reference's AutoRound(...).quantize() on cuda:0"))
+            rec["fixture"] = dict(path=os.path.relpath(fixture_path, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), bytes=sz)
+    finally:
+        os.chdir(cwd)
+    return rec
+
+
+def main():
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--cases", default=",".join(BIG_CASES))
+    ap.add_argument("--fixture", default=None, help="write the reference-on-GPU result of opt125m_w4g128 here")
+    ap.add_argument("--skip-alone", action="store_true")
+    args = ap.parse_args()
+    if reference_root() is None:
+        raise SystemExit("reference tree not present: run tools/stage_reference.sh first")
+    recs = []
+    for c in args.cases.split(","):
+        try:
+            r = run_big_case(c, fixture_path=os.path.abspath(args.fixture) if (args.fixture and c == "opt125m_w4g128") else None,
+                             skip_alone=args.skip_alone)
+        except Exception as e:
+            import traceback
+
+            r = {"case": c, "error": repr(e), "trace": traceback.format_exc()[-3000:]}
+        recs.append(r)
+        slim = {k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if kk != "loss_trace"}) for k, v in r.items()}
+        print(json.dumps(slim)[:6000], flush=True)
+        if args.out:      # rewritten after every case: a later crash keeps the earlier cases
+            with open(args.out, "w") as f:
+                json.dump({"what": "reference AutoRound(...).quantize() on cuda:0 (torch eager) vs the same front door with the auto_round_amd "
+                                   "plugin (module path / fused block path) vs the reference-free fixture flow, at BASELINE block shapes",
+                           "device": torch.cuda.get_device_name(0), "cases": recs}, f, indent=1)
+        _free()
+
+
+if __name__ == "__main__":
+    main()
