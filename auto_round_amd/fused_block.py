@@ -51,6 +51,35 @@ def _is_silu(act) -> bool:
     return "silu" in type(act).__name__.lower() or act is F.silu
 
 
+# Decoder-layer classes whose forward IS the computation written out below.  Structural recognition alone is not enough: other
+# families share every attribute name and differ in the arithmetic (Granite: residual_multiplier; SmolLM3: layers without rotary
+# embedding; HunYuan: q/k norms AFTER the rotation; Ernie 4.5: interleaved rotate_half) -- those keep the generic module path.
+LLAMA_FAMILY = ("LlamaDecoderLayer", "MistralDecoderLayer", "Qwen2DecoderLayer", "Qwen3DecoderLayer")
+OPT_FAMILY = ("OPTDecoderLayer",)
+
+
+def _class_in(block, names) -> bool:
+    return type(block).__name__ in names
+
+
+def _rotary_ok(pe, hd) -> bool:
+    """(cos, sin) of the full head size: partial-rotary models (rotary_dim < head_dim) keep the module path"""
+    if not (isinstance(pe, (tuple, list)) and len(pe) == 2):
+        return False
+    return all(isinstance(t, torch.Tensor) and t.dim() in (2, 3) and t.shape[-1] == hd for t in pe)
+
+
+def outputs_agree(y_fused: torch.Tensor, y_module: torch.Tensor, x: torch.Tensor, tol: float) -> bool:
+    """|| y_fused - y_module || <= tol * || y_module - x ||: the two paths agree on what the block ADDS to its input (the residual
+    stream dominates both outputs, so a distance relative to || y || would hide a wrong branch); one host read"""
+    a, b = y_fused.detach().float(), y_module.detach().float()
+    if a.shape != b.shape:
+        return False
+    ref = b - x.detach().float().reshape(b.shape) if x.numel() == b.numel() else b
+    num, den = float((a - b).norm()), float(ref.norm())
+    return num == num and den == den and num <= tol * den + 1e-6
+
+
 class FusedLlamaBlock:
     """Built per block after `wrapper_block`; `forward(x)` returns the block output connected to autograd through the arena's
     dummy token, its backward fills the arena's dWq buffer."""
@@ -70,6 +99,8 @@ class FusedLlamaBlock:
             n1, n2, attn, mlp = block.input_layernorm, block.post_attention_layernorm, block.self_attn, block.mlp
             proj = [attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj]
         except AttributeError:
+            return None
+        if not _class_in(block, LLAMA_FAMILY):
             return None
         if not arenas or not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not _is_silu(getattr(mlp, "act_fn", None)):
             return None
@@ -109,7 +140,7 @@ class FusedLlamaBlock:
         if not (isinstance(pe, (tuple, list)) and len(pe) == 2) or others.get("past_key_values") is not None:
             return None
         hd = int(getattr(attn, "head_dim", 0))
-        if hd <= 0 or hd % 16 or q.out_features % hd or k.out_features % hd:
+        if hd <= 0 or hd % 16 or q.out_features % hd or k.out_features % hd or not _rotary_ok(pe, hd):
             return None
         hq, hkv = q.out_features // hd, k.out_features // hd
         if hq % hkv or o.in_features != hq * hd or (g.out_features % 8) or (q.in_features % 8):
@@ -198,6 +229,8 @@ class FusedLlamaBlock:
             proj = [attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj]
         except AttributeError:
             return None
+        if not _class_in(block, LLAMA_FAMILY):
+            return None
         if not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not _is_silu(getattr(mlp, "act_fn", None)):
             return None
         if not all(type(p) is torch.nn.Linear for p in proj):
@@ -212,7 +245,7 @@ class FusedLlamaBlock:
         if not (isinstance(pe, (tuple, list)) and len(pe) == 2) or others.get("past_key_values") is not None:
             return None
         hd = int(getattr(attn, "head_dim", 0))
-        if hd <= 0 or hd % 16 or q.out_features % hd or k.out_features % hd or k.out_features != v.out_features:
+        if hd <= 0 or hd % 16 or q.out_features % hd or k.out_features % hd or k.out_features != v.out_features or not _rotary_ok(pe, hd):
             return None
         hq, hkv = q.out_features // hd, k.out_features // hd
         if hq % hkv or o.in_features != hq * hd or (g.out_features % 8) or (q.in_features % 8) or g.out_features != u.out_features:
@@ -349,6 +382,25 @@ class FusedLlamaBlock:
         with torch.no_grad():
             self._backward_impl(ctx, dy)
 
+    def agrees_with_module(self, module_forward, x, input_others) -> bool:
+        """One minibatch through the fused kernels and through the block's own module code (`module_forward(x, others)`): the fused
+        path is only used when both compute the same function (bf16 rounding apart; 4-bit activation grids amplify it).  Guards
+        against look-alike blocks the class whitelist does not know about (a subclass overriding forward, a patched attention)."""
+        act_quant = any(p is not None for p in self.aq.values())
+        with torch.no_grad():
+            if self.arena is not None:
+                for a in self.arenas:
+                    if not a.wq_fresh:
+                        a.qdq_forward()
+            try:
+                y_f = self._forward_impl(x, input_others, None)
+            except ValueError:          # e.g. rotary tables that do not fit the batch
+                return False
+            y_m = module_forward(x, input_others)
+        # bf16 rounding noise of the two paths is a few percent of the block's own contribution on random-init blocks (less on real
+        # ones); a dropped multiplier, a missing / extra rotation or another norm placement changes it by tens of percent
+        return outputs_agree(y_f, y_m, x, 0.35 if act_quant else 0.25)
+
     def _forward_impl(self, x, others, ctx):
         B, S, H = x.shape
         T = B * S
@@ -455,6 +507,8 @@ class FusedOPTBlock(FusedLlamaBlock):
 
     @staticmethod
     def _parts(block):
+        if not _class_in(block, OPT_FAMILY):
+            return None
         try:
             attn = block.self_attn
             return (block.self_attn_layer_norm, block.final_layer_norm, attn,

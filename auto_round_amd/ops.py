@@ -38,11 +38,9 @@ def dt_code(dtype: torch.dtype) -> int:
 
 def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
-        _devs_seen.clear()
         raise _lib.Mi355xLibraryError(
             f"{name} is on {t.device}: the MI355X path only runs on a HIP device and has no CPU fallback")
     if not t.is_contiguous():
-        _devs_seen.clear()
         raise ValueError(f"{name} must be contiguous")
     return t
 
@@ -50,22 +48,28 @@ def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
 import contextlib as _contextlib
 
 _NULLCTX = _contextlib.nullcontext()
-_devs_seen: list = []     # device index of every tensor handed to the launch being assembled (checked by _launch)
+
+
+class _Ptr(int):
+    """A device address that remembers which HIP device it lives on (ctypes takes it as the integer it is): `_launch` derives the
+    launch device from its own arguments -- no module-level bookkeeping that an exception between `_p()` and `_launch()` could
+    leave stale, nothing shared between threads."""
+    dev: int = -1
 
 
 def _p(t: Optional[torch.Tensor], name: str = "tensor"):
     if t is None:
         return None
-    _devs_seen.append(_dev(t, name).device.index)
-    return t.data_ptr()
+    p = _Ptr(_dev(t, name).data_ptr())
+    p.dev = t.device.index
+    return p
 
 
 def _launch(entry: str, *args):
     """One C-ABI call on the stream of the device that OWNS the tensors (not whatever device happens to be current):
     every pointer of a launch must live on one HIP device; if that device is not the current one the call runs under a
     device guard, so `SignRoundQuantizer(device="cuda:1")` works while cuda:0 is current."""
-    devs = set(_devs_seen)
-    _devs_seen.clear()
+    devs = {a.dev for a in args if isinstance(a, _Ptr)}
     if len(devs) != 1:
         raise _lib.Mi355xLibraryError(f"{entry}: tensors live on HIP devices {sorted(devs)}; one launch needs one device")
     (dev,) = devs
@@ -497,12 +501,11 @@ def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate
     N = X2d.shape[1]
     if X2d.shape[0] != K or tuple(out.shape) != (M, N):
         raise ValueError("gemm_dw: shape mismatch")
+    devs = set()
     for t in (dY2d, X2d, out):
         if not t.is_cuda:
             raise _lib.Mi355xLibraryError("gemm_dw: the MI355X path only runs on a HIP device and has no CPU fallback")
-        _devs_seen.append(t.device.index)
-    devs = set(_devs_seen)
-    _devs_seen.clear()
+        devs.add(t.device.index)
     if len(devs) != 1:
         raise _lib.Mi355xLibraryError("gemm_dw: tensors live on different HIP devices")
     (dev,) = devs

@@ -392,6 +392,11 @@ class SignRoundQuantizer:
                                       tn_dx_gemm=cfg.tn_dx_gemm)
             if fused is not None:
                 fused.flash_fwd = bool(cfg.flash_attention)
+                # the fused kernels must compute what the block's own code computes: one small minibatch through both
+                nchk = min(2, nsamples)
+                others_chk = input_others if not per_sample_others else {**input_others, **{k: t[:nchk] for k, t in per_sample_others.items()}}
+                if not fused.agrees_with_module(lambda x, o: self.block_forward(block, x, o), X[:nchk], others_chk):
+                    fused = None
         self.last_fused_block = fused is not None
 
         # one (round, minmax) pair of param groups per arena; lr by the arena's bit-width (quantizer.py:374-417)
@@ -672,6 +677,8 @@ class SignRoundQuantizer:
             fb = build_fused_block_plain(block, input_others, self.config.amp_dtype, sdpa_ctx=self._sdpa_ctx)
             if fb is not None:
                 fb.flash_fwd = bool(self.config.flash_attention)
+                if not fb.agrees_with_module(lambda x, o: self.block_forward(block, x, o), inputs[:min(2, inputs.shape[0])], input_others):
+                    fb = None
         outs = []
         for b0 in range(0, inputs.shape[0], bs):
             x = inputs[b0:b0 + bs]

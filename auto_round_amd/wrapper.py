@@ -405,31 +405,35 @@ class BlockArena:
             ops.sign_sgd_(p, buf, lr)
 
         lo, hi = self.bounds
+        # the forward's in-place clamp of the scale parameters (wrapper.py:257-259) comes first: collect_best_params, which runs
+        # after the forward, sees the clamped values
+        if self.kind == "int":
+            self.min_scale.clamp_(lo, hi)
+        self.max_scale.clamp_(lo, hi)
         if snapshot_flag is not None:       # collect_best_params happens before optimizer.step()
             take = snapshot_flag.to(torch.bool)
             self.best_V.copy_(torch.where(take, self.V, self.best_V))
             self.best_max.copy_(torch.where(take, self.max_scale, self.best_max))
             self.best_min.copy_(torch.where(take, self.min_scale, self.best_min))
-        if self.kind == "int":
-            self.min_scale.clamp_(lo, hi)       # the in-place clamp of _qdq_weight (wrapper.py:257-259), fused in the other path
-            self.max_scale.clamp_(lo, hi)
-            dV, dmin, dmax = ops.qdq_int_bwd(self.dWq, self.W, self.V, self.wmin, self.wmax, self.min_scale, self.max_scale,
-                                             gs=self.gs, bits=self.bits, sym=self.sym_code, scale_dtype=self.scale_dtype,
-                                             q_thresh=self.q_thresh, bounds=self.bounds)
-            step(self.V, dV, lr_v, "v")
-            if self.tune_minmax:
-                if self.sym_code != 2:
-                    step(self.min_scale, dmin, lr_mm, "min")
-                step(self.max_scale, dmax, lr_mm, "max")
-        else:
-            self.max_scale.clamp_(lo, hi)
-            layers = [None] if self.kind == "mx" else self.layers
-            for li, l in enumerate(layers):
-                sl = slice(None) if l is None else slice(l._off, l._off + l.numel)
-                gl = slice(None) if l is None else slice(l._goff, l._goff + l.n_groups)
+        # one layer at a time: a layer whose forward did not run this iteration (a MoE expert without tokens) has grad None in
+        # the reference, and SignSGD skips such parameters -- buffer untouched, no step (sign_sgd.py:356-389)
+        for li, l in enumerate(self.layers):
+            if not l._dw_accum[0]:
+                continue
+            sl, gl = slice(l._off, l._off + l.numel), slice(l._goff, l._goff + l.n_groups)
+            if self.kind == "int":
+                dV, dmin, dmax = ops.qdq_int_bwd(self.dWq[sl], self.W[sl], self.V[sl], self.wmin[gl], self.wmax[gl], self.min_scale[gl],
+                                                 self.max_scale[gl], gs=self.gs, bits=self.bits, sym=self.sym_code,
+                                                 scale_dtype=self.scale_dtype, q_thresh=self.q_thresh, bounds=self.bounds)
+                step(self.V[sl], dV, lr_v, ("v", li))
+                if self.tune_minmax:
+                    if self.sym_code != 2:
+                        step(self.min_scale[gl], dmin, lr_mm, ("min", li))
+                    step(self.max_scale[gl], dmax, lr_mm, ("max", li))
+            else:
                 dV, dmax = ops.qdq_fp4_bwd_sgd_(self.dWq[sl], self.W[sl], self.V[sl], self.absmax[gl], self.max_scale[gl], mode=self.mode,
                                                 gs=self.gs, bounds=self.bounds, init_scale_dev=None if self.init is None else self.init[gl],
-                                                global_scale=None if l is None else l.weight_global_scale_dev, want_grads=True)
+                                                global_scale=l.weight_global_scale_dev if self.kind == "nv" else None, want_grads=True)
                 step(self.V[sl], dV, lr_v, ("v", li))
                 if self.tune_minmax:
                     step(self.max_scale[gl], dmax, lr_mm, ("max", li))
@@ -442,9 +446,6 @@ class BlockArena:
         if snapshot_flag is not None:
             self.alloc_best()
         if momentum:
-            for lyr in self.layers:
-                if not lyr._dw_accum[0]:
-                    lyr.weight_grad.zero_()
             return self._momentum_step(lr_v, lr_mm, snapshot_flag, float(momentum))
         # a layer whose forward did not run this iteration (e.g. a MoE expert that received no token) has no gradient:
         # the reference's SignSGD skips parameters with grad None; here a zero dWq slice makes every sign step 0

@@ -48,3 +48,8 @@ def test_two_ranks_run_the_sharded_pipeline():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["value"] > 0
     assert "tune_sharded over 4 blocks" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1000.0)) < 1e-6 * d["value"] + 1e-9       # whole-job blocks / max-over-ranks time
+    # the record says who took part and what each rank did
+    mg = d["multi_gpu"]
+    assert mg["world_size"] == 2 and [r["rank"] for r in mg["ranks"]] == [0, 1] and all(r["device"] for r in mg["ranks"])
+    assert mg["blocks_tuned_per_rank"] == [2, 2] and mg["calibration_broadcast"]["GBps"] > 0
+    assert "roofline" in d and d["roofline"]["launches"] > 0          # rank 0's own K1 dispatches

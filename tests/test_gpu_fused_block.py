@@ -731,3 +731,145 @@ def test_fused_block_honours_a_sliding_window_mask():
     assert (pred_f.float() - pred_m.float()).abs().mean().item() < 5e-3 * scale
     assert (causal.float() - pred_m.float()).abs().mean().item() > 2e-2 * scale        # the window matters on this input
     unwrapper_block(blk, {})
+
+
+# ---- round 3: one tuning iteration as a captured hipGraph, device-table loop, hybrid split of a partial last round ----------------
+def test_iter_begin_copies_this_iterations_indices_and_learning_rates_and_best_loss_update_advances_the_counter():
+    from auto_round_amd import ops as o
+
+    iters, batch, n_lr = 5, 4, 3
+    sched = torch.arange(iters * batch, dtype=torch.int64, device=_dev()) * 7
+    lr_table = (torch.arange(n_lr * iters, dtype=torch.float32, device=_dev()) + 0.5).reshape(n_lr, iters).contiguous()
+    it = torch.zeros(1, dtype=torch.int32, device=_dev())
+    cur, lr = torch.full((batch,), -1, dtype=torch.int64, device=_dev()), torch.zeros(n_lr, dtype=torch.float32, device=_dev())
+    total, state = torch.zeros(1, device=_dev()), torch.tensor([3.4e38, 0.0, 0.0], device=_dev())
+    istate, hist = torch.zeros(4, dtype=torch.int32, device=_dev()), torch.zeros(iters, device=_dev())
+    losses = [5.0, 4.0, 6.0, 3.5, 3.75]
+    for i in range(iters):
+        o.iter_begin(it, sched, cur, lr_table, lr, iters)
+        assert cur.tolist() == [7 * (i * batch + j) for j in range(batch)]
+        assert lr.tolist() == [k * iters + i + 0.5 for k in range(n_lr)]
+        total.fill_(losses[i])
+        o.best_loss_update(total, state, istate, 12345, iter_dev=it, loss_hist=hist)       # the host-side number is ignored
+        assert int(it.item()) == i + 1 and float(total.item()) == 0.0
+    assert hist.tolist() == losses and state.tolist() == [3.5, 5.0, 3.75] and istate.tolist()[:3] == [0, 3, 3]
+    o.iter_begin(it, sched, cur, lr_table, lr, iters)          # past the last iteration: nothing is touched
+    assert cur.tolist() == [7 * ((iters - 1) * batch + j) for j in range(batch)]
+
+
+@pytest.mark.parametrize("family", ["llama", "opt"])
+def test_captured_hipgraph_iterations_equal_the_host_driven_loop_bit_for_bit(family):
+    """`SignRoundConfig.hip_graph`: iteration 0 eagerly, ONE captured iteration, iters - 1 replays -- the same kernels in the same
+    order as the host-driven loop, so every tuned weight, scale and the whole loss trace must be identical."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    if family == "llama":
+        layer, rope, cfg = _llama_layer(bits=4, gs=32)
+        X, others = _data(rope, cfg, N=16, S=128)
+    else:
+        layer, cfg = _opt_layer(bits=4, gs=32)
+        X, others = _rand(16, 256, cfg.hidden_size, seed=1), {}       # 256 tokens: the flash-attention forward + library backward pair
+    ids = torch.randint(0, 100, (16, X.shape[1]))
+    ids[:, -1] = -100                                           # the reference's default loss mask: same count in every minibatch
+    res = {}
+    for graph in (False, True):
+        blk = copy.deepcopy(layer)
+        random.seed(7)
+        q = SignRoundQuantizer(SignRoundConfig(iters=12, batch_size=4, bits=4, lr=5e-3, minmax_lr=5e-3, fused_block=True, mfma_dw_gemm=True,
+                                               hip_graph=graph), device="cuda")
+        fp_out, q_out, best = q.compress_block(blk, X, others, input_ids=ids)
+        assert q.last_fused_block and q.last_hip_graph is graph and q.last_stats["hip_graph"] is graph
+        res[graph] = (q.last_stats, {n: m.weight.detach().clone() for n, m in blk.named_modules() if isinstance(m, torch.nn.Linear)},
+                      {n: m.scale.clone() for n, m in blk.named_modules() if isinstance(m, torch.nn.Linear)}, q_out)
+    assert res[False][0]["loss_trace"] == res[True][0]["loss_trace"] and len(res[True][0]["loss_trace"]) == 12
+    assert res[True][0]["best_loss"] < 0.9 * res[True][0]["init_loss"] and res[True][0]["best_iter"] == res[False][0]["best_iter"]
+    for n, w in res[False][1].items():
+        assert torch.equal(w, res[True][1][n]), n
+        assert torch.equal(res[False][2][n], res[True][2][n]), n
+    assert torch.equal(res[False][3], res[True][3])
+
+
+def test_hipgraph_is_not_used_where_an_iteration_needs_the_host():
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    layer, rope, cfg = _llama_layer(bits=4, gs=32)
+    X, others = _data(rope, cfg, N=16, S=128)
+    for kw in (dict(dynamic_max_gap=3), dict(gradient_accumulate_steps=2), dict(not_use_best_mse=True), dict(fused_block=False)):
+        blk = copy.deepcopy(layer)
+        random.seed(7)
+        c = dict(iters=6, batch_size=4, bits=4, lr=5e-3, minmax_lr=5e-3, fused_block=True, mfma_dw_gemm=True, hip_graph=True)
+        c.update(kw)
+        q = SignRoundQuantizer(SignRoundConfig(**c), device="cuda")
+        q.compress_block(blk, X, others)
+        assert q.last_hip_graph is False, kw
+    ragged = torch.randint(0, 100, (16, 128))
+    ragged[:8, -5:] = -100                                       # valid-token counts differ between samples: a kernel argument varies
+    ragged[:, -1] = -100
+    blk = copy.deepcopy(layer)
+    random.seed(7)
+    q = SignRoundQuantizer(SignRoundConfig(iters=6, batch_size=4, bits=4, lr=5e-3, minmax_lr=5e-3, fused_block=True, hip_graph=True), device="cuda")
+    q.compress_block(blk, X, others, input_ids=ragged)
+    assert q.last_fused_block and q.last_hip_graph is False
+
+
+@pytest.mark.parametrize("K,M,N", [(2048, 6144, 4096), (4096, 2048, 7168)])       # 384 and 224 tiles... the first has a 128-tile tail
+def test_gemm_dw_hybrid_tail_split_vs_the_plain_launch_and_fp32(K, M, N):
+    """More than one round of 256 x 256 tiles whose last round is at most half full: that round is split along K (two launches +
+    an ordered reduction).  Against the unsplit kernel the result differs only by fp32 summation order."""
+    from auto_round_amd import _lib, ops
+
+    dY, X = _rand(K, M, seed=21), _rand(K, N, seed=22)
+    lib = _lib.load()
+    want_tail = lib.ar_gemm_dw_workspace_bytes(M, N, K) > 0
+    assert want_tail == ((M // 256) * (N // 256) % 256 in range(1, 129) and (M // 256) * (N // 256) > 256)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=_dev())
+    assert ops.gemm_dw(dY, X, out)
+    lib.ar_gemm_dw_config(20, -1)                                 # hybrid off
+    try:
+        plain = torch.empty(M, N, dtype=torch.bfloat16, device=_dev())
+        assert ops.gemm_dw(dY, X, plain)
+    finally:
+        lib.ar_gemm_dw_config(21, -1)
+    ref = dY.float().t() @ X.float()
+    assert torch.allclose(out.float(), ref, rtol=1e-2, atol=2e-2)
+    assert (out == plain).float().mean().item() > (0.995 if want_tail else 0.99999)
+    assert (out == ref.to(torch.bfloat16)).float().mean().item() > 0.99
+    old = _rand(M, N, seed=23)
+    acc = old.clone()
+    assert ops.gemm_dw(dY, X, acc, accumulate=True)
+    assert torch.allclose(acc.float(), old.float() + ref, rtol=1e-2, atol=3e-2)
+
+
+def test_split_k_plan_stays_within_one_round_of_workgroups():
+    from auto_round_amd import _lib
+
+    lib = _lib.load()
+    for M, N, K in ((768, 768, 16384), (2304, 768, 16384), (3072, 768, 16384), (768, 3072, 16384), (1024, 1024, 16384)):
+        tiles = (M // 256) * (N // 256)
+        ns = lib.ar_gemm_dw_workspace_bytes(M, N, K) // (M * N * 4)
+        assert 2 <= ns and tiles * ns <= 256 < tiles * (ns + 1), (M, N, K, ns)
+
+
+def test_a_look_alike_block_that_computes_something_else_keeps_the_module_path():
+    """The class whitelist admits LlamaDecoderLayer; a patched instance whose forward scales the residual branch (what Granite's
+    residual_multiplier does) must be caught by the one-minibatch agreement check and tuned through its own module code."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    layer, rope, cfg = _llama_layer(bits=4, gs=32)
+    X, others = _data(rope, cfg, N=8, S=32)
+    blk = copy.deepcopy(layer)
+    attn_fwd = blk.self_attn.forward
+
+    def scaled_attn(*a, **k):
+        out = attn_fwd(*a, **k)
+        return (out[0] * 0.22,) + tuple(out[1:])
+
+    blk.self_attn.forward = scaled_attn
+    random.seed(7)
+    q = SignRoundQuantizer(SignRoundConfig(iters=4, batch_size=4, bits=4, lr=5e-3, minmax_lr=5e-3, fused_block=True), device="cuda")
+    q.compress_block(blk, X, others)
+    assert q.last_fused_block is False
+    blk = copy.deepcopy(layer)
+    random.seed(7)
+    q.compress_block(blk, X, others)
+    assert q.last_fused_block is True

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""rows_FETCH_SIZE.csv + rows_WRITE_SIZE.csv (tools/rocprof_summary.py --pmc-rows over tools/pmc_traffic_probe.py) -> the JSON
+bench.py reads as profiles/pmc_traffic.json.  HBM bytes per dispatch = (2 * FETCH_SIZE + WRITE_SIZE) KiB: both counters are in KiB
+and FETCH_SIZE reports half the bytes of wide streaming reads on gfx950 (MI355X_MICROARCH.md, HBM section); the calibration copy in
+the same run shows both.  The three variants of the fused backward kernel share one kernel name; the probe launches them in a
+fixed order (REP plain, REP with snapshot, REP with next forward) and this script takes the dispatches in that order.
+
+    python tools/pmc_traffic_merge.py rows_FETCH_SIZE.csv rows_WRITE_SIZE.csv > profiles/pmc_traffic.json"""
+import csv
+import json
+import sys
+
+N, G, REP = 218103808, 1703936, 4
+
+
+def rows(path):
+    out = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            out.setdefault(r["kernel"], []).append(float(r["value"]))
+    return out
+
+
+def pick(d, frag):
+    ks = [k for k in d if frag in k]
+    if len(ks) != 1:
+        raise SystemExit(f"{frag}: {ks}")
+    return d[ks[0]]
+
+
+def main():
+    f, w = rows(sys.argv[1]), rows(sys.argv[2])
+
+    def traffic(frag, sl):
+        fv, wv = pick(f, frag)[sl], pick(w, frag)[sl]
+        return [(2 * a + b) * 1024 for a, b in zip(fv, wv)], fv, wv
+
+    def mean(v):
+        return sum(v) / len(v)
+
+    k1, k1f, k1w = traffic("k_int_fwd_flat", slice(0, REP))
+    b_plain, _, _ = traffic("k_int_bwd_flat", slice(0, REP))
+    b_snap, _, _ = traffic("k_int_bwd_flat", slice(REP, 2 * REP))
+    b_next, _, _ = traffic("k_int_bwd_flat", slice(2 * REP, 3 * REP))
+    cp = [k for k in f if "copy" in k.lower() or "Copy" in k]
+    calib = None
+    if cp:
+        calib = {"kernel": cp[0][:80], "FETCH_SIZE_KiB": mean(f[cp[0]][:2]), "WRITE_SIZE_KiB": mean(w.get(cp[0], [0.0])[:2]), "bytes_copied": 2 * N}
+    alg = {"k_int_fwd": 8 * N + 12 * G, "k_int_bwd": 12 * N + 8 * G, "k_int_bwd_with_snapshot": 16 * N + 16 * G,
+           "k_int_bwd_with_next_fwd": 14 * N + 8 * G}
+    out = {"_note": "HBM bytes per launch at the Llama-3-8B block size (218,103,808 weights, 1,703,936 groups of 128), round 3 kernels: "
+                    "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over tools/pmc_traffic_probe.py, "
+                    "per-dispatch rows by tools/rocprof_summary.py --pmc-rows, merged by tools/pmc_traffic_merge.py. traffic = "
+                    "(2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE reports half of a wide coalesced read stream; see the calibration copy).",
+           "k_int_fwd": mean(k1), "k_int_bwd": mean(b_plain), "k_int_bwd_with_snapshot": mean(b_snap), "k_int_bwd_with_next_fwd": mean(b_next),
+           "algorithmic": alg, "ratio": {"k_int_fwd": mean(k1) / alg["k_int_fwd"], "k_int_bwd": mean(b_plain) / alg["k_int_bwd"],
+                                         "k_int_bwd_with_snapshot": mean(b_snap) / alg["k_int_bwd_with_snapshot"],
+                                         "k_int_bwd_with_next_fwd": mean(b_next) / alg["k_int_bwd_with_next_fwd"]},
+           "calibration_copy": calib, "dispatches_per_variant": REP}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

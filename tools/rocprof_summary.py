@@ -4,6 +4,7 @@ committed under profiles/.
 
   python tools/rocprof_summary.py <results.db> --stats out.csv          # per-kernel calls / total / average (us)
   python tools/rocprof_summary.py <results.db> --pmc out.csv            # per-kernel mean counter values
+  python tools/rocprof_summary.py <results.db> --pmc-rows rows.csv      # one row per (dispatch, counter), in dispatch order
 """
 import argparse
 import csv
@@ -16,6 +17,7 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--stats")
     ap.add_argument("--pmc")
+    ap.add_argument("--pmc-rows", dest="pmc_rows")
     ap.add_argument("--top", type=int, default=60)
     a = ap.parse_args()
     db = sqlite3.connect(a.db)
@@ -44,6 +46,23 @@ def main():
             for (k, c), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
                 w.writerow([k[:160], c, len(v), sum(v) / len(v), min(v), max(v)])
         print(f"wrote {a.pmc} ({len(agg)} kernel/counter pairs); columns={cols}")
+    if a.pmc_rows:
+        pmc_rows(db, a.pmc_rows)
+
+
+def pmc_rows(db, path):
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    ix = {c: i for i, c in enumerate(cols)}
+    name_c = "kernel_name" if "kernel_name" in ix else "name"
+    order_c = next((c for c in ("dispatch_id", "start", "start_timestamp", "id") if c in ix), None)
+    q = "select * from counters_collection" + (f" order by {order_c}" if order_c else "")
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["order", "kernel", "counter", "value"])
+        for r in cur.execute(q):
+            w.writerow([r[ix[order_c]] if order_c else "", r[ix[name_c]][:160], r[ix["counter_name"]], float(r[ix["value"]])])
+    print(f"wrote {path}; ordered by {order_c}; columns={cols}")
 
 
 if __name__ == "__main__":
