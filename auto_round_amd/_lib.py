@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -58,6 +58,9 @@ SIGNATURES = {
     "ar_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, L, I, I, P]),
     "ar_swiglu_fwd": (c_int, [P, L, P, L, L, I, P]),
     "ar_swiglu_bwd": (c_int, [P, P, L, L, L, I, P]),
+    "ar_moe_expand": (c_int, [P, P, P, P, L, L, I, P]),
+    "ar_moe_combine": (c_int, [P, P, P, P, P, L, L, I, I, P]),
+    "ar_moe_rowdot": (c_int, [P, P, P, P, L, L, I, P]),
     "ar_rope_fwd": (c_int, [P, L, P, P, L, P, P, P, L, L, I, I, I, I, P]),
     "ar_headnorm_fwd": (c_int, [P, P, P, P, P, L, L, I, I, I, F, I, P]),
     "ar_headnorm_bwd": (c_int, [P, P, P, P, P, L, L, I, I, I, I, P]),

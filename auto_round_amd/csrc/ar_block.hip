@@ -313,6 +313,70 @@ __global__ __launch_bounds__(kTPB) void k_swiglu_bwd(const void* __restrict__ da
     store8<DT>(gu, r * ld + F + c * kEPT, du);
 }
 
+// ---- sparse-MoE routing glue (sorted-token expert pass) -----------------------------------------------------------------------
+// The expert pass of a MoE block runs over rows sorted by expert: row p of the sorted buffers belongs to token tok[p]; token t's
+// K routed copies sit at rows pos[t * K + k].  Three streaming kernels replace the per-expert index / scale / index_add_ ops of
+// MixtralExperts.forward (transformers/models/mixtral/modeling_mixtral.py) and their autograd mirrors; none uses float atomics.
+//   expand : out[p, :] = dt(scale[p] * src[tok[p], :])                       (scale NULL: plain row gather)
+//   combine: out[t, :] = dt(res[t, :] + sum_k w[t K + k] * D[pos[t K + k], :])   (res / w NULL: 0 / 1), fp32 sum in slot order
+//   rowdot : out[p]    = sum_j A[tok[p], j] * B[p, j]                          (fp32; one wave per row)
+template <int DT>
+__global__ __launch_bounds__(kTPB) void k_moe_expand(const void* __restrict__ src, const int64_t* __restrict__ tok, const float* __restrict__ scale,
+                                                      void* __restrict__ out, int64_t rows, int64_t H) {
+    const int64_t cpr = H / kEPT;
+    const int64_t idx = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+    if (idx >= rows * cpr) return;
+    const int64_t p = idx / cpr, c = idx - p * cpr;
+    float v[8];
+    unpack8<DT>(load8_raw<DT>(src, tok[p] * H + c * kEPT), v);
+    if (scale) {
+        const float sc = scale[p];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= sc;
+    }
+    store8<DT>(out, p * H + c * kEPT, v);
+}
+
+template <int DT>
+__global__ __launch_bounds__(kTPB) void k_moe_combine(const void* __restrict__ D, const int64_t* __restrict__ pos, const float* __restrict__ w,
+                                                       const void* __restrict__ res, void* __restrict__ out, int64_t T, int64_t H, int K) {
+    const int64_t cpr = H / kEPT;
+    const int64_t idx = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+    if (idx >= T * cpr) return;
+    const int64_t t = idx / cpr, c = idx - t * cpr;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (res) unpack8<DT>(load8_raw<DT>(res, t * H + c * kEPT), acc);
+    for (int k = 0; k < K; ++k) {
+        float v[8];
+        unpack8<DT>(load8_raw<DT>(D, pos[t * K + k] * H + c * kEPT), v);
+        const float wk = w ? w[t * K + k] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wk * v[j];
+    }
+    store8<DT>(out, t * H + c * kEPT, acc);
+}
+
+template <int DT>
+__global__ __launch_bounds__(kTPB) void k_moe_rowdot(const void* __restrict__ A, const int64_t* __restrict__ tok, const void* __restrict__ B,
+                                                      float* __restrict__ out, int64_t rows, int64_t H) {
+    const int64_t p = (int64_t)blockIdx.x * (kTPB / kWave) + (threadIdx.x >> 6);
+    if (p >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t a0 = tok[p] * H, b0 = p * H;
+    float s = 0.f;
+    for (int64_t c = lane; c < H / kEPT; c += kWave) {
+        float x[8], y[8];
+        unpack8<DT>(load8_raw<DT>(A, a0 + c * kEPT), x);
+        unpack8<DT>(load8_raw<DT>(B, b0 + c * kEPT), y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += x[j] * y[j];
+    }
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, kWave);
+    if (lane == 0) out[p] = s;
+}
+
 // ---- rotary embedding + grouped-query head repeat -------------------------------------------------------------------------
 // qkv [T, (hq + 2 hkv) * d] (ld) -> q [T, hq*d], k [T, hq*d], v [T, hq*d] with every kv head written hq/hkv times (what repeat_kv
 // materialises for the SDPA kernels).  x_embed = dt(dt(x*cos) + dt(rotate_half(x)*sin))   (apply_rotary_pos_emb, each op rounded).
@@ -614,6 +678,41 @@ extern "C" int ar_rope_bwd(const void* dq, const void* dk, const void* dv, const
     hipStream_t st = (hipStream_t)stream;
     const int grid = grid1d(tokens * (hq + 2 * hkv) * (d / (2 * kEPT)));
 #define AR_CALL(DT) AR_LAUNCH_PROF(AR_PROF_ROPE, tokens, (k_rope_bwd<DT>), grid, kTPB, 0, st, dq, dk, dv, cos, sin, cs_batch_stride, dqkv, ld, tokens, seq, hq, hkv, d)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_moe_expand(const void* src, const int64_t* tok, const float* scale, void* out, int64_t rows, int64_t H, int dt,
+                             ar_stream_t stream) {
+    if (rows <= 0 || H <= 0) return AR_OK;
+    if (H % kEPT || !tok) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d(rows * (H / kEPT));
+#define AR_CALL(DT) hipLaunchKernelGGL((k_moe_expand<DT>), grid, kTPB, 0, st, src, tok, scale, out, rows, H)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_moe_combine(const void* D, const int64_t* pos, const float* w, const void* res, void* out, int64_t T, int64_t H, int K,
+                              int dt, ar_stream_t stream) {
+    if (T <= 0 || H <= 0) return AR_OK;
+    if (H % kEPT || K <= 0 || !pos) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d(T * (H / kEPT));
+#define AR_CALL(DT) hipLaunchKernelGGL((k_moe_combine<DT>), grid, kTPB, 0, st, D, pos, w, res, out, T, H, K)
+    AR_DT_SWITCH2(dt, AR_CALL)
+#undef AR_CALL
+    return launch_status();
+}
+
+extern "C" int ar_moe_rowdot(const void* A, const int64_t* tok, const void* B, float* out, int64_t rows, int64_t H, int dt, ar_stream_t stream) {
+    if (rows <= 0 || H <= 0) return AR_OK;
+    if (H % kEPT || !tok) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)((rows + (kTPB / kWave) - 1) / (kTPB / kWave));
+#define AR_CALL(DT) hipLaunchKernelGGL((k_moe_rowdot<DT>), grid, kTPB, 0, st, A, tok, B, out, rows, H)
     AR_DT_SWITCH2(dt, AR_CALL)
 #undef AR_CALL
     return launch_status();

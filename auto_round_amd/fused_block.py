@@ -56,6 +56,7 @@ def _is_silu(act) -> bool:
 # embedding; HunYuan: q/k norms AFTER the rotation; Ernie 4.5: interleaved rotate_half) -- those keep the generic module path.
 LLAMA_FAMILY = ("LlamaDecoderLayer", "MistralDecoderLayer", "Qwen2DecoderLayer", "Qwen3DecoderLayer")
 OPT_FAMILY = ("OPTDecoderLayer",)
+MOE_FAMILY = ("MixtralDecoderLayer",)
 
 
 def _class_in(block, names) -> bool:
@@ -401,18 +402,19 @@ class FusedLlamaBlock:
         # ones); a dropped multiplier, a missing / extra rotation or another norm placement changes it by tens of percent
         return outputs_agree(y_f, y_m, x, 0.35 if act_quant else 0.25)
 
-    def _forward_impl(self, x, others, ctx):
+    # -- the attention half (shared with the sparse-MoE block) --------------------------------------------------------------
+    def _attn_half_forward(self, x, others, ctx):
+        """RMSNorm -> merged q/k/v GEMM -> [per-head norms] -> rotary -> attention -> o-proj + residual.  -> (x2 [T, H], saved)"""
+        from .wrapper import act_quant_fwd_raw
+
         B, S, H = x.shape
         T = B * S
-        L = self.layers
         x2d = x.reshape(T, H)
         if x2d.dtype != self.dtype:
             x2d = x2d.to(self.dtype)
         x2d = x2d.contiguous()
         cos, sin = self._cos_sin(others, B, S)
         mask = others.get("attention_mask")
-        from .wrapper import act_quant_fwd_raw
-
         aq = self.aq
 
         def fq(t, plan):        # the GEMM's input: fake-quantised activations where the scheme has them
@@ -434,44 +436,23 @@ class FusedLlamaBlock:
         attn2d = attn.detach().transpose(1, 2).reshape(T, self.hq * self.hd)
         attn_in = fq(attn2d, aq["o"])
         x2 = self._linear_residual(x2d, attn_in, self.Wo, self.b_o, inplace=ctx is not None and getattr(self, "_donated", False))
-        h2, rstd2 = ops.rmsnorm_fwd(x2, self.w2, self.eps2, want_rstd=ctx is not None)
-        h2_in = fq(h2, aq["gu"])
-        gu = F.linear(h2_in, self.Wgu, self.b_gu)
-        act = ops.swiglu_fwd(gu, self.Fdim)
-        act_in = fq(act, aq["d"])
-        y = self._linear_residual(x2, act_in, self.Wd, self.b_d)
+        saved = None
         if ctx is not None:
-            ctx.saved = dict(h1=h1, attn=attn, leaves=leaves, attn2d=attn2d, attn_in=attn_in, x2=x2, rstd2=rstd2, h2=h2, h2_in=h2_in,
-                             gu=gu, act=act, act_in=act_in, cos=cos, sin=sin, B=B, S=S, qkv_raw=qkv_raw, rstd_qk=rstd_qk)
-        return y.view(B, S, H)
+            saved = dict(h1=h1, attn=attn, leaves=leaves, attn2d=attn2d, attn_in=attn_in, cos=cos, sin=sin, B=B, S=S, qkv_raw=qkv_raw,
+                         rstd_qk=rstd_qk)
+        return x2, saved
 
-    def _backward_impl(self, ctx, dy):
-        s = ctx.saved
-        ctx.saved = None
-        B, S = s["B"], s["S"]
-        T = B * S
-        L = self.layers
-        dy2d = dy.reshape(T, self.H)
-        if dy2d.dtype != self.dtype:
-            dy2d = dy2d.to(self.dtype)
-        dy2d = dy2d.contiguous()
+    def _attn_half_backward(self, s, dx2):
+        """dx2: gradient w.r.t. the post-attention residual stream (consumed).  Fills dWo and the merged dWqkv."""
         from .wrapper import act_quant_bwd_raw
 
-        aq = self.aq
+        B, S = s["B"], s["S"]
+        T = B * S
+        L, aq = self.layers, self.aq
 
-        def bq(g, x, plan):     # gradient w.r.t. the quantised activation -> gradient w.r.t. the activation
+        def bq(g, x, plan):
             return g if plan is None else act_quant_bwd_raw(g, x, plan)
 
-        # MLP
-        self._dw(dy2d, s.pop("act_in"), self.dWd, [L["d"]])
-        da = bq(self._dx(dy2d, self.Wd, 2), s.pop("act"), aq["d"])
-        dgu = ops.swiglu_bwd_(da, s.pop("gu"), self.Fdim)
-        del da
-        self._dw(dgu, s.pop("h2_in"), self.dWgu, [L["g"], L["u"]])
-        dh2 = bq(self._dx(dgu, self.Wgu, 1), s.pop("h2"), aq["gu"])
-        del dgu
-        dx2 = ops.rmsnorm_bwd(dh2, s.pop("x2"), self.w2, s.pop("rstd2"), dres=dy2d, out=dh2)
-        # attention
         self._dw(dx2, s.pop("attn_in"), self.dWo, [L["o"]])
         dattn = bq(self._dx(dx2, self.Wo, 0), s.pop("attn2d"), aq["o"])
         del dx2
@@ -496,6 +477,55 @@ class FusedLlamaBlock:
             wq, wk, _ = self.qk_norm
             ops.headnorm_bwd_(dqkv, s.pop("qkv_raw"), wq.to(self.dtype), wk.to(self.dtype), s.pop("rstd_qk"), self.hq, self.hkv, self.hd)
         self._dw(dqkv, s.pop("h1"), self.dWqkv, [L["q"], L["k"], L["v"]])
+
+    # -- the two directions of the dense block --------------------------------------------------------------------------------
+    def _forward_impl(self, x, others, ctx):
+        from .wrapper import act_quant_fwd_raw
+
+        B, S, H = x.shape
+        aq = self.aq
+
+        def fq(t, plan):
+            return t if plan is None else act_quant_fwd_raw(t, plan)
+
+        x2, saved = self._attn_half_forward(x, others, ctx)
+        h2, rstd2 = ops.rmsnorm_fwd(x2, self.w2, self.eps2, want_rstd=ctx is not None)
+        h2_in = fq(h2, aq["gu"])
+        gu = F.linear(h2_in, self.Wgu, self.b_gu)
+        act = ops.swiglu_fwd(gu, self.Fdim)
+        act_in = fq(act, aq["d"])
+        y = self._linear_residual(x2, act_in, self.Wd, self.b_d)
+        if ctx is not None:
+            saved.update(x2=x2, rstd2=rstd2, h2=h2, h2_in=h2_in, gu=gu, act=act, act_in=act_in)
+            ctx.saved = saved
+        return y.view(B, S, H)
+
+    def _backward_impl(self, ctx, dy):
+        s = ctx.saved
+        ctx.saved = None
+        T = s["B"] * s["S"]
+        L = self.layers
+        dy2d = dy.reshape(T, self.H)
+        if dy2d.dtype != self.dtype:
+            dy2d = dy2d.to(self.dtype)
+        dy2d = dy2d.contiguous()
+        from .wrapper import act_quant_bwd_raw
+
+        aq = self.aq
+
+        def bq(g, x, plan):     # gradient w.r.t. the quantised activation -> gradient w.r.t. the activation
+            return g if plan is None else act_quant_bwd_raw(g, x, plan)
+
+        # MLP
+        self._dw(dy2d, s.pop("act_in"), self.dWd, [L["d"]])
+        da = bq(self._dx(dy2d, self.Wd, 2), s.pop("act"), aq["d"])
+        dgu = ops.swiglu_bwd_(da, s.pop("gu"), self.Fdim)
+        del da
+        self._dw(dgu, s.pop("h2_in"), self.dWgu, [L["g"], L["u"]])
+        dh2 = bq(self._dx(dgu, self.Wgu, 1), s.pop("h2"), aq["gu"])
+        del dgu
+        dx2 = ops.rmsnorm_bwd(dh2, s.pop("x2"), self.w2, s.pop("rstd2"), dres=dy2d, out=dh2)
+        self._attn_half_backward(s, dx2)
 
 
 class FusedOPTBlock(FusedLlamaBlock):
@@ -730,11 +760,234 @@ class FusedOPTBlock(FusedLlamaBlock):
         self._dw(dqkv, s.pop("h1"), self.dWqkv, self.trio)
 
 
+class FusedMoEBlock(FusedLlamaBlock):
+    """Mixtral-style sparse-MoE decoder block (transformers MixtralDecoderLayer whose fused 3-D expert parameters were unfused by
+    `moe_unfuse.unfuse_moe_experts` -- the reference's "linear_loop" experts, auto_round/modeling/fused_moe/
+    moe_experts_interface.py): the attention half runs through the same kernels as the dense block; the expert half is ONE pass
+    over rows sorted by expert instead of a Python loop of index / SiLU / product / index_add_ ops per expert:
+
+        router (the module's own code, kept in a local autograd graph)      -> top-k weights [T, K], indices [T, K]
+        one stable sort of the (slot, token) pairs, one host read of the per-expert counts
+        xs = gather(h2)  [T K, H]  -> ONE activation fake-quant (gate and up share their input)
+        per expert e with rows r_e:  GU[r_e] = xs_q[r_e] Wgu_e^T   (gate / up merged: adjacent in the arena)
+        act = SwiGLU(GU) (one launch over all rows) -> ONE activation fake-quant
+        per expert:                  D[r_e] = act_q[r_e] Wd_e^T
+        y = x2 + sum_k w[t, k] D[pos[t, k]]          (ar_moe_combine: fp32 sum, one rounding, residual add fused, no atomics)
+
+    and the mirrored backward (weight gradients through the ragged-K MFMA GEMM where it pays; the routing-weight gradient is a
+    row dot product, sent back through the router's local graph).  The per-expert GEMM sizes come from the counts, so one host
+    synchronisation per iteration remains (as in the module path) and the iteration is not captured as a hipGraph."""
+
+    capturable = False
+
+    @classmethod
+    def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True,
+                  tn_dx_gemm=True) -> Optional["FusedMoEBlock"]:
+        from .moe_unfuse import expert_children
+        from .wrapper import WrapperLinear, act_quant_plan
+
+        if not _class_in(block, MOE_FAMILY) or not arenas:
+            return None
+        try:
+            n1, n2, attn, moe = block.input_layernorm, block.post_attention_layernorm, block.self_attn, block.mlp
+            q, k, v, o = attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj
+            router, experts = moe.gate, moe.experts
+        except AttributeError:
+            return None
+        if not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not getattr(experts, "_ar_unfused", False) or not _is_silu(getattr(experts, "act_fn", None)):
+            return None
+        if float(getattr(moe, "jitter_noise", 0.0) or 0.0) != 0.0 and block.training:
+            return None
+        rw = getattr(router, "weight", None)
+        kids = expert_children(experts)
+        if not isinstance(rw, torch.Tensor) or rw.dim() != 2 or not kids or len(kids) != rw.shape[0] or not hasattr(router, "top_k"):
+            return None
+        try:
+            trip = [(e.gate_proj, e.up_proj, e.down_proj) for e in kids]
+        except AttributeError:
+            return None
+        proj = [q, k, v, o] + [p for t in trip for p in t]
+        if not all(isinstance(p, WrapperLinear) for p in proj):
+            return None
+        if any(p.padded or p.is_conv1d or p.orig_layer.bias is not None or not any(p.arena is a for a in arenas) for p in proj):
+            return None
+        if not (q.arena is k.arena is v.arena) or len({a.w_dtype for a in arenas}) != 1 or q.arena.w_dtype != amp_dtype \
+                or amp_dtype not in (torch.bfloat16, torch.float16):
+            return None
+        if not (k._off == q._off + q.numel and v._off == k._off + k.numel):
+            return None
+        H, Fd = q.in_features, trip[0][0].out_features
+        for g, u, d in trip:
+            if not (g.arena is u.arena and u._off == g._off + g.numel and g.in_features == u.in_features == H == d.out_features
+                    and g.out_features == u.out_features == Fd == d.in_features):
+                return None
+        try:
+            plans = [act_quant_plan(p.orig_layer, p.in_features) if p.enable_act_quant else None for p in proj]
+        except NotImplementedError:
+            return None
+        pl_gu, pl_d = plans[4], plans[6]
+        if any(pl is not None and pl[0] == "nv" for pl in plans) or not (plans[0] == plans[1] == plans[2]):
+            return None
+        if any(plans[4 + 3 * i] != pl_gu or plans[5 + 3 * i] != pl_gu or plans[6 + 3 * i] != pl_d for i in range(len(trip))):
+            return None
+        others = dict(input_others or {})
+        pe = others.get("position_embeddings")
+        hd = int(getattr(attn, "head_dim", 0))
+        if others.get("past_key_values") is not None or hd <= 0 or hd % 16 or q.out_features % hd or k.out_features % hd or not _rotary_ok(pe, hd):
+            return None
+        hq, hkv = q.out_features // hd, k.out_features // hd
+        if hq % hkv or o.in_features != hq * hd or Fd % 8 or H % 8 or k.out_features != v.out_features or _qk_norm(attn, hd) is not None:
+            return None
+
+        self = cls()
+        arena = q.arena
+        self.block, self.arena, self.arenas, self.attn = block, arena, list(arenas), attn
+        self.layers = dict(q=q, k=k, v=v, o=o)
+        self.trip = trip
+        self.router, self.top_k, self.E = router, int(router.top_k), len(trip)
+        self.w1, self.eps1 = n1.weight, float(n1.variance_epsilon)
+        self.w2, self.eps2 = n2.weight, float(n2.variance_epsilon)
+        self.hq, self.hkv, self.hd = hq, hkv, hd
+        self.qk_norm = None
+        self.H, self.Fdim = H, Fd
+        self.scaling = getattr(attn, "scaling", None)
+        self.dtype = arena.w_dtype
+        self.sdpa_ctx = sdpa_ctx
+        self.use_mfma_dw = bool(use_mfma_dw)
+        self.aq = dict(qkv=plans[0], o=plans[3], gu=pl_gu, d=pl_d)
+        nqkv = q.numel + k.numel + v.numel
+        self.Wqkv = arena.Wq[q._off:q._off + nqkv].view((hq + 2 * hkv) * hd, H)
+        self.dWqkv = arena.dWq[q._off:q._off + nqkv].view((hq + 2 * hkv) * hd, H)
+        self.Wo, self.dWo = o.weight_q, o.weight_grad
+        self.Wgu = [g.arena.Wq[g._off:g._off + 2 * g.numel].view(2 * Fd, H) for g, u, d in trip]
+        self.dWgu = [g.arena.dWq[g._off:g._off + 2 * g.numel].view(2 * Fd, H) for g, u, d in trip]
+        self.Wd = [d.weight_q for g, u, d in trip]
+        self.dWd = [d.weight_grad for g, u, d in trip]
+        self.b_qkv = self.b_o = None
+        self.set_tn_dx(tn_dx_gemm)
+        return self
+
+    def _dx_weights(self):          # only the o-projection keeps a transposed copy (the experts are 1.4 G weights)
+        return (self.Wo,)
+
+    def _route(self, h2, grad):
+        """The module's own router on the normalised stream (its backward through a local autograd graph), then the sorted-row
+        bookkeeping: tok[p] / pos[t, k] / per-expert counts (the one host read)."""
+        T = h2.shape[0]
+        leaf = None
+        if grad:
+            with torch.enable_grad():
+                leaf = h2.detach().requires_grad_(True)
+                _, rw, ri = self.router(leaf)
+        else:
+            _, rw, ri = self.router(h2)
+        with torch.no_grad():
+            K = ri.shape[1]
+            flat = ri.t().reshape(-1)                                   # index = slot * T + token (the module path's row order)
+            order = torch.argsort(flat, stable=True)
+            counts = torch.bincount(flat, minlength=self.E).tolist()    # the one synchronisation of the iteration
+            tok = (order % T).contiguous()
+            inv = torch.empty_like(order)
+            inv[order] = torch.arange(order.numel(), device=order.device, dtype=order.dtype)
+            pos = inv.view(K, T).t().contiguous()                       # [T, K]: row of token t's k-th routed copy
+            w_tk = rw.detach().to(torch.float32).contiguous()           # [T, K]
+            w_sorted = w_tk[tok, order // T].contiguous()               # [T K]
+        return dict(leaf=leaf, rw=rw, counts=counts, tok=tok, pos=pos, w_tk=w_tk, w_sorted=w_sorted)
+
+    def _forward_impl(self, x, others, ctx):
+        from .wrapper import act_quant_fwd_raw
+
+        B, S, H = x.shape
+        aq = self.aq
+
+        def fq(t, plan):
+            return t if plan is None else act_quant_fwd_raw(t, plan)
+
+        x2, saved = self._attn_half_forward(x, others, ctx)
+        h2, rstd2 = ops.rmsnorm_fwd(x2, self.w2, self.eps2, want_rstd=ctx is not None)
+        r = self._route(h2, grad=ctx is not None)
+        xs = ops.moe_expand(h2, r["tok"])
+        xs_q = fq(xs, aq["gu"])
+        R = xs.shape[0]
+        GU = torch.empty((R, 2 * self.Fdim), dtype=self.dtype, device=x.device)
+        start = 0
+        for e, cnt in enumerate(r["counts"]):
+            if cnt:
+                torch.mm(xs_q[start:start + cnt], self.Wgu[e].t(), out=GU[start:start + cnt])
+            start += cnt
+        act = ops.swiglu_fwd(GU, self.Fdim)
+        act_q = fq(act, aq["d"])
+        D = torch.empty((R, H), dtype=self.dtype, device=x.device)
+        start = 0
+        for e, cnt in enumerate(r["counts"]):
+            if cnt:
+                torch.mm(act_q[start:start + cnt], self.Wd[e].t(), out=D[start:start + cnt])
+            start += cnt
+        y = ops.moe_combine(D, r["pos"], r["w_tk"], res=x2)
+        if ctx is not None:
+            saved.update(x2=x2, rstd2=rstd2, route=r, xs=xs, xs_q=xs_q, GU=GU, act=act, act_q=act_q, D=D)
+            ctx.saved = saved
+        return y.view(B, S, H)
+
+    def _backward_impl(self, ctx, dy):
+        from .wrapper import act_quant_bwd_raw
+
+        s = ctx.saved
+        ctx.saved = None
+        T = s["B"] * s["S"]
+        aq = self.aq
+
+        def bq(g, x, plan):
+            return g if plan is None else act_quant_bwd_raw(g, x, plan)
+
+        dy2d = dy.reshape(T, self.H)
+        if dy2d.dtype != self.dtype:
+            dy2d = dy2d.to(self.dtype)
+        dy2d = dy2d.contiguous()
+        r = s.pop("route")
+        tok, pos, counts = r["tok"], r["pos"], r["counts"]
+        D = s.pop("D")
+        dD = ops.moe_expand(dy2d, tok, scale=r["w_sorted"])             # d (down-projection output) = dt(w * dy[token])
+        drw = ops.moe_rowdot(dy2d, tok, D)[pos]                         # [T, K]: d loss / d routing weight
+        del D
+        act_q = s.pop("act_q")
+        dact_q = torch.empty_like(act_q)
+        start = 0
+        for e, cnt in enumerate(counts):
+            if cnt:
+                rows = slice(start, start + cnt)
+                self._dw(dD[rows], act_q[rows], self.dWd[e], [self.trip[e][2]])
+                torch.mm(dD[rows], self.Wd[e], out=dact_q[rows])
+            start += cnt
+        del dD, act_q
+        dact = bq(dact_q, s.pop("act"), aq["d"])
+        dGU = ops.swiglu_bwd_(dact, s.pop("GU"), self.Fdim)
+        del dact, dact_q
+        xs_q = s.pop("xs_q")
+        dxs_q = torch.empty_like(xs_q)
+        start = 0
+        for e, cnt in enumerate(counts):
+            if cnt:
+                rows = slice(start, start + cnt)
+                self._dw(dGU[rows], xs_q[rows], self.dWgu[e], [self.trip[e][0], self.trip[e][1]])
+                torch.mm(dGU[rows], self.Wgu[e], out=dxs_q[rows])
+            start += cnt
+        del dGU, xs_q
+        dxs = bq(dxs_q, s.pop("xs"), aq["gu"])
+        (dh2_router,) = torch.autograd.grad(r["rw"], r["leaf"], drw.to(r["rw"].dtype))
+        dh2 = ops.moe_combine(dxs, pos, None, res=dh2_router.to(self.dtype).contiguous())      # experts' share + router's share
+        del dxs, dxs_q
+        dx2 = ops.rmsnorm_bwd(dh2, s.pop("x2"), self.w2, s.pop("rstd2"), dres=dy2d, out=dh2)
+        self._attn_half_backward(s, dx2)
+
+
 def build_fused_block(block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True, tn_dx_gemm=True):
     """The fused form of a wrapped block, whichever family recognises it (None: the generic module path)."""
     fb = FusedLlamaBlock.try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=use_mfma_dw, tn_dx_gemm=tn_dx_gemm)
     if fb is None:
         fb = FusedOPTBlock.try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=use_mfma_dw, tn_dx_gemm=tn_dx_gemm)
+    if fb is None:
+        fb = FusedMoEBlock.try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=use_mfma_dw, tn_dx_gemm=tn_dx_gemm)
     return fb
 
 

@@ -439,6 +439,33 @@ def swiglu_bwd_(da2d, gu2d, F_):
     return gu2d
 
 
+def moe_expand(src2d, tok, scale=None, out=None):
+    """out[p] = scale[p] * src2d[tok[p]] (scale None: row gather) -> [len(tok), H]"""
+    R, H = tok.numel(), src2d.shape[1]
+    if out is None:
+        out = torch.empty((R, H), dtype=src2d.dtype, device=src2d.device)
+    _launch("ar_moe_expand", _p(src2d, "src"), _p(tok, "tok"), _p(scale), _p(out), R, H, dt_code(src2d.dtype))
+    return out
+
+
+def moe_combine(D2d, pos, w=None, res=None, out=None):
+    """out[t] = res[t] + sum_k w[t, k] * D2d[pos[t, k]]  (pos int64 [T, K]; w fp32 [T, K] or None; res [T, H] or None)"""
+    T, K = pos.shape
+    H = D2d.shape[1]
+    if out is None:
+        out = torch.empty((T, H), dtype=D2d.dtype, device=D2d.device)
+    _launch("ar_moe_combine", _p(D2d, "D"), _p(pos, "pos"), _p(w), _p(res), _p(out), T, H, K, dt_code(D2d.dtype))
+    return out
+
+
+def moe_rowdot(A2d, tok, B2d):
+    """out[p] = <A2d[tok[p]], B2d[p]> in fp32 -> [len(tok)]"""
+    R, H = tok.numel(), B2d.shape[1]
+    out = torch.empty(R, dtype=torch.float32, device=B2d.device)
+    _launch("ar_moe_rowdot", _p(A2d, "A"), _p(tok, "tok"), _p(B2d, "B"), _p(out), R, H, dt_code(B2d.dtype))
+    return out
+
+
 def rope_fwd(qkv2d, cos, sin, batch, seq, hq, hkv, d):
     """qkv2d [tokens, (hq+2hkv)*d] -> q, k, v [tokens, hq*d] (rotary on q/k, kv heads repeated hq/hkv times)"""
     tokens = qkv2d.shape[0]

@@ -316,6 +316,9 @@ class SignRoundQuantizer:
         self.last_stats: Dict[str, Any] = {}
         self.last_fused_block = False
         self.last_hip_graph = False
+        self._fused_verdict: Dict[Any, bool] = {}        # block signature -> did the fused kernels agree with the module code
+        self._graph_stream = None
+        self._graph_pool = None
 
     # convenience accessors with the reference's attribute names
     @property
@@ -393,9 +396,13 @@ class SignRoundQuantizer:
             if fused is not None:
                 fused.flash_fwd = bool(cfg.flash_attention)
                 # the fused kernels must compute what the block's own code computes: one small minibatch through both
-                nchk = min(2, nsamples)
-                others_chk = input_others if not per_sample_others else {**input_others, **{k: t[:nchk] for k, t in per_sample_others.items()}}
-                if not fused.agrees_with_module(lambda x, o: self.block_forward(block, x, o), X[:nchk], others_chk):
+                # (once per kind of block: the verdict is remembered by class and by whether any submodule carries its own forward)
+                key = ("tune", self._block_signature(block))
+                if key not in self._fused_verdict:
+                    nchk = min(2, nsamples)
+                    others_chk = input_others if not per_sample_others else {**input_others, **{k: t[:nchk] for k, t in per_sample_others.items()}}
+                    self._fused_verdict[key] = fused.agrees_with_module(lambda x, o: self.block_forward(block, x, o), X[:nchk], others_chk)
+                if not self._fused_verdict[key]:
                     fused = None
         self.last_fused_block = fused is not None
 
@@ -569,6 +576,14 @@ class SignRoundQuantizer:
         # hand out independent copies: the arenas' best_* buffers are released with the block's wrappers
         return {n: {k: v.clone() for k, v in d.items()} for n, d in best_params.items()}
 
+    @staticmethod
+    def _block_signature(block):
+        """What decides whether a fused form computes the block's function: the classes involved, the scheme-relevant switches and
+        whether any submodule carries an instance-level `forward` (a patched module)."""
+        mods = list(block.modules())
+        return (tuple(sorted({type(m).__name__ for m in mods})), any("forward" in m.__dict__ for m in mods),
+                tuple(sorted({(int(getattr(m, "act_bits", 16) or 16), str(getattr(m, "act_data_type", ""))) for m in mods if hasattr(m, "act_bits")})))
+
     # -- one iteration as a captured hipGraph -------------------------------------------------------------------------------
     @staticmethod
     def _graph_eligible(cfg, fused, arenas, early_stop, dp_size, accum, per_sample_others, valid_counts, sched_dev, track_best) -> bool:
@@ -577,6 +592,8 @@ class SignRoundQuantizer:
         valid-token count that is the same for every minibatch (it is a kernel ARGUMENT of the loss), no early stopping, no
         micro-batches, no data-parallel exchange, no momentum buffers, no per-tensor (shared-parameter) arenas."""
         if cfg.hip_graph is False or fused is None or not track_best or early_stop or dp_size > 1 or accum or per_sample_others:
+            return False
+        if not getattr(fused, "capturable", True):      # sparse-MoE blocks read the per-expert token counts on the host
             return False
         if sched_dev is None or cfg.iters < 3 or (cfg.momentum or 0.0) or any(a.shared for a in arenas):
             return False
@@ -625,10 +642,22 @@ class SignRoundQuantizer:
         prev_prof = ops.profile_enable(False)                           # per-dispatch event pairs cannot be captured
         graph = None
         try:
-            torch.cuda.synchronize(device)
+            # (capture_begin / capture_end on a side stream directly: the torch.cuda.graph() context also runs gc.collect() and
+            #  empties the allocator's cache on entry -- tens of milliseconds per block on a 380 ms block)
+            if self._graph_stream is None:
+                self._graph_stream = torch.cuda.Stream(device)
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            self._last_graph = None                                     # the previous block's graph gives its pool memory back
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                body()                                                  # recorded, not executed
+            side = self._graph_stream
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                graph.capture_begin(pool=self._graph_pool)
+                try:
+                    body()                                              # recorded, not executed
+                finally:
+                    graph.capture_end()
+            torch.cuda.current_stream(device).wait_stream(side)
         except Exception as e:  # noqa: BLE001 -- any capture failure: the same body runs eagerly instead
             graph = None
             for a, fresh, acc in flags:
@@ -677,7 +706,11 @@ class SignRoundQuantizer:
             fb = build_fused_block_plain(block, input_others, self.config.amp_dtype, sdpa_ctx=self._sdpa_ctx)
             if fb is not None:
                 fb.flash_fwd = bool(self.config.flash_attention)
-                if not fb.agrees_with_module(lambda x, o: self.block_forward(block, x, o), inputs[:min(2, inputs.shape[0])], input_others):
+                key = ("plain", self._block_signature(block))
+                if key not in self._fused_verdict:
+                    self._fused_verdict[key] = fb.agrees_with_module(lambda x, o: self.block_forward(block, x, o),
+                                                                     inputs[:min(2, inputs.shape[0])], input_others)
+                if not self._fused_verdict[key]:
                     fb = None
         outs = []
         for b0 in range(0, inputs.shape[0], bs):

@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 15
+#define AR_ABI_VERSION 16
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -285,6 +285,23 @@ int ar_headnorm_bwd(void* dqkv, const void* qkv, const void* wq, const void* wk,
 int ar_transpose16(const void* src, void* dst, int64_t rows, int64_t cols, ar_stream_t stream);
 int ar_swiglu_fwd(const void* gu, int64_t ld, void* a, int64_t rows, int64_t F, int dt, ar_stream_t stream);
 int ar_swiglu_bwd(const void* da, void* gu, int64_t ld, int64_t rows, int64_t F, int dt, ar_stream_t stream);
+
+/* ---- sparse-MoE routing glue: the expert pass over rows sorted by expert -------------------------------------------------
+ * replaces: the per-expert `hidden_states[token_idx]`, `* top_k_weights[token_idx, top_k_pos, None]` and
+ *           `final_hidden_states.index_add_(0, token_idx, ...)` of MixtralExperts.forward (transformers/models/mixtral/
+ *           modeling_mixtral.py) -- the "linear_loop" experts the reference tunes after unfusing them
+ *           (auto_round/modeling/fused_moe/moe_experts_interface.py) -- and their autograd mirrors, for rows grouped by expert with
+ *           one stable sort: row p of a sorted buffer belongs to token tok[p]; token t's K routed copies are rows pos[t*K + k].
+ * ar_moe_expand : out[p, :] = scale[p] * src[tok[p], :]   (scale NULL: plain gather), rows = T*K
+ * ar_moe_combine: out[t, :] = res[t, :] + sum_k w[t*K + k] * D[pos[t*K + k], :]   (res / w NULL: 0 / 1); fp32 sum in slot order,
+ *                 one rounding -- deterministic, no float atomics
+ * ar_moe_rowdot : out[p] = sum_j A[tok[p], j] * B[p, j]  (fp32): the routing-weight gradient
+ * H % 8 == 0; tok / pos are int64 device arrays. */
+int ar_moe_expand(const void* src, const int64_t* tok, const float* scale, void* out, int64_t rows, int64_t H, int dt,
+                  ar_stream_t stream);
+int ar_moe_combine(const void* D, const int64_t* pos, const float* w, const void* res, void* out, int64_t T, int64_t H, int K, int dt,
+                   ar_stream_t stream);
+int ar_moe_rowdot(const void* A, const int64_t* tok, const void* B, float* out, int64_t rows, int64_t H, int dt, ar_stream_t stream);
 int ar_rope_fwd(const void* qkv, int64_t ld, const void* cos, const void* sin, int64_t cs_batch_stride, void* q, void* k, void* v,
                 int64_t tokens, int64_t seq, int hq, int hkv, int d, int dt, ar_stream_t stream);
 int ar_rope_bwd(const void* dq, const void* dk, const void* dv, const void* cos, const void* sin, int64_t cs_batch_stride,

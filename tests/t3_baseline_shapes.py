@@ -177,7 +177,7 @@ def _tuned_layers(model):
     from auto_round_amd.testing.t3_fixture import decoder_blocks
 
     out = {}
-    for n, p in decoder_blocks(model).named_modules():
+    for n, p in decoder_blocks(model)[0].named_modules():          # the one block of these models; names relative to it
         if isinstance(p, (torch.nn.Linear, Conv1D)) and hasattr(p, "scale"):
             out[n.replace(".orig_layer", "")] = p
     return out
@@ -335,6 +335,11 @@ def run_big_case(name, fixture_path=None, skip_alone=False):
                 rec["fused_vs_module"] = compare_layers(L_mod, L_hip)
 
         # ---- (alone): the reference-free flow of the driver-side test
+        if fixture_path:      # written first: a failure further down must not lose the reference's result
+            sz = write_fixture(fixture_path, case, L_ref, ref_trace, spy.rec,
+                               dict(device=torch.cuda.get_device_name(0), torch=torch.__version__,
+                                    made_by="tests/t3_baseline_shapes.py: the reference's AutoRound(...).quantize() on cuda:0"))
+            rec["fixture"] = dict(path=os.path.relpath(fixture_path, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), bytes=sz)
         if not skip_alone:
             for tag, fused in (("alone_module", False), ("alone_fused", True)):
                 a = fx.tune_with_product(case["arch"], scheme=case["scheme"], scheme_kw={k: v for k, v in case["kw"].items() if k != "enable_alg_ext"},
@@ -352,11 +357,11 @@ def run_big_case(name, fixture_path=None, skip_alone=False):
                 rec[tag] = r
                 del a, L_al
                 _free()
-        if fixture_path:
-            sz = write_fixture(fixture_path, case, L_ref, ref_trace, spy.rec,
-                               dict(device=torch.cuda.get_device_name(0), torch=torch.__version__,
-                                    made_by="tests/t3_baseline_shapes.py: the reference's AutoRound(...).quantize() on cuda:0"))
-            rec["fixture"] = dict(path=os.path.relpath(fixture_path, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), bytes=sz)
+    except Exception as e:      # keep what the earlier stages measured
+        import traceback
+
+        rec["error"] = repr(e)
+        rec["trace"] = traceback.format_exc()[-3000:]
     finally:
         os.chdir(cwd)
     return rec
