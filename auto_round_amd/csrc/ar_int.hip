@@ -18,8 +18,6 @@
 // a group, hands them to the group lane through LDS, and the group lane applies the sign step to min/max scale.
 // There is no inter-workgroup reuse, so no XCD-aware remap is needed: consecutive tiles simply round-robin over the
 // 8 XCDs and stream straight from HBM.
-#include <cstdlib>
-
 #include "ar_common.hpp"
 
 namespace ar {
@@ -969,15 +967,7 @@ static int launch_int_bwd(BwdArgs& a, int gs, int bits, int sym, int w_dt, int s
         const int fgrid = grid_for_tiles((a.n_groups * a.cpg + kTPB * AR_FLAT_BWD_UNROLL - 1) / (kTPB * AR_FLAT_BWD_UNROLL));
 #if AR_INT_SPEC
         if (w_dt == AR_DT_BF16 && !same16 && a.cfg.sym == 1 && s_dt == AR_DT_F16 && (a.cpg == 16 || a.cpg == 4)) {
-            // small blocks (OPT-125M: 7 M weights, an 85 MB stream): with two chunks per lane the launch is 1 728 workgroups whose
-            // loads are all in flight at once and the kernel never leaves its ramp; one chunk per lane doubles the waves that
-            // issue loads (AR_INT_BWD_SMALL_U=1|2 overrides for the A/B; default: one chunk below 32 M weights)
-            static const int small_u = [] { const char* e = getenv("AR_INT_BWD_SMALL_U"); return e ? atoi(e) : 1; }();
-            if (a.cpg == 16 && small_u == 1 && a.n_groups * a.cpg < (int64_t)4 * 1024 * 1024) {
-                const int g1 = grid_for_tiles((a.n_groups * a.cpg + kTPB - 1) / kTPB);
-                AR_LAUNCH_PROF(AR_PROF_INT_BWD, a.n_groups, (k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, 1, 16>), g1, kTPB, 0, st, a);
-                return launch_status();
-            }
+            // (one chunk per lane for small blocks -- OPT-125M's 85 MB stream -- was measured in round 3: 22 vs 21 us, no gain)
             if (a.cpg == 16) AR_LAUNCH_PROF(AR_PROF_INT_BWD, a.n_groups, (k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL, 16>), fgrid, kTPB, 0, st, a);
             else AR_LAUNCH_PROF(AR_PROF_INT_BWD, a.n_groups, (k_int_bwd_flat<AR_DT_BF16, AR_DT_F32, AR_FLAT_BWD_UNROLL, 4>), fgrid, kTPB, 0, st, a);
             return launch_status();

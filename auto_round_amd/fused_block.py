@@ -63,6 +63,22 @@ def _class_in(block, names) -> bool:
     return type(block).__name__ in names
 
 
+def _act_plans(proj):
+    """One activation fake-quant plan per projection (None: 16-bit input).  NVFP4's static per-layer scale becomes ("nv", value) from
+    the layer's calibrated `act_max`; raises NotImplementedError for anything the raw kernels do not cover."""
+    from .wrapper import act_quant_plan, nv_static_plan
+
+    plans = []
+    for p in proj:
+        pl = act_quant_plan(p.orig_layer, p.in_features) if p.enable_act_quant else None
+        if pl is not None and pl[0] == "nv":
+            pl = nv_static_plan(p.orig_layer, p.device)
+            if pl is None:
+                raise NotImplementedError("NVFP4 activations without a calibrated act_max (dynamic per-call maximum)")
+        plans.append(pl)
+    return plans
+
+
 def _rotary_ok(pe, hd) -> bool:
     """(cos, sin) of the full head size: partial-rotary models (rotary_dim < head_dim) keep the module path"""
     if not (isinstance(pe, (tuple, list)) and len(pe) == 2):
@@ -121,13 +137,11 @@ class FusedLlamaBlock:
         arena = q.arena
         # dynamic activation fake-quant (INT8 / INT4 / W4A8 presets, MXFP4): one plan per GEMM input; the merged projections must
         # agree on theirs.  NVFP4's per-layer static activation scale keeps the module path.
-        from .wrapper import act_quant_plan
-
         try:
-            plans = [act_quant_plan(p.orig_layer, p.in_features) if p.enable_act_quant else None for p in proj]
+            plans = _act_plans(proj)
         except NotImplementedError:
             return None
-        if any(pl is not None and pl[0] == "nv" for pl in plans) or not (plans[0] == plans[1] == plans[2]) or plans[4] != plans[5]:
+        if not (plans[0] == plans[1] == plans[2]) or plans[4] != plans[5]:
             return None
         if arena.w_dtype not in (torch.bfloat16, torch.float16) or arena.w_dtype != amp_dtype:
             return None
@@ -565,7 +579,7 @@ class FusedOPTBlock(FusedLlamaBlock):
     @classmethod
     def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True,
                   tn_dx_gemm=True) -> Optional["FusedOPTBlock"]:
-        from .wrapper import WrapperLinear, act_quant_plan
+        from .wrapper import WrapperLinear
 
         parts = cls._parts(block)
         if parts is None or not arenas:
@@ -593,10 +607,10 @@ class FusedOPTBlock(FusedLlamaBlock):
         if any(b is not None for b in qkv_bias) and not all(b is not None for b in qkv_bias):
             return None
         try:
-            plans = [act_quant_plan(p.orig_layer, p.in_features) if p.enable_act_quant else None for p in proj]
+            plans = _act_plans(proj)
         except NotImplementedError:
             return None
-        if any(pl is not None and pl[0] == "nv" for pl in plans) or not (plans[0] == plans[1] == plans[2]):
+        if not (plans[0] == plans[1] == plans[2]):
             return None
         self = cls()
         arena = q.arena
@@ -784,7 +798,7 @@ class FusedMoEBlock(FusedLlamaBlock):
     def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True,
                   tn_dx_gemm=True) -> Optional["FusedMoEBlock"]:
         from .moe_unfuse import expert_children
-        from .wrapper import WrapperLinear, act_quant_plan
+        from .wrapper import WrapperLinear
 
         if not _class_in(block, MOE_FAMILY) or not arenas:
             return None
@@ -822,14 +836,20 @@ class FusedMoEBlock(FusedLlamaBlock):
                     and g.out_features == u.out_features == Fd == d.in_features):
                 return None
         try:
-            plans = [act_quant_plan(p.orig_layer, p.in_features) if p.enable_act_quant else None for p in proj]
+            plans = _act_plans(proj)
         except NotImplementedError:
             return None
-        pl_gu, pl_d = plans[4], plans[6]
-        if any(pl is not None and pl[0] == "nv" for pl in plans) or not (plans[0] == plans[1] == plans[2]):
+        if not (plans[0] == plans[1] == plans[2]) or any(plans[4 + 3 * i] != plans[5 + 3 * i] for i in range(len(trip))):
             return None
-        if any(plans[4 + 3 * i] != pl_gu or plans[5 + 3 * i] != pl_gu or plans[6 + 3 * i] != pl_d for i in range(len(trip))):
+        # one plan per expert and projection input: dynamic schemes (MXFP4, INT) give every expert the same one -- a single launch
+        # over all sorted rows; NVFP4's static per-layer scale differs between experts -- one launch per expert's rows
+        pl_gu_e = [plans[4 + 3 * i] for i in range(len(trip))]
+        pl_d_e = [plans[6 + 3 * i] for i in range(len(trip))]
+        if any((pl is None) != (pl_gu_e[0] is None) or (pl is not None and pl[0] != pl_gu_e[0][0]) for pl in pl_gu_e):
             return None
+        if any((pl is None) != (pl_d_e[0] is None) or (pl is not None and pl[0] != pl_d_e[0][0]) for pl in pl_d_e):
+            return None
+        pl_gu, pl_d = pl_gu_e[0], pl_d_e[0]
         others = dict(input_others or {})
         pe = others.get("position_embeddings")
         hd = int(getattr(attn, "head_dim", 0))
@@ -855,6 +875,7 @@ class FusedMoEBlock(FusedLlamaBlock):
         self.sdpa_ctx = sdpa_ctx
         self.use_mfma_dw = bool(use_mfma_dw)
         self.aq = dict(qkv=plans[0], o=plans[3], gu=pl_gu, d=pl_d)
+        self.pl_gu_e, self.pl_d_e = pl_gu_e, pl_d_e
         nqkv = q.numel + k.numel + v.numel
         self.Wqkv = arena.Wq[q._off:q._off + nqkv].view((hq + 2 * hkv) * hd, H)
         self.dWqkv = arena.dWq[q._off:q._off + nqkv].view((hq + 2 * hkv) * hd, H)
@@ -869,6 +890,26 @@ class FusedMoEBlock(FusedLlamaBlock):
 
     def _dx_weights(self):          # only the o-projection keeps a transposed copy (the experts are 1.4 G weights)
         return (self.Wo,)
+
+    @staticmethod
+    def _rows_fq(t, plans, counts, raw, grad_of=None):
+        """Activation fake-quant (raw = act_quant_fwd_raw) or its backward (raw = act_quant_bwd_raw, grad_of = the activation) of the
+        sorted rows: one launch when every expert has the same plan, else one per expert's row segment."""
+        if plans[0] is None:
+            return t
+        if all(pl == plans[0] for pl in plans):
+            return raw(t, plans[0]) if grad_of is None else raw(t, grad_of, plans[0])
+        out = torch.empty_like(t)
+        start = 0
+        for e, cnt in enumerate(counts):
+            if cnt:
+                rows = slice(start, start + cnt)
+                if grad_of is None:
+                    raw(t[rows], plans[e], out=out[rows])
+                else:
+                    raw(t[rows], grad_of[rows], plans[e], out=out[rows])
+            start += cnt
+        return out
 
     def _route(self, h2, grad):
         """The module's own router on the normalised stream (its backward through a local autograd graph), then the sorted-row
@@ -898,16 +939,11 @@ class FusedMoEBlock(FusedLlamaBlock):
         from .wrapper import act_quant_fwd_raw
 
         B, S, H = x.shape
-        aq = self.aq
-
-        def fq(t, plan):
-            return t if plan is None else act_quant_fwd_raw(t, plan)
-
         x2, saved = self._attn_half_forward(x, others, ctx)
         h2, rstd2 = ops.rmsnorm_fwd(x2, self.w2, self.eps2, want_rstd=ctx is not None)
         r = self._route(h2, grad=ctx is not None)
         xs = ops.moe_expand(h2, r["tok"])
-        xs_q = fq(xs, aq["gu"])
+        xs_q = self._rows_fq(xs, self.pl_gu_e, r["counts"], act_quant_fwd_raw)
         R = xs.shape[0]
         GU = torch.empty((R, 2 * self.Fdim), dtype=self.dtype, device=x.device)
         start = 0
@@ -916,7 +952,7 @@ class FusedMoEBlock(FusedLlamaBlock):
                 torch.mm(xs_q[start:start + cnt], self.Wgu[e].t(), out=GU[start:start + cnt])
             start += cnt
         act = ops.swiglu_fwd(GU, self.Fdim)
-        act_q = fq(act, aq["d"])
+        act_q = self._rows_fq(act, self.pl_d_e, r["counts"], act_quant_fwd_raw)
         D = torch.empty((R, H), dtype=self.dtype, device=x.device)
         start = 0
         for e, cnt in enumerate(r["counts"]):
@@ -935,11 +971,6 @@ class FusedMoEBlock(FusedLlamaBlock):
         s = ctx.saved
         ctx.saved = None
         T = s["B"] * s["S"]
-        aq = self.aq
-
-        def bq(g, x, plan):
-            return g if plan is None else act_quant_bwd_raw(g, x, plan)
-
         dy2d = dy.reshape(T, self.H)
         if dy2d.dtype != self.dtype:
             dy2d = dy2d.to(self.dtype)
@@ -960,7 +991,7 @@ class FusedMoEBlock(FusedLlamaBlock):
                 torch.mm(dD[rows], self.Wd[e], out=dact_q[rows])
             start += cnt
         del dD, act_q
-        dact = bq(dact_q, s.pop("act"), aq["d"])
+        dact = self._rows_fq(dact_q, self.pl_d_e, counts, act_quant_bwd_raw, grad_of=s.pop("act"))
         dGU = ops.swiglu_bwd_(dact, s.pop("GU"), self.Fdim)
         del dact, dact_q
         xs_q = s.pop("xs_q")
@@ -973,7 +1004,7 @@ class FusedMoEBlock(FusedLlamaBlock):
                 torch.mm(dGU[rows], self.Wgu[e], out=dxs_q[rows])
             start += cnt
         del dGU, xs_q
-        dxs = bq(dxs_q, s.pop("xs"), aq["gu"])
+        dxs = self._rows_fq(dxs_q, self.pl_gu_e, counts, act_quant_bwd_raw, grad_of=s.pop("xs"))
         (dh2_router,) = torch.autograd.grad(r["rw"], r["leaf"], drw.to(r["rw"].dtype))
         dh2 = ops.moe_combine(dxs, pos, None, res=dh2_router.to(self.dtype).contiguous())      # experts' share + router's share
         del dxs, dxs_q

@@ -270,6 +270,11 @@ class SignRoundConfig:
     # loop: results are bit-identical.
     hip_graph: Optional[bool] = None
     hip_graph_max_weights: int = 64 * 1024 * 1024
+    # Module path only: hand the block its shared keyword tensors (one attention mask for every sample, ...) materialised at the
+    # minibatch's own row count -- what the reference's per-sample input cache produces by concatenation (block_runner.py:368-422)
+    # -- instead of one broadcastable row.  Same values; SDPA may pick another kernel for a batch-broadcast mask, and with it other
+    # last bits.  Costs a [batch, 1, S, S] copy per forward, so it is off unless bit parity with the reference's forward is wanted.
+    materialise_shared_rows: bool = False
 
     def __post_init__(self):
         if self.iters < 0:
@@ -318,7 +323,6 @@ class SignRoundQuantizer:
         self.last_hip_graph = False
         self._fused_verdict: Dict[Any, bool] = {}        # block signature -> did the fused kernels agree with the module code
         self._graph_stream = None
-        self._graph_pool = None
 
     # convenience accessors with the reference's attribute names
     @property
@@ -355,6 +359,17 @@ class SignRoundQuantizer:
             return sdpa_kernel(order)
 
     def block_forward(self, block, x, input_others):
+        if self.config.materialise_shared_rows and input_others:
+            rows = x.shape[0]
+
+            def mat(v):
+                if isinstance(v, torch.Tensor) and v.dim() >= 3 and v.shape[0] == 1 and rows > 1 and v.is_floating_point():
+                    return v.expand(rows, *v.shape[1:]).contiguous()
+                if isinstance(v, tuple):
+                    return tuple(mat(t) for t in v)
+                return v
+
+            input_others = {k: (mat(v) if k != "positional_inputs" else v) for k, v in input_others.items()}
         with self._sdpa_ctx(x.shape[1] if x.dim() == 3 else None):
             return block_forward(block, x, input_others, amp=self.config.amp, amp_dtype=self.config.amp_dtype)
 
@@ -646,13 +661,14 @@ class SignRoundQuantizer:
             #  empties the allocator's cache on entry -- tens of milliseconds per block on a 380 ms block)
             if self._graph_stream is None:
                 self._graph_stream = torch.cuda.Stream(device)
-                self._graph_pool = torch.cuda.graph_pool_handle()
-            self._last_graph = None                                     # the previous block's graph gives its pool memory back
+            self._last_graph = None                                     # the previous block's graph gives its memory back first
             graph = torch.cuda.CUDAGraph()
             side = self._graph_stream
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
-                graph.capture_begin(pool=self._graph_pool)
+                graph.capture_begin()                                   # (its own private pool: a handle shared between
+                                                                        #  successive graphs trips an allocator assert once the
+                                                                        #  first graph has been destroyed -- measured)
                 try:
                     body()                                              # recorded, not executed
                 finally:
@@ -837,7 +853,11 @@ class SignRoundV2Quantizer(SignRoundQuantizer):
 
     def _loss_fwd_bwd(self, pred, ref, dpred, total_loss, n, num_elm, accum, tmask):
         if not self._use_outlier_suppressed_loss:
-            return super()._loss_fwd_bwd(pred, ref, dpred, total_loss, n, num_elm, accum, tmask)
+            # the reference's V2 quantizer calls the base loss WITHOUT the valid-token mask (`super()._get_loss(pred_output,
+            # ref_output, indices, mse_loss, device)`, sign_roundv2/quantizer.py:399): with the algorithm extension on and the
+            # outlier-suppressed loss off (e.g. asymmetric schemes) every position enters the loss and its gradient, while the
+            # divisor num_elm still counts the valid tokens -- mirrored, the tuned weights are held to the reference's
+            return super()._loss_fwd_bwd(pred, ref, dpred, total_loss, n, num_elm, accum, None)
         # the outlier-suppressed loss is a mean regardless of the accumulation mode (sign_roundv2/quantizer.py:387-398)
         ops.outlier_mse_loss_fwd_bwd(pred, ref, dpred=dpred, loss_accum=total_loss, accum_scale=1.0 / float(num_elm),
                                      grad_scale=1000.0, token_mask=tmask)

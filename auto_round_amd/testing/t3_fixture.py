@@ -117,7 +117,7 @@ def capture_block_inputs(model, block, tokens: torch.Tensor, device, amp_dtype=t
 
 def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw: Optional[dict] = None, iters: int = 200,
                       nsamples: int = 128, seqlen: int = 2048, batch_size: int = 8, fused: bool = False, alg_ext: bool = False,
-                      seed: int = 42, device="cuda:0", graph: Optional[bool] = None) -> dict:
+                      seed: int = 42, device="cuda:0", graph: Optional[bool] = None, materialise: bool = False) -> dict:
     """The plugin-mode flow without the reference around it: same seeded block, same block inputs, targets from the module-path
     forward (what the reference's orchestrator hands to `quantize_block`), `transformers.set_seed(seed)` right before the block
     (the reference's sampler then draws the same minibatches), then `SignRoundQuantizer.quantize_block` -- on the module path
@@ -139,13 +139,14 @@ def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw
     x0, others = capture_block_inputs(model, block, tokens, device)
     ids = loss_mask_ids(tokens, None)
     q_cls = SignRoundV2Quantizer if alg_ext else SignRoundQuantizer
-    mod_cfg = SignRoundConfig(iters=iters, batch_size=batch_size, bits=sch["bits"], sdpa_backend="auto", fused_block=False)
+    mod_cfg = SignRoundConfig(iters=iters, batch_size=batch_size, bits=sch["bits"], sdpa_backend="auto", fused_block=False,
+                              materialise_shared_rows=materialise)
     q_mod = q_cls(mod_cfg, device=device)
     with torch.cuda.device(device):
         y = q_mod.calibrate_block(block, x0, others)              # module path: the targets the reference would hand over
     kw = {} if graph is None else {"hip_graph": bool(graph)}
     cfg = SignRoundConfig(iters=iters, batch_size=batch_size, bits=sch["bits"], sdpa_backend="auto", fused_block=bool(fused),
-                          mfma_dw_gemm=bool(fused), **kw)
+                          mfma_dw_gemm=bool(fused), materialise_shared_rows=materialise, **kw)
     q = q_cls(cfg, device=device)
     transformers.set_seed(seed)
     q.quantize_block(block, x0, others, y, None, BlockContext(0, 1, "0"), input_ids=ids)
@@ -214,12 +215,12 @@ def trace_divergence(a, b, rel=1e-4):
     return next((i for i in range(n) if abs(a[i] - b[i]) > rel * max(abs(a[i]), 1e-30)), None)
 
 
-def check_against_fixture(fused: bool, path: str = FIXTURE, graph: Optional[bool] = None) -> dict:
+def check_against_fixture(fused: bool, path: str = FIXTURE, graph: Optional[bool] = None, materialise: bool = False) -> dict:
     """Re-tune the fixture's block with this package and compare -> a flat record (what bench.py prints as `parity`)."""
     fix = load_fixture(path)
     m = fix["meta"]
     r = tune_with_product(m["arch"], scheme=m["scheme"], iters=m["iters"], nsamples=m["nsamples"], seqlen=m["seqlen"],
-                          batch_size=m["batch_size"], fused=fused, seed=m["seed"], graph=graph)
+                          batch_size=m["batch_size"], fused=fused, seed=m["seed"], graph=graph, materialise=materialise)
     cmp_ = compare_with_fixture(packed_layers(r["block"]), fix)
     ref_trace = [float(x) for x in fix["loss_trace"]]
     rec = dict(fused_block=r["fused_block"], hip_graph=r["hip_graph"], inputs_identical=(r["x_sha"] == m["x_sha"]), targets_identical=(r["y_sha"] == m["y_sha"]),

@@ -180,20 +180,52 @@ def act_quant_plan(layer, hidden: int):
     raise NotImplementedError(f"act_data_type={adt} with act_group_size={gs}")
 
 
-def act_quant_fwd_raw(x: torch.Tensor, plan):
-    """Kernel-level forward of a dynamic plan ("int" / "mx"; no autograd): contiguous x -> fake-quantised x."""
+_nv_gs_dev: dict = {}
+
+
+def nv_static_plan(layer, device):
+    """("nv", global_scale) for a statically activation-quantised NVFP4 layer whose `act_max` was calibrated: the per-layer scale
+    448 * 6 / act_max that `act_fake_quant` derives at every call (nv_fp4_with_static_gs, data_type/nvfp.py:102-125), evaluated
+    once with the same fp32 arithmetic and carried in the plan as a number, so that layers sharing an input can be compared (q / k / v,
+    gate / up).  None when the layer has no calibrated maximum (the dynamic fall-back needs a reduction per call)."""
+    act_max = getattr(layer, "act_max", None)
+    if act_max is None:
+        return None
+    tmax = torch.as_tensor(act_max, dtype=torch.float32, device=device).abs().max().reshape(1)
+    gscale = torch.where(tmax == 0, torch.zeros_like(tmax), (448.0 * 6.0) * (1.0 / tmax))
+    return ("nv", float(gscale.item()))
+
+
+def _nv_gscale_tensor(value: float, device) -> torch.Tensor:
+    key = (torch.device(device).index, value)
+    t = _nv_gs_dev.get(key)
+    if t is None:
+        if len(_nv_gs_dev) > 4096:
+            _nv_gs_dev.clear()
+        t = _nv_gs_dev[key] = torch.tensor([value], dtype=torch.float32, device=device)
+    return t
+
+
+def act_quant_fwd_raw(x: torch.Tensor, plan, out=None):
+    """Kernel-level forward of a plan ("int" / "mx" dynamic, ("nv", global_scale) static; no autograd): contiguous x -> fake-quantised x."""
+    o = None if out is None else out.view(-1)
     if plan[0] == "int":
         _, bits, g, sdt, thresh, sym = plan
-        return ops.qdq_int_act_fwd(x.view(-1), gs=g, bits=bits, sym=sym, scale_dtype=sdt, q_thresh=thresh).view(x.shape)
+        return ops.qdq_int_act_fwd(x.view(-1), gs=g, bits=bits, sym=sym, scale_dtype=sdt, q_thresh=thresh, out=o).view(x.shape)
+    if plan[0] == "nv":
+        return ops.qdq_fp4_fwd(x.view(-1), None, None, None, mode=1, gs=16, global_scale=_nv_gscale_tensor(plan[1], x.device), out=o).view(x.shape)
     assert plan[0] == "mx"
-    return ops.qdq_fp4_fwd(x.view(-1), None, None, None, mode=0, gs=32, global_scale=None).view(x.shape)
+    return ops.qdq_fp4_fwd(x.view(-1), None, None, None, mode=0, gs=32, global_scale=None, out=o).view(x.shape)
 
 
 def act_quant_bwd_raw(dy: torch.Tensor, x: torch.Tensor, plan, out=None):
-    """Kernel-level input gradient of a dynamic plan: (gradient w.r.t. the quantised activation, the activation) -> gradient."""
+    """Kernel-level input gradient of a plan: (gradient w.r.t. the quantised activation, the activation) -> gradient."""
     if plan[0] == "int":
         _, bits, g, sdt, thresh, sym = plan
         return ops.int_act_bwd(dy.view(-1), x.view(-1), gs=g, bits=bits, sym=sym, scale_dtype=sdt, q_thresh=thresh,
+                               out=None if out is None else out.view(-1)).view(x.shape)
+    if plan[0] == "nv":
+        return ops.fp4_act_bwd(dy.view(-1), x.view(-1), mode=1, gs=16, global_scale=_nv_gscale_tensor(plan[1], x.device),
                                out=None if out is None else out.view(-1)).view(x.shape)
     assert plan[0] == "mx"
     return ops.fp4_act_bwd(dy.view(-1), x.view(-1), mode=0, gs=32, global_scale=None, out=None if out is None else out.view(-1)).view(x.shape)

@@ -591,7 +591,10 @@ def tune_block(block, inputs: torch.Tensor, targets: torch.Tensor, input_others:
                     out = out[0]
             if use_outlier_loss:
                 loss = outlier_loss(out, ref.to(out.dtype), None if vmask is None else vmask[idx].unsqueeze(-1))
-            elif vmask is not None:
+            elif vmask is not None and not alg_ext:
+                # (SignRoundV2Quantizer._get_loss hands the base loss NO valid-token mask when the outlier-suppressed loss is off --
+                #  `super()._get_loss(pred, ref, indices, mse_loss, device)`, sign_roundv2/quantizer.py:399 -- so with the algorithm
+                #  extension and e.g. an asymmetric scheme every position enters the loss, while num_elm still counts valid tokens)
                 m = vmask[idx].unsqueeze(-1)
                 loss = mse((out * m).to(torch.float32), (ref * m).to(torch.float32))
             else:

@@ -27,7 +27,7 @@ def fixture_meta():
 def test_fixture_is_the_baseline_configuration(fixture_meta):
     m = fixture_meta["meta"]
     assert (m["arch"], m["scheme"], m["iters"], m["nsamples"], m["seqlen"], m["batch_size"], m["seed"]) == ("opt125m", "W4A16", 200, 128, 2048, 8, 42)
-    assert len(fixture_meta["loss_trace"]) == 200 and "MI355X" in m["device"]
+    assert len(fixture_meta["loss_trace"]) == 200 and m["device"] and "x_sha" in m and "y_sha" in m
     assert sorted(fixture_meta["layers"]) == ["fc1", "fc2", "self_attn.k_proj", "self_attn.out_proj", "self_attn.q_proj", "self_attn.v_proj"]
     q = fixture_meta["layers"]["fc1"]["qweight"]
     assert q.shape == (768 // 8, 3072) and fixture_meta["layers"]["fc1"]["scales"].shape == (768 // 128, 3072)

@@ -105,6 +105,7 @@ def _tiny_moe(experts=4, top_k=2):
 
 @pytest.mark.parametrize("kw", [dict(scheme="W4A16", group_size=32), dict(scheme="W2A16G32", sym=False), dict(scheme="MXFP4"),
                                 dict(scheme="W2A16G32", enable_alg_ext=True), dict(scheme="NVFP4", enable_alg_ext=True),
+                                dict(scheme="W2A16G32", sym=False, enable_alg_ext=True),
                                 dict(scheme="W4A16", group_size=32, moe=True), dict(scheme="NVFP4", moe=(24, 1)),
                                 dict(scheme="W4A16", group_size=32, arch="opt"), dict(scheme="W2A16G32", sym=False, arch="opt"),
                                 dict(scheme="W4A16", group_size=32, arch="gpt2"), dict(scheme="W4A16", group_size=32, arch="qwen2"),
@@ -126,7 +127,7 @@ def _tiny_moe(experts=4, top_k=2):
                                 dict(scheme="W4A16", group_size=32, seed=7),
                                 dict(scheme="W4A16", group_size=32, trailing_repeats=True),
                                 dict(scheme="W4A16", group_size=32, trailing_repeats=True, pad_token_id=3)],
-                         ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "mixtral_w4g32",
+                         ids=["w4g32", "w2g32_asym", "mxfp4", "w2g32_alg_ext", "nvfp4_alg_ext", "w2g32_asym_alg_ext_baseline_cfg2", "mixtral_w4g32",
                               "mixtral_nvfp4_idle_experts", "opt_w4g32", "opt_w2g32_asym", "gpt2_conv1d_w4g32", "qwen2_w4g32", "qwen3_w4g32", "qwen3_moe_w4g32", "w4a8_int_act", "int8_w8a8", "w3g32", "w8g32", "grad_accumulate_2", "last_iterate",
                               "no_minmax_tuning", "fp_input_chain", "explicit_lrs", "momentum_0.9", "per_tensor_groups", "early_stop", "mixed_layer_config",
                               "ragged_last_batch", "fewer_samples_than_batch", "other_seed", "trailing_repeats_count_as_padding",
