@@ -220,6 +220,14 @@ __device__ __forceinline__ float lanes_sum(float v, int width) {
     for (int m = width >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, kWave);
     return v;
 }
+// the same sum in the association torch's reduction kernel uses for a contiguous inner dimension (ATen/native/cuda/Reduce.cuh,
+// block_x_reduce: `for (offset = 1; offset < dim_x; offset <<= 1) value += shfl_down(value, offset)`): neighbours first.  With the
+// in-lane order of bwd8 (two runs of four, like two of torch's float4-vectorised threads) the group sums of the fake-quant
+// backward then round exactly where autograd's `sum_to_size` rounds on this GPU.
+__device__ __forceinline__ float lanes_sum_torch(float v, int width) {
+    for (int m = 1; m < width; m <<= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
 __device__ __forceinline__ float lanes_max(float v, int width) {
     for (int m = width >> 1; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));
     return v;

@@ -274,8 +274,14 @@ struct Sums { float c1, c2, e, dy; };
 template <int XR, bool FAST>
 __device__ __forceinline__ void bwd8_impl(const float (&g)[8], const float (&w)[8], const float (&v)[8], float s, float y,
                                           float zp, float qlo, float qhi, float (&dy)[8], Sums& acc) {
+    // The four group sums are accumulated the way torch's reduction kernel accumulates a contiguous row of fp32 values: every
+    // "thread" of that kernel owns four consecutive elements, added left to right, and the threads are then combined neighbours
+    // first (lanes_sum_torch) -- a lane's eight elements are two such runs.  Keeps d min_scale / d max_scale on the bits autograd
+    // produces on the GPU (T3 probe at g128: tests/t3_baseline_shapes.py).
+    Sums p[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+        Sums& acc = p[k >> 2];
         const float x = round_to<XR>(FAST ? div_fast(w[k], s, y) : w[k] / s);
         const float r = round_ste_value(x + v[k]);
         const float t = r + zp;
@@ -290,6 +296,10 @@ __device__ __forceinline__ void bwd8_impl(const float (&g)[8], const float (&w)[
         acc.e += -e;                                       // SubBackward -> zp (asym)
         acc.dy += dy[k];                                   // AddBackward -> zp (asym)
     }
+    acc.c1 += p[0].c1 + p[1].c1;
+    acc.c2 += p[0].c2 + p[1].c2;
+    acc.e += p[0].e + p[1].e;
+    acc.dy += p[0].dy + p[1].dy;
 }
 template <int XR>
 __device__ __forceinline__ void bwd8(const float (&g)[8], const float (&w)[8], const float (&v)[8], float s, float zp,
@@ -425,9 +435,9 @@ __global__ __launch_bounds__(kTPB, AR_BWD_MINW) void k_int_bwd(const BwdArgs a) 
                 }
             }
             if (u < u_eff) {   // wave-uniform
-                acc.c1 = lanes_sum(acc.c1, cpg);
-                acc.c2 = lanes_sum(acc.c2, cpg);
-                if (!sym) { acc.e = lanes_sum(acc.e, cpg); acc.dy = lanes_sum(acc.dy, cpg); }
+                acc.c1 = lanes_sum_torch(acc.c1, cpg);
+                acc.c2 = lanes_sum_torch(acc.c2, cpg);
+                if (!sym) { acc.e = lanes_sum_torch(acc.e, cpg); acc.dy = lanes_sum_torch(acc.dy, cpg); }
                 if ((tid & (cpg - 1)) == 0 && gl < tile_groups) ssum[gl] = make_float4(acc.c1, acc.c2, acc.e, acc.dy);
             }
         }
@@ -687,9 +697,9 @@ __global__ __launch_bounds__(kTPB) void k_int_bwd_flat(const BwdArgs a0) {
                     for (int k = 0; k < 8; ++k) vnew[k] = v[k];
                 }
             }
-            acc.c1 = lanes_sum(acc.c1, cpg);
-            acc.c2 = lanes_sum(acc.c2, cpg);
-            if (!sym) { acc.e = lanes_sum(acc.e, cpg); acc.dy = lanes_sum(acc.dy, cpg); }
+            acc.c1 = lanes_sum_torch(acc.c1, cpg);
+            acc.c2 = lanes_sum_torch(acc.c2, cpg);
+            if (!sym) { acc.e = lanes_sum_torch(acc.e, cpg); acc.dy = lanes_sum_torch(acc.dy, cpg); }
             if (!ok) continue;
             float gmin, gmax;
             minmax_grads<XR>(a.cfg, q, make_float4(acc.c1, acc.c2, acc.e, acc.dy), gmin, gmax);

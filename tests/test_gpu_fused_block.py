@@ -991,3 +991,60 @@ def test_tuning_a_moe_block_with_the_fused_path_tracks_the_generic_path():
     err_g = (res[False][1].float() - res[False][2].float()).abs().mean().item()
     err_f = (res[True][1].float() - res[True][2].float()).abs().mean().item()
     assert abs(err_f - err_g) <= 0.2 * err_g, (err_f, err_g)
+
+
+def _set_nvfp4(layer, act_max=None):
+    """the reference's NVFP4 preset on every linear (weights nv_fp g16, activations nv_fp4_with_static_gs g16); `act_max`: the
+    calibrated input maximum per layer name suffix (what the act_max hooks leave on the layers before a block is tuned)"""
+    for n, m in layer.named_modules():
+        if isinstance(m, torch.nn.Linear) and getattr(m, "bits", 16) < 16:
+            m.bits, m.group_size, m.sym, m.data_type = 4, 16, True, "nv_fp"
+            m.act_bits, m.act_data_type, m.act_group_size, m.act_sym, m.act_dynamic = 4, "nv_fp4_with_static_gs", 16, True, True
+            if act_max is not None:
+                key = next((k for k in act_max if n.endswith(k)), None)
+                m.act_max = torch.tensor([act_max[key] if key else 4.0], dtype=torch.float32, device=_dev())
+
+
+@pytest.mark.parametrize("moe", [False, True])
+def test_fused_blocks_with_static_nvfp4_activations_match_the_module_path(moe):
+    """NVFP4 (BASELINE configs[4]'s second scheme): per-layer static activation scales 448 * 6 / act_max.  Layers that share an input
+    must agree on the scale (q / k / v; an expert's gate / up); experts differ from each other -> one activation launch per expert."""
+    from auto_round_amd.fused_block import FusedLlamaBlock, FusedMoEBlock, build_fused_block
+    from auto_round_amd.quantizer import block_forward
+    from auto_round_amd.wrapper import unwrapper_block, update_block_global_scale_if_needed, wrapper_block
+
+    layer, rope, cfg = _mixtral_layer() if moe else _llama_layer()
+    amax = {"q_proj": 5.0, "k_proj": 5.0, "v_proj": 5.0, "o_proj": 3.0, "gate_proj": 6.0, "up_proj": 6.0, "down_proj": 2.0,
+            "experts.1.gate_proj": 7.0, "experts.1.up_proj": 7.0, "experts.2.down_proj": 1.5}
+    _set_nvfp4(layer, {k: v for k, v in sorted(amax.items(), key=lambda kv: -len(kv[0]))})
+    X, others = _data(rope, cfg, N=4, S=64)
+    blk = copy.deepcopy(layer)
+    update_block_global_scale_if_needed(blk)
+    wrapper_block(blk, True, False, device="cuda")
+    arenas = blk._ar_arenas
+    fb = build_fused_block(blk, arenas, others, torch.bfloat16)
+    assert isinstance(fb, FusedMoEBlock if moe else FusedLlamaBlock) and fb.aq["qkv"][0] == "nv"
+    if moe:
+        assert len({pl for pl in fb.pl_gu_e}) > 1                    # expert 1 carries its own scale
+    pred_m = block_forward(blk, X, others, amp=True, amp_dtype=torch.bfloat16)
+    dpred = _rand(*pred_m.shape, seed=3, scale=0.1)
+    pred_m.backward(dpred)
+    dW_m = [a.dWq.clone() for a in arenas]
+    for a in arenas:
+        for lyr in a.layers:
+            lyr._dw_accum[0] = False
+        a.dWq.zero_()
+    pred_f = fb.forward(X, others)
+    pred_f.backward(dpred)
+    scale = pred_m.float().abs().mean().item()
+    assert (pred_f.float() - pred_m.float()).abs().mean().item() < 2e-2 * scale
+    for a_m, a in zip(dW_m, arenas):
+        cosine = torch.nn.functional.cosine_similarity(a.dWq.float(), a_m.float(), dim=0).item()
+        assert cosine > 0.99, cosine
+    unwrapper_block(blk, {})
+    # a layer without a calibrated maximum (dynamic per-call scale) keeps the module path
+    blk = copy.deepcopy(layer)
+    del blk.self_attn.o_proj.act_max
+    wrapper_block(blk, True, False, device="cuda")
+    assert build_fused_block(blk, blk._ar_arenas, others, torch.bfloat16) is None
+    unwrapper_block(blk, {})
