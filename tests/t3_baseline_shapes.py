@@ -36,6 +36,8 @@ BIG_CASES = {
     "opt125m_w4g128": dict(arch="opt125m", scheme="W4A16", kw={}, iters=200, nsamples=128, seqlen=2048, batch_size=8),
     # (b) BASELINE configs[1] block dimensions, >= 50 iterations
     "llama8b_w4g128": dict(arch="llama8b", scheme="W4A16", kw={}, iters=50, nsamples=32, seqlen=2048, batch_size=8),
+    # (b') the same block at the full BASELINE recipe (200 iterations, 128 calibration samples)
+    "llama8b_w4g128_full": dict(arch="llama8b", scheme="W4A16", kw={}, iters=200, nsamples=128, seqlen=2048, batch_size=8),
     # (c) BASELINE configs[2] scheme at real width
     "llama8b_w2g32_asym_algext": dict(arch="llama8b", scheme="W2A16G32", kw=dict(sym=False, enable_alg_ext=True), iters=50,
                                       nsamples=32, seqlen=2048, batch_size=8),
@@ -372,7 +374,7 @@ def main():
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
-    ap.add_argument("--cases", default=",".join(BIG_CASES))
+    ap.add_argument("--cases", default="opt125m_w4g128,llama8b_w4g128,llama8b_w2g32_asym_algext")
     ap.add_argument("--fixture", default=None, help="write the reference-on-GPU result of opt125m_w4g128 here")
     ap.add_argument("--skip-alone", action="store_true")
     args = ap.parse_args()
