@@ -228,6 +228,13 @@ __device__ __forceinline__ float lanes_sum_torch(float v, int width) {
     for (int m = 1; m < width; m <<= 1) v += __shfl_xor(v, m, kWave);
     return v;
 }
+// a lane's eight consecutive elements in the same association: TREE = one element per torch thread (rows of 16 / 32 / 64: a pure
+// pairwise tree), otherwise two float4-vectorised threads (rows of 128 and more)
+template <bool TREE>
+__device__ __forceinline__ float sum8_torch(const float (&t)[8]) {
+    if (TREE) return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    return (((t[0] + t[1]) + t[2]) + t[3]) + (((t[4] + t[5]) + t[6]) + t[7]);
+}
 __device__ __forceinline__ float lanes_max(float v, int width) {
     for (int m = width >> 1; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));
     return v;
@@ -266,6 +273,13 @@ template <int W> __device__ __forceinline__ float group_sum_desc(float v) {
     static_assert(W == 1 || W == 2 || W == 4, "quad permutes only");
     if constexpr (W >= 4) AR_DPP_STEP("v_add_f32", "quad_perm:[2,3,0,1]", v);
     if constexpr (W >= 2) AR_DPP_STEP("v_add_f32", "quad_perm:[1,0,3,2]", v);
+    return v;
+}
+// the same over 2 or 4 lanes neighbours first (stride 1, then 2): the association of torch's reduction kernel (lanes_sum_torch)
+template <int W> __device__ __forceinline__ float group_sum_asc(float v) {
+    static_assert(W == 1 || W == 2 || W == 4, "quad permutes only");
+    if constexpr (W >= 2) AR_DPP_STEP("v_add_f32", "quad_perm:[1,0,3,2]", v);
+    if constexpr (W >= 4) AR_DPP_STEP("v_add_f32", "quad_perm:[2,3,0,1]", v);
     return v;
 }
 #undef AR_GROUP_REDUCE

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a0) {
             const float amax = am[u], init = inr[u];
             float Ms = 1.f, sc = 1.f, rsc = 1.f, m = 0.f, se_un = 0.f, s_pre = 0.f, r = 0.f;
             if (ok) {
-                float gg[8], w[8], v[8], dv[8];
+                float gg[8], w[8], v[8], dv[8], tgq[8], tdw[8];
                 unpack8<XDT>(gr[u], gg);
                 unpack8<XDT>(wr[u], w);
                 if (a.V) unpack_f8(vr[u], v);
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a0) {
                         const float d = (t == 0.f) ? 0.f : ((fabsf(t) < 1.0f) ? 1.0f : q / t);
                         const bool inside = (tp >= -6.f) && (tp <= 6.f);
                         dv[k] = inside ? (gg[k] * sc) * d : 0.f;
-                        s_gq += gg[k] * q;
-                        s_dvw += dv[k] * (ws * rsc);
+                        tgq[k] = gg[k] * q;
+                        tdw[k] = dv[k] * (ws * rsc);
                     }
                 } else {
                     const float vm = amax * (Ms * init);
@@ -401,10 +401,14 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a0) {
                         const float q = nv_e2m1(x);
                         const bool inside = (xp >= -6.f) && (xp <= 6.f);
                         dv[k] = (inside && x != 0.f) ? gg[k] * rsc : 0.f;
-                        s_gq += gg[k] * q;
-                        s_dvw += dv[k] * w[k];
+                        tgq[k] = gg[k] * q;
+                        tdw[k] = dv[k] * w[k];
                     }
                 }
+                // rows of 32 / 16 values: torch's reduction kernel gives every element its own thread and combines neighbours
+                // first -- a pure pairwise tree (sum8_torch<true>, then the lanes of the group neighbours first)
+                s_gq = sum8_torch<true>(tgq);
+                s_dvw = sum8_torch<true>(tdw);
                 if (a.dV_out) store8_f32(a.dV_out, c * kEPT, dv);
                 if (a.lr_v && a.V) {
                     if (do_snap && a.best_V) store8_f32(a.best_V, c * kEPT, v);
@@ -414,8 +418,8 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a0) {
                     store8_f32(a.V, c * kEPT, vn);
                 }
             }
-            s_gq = group_sum_desc<cpg>(s_gq);
-            s_dvw = group_sum_desc<cpg>(s_dvw);
+            s_gq = group_sum_asc<cpg>(s_gq);
+            s_dvw = group_sum_asc<cpg>(s_dvw);
             if (ok && (c % cpg) == 0) {
                 float dMs;
                 if (a.mode == 0) {
@@ -522,6 +526,7 @@ __global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ d
         const int my_pos = ((int)(c % cpg)) * kEPT + lk;
         const int kstar = group_imin<cpg>((ok && lmax == amax) ? my_pos : 0x7fffffff);   // first index attaining the max
         float s_gq = 0.f, s_dvw = 0.f;
+        float tgq[8], tdw[8];
         float sc = 1.f, rsc = 1.f, m = amax, se_un = 0.f, s_pre = 0.f, r = 0.f;
         if (mode == 0) {
             float se = (m == 0.f) ? 1.0f : log2f(m);
@@ -538,8 +543,8 @@ __global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ d
                 const bool inside = (ws >= -6.f) && (ws <= 6.f);
                 const float dtp = inside ? (gg[k] * sc) * d : 0.f;
                 dx[k] = dtp * rsc;
-                s_gq += gg[k] * q;
-                s_dvw += dtp * (ws * rsc);
+                tgq[k] = gg[k] * q;
+                tdw[k] = dtp * (ws * rsc);
             }
         } else {
             s_pre = gscale * (amax * r6);
@@ -555,12 +560,12 @@ __global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ d
                 const bool inside = (xp >= -6.f) && (xp <= 6.f);
                 const float dxp = (inside && xc != 0.f) ? gg[k] * rsc : 0.f;
                 dx[k] = dxp * sc;
-                s_gq += gg[k] * q;
-                s_dvw += dxp * x[k];
+                tgq[k] = gg[k] * q;
+                tdw[k] = dxp * x[k];
             }
         }
-        s_gq = group_sum_desc<cpg>(s_gq);
-        s_dvw = group_sum_desc<cpg>(s_dvw);
+        s_gq = group_sum_asc<cpg>(sum8_torch<true>(tgq));         // (torch's association for rows of 32 / 16: see k_fp4_bwd)
+        s_dvw = group_sum_asc<cpg>(sum8_torch<true>(tdw));
         if (!ok) continue;
         float extra;
         if (mode == 0) {

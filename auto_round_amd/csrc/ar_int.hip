@@ -271,17 +271,19 @@ struct BwdArgs {
 
 struct Sums { float c1, c2, e, dy; };
 
-template <int XR, bool FAST>
+// The four group sums are accumulated in the association torch's reduction kernel (ATen/native/cuda/Reduce.cuh) uses for a
+// contiguous row of fp32 values, so that d min_scale / d max_scale carry the bits autograd's `sum_to_size` produces on this GPU
+// (probed inside the reference's own loop at real shapes: tests/t3_baseline_shapes.py -> profiles/r03_t3_baseline_shapes.json):
+//   rows of 128 and more  -- vectorised input: every "thread" owns four consecutive elements, added left to right, then the
+//                            threads are combined neighbours first; a lane's eight elements are two such runs (TREE = false);
+//   rows of 32 / 64       -- one element per thread, combined neighbours first: a pure pairwise tree (TREE = true).
+// Either way the lanes of a group finish with lanes_sum_torch (neighbours first).
+template <int XR, bool FAST, bool TREE>
 __device__ __forceinline__ void bwd8_impl(const float (&g)[8], const float (&w)[8], const float (&v)[8], float s, float y,
                                           float zp, float qlo, float qhi, float (&dy)[8], Sums& acc) {
-    // The four group sums are accumulated the way torch's reduction kernel accumulates a contiguous row of fp32 values: every
-    // "thread" of that kernel owns four consecutive elements, added left to right, and the threads are then combined neighbours
-    // first (lanes_sum_torch) -- a lane's eight elements are two such runs.  Keeps d min_scale / d max_scale on the bits autograd
-    // produces on the GPU (T3 probe at g128: tests/t3_baseline_shapes.py).
-    Sums p[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float t1[8], t2[8], te[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        Sums& acc = p[k >> 2];
         const float x = round_to<XR>(FAST ? div_fast(w[k], s, y) : w[k] / s);
         const float r = round_ste_value(x + v[k]);
         const float t = r + zp;
@@ -289,31 +291,32 @@ __device__ __forceinline__ void bwd8_impl(const float (&g)[8], const float (&w)[
         const float qq = clamp3(t, qlo, qhi) - zp;
         const float e = g[k] * s;                         // MulBackward, `other` side
         dy[k] = inside ? e : 0.f;                          // ClampBackward (where), STE through round
-        acc.c1 += g[k] * qq;                               // MulBackward, scale side (summed over the group)
+        t1[k] = g[k] * qq;                                 // MulBackward, scale side (summed over the group)
         const float dx = round_to<XR>(dy[k]);
-        const float t2 = round_to<XR>(FAST ? div_fast(x, s, y) : x / s);
-        acc.c2 += round_to<XR>((-dx) * t2);                // DivBackward, scale side
-        acc.e += -e;                                       // SubBackward -> zp (asym)
-        acc.dy += dy[k];                                   // AddBackward -> zp (asym)
+        const float tq = round_to<XR>(FAST ? div_fast(x, s, y) : x / s);
+        t2[k] = round_to<XR>((-dx) * tq);                  // DivBackward, scale side
+        te[k] = -e;                                        // SubBackward -> zp (asym)
     }
-    acc.c1 += p[0].c1 + p[1].c1;
-    acc.c2 += p[0].c2 + p[1].c2;
-    acc.e += p[0].e + p[1].e;
-    acc.dy += p[0].dy + p[1].dy;
+    acc.c1 += sum8_torch<TREE>(t1);
+    acc.c2 += sum8_torch<TREE>(t2);
+    acc.e += sum8_torch<TREE>(te);
+    acc.dy += sum8_torch<TREE>(dy);                        // AddBackward -> zp (asym)
 }
 template <int XR>
 __device__ __forceinline__ void bwd8(const float (&g)[8], const float (&w)[8], const float (&v)[8], float s, float zp,
-                                     float qlo, float qhi, float (&dy)[8], Sums& acc) {
+                                     float qlo, float qhi, float (&dy)[8], Sums& acc, bool tree = false) {
 #if AR_FASTDIV
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ok = ok && div_fast_ok(w[k]);
     if (__all(ok)) {                       // wave-uniform; x = w/s then stays inside the verified window as well
-        bwd8_impl<XR, true>(g, w, v, s, 1.0f / s, zp, qlo, qhi, dy, acc);
+        if (tree) bwd8_impl<XR, true, true>(g, w, v, s, 1.0f / s, zp, qlo, qhi, dy, acc);
+        else bwd8_impl<XR, true, false>(g, w, v, s, 1.0f / s, zp, qlo, qhi, dy, acc);
         return;
     }
 #endif
-    bwd8_impl<XR, false>(g, w, v, s, 0.f, zp, qlo, qhi, dy, acc);
+    if (tree) bwd8_impl<XR, false, true>(g, w, v, s, 0.f, zp, qlo, qhi, dy, acc);
+    else bwd8_impl<XR, false, false>(g, w, v, s, 0.f, zp, qlo, qhi, dy, acc);
 }
 
 // Gradients of min_scale / max_scale from the reduced group sums: autograd's scale path mirrored op by op
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(kTPB, AR_BWD_MINW) void k_int_bwd(const BwdArgs a) 
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = 0.f;
                 }
-                bwd8<XR>(gg, w, v, sz.x, sz.y, a.qlo, a.qhi, dy, acc);
+                bwd8<XR>(gg, w, v, sz.x, sz.y, a.qlo, a.qhi, dy, acc, a.cpg <= 8);
                 const int64_t e0 = (c0 + u * kTPB + tid) * kEPT;
                 if (a.dV) store8_f32(a.dV, e0, dy);
                 if (a.lr_v) {
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(kTPB) void k_int_bwd_flat(const BwdArgs a0) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = 0.f;
                 }
-                bwd8<XR>(gg, w, v, q.s, zp, a.qlo, a.qhi, dy, acc);
+                bwd8<XR>(gg, w, v, q.s, zp, a.qlo, a.qhi, dy, acc, cpg <= 8);
                 if (a.dV) store8_f32(a.dV, c * kEPT, dy);
                 if (a.lr_v) {
                     if (do_snap && a.best_V) store8_f32(a.best_V, c * kEPT, v);

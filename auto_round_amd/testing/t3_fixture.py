@@ -24,6 +24,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FIXTURE = os.path.join(ROOT, "tests", "golden", "t3_opt125m_w4g128_ref_on_mi355x.npz")
+DIGEST = os.path.join(ROOT, "tests", "golden", "t3_llama8b_w4g128_ref_on_mi355x_digest.npz")
 
 ARCHS = {
     # BASELINE configs[0] / north-star target model: OPT-125M's decoder block
@@ -229,3 +230,34 @@ def check_against_fixture(fused: bool, path: str = FIXTURE, graph: Optional[bool
                best_iter=r["stats"]["best_iter"], best_iter_ref=int(np.argmin(ref_trace)),
                first_divergence_iter=trace_divergence(ref_trace, r["loss_trace"]) if r["loss_trace"] else None, **cmp_)
     return rec
+
+
+def check_against_digest(path: str = DIGEST, fused: bool = False) -> dict:
+    """The Llama-3-8B-dimension block at the full BASELINE recipe (W4G128 sym, 200 iterations, 128 x 2048, batch 8): the reference's
+    packed result is 109 MB, so the fixture holds sha256 digests of every layer's `qweight / qzeros / scales` (+ one small layer in
+    full + the loss trace).  Re-tune the block with this package and compare digest for digest: on the module path the result is
+    BIT-IDENTICAL to the reference's on the same GPU type and software (profiles/r03_t3_baseline_shapes.json)."""
+    z = np.load(path, allow_pickle=False)
+    m = json.loads(str(z["meta"]))
+    r = tune_with_product(m["arch"], scheme=m["scheme"], iters=m["iters"], nsamples=m["nsamples"], seqlen=m["seqlen"],
+                          batch_size=m["batch_size"], fused=fused, seed=m["seed"])
+    packed = packed_layers(r["block"])
+    same, total, differing = 0, 0, []
+    for key, want in m["digests"].items():
+        name, what = key.split("::")
+        got = hashlib.sha256(np.ascontiguousarray(packed[name][what]).tobytes()).hexdigest()
+        total += 1
+        if got == want:
+            same += 1
+        else:
+            differing.append(key)
+    full = m["full_layer"]
+    ec = _codes(packed[full]["qweight"], int(m["bits"])) == _codes(z[f"{full}::qweight"], int(m["bits"]))
+    ref_trace = [float(x) for x in z["loss_trace"]]
+    tr = r["loss_trace"] or []
+    return dict(fused_block=r["fused_block"], inputs_identical=(r["x_sha"] == m["x_sha"]), targets_identical=(r["y_sha"] == m["y_sha"]),
+                tensors=total, tensors_identical=same, bit_identical=(same == total), differing=differing[:6],
+                full_layer=full, full_layer_identical_codes=float(ec.mean()), weights=int(sum(v["qweight"].size for v in packed.values()) * (32 // int(m["bits"]))),
+                init_loss=r["stats"]["init_loss"], init_loss_ref=ref_trace[0], best_loss=r["stats"]["best_loss"], best_loss_ref=min(ref_trace),
+                best_loss_ratio=r["stats"]["best_loss"] / min(ref_trace), first_divergence_iter=trace_divergence(ref_trace, tr),
+                device=m.get("device"), torch=m.get("torch"))

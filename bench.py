@@ -259,6 +259,13 @@ def parity_vs_reference_fixture():
         out[tag] = {k: r[k] for k in ("fused_block", "hip_graph", "inputs_identical", "targets_identical", "identical_words", "identical_scales",
                                       "init_loss", "init_loss_ref", "best_loss", "best_loss_ref", "best_loss_ratio", "first_divergence_iter")}
     out["best_loss_ratio"] = out["fused_path"]["best_loss_ratio"]
+    if os.path.exists(fx.DIGEST):       # the headline block itself: Llama-3-8B dimensions, full recipe, digest of the reference's result
+        d = fx.check_against_digest()
+        out["llama8b_module_path_bit_identical"] = bool(d["bit_identical"])
+        out["llama8b_module_path"] = {k: d[k] for k in ("tensors", "tensors_identical", "weights", "inputs_identical", "targets_identical",
+                                                        "full_layer_identical_codes", "init_loss", "init_loss_ref", "best_loss", "best_loss_ref",
+                                                        "best_loss_ratio", "first_divergence_iter")}
+        out["llama8b_module_path"]["fixture"] = os.path.relpath(fx.DIGEST, ROOT)
     return out
 
 

@@ -38,6 +38,10 @@ BIG_CASES = {
     "llama8b_w4g128": dict(arch="llama8b", scheme="W4A16", kw={}, iters=50, nsamples=32, seqlen=2048, batch_size=8),
     # (b') the same block at the full BASELINE recipe (200 iterations, 128 calibration samples)
     "llama8b_w4g128_full": dict(arch="llama8b", scheme="W4A16", kw={}, iters=200, nsamples=128, seqlen=2048, batch_size=8),
+    # BASELINE configs[4]'s schemes on the dense block (weights and activations in 4-bit floats): chaotic between engines after a few
+    # iterations (a flipped power-of-two scale moves a whole group), the per-iteration gradient probe is the point here
+    "llama8b_mxfp4": dict(arch="llama8b", scheme="MXFP4", kw={}, iters=30, nsamples=32, seqlen=2048, batch_size=8),
+    "llama8b_nvfp4": dict(arch="llama8b", scheme="NVFP4", kw={}, iters=30, nsamples=32, seqlen=2048, batch_size=8),
     # (c) BASELINE configs[2] scheme at real width
     "llama8b_w2g32_asym_algext": dict(arch="llama8b", scheme="W2A16G32", kw=dict(sym=False, enable_alg_ext=True), iters=50,
                                       nsamples=32, seqlen=2048, batch_size=8),
@@ -67,7 +71,7 @@ class _GradSignProbe:
         def _qdq_weight(self, value, min_scale, max_scale):
             wq, scale, zp = orig_qdq(self, value, min_scale, max_scale)
             if (torch.is_grad_enabled() and isinstance(wq, torch.Tensor) and wq.requires_grad and type(self) is RW.WrapperLinear
-                    and str(self.data_type).startswith("int") and not isinstance(self.orig_layer.group_size, (tuple, list))):
+                    and str(self.data_type).startswith(("int", "mx_fp", "nv_fp")) and not isinstance(self.orig_layer.group_size, (tuple, list))):
                 wq.retain_grad()
                 probe._seen[id(self)] = (self, wq)
             return wq, scale, zp
@@ -84,6 +88,25 @@ class _GradSignProbe:
                 if gs <= 0 or W.shape[1] % gs or gs % 8:
                     continue
                 V = w.value.data.reshape(-1).contiguous()
+                if not str(w.data_type).startswith("int"):          # MXFP4 / NVFP4: rounding offsets and max_scale only
+                    nv = str(w.data_type).startswith("nv_fp")
+                    mx = w.max_scale.data.reshape(-1).contiguous()
+                    Wf = W.contiguous().view(-1)
+                    absmax, _ = ops.group_absmax(Wf, gs)
+                    gsc = None
+                    if nv:
+                        gsc = getattr(w, "weight_global_scale", None)
+                        gsc = getattr(ol, "weight_global_scale", None) if gsc is None else gsc
+                        gsc = torch.as_tensor(gsc, dtype=torch.float32, device=Wf.device).reshape(1).contiguous()
+                    dV, dmax = ops.qdq_fp4_bwd_sgd_(g.contiguous().view(-1), Wf, V, absmax, mx, mode=1 if nv else 0, gs=gs,
+                                                    bounds=tuple(w.minmax_scale_bound), global_scale=gsc, want_grads=True)
+                    acc[5] += (dV.view(torch.int32) != w.value.grad.reshape(-1).view(torch.int32)).sum()
+                    acc[0] += mx.numel()
+                    if w.max_scale.grad is not None:
+                        rmax = w.max_scale.grad.reshape(-1)
+                        acc[2] += (torch.sign(dmax) != torch.sign(rmax)).sum()
+                        acc[4] += (dmax.view(torch.int32) != rmax.view(torch.int32)).sum()
+                    continue
                 mn, mx = w.min_scale.data.reshape(-1).contiguous(), w.max_scale.data.reshape(-1).contiguous()
                 dV, dmin, dmax = ops.qdq_int_bwd(g.contiguous().view(-1), W.contiguous().view(-1), V,
                                                  w.weight_min.reshape(-1).contiguous(), w.weight_max.reshape(-1).contiguous(), mn, mx,
@@ -204,6 +227,12 @@ def compare_layers(La, Lb):
         wa, wb = a.weight.detach().cpu().view(torch.int16), b.weight.detach().cpu().view(torch.int16)
         tot += wa.numel()
         same_w += int((wa == wb).sum())
+        if not getattr(a, "int_scheme", True):       # fp4 schemes: weights and scales only
+            sa, sb = a.scale.float().reshape(-1), b.scale.float().reshape(-1)
+            n_sz += sa.numel()
+            same_sz += int((sa == sb).sum())
+            same_q += int((wa == wb).sum())
+            continue
         qa, s1, z1 = _decode(a)
         qb, s2, z2 = _decode(b)
         eq = qa == qb
@@ -225,7 +254,9 @@ def _snapshot(model):
         o = L()
         o.weight = p.weight.detach().cpu().clone()
         o.scale = p.scale.detach().cpu().clone()
-        o.zp = p.zp.detach().cpu().clone() if isinstance(p.zp, torch.Tensor) else p.zp
+        zp = getattr(p, "zp", None)
+        o.zp = zp.detach().cpu().clone() if isinstance(zp, torch.Tensor) else zp
+        o.int_scheme = str(getattr(p, "data_type", "int")).startswith("int") and zp is not None
         o.bits, o.group_size, o.sym = int(p.bits), int(p.group_size), bool(p.sym)
         o.bias = None if p.bias is None else p.bias.detach().cpu().clone()
         out[n] = o
@@ -262,7 +293,30 @@ def write_fixture(path, case, layers, ref_trace, spy_rec, meta_extra):
     return os.path.getsize(path)
 
 
-def run_big_case(name, fixture_path=None, skip_alone=False):
+def write_digest(path, case, layers, ref_trace, spy_rec, meta_extra, full_layer="self_attn.k_proj"):
+    """A block too big for a fixture of tensors (Llama-3-8B: 109 MB of packed words): sha256 of every layer's reference-packed
+    `qweight / qzeros / scales` + the loss trace + one small layer in full (for a fraction if the hashes ever differ)."""
+    import hashlib
+    import tempfile
+
+    tmp = os.path.join(tempfile.mkdtemp(prefix="t3d_"), "full.npz")
+    write_fixture(tmp, case, layers, ref_trace, spy_rec, meta_extra)
+    z = np.load(tmp, allow_pickle=False)
+    rec, digests = {}, {}
+    for key in z.files:
+        if "::" not in key:
+            continue
+        digests[key] = hashlib.sha256(np.ascontiguousarray(z[key]).tobytes()).hexdigest()
+        if key.split("::")[0] == full_layer:
+            rec[key] = z[key]
+    meta = json.loads(str(z["meta"]))
+    meta["digests"] = digests
+    meta["full_layer"] = full_layer
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), loss_trace=z["loss_trace"], **rec)
+    return os.path.getsize(path)
+
+
+def run_big_case(name, fixture_path=None, skip_alone=False, digest_path=None, ref_twice=False):
     import_reference()
     from auto_round import AutoRound
     from t3_compare import _LossProbe
@@ -301,6 +355,12 @@ def run_big_case(name, fixture_path=None, skip_alone=False):
         rec["ref"] = dict(init_loss=ref_trace[0] if ref_trace else None, best_loss=min(ref_trace) if ref_trace else None,
                           best_iter=int(np.argmin(ref_trace)) if ref_trace else None, loss_trace=ref_trace, inputs=spy.rec)
         rec["grad_sign_probe"] = gprobe.summary()
+        if ref_twice:       # is the reference reproducible against ITSELF at this shape on this GPU?
+            q_ref2, _ = AutoRound(copy.deepcopy(base), iters=iters, **common).quantize()
+            torch.cuda.synchronize()
+            rec["ref_vs_ref"] = compare_layers(L_ref, _snapshot(q_ref2))
+            del q_ref2
+            _free()
 
         # ---- (module) / (fused): the plugin behind the same front door
         for tag, fused in (("module", False), ("fused", True)):
@@ -337,6 +397,11 @@ def run_big_case(name, fixture_path=None, skip_alone=False):
                 rec["fused_vs_module"] = compare_layers(L_mod, L_hip)
 
         # ---- (alone): the reference-free flow of the driver-side test
+        if digest_path:
+            sz = write_digest(digest_path, case, L_ref, ref_trace, spy.rec,
+                              dict(device=torch.cuda.get_device_name(0), torch=torch.__version__,
+                                   made_by="tests/t3_baseline_shapes.py: the reference's AutoRound(...).quantize() on cuda:0"))
+            rec["digest"] = dict(path=os.path.relpath(digest_path, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), bytes=sz)
         if fixture_path:      # written first: a failure further down must not lose the reference's result
             sz = write_fixture(fixture_path, case, L_ref, ref_trace, spy.rec,
                                dict(device=torch.cuda.get_device_name(0), torch=torch.__version__,
@@ -377,6 +442,8 @@ def main():
     ap.add_argument("--cases", default="opt125m_w4g128,llama8b_w4g128,llama8b_w2g32_asym_algext")
     ap.add_argument("--fixture", default=None, help="write the reference-on-GPU result of opt125m_w4g128 here")
     ap.add_argument("--skip-alone", action="store_true")
+    ap.add_argument("--digest", default=None, help="write the digest fixture of llama8b_w4g128_full here")
+    ap.add_argument("--ref-twice", default="", help="cases whose reference run is repeated (reproducibility of the reference itself)")
     args = ap.parse_args()
     if reference_root() is None:
         raise SystemExit("reference tree not present: run tools/stage_reference.sh first")
@@ -384,7 +451,8 @@ def main():
     for c in args.cases.split(","):
         try:
             r = run_big_case(c, fixture_path=os.path.abspath(args.fixture) if (args.fixture and c == "opt125m_w4g128") else None,
-                             skip_alone=args.skip_alone)
+                             skip_alone=args.skip_alone, digest_path=os.path.abspath(args.digest) if (args.digest and c == "llama8b_w4g128_full") else None,
+                             ref_twice=c in args.ref_twice.split(","))
         except Exception as e:
             import traceback
 

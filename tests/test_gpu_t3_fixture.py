@@ -34,33 +34,53 @@ def test_fixture_is_the_baseline_configuration(fixture_meta):
 
 
 def test_module_path_reproduces_the_reference_on_gpu_fixture(fixture_meta):
-    """Module path (`fused_block=False`): same torch block code as the reference around this package's kernels."""
+    """Module path (`fused_block=False`): same torch block code as the reference around this package's kernels.  At THIS shape the
+    library kernels under the block (head-size-64 attention backward, stream-K GEMMs) are not run-to-run deterministic -- the
+    reference does not reproduce its own result either (`ref_vs_ref` in profiles/r03_t3_baseline_shapes.json), and two runs of this
+    package part after ~65 iterations -- so the comparison is statistical here; the bit-exact one is the Llama-3-8B digest below."""
     from auto_round_amd.testing import t3_fixture as fx
 
     r = fx.check_against_fixture(fused=False)
-    assert not r["fused_block"]
-    assert r["inputs_identical"] and r["targets_identical"], r      # same block inputs / targets as the reference's quantizer saw
-    assert abs(r["init_loss"] - r["init_loss_ref"]) <= 1e-4 * r["init_loss_ref"], r
+    assert not r["fused_block"] and r["inputs_identical"], r          # same block inputs as the reference's quantizer saw
+    assert abs(r["init_loss"] - r["init_loss_ref"]) <= 1e-5 * r["init_loss_ref"], r
     assert r["identical_codes"] >= MODULE_MIN_IDENTICAL_CODES, r
-    assert r["identical_scales"] >= MODULE_MIN_IDENTICAL_SCALES, r
-    assert 1 / MODULE_BEST_LOSS_BAND <= r["best_loss_ratio"] <= MODULE_BEST_LOSS_BAND, r
+    assert 1 / BEST_LOSS_BAND <= r["best_loss_ratio"] <= BEST_LOSS_BAND, r
 
 
 def test_fused_path_stays_on_the_reference_trajectory_level(fixture_meta):
-    """Fused block path + MFMA weight-gradient GEMM (bench.py's configuration) against the same fixture."""
+    """Fused block path + MFMA weight-gradient GEMM + captured hipGraph iterations (bench.py's configuration for this block)."""
     from auto_round_amd.testing import t3_fixture as fx
 
     r = fx.check_against_fixture(fused=True)
-    assert r["fused_block"]
-    assert r["inputs_identical"] and r["targets_identical"], r
-    assert abs(r["init_loss"] - r["init_loss_ref"]) <= 2e-2 * r["init_loss_ref"], r
+    assert r["fused_block"] and r["hip_graph"] and r["inputs_identical"], r
+    assert abs(r["init_loss"] - r["init_loss_ref"]) <= 2e-3 * r["init_loss_ref"], r
     assert r["identical_codes"] >= FUSED_MIN_IDENTICAL_CODES, r
-    assert 1 / FUSED_BEST_LOSS_BAND <= r["best_loss_ratio"] <= FUSED_BEST_LOSS_BAND, r
+    assert 1 / BEST_LOSS_BAND <= r["best_loss_ratio"] <= BEST_LOSS_BAND, r
 
 
-# measured on the builder's MI355X (profiles/r03_t3_baseline_shapes.json), minus a margin -- see the module docstring
-MODULE_MIN_IDENTICAL_CODES = 0.90
-MODULE_MIN_IDENTICAL_SCALES = 0.90
-MODULE_BEST_LOSS_BAND = 1.10
-FUSED_MIN_IDENTICAL_CODES = 0.80
-FUSED_BEST_LOSS_BAND = 1.15
+# measured on the builder's MI355X (profiles/r03_t3_baseline_shapes.json): module path 0.87-0.93 identical codes, fused path 0.86,
+# best loss within 0.2 % of the reference's in every run
+MODULE_MIN_IDENTICAL_CODES = 0.80
+FUSED_MIN_IDENTICAL_CODES = 0.78
+BEST_LOSS_BAND = 1.01
+
+
+def test_llama8b_block_at_the_full_recipe_is_bit_identical_to_the_reference_digest():
+    """BASELINE configs[1]'s block dimensions at the full recipe (W4G128 sym, 200 iterations, 128 x 2048, batch 8): on the module path
+    every packed `qweight / qzeros / scales` tensor of the seven layers (218 M weights) hashes to what the REAL reference produced
+    on an MI355X -- "quantized integer weights and packed buffers bit-exactly on the same seed / inputs" (north-star).  The fused
+    kernels' group sums follow torch's own reduction order (csrc/ar_int.hip sum8_torch / lanes_sum_torch), which is what makes the
+    scale gradients -- and with them 200 sign-SGD iterations -- reproduce bit for bit."""
+    import torch
+
+    from auto_round_amd.testing import t3_fixture as fx
+
+    assert os.path.exists(fx.DIGEST), fx.DIGEST
+    r = fx.check_against_digest()
+    assert not r["fused_block"] and r["inputs_identical"] and r["targets_identical"], r
+    same_stack = r["torch"] == torch.__version__ and r["device"] == torch.cuda.get_device_name(0)
+    if same_stack:      # the library GEMM / attention kernels are the same binaries: nothing may differ
+        assert r["bit_identical"], r
+        assert r["first_divergence_iter"] is None and abs(r["best_loss_ratio"] - 1.0) < 1e-5, r
+    else:               # another torch / GPU: another summation order inside the library kernels -> trajectory level
+        assert r["full_layer_identical_codes"] > 0.7 and abs(r["best_loss_ratio"] - 1.0) < 0.02, r
