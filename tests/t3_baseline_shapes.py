@@ -416,7 +416,7 @@ def run_big_case(name, fixture_path=None, skip_alone=False, digest_path=None, re
                 L_al = {}
                 for n, p in a["block"].named_modules():
                     if isinstance(p, torch.nn.Linear) and hasattr(p, "scale"):
-                        L_al[n] = p
+                        L_al[n.replace(".orig_layer", "")] = p
                 r = dict(stats=a["stats"], fused_block=a["fused_block"], hip_graph=a["hip_graph"], inputs_identical=a["x_sha"] == spy.rec["x_sha"],
                          targets_identical=a["y_sha"] == spy.rec["y_sha"], others_keys=a["others_keys"],
                          first_divergence_iter=fx.trace_divergence(ref_trace, a["loss_trace"] or []), loss_trace=a["loss_trace"])
