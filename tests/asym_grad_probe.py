@@ -61,6 +61,14 @@ def main():
         e = g * sU
         dy = torch.where(inside, e, torch.zeros_like(e))
         rec["manual_dV_vs_autograd"] = beq(dy, V.grad)
+        bad = (dV_k.view(torch.int32) != V.grad.reshape(-1).view(torch.int32)).nonzero().reshape(-1)[:6]
+        rec["dV_examples"] = []
+        for i in bad.tolist():
+            gi, k = divmod(i, gs)
+            rec["dV_examples"].append(dict(i=i, W=float(Wg[gi, k]), V=float(V[gi, k]), s=float(s0[gi]), zp=float(zp0[gi]), x=float(x[gi, k]),
+                                           y=float(x[gi, k] + V[gi, k]), r=float(r[gi, k]), t=float(t[gi, k]), g=float(g[gi, k]),
+                                           dV_autograd=float(V.grad[gi, k]), dV_kernel=float(dV_k[i]), lo=float(lo[gi]), hi=float(hi[gi]),
+                                           s_raw=float(s_raw[gi]), mn=float(mn[gi]), mx=float(mx[gi]), wmin=float(wmin[gi]), wmax=float(wmax[gi])))
         for tag, S in (("torchsum", lambda a: a.sum(-1)), ("tree", tree_sum)):
             c1 = S(g * qq).to(torch.float16)
             c2 = S((-dy) * (x / sU)).to(torch.float16)
@@ -72,6 +80,12 @@ def main():
             dlo = (-d32) + (-(dzp / s0))
             dmin_m, dmax_m = dlo * wmin, d32 * wmax
             rec[f"manual_{tag}_vs_autograd"] = {"dmin": beq(dmin_m, mn.grad), "dmax": beq(dmax_m, mx.grad)}
+            if tag == "torchsum":
+                badg = (dmax_k.view(torch.int32) != mx.grad.view(torch.int32)).nonzero().reshape(-1)[:5]
+                rec["dmax_examples"] = [dict(g=int(j), c1=float(c1[j]), c2=float(c2[j]), c3=float(c3[j]), dzp=float(dzp[j]), ds=float(ds[j]), d32=float(d32[j]),
+                                             dmax_autograd=float(mx.grad[j]), dmax_kernel=float(dmax_k[j]), dmin_autograd=float(mn.grad[j]),
+                                             dmin_kernel=float(dmin_k[j]), s=float(s0[j]), zp=float(zp0[j]), wmax=float(wmax[j]), wmin=float(wmin[j]))
+                                        for j in badg.tolist()]
             rec[f"manual_{tag}_vs_kernel"] = {"dmin": beq(dmin_m, dmin_k), "dmax": beq(dmax_m, dmax_k)}
             rec[f"pieces_{tag}"] = {"dzp_a_eq_tree": beq(S(-e), tree_sum(-e)), "dzp_b_eq_tree": beq(S(dy), tree_sum(dy)),
                                     "c1_eq_tree": beq(S(g * qq), tree_sum(g * qq)), "c2_eq_tree": beq(S((-dy) * (x / sU)), tree_sum((-dy) * (x / sU)))}
