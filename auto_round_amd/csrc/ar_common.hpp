@@ -288,6 +288,24 @@ template <int W> __device__ __forceinline__ float group_sum_asc(float v) {
 // ---- per-group INT scale / zero-point (runs once per group, off the streaming path) -----------------------------
 // Mirrors auto_round/data_type/int.py:221-227 (sym) and :283-293 (asym) with the dtype choreography of
 // SURVEY App. A.1/A.2; min/max scale are clamped to [lo,hi] as WrapperLinear._qdq_weight does (wrapper.py:257-259).
+// `tensor / python_scalar` on the GPU is not a division: ATen's CUDA / HIP kernel multiplies by the reciprocal computed once in the
+// op-math type (ATen/native/cuda/BinaryDivTrueKernel.cu: "compute a * reciprocal(b); this may lose one bit of precision").  The
+// reference's `(wmax - wmin) / maxq` and the `/ maxq` of its backward are such divisions; for the asymmetric schemes maxq = 2^bits - 1
+// is not a power of two, so x * fl(1 / maxq) and x / maxq differ in the last bit now and then -- enough to move an fp16 scale that
+// sits on a rounding tie (1e-5 of the groups) and the low bit of 30 % of the scale gradients (tests/asym_grad_probe.py).  The kernels
+// follow the GPU semantics (AR_TORCH_GPU_SCALAR_DIV = 1: what the reference computes when it runs on this device); 0 = the CPU
+// semantics (true division) the CPU-generated golden vectors carry.  Symmetric schemes (maxq a power of two) are the same either way.
+#ifndef AR_TORCH_GPU_SCALAR_DIV
+#define AR_TORCH_GPU_SCALAR_DIV 1
+#endif
+__device__ __forceinline__ float div_py_scalar(float x, float b) {
+#if AR_TORCH_GPU_SCALAR_DIV
+    return x * (1.0f / b);
+#else
+    return x / b;
+#endif
+}
+
 struct IntCfg {
     int bits, sym, s_dt, w_dt;   // sym: 0 asym, 1 sym ("full range"), 2 sym with a searched init scale in the wmax slot
     float thresh;      // q_scale_thresh
@@ -318,7 +336,7 @@ __device__ __forceinline__ void group_scale(const IntCfg& c, float wmin, float w
         q.b = wmax * q.Ms;
         q.sgn = (q.b < q.a) ? 1.f : -1.f;
         const float m = (q.a > q.b) ? q.a : q.b;
-        q.s_raw = round_to_rt(c.s_dt, (q.sgn * m) / maxq);
+        q.s_raw = round_to_rt(c.s_dt, div_py_scalar(q.sgn * m, maxq));
         q.s = (q.s_raw < 0.f) ? ((q.s_raw > -t) ? -t : q.s_raw) : ((q.s_raw < t) ? t : q.s_raw);
         q.zp = maxq;
     } else {
@@ -326,7 +344,7 @@ __device__ __forceinline__ void group_scale(const IntCfg& c, float wmin, float w
         q.a = wmin * q.ms;
         q.b = wmax * q.Ms;
         q.sgn = 1.f;
-        q.s_raw = round_to_rt(c.s_dt, (q.b - q.a) / maxq);
+        q.s_raw = round_to_rt(c.s_dt, div_py_scalar(q.b - q.a, maxq));
         q.s = (q.s_raw < t) ? t : q.s_raw;
         q.zp = __builtin_rintf((-q.a) / q.s);
     }

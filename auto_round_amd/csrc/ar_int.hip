@@ -342,7 +342,7 @@ __device__ __forceinline__ void minmax_grads(const IntCfg& cfg, const GroupQ& q,
     float ds;
     if (sym) ds = (q.s_raw < 0.f) ? ((q.s_raw <= -t) ? ds_c : 0.f) : ((q.s_raw >= t) ? ds_c : 0.f);
     else ds = (q.s_raw >= t) ? ds_c : 0.f;
-    const float d32 = ds / maxq;
+    const float d32 = div_py_scalar(ds, maxq);
     if (cfg.sym == 2) {      // scale = (init_scale * max_scale).to(s_dt); min_scale is not part of the graph
         gmin = 0.f;
         gmax = ds * q.wmax;
