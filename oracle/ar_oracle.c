@@ -162,6 +162,16 @@ typedef struct {
 
 static inline float thresh_in(int s_dt, float t) { return rnd(s_dt, t); }
 
+/* `tensor / python_scalar` (the reference's `(wmax - wmin) / maxq`, data_type/int.py:283, and the `/ maxq` of its backward): torch on
+ * the CPU divides; torch's CUDA / HIP kernel multiplies by fl(1 / scalar) ("may lose one bit of precision",
+ * ATen/native/cuda/BinaryDivTrueKernel.cu).  Identical when the scalar is a power of two (every symmetric scheme); for the
+ * asymmetric ones (maxq = 2^bits - 1) the last bit differs now and then.  mode 0 (default) = CPU semantics, what the CPU-generated
+ * golden vectors carry; mode 1 = what the reference computes when it runs ON the GPU, the semantics the HIP kernels follow. */
+static int g_scalar_div_mode = 0;
+void oracle_set_scalar_div_mode(int gpu) { g_scalar_div_mode = gpu ? 1 : 0; }
+int oracle_get_scalar_div_mode(void) { return g_scalar_div_mode; }
+static inline float div_py_scalar(float x, float b) { return g_scalar_div_mode ? x * (1.0f / b) : x / b; }
+
 static void group_scale_sym(group_q_t* q, int bits, int s_dt, float q_thresh) {
     const float maxq = (float)(1 << (bits - 1));
     q->a = -(q->wmin * q->ms);
@@ -169,7 +179,7 @@ static void group_scale_sym(group_q_t* q, int bits, int s_dt, float q_thresh) {
     q->sgn = (q->b < q->a) ? 1 : -1;
     float m = (q->a > q->b) ? q->a : q->b;
     float max_v = (float)q->sgn * m;
-    q->s_raw = rnd(s_dt, max_v / maxq);
+    q->s_raw = rnd(s_dt, div_py_scalar(max_v, maxq));
     const float t = thresh_in(s_dt, q_thresh);
     if (q->s_raw < 0.f) q->s = (q->s_raw > -t) ? -t : q->s_raw;   /* clamp(max=-t) */
     else q->s = (q->s_raw < t) ? t : q->s_raw;                    /* clamp(min=t) */
@@ -192,7 +202,7 @@ static void group_scale_asym(group_q_t* q, int bits, int s_dt, float q_thresh) {
     q->a = q->wmin * q->ms; /* lo */
     q->b = q->wmax * q->Ms; /* hi */
     q->sgn = 1;
-    q->s_raw = rnd(s_dt, (q->b - q->a) / maxq);
+    q->s_raw = rnd(s_dt, div_py_scalar(q->b - q->a, maxq));
     const float t = thresh_in(s_dt, q_thresh);
     q->s = (q->s_raw < t) ? t : q->s_raw;
     /* -lo is fp32, scale is s_dt: fp32 / s_dt -> fp32 */
@@ -325,7 +335,7 @@ void oracle_qdq_int_bwd(const void* dWq, const void* W, const float* V, const vo
         float ds;
         if (sym) ds = (q.s_raw < 0.f) ? ((q.s_raw <= -t) ? ds_c : 0.f) : ((q.s_raw >= t) ? ds_c : 0.f);
         else ds = (q.s_raw >= t) ? ds_c : 0.f;
-        float d32 = ds / maxq; /* .to(scale_dtype) backward = cast to fp32, then DivBackward by maxq */
+        float d32 = div_py_scalar(ds, maxq); /* .to(scale_dtype) backward = cast to fp32, then DivBackward by maxq */
         if (sym == 2) {
             /* scale = (init_scale * max_scale).to(s_dt): d max_scale = float(ds) * init_scale; min_scale is unused */
             if (dmin) dmin[g] = 0.f;

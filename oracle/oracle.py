@@ -89,6 +89,13 @@ def _f(x):
     return ctypes.c_float(float(x))
 
 
+def set_scalar_div_mode(gpu: bool) -> None:
+    """False (default): `tensor / python_scalar` is a division, as torch evaluates it on the CPU (the golden vectors' semantics);
+    True: a multiplication by fl(1 / scalar), as torch's GPU kernels evaluate it -- what the reference computes when it runs on
+    the GPU and what the HIP kernels follow.  Only the asymmetric INT schemes (maxq = 2^bits - 1) can tell the two apart."""
+    lib().oracle_set_scalar_div_mode(int(bool(gpu)))
+
+
 def group_minmax(W: np.ndarray, w_dt: int, G: int, gs: int):
     wmin = np.empty(G, dtype=np_dtype(w_dt))
     wmax = np.empty(G, dtype=np_dtype(w_dt))
