@@ -63,6 +63,8 @@ struct AttnArgs {
     uint16_t* O;                                                   // [B, S, H, D]
     float* LSE;                                                    // [B, H, S]
     int B, S, H;
+    int64_t ldq, ldkv;                                             // elements between consecutive tokens of Q and of K / V (>= H * D:
+                                                                   // the operands may be column slices of one merged projection output)
     float scale_log2e;                                             // softmax scale * log2(e)
 };
 
@@ -101,10 +103,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd(AttnArgs a) {
     }
     const int b = bh / a.H, head = bh % a.H;
     const int q0 = qt * AQ;
-    const int64_t row_stride = (int64_t)a.H * AD;                  // elements between consecutive tokens
-    const uint16_t* Qb = a.Q + ((int64_t)b * a.S * a.H + head) * AD;
-    const uint16_t* Kb = a.K + ((int64_t)b * a.S * a.H + head) * AD;
-    const uint16_t* Vb = a.V + ((int64_t)b * a.S * a.H + head) * AD;
+    const int64_t row_stride = a.ldkv;                             // elements between consecutive tokens of K / V
+    const uint16_t* Qb = a.Q + (int64_t)b * a.S * a.ldq + head * AD;
+    const uint16_t* Kb = a.K + (int64_t)b * a.S * a.ldkv + head * AD;
+    const uint16_t* Vb = a.V + (int64_t)b * a.S * a.ldkv + head * AD;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
 
     // ---- Q^T fragments (b-operand: n = query = lane & 31, k = d = 16 ks + 8 h .. +7), kept for the whole kernel
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd(AttnArgs a) {
     abf16x8_t qf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        const uint4 r = *reinterpret_cast<const uint4*>(Qb + (int64_t)myq * row_stride + 16 * ks + 8 * h);
+        const uint4 r = *reinterpret_cast<const uint4*>(Qb + (int64_t)myq * a.ldq + 16 * ks + 8 * h);
         qf[ks] = __builtin_bit_cast(abf16x8_t, r);
     }
 
@@ -326,10 +328,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd(AttnArgs a) {
 using namespace ar;
 
 extern "C" int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H,
-                           int64_t D, float scale, int causal, ar_stream_t stream) {
+                           int64_t D, float scale, int causal, int64_t ldq, int64_t ldkv, ar_stream_t stream) {
     if ((D != 128 && D != 64) || !causal || S % 128 || B <= 0 || H <= 0 || S <= 0) return AR_ERR_UNSUPPORTED;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return AR_ERR_UNSUPPORTED;
+    if (ldq <= 0) ldq = H * D;
+    if (ldkv <= 0) ldkv = H * D;
+    if (ldq < H * D || ldkv < H * D || (ldq % 8) || (ldkv % 8) || 64 * ldkv > 0x7fffffffLL) return AR_ERR_UNSUPPORTED;
     AttnArgs a;
+    a.ldq = ldq; a.ldkv = ldkv;
     a.Q = (const uint16_t*)Q; a.K = (const uint16_t*)K; a.V = (const uint16_t*)V; a.O = (uint16_t*)O; a.LSE = LSE;
     a.B = (int)B; a.S = (int)S; a.H = (int)H;
     a.scale_log2e = scale * 1.4426950408889634f;

@@ -620,7 +620,7 @@ class FusedOPTBlock(FusedLlamaBlock):
         self.hq = self.hkv = q.out_features // hd
         self.hd, self.H, self.Fdim = hd, q.in_features, f1.out_features
         self.qscale = float(getattr(attn, "scaling", hd ** -0.5))
-        self.scaling = 1.0                     # OPTAttention scales q itself and calls the attention with scaling = 1
+        self._set_q_scaling()
         self.dtype = arena.w_dtype
         self.sdpa_ctx = sdpa_ctx
         self.use_mfma_dw = bool(use_mfma_dw)
@@ -641,6 +641,17 @@ class FusedOPTBlock(FusedLlamaBlock):
 
     def _dx_weights(self):          # (OPT-125M's 768-wide weights stay below _tn_min_dim: no gain measured there)
         return (self.Wo, self.W1, self.W2)
+
+    def _set_q_scaling(self):
+        """OPTAttention computes q_proj(x) * head_dim^-0.5 in the activation dtype and calls the attention with scaling = 1.  When that
+        factor is a power of two (head size 64: 0.125) the product is exact, so the factor is folded into the attention's softmax
+        scale instead -- same bits, one elementwise pass less in each direction -- and q / k / v are read as column slices of the
+        merged projection output (no copies).  Other head sizes keep the explicit multiply."""
+        import math
+
+        m, _ = math.frexp(self.qscale)
+        self.fold_qscale = (m == 0.5 and self.qscale > 0)
+        self.scaling = self.qscale if self.fold_qscale else 1.0
 
     @classmethod
     def try_build_plain(cls, block, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None) -> Optional["FusedOPTBlock"]:
@@ -667,7 +678,7 @@ class FusedOPTBlock(FusedLlamaBlock):
         self.hq = self.hkv = q.out_features // hd
         self.hd, self.H, self.Fdim = hd, q.in_features, f1.out_features
         self.qscale = float(getattr(attn, "scaling", hd ** -0.5))
-        self.scaling = 1.0
+        self._set_q_scaling()
         self.dtype = amp_dtype
         self.sdpa_ctx = sdpa_ctx
         self.aq = dict(qkv=None, o=None, f1=None, f2=None)
@@ -703,8 +714,10 @@ class FusedOPTBlock(FusedLlamaBlock):
         h1 = fq(h1, aq["qkv"])
         qkv = F.linear(h1, self.Wqkv, self.b_qkv)
         at = {n: i * H for i, n in enumerate(self.order)}
-        q2d = qkv[:, at["q"]:at["q"] + H] * self.qscale     # OPTAttention: q_proj(x) * scaling, in the activation dtype
-        k2d, v2d = qkv[:, at["k"]:at["k"] + H].contiguous(), qkv[:, at["v"]:at["v"] + H].contiguous()
+        q2d = qkv[:, at["q"]:at["q"] + H]
+        if not self.fold_qscale:
+            q2d = q2d * self.qscale                         # OPTAttention: q_proj(x) * scaling, in the activation dtype
+        k2d, v2d = qkv[:, at["k"]:at["k"] + H], qkv[:, at["v"]:at["v"] + H]      # column slices: the attention kernels take the stride
         del qkv
         attn, leaves = self._attention(q2d, k2d, v2d, mask, B, S, grad=ctx is not None)
         attn2d = attn.detach().transpose(1, 2).reshape(T, H)
@@ -766,7 +779,7 @@ class FusedOPTBlock(FusedLlamaBlock):
         grads = dict(q=dq, k=dk, v=dv)
         for i, n in enumerate(self.order):
             dst = dqkv[:, i * H:(i + 1) * H].view(B, S, self.hq, self.hd)
-            if n == "q":
+            if n == "q" and not self.fold_qscale:
                 torch.mul(grads[n].transpose(1, 2), self.qscale, out=dst)
             else:
                 dst.copy_(grads[n].transpose(1, 2))

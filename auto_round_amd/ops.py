@@ -489,11 +489,14 @@ def rope_bwd(dq2d, dk2d, dv2d, cos, sin, batch, seq, hq, hkv, d, out=None):
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq: int, heads: int, head_dim: int, scale=None):
     """Causal attention forward on token-major operands q / k / v [batch * seq, heads * head_dim] (bf16, K / V already repeated to
-    `heads`): -> (out [batch * seq, heads * head_dim], lse [batch, heads, seq] fp32), or None when the kernel does not take the
-    shape (head size other than 128 / 64, seq not a multiple of 128) -- the caller then keeps torch's SDPA."""
-    if q.dtype != torch.bfloat16 or head_dim not in (128, 64) or seq % 128 or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+    `heads`; unit inner stride -- the three may be column slices of one merged projection output, k and v with the same row stride):
+    -> (out [batch * seq, heads * head_dim], lse [batch, heads, seq] fp32), or None when the kernel does not take the shape (head
+    size other than 128 / 64, seq not a multiple of 128) -- the caller then keeps torch's SDPA."""
+    if q.dtype != torch.bfloat16 or head_dim not in (128, 64) or seq % 128:
         return None
-    out = torch.empty_like(q)
+    if any(t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16 for t in (q, k, v)) or k.stride(0) != v.stride(0):
+        return None
+    out = torch.empty((q.shape[0], heads * head_dim), dtype=q.dtype, device=q.device)
     lse = torch.empty((batch, heads, seq), dtype=torch.float32, device=q.device)
     sc = float(scale) if scale is not None else head_dim ** -0.5
     devs = set()
@@ -506,7 +509,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq:
     (dev,) = devs
     with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
         rc = load().ar_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), batch, seq, heads, head_dim,
-                                sc, 1, torch.cuda.current_stream(dev).cuda_stream)
+                                sc, 1, q.stride(0), k.stride(0), torch.cuda.current_stream(dev).cuda_stream)
     if rc == _lib.AR_ERR_UNSUPPORTED:
         return None
     check(rc, "ar_attn_fwd")

@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 16
+#define AR_ABI_VERSION 17
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -331,9 +331,13 @@ int ar_gemm_dw_config(int sem, int order);
  *           Q, K, V, O: [B, S, H, D] token-major bf16 (K / V already repeated to H heads), D = 128 or 64, S a multiple of 128;
  *           LSE [B, H, S] fp32 = natural-log row sums of the scaled scores, the form
  *           aten::_scaled_dot_product_efficient_attention_backward consumes.  scale = 1/sqrt(D) for the stock models.
+ *           ldq / ldkv: elements between consecutive tokens of Q and of K / V (0 = H * D, i.e. contiguous [B, S, H, D]); larger
+ *           strides let the operands be column slices of ONE merged q/k/v projection output (OPT: [tokens, 3 H D]) -- no copies;
+ *           `scale` then also carries a q scaling the module applies before the attention (OPTAttention: q_proj(x) * head_dim^-0.5,
+ *           exact to fold when it is a power of two).
  *           Anything else (no causal mask, other head sizes) returns AR_ERR_UNSUPPORTED and the caller keeps torch's SDPA. */
 int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
-                float scale, int causal, ar_stream_t stream);
+                float scale, int causal, int64_t ldq, int64_t ldkv, ar_stream_t stream);
 
 /* ---- optional device-side timing of the hot kernels (bench.py / tools; OFF by default) --------------------------
  * binding hygiene / measurement, no reference counterpart (the reference times blocks on the host,

@@ -59,11 +59,11 @@ class _HipLossTrace:
         self._ops, self._orig = ops, ops.best_loss_update
         trace = self
 
-        def spy(total_loss, state, istate, it):
+        def spy(total_loss, state, istate, it, *a, **k):
             if it == 0:
                 trace.blocks.append([])
             trace.blocks[-1].append(float(total_loss.item()))
-            return trace._orig(total_loss, state, istate, it)
+            return trace._orig(total_loss, state, istate, it, *a, **k)
 
         ops.best_loss_update = spy
         return self
