@@ -7,6 +7,25 @@
 
 namespace ar {
 
+// d out / d t of the MX element rounding for the clamped element t (q = its E2M1 value), applied to dx4 = d loss / d (rounded element):
+// autograd's own arithmetic, op by op (quant_element, data_type/mxfp.py:49-85).  With P = 2^pe the chain through the rounding itself
+// multiplies and divides by P, 2 and +-1 only -- exact -- so it hands dx4 through; the chain through the private exponent
+// pe = floor_ste(log2 |t|).clip(min = 0) is live for |t| >= 1: the two `2.0 ** pe` nodes receive dx4 * (q / P) and -(dx4 P)((t / P) / P),
+// PowBackward turns each into grad * (P * ln 2) (two separate roundings, then their sum), Log2Backward divides by |t| * ln 2:
+//     dt = dx4 + sign(t) * fl( fl( fl(fl(dx4 q) ln2) - fl(fl(dx4 t) ln2) ) / fl(|t| ln2) )
+// (powers of two commute with every rounding).  Same value as dx4 * q / t; these are the bits torch produces.
+__device__ __forceinline__ float mx_elem_grad(float dx4, float t, float q) {
+    const float LN2F = 0.6931471805599453f;
+    if (t == 0.f) return 0.f;
+    const float at = fabsf(t);
+    if (at < 1.0f) return dx4;
+    const float a = (dx4 * q) * LN2F;
+    const float b = (dx4 * t) * LN2F;
+    const float darg = (a - b) / (at * LN2F);
+    return dx4 + (t > 0.f ? darg : -darg);
+}
+
+
 // literal restatement of mxfp.quant_element(ebits=2, mbits=3, max_norm=6, "even") on |t| <= 6
 // (auto_round/data_type/mxfp.py:49-85).  floor(log2|t|) clipped at 0 is 0/1/2 by comparison (exact in this range).
 __device__ __forceinline__ float mx_e2m1(float t) {
@@ -381,9 +400,8 @@ __global__ __launch_bounds__(kTPB) void k_fp4_bwd(const Fp4BwdArgs a0) {
                         const float tp = ws + v[k];
                         const float t = clamp3(tp, -6.f, 6.f);
                         const float q = mx_e2m1(t);
-                        const float d = (t == 0.f) ? 0.f : ((fabsf(t) < 1.0f) ? 1.0f : q / t);
                         const bool inside = (tp >= -6.f) && (tp <= 6.f);
-                        dv[k] = inside ? (gg[k] * sc) * d : 0.f;
+                        dv[k] = inside ? mx_elem_grad(gg[k] * sc, t, q) : 0.f;
                         tgq[k] = gg[k] * q;
                         tdw[k] = dv[k] * (ws * rsc);
                     }
@@ -539,9 +557,8 @@ __global__ __launch_bounds__(kTPB) void k_fp4_act_bwd(const void* __restrict__ d
                 const float ws = x[k] * rsc;
                 const float t = clamp3(ws, -6.f, 6.f);
                 const float q = mx_e2m1(t);
-                const float d = (t == 0.f) ? 0.f : ((fabsf(t) < 1.0f) ? 1.0f : q / t);
                 const bool inside = (ws >= -6.f) && (ws <= 6.f);
-                const float dtp = inside ? (gg[k] * sc) * d : 0.f;
+                const float dtp = inside ? mx_elem_grad(gg[k] * sc, t, q) : 0.f;
                 dx[k] = dtp * rsc;
                 tgq[k] = gg[k] * q;
                 tdw[k] = dtp * (ws * rsc);
