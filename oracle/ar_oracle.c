@@ -172,6 +172,23 @@ void oracle_set_scalar_div_mode(int gpu) { g_scalar_div_mode = gpu ? 1 : 0; }
 int oracle_get_scalar_div_mode(void) { return g_scalar_div_mode; }
 static inline float div_py_scalar(float x, float b) { return g_scalar_div_mode ? x * (1.0f / b) : x / b; }
 
+/* d out / d t of the MX element rounding (quant_element, data_type/mxfp.py:49-85) applied to dx4 = d loss / d (rounded element), in
+ * autograd's own fp32 arithmetic.  The chain through the rounding itself only multiplies / divides by 2^pe, 2 and +-1 (exact): it
+ * hands dx4 through (0 for t == 0, where sign() kills it).  The chain through the private exponent pe = floor_ste(log2|t|).clip(min=0)
+ * is live for |t| >= 1: the two `2.0 ** pe` nodes receive dx4 * (q / P) and -(dx4 P) ((t / P) / P); PowBackward multiplies each by
+ * P * ln2 (two roundings, then their sum); Log2Backward divides by |t| * ln2; AbsBackward restores the sign.  Equals dx4 * q / t in
+ * exact arithmetic (the closed form of rounds 1-2); these are the bits torch produces, on the CPU and on the GPU alike. */
+static inline float mx_elem_grad(float dx4, float t, float q) {
+    const float LN2F = 0.6931471805599453f;
+    if (t == 0.f) return 0.f;
+    const float at = fabsf(t);
+    if (at < 1.0f) return dx4;
+    const float a = (dx4 * q) * LN2F;
+    const float b = (dx4 * t) * LN2F;
+    const float darg = (a - b) / (at * LN2F);
+    return dx4 + (t > 0.f ? darg : -darg);
+}
+
 static void group_scale_sym(group_q_t* q, int bits, int s_dt, float q_thresh) {
     const float maxq = (float)(1 << (bits - 1));
     q->a = -(q->wmin * q->ms);
@@ -674,10 +691,8 @@ void oracle_qdq_fp4_bwd(const void* dXq, const void* W, const float* V, const fl
                 const float tp = ws + (V ? V[i] : 0.f);
                 const float t = clampf(tp, -6.f, 6.f);
                 const float q = mx_quant_element_fp4(t);
-                const float a = fabsf(t);
-                const float d = (t == 0.f) ? 0.f : ((a < 1.0f) ? 1.0f : q / t);
                 const float inside = (tp >= -6.f && tp <= 6.f) ? 1.f : 0.f;
-                const float dv = (gk * sc) * d * inside;
+                const float dv = inside != 0.f ? mx_elem_grad(gk * sc, t, q) : 0.f;
                 if (dV) dV[i] = dv;
                 s_gq += (double)(gk * q);
                 s_dvw += (double)(dv * (ws / sc));
@@ -750,9 +765,8 @@ void oracle_fp4_act_bwd(const void* dXq, const void* X, float global_scale, int6
                 const float ws = x / sc;
                 const float t = clampf(ws, -6.f, 6.f);
                 const float q = mx_quant_element_fp4(t);
-                const float d = (t == 0.f) ? 0.f : ((fabsf(t) < 1.0f) ? 1.0f : q / t);
                 const float inside = (ws >= -6.f && ws <= 6.f) ? 1.f : 0.f;
-                const float dtp = (gk * sc) * d * inside;
+                const float dtp = inside != 0.f ? mx_elem_grad(gk * sc, t, q) : 0.f;
                 tmp[k] = dtp / sc;
                 s_gq += (double)(gk * q);
                 s_dvw += (double)(dtp * (ws / sc));
