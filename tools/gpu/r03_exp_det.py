@@ -1,14 +1,22 @@
-"""experiment: is the module path run-to-run deterministic at the OPT-125M BASELINE shape (library GEMMs incl. stream-K ones)?"""
+"""experiment: run-to-run determinism of this package's module path at the OPT-125M BASELINE shape, 80 iterations, under variations
+of how the weight-gradient GEMM is issued (env AR_DW_VIA_TEMP) / which engine computes it (mfma_dw_gemm)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from auto_round_amd.testing import t3_fixture as fx
+import auto_round_amd.quantizer as Q
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
+orig = Q.SignRoundConfig.__init__
+if mode == "mfma":
+    def patched(self, *a, **k):
+        orig(self, *a, **k)
+        self.mfma_dw_gemm = True
+    Q.SignRoundConfig.__init__ = patched
 runs = []
-for i in range(2):
-    r = fx.tune_with_product("opt125m", fused=False)
-    runs.append((r["loss_trace"], {n: m.weight.detach().clone() for n, m in r["block"].named_modules() if isinstance(m, torch.nn.Linear)}, r["y_sha"]))
-a, b = runs
-same_trace = a[0] == b[0]
-first = next((i for i, (x, y) in enumerate(zip(a[0], b[0])) if x != y), None)
-same_w = all(torch.equal(a[1][n], b[1][n]) for n in a[1])
-print(json.dumps({"same_loss_trace": same_trace, "first_different_iteration": first, "same_weights": same_w, "same_targets": a[2] == b[2]}))
+for i in range(3):
+    r = fx.tune_with_product("opt125m", fused=False, iters=80)
+    runs.append((r["loss_trace"], r["y_sha"]))
+first = [next((i for i, (x, y) in enumerate(zip(runs[0][0], runs[j][0])) if x != y), None) for j in (1, 2)]
+print(json.dumps({"mode": mode, "AR_DW_VIA_TEMP": os.environ.get("AR_DW_VIA_TEMP"), "first_different_iteration_vs_run0": first,
+                  "same_targets": [runs[0][1] == runs[j][1] for j in (1, 2)]}))
