@@ -29,9 +29,6 @@ except Exception:  # pragma: no cover
     Conv1D = ()
 
 SUPPORTED_INT = ("int", "int_sym", "int_asym")
-import os as _os
-
-_DW_VIA_TEMP = _os.environ.get("AR_DW_VIA_TEMP", "0") == "1"      # experiment: the weight-gradient GEMM into a fresh tensor, then copied
 
 
 def is_int_dtype(data_type: str) -> bool:
@@ -98,9 +95,6 @@ class _QLinearFn(torch.autograd.Function):
             ctx.accumulate[0] = True
         elif ctx.accumulate[0]:
             ctx.dwq_out.addmm_(dy2.t(), x2)
-        elif _DW_VIA_TEMP:
-            ctx.dwq_out.copy_(torch.mm(dy2.t(), x2))
-            ctx.accumulate[0] = True
         else:
             torch.mm(dy2.t(), x2, out=ctx.dwq_out)
             ctx.accumulate[0] = True

@@ -1,5 +1,6 @@
-"""experiment: run-to-run determinism of this package's module path at the OPT-125M BASELINE shape, 80 iterations, under variations
-of how the weight-gradient GEMM is issued (env AR_DW_VIA_TEMP) / which engine computes it (mfma_dw_gemm)."""
+"""experiment: run-to-run determinism of this package's module path at the OPT-125M BASELINE shape, 80 iterations, three runs in one
+process: `plain` (library weight-gradient GEMM) or `mfma` (this repository's deterministic one).  -> profiles/r03_opt125m_determinism.json
+(the committed file also holds a third mode, the library GEMM into a fresh tensor, whose switch was removed again)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
