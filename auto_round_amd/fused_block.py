@@ -902,10 +902,10 @@ class FusedMoEBlock(FusedLlamaBlock):
         return self
 
     def _dx_weights(self):
-        """W^T copies for the input-gradient GEMMs: the o-projection and every expert's merged gate/up and down weights (one more copy
-        of the block's weights in HBM -- 2.9 GB for Mixtral-8x7B -- and one transpose per weight per iteration, ~1 ms, against
-        expert dX GEMMs that run 1.2-1.5x faster with both operands contiguous along the reduction)"""
-        return (self.Wo,) + tuple(self.Wgu) + tuple(self.Wd)
+        """Only the o-projection keeps a transposed copy.  (Transposed copies of every expert's merged gate/up and down weights were
+        measured in round 3: 2.9 GB more HBM and 16 transposes per iteration for expert dX GEMMs in the library's fast layout --
+        9.90 s per Mixtral block against 9.71 s without them.)"""
+        return (self.Wo,)
 
     @staticmethod
     def _rows_fq(t, plans, counts, raw, grad_of=None):
@@ -1004,10 +1004,7 @@ class FusedMoEBlock(FusedLlamaBlock):
             if cnt:
                 rows = slice(start, start + cnt)
                 self._dw(dD[rows], act_q[rows], self.dWd[e], [self.trip[e][2]])
-                if self._tn is not None:
-                    torch.mm(dD[rows], self._tn[1 + self.E + e].t(), out=dact_q[rows])
-                else:
-                    torch.mm(dD[rows], self.Wd[e], out=dact_q[rows])
+                torch.mm(dD[rows], self.Wd[e], out=dact_q[rows])
             start += cnt
         del dD, act_q
         dact = self._rows_fq(dact_q, self.pl_d_e, counts, act_quant_bwd_raw, grad_of=s.pop("act"))
@@ -1020,10 +1017,7 @@ class FusedMoEBlock(FusedLlamaBlock):
             if cnt:
                 rows = slice(start, start + cnt)
                 self._dw(dGU[rows], xs_q[rows], self.dWgu[e], [self.trip[e][0], self.trip[e][1]])
-                if self._tn is not None:
-                    torch.mm(dGU[rows], self._tn[1 + e].t(), out=dxs_q[rows])
-                else:
-                    torch.mm(dGU[rows], self.Wgu[e], out=dxs_q[rows])
+                torch.mm(dGU[rows], self.Wgu[e], out=dxs_q[rows])
             start += cnt
         del dGU, xs_q
         dxs = self._rows_fq(dxs_q, self.pl_gu_e, counts, act_quant_bwd_raw, grad_of=s.pop("xs"))

@@ -323,6 +323,8 @@ class SignRoundQuantizer:
         self.last_hip_graph = False
         self._fused_verdict: Dict[Any, bool] = {}        # block signature -> did the fused kernels agree with the module code
         self._graph_stream = None
+        self._graph_pool = None
+        self._last_graph = None
 
     # convenience accessors with the reference's attribute names
     @property
@@ -659,16 +661,19 @@ class SignRoundQuantizer:
         try:
             # (capture_begin / capture_end on a side stream directly: the torch.cuda.graph() context also runs gc.collect() and
             #  empties the allocator's cache on entry -- tens of milliseconds per block on a 380 ms block)
+            # One allocator pool for the graphs of all blocks: a fresh private pool per capture means fresh hipMallocs for every
+            # activation of every block (tens of milliseconds on a 380 ms block).  The previous block's graph is kept alive until
+            # this capture has ended -- a pool whose last graph was destroyed is released, and capturing into its stale handle trips
+            # an allocator assert (measured) -- its tensors are dead, so the new capture reuses its memory.
             if self._graph_stream is None:
                 self._graph_stream = torch.cuda.Stream(device)
-            self._last_graph = None                                     # the previous block's graph gives its memory back first
+            if self._graph_pool is None or self._last_graph is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
             graph = torch.cuda.CUDAGraph()
             side = self._graph_stream
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
-                graph.capture_begin()                                   # (its own private pool: a handle shared between
-                                                                        #  successive graphs trips an allocator assert once the
-                                                                        #  first graph has been destroyed -- measured)
+                graph.capture_begin(pool=self._graph_pool)
                 try:
                     body()                                              # recorded, not executed
                 finally:

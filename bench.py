@@ -319,7 +319,7 @@ class Bench:
             kw["fused_block"] = fused_block
             kw["mfma_dw_gemm"] = fused_block
         kw["flash_attention"] = not getattr(args, "no_flash_attn", False)
-        kw["hip_graph"] = True if getattr(args, "hip_graph", False) else None
+        kw["hip_graph"] = True if getattr(args, "hip_graph", False) else (False if getattr(args, "no_hip_graph", False) else None)
         self.qcfg = SignRoundConfig(iters=args.iters, batch_size=args.batch_size, bits=self.bits,
                                     fuse_next_forward=fuse_next_forward, sdpa_backend=args.sdpa, data_parallel=dp,
                                     enable_quanted_input=quanted_input, **kw)
@@ -446,6 +446,7 @@ def main():
     ap.add_argument("--hip-graph", action="store_true",
                     help="replay each tuning iteration as one captured hipGraph even while per-dispatch kernel timing is on (the roofline "
                          "objects then only see iteration 0 of every block); without the flag: automatic for small blocks when timing is off")
+    ap.add_argument("--no-hip-graph", action="store_true", help="keep every tuning iteration host-driven (A/B against the captured form)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the opt125m and variants objects")
