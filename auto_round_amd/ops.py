@@ -516,6 +516,45 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq:
     return out, lse
 
 
+_attn_ws: dict = {}
+
+
+def attn_bwd(q, k, v, out, lse, dout, batch: int, seq: int, heads: int, head_dim: int, scale=None, dq=None, dk=None, dv=None):
+    """Causal attention backward (head size 64, deterministic) on token-major operands [batch * seq, heads * 64] with unit inner
+    stride (column slices of merged buffers are fine; so are dq / dk / dv given as such slices): -> (dq, dk, dv), or None when the
+    kernel does not take the shape -- the caller then keeps the library backward."""
+    if head_dim != 64 or seq % 256 or seq > 4096 or q.dtype != torch.bfloat16:
+        return None
+    ts = [q, k, v, out, dout]
+    if any(t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16 or t.dtype != torch.bfloat16 for t in ts):
+        return None
+    T, HD = batch * seq, heads * head_dim
+    outs = []
+    for t in (dq, dk, dv):
+        if t is None:
+            t = torch.empty((T, HD), dtype=q.dtype, device=q.device)
+        if t.dim() != 2 or tuple(t.shape) != (T, HD) or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16:
+            return None
+        outs.append(t)
+    dev = q.device.index
+    if any((not t.is_cuda) or t.device.index != dev for t in ts + outs + [lse]):
+        raise _lib.Mi355xLibraryError("attn_bwd: every tensor must live on one HIP device (no CPU fallback)")
+    need = load().ar_attn_bwd_workspace_bytes(batch, seq, heads)
+    ws = _attn_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _attn_ws[dev] = torch.empty(need, dtype=torch.uint8, device=q.device)
+    sc = float(scale) if scale is not None else head_dim ** -0.5
+    with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
+        rc = load().ar_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), batch, seq, heads, head_dim, sc, 1,
+                                q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0), outs[0].stride(0), outs[1].stride(0),
+                                outs[2].stride(0), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+    if rc == _lib.AR_ERR_UNSUPPORTED:
+        return None
+    check(rc, "ar_attn_bwd")
+    return tuple(outs)
+
+
 _gemm_ws: dict = {}
 
 

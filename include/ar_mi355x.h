@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 17
+#define AR_ABI_VERSION 18
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -338,6 +338,20 @@ int ar_gemm_dw_config(int sem, int order);
  *           Anything else (no causal mask, other head sizes) returns AR_ERR_UNSUPPORTED and the caller keeps torch's SDPA. */
 int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
                 float scale, int causal, int64_t ldq, int64_t ldkv, ar_stream_t stream);
+
+/* ---- causal attention backward, head size 64 (deterministic: two MFMA kernels, no float atomics) ---------------------------
+ * replaces: autograd of the same attention call -- torch's aten::_scaled_dot_product_efficient_attention_backward, i.e. aiter's
+ *           fmha_bwd (+ pre / post-process kernels), which accumulates dQ with fp32 atomics (0.42 ms per call at OPT-125M's minibatch,
+ *           the largest kernel of BASELINE configs[0]).  Q, K, V, dO and the outputs dQ, dK, dV are token-major [B, S, H, 64] bf16 with
+ *           caller-given row strides (ld*: elements between consecutive tokens, 0 = H * 64): inputs and outputs may be column slices
+ *           of merged [tokens, 3 H 64] buffers, so the gradient of a merged q/k/v projection needs no gather pass.  O [B, S, H, 64]
+ *           and LSE [B, H, S] are ar_attn_fwd's results.  workspace: ar_attn_bwd_workspace_bytes(B, S, H) bytes of scratch
+ *           (D = rowsum(dO * O) and lse * log2(e)).  S % 256 == 0, S <= 4096, causal only; anything else AR_ERR_UNSUPPORTED (the
+ *           caller keeps the library backward; head size 128 is left to it on purpose: csrc/ar_attn_bwd.hip). */
+int64_t ar_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H);
+int ar_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ, void* dK, void* dV,
+                int64_t B, int64_t S, int64_t H, int64_t D, float scale, int causal, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, void* workspace, int64_t workspace_bytes, ar_stream_t stream);
 
 /* ---- optional device-side timing of the hot kernels (bench.py / tools; OFF by default) --------------------------
  * binding hygiene / measurement, no reference counterpart (the reference times blocks on the host,

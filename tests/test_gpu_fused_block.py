@@ -1048,3 +1048,53 @@ def test_fused_blocks_with_static_nvfp4_activations_match_the_module_path(moe):
     wrapper_block(blk, True, False, device="cuda")
     assert build_fused_block(blk, blk._ar_arenas, others, torch.bfloat16) is None
     unwrapper_block(blk, {})
+
+
+# ---- round 3: deterministic attention backward at head size 64 ----------------------------------------------------------------
+@pytest.mark.parametrize("B,S,H,strided", [(2, 256, 4, False), (1, 512, 12, True), (3, 1024, 2, True)])
+def test_attention_backward_vs_fp32_autograd_and_the_library(B, S, H, strided):
+    """dQ / dK / dV of the causal attention at head size 64 from csrc/ar_attn_bwd.hip: against fp32 autograd of the exact attention,
+    next to what the library's backward achieves on the same inputs; with operands and results as column slices of merged
+    [tokens, 3 H D] buffers (the OPT block's layout); and run twice -- bit-identical (no atomics)."""
+    from auto_round_amd import ops
+
+    D, T = 64, B * S
+    HD = H * D
+    sc = D ** -0.5
+    if strided:
+        qkv = _rand(T, 3 * HD, seed=31)
+        q, k, v = qkv[:, HD:2 * HD], qkv[:, :HD], qkv[:, 2 * HD:]          # (any order of the three inside the merged buffer)
+    else:
+        q, k, v = _rand(T, HD, seed=31), _rand(T, HD, seed=32), _rand(T, HD, seed=33)
+    do = _rand(T, HD, seed=34, scale=0.1)
+    res = ops.attn_fwd(q, k, v, B, S, H, D, scale=sc)
+    assert res is not None
+    out, lse = res
+
+    def h4(t):
+        return t.reshape(B, S, H, D).transpose(1, 2)
+
+    qf, kf, vf = (h4(t).float().detach().requires_grad_(True) for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf, is_causal=True, scale=sc)
+    ref.backward(h4(do).float())
+    want = [t.grad.transpose(1, 2).reshape(T, HD) for t in (qf, kf, vf)]
+    if strided:
+        dqkv = torch.zeros(T, 3 * HD, dtype=torch.bfloat16, device=_dev())
+        got = ops.attn_bwd(q, k, v, out, lse, do, B, S, H, D, scale=sc, dq=dqkv[:, HD:2 * HD], dk=dqkv[:, :HD], dv=dqkv[:, 2 * HD:])
+    else:
+        got = ops.attn_bwd(q, k, v, out, lse, do, B, S, H, D, scale=sc)
+    assert got is not None
+    z = torch.zeros((), dtype=torch.int64)
+    lib = torch.ops.aten._scaled_dot_product_efficient_attention_backward(h4(do), h4(q), h4(k), h4(v), None, h4(out), lse, z, z, 0.0,
+                                                                         (True, True, True, False), True, scale=sc)[:3]
+    for name, mine, w, l in zip("qkv", got, want, lib):
+        ref_scale = w.abs().mean().item()
+        err = (mine.float() - w).abs().mean().item()
+        err_lib = (l.transpose(1, 2).reshape(T, HD).float() - w).abs().mean().item()
+        assert err < 2e-2 * ref_scale, (name, err, ref_scale)
+        assert err < 1.5 * err_lib + 1e-3 * ref_scale, (name, err, err_lib)        # as accurate as the library's bf16 backward
+        assert torch.allclose(mine.float(), w, rtol=5e-2, atol=5e-2 * w.abs().max().item())
+    again = ops.attn_bwd(q, k, v, out, lse, do, B, S, H, D, scale=sc)
+    for a, b_ in zip(got, again):
+        assert torch.equal(a.contiguous(), b_)
+    assert ops.attn_bwd(q, k, v, out, lse, do, B, S + 128, H, D) is None or S % 256 == 0        # shapes outside the kernel are refused
