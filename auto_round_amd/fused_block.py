@@ -766,24 +766,36 @@ class FusedOPTBlock(FusedLlamaBlock):
         del dx2
         attn, leaves = s.pop("attn"), s.pop("leaves")
         dattn4 = dattn.view(B, S, self.hq, self.hd).transpose(1, 2)
+        dqkv = torch.empty(T, 3 * H, dtype=self.dtype, device=dy2d.device)
+        at = {n: i * H for i, n in enumerate(self.order)}
+        grads = None
         if isinstance(leaves[0], str):
             _, q2d, k2d, v2d, out2d, lse = leaves
-            h4 = lambda t: t.view(B, S, self.hq, self.hd).transpose(1, 2)
-            z = torch.zeros((), dtype=torch.int64)
-            dq, dk, dv, _ = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
-                dattn4, h4(q2d), h4(k2d), h4(v2d), None, h4(out2d), lse, z, z, 0.0, (True, True, True, False), True, scale=self.scaling)
-        else:
-            dq, dk, dv = torch.autograd.grad(attn, leaves, dattn4)
-        del attn, leaves, dattn
-        dqkv = torch.empty(T, 3 * H, dtype=self.dtype, device=dy2d.device)
-        grads = dict(q=dq, k=dk, v=dv)
-        for i, n in enumerate(self.order):
-            dst = dqkv[:, i * H:(i + 1) * H].view(B, S, self.hq, self.hd)
-            if n == "q" and not self.fold_qscale:
-                torch.mul(grads[n].transpose(1, 2), self.qscale, out=dst)
+            done = None
+            if getattr(self, "flash_bwd", True):
+                # hand-written deterministic backward (csrc/ar_attn_bwd.hip: head size 64, S % 256 == 0): reads q / k / v where the
+                # merged projection left them and writes dq / dk / dv into their columns of dqkv -- no transposes, no copies
+                done = ops.attn_bwd(q2d, k2d, v2d, out2d, lse, dattn, B, S, self.hq, self.hd, scale=self.scaling,
+                                    dq=dqkv[:, at["q"]:at["q"] + H], dk=dqkv[:, at["k"]:at["k"] + H], dv=dqkv[:, at["v"]:at["v"] + H])
+            if done is not None:
+                if not self.fold_qscale:
+                    dqkv[:, at["q"]:at["q"] + H].mul_(self.qscale)
             else:
-                dst.copy_(grads[n].transpose(1, 2))
-        del dq, dk, dv, grads
+                h4 = lambda t: t.view(B, S, self.hq, self.hd).transpose(1, 2)
+                z = torch.zeros((), dtype=torch.int64)
+                grads = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
+                    dattn4, h4(q2d), h4(k2d), h4(v2d), None, h4(out2d), lse, z, z, 0.0, (True, True, True, False), True, scale=self.scaling)[:3]
+        else:
+            grads = torch.autograd.grad(attn, leaves, dattn4)
+        del attn, leaves
+        if grads is not None:
+            for n, g in zip("qkv", grads):
+                dst = dqkv[:, at[n]:at[n] + H].view(B, S, self.hq, self.hd)
+                if n == "q" and not self.fold_qscale:
+                    torch.mul(g.transpose(1, 2), self.qscale, out=dst)
+                else:
+                    dst.copy_(g.transpose(1, 2))
+        del grads, dattn
         self._dw(dqkv, s.pop("h1"), self.dWqkv, self.trio)
 
 

@@ -256,8 +256,11 @@ class SignRoundConfig:
     # order, so -- like fused_block -- opt-in.  The front door's enable_torch_compile=True switches both on.
     mfma_dw_gemm: bool = False
     # Inside the fused block: the causal attention forward on the hand-written flash-attention kernel (csrc/ar_attn.hip) instead of
-    # torch's SDPA (AOTriton); the backward stays the library's, fed with this kernel's output and log-sum-exp rows.
+    # torch's SDPA (AOTriton); at head size 128 the backward stays the library's, fed with this kernel's output and log-sum-exp rows.
     flash_attention: bool = True
+    # Head size 64 (OPT): the attention backward on the hand-written deterministic kernel (csrc/ar_attn_bwd.hip) instead of the
+    # library's; needs flash_attention (it consumes that forward's log-sum-exp rows).
+    flash_attention_bwd: bool = True
     # Inside the fused block: the input-gradient GEMMs dX = dY W of o / gate-up / down read a transposed copy of the fake-quant
     # weights (one csrc/ar_block.hip transpose per weight per iteration) -- both operands contiguous along the reduction is the
     # layout hipBLASLt's tuned gfx950 kernel covers (fused_block.FusedLlamaBlock.set_tn_dx).
@@ -412,6 +415,7 @@ class SignRoundQuantizer:
                                       tn_dx_gemm=cfg.tn_dx_gemm)
             if fused is not None:
                 fused.flash_fwd = bool(cfg.flash_attention)
+                fused.flash_bwd = bool(cfg.flash_attention_bwd)
                 # the fused kernels must compute what the block's own code computes: one small minibatch through both
                 # (once per kind of block: the verdict is remembered by class and by whether any submodule carries its own forward)
                 key = ("tune", self._block_signature(block))
@@ -727,6 +731,7 @@ class SignRoundQuantizer:
             fb = build_fused_block_plain(block, input_others, self.config.amp_dtype, sdpa_ctx=self._sdpa_ctx)
             if fb is not None:
                 fb.flash_fwd = bool(self.config.flash_attention)
+                fb.flash_bwd = bool(self.config.flash_attention_bwd)
                 key = ("plain", self._block_signature(block))
                 if key not in self._fused_verdict:
                     self._fused_verdict[key] = fb.agrees_with_module(lambda x, o: self.block_forward(block, x, o),

@@ -319,6 +319,7 @@ class Bench:
             kw["fused_block"] = fused_block
             kw["mfma_dw_gemm"] = fused_block
         kw["flash_attention"] = not getattr(args, "no_flash_attn", False)
+        kw["flash_attention_bwd"] = not getattr(args, "no_attn_bwd", False)
         kw["hip_graph"] = True if getattr(args, "hip_graph", False) else (False if getattr(args, "no_hip_graph", False) else None)
         self.qcfg = SignRoundConfig(iters=args.iters, batch_size=args.batch_size, bits=self.bits,
                                     fuse_next_forward=fuse_next_forward, sdpa_backend=args.sdpa, data_parallel=dp,
@@ -443,6 +444,7 @@ def main():
     ap.add_argument("--alg-ext", action="store_true",
                     help="tune with the algorithm extension (SignRoundV2: imatrix, searched init scales, outlier loss)")
     ap.add_argument("--no-flash-attn", action="store_true", help="fused block: keep torch's SDPA forward instead of csrc/ar_attn.hip")
+    ap.add_argument("--no-attn-bwd", action="store_true", help="fused block, head size 64: keep the library's attention backward instead of csrc/ar_attn_bwd.hip")
     ap.add_argument("--hip-graph", action="store_true",
                     help="replay each tuning iteration as one captured hipGraph even while per-dispatch kernel timing is on (the roofline "
                          "objects then only see iteration 0 of every block); without the flag: automatic for small blocks when timing is off")
@@ -563,6 +565,7 @@ def main():
             "config": {"workload": workload_desc, "scheme": args.scheme or "int", "bits": b.bits, "group_size": b.gs, "sym": b.sym,
                        "iters": args.iters, "nsamples": N, "seqlen": S, "batch_size": args.batch_size,
                        "weights_per_block": n_w, "groups_per_block": G, "includes_packing": True, "flash_attention": bool(b.qcfg.flash_attention and b.qcfg.fused_block),
+                       "flash_attention_bwd": bool(b.qcfg.flash_attention and b.qcfg.flash_attention_bwd and b.qcfg.fused_block and WORKLOADS[args.workload]["family"] == "opt" and WORKLOADS[args.workload]["hidden"] // WORKLOADS[args.workload]["heads"] == 64),
                        "tn_dx_gemm": bool(b.qcfg.tn_dx_gemm and b.qcfg.fused_block), "mfma_dw_gemm": bool(b.qcfg.mfma_dw_gemm),
                        "fuse_next_forward": bool(args.fuse_next_forward), "fused_block": bool(getattr(b.quantizer, "last_fused_block", False)),
                        "hip_graph": bool(getattr(b.quantizer, "last_hip_graph", False)),
