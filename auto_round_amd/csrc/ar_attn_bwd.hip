@@ -11,7 +11,8 @@
 //   LDS in tiles of 64 rows (LDS-DMA, double buffered, the forward's XOR swizzle), compute two score tiles
 //        sc0 = R0 * B0^T,  sc1 = R1 * B1^T          (a-operand: tile rows by ds_read_b128; accumulators: own row on the lane, 16
 //                                                     streamed rows in registers)
-//   turn them into P = exp2(sc0 * c - L2[query]) and E = P * (sc1 - D[query]) in registers, and feed those -- converted to bf16 in
+//   (their accumulators initialised to -lse / scale and -D of the query row, so the softmax shift and the "- D" of dS ride in the
+//   MFMA), turn them into P = exp2(sc0 * c) and E = P * sc1 in registers, and feed those -- converted to bf16 in
 //   place, exactly like P^T in the forward -- as b-operands of the accumulating products, whose a-operands are the SAME tiles read
 //   through the transposing LDS read (ds_read_b64_tr_b16):
 //     MODE 0 (dQ):      own rows = 256 queries;  R0 = K, R1 = V tiles up to the diagonal;  B0 = Q^T, B1 = dO^T;  L2 / D per lane;
@@ -21,7 +22,7 @@
 //                       dV^T += dO^T P,  dK^T += Q^T E     -> dK = scale * acc
 //   7 MFMA passes instead of the 5 an atomics-based backward needs -- the price of determinism; at head size 64 the library runs
 //   at 0.30 PFLOP/s, so the forward kernel's 0.59 PFLOP/s leaves room (at head size 128 the library's 0.71 does not: not built).
-//   k_attn_bwd_prep computes D = rowsum(dO * O) and L2 = lse * log2(e) once.
+//   k_attn_bwd_prep computes -D = -rowsum(dO * O) and -lse / scale once.
 // Outputs are written token-major with a caller-given row stride: dq / dk / dv can be column slices of ONE [tokens, 3 H D] buffer --
 // the gradient of a merged q/k/v projection -- without a gather pass.
 #include "ar_common.hpp"
@@ -44,7 +45,7 @@ __device__ __forceinline__ int battn_swz(int r) {      // the forward's LDS swiz
 
 struct AttnBwdArgs {
     const uint16_t* Q; const uint16_t* K; const uint16_t* V; const uint16_t* dO;     // token-major, row strides below
-    const float* L2; const float* Dv;                                               // [B, H, S] fp32: lse * log2(e), rowsum(dO * O)
+    const float* L2; const float* Dv;                                               // [B, H, S] fp32: -lse / scale, -rowsum(dO * O)
     uint16_t* dQ; uint16_t* dK; uint16_t* dV;
     int B, S, H;
     int64_t ldq, ldk, ldv, ldo;              // elements between consecutive tokens of Q, K, V, dO
@@ -52,10 +53,10 @@ struct AttnBwdArgs {
     float scale, scale_log2e;
 };
 
-// D[b, h, s] = sum_d dO * O (fp32), L2 = lse * log2(e).  One 8-lane group per (token, head) row of 64 values.
+// Dv[b, h, s] = -sum_d dO * O (fp32), L2 = -lse / scale.  One 8-lane group per (token, head) row of 64 values.
 __global__ __launch_bounds__(kTPB) void k_attn_bwd_prep(const uint16_t* __restrict__ dO, int64_t ldo, const uint16_t* __restrict__ O, int64_t ldO,
                                                          const float* __restrict__ lse, float* __restrict__ Dv, float* __restrict__ L2,
-                                                         int B, int S, int H, int AD) {
+                                                         int B, int S, int H, int AD, float inv_scale) {
     const int lpr = AD / 8;                                          // lanes per row
     const int64_t row = ((int64_t)blockIdx.x * kTPB + threadIdx.x) / lpr;
     const int part = threadIdx.x % lpr;
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(kTPB) void k_attn_bwd_prep(const uint16_t* __restri
         const int h = (int)(row % H);
         const int64_t b = tok / S, sq = tok % S;
         const int64_t o = (b * H + h) * S + sq;
-        Dv[o] = s;
-        L2[o] = lse[o] * 1.4426950408889634f;
+        Dv[o] = -s;                          // both rows negated: they are the INITIAL VALUES of the score accumulators (below)
+        L2[o] = -(lse[o] * inv_scale);
     }
 }
 
@@ -197,22 +198,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
         const bool diag = MODE == 0 ? (t0 + BK - 1 > o0 + 32 * wave) : (t0 < o0 + 32 * wave + 31);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {                                 // the two 32-row halves of the tile, one after the other
+            // The score accumulators START at -lse / scale and -D of their query row, so the products come out as
+            // (q.k - lse / scale) and (dO.v - D): the softmax shift and the "- D" of dS cost no VALU instruction (at head size 64
+            // the elementwise step, not the MFMA pipe, bounds this kernel: exp2 issues at quarter rate).
             bf32x16_t s0, s1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
             u32x4_t f0[NKS], f1[NKS];
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) { BW_RREAD(f0[ks], ks, t, 0); BW_RREAD(f1[ks], ks, t, 1); }
-            float vl[16], vd[16];
-            if (MODE == 1) {                                          // L2 / D of this half's 16 streamed rows held by the lane
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s0[r] = myL2; s1[r] = myD; }
+            } else {                                                  // L2 / D of this half's 16 streamed rows: LDS -> accumulator
                 const float* vL = reinterpret_cast<const float*>(lds + VEC_OFF);
                 const float* vD = vL + a.S;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 x = *reinterpret_cast<const float4*>(vL + t0 + 32 * t + 4 * h + 8 * j);
                     const float4 y = *reinterpret_cast<const float4*>(vD + t0 + 32 * t + 4 * h + 8 * j);
-                    vl[4 * j] = x.x; vl[4 * j + 1] = x.y; vl[4 * j + 2] = x.z; vl[4 * j + 3] = x.w;
-                    vd[4 * j] = y.x; vd[4 * j + 1] = y.y; vd[4 * j + 2] = y.z; vd[4 * j + 3] = y.w;
+                    s0[4 * j] = x.x; s0[4 * j + 1] = x.y; s0[4 * j + 2] = x.z; s0[4 * j + 3] = x.w;
+                    s1[4 * j] = y.x; s1[4 * j + 1] = y.y; s1[4 * j + 2] = y.z; s1[4 * j + 3] = y.w;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -233,17 +237,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
                     if (MODE == 1) BW_TREAD(q1lo[s2][dt], q1hi[s2][dt], dt, 2 * t + s2, 1);
                 }
             BW_PIN();
-            // ---- P = exp2(s0 * c - L2[query]) (0 where key > query), E = P * (s1 - D[query]); register r <-> streamed row
-            // 32 t + 4 h + (r & 3) + 8 (r >> 2)
+            // ---- P = exp2(s0 * c) (0 where key > query), E = P * s1; register r <-> streamed row 32 t + 4 h + (r & 3) + 8 (r >> 2)
+            if (diag) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int srow = t0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
-                const bool masked = diag && (MODE == 0 ? (srow > myrow) : (myrow > srow));
-                const float l2 = MODE == 0 ? myL2 : vl[r];
-                const float dd = MODE == 0 ? myD : vd[r];
-                const float p = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], a.scale_log2e, -l2));
-                s0[r] = p;
-                s1[r] = p * (s1[r] - dd);
+                for (int r = 0; r < 16; ++r) {
+                    const int srow = t0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
+                    const bool masked = MODE == 0 ? (srow > myrow) : (myrow > srow);
+                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s0[r] * a.scale_log2e);
+                    s0[r] = p;
+                    s1[r] = p * s1[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s0[r] * a.scale_log2e);
+                    s0[r] = p;
+                    s1[r] = p * s1[r];
+                }
             }
             BW_PIN();
             // ---- accumulate: k = this half's 32 streamed rows in two steps of 16 (the accumulator's row order is the k order)
@@ -349,7 +359,7 @@ extern "C" int ar_attn_bwd(const void* Q, const void* K, const void* V, const vo
     {
         const int64_t rows = B * S * H, lanes = rows * (D / 8);
         hipLaunchKernelGGL(k_attn_bwd_prep, (int)((lanes + kTPB - 1) / kTPB), kTPB, 0, st, (const uint16_t*)dO, lddo, (const uint16_t*)O, ldo_,
-                           LSE, Dv, L2, (int)B, (int)S, (int)H, (int)D);
+                           LSE, Dv, L2, (int)B, (int)S, (int)H, (int)D, 1.0f / scale);
     }
     AttnBwdArgs a;
     a.Q = (const uint16_t*)Q; a.K = (const uint16_t*)K; a.V = (const uint16_t*)V; a.dO = (const uint16_t*)dO;
