@@ -1098,3 +1098,44 @@ def test_attention_backward_vs_fp32_autograd_and_the_library(B, S, H, strided):
     for a, b_ in zip(got, again):
         assert torch.equal(a.contiguous(), b_)
     assert ops.attn_bwd(q, k, v, out, lse, do, B, S + 128, H, D) is None or S % 256 == 0        # shapes outside the kernel are refused
+
+
+def test_fused_opt_block_is_bit_reproducible_run_to_run_at_the_baseline_shape():
+    """BASELINE configs[0]'s shape (OPT-125M block, 128 x 2048 tokens, batch 8): with the first-party attention backward every kernel
+    under the fused path sums in a fixed order -- the library's head-size-64 backward (fp32 atomics) was the one that did not
+    (profiles/r03_opt125m_determinism.json) -- so the same block tuned twice from the same inputs and targets ends at the same bits:
+    loss trace, rounding offsets, packed weights."""
+    import copy
+
+    import transformers
+
+    from auto_round_amd.autoround import loss_mask_ids
+    from auto_round_amd.quantizer import BlockContext, SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.schemes import apply_scheme, resolve_scheme
+    from auto_round_amd.testing import t3_fixture as fx
+
+    dev = torch.device("cuda:0")
+    model = fx.build_model("opt125m").to(dev)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    tokens = fx.calib_tokens("opt125m", 128, 2048)
+    block = fx.decoder_blocks(model)[0]
+    sch = resolve_scheme("W4A16")
+    apply_scheme(block, sch)
+    x0, others = fx.capture_block_inputs(model, block, tokens, dev)
+    ids = loss_mask_ids(tokens, None)
+    y = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=8, bits=4, fused_block=False), device=dev).calibrate_block(block, x0, others)
+    runs = []
+    for _ in range(2):
+        blk = copy.deepcopy(block)
+        q = SignRoundQuantizer(SignRoundConfig(iters=40, batch_size=8, bits=4, fused_block=True, mfma_dw_gemm=True), device=dev)
+        transformers.set_seed(42)
+        q.quantize_block(blk, x0, others, y, None, BlockContext(0, 1, "0"), input_ids=ids)
+        torch.cuda.synchronize()
+        assert q.last_fused_block
+        runs.append((list(q.last_stats["loss_trace"]), fx.packed_layers(blk)))
+    (t0, p0), (t1, p1) = runs
+    assert t0 == t1, [i for i, (a, b_) in enumerate(zip(t0, t1)) if a != b_][:3]
+    for name in p0:
+        for k in p0[name]:
+            assert (p0[name][k] == p1[name][k]).all(), (name, k)
