@@ -283,9 +283,13 @@ class AutoRound:
         for n, m in self.model.named_modules():              # get_lm_head_name: the output projection stays out
             if n.split(".")[-1] == "lm_head" and n not in self.layer_config and n not in ignore:
                 ignore.append(n)
+        fmt = "nvfp4-pack-quantized" if nv else "mxfp4-pack-quantized"
+        live = _compressed_tensors_config("NVFP4" if nv else "MXFP4", ignore, fmt) if act else None
+        if live is not None:      # the package the reference itself asks: whatever fields its installed version emits
+            return live
         return {"config_groups": {"group_0": {"input_activations": quant_args("local" if nv else True) if act else None,
                                               "output_activations": None, "targets": ["Linear"], "weights": quant_args(False)}},
-                "format": "nvfp4-pack-quantized" if nv else "mxfp4-pack-quantized", "global_compression_ratio": None,
+                "format": fmt, "global_compression_ratio": None,
                 "ignore": ignore, "kv_cache_scheme": None, "quant_method": "compressed-tensors",
                 "quantization_status": "compressed", "provider": "auto-round"}
 
@@ -424,3 +428,25 @@ def _first_sample(v, bs):
     if isinstance(v, (tuple, list)):
         return type(v)(_first_sample(x, bs) for x in v)
     return v
+
+
+# The literal in `_llmc_quantization_config` restates what compressed-tensors 0.10.x emitted for its NVFP4 / MXFP4 presets (the
+# layout auto_round/export/export_to_llmcompressor/config.py:103-139 also hard-codes).  When the package is importable its own
+# answer wins, so fields later versions add (scale_dtype / zp_dtype, another observer for NVFP4 inputs) reach the checkpoint
+# exactly as they would from the reference (config.py:56-101 `initialize_quantization` + export_to_fp.py:362-378).
+LLMC_LITERAL_PINNED_TO = "compressed-tensors 0.10"
+
+
+def _compressed_tensors_config(preset: str, ignore, fmt: str):
+    """-> the dict the reference would dump for a preset scheme on every Linear, or None when compressed-tensors is absent."""
+    try:
+        from compressed_tensors.quantization import QuantizationConfig, QuantizationStatus, preset_name_to_scheme
+    except Exception:
+        return None
+    group = preset_name_to_scheme(preset, ["Linear"])
+    cfg = QuantizationConfig(config_groups={"group_0": group}, kv_cache_scheme=None, quantization_status=QuantizationStatus.COMPRESSED,
+                             ignore=list(ignore))
+    setattr(cfg, "format", fmt)
+    out = cfg.to_dict()
+    out["provider"] = "auto-round"
+    return out

@@ -151,6 +151,56 @@ def test_llm_compressor_config_known_answers():
         _shell(tiny_llama(seed=3, vocab=64), True, None)._llmc_quantization_config()          # INT schemes: not this exporter
 
 
+def test_llm_compressor_config_asks_compressed_tensors_when_it_is_importable(monkeypatch):
+    """the literal is the fallback; with compressed-tensors importable the preset scheme's own `to_dict()` is what gets
+    written (as in the reference, config.py:56-101).  The package is not installed here, so a stand-in with the three names the
+    reference imports proves the route and what is passed to it; with the real package the literal is diffed against it."""
+    import sys
+    import types
+
+    from test_gpu_autoround import tiny_llama
+
+    seen = {}
+
+    class _Cfg:
+        def __init__(self, **kw):
+            seen.update(kw)
+
+        def to_dict(self):
+            return {"config_groups": {"group_0": seen["config_groups"]["group_0"]}, "ignore": seen["ignore"], "format": self.format,
+                    "quantization_status": seen["quantization_status"], "extra_field_of_a_newer_version": 1}
+
+    fake = types.ModuleType("compressed_tensors.quantization")
+    fake.QuantizationConfig = _Cfg
+    fake.QuantizationStatus = SimpleNamespace(COMPRESSED="compressed")
+    fake.preset_name_to_scheme = lambda name, targets: {"preset": name, "targets": targets}
+    monkeypatch.setitem(sys.modules, "compressed_tensors", types.ModuleType("compressed_tensors"))
+    monkeypatch.setitem(sys.modules, "compressed_tensors.quantization", fake)
+    nv = _fp4_shell(tiny_llama(seed=3, vocab=64), "NVFP4")._llmc_quantization_config()
+    assert nv["config_groups"]["group_0"] == {"preset": "NVFP4", "targets": ["Linear"]} and nv["extra_field_of_a_newer_version"] == 1
+    assert nv["format"] == "nvfp4-pack-quantized" and nv["provider"] == "auto-round" and nv["ignore"] == ["lm_head"]
+    assert seen["kv_cache_scheme"] is None
+
+
+def test_llm_compressor_literal_matches_the_installed_compressed_tensors():
+    ct = pytest.importorskip("compressed_tensors.quantization")
+    from test_gpu_autoround import tiny_llama
+
+    from auto_round_amd import autoround as ara
+
+    for name in ("NVFP4", "MXFP4"):
+        shell = _fp4_shell(tiny_llama(seed=3, vocab=64), name)
+        live = shell._llmc_quantization_config()
+        saved, ara._compressed_tensors_config = ara._compressed_tensors_config, lambda *a: None
+        try:
+            literal = shell._llmc_quantization_config()
+        finally:
+            ara._compressed_tensors_config = saved
+        for side in ("weights", "input_activations"):
+            lit, liv = literal["config_groups"]["group_0"][side], live["config_groups"]["group_0"][side]
+            assert {k: liv.get(k) for k in lit} == lit, (name, side, ct.__name__, ara.LLMC_LITERAL_PINNED_TO)
+
+
 @needs_ref
 def test_llm_compressor_config_follows_the_reference_helpers_and_dict_layout():
     """compressed-tensors is absent, so the reference cannot build (or save) this config here; what it DOES hold without that
