@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
                     pp[e] = (short)(wp & 0xffffu); pp[e + 1] = (short)(wp >> 16);
                 }
                 if (t == 0) {
-                    if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TR + NEXT) : "memory");
+                    if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TR + NEXT > 15 ? 15 : TR + NEXT) : "memory");      // (4-bit counter)
                     else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NEXT) : "memory");
                 } else {
                     if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TR) : "memory");
