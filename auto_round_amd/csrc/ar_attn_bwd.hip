@@ -190,24 +190,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"                                  \
                  : "=&v"(LO), "=&v"(HI) : "v"(tAlo[DT]), "v"(tAhi[DT]), "n"(BUF * ABUF + (REG) * ATILE + (ST) * 16 * AROW) : "memory")
 
-    // one streamed tile from LDS buffer BUF (compile time); t0 = its first row.  The tile's two 32-row halves run one after the other;
-    // the row fragments of the second half are requested as soon as the first half's score products have been issued (their
-    // registers are free again), so that LDS transfer -- every wave reads the whole tile, 8 waves at once -- hides under the
-    // first half's elementwise and accumulate steps.
+    // one streamed tile from LDS buffer BUF (compile time); t0 = its first row
     auto tile = [&](auto bufc, int t0) {
         constexpr int BUF = decltype(bufc)::value;
         // MODE 0: streamed rows are keys, own row the query -> masked where key > query.  MODE 1: streamed rows are queries, own row
         // the key -> masked where key > query as well.
         const bool diag = MODE == 0 ? (t0 + BK - 1 > o0 + 32 * wave) : (t0 < o0 + 32 * wave + 31);
-        u32x4_t f0[NKS], f1[NKS];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) { BW_RREAD(f0[ks], ks, 0, 0); BW_RREAD(f1[ks], ks, 0, 1); }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t) {                                 // the two 32-row halves of the tile, one after the other
             // The score accumulators START at -lse / scale and -D of their query row, so the products come out as
             // (q.k - lse / scale) and (dO.v - D): the softmax shift and the "- D" of dS cost no VALU instruction (at head size 64
             // the elementwise step, not the MFMA pipe, bounds this kernel: exp2 issues at quarter rate).
             bf32x16_t s0, s1;
+            u32x4_t f0[NKS], f1[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) { BW_RREAD(f0[ks], ks, t, 0); BW_RREAD(f1[ks], ks, t, 1); }
             if (MODE == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s0[r] = myL2; s1[r] = myD; }
@@ -229,9 +226,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8_t, f0[ks]), bf0[ks], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8_t, f1[ks]), bf1[ks], s1, 0, 0, 0);
             }
-            BW_PIN();
-            // transposed fragments of this half: 2 sixteen-row steps x ND d-tiles x (R0 and, in MODE 1, R1), then the NEXT half's
-            // row fragments: all in flight under the elementwise step
+            // transposed fragments of this half: 2 sixteen-row steps x ND d-tiles x (R0 and, in MODE 1, R1): in flight under the
+            // elementwise step
             bs16x4_t q0lo[2][ND], q0hi[2][ND], q1lo[2][ND], q1hi[2][ND];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -240,10 +236,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
                     BW_TREAD(q0lo[s2][dt], q0hi[s2][dt], dt, 2 * t + s2, 0);
                     if (MODE == 1) BW_TREAD(q1lo[s2][dt], q1hi[s2][dt], dt, 2 * t + s2, 1);
                 }
-            if (t == 0) {
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) { BW_RREAD(f0[ks], ks, 1, 0); BW_RREAD(f1[ks], ks, 1, 1); }
-            }
             BW_PIN();
             // ---- P = exp2(s0 * c) (0 where key > query), E = P * s1; register r <-> streamed row 32 t + 4 h + (r & 3) + 8 (r >> 2)
             if (diag) {
@@ -265,8 +257,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
             }
             BW_PIN();
             // ---- accumulate: k = this half's 32 streamed rows in two steps of 16 (the accumulator's row order is the k order)
-            constexpr int TR = MODE == 1 ? 4 * ND : 2 * ND;          // transposed reads of one sixteen-row step
-            constexpr int NEXT = 2 * NKS;                             // the next half's row-fragment reads, issued behind them
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bs16x8_t pe, pp;
@@ -277,13 +267,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
                     const uint32_t wp = pack_bf16x2(s0[8 * s2 + e], s0[8 * s2 + e + 1]);
                     pp[e] = (short)(wp & 0xffffu); pp[e + 1] = (short)(wp >> 16);
                 }
-                if (t == 0) {
-                    if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TR + NEXT > 15 ? 15 : TR + NEXT) : "memory");      // (4-bit counter)
-                    else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NEXT) : "memory");
-                } else {
-                    if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TR) : "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
+                if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MODE == 1 ? 4 * ND : 2 * ND) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 BW_PIN();
 #pragma unroll
                 for (int dt = 0; dt < ND; ++dt) {
