@@ -920,6 +920,24 @@ class FusedMoEBlock(FusedLlamaBlock):
         return (self.Wo,)
 
     @staticmethod
+    def _mm_rows(a, w, out):
+        """out[M, N] = a[M, K] @ w[K, N] for ONE expert's rows.  The library GEMM works in rounds of 256 output tiles (256 x 256, one
+        per CU) and has no stream-K form for these shapes: an expert with a few rows more than a whole number of rounds pays a whole
+        extra round -- at N = 4096 (down-projection forward, gate/up input gradient) 4097..4608 rows cost 2.0-2.4x what 4096 do
+        (profiles/r03_moe_expert_gemm_vs_rows.jsonl).  Where the product is only a few rounds deep the rows are cut at the last
+        whole round and the remainder goes in a second, short call (measured: 720 -> 330 us and 1320 -> 830 us at 4100 rows)."""
+        M, N = a.shape[0], w.shape[1]
+        col_tiles = -(-N // 256)
+        if col_tiles <= 16:                                             # (wider outputs: many rounds, the tail is noise -- measured)
+            per_round = (256 // col_tiles) * 256                        # rows that fill the chip exactly once
+            whole = (M // per_round) * per_round
+            if 0 < whole < M and -(-M // 256) * col_tiles <= 6 * 256:
+                torch.mm(a[:whole], w, out=out[:whole])
+                torch.mm(a[whole:], w, out=out[whole:])
+                return out
+        return torch.mm(a, w, out=out)
+
+    @staticmethod
     def _rows_fq(t, plans, counts, raw, grad_of=None):
         """Activation fake-quant (raw = act_quant_fwd_raw) or its backward (raw = act_quant_bwd_raw, grad_of = the activation) of the
         sorted rows: one launch when every expert has the same plan, else one per expert's row segment."""
@@ -977,7 +995,7 @@ class FusedMoEBlock(FusedLlamaBlock):
         start = 0
         for e, cnt in enumerate(r["counts"]):
             if cnt:
-                torch.mm(xs_q[start:start + cnt], self.Wgu[e].t(), out=GU[start:start + cnt])
+                self._mm_rows(xs_q[start:start + cnt], self.Wgu[e].t(), GU[start:start + cnt])
             start += cnt
         act = ops.swiglu_fwd(GU, self.Fdim)
         act_q = self._rows_fq(act, self.pl_d_e, r["counts"], act_quant_fwd_raw)
@@ -985,7 +1003,7 @@ class FusedMoEBlock(FusedLlamaBlock):
         start = 0
         for e, cnt in enumerate(r["counts"]):
             if cnt:
-                torch.mm(act_q[start:start + cnt], self.Wd[e].t(), out=D[start:start + cnt])
+                self._mm_rows(act_q[start:start + cnt], self.Wd[e].t(), D[start:start + cnt])
             start += cnt
         y = ops.moe_combine(D, r["pos"], r["w_tk"], res=x2)
         if ctx is not None:
@@ -1016,7 +1034,7 @@ class FusedMoEBlock(FusedLlamaBlock):
             if cnt:
                 rows = slice(start, start + cnt)
                 self._dw(dD[rows], act_q[rows], self.dWd[e], [self.trip[e][2]])
-                torch.mm(dD[rows], self.Wd[e], out=dact_q[rows])
+                self._mm_rows(dD[rows], self.Wd[e], dact_q[rows])
             start += cnt
         del dD, act_q
         dact = self._rows_fq(dact_q, self.pl_d_e, counts, act_quant_bwd_raw, grad_of=s.pop("act"))
@@ -1029,7 +1047,7 @@ class FusedMoEBlock(FusedLlamaBlock):
             if cnt:
                 rows = slice(start, start + cnt)
                 self._dw(dGU[rows], xs_q[rows], self.dWgu[e], [self.trip[e][0], self.trip[e][1]])
-                torch.mm(dGU[rows], self.Wgu[e], out=dxs_q[rows])
+                self._mm_rows(dGU[rows], self.Wgu[e], dxs_q[rows])
             start += cnt
         del dGU, xs_q
         dxs = self._rows_fq(dxs_q, self.pl_gu_e, counts, act_quant_bwd_raw, grad_of=s.pop("xs"))
