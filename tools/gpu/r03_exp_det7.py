@@ -1,0 +1,59 @@
+"""Flake localisation under the REAL launch pattern (no synchronisation inside the loop): the fused OPT block runs the same minibatch
+through the same weights ITERS times (the sign-SGD step is replaced by a checksum of the weight-gradient arena, per layer-sized chunk),
+for several kernel substitutions.  Which chunks (and the loss) deviate from the first iteration, how often:
+  chunks 0-2 = q/k/v, 3 = o, 4-7 = fc1, 8-11 = fc2 weight gradients (backward runs fc2 -> fc1 -> o -> qkv)."""
+import copy, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import transformers
+from auto_round_amd import ops
+from auto_round_amd.autoround import loss_mask_ids
+from auto_round_amd.quantizer import BlockContext, SignRoundConfig, SignRoundQuantizer
+from auto_round_amd.schemes import apply_scheme, resolve_scheme
+from auto_round_amd.testing import t3_fixture as fx
+
+dev = torch.device("cuda:0")
+ITERS = int(os.environ.get("ITERS", "1200"))
+SUMS = []
+
+
+def fake_step(dWq, W, V, *a, **k):
+    v = dWq.view(torch.int16).view(12, -1).to(torch.int32)
+    SUMS.append(v.sum(1, dtype=torch.int64) + (v * 7 % 8191).sum(1, dtype=torch.int64))      # no update: the state stays frozen
+
+
+ops.qdq_int_bwd_sgd_ = fake_step
+model = fx.build_model("opt125m").to(dev)
+for p in model.parameters():
+    p.requires_grad_(False)
+tokens = fx.calib_tokens("opt125m", 128, 2048)
+block = fx.decoder_blocks(model)[0]
+apply_scheme(block, resolve_scheme("W4A16"))
+x0, others = fx.capture_block_inputs(model, block, tokens, dev)
+ids = loss_mask_ids(tokens, None)
+y = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=8, bits=4, fused_block=False), device=dev).calibrate_block(block, x0, others)
+sched = [list(range(8))] * ITERS
+res = {}
+for name, kw in dict(default={}, library_dw=dict(mfma_dw_gemm=False), library_attn_bwd=dict(flash_attention_bwd=False),
+                     torch_attention=dict(flash_attention=False), module_path=dict(fused_block=False, mfma_dw_gemm=False)).items():
+    SUMS.clear()
+    blk = copy.deepcopy(block)
+    cfg = dict(iters=ITERS, batch_size=8, bits=4, fused_block=True, mfma_dw_gemm=True, hip_graph=False, not_use_best_mse=True)
+    cfg.update(kw)
+    qz = SignRoundQuantizer(SignRoundConfig(**cfg), device=dev)
+    transformers.set_seed(42)
+    try:
+        qz.quantize_block(blk, x0, others, y, None, BlockContext(0, 1, "0"), input_ids=ids, index_schedule=sched)
+    except Exception as e:  # noqa: BLE001
+        print(name, "failed:", repr(e)[:300], flush=True)
+        continue
+    torch.cuda.synchronize()
+    S = torch.stack(SUMS)                                  # [iterations, 12]
+    bad = (S != S[0]).cpu()
+    loss = torch.tensor([float(v) for v in qz.last_stats["loss_trace"]])
+    lbad = loss != loss[0]
+    rows = [(int(i), [int(c) for c in torch.nonzero(bad[i]).flatten()]) for i in torch.nonzero(bad.any(1)).flatten()[:12]]
+    res[name] = dict(iterations=int(S.shape[0]), flaky_iterations=int(bad.any(1).sum()), flaky_loss_values=int(lbad.sum()),
+                     per_chunk=[int(v) for v in bad.sum(0)], first=rows, fused=bool(qz.last_fused_block))
+    print(name, json.dumps(res[name]), flush=True)
+json.dump(res, open(os.path.join(os.environ.get("OUT", "."), "det_flake_localisation.json"), "w"), indent=1)
