@@ -1101,10 +1101,12 @@ def test_attention_backward_vs_fp32_autograd_and_the_library(B, S, H, strided):
 
 
 def test_fused_opt_block_is_bit_reproducible_run_to_run_at_the_baseline_shape():
-    """BASELINE configs[0]'s shape (OPT-125M block, 128 x 2048 tokens, batch 8): with the first-party attention backward every kernel
-    under the fused path sums in a fixed order -- the library's head-size-64 backward (fp32 atomics) was the one that did not
-    (profiles/r03_opt125m_determinism.json) -- so the same block tuned twice from the same inputs and targets ends at the same bits:
-    loss trace, rounding offsets, packed weights."""
+    """BASELINE configs[0]'s shape (OPT-125M block, 128 x 2048 tokens, batch 8) the way bench.py runs it -- no attention_mask among the
+    block's inputs, i.e. the causal first-party attention kernels: every kernel under the fused path sums in a fixed order, so the
+    same block tuned twice from the same inputs and targets ends at the same bits: loss trace, rounding offsets, packed weights.
+    (With an additive attention_mask -- the reference's calibration flow hands one over -- the attention runs through the library's
+    SDPA, whose forward at this shape returns different low bits in ~0.8 % of asynchronous calls and whose backward uses float
+    atomics: profiles/r03_opt125m_determinism.json; that is also why the reference does not reproduce itself at this shape.)"""
     import copy
 
     import transformers
@@ -1123,10 +1125,11 @@ def test_fused_opt_block_is_bit_reproducible_run_to_run_at_the_baseline_shape():
     sch = resolve_scheme("W4A16")
     apply_scheme(block, sch)
     x0, others = fx.capture_block_inputs(model, block, tokens, dev)
+    others = {k: v for k, v in others.items() if k != "attention_mask"}
     ids = loss_mask_ids(tokens, None)
     y = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=8, bits=4, fused_block=False), device=dev).calibrate_block(block, x0, others)
     runs = []
-    for _ in range(2):
+    for _ in range(3):
         blk = copy.deepcopy(block)
         q = SignRoundQuantizer(SignRoundConfig(iters=40, batch_size=8, bits=4, fused_block=True, mfma_dw_gemm=True), device=dev)
         transformers.set_seed(42)
@@ -1134,8 +1137,9 @@ def test_fused_opt_block_is_bit_reproducible_run_to_run_at_the_baseline_shape():
         torch.cuda.synchronize()
         assert q.last_fused_block
         runs.append((list(q.last_stats["loss_trace"]), fx.packed_layers(blk)))
-    (t0, p0), (t1, p1) = runs
-    assert t0 == t1, [i for i, (a, b_) in enumerate(zip(t0, t1)) if a != b_][:3]
-    for name in p0:
-        for k in p0[name]:
-            assert (p0[name][k] == p1[name][k]).all(), (name, k)
+    t0, p0 = runs[0]
+    for t1, p1 in runs[1:]:
+        assert t0 == t1, [i for i, (a, b_) in enumerate(zip(t0, t1)) if a != b_][:3]
+        for name in p0:
+            for k in p0[name]:
+                assert (p0[name][k] == p1[name][k]).all(), (name, k)

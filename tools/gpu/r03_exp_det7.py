@@ -31,6 +31,8 @@ block = fx.decoder_blocks(model)[0]
 apply_scheme(block, resolve_scheme("W4A16"))
 x0, others = fx.capture_block_inputs(model, block, tokens, dev)
 ids = loss_mask_ids(tokens, None)
+if os.environ.get("NO_MASK"):       # bench.py's situation: no attention_mask among the block's inputs -> the causal first-party kernels
+    others = {k: v for k, v in others.items() if k != "attention_mask"}
 y = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=8, bits=4, fused_block=False), device=dev).calibrate_block(block, x0, others)
 sched = [list(range(8))] * ITERS
 res = {}
@@ -56,4 +58,4 @@ for name, kw in dict(default={}, library_dw=dict(mfma_dw_gemm=False), library_at
     res[name] = dict(iterations=int(S.shape[0]), flaky_iterations=int(bad.any(1).sum()), flaky_loss_values=int(lbad.sum()),
                      per_chunk=[int(v) for v in bad.sum(0)], first=rows, fused=bool(qz.last_fused_block))
     print(name, json.dumps(res[name]), flush=True)
-json.dump(res, open(os.path.join(os.environ.get("OUT", "."), "det_flake_localisation.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(os.environ.get("OUT", "."), "det_flake_localisation_no_mask.json" if os.environ.get("NO_MASK") else "det_flake_localisation.json"), "w"), indent=1)
