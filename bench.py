@@ -570,6 +570,8 @@ def main():
                        "fuse_next_forward": bool(args.fuse_next_forward), "fused_block": bool(getattr(b.quantizer, "last_fused_block", False)),
                        "hip_graph": bool(getattr(b.quantizer, "last_hip_graph", False)),
                        "sdpa_backend": args.sdpa, "alg_ext": bool(args.alg_ext),
+                       "attention_mask": "none: causal attention (what the decoder layer does with attention_mask=None); an explicit "
+                                         "additive mask would send the fused block's attention through torch SDPA instead of csrc/ar_attn*.hip",
                        "parallelism": (f"data-parallel inside the block x{world}" if dp else
                                        (f"block-sharded x{world}: tune_sharded over {world * args.steps} blocks on the fp chain "
                                         f"(broadcast, pipelined relay, gather)" if sharded else "single GPU, quantised-input chaining"))},
