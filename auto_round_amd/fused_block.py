@@ -472,21 +472,29 @@ class FusedLlamaBlock:
         del dx2
         attn, leaves = s.pop("attn"), s.pop("leaves")
         dattn4 = dattn.view(B, S, self.hq, self.hd).transpose(1, 2)
-        if isinstance(leaves[0], str):      # forward was ar_attn_fwd: (tag, q2d, k2d, v2d, out2d, lse)
-            _, q2d, k2d, v2d, out2d, lse = leaves
-            h4 = lambda t: t.view(B, S, self.hq, self.hd).transpose(1, 2)
-            z = torch.zeros((), dtype=torch.int64)
-            dq, dk, dv, _ = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
-                dattn4, h4(q2d), h4(k2d), h4(v2d), None, h4(out2d), lse, z, z, 0.0, (True, True, True, False), True, scale=self.scaling)
-        else:
-            dq, dk, dv = torch.autograd.grad(attn, leaves, dattn4)
-        del attn, leaves, dattn
-
         def tok(t):
             return t.transpose(1, 2).contiguous().view(T, self.hq * self.hd)
 
-        dqkv = ops.rope_bwd(tok(dq), tok(dk), tok(dv), s["cos"], s["sin"], B, S, self.hq, self.hkv, self.hd)
-        del dq, dk, dv
+        done = None
+        if isinstance(leaves[0], str):      # forward was ar_attn_fwd: (tag, q2d, k2d, v2d, out2d, lse)
+            _, q2d, k2d, v2d, out2d, lse = leaves
+            if getattr(self, "flash_bwd", True):
+                # head size 64 (Llama-3.2-1B, Qwen2-0.5B ...): the first-party deterministic backward, token-major like rope_bwd wants
+                done = ops.attn_bwd(q2d, k2d, v2d, out2d, lse, dattn, B, S, self.hq, self.hd, scale=self.scaling)
+            if done is None:
+                h4 = lambda t: t.view(B, S, self.hq, self.hd).transpose(1, 2)
+                z = torch.zeros((), dtype=torch.int64)
+                dq, dk, dv, _ = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
+                    dattn4, h4(q2d), h4(k2d), h4(v2d), None, h4(out2d), lse, z, z, 0.0, (True, True, True, False), True, scale=self.scaling)
+        else:
+            dq, dk, dv = torch.autograd.grad(attn, leaves, dattn4)
+        del attn, leaves
+        if done is None:
+            done = (tok(dq), tok(dk), tok(dv))
+            del dq, dk, dv
+        del dattn
+        dqkv = ops.rope_bwd(done[0], done[1], done[2], s["cos"], s["sin"], B, S, self.hq, self.hkv, self.hd)
+        del done
         if self.qk_norm is not None:
             wq, wk, _ = self.qk_norm
             ops.headnorm_bwd_(dqkv, s.pop("qkv_raw"), wq.to(self.dtype), wk.to(self.dtype), s.pop("rstd_qk"), self.hq, self.hkv, self.hd)

@@ -156,13 +156,20 @@ def _data(rope, cfg, N=8, S=32, seed=1):
     return X, {"position_embeddings": (cos, sin), "attention_mask": None, "position_ids": pos}
 
 
-def test_fused_block_forward_and_weight_gradients_match_the_module_path():
+@pytest.mark.parametrize("S", [64, 256])
+def test_fused_block_forward_and_weight_gradients_match_the_module_path(S, monkeypatch):
+    """S = 64: torch SDPA inside the fused block; S = 256 at head size 64 (Llama-3.2-1B / Qwen2-0.5B geometry): the first-party
+    attention forward AND backward (csrc/ar_attn.hip, ar_attn_bwd.hip) on GQA heads repeated by the RoPE kernel."""
+    from auto_round_amd import ops
     from auto_round_amd.fused_block import FusedLlamaBlock
     from auto_round_amd.quantizer import block_forward
     from auto_round_amd.wrapper import unwrapper_block, wrapper_block
 
+    calls = []
+    real_bwd = ops.attn_bwd
+    monkeypatch.setattr(ops, "attn_bwd", lambda *a, **k: (calls.append(1), real_bwd(*a, **k))[1])
     layer, rope, cfg = _llama_layer()
-    X, others = _data(rope, cfg, N=4, S=64)
+    X, others = _data(rope, cfg, N=4, S=S)
     blk = copy.deepcopy(layer)
     wrapper_block(blk, True, False, device="cuda")
     arenas = blk._ar_arenas
@@ -187,6 +194,7 @@ def test_fused_block_forward_and_weight_gradients_match_the_module_path():
     assert (dW_f.float() - dW_m.float()).abs().mean().item() < 2e-2 * gs
     cosine = torch.nn.functional.cosine_similarity(dW_f.float(), dW_m.float(), dim=0).item()
     assert cosine > 0.999, cosine
+    assert bool(calls) == (S == 256)
     unwrapper_block(blk, {})
 
 
