@@ -86,3 +86,41 @@ def test_nothing_is_built_for_cpu_or_unwrapped_blocks():
                                         (4000, 4096, 16384, False), (4096, 1000, 16384, False)])
 def test_the_mfma_weight_gradient_gemm_is_used_where_its_tiles_fit(M, N, K, want):
     assert mfma_dw_pays(M, N, K) is want
+
+
+@pytest.mark.parametrize("M,N,want", [(4163, 4096, [4096, 67]), (4096, 4096, [4096]), (4000, 4096, [4000]), (8300, 4096, [8192, 108]),
+                                      (4163, 14336, [4163]), (4163, 28672, [4163]), (300, 4096, [300]), (40000, 4096, [40000]),
+                                      (9000, 2048, [8192, 808])])
+def test_expert_gemm_calls_are_cut_at_whole_rounds_of_output_tiles(M, N, want, monkeypatch):
+    """FusedMoEBlock._mm_rows (host logic; the measurement behind it: profiles/r03_moe_expert_gemm_vs_rows.jsonl): an expert whose row
+    count is a little over a whole number of 256-CU rounds of 256 x 256 output tiles goes in two calls where the output is narrow
+    (<= 16 column tiles) and only a few rounds deep; everything else is one call.  The result is the same product either way."""
+    from auto_round_amd.fused_block import FusedMoEBlock
+
+    calls = []
+    real = torch.mm
+
+    def spy(a, w, out=None):
+        calls.append(a.shape[0])
+        return real(a, w, out=out)
+
+    monkeypatch.setattr(torch, "mm", spy)
+    a = torch.randn(M, 8)
+    w = torch.randn(8, N)
+    out = torch.empty(M, N)
+    FusedMoEBlock._mm_rows(a, w, out)
+    assert calls == want
+    monkeypatch.undo()
+    assert torch.equal(out, a @ w)
+
+
+def test_attention_backward_refuses_shapes_outside_the_kernel_before_touching_the_library():
+    from auto_round_amd import ops
+
+    t = torch.zeros(256, 128, dtype=torch.bfloat16)
+    lse = torch.zeros(1, 1, 256)
+    assert ops.attn_bwd(t, t, t, t, lse, t, 1, 256, 1, 128) is None                      # head size 128
+    assert ops.attn_bwd(t, t, t, t, lse, t, 1, 128, 2, 64) is None                       # sequence not a multiple of 256
+    assert ops.attn_bwd(t.float(), t, t, t, lse, t, 1, 256, 2, 64) is None               # not bf16
+    with pytest.raises(Exception):                                                        # right shape, CPU tensors: loud, no fallback
+        ops.attn_bwd(t, t, t, t, lse, t, 1, 256, 2, 64)
