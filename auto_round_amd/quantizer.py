@@ -272,7 +272,11 @@ class SignRoundConfig:
     # (_graph_eligible); True = whenever the loop qualifies; False = never.  Same kernels in the same order as the host-driven
     # loop: results are bit-identical.
     hip_graph: Optional[bool] = None
-    hip_graph_max_weights: int = 64 * 1024 * 1024
+    # Measured on the MI355X box (profiles/r03_bench_default.json `opt125m`): at OPT-125M's block size (7.1 M weights, ~60 launches
+    # of ~25 us each per iteration) a deep host queue already keeps the GPU fed and the replayed graph is the SLOWER form (1.59 vs
+    # 1.49 ms per iteration: ~2 us between graph nodes against ~1.5 from the queue); the graph pays where kernels are shorter than
+    # the host's launch cost, i.e. for smaller blocks.  Hence the automatic mode stops at 4 M weights; `hip_graph=True` forces it.
+    hip_graph_max_weights: int = 4 * 1024 * 1024
     # Module path only: hand the block its shared keyword tensors (one attention mask for every sample, ...) materialised at the
     # minibatch's own row count -- what the reference's per-sample input cache produces by concatenation (block_runner.py:368-422)
     # -- instead of one broadcastable row.  Same values; SDPA may pick another kernel for a batch-broadcast mask, and with it other

@@ -706,14 +706,21 @@ def run_opt125m(args, device, barrier, fused, with_cpu):
     v.fill_inputs()
     random.seed(42)
     steps, warm = 4, 1
-    elapsed, stats = v.timed(steps, warm, barrier, profile=False)
+    elapsed, stats = v.timed(steps, warm, barrier, profile=False)          # the product's automatic choice (host-driven at this size)
     graphed = bool(getattr(v.quantizer, "last_hip_graph", False))
     rec = {"workload": WORKLOADS["opt-125m"]["desc"], "value": steps / elapsed, "unit": "blocks/s", "steps": steps, "warmup": warm,
            "ms_per_step": 1000.0 * elapsed / steps, "ms_per_iter": 1000.0 * elapsed / steps / 200, "weights_per_block": v.n_w,
            "fused_block": bool(getattr(v.quantizer, "last_fused_block", False)), "hip_graph": graphed,
            "loss": {"init": stats["init_loss"], "best": stats["best_loss"], "best_iter": stats["best_iter"]}}
-    # K1 / K2 durations: the timed blocks replay ONE captured hipGraph per iteration, whose dispatches carry no start/stop events, so
-    # the live figures come from one more block of the same workload driven by the host (same kernels, same launch shapes)
+    # the other launch form of the same loop, for comparison: one captured hipGraph per iteration (or, if the automatic choice was the
+    # graph, the host-driven loop)
+    keep = v.qcfg.hip_graph
+    v.qcfg.hip_graph = not graphed
+    e3, _ = v.timed(2, 1, barrier, profile=False)
+    v.qcfg.hip_graph = keep
+    rec["other_launch_form"] = {"hip_graph": bool(getattr(v.quantizer, "last_hip_graph", False)), "steps": 2, "warmup": 1,
+                                "value": 2 / e3, "ms_per_step": 1000.0 * e3 / 2, "ms_per_iter": 1000.0 * e3 / 2 / 200}
+    # K1 / K2 durations: one more host-driven block with start/stop events on every dispatch (captured graphs carry none)
     e2, _ = v.timed(1, 0, barrier, profile=True)
     rec["host_driven_block"] = {"ms_per_step": 1000.0 * e2, "ms_per_iter": 1000.0 * e2 / 200, "hip_graph": False,
                                 "what": "the extra block the roofline objects below were timed on (per-dispatch events cost ~1 us per launch)"}
