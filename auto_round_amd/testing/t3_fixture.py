@@ -31,6 +31,9 @@ ARCHS = {
     "opt125m": dict(family="opt", hidden=768, ffn=3072, heads=12, vocab=50272),
     # BASELINE configs[1]: Llama-3-8B's decoder block (small vocabulary: embeddings are not on the path)
     "llama8b": dict(family="llama", hidden=4096, ffn=14336, heads=32, kv=8, vocab=4096),
+    # BASELINE configs[4]: Mixtral-8x7B's sparse-MoE decoder block (8 experts, top-2)
+    "mixtral8x7b": dict(family="moe", hidden=4096, ffn=14336, heads=32, kv=8, experts=8, top_k=2, vocab=4096),
+    "mixtral_tiny": dict(family="moe", hidden=128, ffn=256, heads=4, kv=2, experts=4, top_k=2, vocab=256),      # (dry runs of the tooling)
 }
 
 
@@ -45,6 +48,15 @@ def build_model(arch: str):
                         vocab_size=a["vocab"], max_position_embeddings=2048, word_embed_proj_dim=a["hidden"])
         cfg._attn_implementation = "sdpa"
         return OPTForCausalLM(cfg).to(torch.bfloat16).eval()
+    if a["family"] == "moe":
+        from transformers import MixtralConfig, MixtralForCausalLM
+
+        cfg = MixtralConfig(hidden_size=a["hidden"], intermediate_size=a["ffn"], num_attention_heads=a["heads"],
+                            num_key_value_heads=a["kv"], num_hidden_layers=1, vocab_size=a["vocab"], rope_theta=1e6,
+                            num_local_experts=a["experts"], num_experts_per_tok=a["top_k"], max_position_embeddings=8192,
+                            sliding_window=None, router_jitter_noise=0.0, tie_word_embeddings=False)
+        cfg._attn_implementation = "sdpa"
+        return MixtralForCausalLM(cfg).to(torch.bfloat16).eval()
     from transformers import LlamaConfig, LlamaForCausalLM
 
     cfg = LlamaConfig(hidden_size=a["hidden"], intermediate_size=a["ffn"], num_attention_heads=a["heads"],

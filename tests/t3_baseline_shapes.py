@@ -42,6 +42,10 @@ BIG_CASES = {
     # iterations (a flipped power-of-two scale moves a whole group), the per-iteration gradient probe is the point here
     "llama8b_mxfp4": dict(arch="llama8b", scheme="MXFP4", kw={}, iters=30, nsamples=32, seqlen=2048, batch_size=8),
     "llama8b_nvfp4": dict(arch="llama8b", scheme="NVFP4", kw={}, iters=30, nsamples=32, seqlen=2048, batch_size=8),
+    # BASELINE configs[4] itself: the Mixtral-8x7B sparse-MoE block (8 experts, top-2; a randomly initialised router keeps all of them
+    # busy), MXFP4 weights and activations -- the reference unfuses the experts into its "linear_loop" form, the plugin into its own
+    "mixtral8x7b_mxfp4": dict(arch="mixtral8x7b", scheme="MXFP4", kw={}, iters=20, nsamples=16, seqlen=2048, batch_size=8),
+    "mixtral_tiny_mxfp4": dict(arch="mixtral_tiny", scheme="MXFP4", kw={}, iters=4, nsamples=4, seqlen=64, batch_size=2),
     # (c) BASELINE configs[2] scheme at real width
     "llama8b_w2g32_asym_algext": dict(arch="llama8b", scheme="W2A16G32", kw=dict(sym=False, enable_alg_ext=True), iters=50,
                                       nsamples=32, seqlen=2048, batch_size=8),
