@@ -124,3 +124,27 @@ def test_attention_backward_refuses_shapes_outside_the_kernel_before_touching_th
     assert ops.attn_bwd(t.float(), t, t, t, lse, t, 1, 256, 2, 64) is None               # not bf16
     with pytest.raises(Exception):                                                        # right shape, CPU tensors: loud, no fallback
         ops.attn_bwd(t, t, t, t, lse, t, 1, 256, 2, 64)
+
+
+def test_the_captured_graph_form_is_chosen_only_where_the_loop_needs_nothing_from_the_host():
+    """SignRoundQuantizer._graph_eligible (host logic): automatic mode = small fused blocks only (measured: at OPT-125M's 7.1 M weights
+    the host-driven loop is the faster form); `hip_graph=True` lifts the size limit, never the structural conditions."""
+    from types import SimpleNamespace as NS
+
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+
+    elig = SignRoundQuantizer._graph_eligible
+    fused, small, opt, big = NS(capturable=True), [NS(n=1 << 20, shared=False)], [NS(n=7077888, shared=False)], [NS(n=218103808, shared=False)]
+    base = dict(early_stop=False, dp_size=1, accum=False, per_sample_others=False, valid_counts=[2047] * 4, sched_dev=object(), track_best=True)
+    auto, forced, off = SignRoundConfig(iters=200), SignRoundConfig(iters=200, hip_graph=True), SignRoundConfig(iters=200, hip_graph=False)
+    assert elig(auto, fused, small, **base) and not elig(auto, fused, opt, **base) and not elig(auto, fused, big, **base)
+    assert elig(forced, fused, opt, **base) and elig(forced, fused, big, **base)
+    assert not elig(off, fused, small, **base)
+    assert not elig(forced, None, small, **base)                                        # module path: autograd runs the block
+    assert not elig(forced, NS(capturable=False), small, **base)                        # sparse MoE: expert counts are read on the host
+    for k, v in dict(early_stop=True, dp_size=2, accum=True, per_sample_others=True, sched_dev=None, track_best=False,
+                     valid_counts=[2047, 2040]).items():
+        assert not elig(forced, fused, small, **{**base, k: v}), k
+    assert not elig(SignRoundConfig(iters=200, hip_graph=True, momentum=0.9), fused, small, **base)
+    assert not elig(forced, fused, [NS(n=1 << 20, shared=True)], **base)
+    assert not elig(SignRoundConfig(iters=2, hip_graph=True), fused, small, **base)
