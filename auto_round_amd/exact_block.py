@@ -1,0 +1,424 @@
+"""`exact_rounding`: a Llama-family decoder block through first-party kernels WITH THE BITS OF THE MODULE PATH.
+
+The fused block path (fused_block.py) computes the same function as the module code with other bf16 rounding points -- the same
+relation the reference's `torch.compile(block_forward)` has to its eager default (auto_round/utils/device.py:112-122) -- and so
+leaves the reference's sign-SGD trajectory after a few iterations.  The north-star asks for the reference's integers bit for bit, and
+the reference's default is the EAGER module code (auto_round/compressors/utils.py:109-172 `block_forward` around
+transformers/models/llama/modeling_llama.py).  This file runs that block with
+
+  * the elementwise / normalisation work on csrc/ar_exact.hip -- every eager op's rounding kept, row sums in the association of
+    ATen's reduction kernel -- instead of ~90 eager launches per iteration;
+  * the GEMMs in the module path's own shapes (q / k / v and gate / up separately, the residual adds as their own roundings), plus
+    whichever faster forms PROVE bit-equal on this GPU and software stack: merged q/k/v and gate/up GEMMs, the hand-written MFMA
+    weight-gradient GEMM (csrc/ar_gemm.hip, unsplit K), input-gradient GEMMs through a transposed weight copy;
+  * the attention through transformers' own `sdpa_attention_forward` (the library kernels the module path calls, same operand
+    layouts), in a local autograd graph.
+
+Nothing is assumed: `ExactLlamaBlock.plan_against_module` runs ONE real minibatch forward + backward through the module code and
+through this class on the same frozen state and compares the block output and every weight gradient bit for bit -- first with every
+segment on torch's own ops (exact by construction), then switching one kernel / GEMM form on at a time and keeping it only if nothing
+changes.  A segment whose kernel does not reproduce torch on the installed stack (another libm, another hipBLASLt) silently stays on
+torch's ops; if even the all-torch form differs the caller keeps the module path.  The plan is what bench.py prints as `exact_plan`.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .fused_block import LLAMA_FAMILY, FusedLlamaBlock, _FusedBlockFn, _class_in
+
+# segments that have a first-party kernel form (False = torch's own ops in a local autograd graph)
+KERNEL_OPTS = ("norm1", "norm2", "rope", "swiglu")
+# GEMM forms that may be faster than the module path's and may or may not be bit-equal to it: input-gradient GEMMs through a
+# transposed weight copy (tn_*), weight-gradient GEMMs on the MFMA kernel -- merged over q/k/v and gate/up (one launch, the
+# elementwise backward kernels write straight into the merged gradient buffer) or per layer -- and merged forward GEMMs
+GEMM_OPTS = ("tn_o", "tn_g", "tn_u", "tn_d", "dw_qkv", "dw_gu", "dw_q", "dw_k", "dw_v", "dw_o", "dw_g", "dw_u", "dw_d", "merged_qkv", "merged_gu")
+# measured at Llama-3-8B's minibatch (profiles/r04_exact_probe.json): the merged forward GEMMs are bit-equal but not faster than
+# the separate ones (0.64 vs 0.62 ms, 2.57 vs 2.46 ms), so the plan does not ask for them unless told to
+DEFAULT_SKIP = ("merged_qkv", "merged_gu")
+FLAG_OPTS = ("swiglu_contract", "norm_rsqrt_f32")
+
+
+def _bits_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    it = {2: torch.int16, 4: torch.int32}[a.element_size()]
+    return bool(torch.equal(a.contiguous().view(it), b.contiguous().view(it)))
+
+
+class ExactLlamaBlock(FusedLlamaBlock):
+    capturable = False          # the attention runs in a local autograd graph: the iteration is host-driven
+    exact = True
+
+    @classmethod
+    def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, amp=True, **_) -> Optional["ExactLlamaBlock"]:
+        if not _class_in(block, LLAMA_FAMILY):
+            return None
+        self = super().try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=False, tn_dx_gemm=False)
+        if self is None or self.qk_norm is not None:
+            return None
+        attn = self.attn
+        if getattr(getattr(attn, "config", None), "_attn_implementation", None) != "sdpa":
+            return None
+        if self.w1.dtype != self.dtype or self.w2.dtype != self.dtype:
+            return None
+        pe = (input_others or {}).get("position_embeddings")
+        if any(t.dtype != self.dtype for t in pe):      # q * cos would promote: another rounding chain
+            return None
+        self.amp = bool(amp)
+        self.plan: Dict[str, bool] = self.base_plan()
+        self._tnx: Dict[str, torch.Tensor] = {}
+        self.plan_report: Optional[dict] = None
+        return self
+
+    # -- plumbing ---------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def base_plan() -> Dict[str, bool]:
+        """every segment on torch's own ops, every GEMM as the module path issues it"""
+        plan = {k: False for k in KERNEL_OPTS + GEMM_OPTS}
+        plan.update(swiglu_contract=True, norm_rsqrt_f32=False)
+        return plan
+
+    def set_plan(self, plan: Dict[str, bool]):
+        self.plan = {**self.base_plan(), **plan}
+        self._tnx = {}
+        for key in ("o", "g", "u", "d"):
+            if self.plan.get("tn_" + key):
+                w = self.layers[key].weight_q
+                if w.shape[0] % 64 or w.shape[1] % 64 or not w.is_contiguous():
+                    self.plan["tn_" + key] = False
+                    continue
+                self._tnx[key] = torch.empty((w.shape[1], w.shape[0]), dtype=w.dtype, device=w.device)
+
+    def _refresh_tn(self):
+        for key, wt in self._tnx.items():
+            ops.transpose16(self.layers[key].weight_q, out=wt)
+
+    def _ctx(self, S):
+        """what the module path runs under: the quantizer's SDPA backend choice and (with amp) autocast"""
+        st = contextlib.ExitStack()
+        if self.sdpa_ctx is not None:
+            st.enter_context(self.sdpa_ctx(S))
+        if self.amp:
+            st.enter_context(torch.autocast(device_type=self.w1.device.type, dtype=self.dtype))
+        return st
+
+    def _bias(self, key):
+        b = self.layers[key].orig_layer.bias
+        return None if b is None else b.to(self.dtype)
+
+    def _dw_x(self, key, dY2d, X2d):
+        """dW of layer `key` (or of the merged "qkv" / "gu" slices) into the arena: the library GEMM exactly as _QLinearFn.backward
+        issues it, or the MFMA kernel with the whole K in one pass where the plan found it bit-equal"""
+        if key in ("qkv", "gu"):
+            lyrs = [self.layers[n] for n in ("q", "k", "v")] if key == "qkv" else [self.layers["g"], self.layers["u"]]
+            out2d = self.dWqkv if key == "qkv" else self.dWgu
+        else:
+            lyrs = [self.layers[key]]
+            out2d = lyrs[0].weight_grad
+        acc = lyrs[0]._dw_accum[0]
+        done = False
+        if self.plan.get("dw_" + key) and out2d.is_contiguous():
+            done = ops.gemm_dw(dY2d, X2d, out2d, accumulate=acc, split=False)
+        if not done:
+            if acc:
+                out2d.addmm_(dY2d.t(), X2d)
+            else:
+                torch.mm(dY2d.t(), X2d, out=out2d)
+        for lyr in lyrs:
+            lyr._dw_accum[0] = True
+            post = getattr(lyr, "_post_dw", None)
+            if post is not None:
+                post()
+
+    def _dx_x(self, key, dY2d):
+        wt = self._tnx.get(key)
+        if wt is not None:
+            return torch.mm(dY2d, wt.t())
+        return torch.mm(dY2d, self.layers[key].weight_q)
+
+    # -- forward ------------------------------------------------------------------------------------------------------------
+    def _forward_impl(self, x, others, ctx):
+        from .wrapper import act_quant_fwd_raw
+
+        P, L, aq = self.plan, self.layers, self.aq
+        grad = ctx is not None
+        B, S, H = x.shape
+        T = B * S
+        x2d = x.reshape(T, H)
+        if x2d.dtype != self.dtype:
+            x2d = x2d.to(self.dtype)
+        x2d = x2d.contiguous()
+        hq, hkv, hd = self.hq, self.hkv, self.hd
+        sv = {}
+
+        def fq(t, plan):
+            return t if plan is None else act_quant_fwd_raw(t, plan)
+
+        if grad:
+            self._refresh_tn()
+        # input_layernorm (the block input needs no gradient)
+        res = ops.rmsnorm_fwd_exact(x2d, self.w1, self.eps1, rsqrt_f32=P["norm_rsqrt_f32"]) if P["norm1"] else None
+        if res is not None:
+            h1 = res[0]
+        else:
+            with self._ctx(S):
+                h1 = self.block.input_layernorm(x2d.view(B, S, H)).reshape(T, H)
+        h1_in = fq(h1, aq["qkv"])
+        # q / k / v
+        if P["merged_qkv"]:
+            qkv = F.linear(h1_in, self.Wqkv, self.b_qkv)
+            nq, nk = hq * hd, hkv * hd
+            q2d, k2d, v2d = qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:]
+        else:
+            q2d, k2d, v2d = (F.linear(h1_in, L[n].weight_q, self._bias(n)) for n in "qkv")
+        # rotary embedding
+        cos, sin = self._cos_sin(others, B, S)
+        rope_graph = None
+        if P["rope"]:
+            qr2d, kr2d = ops.rope_fwd_exact(q2d, k2d, cos, sin, S, hq, hkv, hd)
+            qr4 = qr2d.view(B, S, hq, hd).transpose(1, 2)
+            kr4 = kr2d.view(B, S, hkv, hd).transpose(1, 2)
+        else:
+            from transformers.models.llama.modeling_llama import apply_rotary_pos_emb
+
+            pc, ps = others["position_embeddings"]
+            with torch.enable_grad() if grad else contextlib.nullcontext():
+                ql = q2d.view(B, S, hq, hd).transpose(1, 2).detach().requires_grad_(grad)
+                kl = k2d.view(B, S, hkv, hd).transpose(1, 2).detach().requires_grad_(grad)
+                with self._ctx(S):
+                    qr4, kr4 = apply_rotary_pos_emb(ql, kl, pc, ps)
+            rope_graph = (ql, kl, qr4, kr4)
+            qr4, kr4 = qr4.detach(), kr4.detach()
+        v4 = v2d.view(B, S, hkv, hd).transpose(1, 2)
+        # attention: transformers' own sdpa_attention_forward on the layouts the module hands over
+        from transformers.integrations.sdpa_attention import sdpa_attention_forward
+
+        mask = others.get("attention_mask")
+        with torch.enable_grad() if grad else contextlib.nullcontext():
+            al = [t.detach().requires_grad_(grad) for t in (qr4, kr4, v4)]
+            with self._ctx(S):
+                ao, _ = sdpa_attention_forward(self.attn, al[0], al[1], al[2], mask, dropout=0.0, scaling=self.attn.scaling)
+                ao = ao.reshape(B, S, -1).contiguous()
+        a2d = ao.detach().view(T, hq * hd)
+        a_in = fq(a2d, aq["o"])
+        o_out = F.linear(a_in, L["o"].weight_q, self._bias("o"))
+        # residual + post_attention_layernorm
+        norm_graph = None
+        res = ops.rmsnorm_fwd_exact(o_out, self.w2, self.eps2, res=x2d, rsqrt_f32=P["norm_rsqrt_f32"]) if P["norm2"] else None
+        if res is not None:
+            h2, rstd2, x2 = res
+        else:
+            rstd2 = None
+            x2 = x2d + o_out
+            with torch.enable_grad() if grad else contextlib.nullcontext():
+                x2l = x2.detach().requires_grad_(grad)
+                with self._ctx(S):
+                    h2g = self.block.post_attention_layernorm(x2l.view(B, S, H))
+            norm_graph = (x2l, h2g)
+            h2 = h2g.detach().reshape(T, H)
+        h2_in = fq(h2, aq["gu"])
+        # MLP
+        if P["merged_gu"]:
+            gu = F.linear(h2_in, self.Wgu, self.b_gu)
+            g2d, u2d = gu[:, :self.Fdim], gu[:, self.Fdim:]
+        else:
+            g2d = F.linear(h2_in, L["g"].weight_q, self._bias("g"))
+            u2d = F.linear(h2_in, L["u"].weight_q, self._bias("u"))
+        act_graph = None
+        if P["swiglu"]:
+            act = ops.swiglu_fwd_exact(g2d, u2d)
+        else:
+            with torch.enable_grad() if grad else contextlib.nullcontext():
+                gl, ul = g2d.detach().requires_grad_(grad), u2d.detach().requires_grad_(grad)
+                with self._ctx(S):
+                    actg = self.block.mlp.act_fn(gl) * ul
+            act_graph = (gl, ul, actg)
+            act = actg.detach()
+        act_in = fq(act, aq["d"])
+        d_out = F.linear(act_in, L["d"].weight_q, self._bias("d"))
+        y = x2 + d_out
+        if grad:
+            sv.update(B=B, S=S, h1_in=h1_in, cos=cos, sin=sin, rope_graph=rope_graph, attn_leaves=al, attn_out=ao, a2d=a2d, a_in=a_in,
+                      x2=x2, rstd2=rstd2, norm_graph=norm_graph, h2=h2, h2_in=h2_in, g2d=g2d, u2d=u2d, act_graph=act_graph, act=act,
+                      act_in=act_in)
+            ctx.saved = sv
+        return y.view(B, S, H)
+
+    # -- backward -----------------------------------------------------------------------------------------------------------
+    def _backward_impl(self, ctx, dy):
+        from .wrapper import act_quant_bwd_raw
+
+        s = ctx.saved
+        ctx.saved = None
+        P, aq = self.plan, self.aq
+        B, S = s["B"], s["S"]
+        T, H = B * S, self.H
+        hq, hkv, hd = self.hq, self.hkv, self.hd
+
+        def bq(g, x, plan):
+            return g if plan is None else act_quant_bwd_raw(g, x, plan)
+
+        dy2d = dy.reshape(T, H)
+        if dy2d.dtype != self.dtype:
+            dy2d = dy2d.to(self.dtype)
+        dy2d = dy2d.contiguous()
+        # y = x2 + down(act_in)
+        self._dw_x("d", dy2d, s.pop("act_in"))
+        dact = bq(self._dx_x("d", dy2d), s.pop("act"), aq["d"])
+        g2d, u2d, act_graph = s.pop("g2d"), s.pop("u2d"), s.pop("act_graph")
+        Fd = self.Fdim
+        dgu = torch.empty((T, 2 * Fd), dtype=self.dtype, device=dy2d.device) if P["dw_gu"] else None
+        halves = None if dgu is None else (dgu[:, :Fd], dgu[:, Fd:])       # the merged dW GEMM's operand, written in place
+        if act_graph is None:
+            dg, du = ops.swiglu_bwd_exact(dact, g2d, u2d, contract=P["swiglu_contract"], out=halves)
+        else:
+            gl, ul, actg = act_graph
+            dg, du = torch.autograd.grad(actg, (gl, ul), dact)
+            if halves is not None:
+                halves[0].copy_(dg)
+                halves[1].copy_(du)
+                dg, du = halves
+            else:
+                dg, du = dg.contiguous(), du.contiguous()
+        del dact, g2d, u2d, act_graph
+        h2_in, h2 = s.pop("h2_in"), s.pop("h2")
+        if dgu is not None:
+            self._dw_x("gu", dgu, h2_in)
+        else:
+            self._dw_x("g", dg, h2_in)
+            self._dw_x("u", du, h2_in)
+        # h2 feeds gate_proj and up_proj: two gradients, each through its own activation fake-quant, summed by autograd
+        dh2 = bq(self._dx_x("g", dg), h2, aq["gu"]) + bq(self._dx_x("u", du), h2, aq["gu"])
+        del dg, du, dgu, halves, h2_in, h2
+        norm_graph = s.pop("norm_graph")
+        if norm_graph is None:
+            dx2 = ops.rmsnorm_bwd_exact(dh2, s.pop("x2"), self.w2, s.pop("rstd2"), dres=dy2d, out=dh2)
+        else:
+            x2l, h2g = norm_graph
+            (gx,) = torch.autograd.grad(h2g, x2l, dh2.view(B, S, H))
+            dx2 = gx.reshape(T, H) + dy2d
+        del dh2, norm_graph
+        # x2 = x + o(a_in)
+        self._dw_x("o", dx2, s.pop("a_in"))
+        da = bq(self._dx_x("o", dx2), s.pop("a2d"), aq["o"])
+        del dx2
+        al, ao = s.pop("attn_leaves"), s.pop("attn_out")
+        gq4, gk4, gv4 = torch.autograd.grad(ao, al, da.view(B, S, hq * hd))
+        del al, ao, da
+        rope_graph = s.pop("rope_graph")
+        nq, nk = hq * hd, hkv * hd
+        dqkv = torch.empty((T, nq + 2 * nk), dtype=self.dtype, device=dy2d.device) if P["dw_qkv"] else None
+        slices = None if dqkv is None else (dqkv[:, :nq], dqkv[:, nq:nq + nk])
+        if rope_graph is None:
+            dq2d, dk2d = ops.rope_bwd_exact(gq4, gk4, s["cos"], s["sin"], S, hd, out=slices)
+        else:
+            ql, kl, qr4, kr4 = rope_graph
+            dq4, dk4 = torch.autograd.grad((qr4, kr4), (ql, kl), (gq4, gk4))
+            if slices is not None:
+                slices[0].view(B, S, hq, hd).copy_(dq4.transpose(1, 2))
+                slices[1].view(B, S, hkv, hd).copy_(dk4.transpose(1, 2))
+            else:
+                dq2d = dq4.transpose(1, 2).reshape(T, nq)
+                dk2d = dk4.transpose(1, 2).reshape(T, nk)
+        h1_in = s.pop("h1_in")
+        if dqkv is not None:
+            dqkv[:, nq + nk:].view(B, S, hkv, hd).copy_(gv4.transpose(1, 2))
+            self._dw_x("qkv", dqkv, h1_in)
+        else:
+            dv2d = gv4.transpose(1, 2).reshape(T, nk)
+            self._dw_x("q", dq2d.contiguous(), h1_in)
+            self._dw_x("k", dk2d.contiguous(), h1_in)
+            self._dw_x("v", dv2d.contiguous(), h1_in)
+
+    # -- the proof -----------------------------------------------------------------------------------------------------------
+    def _run_once(self, x, others, dpred):
+        for a in self.arenas:
+            for l in a.layers:
+                l._dw_accum[0] = False
+        y = _FusedBlockFn.apply(x, self.arena.token, self, others)
+        y.backward(dpred)
+        return y.detach(), [a.dWq.clone() for a in self.arenas]
+
+    def plan_against_module(self, module_forward, x, others, ref, want=None) -> Optional[dict]:
+        """One minibatch `x` ([rows, S, H], the loop's real minibatch shape: the library picks its GEMM kernels by shape) with targets
+        `ref`: forward + loss gradient + backward through the module code (`module_forward(x, others)` -> prediction attached to
+        autograd) and through this class, same frozen parameters.  -> the plan (also installed), or None when not even the
+        all-torch form reproduces the module path's bits (the caller then keeps the module path).  `want`: options to try
+        (default: every kernel and GEMM form)."""
+        for a in self.arenas:
+            if not a.wq_fresh:
+                a.qdq_forward()
+        reset = lambda: [l._dw_accum.__setitem__(0, False) for a in self.arenas for l in a.layers]  # noqa: E731
+        reset()
+        pred = module_forward(x, others)
+        pred_c = pred if pred.is_contiguous() else pred.contiguous()
+        dpred = torch.empty_like(pred_c)
+        scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
+        ops.mse_loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred=dpred, loss_accum=scratch, accum_scale=1.0, grad_scale=1000.0)
+        pred_c.backward(dpred)
+        y_ref = pred_c.detach()
+        dw_ref = [a.dWq.clone() for a in self.arenas]
+        del pred, pred_c
+
+        def same(plan):
+            self.set_plan(plan)
+            try:
+                y, dws = self._run_once(x, others, dpred)
+            except (RuntimeError, ValueError, NotImplementedError) as e:      # a kernel refusing the shape: not an option here
+                report["errors"][",".join(k for k, v in plan.items() if v)] = repr(e)[:200]
+                return False
+            return _bits_equal(y, y_ref) and all(_bits_equal(a, b) for a, b in zip(dws, dw_ref))
+
+        report = dict(errors={}, tried=[], kept=[], skipped={})
+        plan = self.base_plan()
+        if not same(plan):
+            reset()
+            self.plan_report = dict(report, usable=False)
+            return None
+
+        def norm_stats_match(rsqrt_f32):
+            """the norm kernels' fp32 row statistics against torch's own ops on the probe minibatch: one bit of rstd rarely moves a
+            bf16 output, so the block-level comparison alone could let a kernel with another rsqrt through"""
+            x2d = x.reshape(-1, x.shape[-1]).to(self.dtype).contiguous()
+            res = ops.rmsnorm_fwd_exact(x2d, self.w1, self.eps1, rsqrt_f32=rsqrt_f32)
+            if res is None:
+                return False
+            want_r = torch.rsqrt(x2d.float().pow(2).mean(-1, keepdim=True) + self.eps1).view(-1)
+            return _bits_equal(res[1], want_r)
+
+        def tiles(key):
+            w = self.layers[key].weight_q
+            return (w.shape[0] // 256) * (w.shape[1] // 256)
+
+        opts = [o for o in (KERNEL_OPTS + GEMM_OPTS) if (want is None and o not in DEFAULT_SKIP) or (want is not None and o in want)]
+        for opt in opts:
+            if opt in ("dw_q", "dw_k", "dw_v") and plan["dw_qkv"] or opt in ("dw_g", "dw_u") and plan["dw_gu"]:
+                report["skipped"][opt] = "covered by the merged weight-gradient GEMM"
+                continue
+            if opt.startswith("dw_") and len(opt) == 4 and tiles(opt[3]) < 256:
+                report["skipped"][opt] = "fewer than 256 output tiles: the library GEMM is the faster one"
+                continue
+            trial = dict(plan)
+            trial[opt] = True
+            variants = [trial]
+            if opt == "swiglu":
+                variants.append(dict(trial, swiglu_contract=False))
+            if opt in ("norm1", "norm2") and not (plan["norm1"] or plan["norm2"]):
+                variants = [tv for tv in (trial, dict(trial, norm_rsqrt_f32=True)) if norm_stats_match(tv["norm_rsqrt_f32"])]
+                if not variants:
+                    report["errors"][opt] = "row statistics differ from torch's (rsqrt / reduction order)"
+            report["tried"].append(opt)
+            for tv in variants:
+                if same(tv):
+                    plan = tv
+                    report["kept"].append(opt)
+                    break
+        self.set_plan(plan)
+        reset()
+        self.plan_report = dict(report, usable=True, plan={k: bool(v) for k, v in plan.items()})
+        return plan

@@ -487,6 +487,108 @@ def rope_bwd(dq2d, dk2d, dv2d, cos, sin, batch, seq, hq, hkv, d, out=None):
     return dqkv
 
 
+# ---- "exact_rounding": eager torch's rounding points and summation order (csrc/ar_exact.hip) --------------------------------------
+def _strided2d(t, name):
+    """a [rows, cols] matrix with unit inner stride, 16-byte aligned rows (a column slice of a wider matrix is fine)"""
+    if not t.is_cuda:
+        raise _lib.Mi355xLibraryError(f"{name} is on {t.device}: the MI355X path only runs on a HIP device and has no CPU fallback")
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16:
+        raise ValueError(f"{name}: expected a 2-D matrix with unit inner stride and 16-byte aligned rows")
+    p = _Ptr(t.data_ptr())
+    p.dev = t.device.index
+    return p
+
+
+def exact_mean_factor(rows: int, hidden: int) -> float:
+    """ATen's mean kernel multiplies the row sum by float(num_outputs) / float(numel) (ReduceMomentKernel.cu mean_kernel_impl)"""
+    import numpy as np
+
+    return float(np.float32(rows) / np.float32(rows * hidden))
+
+
+def rmsnorm_fwd_exact(x2d, weight, eps, res=None, rsqrt_f32=False, raw_sum=False):
+    """LlamaRMSNorm.forward with eager torch's bits.  res given: s = x + res (rounded, its own eager op) is normalised and returned.
+    -> (y, rstd [rows] fp32, s or x2d); None when ATen would take a code path the kernel does not mirror (rows < 8, hidden < 256).
+    rsqrt_f32: the float rsqrt instruction instead of torch-on-ROCm's double evaluation; raw_sum (probes): `rstd` holds the row sums."""
+    rows, H = x2d.shape
+    if rows < 8 or H < 256 or H % 8 or weight.dtype != x2d.dtype or rows * H > 0x1fffffff:
+        return None
+    y = torch.empty_like(x2d)
+    s = torch.empty_like(x2d) if res is not None else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    _launch("ar_rmsnorm_fwd_exact", _p(x2d, "x"), _p(res), _p(weight, "weight"), _p(s), _p(y), _p(rstd), rows, H, float(eps),
+            exact_mean_factor(rows, H), int(bool(rsqrt_f32)) | (2 if raw_sum else 0), dt_code(x2d.dtype))
+    return y, rstd, (s if res is not None else x2d)
+
+
+def rmsnorm_bwd_exact(dy2d, x2d, weight, rstd, dres=None, out=None):
+    """torch autograd's backward of LlamaRMSNorm.forward w.r.t. its input, op by op (+ dres: the residual branch's gradient)"""
+    rows, H = x2d.shape
+    dx = out if out is not None else torch.empty_like(x2d)
+    _launch("ar_rmsnorm_bwd_exact", _p(dy2d, "dy"), _p(x2d, "x"), _p(weight, "weight"), _p(rstd, "rstd"), _p(dres), _p(dx), rows, H,
+            dt_code(x2d.dtype))
+    return dx
+
+
+def rope_fwd_exact(q2d, k2d, cos, sin, seq, hq, hkv, d):
+    """apply_rotary_pos_emb on separate q [tokens, hq*d] / k [tokens, hkv*d] projections (column slices allowed) -> contiguous q, k"""
+    tokens = q2d.shape[0]
+    qo = torch.empty((tokens, hq * d), dtype=q2d.dtype, device=q2d.device)
+    ko = torch.empty((tokens, hkv * d), dtype=q2d.dtype, device=q2d.device)
+    bstride = 0 if cos.shape[0] == 1 else cos.stride(0)
+    _launch("ar_rope_fwd_exact", _strided2d(q2d, "q"), q2d.stride(0), _strided2d(k2d, "k"), k2d.stride(0), _p(cos, "cos"), _p(sin, "sin"), bstride,
+            _p(qo), _p(ko), tokens, seq, hq, hkv, d, dt_code(q2d.dtype))
+    return qo, ko
+
+
+def rope_bwd_exact(gq4, gk4, cos, sin, seq, d, out=None):
+    """gq4 [B, hq, S, d] / gk4 [B, hkv, S, d] (any strides with a contiguous head dimension): gradients of the rotated q / k as the
+    attention backward left them -> (dq [tokens, hq*d], dk [tokens, hkv*d]) gradients of the projections; `out` = (dq, dk) may be
+    column slices of one merged [tokens, (hq + 2 hkv) d] gradient buffer"""
+    def fix(t):
+        if t.stride(3) != 1 or any(st % 8 for st in t.stride()[:3]) or t.data_ptr() % 16:
+            t = t.contiguous()
+        return t
+
+    gq4, gk4 = fix(gq4), fix(gk4)
+    B, hq, S, _ = gq4.shape
+    hkv = gk4.shape[1]
+    tokens = B * S
+    if out is None:
+        dq = torch.empty((tokens, hq * d), dtype=gq4.dtype, device=gq4.device)
+        dk = torch.empty((tokens, hkv * d), dtype=gq4.dtype, device=gq4.device)
+    else:
+        dq, dk = out
+    bstride = 0 if cos.shape[0] == 1 else cos.stride(0)
+    pq, pk = _Ptr(gq4.data_ptr()), _Ptr(gk4.data_ptr())
+    pq.dev = pk.dev = gq4.device.index
+    _launch("ar_rope_bwd_exact", pq, gq4.stride(0), gq4.stride(2), gq4.stride(1), pk, gk4.stride(0), gk4.stride(2), gk4.stride(1),
+            _p(cos, "cos"), _p(sin, "sin"), bstride, _strided2d(dq, "dq"), dq.stride(0), _strided2d(dk, "dk"), dk.stride(0), tokens, seq,
+            hq, hkv, d, dt_code(gq4.dtype))
+    return dq, dk
+
+
+def swiglu_fwd_exact(g2d, u2d):
+    rows, F_ = g2d.shape
+    a = torch.empty((rows, F_), dtype=g2d.dtype, device=g2d.device)
+    _launch("ar_swiglu_fwd_exact", _strided2d(g2d, "gate"), g2d.stride(0), _strided2d(u2d, "up"), u2d.stride(0), _p(a), rows, F_, dt_code(g2d.dtype))
+    return a
+
+
+def swiglu_bwd_exact(da2d, g2d, u2d, contract: bool, out=None):
+    """-> (d gate, d up) [rows, F]; contract: `1 + g * (1 - s)` of silu_backward as an fma (what ATen's kernel compiles to); `out` =
+    (dg, du) may be the two halves of one merged [rows, 2F] gradient buffer"""
+    rows, F_ = g2d.shape
+    if out is None:
+        dg = torch.empty((rows, F_), dtype=g2d.dtype, device=g2d.device)
+        du = torch.empty_like(dg)
+    else:
+        dg, du = out
+    _launch("ar_swiglu_bwd_exact", _p(da2d, "da"), _strided2d(g2d, "gate"), g2d.stride(0), _strided2d(u2d, "up"), u2d.stride(0),
+            _strided2d(dg, "dg"), dg.stride(0), _strided2d(du, "du"), du.stride(0), rows, F_, int(bool(contract)), dt_code(g2d.dtype))
+    return dg, du
+
+
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq: int, heads: int, head_dim: int, scale=None):
     """Causal attention forward on token-major operands q / k / v [batch * seq, heads * head_dim] (bf16, K / V already repeated to
     `heads`; unit inner stride -- the three may be column slices of one merged projection output, k and v with the same row stride):
@@ -558,10 +660,12 @@ def attn_bwd(q, k, v, out, lse, dout, batch: int, seq: int, heads: int, head_dim
 _gemm_ws: dict = {}
 
 
-def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> bool:
+def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate: bool = False, split: bool = True) -> bool:
     """out[M,N] (+)= dY2d[K,M]^T @ X2d[K,N] through the hand-written MFMA kernel (bf16, fp32 accumulate).  Operands may be
     column slices of wider row-major buffers (unit inner stride).  -> False when the shape / alignment is outside what the
-    kernel takes (the caller then keeps the library GEMM); raises on a failed launch."""
+    kernel takes (the caller then keeps the library GEMM); raises on a failed launch.  split=False: no workspace is handed over,
+    so every output element is ONE pass over K in token order (no split-K partial sums): the summation order the exact_rounding
+    plan compares with the library's."""
     if dY2d.dtype != torch.bfloat16 or X2d.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
         return False
     if dY2d.dim() != 2 or X2d.dim() != 2 or out.dim() != 2 or dY2d.stride(1) != 1 or X2d.stride(1) != 1 or out.stride(1) != 1:
@@ -578,7 +682,7 @@ def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate
     if len(devs) != 1:
         raise _lib.Mi355xLibraryError("gemm_dw: tensors live on different HIP devices")
     (dev,) = devs
-    ws_bytes = load().ar_gemm_dw_workspace_bytes(M, N, K)
+    ws_bytes = load().ar_gemm_dw_workspace_bytes(M, N, K) if split else 0
     ws = None
     if ws_bytes > 0:                # split-K partial tiles: one growing scratch buffer per device, reused by every call
         ws = _gemm_ws.get(dev)

@@ -282,6 +282,13 @@ class SignRoundConfig:
     # -- instead of one broadcastable row.  Same values; SDPA may pick another kernel for a batch-broadcast mask, and with it other
     # last bits.  Costs a [batch, 1, S, S] copy per forward, so it is off unless bit parity with the reference's forward is wanted.
     materialise_shared_rows: bool = False
+    # Llama-family blocks through first-party kernels that keep the MODULE PATH'S BITS (auto_round_amd/exact_block.py,
+    # csrc/ar_exact.hip): eager torch's rounding points and reduction order in the elementwise kernels, the module path's GEMM
+    # shapes plus whichever faster GEMM forms prove bit-equal on this GPU / software stack.  Verified against the module code on
+    # one real minibatch per kind of block before it is used; where the proof fails the module path runs.  Takes precedence over
+    # `fused_block` (whose rounding points differ): with this switch on a block is never tuned on a path that is not bit-identical
+    # to the module path.
+    exact_rounding: bool = False
 
     def __post_init__(self):
         if self.iters < 0:
@@ -329,6 +336,9 @@ class SignRoundQuantizer:
         self.last_fused_block = False
         self.last_hip_graph = False
         self._fused_verdict: Dict[Any, bool] = {}        # block signature -> did the fused kernels agree with the module code
+        self._exact_plans: Dict[Any, Any] = {}           # (block signature, minibatch shape) -> proven exact_rounding plan | False
+        self.last_exact = False
+        self.last_exact_report: Optional[dict] = None
         self._graph_stream = None
         self._graph_pool = None
         self._last_graph = None
@@ -367,18 +377,22 @@ class SignRoundQuantizer:
         except TypeError:  # pragma: no cover  (older torch without set_priority)
             return sdpa_kernel(order)
 
+    def _others_for(self, rows: int, input_others):
+        """`materialise_shared_rows`: the block's shared keyword tensors at the minibatch's own row count (see SignRoundConfig)"""
+        if not (self.config.materialise_shared_rows and input_others):
+            return input_others
+
+        def mat(v):
+            if isinstance(v, torch.Tensor) and v.dim() >= 3 and v.shape[0] == 1 and rows > 1 and v.is_floating_point():
+                return v.expand(rows, *v.shape[1:]).contiguous()
+            if isinstance(v, tuple):
+                return tuple(mat(t) for t in v)
+            return v
+
+        return {k: (mat(v) if k != "positional_inputs" else v) for k, v in input_others.items()}
+
     def block_forward(self, block, x, input_others):
-        if self.config.materialise_shared_rows and input_others:
-            rows = x.shape[0]
-
-            def mat(v):
-                if isinstance(v, torch.Tensor) and v.dim() >= 3 and v.shape[0] == 1 and rows > 1 and v.is_floating_point():
-                    return v.expand(rows, *v.shape[1:]).contiguous()
-                if isinstance(v, tuple):
-                    return tuple(mat(t) for t in v)
-                return v
-
-            input_others = {k: (mat(v) if k != "positional_inputs" else v) for k, v in input_others.items()}
+        input_others = self._others_for(x.shape[0], input_others)
         with self._sdpa_ctx(x.shape[1] if x.dim() == 3 else None):
             return block_forward(block, x, input_others, amp=self.config.amp, amp_dtype=self.config.amp_dtype)
 
@@ -412,7 +426,12 @@ class SignRoundQuantizer:
             for lyr in a.layers:
                 lyr._mfma_dw = bool(cfg.mfma_dw_gemm)
         fused = None
-        if cfg.fused_block and cfg.amp:
+        self.last_exact = False
+        if cfg.exact_rounding and cfg.amp:
+            fused = self._build_exact(block, arenas, input_others, per_sample_others, X, Y,
+                                      min(cfg.batch_size, min(nsamples, cfg.batch_size * cfg.gradient_accumulate_steps)))
+            self.last_exact = fused is not None
+        elif cfg.fused_block and cfg.amp:
             from .fused_block import build_fused_block
 
             fused = build_fused_block(block, arenas, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx, use_mfma_dw=cfg.mfma_dw_gemm,
@@ -522,7 +541,10 @@ class SignRoundQuantizer:
                 if direct:          # captured iterations: the fused block's own forward / backward, no autograd graph in between
                     pred, ctx = fused.forward_direct(x, others_b, donate_input=True)
                 else:
-                    pred = fused.forward(x, others_b, donate_input=True) if fused is not None else self.block_forward(block, x, others_b)      # x: scratch rows
+                    if fused is not None:
+                        pred = fused.forward(x, self._others_for(nb, others_b) if self.last_exact else others_b, donate_input=True)
+                    else:
+                        pred = self.block_forward(block, x, others_b)      # x: scratch rows
                 pred_c = pred if pred.is_contiguous() else pred.contiguous()
                 dpred = scratch["dpred"]
                 if dpred is None or dpred.shape != pred_c.shape or dpred.dtype != pred_c.dtype:
@@ -600,6 +622,33 @@ class SignRoundQuantizer:
             unwrapper_block(block, best_params)
         # hand out independent copies: the arenas' best_* buffers are released with the block's wrappers
         return {n: {k: v.clone() for k, v in d.items()} for n, d in best_params.items()}
+
+    def _build_exact(self, block, arenas, input_others, per_sample_others, X, Y, rows: int):
+        """The exact_rounding form of a wrapped block, or None (module path): recognised by exact_block.ExactLlamaBlock and PROVEN
+        bit-equal to the module code on one real minibatch (first `rows` samples) -- once per kind of block and minibatch shape;
+        later blocks of the same kind reuse the plan."""
+        from .exact_block import ExactLlamaBlock
+
+        cfg = self.config
+        if cfg.data_parallel or not isinstance(input_others, dict):
+            return None
+        eb = ExactLlamaBlock.try_build(block, arenas, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx, amp=cfg.amp)
+        if eb is None:
+            return None
+        mask = input_others.get("attention_mask")
+        key = ("exact", self._block_signature(block), rows, tuple(X.shape[1:]), str(X.dtype), bool(per_sample_others),
+               None if mask is None else (tuple(mask.shape), str(mask.dtype)), cfg.sdpa_backend, cfg.materialise_shared_rows)
+        plan = self._exact_plans.get(key)
+        if plan is None:
+            others_chk = input_others if not per_sample_others else {**input_others, **{k: t[:rows] for k, t in per_sample_others.items()}}
+            plan = eb.plan_against_module(lambda x, o: self.block_forward(block, x, o), X[:rows].clone(),
+                                          self._others_for(rows, others_chk), Y[:rows])
+            self._exact_plans[key] = plan if plan is not None else False
+            self.last_exact_report = eb.plan_report
+        if not plan:
+            return None
+        eb.set_plan(plan)
+        return eb
 
     @staticmethod
     def _block_signature(block):

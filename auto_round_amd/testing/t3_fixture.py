@@ -130,11 +130,12 @@ def capture_block_inputs(model, block, tokens: torch.Tensor, device, amp_dtype=t
 
 def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw: Optional[dict] = None, iters: int = 200,
                       nsamples: int = 128, seqlen: int = 2048, batch_size: int = 8, fused: bool = False, alg_ext: bool = False,
-                      seed: int = 42, device="cuda:0", graph: Optional[bool] = None, materialise: bool = False) -> dict:
+                      seed: int = 42, device="cuda:0", graph: Optional[bool] = None, materialise: bool = False, exact: bool = False) -> dict:
     """The plugin-mode flow without the reference around it: same seeded block, same block inputs, targets from the module-path
     forward (what the reference's orchestrator hands to `quantize_block`), `transformers.set_seed(seed)` right before the block
     (the reference's sampler then draws the same minibatches), then `SignRoundQuantizer.quantize_block` -- on the module path
-    (`fused=False`) or the fused block path with the MFMA weight-gradient GEMM (`fused=True`)."""
+    (`fused=False`), the fused block path with the MFMA weight-gradient GEMM (`fused=True`), or the exact_rounding path
+    (`exact=True`: first-party kernels proven bit-equal to the module path, auto_round_amd/exact_block.py)."""
     import transformers
 
     from auto_round_amd.autoround import loss_mask_ids
@@ -159,15 +160,21 @@ def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw
         y = q_mod.calibrate_block(block, x0, others)              # module path: the targets the reference would hand over
     kw = {} if graph is None else {"hip_graph": bool(graph)}
     cfg = SignRoundConfig(iters=iters, batch_size=batch_size, bits=sch["bits"], sdpa_backend="auto", fused_block=bool(fused),
-                          mfma_dw_gemm=bool(fused), materialise_shared_rows=materialise, **kw)
+                          mfma_dw_gemm=bool(fused), materialise_shared_rows=materialise, exact_rounding=bool(exact), **kw)
     q = q_cls(cfg, device=device)
     transformers.set_seed(seed)
+    import time
+
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
     q.quantize_block(block, x0, others, y, None, BlockContext(0, 1, "0"), input_ids=ids)
     torch.cuda.synchronize(device)
+    tune_s = time.perf_counter() - t0
     stats = dict(q.last_stats)
     loss_trace = stats.pop("loss_trace", None)      # recorded on the device by ar_best_loss_update, one read per block
     return dict(block=block, stats=stats, loss_trace=loss_trace, x_sha=sha(x0), y_sha=sha(y),
-                fused_block=bool(q.last_fused_block), hip_graph=bool(q.last_hip_graph), others_keys=sorted(others))
+                fused_block=bool(q.last_fused_block), hip_graph=bool(q.last_hip_graph), others_keys=sorted(others),
+                exact_block=bool(q.last_exact), exact_report=q.last_exact_report, tune_s=tune_s)
 
 
 def packed_layers(block) -> Dict[str, Dict[str, np.ndarray]]:
@@ -244,7 +251,7 @@ def check_against_fixture(fused: bool, path: str = FIXTURE, graph: Optional[bool
     return rec
 
 
-def check_against_digest(path: str = DIGEST, fused: bool = False) -> dict:
+def check_against_digest(path: str = DIGEST, fused: bool = False, exact: bool = False) -> dict:
     """The Llama-3-8B-dimension block at the full BASELINE recipe (W4G128 sym, 200 iterations, 128 x 2048, batch 8): the reference's
     packed result is 109 MB, so the fixture holds sha256 digests of every layer's `qweight / qzeros / scales` (+ one small layer in
     full + the loss trace).  Re-tune the block with this package and compare digest for digest: on the module path the result is
@@ -252,7 +259,7 @@ def check_against_digest(path: str = DIGEST, fused: bool = False) -> dict:
     z = np.load(path, allow_pickle=False)
     m = json.loads(str(z["meta"]))
     r = tune_with_product(m["arch"], scheme=m["scheme"], iters=m["iters"], nsamples=m["nsamples"], seqlen=m["seqlen"],
-                          batch_size=m["batch_size"], fused=fused, seed=m["seed"])
+                          batch_size=m["batch_size"], fused=fused, seed=m["seed"], exact=exact)
     packed = packed_layers(r["block"])
     same, total, differing = 0, 0, []
     for key, want in m["digests"].items():
@@ -267,7 +274,8 @@ def check_against_digest(path: str = DIGEST, fused: bool = False) -> dict:
     ec = _codes(packed[full]["qweight"], int(m["bits"])) == _codes(z[f"{full}::qweight"], int(m["bits"]))
     ref_trace = [float(x) for x in z["loss_trace"]]
     tr = r["loss_trace"] or []
-    return dict(fused_block=r["fused_block"], inputs_identical=(r["x_sha"] == m["x_sha"]), targets_identical=(r["y_sha"] == m["y_sha"]),
+    return dict(fused_block=r["fused_block"], exact_block=r["exact_block"], exact_plan=(r["exact_report"] or {}).get("plan"), tune_s=r["tune_s"],
+                inputs_identical=(r["x_sha"] == m["x_sha"]), targets_identical=(r["y_sha"] == m["y_sha"]),
                 tensors=total, tensors_identical=same, bit_identical=(same == total), differing=differing[:6],
                 full_layer=full, full_layer_identical_codes=float(ec.mean()), weights=int(sum(v["qweight"].size for v in packed.values()) * (32 // int(m["bits"]))),
                 init_loss=r["stats"]["init_loss"], init_loss_ref=ref_trace[0], best_loss=r["stats"]["best_loss"], best_loss_ref=min(ref_trace),

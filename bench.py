@@ -135,12 +135,23 @@ def build_block(w, bits, gs, sym, device, seed, attn="sdpa", scheme=None):
     return layer, rope, cfg, n_w
 
 
-def make_others(rope, seqlen, device, x1):
+def calibration_mask(seqlen, device, dtype=torch.bfloat16):
+    """The attention mask the reference's calibration flow hands to every block (auto_round/calibration/llm.py:360-402: attention_mask =
+    ones with the LAST position cleared -> transformers builds the boolean [1, 1, S, S] mask `causal & key-is-valid`; the reference's
+    input cache then casts it to the amp dtype (calibration/inputs.py:100-107), i.e. a 0/1 ADDITIVE bias from then on).  This is what
+    `auto_round_amd.testing.t3_fixture.capture_block_inputs` records from a real model forward."""
+    keep = torch.tril(torch.ones(seqlen, seqlen, dtype=torch.bool, device=device))
+    keep[:, -1] = False
+    return keep.to(dtype)[None, None]
+
+
+def make_others(rope, seqlen, device, x1, mask="none"):
     if rope is None:
-        return {}
+        return {} if mask != "calibration" else {"attention_mask": calibration_mask(seqlen, device)}
     pos = torch.arange(seqlen, device=device).unsqueeze(0)
     cos, sin = rope(x1, pos)
-    return {"position_embeddings": (cos, sin), "attention_mask": None, "position_ids": pos}
+    return {"position_embeddings": (cos, sin), "attention_mask": calibration_mask(seqlen, device) if mask == "calibration" else None,
+            "position_ids": pos}
 
 
 def host_ram_gb():
@@ -152,7 +163,7 @@ def host_ram_gb():
         return 0.0
 
 
-def cpu_baseline(w, bits, gs, sym, seqlen, batch_size, iters, timed=5, extrapolate=True):
+def cpu_baseline(w, bits, gs, sym, seqlen, batch_size, iters, timed=5, extrapolate=True, mask="none"):
     """oracle/torch_ref (the pinned torch restatement of the reference loop) on the host cores, bounded sample.
 
     extrapolate=True (big blocks): `timed` tuning iterations at batch 1 and `timed` at batch 2 of the real sequence length; the
@@ -170,7 +181,7 @@ def cpu_baseline(w, bits, gs, sym, seqlen, batch_size, iters, timed=5, extrapola
         extrapolate, real_big, timed = False, True, 3
     b_max = 2 if extrapolate else batch_size
     X = torch.randn(b_max, S, H).to(torch.bfloat16)
-    others = make_others(rope, S, "cpu", X[:1])
+    others = make_others(rope, S, "cpu", X[:1], mask=mask)
 
     def fwd(blk, x, o):
         out = blk(x, **o)
@@ -266,6 +277,11 @@ def parity_vs_reference_fixture():
                                                         "full_layer_identical_codes", "init_loss", "init_loss_ref", "best_loss", "best_loss_ref",
                                                         "best_loss_ratio", "first_divergence_iter")}
         out["llama8b_module_path"]["fixture"] = os.path.relpath(fx.DIGEST, ROOT)
+        e = fx.check_against_digest(exact=True)          # exact_rounding: the path the headline is measured on
+        out["llama8b_exact_path_bit_identical"] = bool(e["bit_identical"] and e["exact_block"])
+        out["llama8b_exact_path"] = {k: e[k] for k in ("exact_block", "exact_plan", "tensors", "tensors_identical", "weights", "inputs_identical",
+                                                       "targets_identical", "full_layer_identical_codes", "init_loss", "init_loss_ref", "best_loss",
+                                                       "best_loss_ref", "best_loss_ratio", "first_divergence_iter", "tune_s")}
     return out
 
 
@@ -287,14 +303,23 @@ class Bench:
     """One workload on this rank's GPU: block, synthetic calibration data, quantizer; `timed(steps, warmup)` -> dict."""
 
     def __init__(self, args, wname, device, seed_rank=0, scheme=None, fuse_next_forward=False, fused_block=None, dp=False,
-                 quanted_input=True):
+                 quanted_input=True, path=None, mask=None):
+        """path: "exact" (exact_rounding: first-party kernels proven bit-equal to the module path), "fused" (the fused block path:
+        other bf16 rounding points, trajectory-level parity) or "module" (transformers' module code); None: from `fused_block`.
+        mask: "calibration" (the 0/1 additive mask of the reference's calibration flow) or "none" (causal attention)."""
         from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer, SignRoundV2Quantizer
 
         self.args, self.wname, self.device = args, wname, device
         self.w = w = WORKLOADS[wname]
         self.sym = not args.asym
+        if path is None:
+            path = "fused" if fused_block or fused_block is None else "module"
+        self.path, self.mask = path, (mask or "none")
+        fused_block = path == "fused"
         attn = "sdpa"
-        if args.sdpa == "efficient":     # explicit K/V head repeat so that the efficient SDPA kernels are eligible for GQA
+        # the reference's flow: stock "sdpa" attention under torch's own backend choice -- what the module / exact paths mirror
+        self.sdpa = args.sdpa if path == "fused" else "auto"
+        if self.sdpa == "efficient":     # explicit K/V head repeat so that the efficient SDPA kernels are eligible for GQA
             from auto_round_amd.attention import register_mi355x_sdpa
 
             attn = register_mi355x_sdpa()
@@ -309,7 +334,7 @@ class Bench:
         self.master = {n: p.detach().clone() for n, p in self.layer.named_parameters()}
         self.S, self.H, self.N = args.seqlen, w["hidden"], args.nsamples
         self.X = torch.empty(self.N, self.S, self.H, dtype=torch.bfloat16, device=device)
-        self.others = make_others(self.rope, self.S, device, self.X[:1])
+        self.others = make_others(self.rope, self.S, device, self.X[:1], mask=self.mask)
         # token ids as the reference's calibrator caches them: the last position of every sample is marked -100 and is
         # excluded from the loss (calibration/llm.py:340-360) -> the masked loss path is the reference's default path
         self.token_ids = torch.randint(0, 32000, (self.N, self.S), generator=torch.Generator().manual_seed(3))
@@ -322,8 +347,8 @@ class Bench:
         kw["flash_attention_bwd"] = not getattr(args, "no_attn_bwd", False)
         kw["hip_graph"] = True if getattr(args, "hip_graph", False) else (False if getattr(args, "no_hip_graph", False) else None)
         self.qcfg = SignRoundConfig(iters=args.iters, batch_size=args.batch_size, bits=self.bits,
-                                    fuse_next_forward=fuse_next_forward, sdpa_backend=args.sdpa, data_parallel=dp,
-                                    enable_quanted_input=quanted_input, **kw)
+                                    fuse_next_forward=fuse_next_forward, sdpa_backend=self.sdpa, data_parallel=dp,
+                                    enable_quanted_input=quanted_input, exact_rounding=(path == "exact"), **kw)
         self.quantizer = (SignRoundV2Quantizer if args.alg_ext else SignRoundQuantizer)(self.qcfg, device=device)
         self.fuse_next_forward = fuse_next_forward
 
@@ -434,8 +459,14 @@ def main():
                     help="reference scheme preset (overrides --bits/--group-size/--asym); MXFP4/NVFP4 include 4-bit activations")
     ap.add_argument("--fuse-next-forward", action="store_true",
                     help="emit the next iteration's Wq from the fused backward kernel (K1 then runs once per block)")
-    ap.add_argument("--no-fused-block", action="store_true",
-                    help="run the block through transformers' module code (eager torch elementwise ops) instead of the fused HIP block path")
+    ap.add_argument("--path", default="exact", choices=["exact", "fused", "module"],
+                    help="exact (default): exact_rounding -- first-party kernels proven bit-equal to the module path, the reference's own "
+                         "trajectory; fused: the fused block path (other bf16 rounding points, first-party attention; trajectory-level "
+                         "parity); module: transformers' module code around the quant kernels")
+    ap.add_argument("--mask", default="calibration", choices=["calibration", "none"],
+                    help="calibration (default): the 0/1 additive attention mask the reference's calibration flow hands to every block; "
+                         "none: causal attention (attention_mask=None)")
+    ap.add_argument("--no-fused-block", action="store_true", help="same as --path module")
     ap.add_argument("--sdpa", default="efficient", choices=["auto", "efficient", "flash", "math"],
                     help="SDPA backend priority for the block attention (see SignRoundConfig.sdpa_backend)")
     ap.add_argument("--data-parallel", action="store_true",
@@ -495,10 +526,13 @@ def main():
 
     dp = bool(args.data_parallel and world > 1)
     sharded = world > 1 and not dp
-    fused = not args.no_fused_block
+    path = "module" if args.no_fused_block else args.path
+    if path == "exact" and (dp or WORKLOADS[args.workload]["family"] != "llama"):
+        path = "fused"          # exact_rounding covers the Llama family, one rank per block; everything else: the fused path
+    fused = path == "fused"
     profile = not args.no_kernel_timing
     b = Bench(args, args.workload, device, seed_rank=0 if dp else rank, scheme=args.scheme,
-              fuse_next_forward=args.fuse_next_forward, fused_block=fused, dp=dp, quanted_input=not sharded)
+              fuse_next_forward=args.fuse_next_forward, dp=dp, quanted_input=not sharded, path=path, mask=args.mask)
     if rank == 0 or not sharded:
         b.fill_inputs()
     random.seed(42 + (0 if dp else rank))
@@ -567,11 +601,16 @@ def main():
                        "weights_per_block": n_w, "groups_per_block": G, "includes_packing": True, "flash_attention": bool(b.qcfg.flash_attention and b.qcfg.fused_block),
                        "flash_attention_bwd": bool(b.qcfg.flash_attention and b.qcfg.flash_attention_bwd and b.qcfg.fused_block and WORKLOADS[args.workload]["family"] == "opt" and WORKLOADS[args.workload]["hidden"] // WORKLOADS[args.workload]["heads"] == 64),
                        "tn_dx_gemm": bool(b.qcfg.tn_dx_gemm and b.qcfg.fused_block), "mfma_dw_gemm": bool(b.qcfg.mfma_dw_gemm),
-                       "fuse_next_forward": bool(args.fuse_next_forward), "fused_block": bool(getattr(b.quantizer, "last_fused_block", False)),
+                       "fuse_next_forward": bool(args.fuse_next_forward),
+                       "path": path, "exact_rounding": bool(getattr(b.quantizer, "last_exact", False)),
+                       "fused_block": bool(getattr(b.quantizer, "last_fused_block", False) and not getattr(b.quantizer, "last_exact", False)),
+                       "exact_plan": (getattr(b.quantizer, "last_exact_report", None) or {}).get("plan"),
                        "hip_graph": bool(getattr(b.quantizer, "last_hip_graph", False)),
-                       "sdpa_backend": args.sdpa, "alg_ext": bool(args.alg_ext),
-                       "attention_mask": "none: causal attention (what the decoder layer does with attention_mask=None); an explicit "
-                                         "additive mask would send the fused block's attention through torch SDPA instead of csrc/ar_attn*.hip",
+                       "sdpa_backend": b.sdpa, "alg_ext": bool(args.alg_ext),
+                       "attention_mask": ("calibration: the [1, 1, S, S] 0/1 additive mask of the reference's calibration flow "
+                                          "(calibration/llm.py:360-402, inputs.py:100-107) -- the attention is the library's (torch SDPA), as in the reference"
+                                          if args.mask == "calibration" else
+                                          "none: causal attention (attention_mask=None; the fused path then runs csrc/ar_attn*.hip)"),
                        "parallelism": (f"data-parallel inside the block x{world}" if dp else
                                        (f"block-sharded x{world}: tune_sharded over {world * args.steps} blocks on the fp chain "
                                         f"(broadcast, pipelined relay, gather)" if sharded else "single GPU, quantised-input chaining"))},
@@ -582,10 +621,12 @@ def main():
             out.update(b.rooflines())          # (N > 1: rank 0's own dispatches)
         if multi is not None:
             out["multi_gpu"] = multi
+        if profile and "roofline_bwd_sgd" in out:       # (also nested: the driver's record keeps `roofline`, not its siblings)
+            out["roofline"]["bwd_sgd"] = {k: out["roofline_bwd_sgd"][k] for k in ("kernel", "achieved", "peak", "frac", "traffic", "avg_launch_ms", "launches")}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 big = n_w > 50_000_000
-                out["cpu_baseline"] = cpu_baseline(w, b.bits, b.gs, b.sym, S, args.batch_size, args.iters, extrapolate=big)
+                out["cpu_baseline"] = cpu_baseline(w, b.bits, b.gs, b.sym, S, args.batch_size, args.iters, extrapolate=big, mask=args.mask)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"error": repr(e)}
@@ -597,15 +638,17 @@ def main():
                 if ref is not None:
                     out["cpu_reference_quoted"] = ref
                     out["speedup_vs_cpu_reference_quoted"] = out["value"] / ref["value"]
+                    if "error" not in out["cpu_baseline"]:
+                        out["cpu_baseline"]["reference_quoted"] = ref
         if world == 1 and default_cfg and args.workload == "llama3-8b" and not args.no_extras:
             del b.X, b.layer, b.master
             torch.cuda.empty_cache()
             try:
-                out["variants"] = run_variants(args, device, barrier, fused)
+                out["variants"] = run_variants(args, device, barrier, path)
             except Exception as e:  # pragma: no cover
                 out["variants"] = {"error": repr(e)}
             try:
-                out["opt125m"] = run_opt125m(args, device, barrier, fused, not args.no_cpu_baseline)
+                out["opt125m"] = run_opt125m(args, device, barrier, True, not args.no_cpu_baseline)
             except Exception as e:  # pragma: no cover
                 out["opt125m"] = {"error": repr(e)}
             torch.cuda.empty_cache()
@@ -613,6 +656,7 @@ def main():
                 out["parity"] = parity_vs_reference_fixture()
             except Exception as e:  # pragma: no cover
                 out["parity"] = {"error": repr(e)}
+            nest_for_the_driver(out, path, args.mask)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -678,25 +722,66 @@ def _mini(args, **over):
     return a
 
 
-def run_variants(args, device, barrier, fused_default):
-    """The same Llama-3-8B block under the other switch settings, 1 warm-up + 2 timed steps each."""
+def run_variants(args, device, barrier, headline_path):
+    """The same Llama-3-8B block on the other paths / attention configurations, 1 warm-up + 2 timed steps each: the module path (the
+    product default, what exact_rounding reproduces), the fused block path under the calibration mask, and the fused block path with
+    causal attention on the first-party attention kernels (round 3's headline configuration)."""
     out = {}
-    for name, kw in (("fuse_next_forward_on", dict(fuse_next_forward=True, fused_block=fused_default)),
-                     ("fused_block_" + ("off" if fused_default else "on"), dict(fuse_next_forward=False, fused_block=not fused_default))):
-        v = Bench(args, "llama3-8b", device, **kw)
+    todo = [("module_path_calibration_mask", dict(path="module", mask="calibration")),
+            ("fused_path_calibration_mask", dict(path="fused", mask="calibration")),
+            ("fused_path_no_mask", dict(path="fused", mask="none")),
+            ("exact_path_calibration_mask", dict(path="exact", mask="calibration"))]
+    for name, kw in todo:
+        if kw["path"] == headline_path and kw["mask"] == args.mask:
+            continue
+        v = Bench(args, "llama3-8b", device, fuse_next_forward=False, **kw)
         v.fill_inputs()
         random.seed(42)
-        elapsed, stats = v.timed(2, 1, barrier, profile=True)
-        rec = {"value": 2 / elapsed, "unit": "blocks/s", "ms_per_step": 500.0 * elapsed, "steps": 2, "warmup": 1,
-               "fuse_next_forward": v.fuse_next_forward, "fused_block": bool(getattr(v.quantizer, "last_fused_block", False)),
-               "loss": {"init": stats["init_loss"], "best": stats["best_loss"]}}
-        rf = v.rooflines()
-        if "roofline_bwd_sgd" in rf:
-            rec["roofline_bwd_sgd"] = {k: rf["roofline_bwd_sgd"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches")}
-        out[name] = rec
+        elapsed, stats = v.timed(2, 1, barrier, profile=False)
+        out[name] = {"value": 2 / elapsed, "unit": "blocks/s", "ms_per_step": 500.0 * elapsed, "ms_per_iter": 500.0 * elapsed / max(args.iters, 1),
+                     "steps": 2, "warmup": 1, "path": kw["path"], "attention_mask": kw["mask"],
+                     "exact_rounding": bool(getattr(v.quantizer, "last_exact", False)),
+                     "fused_block": bool(getattr(v.quantizer, "last_fused_block", False) and not getattr(v.quantizer, "last_exact", False)),
+                     "bit_identical_to_module_path": kw["path"] in ("module", "exact"),
+                     "loss": {"init": stats["init_loss"], "best": stats["best_loss"]}}
         del v
         torch.cuda.empty_cache()
     return out
+
+
+def nest_for_the_driver(out, path, mask):
+    """The driver's BENCH record keeps `config`, `roofline` and `cpu_baseline` of this line: everything a reader
+    needs to check the claim is repeated under those three keys -- the bit-identical path's own rate, the other paths, the
+    north-star's OPT-125M configuration with its K1 / K2 roofline fractions, the live parity verdicts."""
+    cfg, rf = out["config"], out.get("roofline")
+    var = out.get("variants") or {}
+    par = out.get("parity") or {}
+    me = {"blocks_per_s": out["value"], "ms_per_step": out["ms_per_step"], "ms_per_iter": out["ms_per_iter"], "attention_mask": mask}
+    short = lambda r: None if not isinstance(r, dict) or "value" not in r else {"blocks_per_s": r["value"], "ms_per_step": r["ms_per_step"], "ms_per_iter": r.get("ms_per_iter")}  # noqa: E731
+    exact_rec = me if path == "exact" else short(var.get("exact_path_calibration_mask"))
+    cfg["bit_identical_path"] = dict(exact_rec or {}, what="exact_rounding: first-party kernels + GEMM forms proven bit-equal to the module "
+                                     "path on a real minibatch (config.exact_plan); the digest below is the reference's own result",
+                                     digest_bit_identical=par.get("llama8b_exact_path_bit_identical"),
+                                     digest_tensors_identical=(par.get("llama8b_exact_path") or {}).get("tensors_identical"),
+                                     module_path=short(var.get("module_path_calibration_mask")) if path != "module" else me)
+    cfg["trajectory_level_paths"] = {"fused_path_calibration_mask": short(var.get("fused_path_calibration_mask")) if not (path == "fused" and mask == "calibration") else me,
+                                     "fused_path_no_mask": short(var.get("fused_path_no_mask")) if not (path == "fused" and mask == "none") else me,
+                                     "what": "the fused block path: other bf16 rounding points (like the reference's torch.compile path); with "
+                                             "no mask its attention is csrc/ar_attn*.hip (round 3's headline configuration)"}
+    cfg["parity"] = {k: par.get(k) for k in ("llama8b_module_path_bit_identical", "llama8b_exact_path_bit_identical", "module_path_identical_codes",
+                                             "fused_path_identical_codes", "best_loss_ratio")}
+    opt = out.get("opt125m") or {}
+    if "value" in opt:
+        cfg["opt125m"] = {"blocks_per_s": opt["value"], "ms_per_step": opt["ms_per_step"], "ms_per_iter": opt["ms_per_iter"], "hip_graph": opt.get("hip_graph"),
+                          "fused_block": opt.get("fused_block"), "speedup_vs_cpu_reference_quoted": opt.get("speedup_vs_cpu_reference_quoted")}
+        if isinstance(rf, dict):
+            rf["opt125m"] = {"k1": {k: opt.get("roofline", {}).get(k) for k in ("achieved", "peak", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch")},
+                             "k2": {k: opt.get("roofline_bwd_sgd", {}).get(k) for k in ("achieved", "peak", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch")},
+                             "ms_per_iter": opt["ms_per_iter"], "blocks_per_s": opt["value"]}
+        cb = out.get("cpu_baseline")
+        if isinstance(cb, dict) and "error" not in cb:
+            cb["opt125m"] = {"port": {k: (opt.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind", "sec_per_iter_at_batch")},
+                             "reference_quoted": opt.get("cpu_reference_quoted")}
 
 
 def run_opt125m(args, device, barrier, fused, with_cpu):

@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 18
+#define AR_ABI_VERSION 19
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -306,6 +306,38 @@ int ar_rope_fwd(const void* qkv, int64_t ld, const void* cos, const void* sin, i
                 int64_t tokens, int64_t seq, int hq, int hkv, int d, int dt, ar_stream_t stream);
 int ar_rope_bwd(const void* dq, const void* dk, const void* dv, const void* cos, const void* sin, int64_t cs_batch_stride,
                 void* dqkv, int64_t ld, int64_t tokens, int64_t seq, int hq, int hkv, int d, int dt, ar_stream_t stream);
+
+/* ---- the same elementwise work with EAGER TORCH'S OWN ROUNDING POINTS AND SUMMATION ORDER ("exact_rounding") ---------------
+ * replaces: the module code the reference's DEFAULT (non-compiled) path runs through block_forward
+ *           (auto_round/compressors/utils.py:109-172; transformers/models/llama/modeling_llama.py LlamaRMSNorm.forward,
+ *           apply_rotary_pos_emb, LlamaMLP.forward) and torch autograd's backward of it, bit for bit on this GPU: every eager op
+ *           rounds to the tensor dtype, row sums follow the association of ATen's reduction kernel (csrc/ar_exact.hip), so a block
+ *           run through these kernels follows the reference's own sign-SGD trajectory (auto_round_amd/exact_block.py verifies that
+ *           against the module code once per kind of block before using them).  Token-major [rows, features], dt = BF16 | F16.
+ *   ar_rmsnorm_fwd_exact  s = dt(x + res) when res != NULL (written to sum_out), else s = x;  y = w * dt(s * rsqrt(mean(s^2) + eps));
+ *                         mean = torch's row sum * mean_factor (<= 0: float(rows) / float(rows * hidden)); rstd_out [rows] fp32;
+ *                         the rsqrt is evaluated in double and rounded (what torch.rsqrt does on a float tensor in its HIP build);
+ *                         flags & 1: the float instruction instead, flags & 2: rstd_out receives the raw row sums (probes)
+ *   ar_rmsnorm_bwd_exact  autograd of the above w.r.t. s, op by op (+ dres: the residual branch's gradient, added in dt)
+ *   ar_rope_fwd_exact     q [tokens, hq*d] (row stride ldq), k [tokens, hkv*d] (ldk) -> rotated, contiguous; cos / sin as ar_rope_fwd
+ *   ar_rope_bwd_exact     gradients of the rotated q / k, [B, S, h, d] through element strides (batch, token, head) -> d q, d k
+ *                         (token-major, row strides lddq / lddk: column slices of one merged gradient buffer are fine)
+ *   ar_swiglu_fwd_exact   a = dt(dt(silu(g)) * u), g / u separate [rows, F] matrices with row strides
+ *   ar_swiglu_bwd_exact   dg, du [rows, F] (row strides lddg / lddu) from da, g, u; contract != 0: `1 + g * (1 - s)` as the fma ATen's silu_backward kernel has
+ * Unsupported shapes (rows < 8, hidden < 256, ...: another ATen code path) return AR_ERR_UNSUPPORTED and the caller keeps torch. */
+int ar_rmsnorm_fwd_exact(const void* x, const void* res, const void* w, void* sum_out, void* y, float* rstd_out, int64_t rows, int hidden,
+                         float eps, float mean_factor, int flags, int dt, ar_stream_t stream);
+int ar_rmsnorm_bwd_exact(const void* dy, const void* x, const void* w, const float* rstd, const void* dres, void* dx, int64_t rows,
+                         int hidden, int dt, ar_stream_t stream);
+int ar_rope_fwd_exact(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* cos, const void* sin, int64_t cs_batch_stride,
+                      void* q_out, void* k_out, int64_t tokens, int64_t seq, int hq, int hkv, int d, int dt, ar_stream_t stream);
+int ar_rope_bwd_exact(const void* gq, int64_t q_sb, int64_t q_ss, int64_t q_sh, const void* gk, int64_t k_sb, int64_t k_ss, int64_t k_sh,
+                      const void* cos, const void* sin, int64_t cs_batch_stride, void* dq, int64_t lddq, void* dk, int64_t lddk, int64_t tokens,
+                      int64_t seq, int hq, int hkv, int d, int dt, ar_stream_t stream);
+int ar_swiglu_fwd_exact(const void* g, int64_t ldg, const void* u, int64_t ldu, void* a, int64_t rows, int64_t F, int dt,
+                        ar_stream_t stream);
+int ar_swiglu_bwd_exact(const void* da, const void* g, int64_t ldg, const void* u, int64_t ldu, void* dg, int64_t lddg, void* du, int64_t lddu,
+                        int64_t rows, int64_t F, int contract, int dt, ar_stream_t stream);
 
 /* ---- weight-gradient GEMM (hand-written MFMA, gfx950) -------------------------------------------------------------
  * replaces: the autograd backward of F.linear(x, weight_q) with respect to weight_q inside WrapperLinear.forward

@@ -1,0 +1,110 @@
+"""CPU check of the ORCHESTRATION of auto_round_amd/exact_block.py (which GEMM feeds which, gradient routing through the local
+autograd graphs, the residual / accumulation order) with every segment on torch's own ops -- the form `plan_against_module` starts
+from.  The same seeded Llama decoder layer runs through transformers' module code under autograd and through
+ExactLlamaBlock._forward_impl / _backward_impl; the block output and all seven weight gradients must agree bit for bit (the CPU
+kernels are deterministic and both sides issue the same ops).  The HIP kernels themselves are compared with torch on the GPU
+(tests/test_gpu_exact_block.py)."""
+import types
+
+import pytest
+import torch
+
+
+def _layer(hidden=64, inter=160, heads=4, kv=2, seq=16, batch=2, bias=False):
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaDecoderLayer, LlamaRotaryEmbedding
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=hidden, intermediate_size=inter, num_attention_heads=heads, num_key_value_heads=kv,
+                      num_hidden_layers=1, vocab_size=32, max_position_embeddings=64, attention_bias=bias, mlp_bias=bias)
+    cfg._attn_implementation = "sdpa"
+    blk = LlamaDecoderLayer(cfg, 0).to(torch.bfloat16)
+    for p in blk.parameters():
+        torch.nn.init.normal_(p, std=0.3)
+    rot = LlamaRotaryEmbedding(cfg)
+    x = torch.randn(batch, seq, hidden).to(torch.bfloat16)
+    pos = torch.arange(seq)[None]
+    cos, sin = rot(x, pos)
+    return cfg, blk, x, (cos.to(torch.bfloat16), sin.to(torch.bfloat16))
+
+
+def _exact_over(blk, cfg, pe):
+    from auto_round_amd.exact_block import GEMM_OPTS, KERNEL_OPTS, ExactLlamaBlock
+
+    attn, mlp = blk.self_attn, blk.mlp
+    mods = dict(q=attn.q_proj, k=attn.k_proj, v=attn.v_proj, o=attn.o_proj, g=mlp.gate_proj, u=mlp.up_proj, d=mlp.down_proj)
+    layers = {n: types.SimpleNamespace(weight_q=m.weight.detach(), weight_grad=torch.zeros_like(m.weight), _dw_accum=[False], orig_layer=m)
+              for n, m in mods.items()}
+    eb = object.__new__(ExactLlamaBlock)
+    eb.block, eb.layers, eb.attn = blk, layers, attn
+    eb.hq, eb.hkv, eb.hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.hidden_size // cfg.num_attention_heads
+    eb.H, eb.Fdim, eb.dtype = cfg.hidden_size, cfg.intermediate_size, torch.bfloat16
+    eb.aq = dict(qkv=None, o=None, gu=None, d=None)
+    eb.w1, eb.eps1 = blk.input_layernorm.weight, blk.input_layernorm.variance_epsilon
+    eb.w2, eb.eps2 = blk.post_attention_layernorm.weight, blk.post_attention_layernorm.variance_epsilon
+    eb.sdpa_ctx, eb.amp, eb.qk_norm = None, False, None
+    eb.plan = {k: False for k in KERNEL_OPTS + GEMM_OPTS}
+    eb.plan["swiglu_contract"] = True
+    eb._tnx = {}
+    # merged gradient buffers as the arena lays them out: [q; k; v] and [gate; up] contiguous, the per-layer gradients are views
+    eb.dWqkv = torch.zeros(sum(mods[n].weight.shape[0] for n in "qkv"), cfg.hidden_size, dtype=torch.bfloat16)
+    eb.dWgu = torch.zeros(2 * cfg.intermediate_size, cfg.hidden_size, dtype=torch.bfloat16)
+    r0 = 0
+    for n in "qkv":
+        r1 = r0 + mods[n].weight.shape[0]
+        layers[n].weight_grad = eb.dWqkv[r0:r1]
+        r0 = r1
+    layers["g"].weight_grad, layers["u"].weight_grad = eb.dWgu[:cfg.intermediate_size], eb.dWgu[cfg.intermediate_size:]
+    return eb, layers, mods
+
+
+@pytest.mark.parametrize("mask_kind", ["none", "additive"])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("merged_dw", [False, True])
+def test_all_torch_plan_reproduces_the_module_code_bit_for_bit(mask_kind, bias, merged_dw, monkeypatch):
+    cfg, blk, x, pe = _layer(bias=bias)
+    B, S, _ = x.shape
+    mask = None
+    if mask_kind == "additive":     # what the reference's calibration flow hands over: a 0/1 additive bias in the amp dtype
+        mask = torch.tril(torch.ones(S, S)).to(torch.bfloat16)[None, None]
+    others = dict(position_embeddings=pe, attention_mask=mask)
+    dy = torch.randn(B, S, cfg.hidden_size).to(torch.bfloat16)
+
+    for p in blk.parameters():
+        p.requires_grad_(True)
+    y_ref = blk(x, attention_mask=mask, position_embeddings=pe)
+    y_ref = y_ref[0] if isinstance(y_ref, tuple) else y_ref
+    y_ref.backward(dy)
+
+    eb, layers, mods = _exact_over(blk, cfg, pe)
+    if merged_dw:       # the merged weight-gradient buffers (one [tokens, q+k+v] / [tokens, 2F] operand); the MFMA kernel itself is
+        from auto_round_amd import ops      # GPU-only: here the library GEMM takes the merged operands
+        monkeypatch.setattr(ops, "gemm_dw", lambda *a, **k: False)
+        eb.plan.update(dw_qkv=True, dw_gu=True)
+    ctx = types.SimpleNamespace(saved=None)
+    with torch.no_grad():
+        y = eb._forward_impl(x, others, ctx)
+        eb._backward_impl(ctx, dy)
+    assert torch.equal(y.view(torch.int16), y_ref.detach().view(torch.int16))
+    for n, m in mods.items():
+        assert torch.equal(layers[n].weight_grad.view(torch.int16), m.weight.grad.view(torch.int16)), n
+
+
+def test_gradients_accumulate_over_micro_batches_like_addmm():
+    cfg, blk, x, pe = _layer()
+    others = dict(position_embeddings=pe, attention_mask=None)
+    dy = torch.randn_like(x)
+    eb, layers, mods = _exact_over(blk, cfg, pe)
+    for _ in range(2):
+        ctx = types.SimpleNamespace(saved=None)
+        with torch.no_grad():
+            eb._forward_impl(x, others, ctx)
+            eb._backward_impl(ctx, dy)
+    for p in blk.parameters():
+        p.requires_grad_(True)
+    for _ in range(2):
+        out = blk(x, position_embeddings=pe)
+        (out[0] if isinstance(out, tuple) else out).backward(dy)
+    # autograd accumulates .grad += g (two roundings); the arena form is addmm_ (one): close, not necessarily equal
+    for n, m in mods.items():
+        assert torch.allclose(layers[n].weight_grad.float(), m.weight.grad.float(), rtol=2e-2, atol=1e-2), n
