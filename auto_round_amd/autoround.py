@@ -443,10 +443,23 @@ def _compressed_tensors_config(preset: str, ignore, fmt: str):
         from compressed_tensors.quantization import QuantizationConfig, QuantizationStatus, preset_name_to_scheme
     except Exception:
         return None
-    group = preset_name_to_scheme(preset, ["Linear"])
-    cfg = QuantizationConfig(config_groups={"group_0": group}, kv_cache_scheme=None, quantization_status=QuantizationStatus.COMPRESSED,
-                             ignore=list(ignore))
-    setattr(cfg, "format", fmt)
-    out = cfg.to_dict()
+    try:        # an installed version without the preset (KeyError), another constructor signature, ...: the pinned literal is used
+        group = preset_name_to_scheme(preset, ["Linear"])
+        cfg = QuantizationConfig(config_groups={"group_0": group}, kv_cache_scheme=None, quantization_status=QuantizationStatus.COMPRESSED,
+                                 ignore=list(ignore))
+        setattr(cfg, "format", fmt)
+        out = cfg.to_dict()
+    except Exception as e:  # noqa: BLE001
+        import warnings
+
+        warnings.warn(f"compressed-tensors is importable but did not produce the {preset} config ({e!r}); writing the literal pinned to "
+                      f"{LLMC_LITERAL_PINNED_TO}")
+        return None
     out["provider"] = "auto-round"
+    try:        # which version wrote the dict: the same run gives the same checkpoint only on the same version
+        import compressed_tensors
+
+        out["compressed_tensors_version"] = str(getattr(compressed_tensors, "__version__", "unknown"))
+    except Exception:  # noqa: BLE001
+        pass
     return out

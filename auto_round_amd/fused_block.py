@@ -86,15 +86,23 @@ def _rotary_ok(pe, hd) -> bool:
     return all(isinstance(t, torch.Tensor) and t.dim() in (2, 3) and t.shape[-1] == hd for t in pe)
 
 
-def outputs_agree(y_fused: torch.Tensor, y_module: torch.Tensor, x: torch.Tensor, tol: float) -> bool:
-    """|| y_fused - y_module || <= tol * || y_module - x ||: the two paths agree on what the block ADDS to its input (the residual
-    stream dominates both outputs, so a distance relative to || y || would hide a wrong branch); one host read"""
+def disagreement(y_fused: torch.Tensor, y_module: torch.Tensor, x: torch.Tensor) -> float:
+    """|| y_fused - y_module || / || y_module - x ||: how far the two paths are apart in units of what the block ADDS to its input
+    (the residual stream dominates both outputs, so a distance relative to || y || would hide a wrong branch); one host read"""
     a, b = y_fused.detach().float(), y_module.detach().float()
     if a.shape != b.shape:
-        return False
+        return float("inf")
     ref = b - x.detach().float().reshape(b.shape) if x.numel() == b.numel() else b
     num, den = float((a - b).norm()), float(ref.norm())
-    return num == num and den == den and num <= tol * den + 1e-6
+    if num != num or den != den:
+        return float("inf")
+    if den <= 0.0:
+        return 0.0 if num <= 1e-6 else float("inf")
+    return max(num - 1e-6, 0.0) / den
+
+
+def outputs_agree(y_fused: torch.Tensor, y_module: torch.Tensor, x: torch.Tensor, tol: float) -> bool:
+    return disagreement(y_fused, y_module, x) <= tol
 
 
 class FusedLlamaBlock:
@@ -409,12 +417,14 @@ class FusedLlamaBlock:
                         a.qdq_forward()
             try:
                 y_f = self._forward_impl(x, input_others, None)
-            except ValueError:          # e.g. rotary tables that do not fit the batch
+            except Exception as e:  # noqa: BLE001 -- a look-alike block the kernels do not fit (rotary tables of another shape, an
+                self.last_disagreement = repr(e)          # operand a kernel refuses): the module path, not an aborted quantisation
                 return False
             y_m = module_forward(x, input_others)
         # bf16 rounding noise of the two paths is a few percent of the block's own contribution on random-init blocks (less on real
         # ones); a dropped multiplier, a missing / extra rotation or another norm placement changes it by tens of percent
-        return outputs_agree(y_f, y_m, x, 0.35 if act_quant else 0.25)
+        self.last_disagreement = disagreement(y_f, y_m, x)
+        return self.last_disagreement <= (0.35 if act_quant else 0.25)
 
     # -- the attention half (shared with the sparse-MoE block) --------------------------------------------------------------
     def _attn_half_forward(self, x, others, ctx):

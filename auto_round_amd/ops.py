@@ -439,9 +439,24 @@ def swiglu_bwd_(da2d, gu2d, F_):
     return gu2d
 
 
+def _chk(t, name, dtype, shape=None):
+    """the kernels trust raw pointers: a wrong index / weight dtype would read out of bounds instead of failing"""
+    if t is None:
+        return
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
 def moe_expand(src2d, tok, scale=None, out=None):
     """out[p] = scale[p] * src2d[tok[p]] (scale None: row gather) -> [len(tok), H]"""
     R, H = tok.numel(), src2d.shape[1]
+    _chk(tok, "tok", torch.int64)
+    _chk(scale, "scale", torch.float32, (R,))
+    _chk(out, "out", src2d.dtype, (R, H))
     if out is None:
         out = torch.empty((R, H), dtype=src2d.dtype, device=src2d.device)
     _launch("ar_moe_expand", _p(src2d, "src"), _p(tok, "tok"), _p(scale), _p(out), R, H, dt_code(src2d.dtype))
@@ -452,6 +467,11 @@ def moe_combine(D2d, pos, w=None, res=None, out=None):
     """out[t] = res[t] + sum_k w[t, k] * D2d[pos[t, k]]  (pos int64 [T, K]; w fp32 [T, K] or None; res [T, H] or None)"""
     T, K = pos.shape
     H = D2d.shape[1]
+    _chk(pos, "pos", torch.int64)
+    _chk(w, "w", torch.float32, (T, K))
+    _chk(res, "res", D2d.dtype, (T, H))
+    if D2d.shape[0] < T * K:
+        raise ValueError(f"moe_combine: D has {D2d.shape[0]} rows, the {T} x {K} positions address {T * K}")
     if out is None:
         out = torch.empty((T, H), dtype=D2d.dtype, device=D2d.device)
     _launch("ar_moe_combine", _p(D2d, "D"), _p(pos, "pos"), _p(w), _p(res), _p(out), T, H, K, dt_code(D2d.dtype))
@@ -461,6 +481,9 @@ def moe_combine(D2d, pos, w=None, res=None, out=None):
 def moe_rowdot(A2d, tok, B2d):
     """out[p] = <A2d[tok[p]], B2d[p]> in fp32 -> [len(tok)]"""
     R, H = tok.numel(), B2d.shape[1]
+    _chk(tok, "tok", torch.int64)
+    if B2d.shape[0] != R or A2d.shape[1] != H or A2d.dtype != B2d.dtype:
+        raise ValueError("moe_rowdot: B must have one row per entry of tok and A the same row length / dtype")
     out = torch.empty(R, dtype=torch.float32, device=B2d.device)
     _launch("ar_moe_rowdot", _p(A2d, "A"), _p(tok, "tok"), _p(B2d, "B"), _p(out), R, H, dt_code(B2d.dtype))
     return out
@@ -631,6 +654,9 @@ def attn_bwd(q, k, v, out, lse, dout, batch: int, seq: int, heads: int, head_dim
     if any(t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16 or t.dtype != torch.bfloat16 for t in ts):
         return None
     T, HD = batch * seq, heads * head_dim
+    _chk(lse, "lse", torch.float32, (batch, heads, seq))
+    if any(tuple(t.shape) != (T, HD) for t in ts):
+        raise ValueError(f"attn_bwd: q / k / v / out / dout must be [{T}, {HD}]")
     outs = []
     for t in (dq, dk, dv):
         if t is None:

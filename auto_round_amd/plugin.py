@@ -32,13 +32,15 @@ def register():
         """Same fields as the reference SignRoundConfig; selects the MI355X quantizer.  Being a subclass it is not
         coerced to the V2/Adam variants by normalize_algorithm_config (registry.py: `type(config) is SignRoundConfig`).
 
-        One extra, MI355X-only key: `fused_block` (None = follow the front door's `enable_torch_compile`, the reference's switch
+        Two extra, MI355X-only keys: `fused_block` (None = follow the front door's `enable_torch_compile`, the reference's switch
         for its own compiled block forward; True / False = force the fused HIP block path and the MFMA weight-gradient GEMM on /
-        off)."""
+        off) and `exact_rounding` (Llama-family blocks through first-party kernels that keep the eager path's bits --
+        auto_round_amd/exact_block.py; takes precedence over `fused_block`)."""
 
-        def __init__(self, *, fused_block=None, **kwargs):
+        def __init__(self, *, fused_block=None, exact_rounding=False, **kwargs):
             super().__init__(**kwargs)
             self.fused_block = fused_block
+            self.exact_rounding = bool(exact_rounding)
 
     @register_pipeline_member(_Config)
     class _Quantizer(_RefQuantizer):
@@ -68,7 +70,7 @@ def register():
             if fused is None:
                 fused = bool(getattr(getattr(self, "compress_context", None), "enable_torch_compile", False))
             cfg = SignRoundConfig(
-                fused_block=bool(fused), mfma_dw_gemm=bool(fused),
+                fused_block=bool(fused), mfma_dw_gemm=bool(fused), exact_rounding=bool(getattr(c, "exact_rounding", False)),
                 iters=self.iters, lr=None if getattr(c, "lr_is_auto", False) else self.lr,
                 minmax_lr=None if getattr(c, "minmax_lr_is_auto", False) else self.minmax_lr,
                 lr_scheduler=self.lr_scheduler, momentum=getattr(self, "momentum", 0.0) or 0.0, enable_minmax_tuning=self.enable_minmax_tuning,
@@ -79,7 +81,9 @@ def register():
                 amp=bool(self.model_context.amp), amp_dtype=self.model_context.amp_dtype or torch.bfloat16)
             # enable_alg_ext=True selects the algorithm extension (searched init scales, imatrix, outlier-suppressed loss)
             q_cls = SignRoundV2Quantizer if getattr(self, "enable_alg_ext", False) else SignRoundQuantizer
-            q = q_cls(cfg, device=device_manager.device)
+            q = self.__dict__.get("_mi355x_engine")      # one engine per run: the exact_rounding proof is made once per kind of block
+            if q is None or type(q) is not q_cls or q.device != torch.device(device_manager.device) or q.config != cfg:
+                q = self.__dict__["_mi355x_engine"] = q_cls(cfg, device=device_manager.device)
             best = q.quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids=input_ids)
             adopt_act_quant_shells(block, device_manager.device)
             st = q.last_stats

@@ -441,11 +441,12 @@ class SignRoundQuantizer:
                 fused.flash_bwd = bool(cfg.flash_attention_bwd)
                 # the fused kernels must compute what the block's own code computes: one small minibatch through both
                 # (once per kind of block: the verdict is remembered by class and by whether any submodule carries its own forward)
-                key = ("tune", self._block_signature(block))
+                key = ("tune", self._block_signature(block), self._others_signature(block, input_others))
                 if key not in self._fused_verdict:
                     nchk = min(2, nsamples)
                     others_chk = input_others if not per_sample_others else {**input_others, **{k: t[:nchk] for k, t in per_sample_others.items()}}
                     self._fused_verdict[key] = fused.agrees_with_module(lambda x, o: self.block_forward(block, x, o), X[:nchk], others_chk)
+                    self._report_fused_verdict(block, fused, self._fused_verdict[key])
                 if not self._fused_verdict[key]:
                     fused = None
         self.last_fused_block = fused is not None
@@ -651,6 +652,26 @@ class SignRoundQuantizer:
         return eb
 
     @staticmethod
+    def _others_signature(block, input_others):
+        """what else changes the arithmetic between two blocks of one class: whether a mask is among the inputs (the attention then
+        takes another kernel) and per-layer attributes such as the layer type of hybrid (sliding / full attention) stacks"""
+        mask = (input_others or {}).get("attention_mask") if isinstance(input_others, dict) else None
+        return (mask is not None, str(getattr(block, "attention_type", getattr(getattr(block, "self_attn", None), "layer_type", ""))),
+                getattr(getattr(block, "self_attn", None), "sliding_window", None) is not None)
+
+    @staticmethod
+    def _report_fused_verdict(block, fused, ok):
+        import warnings
+
+        from .fused_block import LLAMA_FAMILY, MOE_FAMILY, OPT_FAMILY
+
+        d = getattr(fused, "last_disagreement", None)
+        if not ok and type(block).__name__ in LLAMA_FAMILY + OPT_FAMILY + MOE_FAMILY:
+            warnings.warn(f"fused block path: {type(block).__name__} is on the class whitelist but its fused form does not agree with the "
+                          f"module code on the check minibatch (distance / block contribution = {d}); every block of this kind keeps "
+                          f"the module path")
+
+    @staticmethod
     def _block_signature(block):
         """What decides whether a fused form computes the block's function: the classes involved, the scheme-relevant switches and
         whether any submodule carries an instance-level `forward` (a patched module)."""
@@ -711,7 +732,11 @@ class SignRoundQuantizer:
             ops.best_loss_update(total_loss, state, istate, 0, iter_dev=it_dev, loss_hist=loss_hist)
             optimizer.step()
 
-        body()                                                          # iteration 0
+        try:
+            body()                                                      # iteration 0
+        except BaseException:
+            optimizer.lr_override = None
+            raise
         flags = [(a, a.wq_fresh, [l._dw_accum[0] for l in a.layers]) for a in arenas]
         prev_prof = ops.profile_enable(False)                           # per-dispatch event pairs cannot be captured
         graph = None
@@ -736,8 +761,8 @@ class SignRoundQuantizer:
                 finally:
                     graph.capture_end()
             torch.cuda.current_stream(device).wait_stream(side)
-        except Exception as e:  # noqa: BLE001 -- any capture failure: the same body runs eagerly instead
-            graph = None
+        except RuntimeError as e:   # a failed capture (an op that synchronises, an allocation outside the pool): the same body runs
+            graph = None            # eagerly instead -- still from the device tables (lr_table / index schedule), as iteration 0 did
             for a, fresh, acc in flags:
                 a.wq_fresh = fresh
                 for l, v in zip(a.layers, acc):
@@ -746,12 +771,14 @@ class SignRoundQuantizer:
         finally:
             ops.profile_enable(prev_prof)
         self.last_hip_graph = graph is not None
-        for _ in range(1, iters):
-            if graph is not None:
-                graph.replay()
-            else:
-                body()
-        optimizer.lr_override = None
+        try:
+            for _ in range(1, iters):
+                if graph is not None:
+                    graph.replay()
+                else:
+                    body()
+        finally:
+            optimizer.lr_override = None    # (also when a replay raises: the optimizer must not keep pointing at this block's tables)
         self._last_graph = graph            # (kept until the next block: replays may still be in flight)
         return iters
 
@@ -785,10 +812,11 @@ class SignRoundQuantizer:
             if fb is not None:
                 fb.flash_fwd = bool(self.config.flash_attention)
                 fb.flash_bwd = bool(self.config.flash_attention_bwd)
-                key = ("plain", self._block_signature(block))
+                key = ("plain", self._block_signature(block), self._others_signature(block, input_others))
                 if key not in self._fused_verdict:
                     self._fused_verdict[key] = fb.agrees_with_module(lambda x, o: self.block_forward(block, x, o),
                                                                      inputs[:min(2, inputs.shape[0])], input_others)
+                    self._report_fused_verdict(block, fb, self._fused_verdict[key])
                 if not self._fused_verdict[key]:
                     fb = None
         outs = []

@@ -130,7 +130,8 @@ def capture_block_inputs(model, block, tokens: torch.Tensor, device, amp_dtype=t
 
 def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw: Optional[dict] = None, iters: int = 200,
                       nsamples: int = 128, seqlen: int = 2048, batch_size: int = 8, fused: bool = False, alg_ext: bool = False,
-                      seed: int = 42, device="cuda:0", graph: Optional[bool] = None, materialise: bool = False, exact: bool = False) -> dict:
+                      seed: int = 42, device="cuda:0", graph: Optional[bool] = None, materialise: bool = False, exact: bool = False,
+                      lr: Optional[float] = None, minmax_lr: Optional[float] = None) -> dict:
     """The plugin-mode flow without the reference around it: same seeded block, same block inputs, targets from the module-path
     forward (what the reference's orchestrator hands to `quantize_block`), `transformers.set_seed(seed)` right before the block
     (the reference's sampler then draws the same minibatches), then `SignRoundQuantizer.quantize_block` -- on the module path
@@ -159,6 +160,8 @@ def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw
     with torch.cuda.device(device):
         y = q_mod.calibrate_block(block, x0, others)              # module path: the targets the reference would hand over
     kw = {} if graph is None else {"hip_graph": bool(graph)}
+    if lr is not None:
+        kw.update(lr=float(lr), minmax_lr=float(minmax_lr if minmax_lr is not None else lr))
     cfg = SignRoundConfig(iters=iters, batch_size=batch_size, bits=sch["bits"], sdpa_backend="auto", fused_block=bool(fused),
                           mfma_dw_gemm=bool(fused), materialise_shared_rows=materialise, exact_rounding=bool(exact), **kw)
     q = q_cls(cfg, device=device)
@@ -281,3 +284,65 @@ def check_against_digest(path: str = DIGEST, fused: bool = False, exact: bool = 
                 init_loss=r["stats"]["init_loss"], init_loss_ref=ref_trace[0], best_loss=r["stats"]["best_loss"], best_loss_ref=min(ref_trace),
                 best_loss_ratio=r["stats"]["best_loss"] / min(ref_trace), first_divergence_iter=trace_divergence(ref_trace, tr),
                 device=m.get("device"), torch=m.get("torch"))
+
+
+# ---- scheme-agnostic digests (round 4): sha256 of every tuned layer's fake-quant weight, scale and zero point ----------------------
+def tuned_layer_tensors(block) -> Dict[str, Dict[str, np.ndarray]]:
+    """name -> {weight (bf16 bits), scale (fp32), zp (fp32 or the scalar)} of every tuned layer of an unwrapped block, in one canonical
+    form for the reference's result and this package's (the packers -- bit-exact against the reference's own `pack` on goldens -- are a
+    pure function of these three)."""
+    out = {}
+    for n, p in block.named_modules():
+        if isinstance(p, torch.nn.Linear) and hasattr(p, "scale"):
+            zp = getattr(p, "zp", None)
+            out[n.replace(".orig_layer", "")] = dict(
+                weight=p.weight.detach().contiguous().cpu().view(torch.int16).numpy(),
+                scale=p.scale.detach().float().reshape(-1).cpu().numpy(),
+                zp=(zp.detach().float().reshape(-1).cpu().numpy() if isinstance(zp, torch.Tensor) else np.asarray([-1.0 if zp is None else float(zp)], dtype=np.float32)))
+    return out
+
+
+def digest_of(tensors: Dict[str, Dict[str, np.ndarray]]) -> Dict[str, str]:
+    return {f"{n}::{k}": hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() for n, d in tensors.items() for k, v in d.items()}
+
+
+FULL_PREFIX = 1 << 16
+
+
+def write_digest_v2(path: str, case: dict, tensors, ref_trace, x_sha: str, y_sha: str, meta_extra: dict, full_layer: Optional[str] = None) -> int:
+    names = sorted(tensors)
+    full = full_layer or min(names, key=lambda n: tensors[n]["weight"].size)
+    meta = dict(format="t3v2", arch=case["arch"], scheme=case["scheme"], scheme_kw=case.get("kw", {}), iters=case["iters"], nsamples=case["nsamples"],
+                seqlen=case["seqlen"], batch_size=case["batch_size"], seed=42, x_sha=x_sha, y_sha=y_sha, digests=digest_of(tensors),
+                full_layer=full, layers=names, **meta_extra)
+    # (one layer's first FULL_PREFIX values in full: a fraction to look at if the hashes ever differ, a few hundred KB)
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), loss_trace=np.asarray(ref_trace, dtype=np.float64),
+                        **{f"{full}::{k}": np.ascontiguousarray(v).reshape(-1)[:FULL_PREFIX] for k, v in tensors[full].items()})
+    return os.path.getsize(path)
+
+
+def check_against_digest_v2(path: str, fused: bool = False, exact: bool = False) -> dict:
+    """Re-tune the digest's block (any scheme: W2G32 asym + algorithm extension, MXFP4, NVFP4 ...) with this package, reference-free,
+    and compare every tuned layer's fake-quant weight / scale / zero point with what the REAL reference produced on an MI355X."""
+    z = np.load(path, allow_pickle=False)
+    m = json.loads(str(z["meta"]))
+    kw = dict(m.get("scheme_kw") or {})
+    alg_ext = bool(kw.pop("enable_alg_ext", False))
+    lr, mmlr = kw.pop("lr", None), kw.pop("minmax_lr", None)
+    r = tune_with_product(m["arch"], scheme=m["scheme"], scheme_kw=kw, iters=m["iters"], nsamples=m["nsamples"], seqlen=m["seqlen"],
+                          batch_size=m["batch_size"], fused=fused, seed=m["seed"], exact=exact, alg_ext=alg_ext, lr=lr, minmax_lr=mmlr)
+    mine = tuned_layer_tensors(r["block"])
+    got = digest_of(mine)
+    differing = sorted(k for k, want in m["digests"].items() if got.get(k) != want)
+    full = m["full_layer"]
+    want_w = z[f"{full}::weight"].reshape(-1)
+    same_w = float((mine[full]["weight"].reshape(-1)[:want_w.size] == want_w).mean()) if full in mine else 0.0
+    ref_trace = [float(x) for x in z["loss_trace"]]
+    tr = r["loss_trace"] or []
+    return dict(case=os.path.basename(path), fused_block=r["fused_block"], exact_block=r["exact_block"], exact_plan=(r["exact_report"] or {}).get("plan"),
+                inputs_identical=(r["x_sha"] == m["x_sha"]), targets_identical=(r["y_sha"] == m["y_sha"]), tensors=len(m["digests"]),
+                tensors_identical=len(m["digests"]) - len(differing), bit_identical=(not differing and sorted(mine) == sorted(m["layers"])),
+                differing=differing[:6], full_layer=full, full_layer_identical_weights=same_w, init_loss=r["stats"]["init_loss"],
+                init_loss_ref=ref_trace[0], best_loss=r["stats"]["best_loss"], best_loss_ref=min(ref_trace),
+                best_loss_ratio=r["stats"]["best_loss"] / min(ref_trace), first_divergence_iter=trace_divergence(ref_trace, tr),
+                tune_s=r["tune_s"], device=m.get("device"), torch=m.get("torch"))

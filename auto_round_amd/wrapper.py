@@ -197,12 +197,15 @@ def nv_static_plan(layer, device):
 
 
 def _nv_gscale_tensor(value: float, device) -> torch.Tensor:
-    key = (torch.device(device).index, value)
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:        # a bare "cuda": the CURRENT device, which set_device may have changed
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, value)
     t = _nv_gs_dev.get(key)
     if t is None:
         if len(_nv_gs_dev) > 4096:
             _nv_gs_dev.clear()
-        t = _nv_gs_dev[key] = torch.tensor([value], dtype=torch.float32, device=device)
+        t = _nv_gs_dev[key] = torch.tensor([value], dtype=torch.float32, device=dev)
     return t
 
 

@@ -49,6 +49,15 @@ BIG_CASES = {
     # (c) BASELINE configs[2] scheme at real width
     "llama8b_w2g32_asym_algext": dict(arch="llama8b", scheme="W2A16G32", kw=dict(sym=False, enable_alg_ext=True), iters=50,
                                       nsamples=32, seqlen=2048, batch_size=8),
+    # ---- round 4: enough iterations to move, the configs' own learning rates, digests for the driver-side tests
+    # configs[2]: 200 of its 1000 iterations at ITS learning rate (2 / 1000, what iters=1000 at 2 bits selects: sign_round/config.py:110-140)
+    "llama8b_w2g32_asym_algext_200": dict(arch="llama8b", scheme="W2A16G32", kw=dict(sym=False, enable_alg_ext=True, lr=2e-3, minmax_lr=2e-3),
+                                          iters=200, nsamples=64, seqlen=2048, batch_size=8),
+    "llama8b_mxfp4_200": dict(arch="llama8b", scheme="MXFP4", kw={}, iters=200, nsamples=64, seqlen=2048, batch_size=8),
+    "llama8b_nvfp4_200": dict(arch="llama8b", scheme="NVFP4", kw={}, iters=200, nsamples=64, seqlen=2048, batch_size=8),
+    # configs[4] itself with a learning rate that lets the trajectory move (1 / 200) and 64 samples
+    "mixtral8x7b_mxfp4_100": dict(arch="mixtral8x7b", scheme="MXFP4", kw=dict(lr=5e-3, minmax_lr=5e-3), iters=100, nsamples=64, seqlen=2048,
+                                  batch_size=8),
 }
 
 
@@ -320,7 +329,7 @@ def write_digest(path, case, layers, ref_trace, spy_rec, meta_extra, full_layer=
     return os.path.getsize(path)
 
 
-def run_big_case(name, fixture_path=None, skip_alone=False, digest_path=None, ref_twice=False):
+def run_big_case(name, fixture_path=None, skip_alone=False, digest_path=None, ref_twice=False, digest_v2_path=None):
     import_reference()
     from auto_round import AutoRound
     from t3_compare import _LossProbe
@@ -353,6 +362,7 @@ def run_big_case(name, fixture_path=None, skip_alone=False, digest_path=None, re
         torch.cuda.synchronize()
         rec["ref_wall_s"] = time.perf_counter() - t0
         L_ref = _snapshot(q_ref)
+        q_ref_model_holder = [q_ref] if digest_v2_path else []          # (kept on the GPU until the digest is written)
         del q_ref
         _free()
         ref_trace = probe.traces[0] if probe.traces else []
@@ -366,20 +376,31 @@ def run_big_case(name, fixture_path=None, skip_alone=False, digest_path=None, re
             del q_ref2
             _free()
 
-        # ---- (module) / (fused): the plugin behind the same front door
-        for tag, fused in (("module", False), ("fused", True)):
+        lr_kw = {k: case["kw"][k] for k in ("lr", "minmax_lr") if k in case["kw"]}
+        if digest_v2_path:      # written first: a failure further down must not lose the reference's result
+            from auto_round_amd.testing.t3_fixture import decoder_blocks, tuned_layer_tensors, write_digest_v2
+
+            sz = write_digest_v2(digest_v2_path, case, tuned_layer_tensors(decoder_blocks(q_ref_model_holder[0])[0]), ref_trace, spy.rec["x_sha"],
+                                 spy.rec["y_sha"], dict(device=torch.cuda.get_device_name(0), torch=torch.__version__,
+                                                        made_by="tests/t3_baseline_shapes.py: the reference's AutoRound(...).quantize() on cuda:0"))
+            rec["digest_v2"] = dict(path=os.path.relpath(digest_v2_path, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), bytes=sz)
+        q_ref_model_holder.clear()
+        _free()
+        # ---- (module) / (fused) / (exact): the plugin behind the same front door
+        for tag, fused, exact in (("module", False, False), ("fused", True, False), ("exact", False, True)):
             stats = []
             orig_qb = product.SignRoundQuantizer.quantize_block
 
             def spy_qb(self, *a, **k):
                 out = orig_qb(self, *a, **k)
-                stats.append(dict(self.last_stats, fused_block=bool(self.last_fused_block)))
+                stats.append(dict(self.last_stats, fused_block=bool(self.last_fused_block), exact_block=bool(self.last_exact),
+                                  exact_plan=(self.last_exact_report or {}).get("plan") if self.last_exact else None))
                 return out
 
             product.SignRoundQuantizer.quantize_block = spy_qb
             t0 = time.perf_counter()
             try:
-                q_hip, _ = AutoRound(copy.deepcopy(base), alg_configs=Cfg(iters=iters, fused_block=fused), **common).quantize()
+                q_hip, _ = AutoRound(copy.deepcopy(base), alg_configs=Cfg(iters=iters, fused_block=fused, exact_rounding=exact, **lr_kw), **common).quantize()
             finally:
                 product.SignRoundQuantizer.quantize_block = orig_qb
             torch.cuda.synchronize()
@@ -398,7 +419,7 @@ def run_big_case(name, fixture_path=None, skip_alone=False, digest_path=None, re
             if tag == "module":
                 L_mod = L_hip
             else:
-                rec["fused_vs_module"] = compare_layers(L_mod, L_hip)
+                rec[f"{tag}_vs_module"] = compare_layers(L_mod, L_hip)
 
         # ---- (alone): the reference-free flow of the driver-side test
         if digest_path:
@@ -412,16 +433,17 @@ def run_big_case(name, fixture_path=None, skip_alone=False, digest_path=None, re
                                     made_by="tests/t3_baseline_shapes.py: the reference's AutoRound(...).quantize() on cuda:0"))
             rec["fixture"] = dict(path=os.path.relpath(fixture_path, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), bytes=sz)
         if not skip_alone:
-            for tag, fused in (("alone_module", False), ("alone_fused", True)):
-                a = fx.tune_with_product(case["arch"], scheme=case["scheme"], scheme_kw={k: v for k, v in case["kw"].items() if k != "enable_alg_ext"},
+            for tag, fused, exact in (("alone_module", False, False), ("alone_fused", True, False), ("alone_exact", False, True)):
+                a = fx.tune_with_product(case["arch"], scheme=case["scheme"],
+                                         scheme_kw={k: v for k, v in case["kw"].items() if k not in ("enable_alg_ext", "lr", "minmax_lr")},
                                          iters=iters, nsamples=case["nsamples"], seqlen=case["seqlen"], batch_size=case["batch_size"],
-                                         fused=fused, alg_ext=bool(case["kw"].get("enable_alg_ext")))
+                                         fused=fused, exact=exact, alg_ext=bool(case["kw"].get("enable_alg_ext")), **lr_kw)
 
                 L_al = {}
                 for n, p in a["block"].named_modules():
                     if isinstance(p, torch.nn.Linear) and hasattr(p, "scale"):
                         L_al[n.replace(".orig_layer", "")] = p
-                r = dict(stats=a["stats"], fused_block=a["fused_block"], hip_graph=a["hip_graph"], inputs_identical=a["x_sha"] == spy.rec["x_sha"],
+                r = dict(stats=a["stats"], fused_block=a["fused_block"], exact_block=a["exact_block"], tune_s=a["tune_s"], hip_graph=a["hip_graph"], inputs_identical=a["x_sha"] == spy.rec["x_sha"],
                          targets_identical=a["y_sha"] == spy.rec["y_sha"], others_keys=a["others_keys"],
                          first_divergence_iter=fx.trace_divergence(ref_trace, a["loss_trace"] or []), loss_trace=a["loss_trace"])
                 r.update(compare_layers(L_ref, L_al))
@@ -448,6 +470,7 @@ def main():
     ap.add_argument("--skip-alone", action="store_true")
     ap.add_argument("--digest", default=None, help="write the digest fixture of llama8b_w4g128_full here")
     ap.add_argument("--ref-twice", default="", help="cases whose reference run is repeated (reproducibility of the reference itself)")
+    ap.add_argument("--digest-dir", default=None, help="write a scheme-agnostic digest t3v2_<case>.npz of every dense case's reference result here")
     args = ap.parse_args()
     if reference_root() is None:
         raise SystemExit("reference tree not present: run tools/stage_reference.sh first")
@@ -456,7 +479,9 @@ def main():
         try:
             r = run_big_case(c, fixture_path=os.path.abspath(args.fixture) if (args.fixture and c == "opt125m_w4g128") else None,
                              skip_alone=args.skip_alone, digest_path=os.path.abspath(args.digest) if (args.digest and c == "llama8b_w4g128_full") else None,
-                             ref_twice=c in args.ref_twice.split(","))
+                             ref_twice=c in args.ref_twice.split(","),
+                             digest_v2_path=(os.path.join(os.path.abspath(args.digest_dir), f"t3v2_{c}.npz")
+                                             if (args.digest_dir and BIG_CASES[c]["arch"] == "llama8b") else None))
         except Exception as e:
             import traceback
 

@@ -1,0 +1,217 @@
+"""`exact_rounding` on the GPU: csrc/ar_exact.hip against the eager op chains it stands for -- transformers' own modules under torch
+autograd ON THE SAME DEVICE, which is what the reference computes when it runs here -- bit for bit, and ExactLlamaBlock against the
+module path (block output, every weight gradient, then whole tuned blocks).  The kernels are called through the C ABI (ops.*_exact).
+The oracle for this file is torch itself: the reference's arithmetic for these ops IS torch's eager kernels."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def bits(t):
+    return t.contiguous().view({2: torch.int16, 4: torch.int32}[t.element_size()])
+
+
+def same(a, b):
+    return a.shape == b.shape and bool(torch.equal(bits(a), bits(b)))
+
+
+def gen(seed=0):
+    return torch.Generator(device=DEV).manual_seed(seed)
+
+
+# (rows, hidden): short rows, a non-power-of-two row (Qwen2-7B), Llama-3-8B's minibatch, rows ATen splits over 8 thread-rows (70B)
+@pytest.mark.parametrize("T,H", [(64, 256), (128, 768), (2048, 3584), (16384, 4096), (4096, 8192), (512, 8320)])
+def test_rmsnorm_forward_and_backward_have_eager_torchs_bits(T, H):
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+
+    from auto_round_amd import ops
+
+    g = gen(T + H)
+    norm = LlamaRMSNorm(H, 1e-5).to(BF).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(H, device=DEV, generator=g))
+    w = norm.weight.detach()
+    x = torch.randn(T, H, device=DEV, generator=g).to(BF)
+    r = (0.5 * torch.randn(T, H, device=DEV, generator=g)).to(BF)
+    dy = (0.01 * torch.randn(T, H, device=DEV, generator=g)).to(BF)
+    dres = (0.01 * torch.randn(T, H, device=DEV, generator=g)).to(BF)
+    s = x + r                                                   # the residual add, its own eager op
+    sl = s.detach().requires_grad_(True)
+    y = norm(sl.view(1, T, H))
+    y.backward(dy.view(1, T, H))
+    rstd_t = torch.rsqrt(s.float().pow(2).mean(-1, keepdim=True) + 1e-5).view(-1)
+
+    y2, rstd, s2 = ops.rmsnorm_fwd_exact(x, w, 1e-5, res=r)
+    assert same(s2, s)
+    assert same(ops.rmsnorm_fwd_exact(s, w, 1e-5, raw_sum=True)[1], s.float().pow(2).sum(-1))      # ATen's reduction order
+    assert same(rstd, rstd_t)                                    # fp32 row statistics: mean factor, eps, torch's rsqrt
+    assert same(y2, y.detach().view(T, H))
+    assert same(ops.rmsnorm_bwd_exact(dy, s2, w, rstd), sl.grad)
+    assert same(ops.rmsnorm_bwd_exact(dy, s2, w, rstd, dres=dres), sl.grad + dres)
+
+
+def test_rmsnorm_exact_refuses_what_it_does_not_mirror():
+    from auto_round_amd import ops
+
+    w = torch.ones(128, dtype=BF, device=DEV)
+    assert ops.rmsnorm_fwd_exact(torch.zeros(64, 128, dtype=BF, device=DEV), w, 1e-5) is None            # short rows: another ATen path
+    w = torch.ones(512, dtype=BF, device=DEV)
+    assert ops.rmsnorm_fwd_exact(torch.zeros(4, 512, dtype=BF, device=DEV), w, 1e-5) is None             # < 8 rows: a wider thread row
+
+
+@pytest.mark.parametrize("B,S,hq,hkv,d", [(2, 128, 4, 2, 64), (8, 2048, 32, 8, 128), (1, 256, 8, 8, 96)])
+def test_rotary_forward_and_backward_have_eager_torchs_bits(B, S, hq, hkv, d):
+    from transformers.models.llama.modeling_llama import apply_rotary_pos_emb
+
+    from auto_round_amd import ops
+
+    if d % 16:
+        pytest.skip("head size must be a multiple of 16")
+    g = gen(S + d)
+    T = B * S
+    q = torch.randn(T, hq * d, device=DEV, generator=g).to(BF)
+    k = torch.randn(T, hkv * d, device=DEV, generator=g).to(BF)
+    ang = torch.rand(1, S, d, device=DEV, generator=g) * 6.28
+    cos, sin = ang.cos().to(BF).contiguous(), ang.sin().to(BF).contiguous()
+    ql = q.view(B, S, hq, d).transpose(1, 2).detach().requires_grad_(True)
+    kl = k.view(B, S, hkv, d).transpose(1, 2).detach().requires_grad_(True)
+    qr, kr = apply_rotary_pos_emb(ql, kl, cos, sin)
+    gq = torch.randn(B, hq, S, d, device=DEV, generator=g).to(BF)
+    gk = torch.randn(B, hkv, S, d, device=DEV, generator=g).to(BF)
+    dq, dk = torch.autograd.grad((qr, kr), (ql, kl), (gq, gk))
+    tok = lambda t: t.transpose(1, 2).reshape(T, -1)  # noqa: E731
+
+    q2, k2 = ops.rope_fwd_exact(q, k, cos, sin, S, hq, hkv, d)
+    assert same(q2, tok(qr.detach())) and same(k2, tok(kr.detach()))
+    # column slices of a merged projection as inputs
+    qkv = torch.cat([q, k, k], dim=1).contiguous()
+    q3, k3 = ops.rope_fwd_exact(qkv[:, :hq * d], qkv[:, hq * d:(hq + hkv) * d], cos, sin, S, hq, hkv, d)
+    assert same(q3, q2) and same(k3, k2)
+    dq2, dk2 = ops.rope_bwd_exact(gq, gk, cos, sin, S, d)
+    assert same(dq2, tok(dq)) and same(dk2, tok(dk))
+    # token-major strides (what the flash backward leaves) and a merged gradient buffer as the destination
+    merged = torch.empty(T, (hq + 2 * hkv) * d, dtype=BF, device=DEV)
+    ops.rope_bwd_exact(gq.transpose(1, 2).contiguous().transpose(1, 2), gk, cos, sin, S, d,
+                       out=(merged[:, :hq * d], merged[:, hq * d:(hq + hkv) * d]))
+    assert same(merged[:, :hq * d], tok(dq)) and same(merged[:, hq * d:(hq + hkv) * d], tok(dk))
+
+
+def test_swiglu_forward_is_eager_torch_for_every_bf16_gate_value_and_backward_matches_autograd():
+    from auto_round_amd import ops
+
+    g = gen(7)
+    allb = torch.arange(65536, device=DEV, dtype=torch.int32).to(torch.int16).view(BF)
+    allb = allb[torch.isfinite(allb.float())]
+    n = allb.numel() // 8 * 8
+    gate = allb[:n].repeat(64, 1).contiguous()
+    up = torch.randn(64, n, device=DEV, generator=g).to(BF)
+    da = torch.randn(64, n, device=DEV, generator=g).to(BF)
+    gl, ul = gate.clone().requires_grad_(True), up.clone().requires_grad_(True)
+    a = torch.nn.functional.silu(gl) * ul
+    dgl, dul = torch.autograd.grad(a, (gl, ul), da)
+    assert same(ops.swiglu_fwd_exact(gate, up), a.detach())
+    ok = []
+    for contract in (True, False):                      # one of the two forms of silu_backward's inner expression is ATen's
+        dg, du = ops.swiglu_bwd_exact(da, gate, up, contract=contract)
+        assert same(du, dul)
+        ok.append(same(dg, dgl))
+    assert any(ok), ok
+    # realistic magnitudes, the halves of a merged gradient buffer as the destination, column slices of a merged projection as input
+    F_ = 14336
+    gu = torch.randn(2048, 2 * F_, device=DEV, generator=g).to(BF)
+    da = (0.01 * torch.randn(2048, F_, device=DEV, generator=g)).to(BF)
+    gl, ul = gu[:, :F_].clone().requires_grad_(True), gu[:, F_:].clone().requires_grad_(True)
+    a = torch.nn.functional.silu(gl) * ul
+    dgl, dul = torch.autograd.grad(a, (gl, ul), da)
+    assert same(ops.swiglu_fwd_exact(gu[:, :F_], gu[:, F_:]), a.detach())
+    dgu = torch.empty_like(gu)
+    ops.swiglu_bwd_exact(da, gu[:, :F_], gu[:, F_:], contract=ok[0], out=(dgu[:, :F_], dgu[:, F_:]))
+    assert same(dgu[:, :F_], dgl) and same(dgu[:, F_:], dul)
+
+
+# ---- the block ---------------------------------------------------------------------------------------------------------------
+def _small_llama(hidden=512, inter=1024, heads=4, kv=2, seq=256, nsamples=16, layers=1, seed=0):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(seed)
+    cfg = LlamaConfig(hidden_size=hidden, intermediate_size=inter, num_attention_heads=heads, num_key_value_heads=kv,
+                      num_hidden_layers=layers, vocab_size=512, max_position_embeddings=1024, tie_word_embeddings=False)
+    cfg._attn_implementation = "sdpa"
+    model = LlamaForCausalLM(cfg).to(BF).eval().to(DEV)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    tokens = torch.randint(0, 512, (nsamples, seq), generator=torch.Generator().manual_seed(1))
+    return model, tokens
+
+
+def _tune(model, tokens, *, exact, with_mask, iters=12, scheme="W4A16", seed=42):
+    import transformers
+
+    from auto_round_amd.autoround import loss_mask_ids
+    from auto_round_amd.export import pack_block
+    from auto_round_amd.quantizer import BlockContext, SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.schemes import apply_scheme, resolve_scheme
+    from auto_round_amd.testing import t3_fixture as fx
+
+    import copy
+
+    model = copy.deepcopy(model)
+    block = fx.decoder_blocks(model)[0]
+    sch = resolve_scheme(scheme)
+    apply_scheme(block, sch)
+    x0, others = fx.capture_block_inputs(model, block, tokens, torch.device(DEV))
+    if not with_mask:
+        others = {k: v for k, v in others.items() if k != "attention_mask"}
+    cfg = SignRoundConfig(iters=iters, batch_size=8, bits=sch["bits"], sdpa_backend="auto", exact_rounding=exact)
+    q = SignRoundQuantizer(cfg, device=DEV)
+    y = q.calibrate_block(block, x0, others)
+    transformers.set_seed(seed)
+    q.quantize_block(block, x0, others, y, None, BlockContext(0, 1, "0"), input_ids=loss_mask_ids(tokens, None))
+    torch.cuda.synchronize()
+    packed = {n: (ql.qweight.clone(), ql.scales.clone(), ql.qzeros.clone()) for n, ql in pack_block(block).items()}
+    return q, packed
+
+
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_exact_block_is_proven_against_the_module_path_and_tunes_to_identical_packed_weights(with_mask):
+    """A small Llama block (hidden 512, GQA, head size 128) through the whole tuning loop twice: module path and exact_rounding.  The plan
+    must have been proven (first-party norm / rotary / SwiGLU kernels in it) and every packed tensor must be identical."""
+    model, tokens = _small_llama()
+    q_mod, packed_mod = _tune(model, tokens, exact=False, with_mask=with_mask)
+    q_ex, packed_ex = _tune(model, tokens, exact=True, with_mask=with_mask)
+    assert not q_mod.last_exact and q_ex.last_exact
+    rep = q_ex.last_exact_report
+    assert rep and rep["usable"], rep
+    plan = rep["plan"]
+    assert plan["norm1"] and plan["norm2"] and plan["rope"] and plan["swiglu"], rep
+    assert q_ex.last_stats["loss_trace"] == q_mod.last_stats["loss_trace"]
+    assert sorted(packed_ex) == sorted(packed_mod)
+    for n in packed_mod:
+        for a, b in zip(packed_ex[n], packed_mod[n]):
+            assert torch.equal(a, b), n
+
+
+def test_exact_plan_is_reused_for_later_blocks_of_the_same_kind_and_refused_for_unsupported_ones():
+    from auto_round_amd.exact_block import ExactLlamaBlock
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.schemes import apply_scheme, resolve_scheme
+    from auto_round_amd.testing import t3_fixture as fx
+
+    model, tokens = _small_llama(layers=2)
+    blocks = fx.decoder_blocks(model)
+    sch = resolve_scheme("W4A16")
+    for b in blocks:
+        apply_scheme(b, sch)
+    x0, others = fx.capture_block_inputs(model, blocks[0], tokens, torch.device(DEV))
+    q = SignRoundQuantizer(SignRoundConfig(iters=3, batch_size=8, bits=4, sdpa_backend="auto", exact_rounding=True), device=DEV)
+    x = x0
+    for b in blocks:
+        fp_out, q_out, _ = q.compress_block(b, x, others)
+        assert q.last_exact
+        x = fp_out
+    assert len(q._exact_plans) == 1                                 # one proof, two blocks
+    # an OPT block is not covered: exact_rounding then means the module path, never the (inexact) fused path
+    assert ExactLlamaBlock.try_build(torch.nn.Linear(4, 4), [], {}) is None
