@@ -1063,8 +1063,25 @@ extern "C" int64_t ar_gemm_dw_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     return r ? (int64_t)r * tns * GB * GB * 4 : 0;
 }
 
+static int gemm_dw_impl(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx, int64_t ldw,
+                        int accumulate, void* workspace, int64_t workspace_bytes, int force_ns, ar_stream_t stream);
+
 extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
                           int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, ar_stream_t stream) {
+    return gemm_dw_impl(dY, X, dW, M, N, K, ldy, ldx, ldw, accumulate, workspace, workspace_bytes, 0, stream);
+}
+
+// nsplit >= 1: every output tile is computed as `nsplit` contiguous K slices (whole 128-row chunks, slice s = chunks s/nsplit ..
+// (s+1)/nsplit) summed in slice order -- the caller chooses the summation structure instead of the launch-shape heuristics
+// (1: one pass over K).  Needs nsplit * M * N * 4 bytes of workspace for nsplit > 1.
+extern "C" int ar_gemm_dw_ex(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
+                             int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, int nsplit, ar_stream_t stream) {
+    if (nsplit < 1 || nsplit > 64) return AR_ERR_UNSUPPORTED;
+    return gemm_dw_impl(dY, X, dW, M, N, K, ldy, ldx, ldw, accumulate, workspace, workspace_bytes, nsplit, stream);
+}
+
+static int gemm_dw_impl(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx, int64_t ldw,
+                        int accumulate, void* workspace, int64_t workspace_bytes, int force_ns, ar_stream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return AR_OK;
     if (M % GB || N % GB || K < GD * GU || (ldy % 8) || (ldx % 8) || (ldw % 4)) return AR_ERR_UNSUPPORTED;
     if (K % 128 && g_gemm_kernel != 7) return AR_ERR_UNSUPPORTED;       // only the default kernel completes a ragged K with zeros
@@ -1105,7 +1122,9 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
                 (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
                 (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
             }
-            const int ns = splitk_plan(M, N, K);
+            const int ns = force_ns > 0 ? force_ns : splitk_plan(M, N, K);
+            if (force_ns > 1 && !(workspace && workspace_bytes >= (int64_t)ns * M * N * 4 && (ldw % 8) == 0 && !((uintptr_t)dW & 15) && K / 128 >= ns))
+                return AR_ERR_UNSUPPORTED;          // a forced structure is either delivered or refused, never silently replaced
             if (ns > 1 && workspace && workspace_bytes >= (int64_t)ns * M * N * 4 && (ldw % 8) == 0 && !((uintptr_t)dW & 15)) {
                 a.ws = (float*)workspace; a.nsplit = ns;
                 if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, true, true>), grid * ns, GTHREADS, GEMM_LDS, st, a);
@@ -1115,7 +1134,7 @@ extern "C" int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, in
                 return launch_status();
             }
             int tns = 1;
-            const int rtail = (K % 128 == 0 && g_gemm_tail) ? tail_plan(M, N, K, &tns) : 0;
+            const int rtail = (K % 128 == 0 && g_gemm_tail && force_ns == 0) ? tail_plan(M, N, K, &tns) : 0;
             if (rtail && workspace && workspace_bytes >= (int64_t)rtail * tns * GB * GB * 4 && (ldw % 8) == 0 && !((uintptr_t)dW & 15)) {
                 // full rounds with the whole K, then the last (partial) round split along K, then its slices summed in order
                 AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true>), grid - rtail, GTHREADS, GEMM_LDS, st, a);

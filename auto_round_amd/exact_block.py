@@ -35,7 +35,8 @@ from .fused_block import LLAMA_FAMILY, FusedLlamaBlock, _FusedBlockFn, _class_in
 KERNEL_OPTS = ("norm1", "norm2", "rope", "swiglu")
 # GEMM forms that may be faster than the module path's and may or may not be bit-equal to it: input-gradient GEMMs through a
 # transposed weight copy (tn_*), weight-gradient GEMMs on the MFMA kernel -- merged over q/k/v and gate/up (one launch, the
-# elementwise backward kernels write straight into the merged gradient buffer) or per layer -- and merged forward GEMMs
+# elementwise backward kernels write straight into the merged gradient buffer) or per layer; plan value 1 = one pass over K,
+# n >= 2 = n contiguous K slices summed in order (whichever reproduces the library's result for the shape) -- and merged forward GEMMs
 GEMM_OPTS = ("tn_o", "tn_g", "tn_u", "tn_d", "dw_qkv", "dw_gu", "dw_q", "dw_k", "dw_v", "dw_o", "dw_g", "dw_u", "dw_d", "merged_qkv", "merged_gu")
 # measured at Llama-3-8B's minibatch (profiles/r04_exact_probe.json): the merged forward GEMMs are bit-equal but not faster than
 # the separate ones (0.64 vs 0.62 ms, 2.57 vs 2.46 ms), so the plan does not ask for them unless told to
@@ -122,8 +123,9 @@ class ExactLlamaBlock(FusedLlamaBlock):
             out2d = lyrs[0].weight_grad
         acc = lyrs[0]._dw_accum[0]
         done = False
-        if self.plan.get("dw_" + key) and out2d.is_contiguous():
-            done = ops.gemm_dw(dY2d, X2d, out2d, accumulate=acc, split=False)
+        mode = int(self.plan.get("dw_" + key) or 0)         # 0: library; 1: MFMA kernel, one pass over K; n >= 2: n contiguous K slices
+        if mode and out2d.is_contiguous():
+            done = ops.gemm_dw(dY2d, X2d, out2d, accumulate=acc, split=(False if mode == 1 else mode))
         if not done:
             if acc:
                 out2d.addmm_(dY2d.t(), X2d)
@@ -406,6 +408,11 @@ class ExactLlamaBlock(FusedLlamaBlock):
             trial = dict(plan)
             trial[opt] = True
             variants = [trial]
+            if opt.startswith("dw_"):
+                # the library's kernel for a shape may itself split K (hipBLASLt picks a global split by launch shape: Llama-3-8B's
+                # 14336 x 4096 weight gradients are 896 tiles = 3.5 rounds of 256 CUs, and two K slices make it 7 full rounds): try
+                # the same structures -- one pass, then 2 / 3 / 4 contiguous slices summed in order
+                variants = [dict(trial, **{opt: n}) for n in (1, 2, 3, 4)]
             if opt == "swiglu":
                 variants.append(dict(trial, swiglu_contract=False))
             if opt in ("norm1", "norm2") and not (plan["norm1"] or plan["norm2"]):
@@ -420,5 +427,5 @@ class ExactLlamaBlock(FusedLlamaBlock):
                     break
         self.set_plan(plan)
         reset()
-        self.plan_report = dict(report, usable=True, plan={k: bool(v) for k, v in plan.items()})
+        self.plan_report = dict(report, usable=True, plan={k: (int(v) if k.startswith("dw_") else bool(v)) for k, v in plan.items()})
         return plan

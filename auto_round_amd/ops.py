@@ -689,9 +689,10 @@ _gemm_ws: dict = {}
 def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate: bool = False, split: bool = True) -> bool:
     """out[M,N] (+)= dY2d[K,M]^T @ X2d[K,N] through the hand-written MFMA kernel (bf16, fp32 accumulate).  Operands may be
     column slices of wider row-major buffers (unit inner stride).  -> False when the shape / alignment is outside what the
-    kernel takes (the caller then keeps the library GEMM); raises on a failed launch.  split=False: no workspace is handed over,
-    so every output element is ONE pass over K in token order (no split-K partial sums): the summation order the exact_rounding
-    plan compares with the library's."""
+    kernel takes (the caller then keeps the library GEMM); raises on a failed launch.  split: True = the kernel's own launch-shape
+    plans (split-K for few tiles, a split last round); False or 1 = every output element is ONE pass over K in token order; an int
+    n >= 2 = exactly n contiguous K slices summed in slice order (ar_gemm_dw_ex) -- the summation structures the exact_rounding plan
+    compares with the library's."""
     if dY2d.dtype != torch.bfloat16 or X2d.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
         return False
     if dY2d.dim() != 2 or X2d.dim() != 2 or out.dim() != 2 or dY2d.stride(1) != 1 or X2d.stride(1) != 1 or out.stride(1) != 1:
@@ -708,7 +709,8 @@ def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate
     if len(devs) != 1:
         raise _lib.Mi355xLibraryError("gemm_dw: tensors live on different HIP devices")
     (dev,) = devs
-    ws_bytes = load().ar_gemm_dw_workspace_bytes(M, N, K) if split else 0
+    forced = 0 if split is True else (1 if split is False else int(split))
+    ws_bytes = load().ar_gemm_dw_workspace_bytes(M, N, K) if forced == 0 else (forced * M * N * 4 if forced > 1 else 0)
     ws = None
     if ws_bytes > 0:                # split-K partial tiles: one growing scratch buffer per device, reused by every call
         ws = _gemm_ws.get(dev)
@@ -716,9 +718,14 @@ def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=f"cuda:{dev}")
             _gemm_ws[dev] = ws
     with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
-        rc = load().ar_gemm_dw(dY2d.data_ptr(), X2d.data_ptr(), out.data_ptr(), M, N, K, dY2d.stride(0), X2d.stride(0), out.stride(0),
-                               int(bool(accumulate)), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
-                               torch.cuda.current_stream(dev).cuda_stream)
+        if forced:
+            rc = load().ar_gemm_dw_ex(dY2d.data_ptr(), X2d.data_ptr(), out.data_ptr(), M, N, K, dY2d.stride(0), X2d.stride(0), out.stride(0),
+                                      int(bool(accumulate)), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), forced,
+                                      torch.cuda.current_stream(dev).cuda_stream)
+        else:
+            rc = load().ar_gemm_dw(dY2d.data_ptr(), X2d.data_ptr(), out.data_ptr(), M, N, K, dY2d.stride(0), X2d.stride(0), out.stride(0),
+                                   int(bool(accumulate)), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
+                                   torch.cuda.current_stream(dev).cuda_stream)
     if rc == _lib.AR_ERR_UNSUPPORTED:
         return False
     check(rc, "ar_gemm_dw")

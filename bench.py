@@ -50,6 +50,8 @@ WORKLOADS = {
                       desc="Llama-3-8B decoder block, W4 group_size=128 sym (BASELINE.json configs[1])"),
     "llama3-70b": dict(hidden=8192, ffn=28672, heads=64, kv=8, family="llama",
                        desc="Llama-3-70B decoder block, W4 group_size=128 sym (configs[3], one block per step)"),
+    "llama-tiny": dict(hidden=512, ffn=1024, heads=4, kv=2, family="llama",
+                       desc="a small Llama-shaped block (hidden 512, GQA 4/2, head size 128) for the test suite -- not a BASELINE config"),
     "opt-125m": dict(hidden=768, ffn=3072, heads=12, kv=12, family="opt",
                      desc="OPT-125M decoder block, W4 group_size=128 sym (BASELINE.json configs[0])"),
     "mixtral-8x7b": dict(hidden=4096, ffn=14336, heads=32, kv=8, family="moe", experts=8, top_k=2,

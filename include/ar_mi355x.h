@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 19
+#define AR_ABI_VERSION 20
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -348,6 +348,13 @@ int ar_swiglu_bwd_exact(const void* da, const void* g, int64_t ldg, const void* 
  *           caller keeps the library GEMM.  Needs 128 KB of dynamic LDS per workgroup. */
 int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
                int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, ar_stream_t stream);
+/* The same GEMM with the summation structure chosen by the caller: nsplit = 1 is one pass over K in token order, nsplit >= 2 splits
+ * K into that many contiguous slices of whole 128-row chunks whose fp32 partial tiles (workspace: nsplit * M * N * 4 bytes) are
+ * summed in slice order.  exact_rounding (auto_round_amd/exact_block.py) uses it to reproduce, bit for bit, the weight gradient
+ * the library GEMM behind torch autograd's `grad_output.t().mm(input)` (auto_round/wrapper.py:528-556) returns for a shape --
+ * whichever structure proves equal on the installed stack.  A structure that cannot be delivered returns AR_ERR_UNSUPPORTED. */
+int ar_gemm_dw_ex(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
+                  int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, int nsplit, ar_stream_t stream);
 /* caller-owned scratch ar_gemm_dw wants for (M, N, K) (the library never allocates): 0 when the output tiles alone fill the
  * chip; otherwise the fp32 partial tiles of its split-K form (few tiles, deep K -- e.g. OPT-125M's 768x768 weight against 16384
  * tokens), which are summed in slice order, i.e. deterministically.  Without the workspace the call still works, unsplit. */

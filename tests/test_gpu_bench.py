@@ -53,3 +53,34 @@ def test_two_ranks_run_the_sharded_pipeline():
     assert mg["world_size"] == 2 and [r["rank"] for r in mg["ranks"]] == [0, 1] and all(r["device"] for r in mg["ranks"])
     assert mg["blocks_tuned_per_rank"] == [2, 2] and mg["calibration_broadcast"]["GBps"] > 0
     assert "roofline" in d and d["roofline"]["launches"] > 0          # rank 0's own K1 dispatches
+
+
+TINY_LLAMA = ["--workload", "llama-tiny", "--iters", "4", "--nsamples", "16", "--seqlen", "128", "--batch-size", "4", "--no-cpu-baseline"]
+
+
+def test_default_path_is_exact_rounding_under_the_calibration_mask_and_says_so():
+    """bench.py's defaults: the bit-identical path (`exact_rounding`, proven against the module code before the timed region) under the
+    reference's calibration mask; the line names the path, the mask and the proven plan under `config` (a key the driver keeps)."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-extras"] + TINY_LLAMA, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    c = _last_json(r.stdout)["config"]
+    assert c["path"] == "exact" and c["exact_rounding"] is True and c["fused_block"] is False
+    assert c["attention_mask"].startswith("calibration") and c["sdpa_backend"] == "auto"
+    plan = c["exact_plan"]
+    assert plan["norm1"] and plan["norm2"] and plan["rope"] and plan["swiglu"], plan
+
+
+def test_two_ranks_shard_blocks_on_the_exact_path():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, AR_BENCH_ONE_DEVICE_DEBUG="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"] + TINY_LLAMA
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["path"] == "exact" and d["config"]["exact_rounding"] is True
+    assert d["multi_gpu"]["blocks_tuned_per_rank"] == [2, 2]

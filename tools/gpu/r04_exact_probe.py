@@ -184,6 +184,25 @@ def stage_gemms():
     return out
 
 
+def stage_dw_split():
+    """the library's weight-gradient GEMM vs the MFMA kernel with n contiguous K slices, at the shapes the one-pass form misses"""
+    out = {}
+    g = torch.Generator(device=DEV).manual_seed(2)
+    T, H, Fd = 16384, 4096, 14336
+    for name, (o, i) in dict(g=(Fd, H), d=(H, Fd), o=(H, H), big70b=(28672, 8192)).items():
+        dY = (0.01 * torch.randn(T, o, device=DEV, generator=g)).to(BF)
+        X = torch.randn(T, i, device=DEV, generator=g).to(BF)
+        ref = torch.mm(dY.t(), X)
+        rec = dict(ms_lib=timed(lambda: torch.mm(dY.t(), X)))
+        for n in (1, 2, 3, 4, 7, 8):
+            mine = torch.empty_like(ref)
+            ok = ops.gemm_dw(dY, X, mine, split=(False if n == 1 else n))
+            rec[f"slices_{n}"] = dict(**diff(mine, ref), ms=timed(lambda: ops.gemm_dw(dY, X, mine, split=(False if n == 1 else n)))) if ok else "refused"
+        out[f"dw_{name}"] = rec
+        del dY, X, ref, mine
+    return out
+
+
 def build_llama8b(nsamples=16, seqlen=2048):
     from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
     from auto_round_amd.schemes import apply_scheme, resolve_scheme
@@ -273,7 +292,7 @@ def main():
     ap.add_argument("--out", default="gpurun_out/r04_exact_probe.json")
     a = ap.parse_args()
     res = dict(device=torch.cuda.get_device_name(0), torch=torch.__version__)
-    stages = dict(kernels=stage_kernels, gemms=stage_gemms, plan=lambda: stage_plan_and_time(True),
+    stages = dict(kernels=stage_kernels, gemms=stage_gemms, dw_split=stage_dw_split, plan=lambda: stage_plan_and_time(True),
                   plan_nomask=lambda: stage_plan_and_time(False), digest=stage_digest)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     for name in a.stage.split(","):
