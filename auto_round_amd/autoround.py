@@ -66,6 +66,9 @@ class AutoRound:
         for k in ("low_gpu_mem_usage", "low_cpu_mem_usage"):
             kwargs.pop(k, None)
         fused = bool(kwargs.pop("enable_torch_compile", False))
+        # MI355X-only: Llama-family blocks through the first-party kernels that keep the eager path's bits (exact_block.py) -- on by
+        # default: same results as the module code (proven per kind of block before use, module path otherwise), fewer launches
+        exact = bool(kwargs.pop("exact_rounding", True)) and not fused
         if kwargs.pop("platform", "hf") != "hf":
             raise NotImplementedError("only Hugging Face models (platform='hf') are handled")
         legacy_device = kwargs.pop("device", None)           # autoround.py:753-757: deprecated alias of device_map
@@ -103,7 +106,7 @@ class AutoRound:
                                       enable_minmax_tuning=enable_minmax_tuning, enable_quanted_input=enable_quanted_input,
                                       gradient_accumulate_steps=gradient_accumulate_steps, not_use_best_mse=not_use_best_mse,
                                       dynamic_max_gap=dynamic_max_gap, amp=amp, amp_dtype=amp_dtype, momentum=momentum, fused_block=fused,
-                                      mfma_dw_gemm=fused)
+                                      mfma_dw_gemm=fused, exact_rounding=exact)
         self.layer_config_in = layer_config
         self.layer_config: Dict[str, dict] = {}
         self.block_names: List[str] = []

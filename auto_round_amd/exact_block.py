@@ -124,8 +124,8 @@ class ExactLlamaBlock(FusedLlamaBlock):
         acc = lyrs[0]._dw_accum[0]
         done = False
         mode = int(self.plan.get("dw_" + key) or 0)         # 0: library; 1: MFMA kernel, one pass over K; n >= 2: n contiguous K slices
-        if mode and out2d.is_contiguous():
-            done = ops.gemm_dw(dY2d, X2d, out2d, accumulate=acc, split=(False if mode == 1 else mode))
+        if mode and not acc and out2d.is_contiguous():      # (accumulating micro-batches: the library's addmm_, as the module path -- the
+            done = ops.gemm_dw(dY2d, X2d, out2d, accumulate=False, split=(False if mode == 1 else mode))      # proof covered the plain product)
         if not done:
             if acc:
                 out2d.addmm_(dY2d.t(), X2d)

@@ -840,7 +840,7 @@ class FusedMoEBlock(FusedLlamaBlock):
     @classmethod
     def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True,
                   tn_dx_gemm=True) -> Optional["FusedMoEBlock"]:
-        from .moe_unfuse import expert_children
+        from .moe_unfuse import expert_children, is_linear_loop_experts
         from .wrapper import WrapperLinear
 
         if not _class_in(block, MOE_FAMILY) or not arenas:
@@ -851,7 +851,9 @@ class FusedMoEBlock(FusedLlamaBlock):
             router, experts = moe.gate, moe.experts
         except AttributeError:
             return None
-        if not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not getattr(experts, "_ar_unfused", False) or not _is_silu(getattr(experts, "act_fn", None)):
+        # (the experts in their unfused "linear loop" form: this package's own unfusing or the reference's -- behind the reference's
+        #  front door the block arrives with ITS numbered expert containers, moe_experts_interface.py:173-289)
+        if not (_is_rmsnorm(n1) and _is_rmsnorm(n2)) or not is_linear_loop_experts(experts) or not _is_silu(getattr(experts, "act_fn", None)):
             return None
         if float(getattr(moe, "jitter_noise", 0.0) or 0.0) != 0.0 and block.training:
             return None

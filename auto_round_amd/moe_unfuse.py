@@ -89,3 +89,18 @@ def expert_children(experts: nn.Module):
         return list(experts)
     kids = [c for k, c in getattr(experts, "_modules", {}).items() if k.isdigit()]
     return kids or None
+
+
+def is_linear_loop_experts(experts: nn.Module) -> bool:
+    """An experts module in the unfused "linear loop" form -- this package's (`unfuse_moe_experts`) or the reference's
+    (auto_round/modeling/fused_moe/moe_experts_interface.py:173-289 `linear_loop_experts_forward`: numbered children, each with
+    `gate_proj` / `up_proj` / `down_proj`, an `act_fn`, `num_experts`, no custom `_apply_gate`): out[t] = sum_k w[t, k] *
+    down_e(act(gate_e(x_t)) * up_e(x_t)).  What the fused MoE block computes in one sorted-row pass."""
+    if getattr(experts, "_ar_unfused", False):
+        return True
+    kids = expert_children(experts)
+    if not kids or isinstance(experts, (nn.ModuleList, list, tuple)) or hasattr(experts, "_apply_gate"):
+        return False
+    if int(getattr(experts, "num_experts", len(kids))) != len(kids) or not callable(getattr(experts, "act_fn", None)):
+        return False
+    return all(all(hasattr(c, n) for n in ("gate_proj", "up_proj", "down_proj")) for c in kids)

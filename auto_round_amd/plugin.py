@@ -34,10 +34,11 @@ def register():
 
         Two extra, MI355X-only keys: `fused_block` (None = follow the front door's `enable_torch_compile`, the reference's switch
         for its own compiled block forward; True / False = force the fused HIP block path and the MFMA weight-gradient GEMM on /
-        off) and `exact_rounding` (Llama-family blocks through first-party kernels that keep the eager path's bits --
-        auto_round_amd/exact_block.py; takes precedence over `fused_block`)."""
+        off) and `exact_rounding` (default on: Llama-family blocks through first-party kernels that keep the eager path's bits,
+        proven against the module code per kind of block -- auto_round_amd/exact_block.py; ignored when the fused path is asked
+        for)."""
 
-        def __init__(self, *, fused_block=None, exact_rounding=False, **kwargs):
+        def __init__(self, *, fused_block=None, exact_rounding=True, **kwargs):
             super().__init__(**kwargs)
             self.fused_block = fused_block
             self.exact_rounding = bool(exact_rounding)
@@ -70,7 +71,7 @@ def register():
             if fused is None:
                 fused = bool(getattr(getattr(self, "compress_context", None), "enable_torch_compile", False))
             cfg = SignRoundConfig(
-                fused_block=bool(fused), mfma_dw_gemm=bool(fused), exact_rounding=bool(getattr(c, "exact_rounding", False)),
+                fused_block=bool(fused), mfma_dw_gemm=bool(fused), exact_rounding=bool(getattr(c, "exact_rounding", True)) and not fused,
                 iters=self.iters, lr=None if getattr(c, "lr_is_auto", False) else self.lr,
                 minmax_lr=None if getattr(c, "minmax_lr_is_auto", False) else self.minmax_lr,
                 lr_scheduler=self.lr_scheduler, momentum=getattr(self, "momentum", 0.0) or 0.0, enable_minmax_tuning=self.enable_minmax_tuning,

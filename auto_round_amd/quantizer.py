@@ -642,8 +642,17 @@ class SignRoundQuantizer:
         plan = self._exact_plans.get(key)
         if plan is None:
             others_chk = input_others if not per_sample_others else {**input_others, **{k: t[:rows] for k, t in per_sample_others.items()}}
-            plan = eb.plan_against_module(lambda x, o: self.block_forward(block, x, o), X[:rows].clone(),
-                                          self._others_for(rows, others_chk), Y[:rows])
+            try:
+                plan = eb.plan_against_module(lambda x, o: self.block_forward(block, x, o), X[:rows].clone(),
+                                              self._others_for(rows, others_chk), Y[:rows])
+            except Exception as e:  # noqa: BLE001 -- a block the class does not fit after all: the module path, never an aborted run
+                import warnings
+
+                warnings.warn(f"exact_rounding: the proof against the module code raised {e!r}; {type(block).__name__} keeps the module path")
+                plan = None
+                for a in arenas:
+                    for l in a.layers:
+                        l._dw_accum[0] = False
             self._exact_plans[key] = plan if plan is not None else False
             self.last_exact_report = eb.plan_report
         if not plan:

@@ -118,3 +118,34 @@ def test_expert_grouping_keeps_the_reference_row_order():
                 assert e not in log                              # not called
             else:
                 assert torch.equal(log[e], tok.float()), (trial, e)
+
+
+def test_the_references_linear_loop_experts_are_recognised_like_this_packages_own():
+    """Behind the reference's front door a Mixtral block arrives with the REFERENCE's unfused experts (numbered containers with
+    gate_proj / up_proj / down_proj, act_fn, num_experts; moe_experts_interface.py:173-289) -- the fused MoE block must take them."""
+    import torch
+    from torch import nn
+
+    from auto_round_amd.moe_unfuse import is_linear_loop_experts
+
+    class RefExperts(nn.Module):            # the structure the reference leaves behind (no `_ar_unfused` marker)
+        def __init__(self, E=4, H=16, F=32):
+            super().__init__()
+            self.num_experts, self.act_fn = E, nn.SiLU()
+            for e in range(E):
+                c = nn.Module()
+                c.gate_proj, c.up_proj, c.down_proj = nn.Linear(H, F, bias=False), nn.Linear(H, F, bias=False), nn.Linear(F, H, bias=False)
+                self.add_module(str(e), c)
+
+    ex = RefExperts()
+    assert is_linear_loop_experts(ex)
+    ex._apply_gate = lambda x: x            # a custom gate: another function than SwiGLU
+    assert not is_linear_loop_experts(ex)
+    ex = RefExperts()
+    del ex._modules["3"].down_proj
+    assert not is_linear_loop_experts(ex)
+    assert not is_linear_loop_experts(nn.ModuleList([nn.Linear(4, 4)]))
+    ex = RefExperts()
+    ex.num_experts = 5                      # containers missing
+    assert not is_linear_loop_experts(ex)
+    assert not is_linear_loop_experts(torch.nn.Linear(4, 4))
