@@ -16,7 +16,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p "$O"
 recipe=$1; shift
 case "$recipe" in
   suite)
-    timeout ${AR_TIMEOUT:-1500} python -m pytest tests -q -m gpu -x "$@" > "$O/gpu_suite.log" 2>&1; echo "suite rc=$?"; tail -5 "$O/gpu_suite.log" ;;
+    timeout ${AR_TIMEOUT:-1500} python -m pytest tests -q -m gpu "$@" > "$O/gpu_suite.log" 2>&1; echo "suite rc=$?"; tail -5 "$O/gpu_suite.log" ;;
   bench)
     timeout ${AR_TIMEOUT:-1500} python bench.py "$@" > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"; tail -c 400 "$O/bench.err"; tail -c 3000 "$O/bench.json" ;;
   rocprof)
