@@ -66,11 +66,17 @@ struct AttnArgs {
     int64_t ldq, ldkv;                                             // elements between consecutive tokens of Q and of K / V (>= H * D:
                                                                    // the operands may be column slices of one merged projection output)
     float scale_log2e;                                             // softmax scale * log2(e)
+    float bias_in_l2, bias_out_l2;                                 // MASKED: additive bias * log2(e) inside / outside the kept region
+    int valid_len;                                                 // MASKED: keys >= valid_len are outside (key padding at the end)
 };
 
 // WAVES waves of 32 queries per workgroup: 8 (256 queries, 512 threads) halves the K / V staging per wave and per query against 4 --
 // the LDS-DMA issue is the largest non-MFMA cost of the kernel (ablations in DESIGN.md) -- and is used whenever S % 256 == 0.
-template <int WAVES, int AD>
+// MASKED = false: causal attention (keys after the query are skipped).  MASKED = true: the structured additive mask of a calibration
+// flow -- bias(q, k) = bias_in where `k <= q and k < valid_len`, bias_out elsewhere, BOTH finite (transformers >= 5 hands the block a
+// boolean `causal & key-is-valid` mask and the reference's input cache casts it to a 0 / 1 bias: auto_round/calibration/llm.py:360-402,
+// inputs.py:100-107) -- so every query attends to every key and no tile is skipped; the bias is two registers, not an [S, S] operand.
+template <int WAVES, int AD, bool MASKED = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd(AttnArgs a) {
     constexpr int AROW = AD * 2;         // bytes per staged key / value row
     constexpr int ATILE = AK * AROW;     // one operand's tile (16 KB at D = 128)
@@ -214,7 +220,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd(AttnArgs a) {
         if (!(AR_ATTN_ABL & 2)) {
         // row maximum on the raw scores (the scale is positive), then p = exp2(s * scale - m) as one fma + v_exp_f32
         float mx = -INFINITY;
-        if (diag) {
+        if (MASKED) {
+            // scores in log2 units with the bias added: s * scale * log2 e + (kept ? bias_in : bias_out) * log2 e
+            const bool plain = !diag && k0 + AK <= a.valid_len;           // wave-uniform: every (query, key) of the tile is kept
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
+                    const float bias = (plain || (key <= myq && key < a.valid_len)) ? a.bias_in_l2 : a.bias_out_l2;
+                    s[t][r] = __builtin_fmaf(s[t][r], a.scale_log2e, bias);
+                }
+        } else if (diag) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -228,14 +245,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
         mx = halves_max(mx);
-        const float m_new = fmaxf(m_run, mx * a.scale_log2e);             // finite: key 0 is visible to every query
+        const float m_new = fmaxf(m_run, MASKED ? mx : mx * a.scale_log2e);     // finite: key 0 is visible to every query
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // raw v_exp_f32: arguments <= 0
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], a.scale_log2e, -m_new));
+                const float p = __builtin_amdgcn_exp2f(MASKED ? s[t][r] - m_new : __builtin_fmaf(s[t][r], a.scale_log2e, -m_new));
                 s[t][r] = p;
                 psum += p;
             }
@@ -292,17 +309,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd(AttnArgs a) {
         }
     };
 
-    const int n_kt = (q0 + AQ) / AK;                                      // key tiles up to the diagonal: always an even number
+    const int n_kt = MASKED ? a.S / AK : (q0 + AQ) / AK;                  // causal: key tiles up to the diagonal; always an even number
     issue_tile(0, 0);
     for (int kt = 0; kt < n_kt; kt += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                     // tile kt landed for everybody; buffer 1 is free
         if (!(AR_ATTN_ABL & 1)) issue_tile(kt + 1, 1);
-        if (kt * AK <= q0 + 32 * wave + 31) tile(std::integral_constant<int, 0>{}, kt);     // else every query precedes the tile
+        if (MASKED || kt * AK <= q0 + 32 * wave + 31) tile(std::integral_constant<int, 0>{}, kt);     // else every query precedes the tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < n_kt && !(AR_ATTN_ABL & 1)) issue_tile(kt + 2, 0);
-        if ((kt + 1) * AK <= q0 + 32 * wave + 31) tile(std::integral_constant<int, 1>{}, kt + 1);
+        if (MASKED || (kt + 1) * AK <= q0 + 32 * wave + 31) tile(std::integral_constant<int, 1>{}, kt + 1);
     }
 #undef AR_KREAD
 #undef AR_VREAD
@@ -327,8 +344,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_fwd(AttnArgs a) {
 
 using namespace ar;
 
+static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
+                         float scale, int causal, int64_t ldq, int64_t ldkv, bool masked, float bias_in, float bias_out, int64_t valid_len,
+                         ar_stream_t stream);
+
 extern "C" int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H,
                            int64_t D, float scale, int causal, int64_t ldq, int64_t ldkv, ar_stream_t stream) {
+    return attn_fwd_impl(Q, K, V, O, LSE, B, S, H, D, scale, causal, ldq, ldkv, false, 0.f, 0.f, S, stream);
+}
+
+extern "C" int ar_attn_fwd_masked(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H,
+                                  int64_t D, float scale, float bias_in, float bias_out, int64_t valid_len, int64_t ldq, int64_t ldkv,
+                                  ar_stream_t stream) {
+    if (!(bias_in == bias_in) || !(bias_out == bias_out) || fabsf(bias_in) > 1e4f || fabsf(bias_out) > 1e4f || valid_len < 1 || valid_len > S)
+        return AR_ERR_UNSUPPORTED;          // hard (-inf) masks are another kernel's job: every key must keep a finite score
+    return attn_fwd_impl(Q, K, V, O, LSE, B, S, H, D, scale, 1, ldq, ldkv, true, bias_in, bias_out, valid_len, stream);
+}
+
+static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
+                         float scale, int causal, int64_t ldq, int64_t ldkv, bool masked, float bias_in, float bias_out, int64_t valid_len,
+                         ar_stream_t stream) {
     if ((D != 128 && D != 64) || !causal || S % 128 || B <= 0 || H <= 0 || S <= 0) return AR_ERR_UNSUPPORTED;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return AR_ERR_UNSUPPORTED;
     if (ldq <= 0) ldq = H * D;
@@ -339,6 +374,7 @@ extern "C" int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O,
     a.Q = (const uint16_t*)Q; a.K = (const uint16_t*)K; a.V = (const uint16_t*)V; a.O = (uint16_t*)O; a.LSE = LSE;
     a.B = (int)B; a.S = (int)S; a.H = (int)H;
     a.scale_log2e = scale * 1.4426950408889634f;
+    a.bias_in_l2 = bias_in * 1.4426950408889634f; a.bias_out_l2 = bias_out * 1.4426950408889634f; a.valid_len = (int)valid_len;
     constexpr int LDS128 = 4 * AK * 128 * 2, LDS64 = 4 * AK * 64 * 2;      // 2 buffers x (K tile + V tile)
     static PerDeviceOnce attr;
     if (attr.first()) {
@@ -346,6 +382,21 @@ extern "C" int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O,
         (void)hipFuncSetAttribute((const void*)k_attn_fwd<8, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
     }
     hipStream_t st = (hipStream_t)stream;
+    if (masked) {
+        static PerDeviceOnce attr_m;
+        if (attr_m.first()) {
+            (void)hipFuncSetAttribute((const void*)k_attn_fwd<4, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+            (void)hipFuncSetAttribute((const void*)k_attn_fwd<8, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+        }
+        if (D == 128) {
+            if (S % 256 == 0) hipLaunchKernelGGL((k_attn_fwd<8, 128, true>), (int)(B * H * (S / 256)), 512, LDS128, st, a);
+            else hipLaunchKernelGGL((k_attn_fwd<4, 128, true>), (int)(B * H * (S / 128)), 256, LDS128, st, a);
+        } else {
+            if (S % 256 == 0) hipLaunchKernelGGL((k_attn_fwd<8, 64, true>), (int)(B * H * (S / 256)), 512, LDS64, st, a);
+            else hipLaunchKernelGGL((k_attn_fwd<4, 64, true>), (int)(B * H * (S / 128)), 256, LDS64, st, a);
+        }
+        return launch_status();
+    }
     if (D == 128) {
         if (S % 256 == 0) hipLaunchKernelGGL((k_attn_fwd<8, 128>), (int)(B * H * (S / 256)), 512, LDS128, st, a);
         else hipLaunchKernelGGL((k_attn_fwd<4, 128>), (int)(B * H * (S / 128)), 256, LDS128, st, a);

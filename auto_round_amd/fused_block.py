@@ -328,6 +328,15 @@ class FusedLlamaBlock:
             if res is not None:
                 out2d, lse = res
                 return heads(out2d), (("flash", q2d, k2d, v2d, out2d, lse) if grad else None)
+        if mask is not None and S > 1 and getattr(self, "flash_fwd", True) and efficient_backward_ok(S):
+            # the calibration flow's structured mask (0 / 1 additive bias over `causal & key-is-valid`): the same kernel with the bias
+            # in two registers; the library's backward gets the real bias tensor and this forward's log-sum-exp rows
+            st = ops.mask_structure(mask, S)
+            if st is not None:
+                res = ops.attn_fwd(q2d, k2d, v2d, B, S, hq, hd, scale=self.scaling, mask_struct=st)
+                if res is not None:
+                    out2d, lse = res
+                    return heads(out2d), (("flash", q2d, k2d, v2d, out2d, lse, mask) if grad else None)
         ctx = self.sdpa_ctx(S) if self.sdpa_ctx is not None else contextlib.nullcontext()
         if mask is not None and mask.dim() == 4:
             mask = mask[:, :, :, :S]
@@ -486,16 +495,19 @@ class FusedLlamaBlock:
             return t.transpose(1, 2).contiguous().view(T, self.hq * self.hd)
 
         done = None
-        if isinstance(leaves[0], str):      # forward was ar_attn_fwd: (tag, q2d, k2d, v2d, out2d, lse)
-            _, q2d, k2d, v2d, out2d, lse = leaves
-            if getattr(self, "flash_bwd", True):
+        if isinstance(leaves[0], str):      # forward was ar_attn_fwd: (tag, q2d, k2d, v2d, out2d, lse[, mask])
+            _, q2d, k2d, v2d, out2d, lse = leaves[:6]
+            bias = leaves[6] if len(leaves) > 6 else None
+            if bias is not None:
+                bias = bias.to(q2d.dtype).expand(B, self.hq, S, S)
+            if bias is None and getattr(self, "flash_bwd", True):
                 # head size 64 (Llama-3.2-1B, Qwen2-0.5B ...): the first-party deterministic backward, token-major like rope_bwd wants
                 done = ops.attn_bwd(q2d, k2d, v2d, out2d, lse, dattn, B, S, self.hq, self.hd, scale=self.scaling)
             if done is None:
                 h4 = lambda t: t.view(B, S, self.hq, self.hd).transpose(1, 2)
                 z = torch.zeros((), dtype=torch.int64)
                 dq, dk, dv, _ = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
-                    dattn4, h4(q2d), h4(k2d), h4(v2d), None, h4(out2d), lse, z, z, 0.0, (True, True, True, False), True, scale=self.scaling)
+                    dattn4, h4(q2d), h4(k2d), h4(v2d), bias, h4(out2d), lse, z, z, 0.0, (True, True, True, False), bias is None, scale=self.scaling)
         else:
             dq, dk, dv = torch.autograd.grad(attn, leaves, dattn4)
         del attn, leaves
@@ -788,9 +800,12 @@ class FusedOPTBlock(FusedLlamaBlock):
         at = {n: i * H for i, n in enumerate(self.order)}
         grads = None
         if isinstance(leaves[0], str):
-            _, q2d, k2d, v2d, out2d, lse = leaves
+            _, q2d, k2d, v2d, out2d, lse = leaves[:6]
+            bias = leaves[6] if len(leaves) > 6 else None
+            if bias is not None:
+                bias = bias.to(q2d.dtype).expand(B, self.hq, S, S)
             done = None
-            if getattr(self, "flash_bwd", True):
+            if bias is None and getattr(self, "flash_bwd", True):
                 # hand-written deterministic backward (csrc/ar_attn_bwd.hip: head size 64, S % 256 == 0): reads q / k / v where the
                 # merged projection left them and writes dq / dk / dv into their columns of dqkv -- no transposes, no copies
                 done = ops.attn_bwd(q2d, k2d, v2d, out2d, lse, dattn, B, S, self.hq, self.hd, scale=self.scaling,
@@ -802,7 +817,7 @@ class FusedOPTBlock(FusedLlamaBlock):
                 h4 = lambda t: t.view(B, S, self.hq, self.hd).transpose(1, 2)
                 z = torch.zeros((), dtype=torch.int64)
                 grads = torch.ops.aten._scaled_dot_product_efficient_attention_backward(
-                    dattn4, h4(q2d), h4(k2d), h4(v2d), None, h4(out2d), lse, z, z, 0.0, (True, True, True, False), True, scale=self.scaling)[:3]
+                    dattn4, h4(q2d), h4(k2d), h4(v2d), bias, h4(out2d), lse, z, z, 0.0, (True, True, True, False), bias is None, scale=self.scaling)[:3]
         else:
             grads = torch.autograd.grad(attn, leaves, dattn4)
         del attn, leaves

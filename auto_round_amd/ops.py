@@ -612,8 +612,10 @@ def swiglu_bwd_exact(da2d, g2d, u2d, contract: bool, out=None):
     return dg, du
 
 
-def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq: int, heads: int, head_dim: int, scale=None):
-    """Causal attention forward on token-major operands q / k / v [batch * seq, heads * head_dim] (bf16, K / V already repeated to
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq: int, heads: int, head_dim: int, scale=None, mask_struct=None):
+    """mask_struct = (bias_in, bias_out, valid_len): the structured additive mask of a calibration flow instead of causality
+    (ar_attn_fwd_masked: bias_in where `k <= q and k < valid_len`, bias_out elsewhere, both finite; see `mask_structure`).
+    Causal attention forward on token-major operands q / k / v [batch * seq, heads * head_dim] (bf16, K / V already repeated to
     `heads`; unit inner stride -- the three may be column slices of one merged projection output, k and v with the same row stride):
     -> (out [batch * seq, heads * head_dim], lse [batch, heads, seq] fp32), or None when the kernel does not take the shape (head
     size other than 128 / 64, seq not a multiple of 128) -- the caller then keeps torch's SDPA."""
@@ -633,12 +635,58 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq:
         raise _lib.Mi355xLibraryError("attn_fwd: tensors live on different HIP devices")
     (dev,) = devs
     with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
-        rc = load().ar_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), batch, seq, heads, head_dim,
-                                sc, 1, q.stride(0), k.stride(0), torch.cuda.current_stream(dev).cuda_stream)
+        if mask_struct is not None:
+            b_in, b_out, valid = mask_struct
+            rc = load().ar_attn_fwd_masked(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), batch, seq, heads, head_dim,
+                                           sc, float(b_in), float(b_out), int(valid), q.stride(0), k.stride(0),
+                                           torch.cuda.current_stream(dev).cuda_stream)
+        else:
+            rc = load().ar_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), batch, seq, heads, head_dim,
+                                    sc, 1, q.stride(0), k.stride(0), torch.cuda.current_stream(dev).cuda_stream)
     if rc == _lib.AR_ERR_UNSUPPORTED:
         return None
     check(rc, "ar_attn_fwd")
     return out, lse
+
+
+_mask_struct_cache: dict = {}
+
+
+def mask_structure(mask: torch.Tensor, seq: int):
+    """(bias_in, bias_out, valid_len) when `mask` -- a [1 | B, 1, S, S] additive attention mask with the same rows for every batch
+    entry -- is the calibration flow's structured mask: one finite value where `k <= q and k < valid_len`, another finite value
+    elsewhere (auto_round/calibration/llm.py:360-402 + inputs.py:100-107: the boolean `causal & key-is-valid` mask cast to 0 / 1).
+    None for anything else (hard -inf masks, per-sample padding, arbitrary biases): the caller keeps torch's SDPA.  One device
+    comparison and one host read per distinct mask tensor (cached per tensor object and version: the mask is the same object every
+    iteration)."""
+    if mask is None or mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[-1] != seq or mask.shape[-2] != seq or not mask.is_floating_point():
+        return None
+    import weakref
+
+    key = id(mask)          # (the tensor OBJECT, held weakly: a freed mask's address -- and its id -- can be handed out again)
+    hit = _mask_struct_cache.get(key)
+    if hit is not None and hit[0]() is mask and hit[1] == mask._version:
+        return hit[2]
+    with torch.no_grad():
+        m = mask[0, 0].float()
+        ok_batch = bool((mask == mask[:1]).all()) if mask.shape[0] > 1 else True
+        b_in, b_out = float(m[0, 0]), float(m[0, seq - 1]) if seq > 1 else float(m[0, 0])
+        last = m[seq - 1]                                   # the last query sees every causal key: its row shows the key padding
+        invalid = (last != b_in)
+        n_inv = int(invalid.sum())
+        valid = seq - n_inv
+        res = None
+        finite = all(abs(v) <= 1e4 for v in (b_in, b_out))
+        if ok_batch and finite and valid >= 1 and b_in != b_out and (n_inv == 0 or bool(invalid[valid:].all())):
+            idx = torch.arange(seq, device=mask.device)
+            keep = (idx[None, :] <= idx[:, None]) & (idx[None, :] < valid)
+            want = torch.where(keep, torch.full_like(m, b_in), torch.full_like(m, b_out))
+            if bool((m == want).all()):
+                res = (b_in, b_out, valid)
+    if len(_mask_struct_cache) > 64:
+        _mask_struct_cache.clear()
+    _mask_struct_cache[key] = (weakref.ref(mask), mask._version, res)
+    return res
 
 
 _attn_ws: dict = {}

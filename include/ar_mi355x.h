@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 20
+#define AR_ABI_VERSION 21
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -377,6 +377,15 @@ int ar_gemm_dw_config(int sem, int order);
  *           Anything else (no causal mask, other head sizes) returns AR_ERR_UNSUPPORTED and the caller keeps torch's SDPA. */
 int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
                 float scale, int causal, int64_t ldq, int64_t ldkv, ar_stream_t stream);
+/* The same forward for the attention mask the reference's calibration flow really hands to a block
+ * (auto_round/calibration/llm.py:360-402: attention_mask = ones with the last position cleared -> transformers >= 5 builds the boolean
+ * [1, 1, S, S] mask `causal & key-is-valid`; auto_round/calibration/inputs.py:100-107 casts it to the amp dtype, i.e. a 0 / 1 ADDITIVE
+ * bias): softmax(scale * Q K^T + bias), bias(q, k) = bias_in where k <= q and k < valid_len, bias_out elsewhere -- both finite, so
+ * every query attends to every key (no tile is skipped) and the mask costs two registers instead of an [S, S] operand.  LSE includes
+ * the bias (what aten::_scaled_dot_product_efficient_attention_backward with the same attn_bias expects).  Hard masks (-inf) and
+ * unstructured biases return AR_ERR_UNSUPPORTED: the caller keeps torch's SDPA. */
+int ar_attn_fwd_masked(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
+                       float scale, float bias_in, float bias_out, int64_t valid_len, int64_t ldq, int64_t ldkv, ar_stream_t stream);
 
 /* ---- causal attention backward, head size 64 (deterministic: two MFMA kernels, no float atomics) ---------------------------
  * replaces: autograd of the same attention call -- torch's aten::_scaled_dot_product_efficient_attention_backward, i.e. aiter's
