@@ -94,13 +94,27 @@ def expert_children(experts: nn.Module):
 def is_linear_loop_experts(experts: nn.Module) -> bool:
     """An experts module in the unfused "linear loop" form -- this package's (`unfuse_moe_experts`) or the reference's
     (auto_round/modeling/fused_moe/moe_experts_interface.py:173-289 `linear_loop_experts_forward`: numbered children, each with
-    `gate_proj` / `up_proj` / `down_proj`, an `act_fn`, `num_experts`, no custom `_apply_gate`): out[t] = sum_k w[t, k] *
+    `gate_proj` / `up_proj` / `down_proj`, an `act_fn`, `num_experts`, `_apply_gate` absent or the standard act(gate) * up): out[t] = sum_k w[t, k] *
     down_e(act(gate_e(x_t)) * up_e(x_t)).  What the fused MoE block computes in one sorted-row pass."""
     if getattr(experts, "_ar_unfused", False):
         return True
     kids = expert_children(experts)
-    if not kids or isinstance(experts, (nn.ModuleList, list, tuple)) or hasattr(experts, "_apply_gate"):
+    if not kids or isinstance(experts, (nn.ModuleList, list, tuple)):
         return False
     if int(getattr(experts, "num_experts", len(kids))) != len(kids) or not callable(getattr(experts, "act_fn", None)):
         return False
-    return all(all(hasattr(c, n) for n in ("gate_proj", "up_proj", "down_proj")) for c in kids)
+    if not all(all(hasattr(c, n) for n in ("gate_proj", "up_proj", "down_proj")) for c in kids):
+        return False
+    gate = getattr(experts, "_apply_gate", None)
+    if gate is not None:
+        # transformers' experts classes carry `_apply_gate(cat(gate, up))` and the reference's loop calls it when present
+        # (moe_experts_interface.py:246-250); the standard one is act_fn(gate) * up -- anything else (GPT-OSS's clamped, interleaved
+        # gate ...) is another function than the fused block's SwiGLU kernel
+        try:
+            probe = torch.linspace(-3.0, 3.0, 64, dtype=torch.float32).view(2, 32)
+            with torch.no_grad():
+                if not torch.allclose(gate(probe), experts.act_fn(probe[:, :16]) * probe[:, 16:], rtol=1e-6, atol=1e-6):
+                    return False
+        except Exception:  # noqa: BLE001
+            return False
+    return True

@@ -139,7 +139,9 @@ def test_the_references_linear_loop_experts_are_recognised_like_this_packages_ow
 
     ex = RefExperts()
     assert is_linear_loop_experts(ex)
-    ex._apply_gate = lambda x: x            # a custom gate: another function than SwiGLU
+    ex._apply_gate = lambda gu: ex.act_fn(gu[..., :gu.shape[-1] // 2]) * gu[..., gu.shape[-1] // 2:]      # transformers' standard gate
+    assert is_linear_loop_experts(ex)
+    ex._apply_gate = lambda x: x[..., :x.shape[-1] // 2]            # a custom gate: another function than SwiGLU
     assert not is_linear_loop_experts(ex)
     ex = RefExperts()
     del ex._modules["3"].down_proj
@@ -149,3 +151,26 @@ def test_the_references_linear_loop_experts_are_recognised_like_this_packages_ow
     ex.num_experts = 5                      # containers missing
     assert not is_linear_loop_experts(ex)
     assert not is_linear_loop_experts(torch.nn.Linear(4, 4))
+
+
+def test_live_the_references_own_unfusing_of_a_mixtral_block_is_recognised():
+    """With the reference tree at hand: a tiny Mixtral through the REFERENCE's `prepare_model_for_moe_quantization`
+    (moe_experts_interface.py) -- transformers' MixtralExperts keeps its standard `_apply_gate` -- is what the fused MoE block must take."""
+    import pytest
+
+    from ref_tree import import_reference, reference_root
+
+    if reference_root() is None:
+        pytest.skip("reference tree not present")
+    import_reference()
+    import auto_round.modeling.fused_moe.moe_experts_interface as mi
+
+    from auto_round_amd.moe_unfuse import expert_children, is_linear_loop_experts
+    from auto_round_amd.testing import t3_fixture as fx
+
+    model = fx.build_model("mixtral_tiny")
+    assert mi.prepare_model_for_moe_quantization(model)
+    experts = fx.decoder_blocks(model)[0].mlp.experts
+    assert hasattr(experts, "_apply_gate") and is_linear_loop_experts(experts)
+    kids = expert_children(experts)
+    assert len(kids) == experts.num_experts and all(hasattr(k, "gate_proj") for k in kids)
