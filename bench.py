@@ -11,25 +11,29 @@ final int4 packing -- i.e. what the reference times per block in `_quantize_bloc
 iters=200, nsamples=128, seqlen=2048, batch 8 (random-init weights of that architecture, synthetic N(0,1) hidden
 states: there is no network for checkpoints or datasets).
 
+Defaults (round 4): `--path exact --mask calibration` -- the block runs on `exact_rounding` (auto_round_amd/exact_block.py: first-party
+kernels with eager torch's bits, proven against the module code before the timed region) under the attention mask the reference's
+calibration flow hands to every block: the configuration whose packed result is bit-identical to the reference's.  `--path fused
+--mask none` is round 3's headline configuration (fused block path, first-party causal attention: trajectory-level parity).
+
 Multi-GPU (N>1, weak scaling): the REAL block-sharded pipeline (auto_round_amd/sharding.py `tune_sharded`) over a stack
 of N*K blocks tuned against the fp activation chain (`enable_quanted_input=False`, the only mode in which blocks are
 independent): RCCL broadcast of the shared calibration activations, pipelined point-to-point relay of the fp chain, every
 rank tunes its K blocks, packed results gathered on rank 0.  No per-iteration collective.  value = N*K blocks / max-over-
 ranks time.  `--data-parallel` is the strong-scaling alternative inside one block.
 
-Extra objects on the JSON line (N=1):
+Objects on the JSON line (N=1).  The driver's record keeps `config`, `roofline` and `cpu_baseline`, so everything a reader needs is
+(also) nested under those three (`nest_for_the_driver`):
   roofline          quant-forward kernel (K1, `k_int_fwd_flat`): algorithmic bytes (8 B/elem + 12 B/group) / the
                     kernel's own average duration, measured live inside the timed region with device start/stop events
                     attached to each dispatch (`ar_profile_*`, hipExtLaunchKernelGGL) -- the same quantity rocprofv3
-                    --kernel-trace reports, also for an 11 us kernel
-  roofline_bwd_sgd  same for the fused backward + sign-SGD kernel (12 B/elem + 8 B/group, +4 B/elem on snapshot iterations)
+                    --kernel-trace reports, also for an 11 us kernel;  `.bwd_sgd` = the fused backward + sign-SGD kernel
+                    (12 B/elem + 8 B/group, +4 B/elem on snapshot iterations);  `.opt125m` = K1 / K2 of the OPT-125M block
   cpu_baseline      oracle/torch_ref (torch restatement of the reference loop, kind "port") timed on the host cores on a
-                    bounded sample (5 timed iterations, spread reported)
-  opt125m           the north-star's headline configuration (BASELINE configs[0], OPT-125M W4G128) on the same GPU in the same
-                    run: blocks/s, K1/K2 roofline, the port's CPU figure measured live and the REAL reference's CPU figure
-                    quoted from profiles/r01_reference_cpu_opt125m_full_block.json with its core count
-  variants          the same Llama-3-8B block under the other switch settings (2 steps each): `fuse_next_forward` on (the
-                    product default; K1 then runs once per block) and the fused block path off / on
+                    bounded sample;  `.reference_quoted` = the REAL reference's CPU figure from the build container;  `.opt125m`
+  config            workload, path, mask, the proven `exact_plan`;  `.bit_identical_path` (rate + live digest verdict + the module
+                    path's rate), `.trajectory_level_paths` (fused path with / without the mask), `.parity`, `.opt125m`
+  opt125m, variants, parity, roofline_bwd_sgd, cpu_reference_quoted   the same objects in full at the top level
 """
 import argparse
 import json
