@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -80,6 +80,7 @@ SIGNATURES = {
     "ar_attn_fwd_masked": (c_int, [P, P, P, P, P, L, L, L, L, F, F, F, L, L, L, P]),
     "ar_attn_bwd_workspace_bytes": (c_int64, [L, L, L]),
     "ar_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, L, L, L, L, F, I, L, L, L, L, L, L, L, L, P, L, P]),
+    "ar_attn_bwd_masked": (c_int, [P, P, P, P, P, P, P, P, P, L, L, L, L, F, F, F, L, L, L, L, L, L, L, L, L, P, L, P]),
     "ar_profile_enable": (c_int, [I]),
     "ar_profile_reset": (c_int, []),
     "ar_profile_read": (c_int, [I, L, P, P, P]),

@@ -51,6 +51,8 @@ struct AttnBwdArgs {
     int64_t ldq, ldk, ldv, ldo;              // elements between consecutive tokens of Q, K, V, dO
     int64_t lddq, lddk, lddv;                // ... of the outputs
     float scale, scale_log2e;
+    float bias_in_l2, bias_out_l2;           // MASKED: additive bias * log2(e) inside / outside the kept region (ar_attn_fwd_masked)
+    int valid_len;                           // MASKED: keys >= valid_len are outside
 };
 
 // Dv[b, h, s] = -sum_d dO * O (fp32), L2 = -lse / scale.  One 8-lane group per (token, head) row of 64 values.
@@ -82,7 +84,13 @@ __global__ __launch_bounds__(kTPB) void k_attn_bwd_prep(const uint16_t* __restri
     }
 }
 
-template <int MODE, int WAVES, int AD>
+// MASKED (round 4): the calibration flow's structured additive mask instead of causality -- bias(q, k) = bias_in where `k <= q and
+// k < valid_len`, bias_out elsewhere, both finite (csrc/ar_attn.hip k_attn_fwd<.., MASKED>): every (query, key) pair contributes, no
+// tile is skipped, P = exp2((q.k - lse / scale) * c + bias * log2 e); dS = P (dP - D) as before (the bias is a constant).
+// (Head size 128 was compiled in round 4 for the masked form -- the library's additive-bias backward is slow there -- and dropped:
+//  16 resident b-operand registers + 8 accumulator tiles per lane do not fit the 256 registers a wave has at two waves per SIMD;
+//  the MODE 1 kernel spilled 157 registers to scratch.  It needs another decomposition, not this skeleton.)
+template <int MODE, int WAVES, int AD, bool MASKED = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
     constexpr int AROW = AD * 2;         // bytes per staged row
     constexpr int ATILE = BK * AROW;     // one tensor's tile
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
     constexpr int CPR = AROW / 16;
     constexpr int NP = RPW / RPI;
     static_assert(NP >= 1, "a wave stages at least one DMA instruction per tensor");
-    static_assert(AD == 64, "head size 64 only (register budget of MODE 1 at 128: see the header comment)");
+    static_assert(AD == 64, "head size 64 only (register budget at 128: see the comment above)");
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -195,7 +203,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
         constexpr int BUF = decltype(bufc)::value;
         // MODE 0: streamed rows are keys, own row the query -> masked where key > query.  MODE 1: streamed rows are queries, own row
         // the key -> masked where key > query as well.
-        const bool diag = MODE == 0 ? (t0 + BK - 1 > o0 + 32 * wave) : (t0 < o0 + 32 * wave + 31);
+        // MASKED: `diag` = the tile is not entirely inside the kept region for this wave (some pair has key > query or key >= valid_len)
+        const bool diag = MASKED ? (MODE == 0 ? (t0 + BK - 1 > o0 + 32 * wave || t0 + BK > a.valid_len)
+                                              : (t0 < o0 + 32 * wave + 31 || o0 + 32 * wave + 31 >= a.valid_len))
+                                 : (MODE == 0 ? (t0 + BK - 1 > o0 + 32 * wave) : (t0 < o0 + 32 * wave + 31));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {                                 // the two 32-row halves of the tile, one after the other
             // The score accumulators START at -lse / scale and -D of their query row, so the products come out as
@@ -238,7 +249,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
                 }
             BW_PIN();
             // ---- P = exp2(s0 * c) (0 where key > query), E = P * s1; register r <-> streamed row 32 t + 4 h + (r & 3) + 8 (r >> 2)
-            if (diag) {
+            if (MASKED) {
+                if (diag) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int srow = t0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
+                        const int query = MODE == 0 ? myrow : srow, key = MODE == 0 ? srow : myrow;
+                        const float bias = (key <= query && key < a.valid_len) ? a.bias_in_l2 : a.bias_out_l2;
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], a.scale_log2e, bias));
+                        s0[r] = p;
+                        s1[r] = p * s1[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], a.scale_log2e, a.bias_in_l2));
+                        s0[r] = p;
+                        s1[r] = p * s1[r];
+                    }
+                }
+            } else if (diag) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int srow = t0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
@@ -267,7 +297,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
                     const uint32_t wp = pack_bf16x2(s0[8 * s2 + e], s0[8 * s2 + e + 1]);
                     pp[e] = (short)(wp & 0xffffu); pp[e + 1] = (short)(wp >> 16);
                 }
-                if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MODE == 1 ? 4 * ND : 2 * ND) : "memory");
+                // (the second step's reads may stay in flight; the counter field holds at most 15)
+                if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MODE == 1 ? 4 * ND : 2 * ND) > 15 ? 15 : (MODE == 1 ? 4 * ND : 2 * ND)) : "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 BW_PIN();
 #pragma unroll
@@ -285,8 +316,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
     };
 
     // ---- tile loop.  MODE 0: key tiles 0 .. diagonal;  MODE 1: query tiles from the diagonal to the end.  Always an even count.
-    const int t_first = MODE == 0 ? 0 : o0 / BK;
-    const int t_end = MODE == 0 ? (o0 + AQ) / BK : a.S / BK;
+    const int t_first = (MODE == 0 || MASKED) ? 0 : o0 / BK;
+    const int t_end = (MODE == 0 && !MASKED) ? (o0 + AQ) / BK : a.S / BK;
     __syncthreads();                                                  // (MODE 1: the L2 / D rows are in LDS)
     issue_tile(t_first, 0);
     for (int t = t_first; t < t_end; t += 2) {
@@ -295,7 +326,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
         issue_tile(t + 1, 1);
         {   // wave-uniform skip: no (key <= query) pair between the wave's own rows and this tile
             const int t0 = t * BK;
-            const bool live = MODE == 0 ? (t0 <= o0 + 32 * wave + 31) : (t0 + BK - 1 >= o0 + 32 * wave);
+            const bool live = MASKED || (MODE == 0 ? (t0 <= o0 + 32 * wave + 31) : (t0 + BK - 1 >= o0 + 32 * wave));
             if (live) tile(std::integral_constant<int, 0>{}, t0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -303,7 +334,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
         if (t + 2 < t_end) issue_tile(t + 2, 0);
         {
             const int t0 = (t + 1) * BK;
-            const bool live = MODE == 0 ? (t0 <= o0 + 32 * wave + 31) : (t0 + BK - 1 >= o0 + 32 * wave);
+            const bool live = MASKED || (MODE == 0 ? (t0 <= o0 + 32 * wave + 31) : (t0 + BK - 1 >= o0 + 32 * wave));
             if (live) tile(std::integral_constant<int, 1>{}, t0);
         }
     }
@@ -333,10 +364,34 @@ using namespace ar;
 
 extern "C" int64_t ar_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H) { return 2 * B * S * H * (int64_t)sizeof(float); }
 
+static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ, void* dK,
+                         void* dV, int64_t B, int64_t S, int64_t H, int64_t D, float scale, int causal, int64_t ldq, int64_t ldk,
+                         int64_t ldv, int64_t ldo_, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, void* workspace,
+                         int64_t workspace_bytes, bool masked, float bias_in, float bias_out, int64_t valid_len, ar_stream_t stream);
+
 extern "C" int ar_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ, void* dK,
                            void* dV, int64_t B, int64_t S, int64_t H, int64_t D, float scale, int causal, int64_t ldq, int64_t ldk,
                            int64_t ldv, int64_t ldo_, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, void* workspace,
                            int64_t workspace_bytes, ar_stream_t stream) {
+    if (D != 64) return AR_ERR_UNSUPPORTED;
+    return attn_bwd_impl(Q, K, V, O, dO, LSE, dQ, dK, dV, B, S, H, D, scale, causal, ldq, ldk, ldv, ldo_, lddo, lddq, lddk, lddv, workspace,
+                         workspace_bytes, false, 0.f, 0.f, S, stream);
+}
+
+extern "C" int ar_attn_bwd_masked(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
+                                  void* dK, void* dV, int64_t B, int64_t S, int64_t H, int64_t D, float scale, float bias_in, float bias_out,
+                                  int64_t valid_len, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo_, int64_t lddo, int64_t lddq,
+                                  int64_t lddk, int64_t lddv, void* workspace, int64_t workspace_bytes, ar_stream_t stream) {
+    if (!(bias_in == bias_in) || !(bias_out == bias_out) || fabsf(bias_in) > 1e4f || fabsf(bias_out) > 1e4f || valid_len < 1 || valid_len > S)
+        return AR_ERR_UNSUPPORTED;
+    return attn_bwd_impl(Q, K, V, O, dO, LSE, dQ, dK, dV, B, S, H, D, scale, 1, ldq, ldk, ldv, ldo_, lddo, lddq, lddk, lddv, workspace,
+                         workspace_bytes, true, bias_in, bias_out, valid_len, stream);
+}
+
+static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ, void* dK,
+                         void* dV, int64_t B, int64_t S, int64_t H, int64_t D, float scale, int causal, int64_t ldq, int64_t ldk,
+                         int64_t ldv, int64_t ldo_, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, void* workspace,
+                         int64_t workspace_bytes, bool masked, float bias_in, float bias_out, int64_t valid_len, ar_stream_t stream) {
     if (D != 64 || !causal || S % 256 || S > 4096 || B <= 0 || H <= 0) return AR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < ar_attn_bwd_workspace_bytes(B, S, H)) return AR_ERR_UNSUPPORTED;
     const int64_t hd = H * D;
@@ -369,15 +424,24 @@ extern "C" int ar_attn_bwd(const void* Q, const void* K, const void* V, const vo
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = lddo;
     a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+    a.bias_in_l2 = bias_in * 1.4426950408889634f; a.bias_out_l2 = bias_out * 1.4426950408889634f; a.valid_len = (int)valid_len;
     constexpr int LDS_T = 4 * BK * 64 * 2;                            // 2 buffers x (R0 tile + R1 tile) at head size 64
-    const int lds1 = LDS_T + (int)(2 * S * sizeof(float));
+    const int vec = (int)(2 * S * sizeof(float));
     static PerDeviceOnce attr;
     if (attr.first()) {
+        constexpr int VEC_MAX = 2 * 4096 * (int)sizeof(float);
         (void)hipFuncSetAttribute((const void*)k_attn_bwd<0, 8, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T);
-        (void)hipFuncSetAttribute((const void*)k_attn_bwd<1, 8, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T + 2 * 4096 * (int)sizeof(float));
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd<1, 8, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T + VEC_MAX);
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd<0, 8, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T);
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd<1, 8, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T + VEC_MAX);
     }
     const int grid = (int)(B * H * (S / 256));
-    hipLaunchKernelGGL((k_attn_bwd<1, 8, 64>), grid, 512, lds1, st, a);
-    hipLaunchKernelGGL((k_attn_bwd<0, 8, 64>), grid, 512, LDS_T, st, a);
+    if (masked) {
+        hipLaunchKernelGGL((k_attn_bwd<1, 8, 64, true>), grid, 512, LDS_T + vec, st, a);
+        hipLaunchKernelGGL((k_attn_bwd<0, 8, 64, true>), grid, 512, LDS_T, st, a);
+    } else {
+        hipLaunchKernelGGL((k_attn_bwd<1, 8, 64>), grid, 512, LDS_T + vec, st, a);
+        hipLaunchKernelGGL((k_attn_bwd<0, 8, 64>), grid, 512, LDS_T, st, a);
+    }
     return launch_status();
 }

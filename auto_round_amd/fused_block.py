@@ -498,11 +498,13 @@ class FusedLlamaBlock:
         if isinstance(leaves[0], str):      # forward was ar_attn_fwd: (tag, q2d, k2d, v2d, out2d, lse[, mask])
             _, q2d, k2d, v2d, out2d, lse = leaves[:6]
             bias = leaves[6] if len(leaves) > 6 else None
+            st = ops.mask_structure(bias, S) if bias is not None else None
             if bias is not None:
                 bias = bias.to(q2d.dtype).expand(B, self.hq, S, S)
-            if bias is None and getattr(self, "flash_bwd", True):
+            if (bias is None or st is not None) and getattr(self, "flash_bwd", True):
                 # head size 64 (Llama-3.2-1B, Qwen2-0.5B ...): the first-party deterministic backward, token-major like rope_bwd wants
-                done = ops.attn_bwd(q2d, k2d, v2d, out2d, lse, dattn, B, S, self.hq, self.hd, scale=self.scaling)
+                # (causal, or the calibration flow's structured mask)
+                done = ops.attn_bwd(q2d, k2d, v2d, out2d, lse, dattn, B, S, self.hq, self.hd, scale=self.scaling, mask_struct=st)
             if done is None:
                 h4 = lambda t: t.view(B, S, self.hq, self.hd).transpose(1, 2)
                 z = torch.zeros((), dtype=torch.int64)
@@ -802,13 +804,15 @@ class FusedOPTBlock(FusedLlamaBlock):
         if isinstance(leaves[0], str):
             _, q2d, k2d, v2d, out2d, lse = leaves[:6]
             bias = leaves[6] if len(leaves) > 6 else None
+            st = ops.mask_structure(bias, S) if bias is not None else None
             if bias is not None:
                 bias = bias.to(q2d.dtype).expand(B, self.hq, S, S)
             done = None
-            if bias is None and getattr(self, "flash_bwd", True):
+            if (bias is None or st is not None) and getattr(self, "flash_bwd", True):
                 # hand-written deterministic backward (csrc/ar_attn_bwd.hip: head size 64, S % 256 == 0): reads q / k / v where the
                 # merged projection left them and writes dq / dk / dv into their columns of dqkv -- no transposes, no copies
-                done = ops.attn_bwd(q2d, k2d, v2d, out2d, lse, dattn, B, S, self.hq, self.hd, scale=self.scaling,
+                # (causal, or the calibration flow's structured mask)
+                done = ops.attn_bwd(q2d, k2d, v2d, out2d, lse, dattn, B, S, self.hq, self.hd, scale=self.scaling, mask_struct=st,
                                     dq=dqkv[:, at["q"]:at["q"] + H], dk=dqkv[:, at["k"]:at["k"] + H], dv=dqkv[:, at["v"]:at["v"] + H])
             if done is not None:
                 if not self.fold_qscale:

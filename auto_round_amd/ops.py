@@ -692,8 +692,10 @@ def mask_structure(mask: torch.Tensor, seq: int):
 _attn_ws: dict = {}
 
 
-def attn_bwd(q, k, v, out, lse, dout, batch: int, seq: int, heads: int, head_dim: int, scale=None, dq=None, dk=None, dv=None):
-    """Causal attention backward (head size 64, deterministic) on token-major operands [batch * seq, heads * 64] with unit inner
+def attn_bwd(q, k, v, out, lse, dout, batch: int, seq: int, heads: int, head_dim: int, scale=None, dq=None, dk=None, dv=None, mask_struct=None):
+    """mask_struct = (bias_in, bias_out, valid_len): the calibration flow's structured additive mask instead of causality
+    (ar_attn_bwd_masked; `out` / `lse` then come from `attn_fwd(..., mask_struct=...)`).
+    Causal attention backward (head size 64, deterministic) on token-major operands [batch * seq, heads * 64] with unit inner
     stride (column slices of merged buffers are fine; so are dq / dk / dv given as such slices): -> (dq, dk, dv), or None when the
     kernel does not take the shape -- the caller then keeps the library backward."""
     if head_dim != 64 or seq % 256 or seq > 4096 or q.dtype != torch.bfloat16:
@@ -721,10 +723,18 @@ def attn_bwd(q, k, v, out, lse, dout, batch: int, seq: int, heads: int, head_dim
         ws = _attn_ws[dev] = torch.empty(need, dtype=torch.uint8, device=q.device)
     sc = float(scale) if scale is not None else head_dim ** -0.5
     with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
-        rc = load().ar_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                                outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), batch, seq, heads, head_dim, sc, 1,
-                                q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0), outs[0].stride(0), outs[1].stride(0),
-                                outs[2].stride(0), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+        if mask_struct is not None:
+            b_in, b_out, valid = mask_struct
+            rc = load().ar_attn_bwd_masked(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                           outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), batch, seq, heads, head_dim, sc,
+                                           float(b_in), float(b_out), int(valid), q.stride(0), k.stride(0), v.stride(0), out.stride(0),
+                                           dout.stride(0), outs[0].stride(0), outs[1].stride(0), outs[2].stride(0), ws.data_ptr(), ws.numel(),
+                                           torch.cuda.current_stream(dev).cuda_stream)
+        else:
+            rc = load().ar_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                    outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), batch, seq, heads, head_dim, sc, 1,
+                                    q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0), outs[0].stride(0), outs[1].stride(0),
+                                    outs[2].stride(0), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
     if rc == _lib.AR_ERR_UNSUPPORTED:
         return None
     check(rc, "ar_attn_bwd")

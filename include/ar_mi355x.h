@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 21
+#define AR_ABI_VERSION 22
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -400,6 +400,13 @@ int64_t ar_attn_bwd_workspace_bytes(int64_t B, int64_t S, int64_t H);
 int ar_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ, void* dK, void* dV,
                 int64_t B, int64_t S, int64_t H, int64_t D, float scale, int causal, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                 int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, void* workspace, int64_t workspace_bytes, ar_stream_t stream);
+/* The same backward (head size 64, deterministic) for the calibration flow's structured additive mask (ar_attn_fwd_masked:
+ * bias_in where k <= q and k < valid_len, bias_out elsewhere; auto_round/calibration/llm.py:360-402, inputs.py:100-107): every
+ * (query, key) pair contributes, no tile is skipped.  O / LSE are ar_attn_fwd_masked's results. */
+int ar_attn_bwd_masked(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ, void* dK,
+                       void* dV, int64_t B, int64_t S, int64_t H, int64_t D, float scale, float bias_in, float bias_out, int64_t valid_len,
+                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv,
+                       void* workspace, int64_t workspace_bytes, ar_stream_t stream);
 
 /* ---- optional device-side timing of the hot kernels (bench.py / tools; OFF by default) --------------------------
  * binding hygiene / measurement, no reference counterpart (the reference times blocks on the host,

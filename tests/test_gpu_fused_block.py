@@ -435,6 +435,46 @@ def test_masked_attention_forward_vs_fp32_attention_with_the_calibration_mask(B,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,S,H,cleared", [(1, 256, 2, 1), (2, 512, 12, 1), (1, 2048, 3, 1), (2, 1024, 4, 130)])
+def test_masked_attention_backward_head_size_64_vs_fp32_autograd(B, S, H, cleared):
+    """`ar_attn_bwd_masked` (head size 64, deterministic) under the calibration mask against fp32 autograd of
+    softmax(QK^T / sqrt(d) + mask)V, next to the library's additive-bias backward on the same inputs; run twice: bit-identical."""
+    import math
+
+    from auto_round_amd import ops
+
+    D, T = 64, B * S
+    HD = H * D
+    q, k, v = (_rand(T, HD, seed=71 + i) for i in range(3))
+    do = _rand(T, HD, seed=74, scale=0.1)
+    mask = _calibration_mask(S, cleared)
+    st = ops.mask_structure(mask, S)
+    out, lse = ops.attn_fwd(q, k, v, B, S, H, D, mask_struct=st)
+    got = ops.attn_bwd(q, k, v, out, lse, do, B, S, H, D, mask_struct=st)
+    assert got is not None
+
+    def h4(t):
+        return t.reshape(B, S, H, D).transpose(1, 2)
+
+    qf, kf, vf = (h4(t).float().detach().requires_grad_(True) for t in (q, k, v))
+    sc = (qf @ kf.transpose(-1, -2)) / math.sqrt(D) + mask.float()
+    (torch.softmax(sc, -1) @ vf).backward(h4(do).float())
+    want = [t.grad.transpose(1, 2).reshape(T, HD) for t in (qf, kf, vf)]
+    z = torch.zeros((), dtype=torch.int64)
+    lib = torch.ops.aten._scaled_dot_product_efficient_attention_backward(h4(do), h4(q), h4(k), h4(v), mask.expand(B, H, S, S), h4(out), lse, z, z,
+                                                                         0.0, (True, True, True, False), False)[:3]
+    for name, mine, w, l in zip("qkv", got, want, lib):
+        ref_scale = w.abs().mean().item()
+        err = (mine.float() - w).abs().mean().item()
+        err_lib = (l.transpose(1, 2).reshape(T, HD).float() - w).abs().mean().item()
+        assert err < 2e-2 * ref_scale, (name, err, ref_scale)
+        assert err < 1.5 * err_lib + 1e-3 * ref_scale, (name, err, err_lib)
+    again = ops.attn_bwd(q, k, v, out, lse, do, B, S, H, D, mask_struct=st)
+    for a, b_ in zip(got, again):
+        assert torch.equal(a, b_)
+
+
+@pytest.mark.gpu
 def test_mask_structure_takes_only_the_calibration_flows_finite_structured_mask():
     from auto_round_amd import ops
 
