@@ -76,6 +76,68 @@ class ExactLlamaBlock(FusedLlamaBlock):
         self.plan_report: Optional[dict] = None
         return self
 
+    @classmethod
+    def try_build_plain(cls, block, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, amp=True) -> Optional["ExactLlamaBlock"]:
+        """The no-grad form for an UNWRAPPED block (plain nn.Linear layers): the reference forward that produces the block's targets
+        and the quantised-output forward that feeds the next block (composer.py steps 3 and 6) through the same kernels -- their
+        results enter the loss and the next block's input, so they must carry the module code's bits too
+        (`plan_forward_against_module`).  Refused like the fused form (hooks on a projection, activation-quant shells)."""
+        import types
+
+        if not _class_in(block, LLAMA_FAMILY):
+            return None
+        self = super().try_build_plain(block, input_others, amp_dtype, sdpa_ctx=sdpa_ctx)
+        if self is None or self.qk_norm is not None:
+            return None
+        attn, mlp = self.attn, block.mlp
+        if getattr(getattr(attn, "config", None), "_attn_implementation", None) != "sdpa":
+            return None
+        if self.w1.dtype != self.dtype or self.w2.dtype != self.dtype:
+            return None
+        pe = (input_others or {}).get("position_embeddings")
+        if any(t.dtype != self.dtype for t in pe):
+            return None
+        mods = dict(q=attn.q_proj, k=attn.k_proj, v=attn.v_proj, o=attn.o_proj, g=mlp.gate_proj, u=mlp.up_proj, d=mlp.down_proj)
+        self.layers = {n: types.SimpleNamespace(weight_q=m.weight, orig_layer=m) for n, m in mods.items()}
+        self.arenas = []
+        self.amp = bool(amp)
+        self.plan = self.base_plan()
+        self._tnx = {}
+        self.plan_report = None
+        return self
+
+    def plan_forward_against_module(self, module_forward, x, others) -> Optional[dict]:
+        """Forward-only proof for the no-grad form: the module code's output on one real minibatch against this class's, first with every
+        segment on torch's own ops, then one elementwise kernel at a time.  -> the plan (installed), or None (module path)."""
+        with torch.no_grad():
+            y_ref = module_forward(x, others).detach()
+
+            def same(plan):
+                self.set_plan(plan)
+                try:
+                    return _bits_equal(self._forward_impl(x, others, None).detach(), y_ref)
+                except (RuntimeError, ValueError, NotImplementedError):
+                    return False
+
+            plan = self.base_plan()
+            if not same(plan):
+                self.plan_report = dict(usable=False)
+                return None
+            x2d = x.reshape(-1, x.shape[-1]).to(self.dtype).contiguous()
+            res = ops.rmsnorm_fwd_exact(x2d, self.w1, self.eps1)
+            stats_ok = res is not None and _bits_equal(res[1], torch.rsqrt(x2d.float().pow(2).mean(-1, keepdim=True) + self.eps1).view(-1))
+            kept = []
+            for opt in KERNEL_OPTS:
+                if opt in ("norm1", "norm2") and not stats_ok:
+                    continue
+                trial = dict(plan, **{opt: True})
+                if same(trial):
+                    plan = trial
+                    kept.append(opt)
+            self.set_plan(plan)
+            self.plan_report = dict(usable=True, kept=kept, plan={k: bool(v) for k, v in plan.items() if k in KERNEL_OPTS})
+        return plan
+
     # -- plumbing ---------------------------------------------------------------------------------------------------------
     @staticmethod
     def base_plan() -> Dict[str, bool]:

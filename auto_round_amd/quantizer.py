@@ -660,6 +660,37 @@ class SignRoundQuantizer:
         eb.set_plan(plan)
         return eb
 
+    def _build_exact_plain(self, block, inputs, input_others, rows: int):
+        """The exact_rounding form of an UNWRAPPED block for the no-grad passes (targets, quantised-output forward), proven against the
+        module code's output bits once per kind of block; None: the module path."""
+        from .exact_block import ExactLlamaBlock
+
+        cfg = self.config
+        try:
+            eb = ExactLlamaBlock.try_build_plain(block, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx, amp=cfg.amp)
+        except Exception:  # noqa: BLE001 -- anything unexpected about the block: the module path
+            eb = None
+        if eb is None:
+            return None
+        mask = input_others.get("attention_mask")
+        key = ("exact_plain", self._block_signature(block), rows, tuple(inputs.shape[1:]), str(inputs.dtype),
+               None if mask is None else (tuple(mask.shape), str(mask.dtype)), cfg.sdpa_backend, cfg.materialise_shared_rows)
+        plan = self._exact_plans.get(key)
+        if plan is None:
+            try:
+                plan = eb.plan_forward_against_module(lambda x, o: self.block_forward(block, x, o), inputs[:rows],
+                                                      self._others_for(rows, input_others))
+            except Exception as e:  # noqa: BLE001
+                import warnings
+
+                warnings.warn(f"exact_rounding (no-grad form): the proof against the module code raised {e!r}; module path")
+                plan = None
+            self._exact_plans[key] = plan if plan is not None else False
+        if not plan:
+            return None
+        eb.set_plan(plan)
+        return eb
+
     @staticmethod
     def _others_signature(block, input_others):
         """what else changes the arithmetic between two blocks of one class: whether a mask is among the inputs (the attention then
@@ -814,7 +845,13 @@ class SignRoundQuantizer:
         """No-grad forward of every cached sample in minibatches -> [N, S, H] (composer.py steps 3 and 6)."""
         bs = batch_size or self.config.batch_size
         fb = None
-        if self.config.fused_block and self.config.amp and isinstance(input_others, dict):
+        if self.config.exact_rounding and self.config.amp and isinstance(input_others, dict) and not self.config.data_parallel:
+            fb = self._build_exact_plain(block, inputs, input_others, min(bs, inputs.shape[0]))
+            if fb is not None:
+                outs = [fb.forward_nograd(inputs[b0:b0 + bs], self._others_for(min(bs, inputs.shape[0] - b0), input_others))
+                        for b0 in range(0, inputs.shape[0], bs)]
+                return torch.cat(outs, dim=0)
+        elif self.config.fused_block and self.config.amp and isinstance(input_others, dict):
             from .fused_block import build_fused_block_plain
 
             fb = build_fused_block_plain(block, input_others, self.config.amp_dtype, sdpa_ctx=self._sdpa_ctx)

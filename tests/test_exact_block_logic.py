@@ -108,3 +108,15 @@ def test_gradients_accumulate_over_micro_batches_like_addmm():
     # autograd accumulates .grad += g (two roundings); the arena form is addmm_ (one): close, not necessarily equal
     for n, m in mods.items():
         assert torch.allclose(layers[n].weight_grad.float(), m.weight.grad.float(), rtol=2e-2, atol=1e-2), n
+
+
+def test_the_no_grad_form_is_the_same_forward():
+    """`forward_nograd` (targets, quantised-output forward): `_forward_impl` without a context -- no autograd leaves, same bits."""
+    cfg, blk, x, pe = _layer()
+    others = dict(position_embeddings=pe, attention_mask=None)
+    with torch.no_grad():
+        y_ref = blk(x, position_embeddings=pe)
+        y_ref = y_ref[0] if isinstance(y_ref, tuple) else y_ref
+        eb, _, _ = _exact_over(blk, cfg, pe)
+        y = eb._forward_impl(x, others, None)
+    assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)) and not y.requires_grad

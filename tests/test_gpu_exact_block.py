@@ -215,3 +215,27 @@ def test_exact_plan_is_reused_for_later_blocks_of_the_same_kind_and_refused_for_
     assert len(q._exact_plans) == 1                                 # one proof, two blocks
     # an OPT block is not covered: exact_rounding then means the module path, never the (inexact) fused path
     assert ExactLlamaBlock.try_build(torch.nn.Linear(4, 4), [], {}) is None
+
+
+def test_no_grad_passes_run_on_the_exact_kernels_and_keep_the_module_codes_bits():
+    """composer steps 3 and 6 (targets, quantised-output forward) with exact_rounding: `forward_all` through ExactLlamaBlock's no-grad
+    form, proven against the module code, bit-identical to the module path's `forward_all`."""
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.testing import t3_fixture as fx
+
+    model, tokens = _small_llama()
+    block = fx.decoder_blocks(model)[0]
+    x0, others = fx.capture_block_inputs(model, block, tokens, torch.device(DEV))
+    q_mod = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=8, bits=4, sdpa_backend="auto"), device=DEV)
+    q_ex = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=8, bits=4, sdpa_backend="auto", exact_rounding=True), device=DEV)
+    y_mod = q_mod.forward_all(block, x0, others)
+    y_ex = q_ex.forward_all(block, x0, others)
+    plans = [v for k, v in q_ex._exact_plans.items() if k[0] == "exact_plain"]
+    assert plans and plans[0] and all(plans[0][k] for k in ("norm1", "norm2", "rope", "swiglu")), plans
+    assert same(y_ex, y_mod)
+    # a hooked projection (calibration hooks must see the module calls) keeps the module path
+    h = block.mlp.down_proj.register_forward_hook(lambda m, i, o: None)
+    try:
+        assert q_ex._build_exact_plain(block, x0, others, 8) is None
+    finally:
+        h.remove()
