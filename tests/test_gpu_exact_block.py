@@ -212,7 +212,8 @@ def test_exact_plan_is_reused_for_later_blocks_of_the_same_kind_and_refused_for_
         fp_out, q_out, _ = q.compress_block(b, x, others)
         assert q.last_exact
         x = fp_out
-    assert len(q._exact_plans) == 1                                 # one proof, two blocks
+    kinds = [k[0] for k in q._exact_plans]
+    assert kinds.count("exact") == 1 and kinds.count("exact_plain") == 1        # one proof per form, two blocks
     # an OPT block is not covered: exact_rounding then means the module path, never the (inexact) fused path
     assert ExactLlamaBlock.try_build(torch.nn.Linear(4, 4), [], {}) is None
 
