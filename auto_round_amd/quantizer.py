@@ -657,6 +657,10 @@ class SignRoundQuantizer:
             self.last_exact_report = eb.plan_report
         if not plan:
             return None
+        if cfg.gradient_accumulate_steps != 1:
+            # micro-batches accumulate dW with addmm_ in the module path (the proof covered the plain product): every weight gradient
+            # through the library exactly as _QLinearFn.backward issues it, layer by layer
+            plan = {k: (0 if k.startswith("dw_") else v) for k, v in plan.items()}
         eb.set_plan(plan)
         return eb
 
