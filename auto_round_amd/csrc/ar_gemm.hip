@@ -52,10 +52,18 @@ struct GemmArgs {
     int nsplit;
     int tile0;           // > 0: split-K over the LAST tiles of the launch order only (tile0 = first of them); partial tiles are
                          // then stored compactly, [tile - tile0][nsplit][256][256]
+    const int* tlist;    // caller-given launch order (ar_gemm_dw_sk): entry i = row-major tile id; nullptr: the kernel's own order
+    const int* ksplit;   // ar_gemm_dw_sk: per split tile (entry tile - tile0) the k-row where its two parts meet, 0 = one part
 };
 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& a, int bid, int& tm, int& tn) {
     const int nwg = a.tiles_m * a.tiles_n;
+    if (a.tlist) {
+        const int id = a.tlist[bid];
+        tm = id / a.tiles_n;
+        tn = id % a.tiles_n;
+        return;
+    }
     if (a.order == 2 && (a.tiles_m % 2 == 0) && (a.tiles_n % 8 == 0) && ((nwg / 16) % 8 == 0)) {
         const int x = bid & 7, s = bid >> 3, t = s >> 4, j = s & 15;
         const int pn = a.tiles_n >> 3;
@@ -545,9 +553,19 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     const int grp = wave >> 2, wm = wave & 3, wn = wave >> 2;
     int tm, tn;
     int sp = 0;
-    int64_t krow0 = 0;
+    int64_t krow0 = 0, kend = a.K;
     int U = (a.K + 127) / 128 * 8;                 // k16 units, whole 128-row chunks (without TAIL the host guarantees K % 128 == 0)
-    if (SPLITK) {
+    if (SPLITK && TAIL && a.ksplit) {
+        // a caller-given two-part structure per tile (ar_gemm_dw_sk): part 0 = k-rows [0, ks), part 1 = [ks, K); ks = 0: one part
+        sp = blockIdx.x & 1;
+        const int tile = blockIdx.x >> 1;
+        const int ks = a.ksplit[tile];
+        if (sp == 1 && ks == 0) return;            // uniform over the workgroup, before any barrier
+        tile_of_block(a, a.tile0 + tile, tm, tn);
+        krow0 = sp ? ks : 0;
+        kend = (sp == 0 && ks > 0) ? ks : a.K;
+        U = (int)((kend - krow0 + 127) / 128) * 8;
+    } else if (SPLITK) {
         sp = blockIdx.x % a.nsplit;
         const int tile = blockIdx.x / a.nsplit;
         if (a.tile0 > 0) {
@@ -602,7 +620,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
 
     int vnext = 0;                                 // next unit to stage
     auto issue_unit = [&](int slot_unit) {         // slot_unit: 0..7 compile-time after unrolling
-        const bool real = !TAIL || vrow < a.K;
+        const bool real = !TAIL || vrow < kend;
         __builtin_amdgcn_global_load_lds((const void*)(real ? srcP : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const void*)(real ? srcQ : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
         ++vnext;
@@ -629,11 +647,11 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     Pair f;
     // one phase on pair slot S (0..3): L part then M part
     auto issue_p = [&](int slot_unit) {
-        const bool real = !TAIL || vrow < a.K;
+        const bool real = !TAIL || vrow < kend;
         __builtin_amdgcn_global_load_lds((const void*)(real ? srcP : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
     };
     auto issue_q = [&](int slot_unit) {
-        const bool real = !TAIL || vrow < a.K;
+        const bool real = !TAIL || vrow < kend;
         __builtin_amdgcn_global_load_lds((const void*)(real ? srcQ : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
         ++vnext;
         vrow += GU;
@@ -691,7 +709,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
 
     const int h = lane >> 5;
     if (SPLITK) {
-        const bool compact = a.tile0 > 0;
+        const bool compact = a.tile0 > 0 || (TAIL && a.ksplit);
         float* wsp = compact ? a.ws + ((int64_t)(blockIdx.x / a.nsplit) * a.nsplit + sp) * (GB * GB) : a.ws + (int64_t)sp * a.M * a.N;
         const int64_t wld = compact ? GB : a.N;
 #pragma unroll
@@ -993,7 +1011,8 @@ __global__ __launch_bounds__(kTPB) void k_splitk_reduce_tiles(GemmArgs a) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    for (int s = 0; s < a.nsplit; ++s) {
+    const int nsl = (a.ksplit && a.ksplit[t] == 0) ? 1 : a.nsplit;
+    for (int s = 0; s < nsl; ++s) {
         float p[8];
         unpack_f8(load8_f32(base, (int64_t)s * (GB * GB)), p);
 #pragma unroll
@@ -1080,6 +1099,41 @@ extern "C" int ar_gemm_dw_ex(const void* dY, const void* X, void* dW, int64_t M,
     return gemm_dw_impl(dY, X, dW, M, N, K, ldy, ldx, ldw, accumulate, workspace, workspace_bytes, nsplit, stream);
 }
 
+// The summation structure of a stream-K GEMM, given by the caller: the tiles `tlist[0 .. n_dp)` (row-major tile ids, in launch
+// order) are summed in one pass over K; each of the remaining tiles `tlist[n_dp + i]` in two parts, k-rows [0, ksplit[i]) and
+// [ksplit[i], K) (a multiple of 16; 0 = one part after all), each from a zero accumulator, added in fp32 and rounded once.  This is
+// how the exact path reproduces, bit for bit, a library kernel that streams its last tiles over a fixed grid.
+// Both tables live on the device.  Workspace: (tiles - n_dp) * 2 * 256 * 256 * 4 bytes.
+extern "C" int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
+                             int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, const int32_t* tlist,
+                             const int32_t* ksplit, int n_dp, ar_stream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return AR_OK;
+    if (M % GB || N % GB || K < 128 || (ldy % 8) || (ldx % 8) || (ldw % 8) || !tlist) return AR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)dY | (uintptr_t)X) & 15) || ((uintptr_t)dW & 15)) return AR_ERR_UNSUPPORTED;
+    GemmArgs a;
+    a.ws = nullptr; a.nsplit = 1; a.tile0 = 0; a.tlist = tlist; a.ksplit = nullptr;
+    a.Y = (const uint16_t*)dY; a.X = (const uint16_t*)X; a.W = (uint16_t*)dW;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = accumulate;
+    a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = 0;
+    const int grid = a.tiles_m * a.tiles_n;
+    if (n_dp < 0 || n_dp > grid) return AR_ERR_UNSUPPORTED;
+    const int n_sk = grid - n_dp;
+    if (n_sk && (!ksplit || !workspace || workspace_bytes < (int64_t)n_sk * 2 * GB * GB * 4)) return AR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    static PerDeviceOnce once;
+    if (once.first()) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    }
+    if (n_dp) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, true>), n_dp, GTHREADS, GEMM_LDS, st, a);
+    if (n_sk) {
+        a.ws = (float*)workspace; a.nsplit = 2; a.tile0 = n_dp; a.ksplit = ksplit;
+        hipLaunchKernelGGL((k_gemm_dw4<true, true, true>), n_sk * 2, GTHREADS, GEMM_LDS, st, a);
+        hipLaunchKernelGGL(k_splitk_reduce_tiles, n_sk * 32, kTPB, 0, st, a);
+    }
+    return launch_status();
+}
+
 static int gemm_dw_impl(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx, int64_t ldw,
                         int accumulate, void* workspace, int64_t workspace_bytes, int force_ns, ar_stream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return AR_OK;
@@ -1087,7 +1141,7 @@ static int gemm_dw_impl(const void* dY, const void* X, void* dW, int64_t M, int6
     if (K % 128 && g_gemm_kernel != 7) return AR_ERR_UNSUPPORTED;       // only the default kernel completes a ragged K with zeros
     if (((uintptr_t)dY | (uintptr_t)X) & 15 || ((uintptr_t)dW & 7)) return AR_ERR_UNSUPPORTED;
     GemmArgs a;
-    a.ws = nullptr; a.nsplit = 1; a.tile0 = 0;
+    a.ws = nullptr; a.nsplit = 1; a.tile0 = 0; a.tlist = nullptr; a.ksplit = nullptr;
     a.Y = (const uint16_t*)dY; a.X = (const uint16_t*)X; a.W = (uint16_t*)dW;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = accumulate;
     a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = g_gemm_order;
