@@ -555,16 +555,28 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     int sp = 0;
     int64_t krow0 = 0, kend = a.K;
     int U = (a.K + 127) / 128 * 8;                 // k16 units, whole 128-row chunks (without TAIL the host guarantees K % 128 == 0)
+    bool part = SPLITK;                            // this workgroup leaves an fp32 partial tile in the workspace
+    int slot = 0;                                  // ... at this compact slot
     if (SPLITK && TAIL && a.ksplit) {
-        // a caller-given two-part structure per tile (ar_gemm_dw_sk): part 0 = k-rows [0, ks), part 1 = [ks, K); ks = 0: one part
-        sp = blockIdx.x & 1;
-        const int tile = blockIdx.x >> 1;
-        const int ks = a.ksplit[tile];
-        if (sp == 1 && ks == 0) return;            // uniform over the workgroup, before any barrier
-        tile_of_block(a, a.tile0 + tile, tm, tn);
-        krow0 = sp ? ks : 0;
-        kend = (sp == 0 && ks > 0) ? ks : a.K;
-        U = (int)((kend - krow0 + 127) / 128) * 8;
+        // a caller-given stream-K structure (ar_gemm_dw_sk), one launch: workgroups [0, tile0) sum a whole tile each and store it;
+        // the others come in pairs, one per part of a two-part tile: part 0 = k-rows [0, ks), part 1 = [ks, K); ks = 0: one part
+        int b = blockIdx.x;
+        if (b < a.tile0) {
+            tile_of_block(a, b, tm, tn);
+            part = false;
+        } else {
+            b -= a.tile0;
+            sp = b & 1;
+            const int tile = b >> 1;
+            const int ks = a.ksplit[tile];
+            if (sp == 1 && ks == 0) return;        // uniform over the workgroup, before any barrier
+            tile_of_block(a, a.tile0 + tile, tm, tn);
+            krow0 = sp ? ks : 0;
+            kend = (sp == 0 && ks > 0) ? ks : a.K;
+            U = (int)((kend - krow0 + 127) / 128) * 8;
+            part = ks > 0;
+            slot = b;
+        }
     } else if (SPLITK) {
         sp = blockIdx.x % a.nsplit;
         const int tile = blockIdx.x / a.nsplit;
@@ -708,9 +720,11 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
 #undef AR_PIN
 
     const int h = lane >> 5;
-    if (SPLITK) {
-        const bool compact = a.tile0 > 0 || (TAIL && a.ksplit);
-        float* wsp = compact ? a.ws + ((int64_t)(blockIdx.x / a.nsplit) * a.nsplit + sp) * (GB * GB) : a.ws + (int64_t)sp * a.M * a.N;
+    if (SPLITK && part) {
+        const bool sk = TAIL && a.ksplit;
+        const bool compact = a.tile0 > 0 || sk;
+        float* wsp = sk ? a.ws + (int64_t)slot * (GB * GB)
+                        : (compact ? a.ws + ((int64_t)(blockIdx.x / a.nsplit) * a.nsplit + sp) * (GB * GB) : a.ws + (int64_t)sp * a.M * a.N);
         const int64_t wld = compact ? GB : a.N;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -1011,8 +1025,8 @@ __global__ __launch_bounds__(kTPB) void k_splitk_reduce_tiles(GemmArgs a) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    const int nsl = (a.ksplit && a.ksplit[t] == 0) ? 1 : a.nsplit;
-    for (int s = 0; s < nsl; ++s) {
+    if (a.ksplit && a.ksplit[t] == 0) return;                        // ar_gemm_dw_sk: a one-part tile was stored by its workgroup
+    for (int s = 0; s < a.nsplit; ++s) {
         float p[8];
         unpack_f8(load8_f32(base, (int64_t)s * (GB * GB)), p);
 #pragma unroll
@@ -1125,12 +1139,13 @@ extern "C" int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M,
         (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     }
-    if (n_dp) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, true>), n_dp, GTHREADS, GEMM_LDS, st, a);
-    if (n_sk) {
-        a.ws = (float*)workspace; a.nsplit = 2; a.tile0 = n_dp; a.ksplit = ksplit;
-        hipLaunchKernelGGL((k_gemm_dw4<true, true, true>), n_sk * 2, GTHREADS, GEMM_LDS, st, a);
-        hipLaunchKernelGGL(k_splitk_reduce_tiles, n_sk * 32, kTPB, 0, st, a);
+    if (!n_sk) {
+        AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, true>), grid, GTHREADS, GEMM_LDS, st, a);
+        return launch_status();
     }
+    a.ws = (float*)workspace; a.nsplit = 2; a.tile0 = n_dp; a.ksplit = ksplit;
+    AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, true, true>), n_dp + n_sk * 2, GTHREADS, GEMM_LDS, st, a);
+    hipLaunchKernelGGL(k_splitk_reduce_tiles, n_sk * 32, kTPB, 0, st, a);
     return launch_status();
 }
 

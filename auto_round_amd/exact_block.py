@@ -28,10 +28,11 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, streamk
 from .fused_block import LLAMA_FAMILY, FusedLlamaBlock, _FusedBlockFn, _class_in
 
 # segments that have a first-party kernel form (False = torch's own ops in a local autograd graph)
+STREAMK = -1        # plan value of a dw_* option: the library kernel's stream-K summation structure
 KERNEL_OPTS = ("norm1", "norm2", "rope", "swiglu")
 # GEMM forms that may be faster than the module path's and may or may not be bit-equal to it: input-gradient GEMMs through a
 # transposed weight copy (tn_*), weight-gradient GEMMs on the MFMA kernel -- merged over q/k/v and gate/up (one launch, the
@@ -185,8 +186,12 @@ class ExactLlamaBlock(FusedLlamaBlock):
             out2d = lyrs[0].weight_grad
         acc = lyrs[0]._dw_accum[0]
         done = False
-        mode = int(self.plan.get("dw_" + key) or 0)         # 0: library; 1: MFMA kernel, one pass over K; n >= 2: n contiguous K slices
-        if mode and not acc and out2d.is_contiguous():      # (accumulating micro-batches: the library's addmm_, as the module path -- the
+        mode = int(self.plan.get("dw_" + key) or 0)         # 0: library; 1: MFMA kernel, one pass over K; n >= 2: n contiguous K slices;
+        if mode == STREAMK and not acc and out2d.is_contiguous():      # -1: the library kernel's own stream-K structure (streamk.py)
+            st = streamk.find_on_device(dY2d, X2d)          # found on the proof's minibatch, a dictionary lookup afterwards
+            if st is not None:
+                done = ops.gemm_dw_sk(dY2d, X2d, out2d, st[1], st[2], st[0].n_dp)
+        elif mode > 0 and not acc and out2d.is_contiguous():      # (accumulating micro-batches: the library's addmm_, as the module path -- the
             done = ops.gemm_dw(dY2d, X2d, out2d, accumulate=False, split=(False if mode == 1 else mode))      # proof covered the plain product)
         if not done:
             if acc:
@@ -198,6 +203,18 @@ class ExactLlamaBlock(FusedLlamaBlock):
             post = getattr(lyr, "_post_dw", None)
             if post is not None:
                 post()
+
+    def _streamk_found(self, key):
+        """the stream-K structure the last `_dw_x(key, ...)` with plan value STREAMK ran with, or None"""
+        if key in ("qkv", "gu"):
+            names = ("q", "k", "v") if key == "qkv" else ("g", "u")
+            M = sum(self.layers[n].weight_q.shape[0] for n in names)
+            N = self.layers[names[0]].weight_q.shape[1]
+        else:
+            M, N = self.layers[key].weight_q.shape
+        w = self.layers["q"].weight_q
+        hits = [v for (dev, m, n, _k), v in streamk._found.items() if dev == w.device.index and (m, n) == (M, N) and v is not None]
+        return hits[-1][0] if hits else None
 
     def _dx_x(self, key, dY2d):
         wt = self._tnx.get(key)
@@ -474,7 +491,8 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 # the library's kernel for a shape may itself split K (hipBLASLt picks a global split by launch shape: Llama-3-8B's
                 # 14336 x 4096 weight gradients are 896 tiles = 3.5 rounds of 256 CUs, and two K slices make it 7 full rounds): try
                 # the same structures -- one pass, then 2 / 3 / 4 contiguous slices summed in order
-                variants = [dict(trial, **{opt: n}) for n in (1, 2, 3, 4)]
+                # -- or stream its last tiles over a fixed grid (STREAMK: the structure is found from which tiles differ from one pass)
+                variants = [dict(trial, **{opt: n}) for n in (1, 2, 3, 4, STREAMK)]
             if opt == "swiglu":
                 variants.append(dict(trial, swiglu_contract=False))
             if opt in ("norm1", "norm2") and not (plan["norm1"] or plan["norm2"]):
@@ -483,10 +501,17 @@ class ExactLlamaBlock(FusedLlamaBlock):
                     report["errors"][opt] = "row statistics differ from torch's (rsqrt / reduction order)"
             report["tried"].append(opt)
             for tv in variants:
-                if same(tv):
-                    plan = tv
-                    report["kept"].append(opt)
-                    break
+                if not same(tv):
+                    continue
+                if tv.get(opt) == STREAMK:
+                    st = self._streamk_found(opt[3:])
+                    if st is None:             # no structure found: the call fell through to the library, nothing was proven
+                        continue
+                    report.setdefault("streamk", {})[opt] = dict(grid=st.grid, wgm=st.wgm, depth=st.depth, one_pass_tiles=st.n_dp,
+                                                                   two_part_tiles=st.two_part_tiles)
+                plan = tv
+                report["kept"].append(opt)
+                break
         self.set_plan(plan)
         reset()
         self.plan_report = dict(report, usable=True, plan={k: (int(v) if k.startswith("dw_") else bool(v)) for k, v in plan.items()})

@@ -1,0 +1,150 @@
+"""The summation structure of a stream-K weight-gradient GEMM, as host logic.
+
+hipBLASLt's kernel for some `dY^T X` shapes (Llama-3-8B's 14336 x 4096 gate / up / down gradients: 896 tiles of 256 x 256 on 256
+CUs) is a two-tile stream-K kernel: over a grid of G workgroups it sums the first `tiles - sk` tiles of its launch order in one pass
+over K each (G | tiles - sk), and streams the last `sk = tiles % G + G` tiles: their `sk * iters` K-iterations (`depth` k-rows each)
+are cut into G consecutive runs of `ceil(sk * iters / G)` iterations, one per workgroup, so a tile a cut falls into is the fp32 sum
+of two partial accumulations, [0, cut) and [cut, K).  The launch order walks bands of `wgm` tile-rows, rows fastest (wgm < 0:
+bands of tile-columns, columns fastest).  G, wgm and depth are the library's choice per shape and are not published; `discover`
+finds them from WHICH tiles of the library's result differ from a one-pass sum, `ops.gemm_dw_sk` then reproduces the result bit
+for bit (profiles/r04_dw_streamk_probe.json: all 896 tiles at G = 246, wgm = 6, depth = 32).  exact_rounding's plan proof is the
+judge: a structure is only used where it made a real minibatch's gradients identical to the module path's.
+
+Nothing of the reference corresponds to this file: the reference calls torch autograd, autograd calls the library
+(auto_round/wrapper.py:528-556 `F.linear` -> `grad_output.t().mm(input)`), and bit-identity with the reference means bit-identity
+with that library kernel."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Tuple
+
+import numpy as np
+
+TILE = 256
+WGMS = (1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 32, -2, -3, -4, -5, -6, -7, -8, -12, -16, -32)
+DEPTHS = (32, 64, 16, 128)
+
+
+@dataclass(frozen=True)
+class Structure:
+    grid: int
+    wgm: int
+    depth: int
+    n_dp: int
+    tlist: np.ndarray        # int32 [tiles]: row-major tile ids in launch order
+    ksplit: np.ndarray       # int32 [tiles - n_dp]: k-row where the tile's two parts meet, 0 = one part
+
+    def key(self) -> bytes:
+        return self.tlist[self.n_dp:].tobytes() + self.ksplit.tobytes() + self.tlist[:self.n_dp].tobytes()
+
+    @property
+    def two_part_tiles(self) -> int:
+        return int((self.ksplit > 0).sum())
+
+
+def tile_order(tm: int, tn: int, wgm: int) -> np.ndarray:
+    """row-major ids of the tm x tn tiles in launch order: bands of |wgm| tile-rows, rows fastest inside a band (wgm > 0), or bands
+    of tile-columns, columns fastest (wgm < 0); the last band holds what is left"""
+    ids = np.arange(tm * tn, dtype=np.int32).reshape(tm, tn)
+    w = abs(int(wgm))
+    if w <= 0:
+        raise ValueError("wgm must not be 0")
+    if wgm > 0:
+        bands = [ids[b:b + w].T.reshape(-1) for b in range(0, tm, w)]
+    else:
+        bands = [ids[:, b:b + w].reshape(-1) for b in range(0, tn, w)]
+    return np.concatenate(bands)
+
+
+def structure(tm: int, tn: int, K: int, grid: int, wgm: int, depth: int = 32) -> Optional[Structure]:
+    """The two-tile stream-K structure of a tm x tn tile problem over `grid` workgroups, or None where a streamed tile would be
+    cut more than once (ar_gemm_dw_sk sums at most two parts)."""
+    tiles = tm * tn
+    if grid < 1 or depth < 16 or depth % 16 or K < depth:
+        return None
+    iters = -(-K // depth)
+    sk = tiles % grid + grid if tiles > grid else tiles
+    n_dp = tiles - sk
+    total = sk * iters
+    run = -(-total // grid)
+    if run < iters:
+        return None
+    cuts = np.arange(run, total, run, dtype=np.int64)
+    j, s = cuts // iters, cuts % iters
+    keep = s > 0
+    j, s = j[keep], s[keep]
+    if len(np.unique(j)) != len(j):
+        return None
+    ksplit = np.zeros(sk, dtype=np.int32)
+    ksplit[j] = (s * depth).astype(np.int32)
+    return Structure(int(grid), int(wgm), int(depth), int(n_dp), tile_order(tm, tn, wgm), ksplit)
+
+
+def discover(mismatch: np.ndarray, K: int, grids: Optional[Iterable[int]] = None, wgms: Iterable[int] = WGMS,
+             depths: Iterable[int] = DEPTHS, limit: int = 8) -> List[Structure]:
+    """Candidate structures for a library result whose tiles `mismatch` ([tm, tn] bool) differ from a one-pass sum: every differing
+    tile must be a two-part tile of the candidate; fewest two-part tiles that do NOT differ first (a part of a few iterations often
+    leaves the bf16 result as it was, so that count is small but not zero).  Distinct structures only."""
+    mm = np.asarray(mismatch, dtype=bool)
+    tm, tn = mm.shape
+    flat = mm.reshape(-1)
+    n_mis = int(flat.sum())
+    if n_mis == 0:
+        return []
+    if grids is None:
+        # G - 1 cuts, all but those landing on a tile boundary split a tile; a few split tiles do not show
+        grids = range(max(2, n_mis), int(n_mis * 1.25) + 34)
+    orders = {w: tile_order(tm, tn, w) for w in wgms if abs(w) <= (tm if w > 0 else tn) or abs(w) == 1}
+    found, seen = [], set()
+    for depth in depths:
+        for grid in grids:
+            base = structure(tm, tn, K, grid, 1, depth)
+            if base is None:
+                continue
+            split_pos = np.nonzero(base.ksplit)[0] + base.n_dp
+            if len(split_pos) < n_mis:
+                continue
+            for w, order in orders.items():
+                if int(flat[order[split_pos]].sum()) != n_mis:
+                    continue
+                st = Structure(base.grid, w, depth, base.n_dp, order, base.ksplit)
+                k = st.key()
+                if k in seen:
+                    continue
+                seen.add(k)
+                found.append((len(split_pos) - n_mis, st))
+    found.sort(key=lambda t: t[0])
+    return [st for _, st in found[:limit]]
+
+
+_found = {}     # (device index, M, N, K) -> (Structure, tlist tensor, ksplit tensor) | None
+
+
+def find_on_device(dY2d, X2d, lib_out=None):
+    """The structure that makes `ops.gemm_dw_sk` equal, bit for bit, to the library's `dY2d.t() @ X2d` on these operands (a real
+    gradient pair), or None.  -> (Structure, tlist, ksplit) with the tables on the operands' device; cached per shape and device."""
+    import torch
+
+    from . import ops
+    K, M = dY2d.shape
+    N = X2d.shape[1]
+    key = (dY2d.device.index, M, N, K)
+    if key in _found:
+        return _found[key]
+    _found[key] = None
+    if M % TILE or N % TILE or dY2d.dtype != torch.bfloat16:
+        return None
+    lib = torch.mm(dY2d.t(), X2d) if lib_out is None else lib_out
+    mine = torch.empty_like(lib)
+    if not ops.gemm_dw(dY2d, X2d, mine, split=False):
+        return None
+    tm, tn = M // TILE, N // TILE
+    libi = lib.view(torch.int16)
+    mm = ~(mine.view(torch.int16) == libi).view(tm, TILE, tn, TILE).all(dim=3).all(dim=1)
+    for st in discover(mm.cpu().numpy(), K):
+        tl = torch.from_numpy(st.tlist).to(dY2d.device)
+        ks = torch.from_numpy(st.ksplit).to(dY2d.device)
+        if ops.gemm_dw_sk(dY2d, X2d, mine, tl, ks, st.n_dp) and bool(torch.equal(mine.view(torch.int16), libi)):
+            _found[key] = (st, tl, ks)
+            break
+    return _found[key]

@@ -1,0 +1,78 @@
+"""Host logic of the stream-K summation structure (auto_round_amd/streamk.py) against the map measured on the library
+(tests/golden/streamk_llama8b_dw_map.json, made by tools/gpu/r04_dw_streamk_probe.py on an MI355X)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from auto_round_amd import streamk as sk
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "streamk_llama8b_dw_map.json")
+
+
+def test_tile_order_is_a_permutation_and_walks_bands():
+    for tm, tn, w in [(56, 16, 6), (16, 56, 6), (5, 7, 3), (4, 4, 1), (3, 9, -4), (8, 8, -8), (7, 3, 16)]:
+        o = sk.tile_order(tm, tn, w)
+        assert sorted(o.tolist()) == list(range(tm * tn))
+    o = sk.tile_order(5, 3, 2).tolist()
+    # band of rows 0-1: columns in turn, rows fastest; then rows 2-3; then the single row 4
+    assert o == [0, 3, 1, 4, 2, 5, 6, 9, 7, 10, 8, 11, 12, 13, 14]
+    assert sk.tile_order(2, 5, -2).tolist() == [0, 1, 5, 6, 2, 3, 7, 8, 4, 9]
+    assert sk.tile_order(3, 4, 1).tolist() == list(range(12))
+    with pytest.raises(ValueError):
+        sk.tile_order(2, 2, 0)
+
+
+def test_structure_counts():
+    st = sk.structure(56, 16, 16384, 246, 6, 32)
+    assert st.n_dp == 492 and len(st.ksplit) == 404 and st.n_dp % 246 == 0
+    assert st.two_part_tiles == 245                       # 245 cuts, none on a tile boundary
+    assert (st.ksplit % 32 == 0).all() and st.ksplit.max() < 16384
+    # a grid that divides the tiles: everything in one pass except the streamed last `grid` tiles, which the cuts leave whole
+    st = sk.structure(7, 32, 4096, 224, 4, 32)
+    assert st.n_dp == 0 or st.two_part_tiles == 0
+    # runs shorter than a tile would cut a tile twice: not a structure ar_gemm_dw_sk can sum
+    assert sk.structure(2, 2, 16384, 16, 1, 32) is None
+    assert sk.structure(4, 4, 16, 8, 1, 32) is None       # K below one iteration
+
+
+@pytest.mark.parametrize("name", ["g", "d"])
+def test_structure_reproduces_the_measured_map(name):
+    rec = json.load(open(GOLD))[name]
+    seen = np.array(rec["split_row_by_tile"])
+    tm, tn = seen.shape
+    st = sk.structure(tm, tn, rec["K"], 246, 6, 32)
+    pred = np.zeros(tm * tn, dtype=np.int64)
+    pred[st.tlist[st.n_dp:]] = st.ksplit
+    pred = pred.reshape(tm, tn)
+    differ = np.argwhere(pred != seen)
+    # the only disagreements: cuts within 45 iterations of the tile end, where the probe's first matching s is not unique
+    assert len(differ) <= 8
+    for r, c in differ:
+        assert pred[r, c] >= (512 - 45) * 32, (r, c, pred[r, c], seen[r, c])
+    # every tile the probe found to be in two parts is a two-part tile of the structure
+    assert ((seen > 0) <= (pred > 0)).all()
+
+
+@pytest.mark.parametrize("name", ["g", "d"])
+def test_discover_finds_the_structure_from_the_mismatch_mask(name):
+    rec = json.load(open(GOLD))[name]
+    seen = np.array(rec["split_row_by_tile"])
+    found = sk.discover(seen > 0, rec["K"])
+    assert found and (found[0].grid, found[0].wgm, found[0].depth, found[0].n_dp) == (246, 6, 32, 492)
+    assert sk.discover(np.zeros_like(seen, dtype=bool), rec["K"]) == []
+
+
+def test_discover_round_trip_on_synthetic_structures():
+    rng = np.random.default_rng(0)
+    for tm, tn, K, grid, wgm, depth in [(24, 16, 8192, 200, 8, 32), (16, 24, 8192, 120, -4, 64), (40, 8, 4096, 96, 1, 32)]:
+        st = sk.structure(tm, tn, K, grid, wgm, depth)
+        assert st is not None
+        mask = np.zeros(tm * tn, dtype=bool)
+        split = st.tlist[st.n_dp:][st.ksplit > 0]
+        mask[split] = True
+        hide = rng.choice(split, size=min(2, len(split)), replace=False)      # split tiles that happen to equal the one-pass sum
+        mask[hide] = False
+        found = sk.discover(mask.reshape(tm, tn), K)
+        assert any(f.key() == st.key() for f in found), (tm, tn, grid, wgm, depth)
