@@ -74,7 +74,7 @@ SIGNATURES = {
     "ar_swiglu_bwd_exact": (c_int, [P, P, L, P, L, P, L, P, L, L, L, I, I, P]),
     "ar_gemm_dw": (c_int, [P, P, P, L, L, L, L, L, L, I, P, L, P]),
     "ar_gemm_dw_ex": (c_int, [P, P, P, L, L, L, L, L, L, I, P, L, I, P]),
-    "ar_gemm_dw_sk": (c_int, [P, P, P, L, L, L, L, L, L, I, P, L, P, P, I, P]),
+    "ar_gemm_dw_sk": (c_int, [P, P, P, L, L, L, L, L, L, P, L, P, P]),
     "ar_gemm_dw_workspace_bytes": (c_int64, [L, L, L]),
     "ar_gemm_dw_config": (c_int, [I, I]),
     "ar_attn_fwd": (c_int, [P, P, P, P, P, L, L, L, L, F, I, L, L, P]),

@@ -52,18 +52,11 @@ struct GemmArgs {
     int nsplit;
     int tile0;           // > 0: split-K over the LAST tiles of the launch order only (tile0 = first of them); partial tiles are
                          // then stored compactly, [tile - tile0][nsplit][256][256]
-    const int* tlist;    // caller-given launch order (ar_gemm_dw_sk): entry i = row-major tile id; nullptr: the kernel's own order
-    const int* ksplit;   // ar_gemm_dw_sk: per split tile (entry tile - tile0) the k-row where its two parts meet, 0 = one part
+    const int* kcut;     // ar_gemm_dw_sk: per row-major tile the k-row where its two parts meet (0 = one part); ws = [tile][256 * 256] fp32
 };
 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& a, int bid, int& tm, int& tn) {
     const int nwg = a.tiles_m * a.tiles_n;
-    if (a.tlist) {
-        const int id = a.tlist[bid];
-        tm = id / a.tiles_n;
-        tn = id % a.tiles_n;
-        return;
-    }
     if (a.order == 2 && (a.tiles_m % 2 == 0) && (a.tiles_n % 8 == 0) && ((nwg / 16) % 8 == 0)) {
         const int x = bid & 7, s = bid >> 3, t = s >> 4, j = s & 15;
         const int pn = a.tiles_n >> 3;
@@ -545,7 +538,11 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw2_abl(GemmArgs a) {
 // TAIL: K is not a multiple of 128 (an expert's share of the tokens in a MoE block): the last 128-row chunk is completed with
 // zeros -- every lane of the LDS-DMA supplies its own source address, so rows past K simply read a 512-byte row of zeros.
 __device__ __attribute__((aligned(512))) uint16_t g_zero_row[256];
-template <bool STAGGER, bool SPLITK = false, bool TAIL = false>
+// CUT (ar_gemm_dw_sk): a tile may be the sum of TWO accumulations, k-rows [0, cut) and [cut, K) -- the structure of a stream-K
+// kernel that hands the tile's K range to two workgroups.  One workgroup still walks the whole K in order (same operand traffic
+// and L2 sharing as the plain kernel): at the cut it parks its accumulators in the workspace (fp32, lane-major), restarts from zero,
+// and adds the parked part back before the one rounding to bf16.
+template <bool STAGGER, bool SPLITK = false, bool TAIL = false, bool CUT = false>
 __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -555,29 +552,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     int sp = 0;
     int64_t krow0 = 0, kend = a.K;
     int U = (a.K + 127) / 128 * 8;                 // k16 units, whole 128-row chunks (without TAIL the host guarantees K % 128 == 0)
-    bool part = SPLITK;                            // this workgroup leaves an fp32 partial tile in the workspace
-    int slot = 0;                                  // ... at this compact slot
-    if (SPLITK && TAIL && a.ksplit) {
-        // a caller-given stream-K structure (ar_gemm_dw_sk), one launch: workgroups [0, tile0) sum a whole tile each and store it;
-        // the others come in pairs, one per part of a two-part tile: part 0 = k-rows [0, ks), part 1 = [ks, K); ks = 0: one part
-        int b = blockIdx.x;
-        if (b < a.tile0) {
-            tile_of_block(a, b, tm, tn);
-            part = false;
-        } else {
-            b -= a.tile0;
-            sp = b & 1;
-            const int tile = b >> 1;
-            const int ks = a.ksplit[tile];
-            if (sp == 1 && ks == 0) return;        // uniform over the workgroup, before any barrier
-            tile_of_block(a, a.tile0 + tile, tm, tn);
-            krow0 = sp ? ks : 0;
-            kend = (sp == 0 && ks > 0) ? ks : a.K;
-            U = (int)((kend - krow0 + 127) / 128) * 8;
-            part = ks > 0;
-            slot = b;
-        }
-    } else if (SPLITK) {
+    if (SPLITK) {
         sp = blockIdx.x % a.nsplit;
         const int tile = blockIdx.x / a.nsplit;
         if (a.tile0 > 0) {
@@ -594,6 +569,9 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
         tile_of_block(a, blockIdx.x, tm, tn);
     }
     const int64_t m0 = (int64_t)tm * GB, n0 = (int64_t)tn * GB;
+    const int tile_id = tm * a.tiles_n + tn;
+    const int cut_u = CUT ? (a.kcut[tile_id] >> 4) : 0;                         // in k16 units; 0: no cut
+    float* park = CUT ? a.ws + (int64_t)tile_id * (GB * GB) + tid * 4 : nullptr;
 
     const int drow = 2 * wave + (lane >> 5);
     const int lchunk = (lane & 31) ^ ((drow & 3) << 2);
@@ -706,25 +684,50 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     wait_vm<8>();
     bar();
     if (STAGGER && grp == 1) bar();
+    auto park_acc = [&]() {                          // the cut: accumulators out (32 x 16 bytes per lane, coalesced), restart from zero
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    st16f(park + ((mi * 4 + ni) * 4 + t) * (GTHREADS * 4), make_float4(acc[mi][ni][4 * t + 0], acc[mi][ni][4 * t + 1],
+                                                                                      acc[mi][ni][4 * t + 2], acc[mi][ni][4 * t + 3]));
+                    acc[mi][ni][4 * t + 0] = 0.f; acc[mi][ni][4 * t + 1] = 0.f; acc[mi][ni][4 * t + 2] = 0.f; acc[mi][ni][4 * t + 3] = 0.f;
+                }
+    };
     for (int u = 0; u < U; u += 8) {
         AR_PHASE(0);
+        if (CUT && u + 2 == cut_u) park_acc();
         AR_PHASE(1);
+        if (CUT && u + 4 == cut_u) park_acc();
         AR_PHASE(2);
+        if (CUT && u + 6 == cut_u) park_acc();
         AR_PHASE(3);
+        if (CUT && u + 8 == cut_u) park_acc();
     }
     if (STAGGER && grp == 0) bar();
     wait_vm<0>();
+    if (CUT && cut_u > 0) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 p = *reinterpret_cast<const float4*>(park + ((mi * 4 + ni) * 4 + t) * (GTHREADS * 4));
+                    acc[mi][ni][4 * t + 0] += p.x; acc[mi][ni][4 * t + 1] += p.y; acc[mi][ni][4 * t + 2] += p.z; acc[mi][ni][4 * t + 3] += p.w;
+                }
+    }
 #undef AR_PHASE
 #undef AR_RD
 #undef AR_MMA
 #undef AR_PIN
 
     const int h = lane >> 5;
-    if (SPLITK && part) {
-        const bool sk = TAIL && a.ksplit;
-        const bool compact = a.tile0 > 0 || sk;
-        float* wsp = sk ? a.ws + (int64_t)slot * (GB * GB)
-                        : (compact ? a.ws + ((int64_t)(blockIdx.x / a.nsplit) * a.nsplit + sp) * (GB * GB) : a.ws + (int64_t)sp * a.M * a.N);
+    if (SPLITK) {
+        const bool compact = a.tile0 > 0;
+        float* wsp = compact ? a.ws + ((int64_t)(blockIdx.x / a.nsplit) * a.nsplit + sp) * (GB * GB) : a.ws + (int64_t)sp * a.M * a.N;
         const int64_t wld = compact ? GB : a.N;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -1025,7 +1028,6 @@ __global__ __launch_bounds__(kTPB) void k_splitk_reduce_tiles(GemmArgs a) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    if (a.ksplit && a.ksplit[t] == 0) return;                        // ar_gemm_dw_sk: a one-part tile was stored by its workgroup
     for (int s = 0; s < a.nsplit; ++s) {
         float p[8];
         unpack_f8(load8_f32(base, (int64_t)s * (GB * GB)), p);
@@ -1113,39 +1115,31 @@ extern "C" int ar_gemm_dw_ex(const void* dY, const void* X, void* dW, int64_t M,
     return gemm_dw_impl(dY, X, dW, M, N, K, ldy, ldx, ldw, accumulate, workspace, workspace_bytes, nsplit, stream);
 }
 
-// The summation structure of a stream-K GEMM, given by the caller: the tiles `tlist[0 .. n_dp)` (row-major tile ids, in launch
-// order) are summed in one pass over K; each of the remaining tiles `tlist[n_dp + i]` in two parts, k-rows [0, ksplit[i]) and
-// [ksplit[i], K) (a multiple of 16; 0 = one part after all), each from a zero accumulator, added in fp32 and rounded once.  This is
-// how the exact path reproduces, bit for bit, a library kernel that streams its last tiles over a fixed grid.
-// Both tables live on the device.  Workspace: (tiles - n_dp) * 2 * 256 * 256 * 4 bytes.
+// The summation structure of a stream-K GEMM, given by the caller: tile t (row-major 256 x 256 tile id) is summed in one pass over
+// K when kcut[t] == 0, else in two parts, k-rows [0, kcut[t]) and [kcut[t], K) (a multiple of 32, 0 < kcut < K), each from a zero
+// accumulator, added in fp32 and rounded once.  This is how the exact path reproduces, bit for bit, a library kernel that streams
+// its last tiles over a fixed grid (auto_round_amd/streamk.py).  kcut lives on the device.  Workspace: tiles * 256 * 256 * 4 bytes
+// (only the two-part tiles' slots are touched).
 extern "C" int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
-                             int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, const int32_t* tlist,
-                             const int32_t* ksplit, int n_dp, ar_stream_t stream) {
+                             int64_t ldw, void* workspace, int64_t workspace_bytes, const int32_t* kcut, ar_stream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return AR_OK;
-    if (M % GB || N % GB || K < 128 || (ldy % 8) || (ldx % 8) || (ldw % 8) || !tlist) return AR_ERR_UNSUPPORTED;
-    if ((((uintptr_t)dY | (uintptr_t)X) & 15) || ((uintptr_t)dW & 15)) return AR_ERR_UNSUPPORTED;
+    if (M % GB || N % GB || K < 128 || (ldy % 8) || (ldx % 8) || (ldw % 4) || !kcut) return AR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)dY | (uintptr_t)X) & 15) || ((uintptr_t)dW & 7) || ((uintptr_t)workspace & 15)) return AR_ERR_UNSUPPORTED;
     GemmArgs a;
-    a.ws = nullptr; a.nsplit = 1; a.tile0 = 0; a.tlist = tlist; a.ksplit = nullptr;
+    a.nsplit = 1; a.tile0 = 0; a.kcut = kcut; a.ws = (float*)workspace;
     a.Y = (const uint16_t*)dY; a.X = (const uint16_t*)X; a.W = (uint16_t*)dW;
-    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = accumulate;
-    a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = 0;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = 0;
+    a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = g_gemm_order;
     const int grid = a.tiles_m * a.tiles_n;
-    if (n_dp < 0 || n_dp > grid) return AR_ERR_UNSUPPORTED;
-    const int n_sk = grid - n_dp;
-    if (n_sk && (!ksplit || !workspace || workspace_bytes < (int64_t)n_sk * 2 * GB * GB * 4)) return AR_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < (int64_t)grid * GB * GB * 4) return AR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     static PerDeviceOnce once;
     if (once.first()) {
-        (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     }
-    if (!n_sk) {
-        AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, true>), grid, GTHREADS, GEMM_LDS, st, a);
-        return launch_status();
-    }
-    a.ws = (float*)workspace; a.nsplit = 2; a.tile0 = n_dp; a.ksplit = ksplit;
-    AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, true, true>), n_dp + n_sk * 2, GTHREADS, GEMM_LDS, st, a);
-    hipLaunchKernelGGL(k_splitk_reduce_tiles, n_sk * 32, kTPB, 0, st, a);
+    if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, true, true>), grid, GTHREADS, GEMM_LDS, st, a);
+    else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, false, true>), grid, GTHREADS, GEMM_LDS, st, a);
     return launch_status();
 }
 
@@ -1156,7 +1150,7 @@ static int gemm_dw_impl(const void* dY, const void* X, void* dW, int64_t M, int6
     if (K % 128 && g_gemm_kernel != 7) return AR_ERR_UNSUPPORTED;       // only the default kernel completes a ragged K with zeros
     if (((uintptr_t)dY | (uintptr_t)X) & 15 || ((uintptr_t)dW & 7)) return AR_ERR_UNSUPPORTED;
     GemmArgs a;
-    a.ws = nullptr; a.nsplit = 1; a.tile0 = 0; a.tlist = nullptr; a.ksplit = nullptr;
+    a.ws = nullptr; a.nsplit = 1; a.tile0 = 0; a.kcut = nullptr;
     a.Y = (const uint16_t*)dY; a.X = (const uint16_t*)X; a.W = (uint16_t*)dW;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = accumulate;
     a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = g_gemm_order;

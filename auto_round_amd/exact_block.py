@@ -190,7 +190,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
         if mode == STREAMK and not acc and out2d.is_contiguous():      # -1: the library kernel's own stream-K structure (streamk.py)
             st = streamk.find_on_device(dY2d, X2d)          # found on the proof's minibatch, a dictionary lookup afterwards
             if st is not None:
-                done = ops.gemm_dw_sk(dY2d, X2d, out2d, st[1], st[2], st[0].n_dp)
+                done = ops.gemm_dw_sk(dY2d, X2d, out2d, st[1])
         elif mode > 0 and not acc and out2d.is_contiguous():      # (accumulating micro-batches: the library's addmm_, as the module path -- the
             done = ops.gemm_dw(dY2d, X2d, out2d, accumulate=False, split=(False if mode == 1 else mode))      # proof covered the plain product)
         if not done:

@@ -790,10 +790,10 @@ def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate
     return True
 
 
-def gemm_dw_sk(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, tlist: torch.Tensor, ksplit: torch.Tensor, n_dp: int) -> bool:
-    """out[M,N] = dY2d[K,M]^T @ X2d[K,N] with a stream-K summation structure (ar_gemm_dw_sk): the tiles `tlist[:n_dp]` (row-major
-    256 x 256 tile ids, int32, on the device) in one pass over K, each tile `tlist[n_dp + i]` as k-rows [0, ksplit[i]) + [ksplit[i], K)
-    (0 = one part).  -> False when the shape is outside what the kernel takes."""
+def gemm_dw_sk(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, kcut: torch.Tensor) -> bool:
+    """out[M,N] = dY2d[K,M]^T @ X2d[K,N] with a stream-K summation structure (ar_gemm_dw_sk): the 256 x 256 output tile t (row-major)
+    in one pass over K when kcut[t] == 0, else as k-rows [0, kcut[t]) + [kcut[t], K).  kcut: int32 [tiles] on the device, multiples
+    of 32.  -> False when the shape is outside what the kernel takes."""
     if dY2d.dtype != torch.bfloat16 or X2d.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
         return False
     if dY2d.dim() != 2 or X2d.dim() != 2 or out.dim() != 2 or dY2d.stride(1) != 1 or X2d.stride(1) != 1 or out.stride(1) != 1:
@@ -805,29 +805,24 @@ def gemm_dw_sk(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, tlist: 
     if M % 256 or N % 256:
         return False
     tiles = (M // 256) * (N // 256)
-    n_dp = int(n_dp)
-    for t, n in ((tlist, tiles), (ksplit, tiles - n_dp)):
-        if t.dtype != torch.int32 or t.dim() != 1 or not t.is_contiguous() or t.numel() < n:
-            raise ValueError("gemm_dw_sk: tlist / ksplit must be contiguous int32 tables of tiles / tiles - n_dp entries")
+    if kcut.dtype != torch.int32 or kcut.dim() != 1 or not kcut.is_contiguous() or kcut.numel() != tiles:
+        raise ValueError("gemm_dw_sk: kcut must be a contiguous int32 table with one entry per 256 x 256 output tile")
     devs = set()
-    for t in (dY2d, X2d, out, tlist, ksplit):
+    for t in (dY2d, X2d, out, kcut):
         if not t.is_cuda:
             raise _lib.Mi355xLibraryError("gemm_dw_sk: the MI355X path only runs on a HIP device and has no CPU fallback")
         devs.add(t.device.index)
     if len(devs) != 1:
         raise _lib.Mi355xLibraryError("gemm_dw_sk: tensors live on different HIP devices")
     (dev,) = devs
-    ws_bytes = (tiles - n_dp) * 2 * 256 * 256 * 4
-    ws = None
-    if ws_bytes > 0:
-        ws = _gemm_ws.get(dev)
-        if ws is None or ws.numel() < ws_bytes:
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=f"cuda:{dev}")
-            _gemm_ws[dev] = ws
+    ws_bytes = tiles * 256 * 256 * 4
+    ws = _gemm_ws.get(dev)
+    if ws is None or ws.numel() < ws_bytes:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=f"cuda:{dev}")
+        _gemm_ws[dev] = ws
     with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
         rc = load().ar_gemm_dw_sk(dY2d.data_ptr(), X2d.data_ptr(), out.data_ptr(), M, N, K, dY2d.stride(0), X2d.stride(0), out.stride(0),
-                                  0, None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), tlist.data_ptr(),
-                                  ksplit.data_ptr(), n_dp, torch.cuda.current_stream(dev).cuda_stream)
+                                  ws.data_ptr(), ws.numel(), kcut.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     if rc == _lib.AR_ERR_UNSUPPORTED:
         return False
     check(rc, "ar_gemm_dw_sk")

@@ -22,7 +22,7 @@ import numpy as np
 
 TILE = 256
 WGMS = (1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 32, -2, -3, -4, -5, -6, -7, -8, -12, -16, -32)
-DEPTHS = (32, 64, 16, 128)
+DEPTHS = (32, 64, 128)
 
 
 @dataclass(frozen=True)
@@ -35,7 +35,13 @@ class Structure:
     ksplit: np.ndarray       # int32 [tiles - n_dp]: k-row where the tile's two parts meet, 0 = one part
 
     def key(self) -> bytes:
-        return self.tlist[self.n_dp:].tobytes() + self.ksplit.tobytes() + self.tlist[:self.n_dp].tobytes()
+        return self.kcut().tobytes()
+
+    def kcut(self) -> np.ndarray:
+        """int32 [tiles], row-major: the k-row where the tile's two parts meet, 0 = one pass (what ar_gemm_dw_sk takes)"""
+        out = np.zeros(len(self.tlist), dtype=np.int32)
+        out[self.tlist[self.n_dp:]] = self.ksplit
+        return out
 
     @property
     def two_part_tiles(self) -> int:
@@ -58,9 +64,9 @@ def tile_order(tm: int, tn: int, wgm: int) -> np.ndarray:
 
 def structure(tm: int, tn: int, K: int, grid: int, wgm: int, depth: int = 32) -> Optional[Structure]:
     """The two-tile stream-K structure of a tm x tn tile problem over `grid` workgroups, or None where a streamed tile would be
-    cut more than once (ar_gemm_dw_sk sums at most two parts)."""
+    cut more than once (ar_gemm_dw_sk sums at most two parts) or not at a multiple of 32 k-rows."""
     tiles = tm * tn
-    if grid < 1 or depth < 16 or depth % 16 or K < depth:
+    if grid < 1 or depth < 32 or depth % 32 or K < depth:
         return None
     iters = -(-K // depth)
     sk = tiles % grid + grid if tiles > grid else tiles
@@ -117,12 +123,12 @@ def discover(mismatch: np.ndarray, K: int, grids: Optional[Iterable[int]] = None
     return [st for _, st in found[:limit]]
 
 
-_found = {}     # (device index, M, N, K) -> (Structure, tlist tensor, ksplit tensor) | None
+_found = {}     # (device index, M, N, K) -> (Structure, kcut tensor on the device) | None
 
 
 def find_on_device(dY2d, X2d, lib_out=None):
     """The structure that makes `ops.gemm_dw_sk` equal, bit for bit, to the library's `dY2d.t() @ X2d` on these operands (a real
-    gradient pair), or None.  -> (Structure, tlist, ksplit) with the tables on the operands' device; cached per shape and device."""
+    gradient pair), or None.  -> (Structure, kcut) with the table on the operands' device; cached per shape and device."""
     import torch
 
     from . import ops
@@ -142,9 +148,8 @@ def find_on_device(dY2d, X2d, lib_out=None):
     libi = lib.view(torch.int16)
     mm = ~(mine.view(torch.int16) == libi).view(tm, TILE, tn, TILE).all(dim=3).all(dim=1)
     for st in discover(mm.cpu().numpy(), K):
-        tl = torch.from_numpy(st.tlist).to(dY2d.device)
-        ks = torch.from_numpy(st.ksplit).to(dY2d.device)
-        if ops.gemm_dw_sk(dY2d, X2d, mine, tl, ks, st.n_dp) and bool(torch.equal(mine.view(torch.int16), libi)):
-            _found[key] = (st, tl, ks)
+        kc = torch.from_numpy(st.kcut()).to(dY2d.device)
+        if ops.gemm_dw_sk(dY2d, X2d, mine, kc) and bool(torch.equal(mine.view(torch.int16), libi)):
+            _found[key] = (st, kc)
             break
     return _found[key]

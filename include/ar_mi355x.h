@@ -355,14 +355,13 @@ int ar_gemm_dw(const void* dY, const void* X, void* dW, int64_t M, int64_t N, in
  * whichever structure proves equal on the installed stack.  A structure that cannot be delivered returns AR_ERR_UNSUPPORTED. */
 int ar_gemm_dw_ex(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
                   int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, int nsplit, ar_stream_t stream);
-/* The same GEMM with a stream-K summation structure given by the caller: the tiles tlist[0 .. n_dp) (row-major 256 x 256 tile ids
- * in launch order) are summed in one pass over K, each remaining tile tlist[n_dp + i] in two parts, k-rows [0, ksplit[i]) and
- * [ksplit[i], K) (multiples of 16; 0 = one part), each from a zero accumulator, added in fp32, rounded once.  Reproduces the
- * library kernel behind the same autograd GEMM (auto_round/wrapper.py:528-556) when that kernel streams its last tiles over a
- * fixed workgroup grid.  tlist / ksplit are device arrays; workspace = (tiles - n_dp) * 2 * 256 * 256 * 4 bytes. */
+/* The same GEMM with a stream-K summation structure given by the caller: tile t (row-major id of the 256 x 256 output tiles) is
+ * summed in one pass over K when kcut[t] == 0, else in two parts, k-rows [0, kcut[t]) and [kcut[t], K) (a multiple of 32), each
+ * from a zero accumulator, added in fp32, rounded once.  Reproduces the library kernel behind the same autograd GEMM
+ * (auto_round/wrapper.py:528-556) when that kernel streams its last tiles over a fixed workgroup grid (auto_round_amd/streamk.py
+ * finds the structure).  kcut is a device array of tiles entries; workspace = tiles * 256 * 256 * 4 bytes, 16-byte aligned. */
 int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
-                  int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, const int32_t* tlist,
-                  const int32_t* ksplit, int n_dp, ar_stream_t stream);
+                  int64_t ldw, void* workspace, int64_t workspace_bytes, const int32_t* kcut, ar_stream_t stream);
 /* caller-owned scratch ar_gemm_dw wants for (M, N, K) (the library never allocates): 0 when the output tiles alone fill the
  * chip; otherwise the fp32 partial tiles of its split-K form (few tiles, deep K -- e.g. OPT-125M's 768x768 weight against 16384
  * tokens), which are summed in slice order, i.e. deterministically.  Without the workspace the call still works, unsplit. */

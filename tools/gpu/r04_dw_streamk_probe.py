@@ -24,20 +24,19 @@ for name in only:
     lib = torch.mm(dY.t(), X).view(torch.int16)
     tm, tn = o // 256, i // 256
     tiles = tm * tn
-    tlist = torch.arange(tiles, dtype=torch.int32, device=DEV)
     mine = torch.empty(o, i, dtype=BF, device=DEV)
 
     def tile_eq():
         return (mine.view(torch.int16) == lib).view(tm, 256, tn, 256).all(dim=3).all(dim=1).reshape(-1)
 
     ks = torch.zeros(tiles, dtype=torch.int32, device=DEV)
-    assert ops.gemm_dw_sk(dY, X, mine, tlist, ks, 0)
+    assert ops.gemm_dw_sk(dY, X, mine, ks)
     one = tile_eq()
     ref1 = torch.empty_like(mine)
     assert ops.gemm_dw(dY, X, ref1, split=False)
     sane1 = bool(torch.equal(ref1.view(torch.int16), mine.view(torch.int16)))
     ks.fill_(T // 2)
-    assert ops.gemm_dw_sk(dY, X, mine, tlist, ks, 0)
+    assert ops.gemm_dw_sk(dY, X, mine, ks)
     assert ops.gemm_dw(dY, X, ref1, split=2)
     sane2 = bool(torch.equal(ref1.view(torch.int16), mine.view(torch.int16)))
     found = torch.where(one, torch.zeros(tiles, dtype=torch.int64, device=DEV), torch.full((tiles,), -1, dtype=torch.int64, device=DEV))
@@ -45,7 +44,7 @@ for name in only:
     if not bool(one.all()):
         for s in range(step, T, step):
             ks.fill_(s)
-            assert ops.gemm_dw_sk(dY, X, mine, tlist, ks, 0)
+            assert ops.gemm_dw_sk(dY, X, mine, ks)
             eq = tile_eq()
             nmatch += eq.to(torch.int64)
             found = torch.where((found < 0) & eq, torch.full_like(found, s), found)

@@ -33,7 +33,7 @@ for name, (o, i) in dict(g=(14336, 4096), d=(4096, 14336)).items():
     st = streamk.find_on_device(dY, X)
     rec = dict(found=st is not None)
     if st is not None:
-        s, tl, ks = st
+        s, kc = st
         rec.update(grid=s.grid, wgm=s.wgm, depth=s.depth, one_pass_tiles=s.n_dp, two_part_tiles=s.two_part_tiles)
         same = []
         for seed in (12, 13, 14):
@@ -42,14 +42,14 @@ for name, (o, i) in dict(g=(14336, 4096), d=(4096, 14336)).items():
             X2 = (torch.randn(T, i, device=DEV, generator=gen) * 3).to(BF)
             lib = torch.mm(dY2.t(), X2)
             mine = torch.empty_like(lib)
-            assert ops.gemm_dw_sk(dY2, X2, mine, tl, ks, s.n_dp)
+            assert ops.gemm_dw_sk(dY2, X2, mine, kc)
             same.append(bool(torch.equal(lib.view(torch.int16), mine.view(torch.int16))))
         rec["equal_on_other_operands"] = same
         mine = torch.empty(o, i, dtype=BF, device=DEV)
         fl = 2.0 * T * o * i
         for label, fn in dict(library=lambda: torch.mm(dY.t(), X, out=mine), mfma_own_plan=lambda: ops.gemm_dw(dY, X, mine),
                               mfma_one_pass=lambda: ops.gemm_dw(dY, X, mine, split=False),
-                              mfma_streamk_structure=lambda: ops.gemm_dw_sk(dY, X, mine, tl, ks, s.n_dp)).items():
+                              mfma_streamk_structure=lambda: ops.gemm_dw_sk(dY, X, mine, kc)).items():
             ms = timed(fn)
             rec[label] = dict(ms=round(ms, 4), pflops=round(fl / ms / 1e12, 3))
     out[name] = rec
