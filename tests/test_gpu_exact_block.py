@@ -240,3 +240,66 @@ def test_no_grad_passes_run_on_the_exact_kernels_and_keep_the_module_codes_bits(
         assert q_ex._build_exact_plain(block, x0, others, 8) is None
     finally:
         h.remove()
+
+
+# ---- the stream-K form of the weight-gradient GEMM (ar_gemm_dw_sk, auto_round_amd/streamk.py) ---------------------------------
+def _operands(K, M, N, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    dY = (0.01 * torch.randn(K, M, device=DEV, generator=g)).to(torch.bfloat16)
+    X = torch.randn(K, N, device=DEV, generator=g).to(torch.bfloat16)
+    return dY, X
+
+
+@pytest.mark.parametrize("K", [2048, 448])          # 448 = 3.5 chunks of 128 k-rows: the zero-completed last chunk
+def test_gemm_dw_sk_is_the_two_part_sum_it_says(K):
+    from auto_round_amd import ops
+    M, N = 512, 768
+    dY, X = _operands(K, M, N, 3)
+    tiles = (M // 256) * (N // 256)
+    one, got = torch.empty(M, N, dtype=torch.bfloat16, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    assert ops.gemm_dw(dY, X, one, split=False)
+    kcut = torch.zeros(tiles, dtype=torch.int32, device=DEV)
+    assert ops.gemm_dw_sk(dY, X, got, kcut)                         # no cut anywhere: the one-pass kernel's bits
+    assert torch.equal(got.view(torch.int16), one.view(torch.int16))
+    half = (-(-K // 128) // 2) * 128                                # where ar_gemm_dw_ex(nsplit=2) puts its slice boundary
+    two = torch.empty_like(one)
+    assert ops.gemm_dw(dY, X, two, split=2)
+    kcut.fill_(half)
+    assert ops.gemm_dw_sk(dY, X, got, kcut)
+    assert torch.equal(got.view(torch.int16), two.view(torch.int16))
+    # a cut per tile, at multiples of 32 k-rows that are not chunk boundaries: part sums in fp32 from sliced operands
+    cuts = [32 * (1 + (5 * t) % (K // 32 - 1)) for t in range(tiles)]
+    kcut.copy_(torch.tensor(cuts, dtype=torch.int32))
+    assert ops.gemm_dw_sk(dY, X, got, kcut)
+    ref = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    for t, c in enumerate(cuts):
+        r0, c0 = (t // (N // 256)) * 256, (t % (N // 256)) * 256
+        a, b = dY[:, r0:r0 + 256].float(), X[:, c0:c0 + 256].float()
+        ref[r0:r0 + 256, c0:c0 + 256] = a[:c].t() @ b[:c] + a[c:].t() @ b[c:]
+    assert (got.float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    with pytest.raises(ValueError):
+        ops.gemm_dw_sk(dY, X, got, kcut[:-1].contiguous())
+
+
+def test_streamk_structure_found_on_one_gradient_pair_reproduces_the_library_on_others():
+    """Llama-3-8B's gate / up gradient shape, where the library's kernel streams its last tiles over a fixed grid: whatever the
+    installed library does there, the structure `find_on_device` settles on (or the one-pass kernel) must give its bits on
+    operands it has not seen."""
+    from auto_round_amd import ops, streamk
+    K, M, N = 16384, 14336, 4096
+    dY, X = _operands(K, M, N, 21)
+    streamk._found.pop((torch.device(DEV).index or 0, M, N, K), None)
+    st = streamk.find_on_device(dY, X)
+    lib = torch.mm(dY.t(), X)
+    one = torch.empty_like(lib)
+    assert ops.gemm_dw(dY, X, one, split=False)
+    if st is None:
+        assert torch.equal(one.view(torch.int16), lib.view(torch.int16)), "neither one pass nor a stream-K structure reproduces the library"
+        return
+    structure, kcut = st
+    assert structure.two_part_tiles > 0 and structure.n_dp % structure.grid == 0
+    for seed in (22, 23):
+        dY2, X2 = _operands(K, M, N, seed)
+        got = torch.empty_like(lib)
+        assert ops.gemm_dw_sk(dY2, X2, got, kcut)
+        assert torch.equal(got.view(torch.int16), torch.mm(dY2.t(), X2).view(torch.int16))
