@@ -31,7 +31,8 @@ Objects on the JSON line (N=1).  The driver's record keeps `config`, `roofline` 
                     (12 B/elem + 8 B/group, +4 B/elem on snapshot iterations);  `.opt125m` = K1 / K2 of the OPT-125M block
   cpu_baseline      oracle/torch_ref (torch restatement of the reference loop, kind "port") timed on the host cores on a
                     bounded sample;  `.reference_quoted` = the REAL reference's CPU figure from the build container;  `.opt125m`
-  config            workload, path, mask, the proven `exact_plan`;  `.bit_identical_path` (rate + live digest verdict + the module
+  config            workload, path, mask, the proven `exact_plan` (+ `exact_streamk`: the library's stream-K structures the weight
+                    gradients reproduce);  `.bit_identical_path` (rate + live digest verdict + the module
                     path's rate), `.trajectory_level_paths` (fused path with / without the mask), `.parity`, `.opt125m`
   opt125m, variants, parity, roofline_bwd_sgd, cpu_reference_quoted   the same objects in full at the top level
 """
@@ -611,6 +612,7 @@ def main():
                        "path": path, "exact_rounding": bool(getattr(b.quantizer, "last_exact", False)),
                        "fused_block": bool(getattr(b.quantizer, "last_fused_block", False) and not getattr(b.quantizer, "last_exact", False)),
                        "exact_plan": (getattr(b.quantizer, "last_exact_report", None) or {}).get("plan"),
+                       "exact_streamk": (getattr(b.quantizer, "last_exact_report", None) or {}).get("streamk"),
                        "hip_graph": bool(getattr(b.quantizer, "last_hip_graph", False)),
                        "sdpa_backend": b.sdpa, "alg_ext": bool(args.alg_ext),
                        "attention_mask": ("calibration: the [1, 1, S, S] 0/1 additive mask of the reference's calibration flow "

@@ -120,3 +120,43 @@ def test_the_no_grad_form_is_the_same_forward():
         eb, _, _ = _exact_over(blk, cfg, pe)
         y = eb._forward_impl(x, others, None)
     assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16)) and not y.requires_grad
+
+
+def test_streamk_plan_value_routes_the_weight_gradient_through_the_found_structure_or_the_library(monkeypatch):
+    """dw_* = STREAMK: `_dw_x` asks streamk.find_on_device for the shape's structure and hands its cut table to ops.gemm_dw_sk; with no
+    structure the library GEMM runs (and `_streamk_found` says so, which is what keeps the plan search from recording an unproven
+    option).  Host logic only: both device calls are stubbed."""
+    from auto_round_amd import exact_block, ops, streamk
+    cfg, blk, x, pe = _layer()
+    eb, layers, mods = _exact_over(blk, cfg, pe)
+    T = x.shape[0] * x.shape[1]
+    dY = torch.randn(T, layers["g"].weight_q.shape[0]).to(torch.bfloat16)
+    X = torch.randn(T, layers["g"].weight_q.shape[1]).to(torch.bfloat16)
+    want = torch.mm(dY.t(), X)
+    calls = []
+
+    def fake_sk(dY2d, X2d, out, kcut):
+        calls.append(kcut)
+        torch.mm(dY2d.t(), X2d, out=out)
+        return True
+
+    monkeypatch.setattr(ops, "gemm_dw_sk", fake_sk)
+    eb.plan["dw_g"] = exact_block.STREAMK
+    M, N = layers["g"].weight_q.shape
+    st = streamk.Structure(4, 1, 32, 0, streamk.tile_order(1, 1, 1), torch.zeros(1, dtype=torch.int32).numpy())
+    monkeypatch.setattr(streamk, "_found", {(None, M, N, T): (st, "kcut-table")})
+    monkeypatch.setattr(streamk, "find_on_device", lambda a, b: streamk._found[(None, a.shape[1], b.shape[1], a.shape[0])])
+    layers["g"]._dw_accum[0] = False
+    eb._dw_x("g", dY, X)
+    assert calls == ["kcut-table"] and torch.equal(layers["g"].weight_grad, want)
+    assert eb._streamk_found("g") is st
+    # accumulating micro-batches never take the first-party form (the proof covered the plain product only)
+    eb._dw_x("g", dY, X)
+    assert len(calls) == 1
+    # no structure for the shape: the library runs, and the plan search can see that nothing was proven
+    monkeypatch.setattr(streamk, "_found", {(None, M, N, T): None})
+    layers["g"]._dw_accum[0] = False
+    layers["g"].weight_grad.zero_()
+    eb._dw_x("g", dY, X)
+    assert len(calls) == 1 and torch.equal(layers["g"].weight_grad, want)
+    assert eb._streamk_found("g") is None
