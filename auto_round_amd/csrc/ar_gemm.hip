@@ -570,7 +570,11 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     }
     const int64_t m0 = (int64_t)tm * GB, n0 = (int64_t)tn * GB;
     const int tile_id = tm * a.tiles_n + tn;
-    const int cut_u = CUT ? (a.kcut[tile_id] >> 4) : 0;                         // in k16 units; 0: no cut
+    int cut_u = 0;                                                              // the cut in k16 units; 0: none
+    if (CUT) {
+        const int cut = a.kcut[tile_id];
+        if (cut > 0 && cut < a.K && (cut & 31) == 0) cut_u = cut >> 4;          // (anything else in the table: one pass)
+    }
     float* park = CUT ? a.ws + (int64_t)tile_id * (GB * GB) + tid * 4 : nullptr;
 
     const int drow = 2 * wave + (lane >> 5);

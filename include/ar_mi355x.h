@@ -357,7 +357,8 @@ int ar_gemm_dw_ex(const void* dY, const void* X, void* dW, int64_t M, int64_t N,
                   int64_t ldw, int accumulate, void* workspace, int64_t workspace_bytes, int nsplit, ar_stream_t stream);
 /* The same GEMM with a stream-K summation structure given by the caller: tile t (row-major id of the 256 x 256 output tiles) is
  * summed in one pass over K when kcut[t] == 0, else in two parts, k-rows [0, kcut[t]) and [kcut[t], K) (a multiple of 32), each
- * from a zero accumulator, added in fp32, rounded once.  Reproduces the library kernel behind the same autograd GEMM
+ * from a zero accumulator, added in fp32, rounded once (an entry that is not such a multiple of 32 inside (0, K) means one pass).
+ * Reproduces the library kernel behind the same autograd GEMM
  * (auto_round/wrapper.py:528-556) when that kernel streams its last tiles over a fixed workgroup grid (auto_round_amd/streamk.py
  * finds the structure).  kcut is a device array of tiles entries; workspace = tiles * 256 * 256 * 4 bytes, 16-byte aligned. */
 int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,

@@ -277,6 +277,10 @@ def test_gemm_dw_sk_is_the_two_part_sum_it_says(K):
         a, b = dY[:, r0:r0 + 256].float(), X[:, c0:c0 + 256].float()
         ref[r0:r0 + 256, c0:c0 + 256] = a[:c].t() @ b[:c] + a[c:].t() @ b[c:]
     assert (got.float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    # entries that are not a multiple of 32 inside (0, K) mean "one pass"
+    kcut.copy_(torch.tensor([16, K, -32, K + 64, 48, 0][:tiles], dtype=torch.int32))
+    assert ops.gemm_dw_sk(dY, X, got, kcut)
+    assert torch.equal(got.view(torch.int16), one.view(torch.int16))
     with pytest.raises(ValueError):
         ops.gemm_dw_sk(dY, X, got, kcut[:-1].contiguous())
 
