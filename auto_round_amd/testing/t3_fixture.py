@@ -31,6 +31,8 @@ ARCHS = {
     "opt125m": dict(family="opt", hidden=768, ffn=3072, heads=12, vocab=50272),
     # BASELINE configs[1]: Llama-3-8B's decoder block (small vocabulary: embeddings are not on the path)
     "llama8b": dict(family="llama", hidden=4096, ffn=14336, heads=32, kv=8, vocab=4096),
+    # BASELINE configs[3]: Llama-3-70B's decoder block (K = 8192: rows ATen's reduction splits over 8 thread-rows, other library GEMM kernels)
+    "llama70b": dict(family="llama", hidden=8192, ffn=28672, heads=64, kv=8, vocab=4096),
     # BASELINE configs[4]: Mixtral-8x7B's sparse-MoE decoder block (8 experts, top-2)
     "mixtral8x7b": dict(family="moe", hidden=4096, ffn=14336, heads=32, kv=8, experts=8, top_k=2, vocab=4096),
     "mixtral_tiny": dict(family="moe", hidden=128, ffn=256, heads=4, kv=2, experts=4, top_k=2, vocab=256),      # (dry runs of the tooling)

@@ -55,6 +55,8 @@ BIG_CASES = {
                                           iters=200, nsamples=64, seqlen=2048, batch_size=8),
     "llama8b_mxfp4_200": dict(arch="llama8b", scheme="MXFP4", kw={}, iters=200, nsamples=64, seqlen=2048, batch_size=8),
     "llama8b_nvfp4_200": dict(arch="llama8b", scheme="NVFP4", kw={}, iters=200, nsamples=64, seqlen=2048, batch_size=8),
+    # configs[3]'s block (Llama-3-70B dimensions) at the full iteration count
+    "llama70b_w4g128_200": dict(arch="llama70b", scheme="W4A16", kw={}, iters=200, nsamples=64, seqlen=2048, batch_size=8),
     # configs[4] itself with a learning rate that lets the trajectory move (1 / 200) and 64 samples
     "mixtral8x7b_mxfp4_100": dict(arch="mixtral8x7b", scheme="MXFP4", kw=dict(lr=5e-3, minmax_lr=5e-3), iters=100, nsamples=64, seqlen=2048,
                                   batch_size=8),
@@ -472,6 +474,7 @@ def main():
     ap.add_argument("--ref-twice", default="", help="cases whose reference run is repeated (reproducibility of the reference itself)")
     ap.add_argument("--digest-dir", default=None, help="write a scheme-agnostic digest t3v2_<case>.npz of every dense case's reference result here")
     args = ap.parse_args()
+    from auto_round_amd.testing import t3_fixture as fx
     if reference_root() is None:
         raise SystemExit("reference tree not present: run tools/stage_reference.sh first")
     recs = []
@@ -481,7 +484,7 @@ def main():
                              skip_alone=args.skip_alone, digest_path=os.path.abspath(args.digest) if (args.digest and c == "llama8b_w4g128_full") else None,
                              ref_twice=c in args.ref_twice.split(","),
                              digest_v2_path=(os.path.join(os.path.abspath(args.digest_dir), f"t3v2_{c}.npz")
-                                             if (args.digest_dir and BIG_CASES[c]["arch"] == "llama8b") else None))
+                                             if (args.digest_dir and fx.ARCHS[BIG_CASES[c]["arch"]]["family"] == "llama") else None))
         except Exception as e:
             import traceback
 
