@@ -212,9 +212,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
             N = self.layers[names[0]].weight_q.shape[1]
         else:
             M, N = self.layers[key].weight_q.shape
-        w = self.layers["q"].weight_q
-        hits = [v for (dev, m, n, _k), v in streamk._found.items() if dev == w.device.index and (m, n) == (M, N) and v is not None]
-        return hits[-1][0] if hits else None
+        return streamk.found_for(self.layers["q"].weight_q.device.index, M, N)
 
     def _dx_x(self, key, dY2d):
         wt = self._tnx.get(key)

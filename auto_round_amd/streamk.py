@@ -126,6 +126,12 @@ def discover(mismatch: np.ndarray, K: int, grids: Optional[Iterable[int]] = None
 _found = {}     # (device index, M, N, K) -> (Structure, kcut tensor on the device) | None
 
 
+def found_for(device_index, M: int, N: int) -> Optional[Structure]:
+    """the structure `find_on_device` settled on for a [M, N] weight gradient on that device (any K), or None"""
+    hits = [v for (dev, m, n, _k), v in _found.items() if dev == device_index and (m, n) == (M, N) and v is not None]
+    return hits[-1][0] if hits else None
+
+
 def find_on_device(dY2d, X2d, lib_out=None):
     """The structure that makes `ops.gemm_dw_sk` equal, bit for bit, to the library's `dY2d.t() @ X2d` on these operands (a real
     gradient pair), or None.  -> (Structure, kcut) with the table on the operands' device; cached per shape and device."""
