@@ -188,9 +188,13 @@ class ExactLlamaBlock(FusedLlamaBlock):
         done = False
         mode = int(self.plan.get("dw_" + key) or 0)         # 0: library; 1: MFMA kernel, one pass over K; n >= 2: n contiguous K slices;
         if mode == STREAMK and not acc and out2d.is_contiguous():      # -1: the library kernel's own stream-K structure (streamk.py)
-            st = streamk.find_on_device(dY2d, X2d)          # found on the proof's minibatch, a dictionary lookup afterwards
-            if st is not None:
-                done = ops.gemm_dw_sk(dY2d, X2d, out2d, st[1])
+            if len(lyrs) > 1:                               # merged rows: every layer's rows in the structure of ITS OWN library GEMM
+                kcut = streamk.find_merged_on_device(dY2d, X2d, [l.weight_q.shape[0] for l in lyrs])
+            else:
+                st = streamk.find_on_device(dY2d, X2d)      # found on the proof's minibatch, a dictionary lookup afterwards
+                kcut = None if st is None else st[1]
+            if kcut is not None:
+                done = ops.gemm_dw_sk(dY2d, X2d, out2d, kcut)
         elif mode > 0 and not acc and out2d.is_contiguous():      # (accumulating micro-batches: the library's addmm_, as the module path -- the
             done = ops.gemm_dw(dY2d, X2d, out2d, accumulate=False, split=(False if mode == 1 else mode))      # proof covered the plain product)
         if not done:
@@ -205,14 +209,24 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 post()
 
     def _streamk_found(self, key):
-        """the stream-K structure the last `_dw_x(key, ...)` with plan value STREAMK ran with, or None"""
-        if key in ("qkv", "gu"):
-            names = ("q", "k", "v") if key == "qkv" else ("g", "u")
-            M = sum(self.layers[n].weight_q.shape[0] for n in names)
-            N = self.layers[names[0]].weight_q.shape[1]
-        else:
-            M, N = self.layers[key].weight_q.shape
-        return streamk.found_for(self.layers["q"].weight_q.device.index, M, N)
+        """what the last `_dw_x(key, ...)` with plan value STREAMK ran with: per layer of `key` the stream-K structure (None: one pass
+        is that layer's library sum), or None when the call fell through to the library"""
+        names = {"qkv": ("q", "k", "v"), "gu": ("g", "u")}.get(key, (key,))
+        dev = self.layers[names[0]].weight_q.device.index
+        if len(names) > 1:
+            rows = tuple(int(self.layers[n].weight_q.shape[0]) for n in names)
+            if not any(v is not None for (d, r, _n, _k), v in streamk._merged.items() if d == dev and r == rows):
+                return None
+        out = []
+        for n in names:
+            M, N = self.layers[n].weight_q.shape
+            hits = [v for (d, m, nn, _k), v in streamk._found.items() if d == dev and (m, nn) == (M, N) and v is not None]
+            if not hits:
+                return None
+            out.append(hits[-1][0])
+        if all(st is None for st in out):      # every layer is a one-pass sum: plan value 1 covers that, STREAMK proves nothing new
+            return None if len(names) == 1 else out
+        return out
 
     def _dx_x(self, key, dY2d):
         wt = self._tnx.get(key)
@@ -503,11 +517,12 @@ class ExactLlamaBlock(FusedLlamaBlock):
                     if not same(tv):
                         continue
                     if tv.get(opt) == STREAMK:
-                        st = self._streamk_found(opt[3:])
-                        if st is None:         # no structure found: the call fell through to the library, nothing was proven
+                        sts = self._streamk_found(opt[3:])
+                        if sts is None:        # no structure found: the call fell through to the library, nothing was proven
                             continue
-                        report.setdefault("streamk", {})[opt] = dict(grid=st.grid, wgm=st.wgm, depth=st.depth, one_pass_tiles=st.n_dp,
-                                                                       two_part_tiles=st.two_part_tiles)
+                        report.setdefault("streamk", {})[opt] = [
+                            dict(one_pass=True) if st is None else dict(grid=st.grid, wgm=st.wgm, depth=st.depth, one_pass_tiles=st.n_dp,
+                                                                        two_part_tiles=st.two_part_tiles) for st in sts]
                     plan = tv
                     report["kept"].append(opt)
                     if attempt:

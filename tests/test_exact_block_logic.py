@@ -149,7 +149,7 @@ def test_streamk_plan_value_routes_the_weight_gradient_through_the_found_structu
     layers["g"]._dw_accum[0] = False
     eb._dw_x("g", dY, X)
     assert calls == ["kcut-table"] and torch.equal(layers["g"].weight_grad, want)
-    assert eb._streamk_found("g") is st
+    assert eb._streamk_found("g") == [st] and eb._streamk_found("g")[0] is st
     # accumulating micro-batches never take the first-party form (the proof covered the plain product only)
     eb._dw_x("g", dY, X)
     assert len(calls) == 1
@@ -160,3 +160,19 @@ def test_streamk_plan_value_routes_the_weight_gradient_through_the_found_structu
     eb._dw_x("g", dY, X)
     assert len(calls) == 1 and torch.equal(layers["g"].weight_grad, want)
     assert eb._streamk_found("g") is None
+    # the merged gate | up gradient: one launch, every layer's rows in the structure of its own library GEMM
+    F = layers["g"].weight_q.shape[0]
+    dgu = torch.randn(T, 2 * F).to(torch.bfloat16)
+    eb.dWgu = torch.empty(2 * F, N, dtype=torch.bfloat16)
+    eb.plan["dw_gu"] = exact_block.STREAMK
+    asked = []
+    monkeypatch.setattr(streamk, "find_merged_on_device", lambda a, b, rows: asked.append(list(rows)) or "merged-table")
+    for n in ("g", "u"):
+        layers[n]._dw_accum[0] = False
+    eb._dw_x("gu", dgu, X)
+    assert asked == [[F, F]] and calls[-1] == "merged-table" and torch.equal(eb.dWgu, torch.mm(dgu.t(), X))
+    monkeypatch.setattr(streamk, "_merged", {(None, (F, F), N, T): "merged-table"})
+    monkeypatch.setattr(streamk, "_found", {(None, M, N, T): (st, "kcut-table")})
+    assert eb._streamk_found("gu") == [st, st]
+    monkeypatch.setattr(streamk, "_merged", {})
+    assert eb._streamk_found("gu") is None

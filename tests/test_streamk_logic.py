@@ -76,3 +76,28 @@ def test_discover_round_trip_on_synthetic_structures():
         mask[hide] = False
         found = sk.discover(mask.reshape(tm, tn), K)
         assert any(f.key() == st.key() for f in found), (tm, tn, grid, wgm, depth)
+
+
+def test_merged_table_is_the_parts_tables_in_row_order(monkeypatch):
+    import torch
+    sk._merged.clear()
+    seen = []
+
+    def fake_find(dY, X, lib_out=None):
+        seen.append((tuple(dY.shape), dY.is_contiguous()))
+        m = dY.shape[1]
+        if m == 768:
+            return None
+        return (None, torch.full(((m // 256) * (X.shape[1] // 256),), m, dtype=torch.int32))
+
+    monkeypatch.setattr(sk, "find_on_device", fake_find)
+    dY, X = torch.zeros(64, 512 + 256, dtype=torch.bfloat16), torch.zeros(64, 512, dtype=torch.bfloat16)
+    kc = sk.find_merged_on_device(dY, X, [512, 256])
+    assert kc.tolist() == [512] * 4 + [256] * 2                  # 2 x 2 tiles of the first part, then 1 x 2 of the second
+    assert seen == [((64, 512), True), ((64, 256), True)]        # contiguous copies: the operand form of the module path's own call
+    assert sk.find_merged_on_device(dY, X, [512, 256]) is kc     # cached
+    assert sk.find_merged_on_device(dY, X, [256, 256]) is None   # rows that do not add up
+    assert sk.find_merged_on_device(dY, X, [384, 384]) is None   # not whole tiles
+    dY2 = torch.zeros(64, 768 + 256, dtype=torch.bfloat16)
+    assert sk.find_merged_on_device(dY2, X, [768, 256]) is None  # a part without a reproducing structure
+    sk._merged.clear()
