@@ -144,7 +144,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
     def base_plan() -> Dict[str, bool]:
         """every segment on torch's own ops, every GEMM as the module path issues it"""
         plan = {k: False for k in KERNEL_OPTS + GEMM_OPTS}
-        plan.update(swiglu_contract=True, norm_rsqrt_f32=False, dw_pack=False)
+        plan.update(swiglu_contract=True, norm_rsqrt_f32=False)
         return plan
 
     def set_plan(self, plan: Dict[str, bool]):
@@ -360,20 +360,8 @@ class ExactLlamaBlock(FusedLlamaBlock):
         if dy2d.dtype != self.dtype:
             dy2d = dy2d.to(self.dtype)
         dy2d = dy2d.contiguous()
-        # dw_pack: the weight gradients of down_proj and o_proj wait for the merged q/k/v one (the last GEMM of the backward: the
-        # block input needs no gradient) and the three first-party kernels run side by side on three streams -- 896 + 256 + 384 tiles
-        # are six full rounds of 256 workgroups instead of 4 + 1 + 2 (the same kernels on the same operands: no bit changes)
-        pack = bool(P.get("dw_pack")) and not self.layers["d"]._dw_accum[0]
-        late = []
-
-        def dw(key, dY, X):
-            if pack:
-                late.append((key, dY, X))
-            else:
-                self._dw_x(key, dY, X)
-
         # y = x2 + down(act_in)
-        dw("d", dy2d, s.pop("act_in"))
+        self._dw_x("d", dy2d, s.pop("act_in"))
         dact = bq(self._dx_x("d", dy2d), s.pop("act"), aq["d"])
         g2d, u2d, act_graph = s.pop("g2d"), s.pop("u2d"), s.pop("act_graph")
         Fd = self.Fdim
@@ -409,7 +397,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
             dx2 = gx.reshape(T, H) + dy2d
         del dh2, norm_graph
         # x2 = x + o(a_in)
-        dw("o", dx2, s.pop("a_in"))
+        self._dw_x("o", dx2, s.pop("a_in"))
         da = bq(self._dx_x("o", dx2), s.pop("a2d"), aq["o"])
         del dx2
         al, ao = s.pop("attn_leaves"), s.pop("attn_out")
@@ -433,31 +421,12 @@ class ExactLlamaBlock(FusedLlamaBlock):
         h1_in = s.pop("h1_in")
         if dqkv is not None:
             dqkv[:, nq + nk:].view(B, S, hkv, hd).copy_(gv4.transpose(1, 2))
-        if late:
-            main = torch.cuda.current_stream(dy2d.device)
-            ready = main.record_event()
-            sides = self._side_streams(dy2d.device, len(late))
-            for (key, dY, X), st in zip(late, sides):
-                st.wait_event(ready)
-                with torch.cuda.stream(st):
-                    self._dw_x(key, dY, X)
-        if dqkv is not None:
             self._dw_x("qkv", dqkv, h1_in)
         else:
             dv2d = gv4.transpose(1, 2).reshape(T, nk)
             self._dw_x("q", dq2d.contiguous(), h1_in)
             self._dw_x("k", dk2d.contiguous(), h1_in)
             self._dw_x("v", dv2d.contiguous(), h1_in)
-        if late:
-            for st in sides:
-                main.wait_stream(st)      # (the operands stay referenced by `late` until here; what follows is ordered after the join)
-            late.clear()
-
-    def _side_streams(self, device, n):
-        have = getattr(self, "_streams", None)
-        if have is None or len(have) < n or have[0].device != torch.device(device):
-            self._streams = have = [torch.cuda.Stream(device=device) for _ in range(n)]
-        return have[:n]
 
     # -- the proof -----------------------------------------------------------------------------------------------------------
     def _run_once(self, x, others, dpred):
@@ -467,18 +436,6 @@ class ExactLlamaBlock(FusedLlamaBlock):
         y = _FusedBlockFn.apply(x, self.arena.token, self, others)
         y.backward(dpred)
         return y.detach(), [a.dWq.clone() for a in self.arenas]
-
-    def _time_plan(self, plan, x, others, dpred, reps=3) -> float:
-        """ms per forward + backward of `plan` on the proof minibatch (device events; the first run warms up)"""
-        self.set_plan(plan)
-        self._run_once(x, others, dpred)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            self._run_once(x, others, dpred)
-        b.record()
-        torch.cuda.synchronize(x.device)
-        return a.elapsed_time(b) / reps
 
     def plan_against_module(self, module_forward, x, others, ref, want=None) -> Optional[dict]:
         """One minibatch `x` ([rows, S, H], the loop's real minibatch shape: the library picks its GEMM kernels by shape) with targets
@@ -575,17 +532,6 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 # call, profiles/r04_digest_repeat.json): an option that failed once gets one more comparison before it is dropped
                 if opt in report["kept"] or opt.startswith("dw_"):
                     break
-        # side-by-side weight gradients: only first-party kernels (the library's GEMMs share a workspace per handle), and only where it
-        # is FASTER on this device -- the bits cannot change, the time can
-        if (want is None or "dw_pack" in want) and plan["dw_d"] and plan["dw_o"] and plan["dw_qkv"] and x.is_cuda:
-            report["tried"].append("dw_pack")
-            trial = dict(plan, dw_pack=True)
-            if same(trial):
-                t_plain, t_pack = self._time_plan(plan, x, others, dpred), self._time_plan(trial, x, others, dpred)
-                report["dw_pack_ms"] = dict(separate=round(t_plain, 3), side_by_side=round(t_pack, 3))
-                if t_pack < t_plain:
-                    plan = trial
-                    report["kept"].append("dw_pack")
         self.set_plan(plan)
         reset()
         self.plan_report = dict(report, usable=True, plan={k: (int(v) if k.startswith("dw_") else bool(v)) for k, v in plan.items()})

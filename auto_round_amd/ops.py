@@ -771,11 +771,10 @@ def gemm_dw(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, accumulate
     ws_bytes = load().ar_gemm_dw_workspace_bytes(M, N, K) if forced == 0 else (forced * M * N * 4 if forced > 1 else 0)
     ws = None
     if ws_bytes > 0:                # split-K partial tiles: one growing scratch buffer per device, reused by every call
-        wkey = (dev, torch.cuda.current_stream(dev).cuda_stream)      # per stream: weight-gradient GEMMs may run side by side
-        ws = _gemm_ws.get(wkey)
+        ws = _gemm_ws.get(dev)
         if ws is None or ws.numel() < ws_bytes:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=f"cuda:{dev}")
-            _gemm_ws[wkey] = ws
+            _gemm_ws[dev] = ws
     with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
         if forced:
             rc = load().ar_gemm_dw_ex(dY2d.data_ptr(), X2d.data_ptr(), out.data_ptr(), M, N, K, dY2d.stride(0), X2d.stride(0), out.stride(0),
@@ -817,11 +816,10 @@ def gemm_dw_sk(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, kcut: t
         raise _lib.Mi355xLibraryError("gemm_dw_sk: tensors live on different HIP devices")
     (dev,) = devs
     ws_bytes = tiles * 256 * 256 * 4
-    wkey = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _gemm_ws.get(wkey)
+    ws = _gemm_ws.get(dev)
     if ws is None or ws.numel() < ws_bytes:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=f"cuda:{dev}")
-        _gemm_ws[wkey] = ws
+        _gemm_ws[dev] = ws
     with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
         rc = load().ar_gemm_dw_sk(dY2d.data_ptr(), X2d.data_ptr(), out.data_ptr(), M, N, K, dY2d.stride(0), X2d.stride(0), out.stride(0),
                                   ws.data_ptr(), ws.numel(), kcut.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
