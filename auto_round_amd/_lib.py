@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 24
+ABI_VERSION = 23
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -75,7 +75,6 @@ SIGNATURES = {
     "ar_gemm_dw": (c_int, [P, P, P, L, L, L, L, L, L, I, P, L, P]),
     "ar_gemm_dw_ex": (c_int, [P, P, P, L, L, L, L, L, L, I, P, L, I, P]),
     "ar_gemm_dw_sk": (c_int, [P, P, P, L, L, L, L, L, L, P, L, P, P]),
-    "ar_gemm_dw_group": (c_int, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ar_gemm_dw_workspace_bytes": (c_int64, [L, L, L]),
     "ar_gemm_dw_config": (c_int, [I, I]),
     "ar_attn_fwd": (c_int, [P, P, P, P, P, L, L, L, L, F, I, L, L, P]),

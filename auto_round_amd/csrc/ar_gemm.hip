@@ -542,8 +542,8 @@ __device__ __attribute__((aligned(512))) uint16_t g_zero_row[256];
 // kernel that hands the tile's K range to two workgroups.  One workgroup still walks the whole K in order (same operand traffic
 // and L2 sharing as the plain kernel): at the cut it parks its accumulators in the workspace (fp32, lane-major), restarts from zero,
 // and adds the parked part back before the one rounding to bf16.
-template <bool STAGGER, bool SPLITK, bool TAIL, bool CUT>
-__device__ __forceinline__ void gemm_dw4_body(const GemmArgs& a, const int bid) {      // bid: the workgroup's index within ITS problem
+template <bool STAGGER, bool SPLITK = false, bool TAIL = false, bool CUT = false>
+__global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -553,8 +553,8 @@ __device__ __forceinline__ void gemm_dw4_body(const GemmArgs& a, const int bid) 
     int64_t krow0 = 0, kend = a.K;
     int U = (a.K + 127) / 128 * 8;                 // k16 units, whole 128-row chunks (without TAIL the host guarantees K % 128 == 0)
     if (SPLITK) {
-        sp = bid % a.nsplit;
-        const int tile = bid / a.nsplit;
+        sp = blockIdx.x % a.nsplit;
+        const int tile = blockIdx.x / a.nsplit;
         if (a.tile0 > 0) {
             tile_of_block(a, a.tile0 + tile, tm, tn);      // the tail of the full launch's own tile order
         } else {
@@ -566,7 +566,7 @@ __device__ __forceinline__ void gemm_dw4_body(const GemmArgs& a, const int bid) 
         krow0 = (int64_t)c0 * 128;
         U = (c1 - c0) * 8;
     } else {
-        tile_of_block(a, bid, tm, tn);
+        tile_of_block(a, blockIdx.x, tm, tn);
     }
     const int64_t m0 = (int64_t)tm * GB, n0 = (int64_t)tn * GB;
     const int tile_id = tm * a.tiles_n + tn;
@@ -731,7 +731,7 @@ __device__ __forceinline__ void gemm_dw4_body(const GemmArgs& a, const int bid) 
     const int h = lane >> 5;
     if (SPLITK) {
         const bool compact = a.tile0 > 0;
-        float* wsp = compact ? a.ws + ((int64_t)(bid / a.nsplit) * a.nsplit + sp) * (GB * GB) : a.ws + (int64_t)sp * a.M * a.N;
+        float* wsp = compact ? a.ws + ((int64_t)(blockIdx.x / a.nsplit) * a.nsplit + sp) * (GB * GB) : a.ws + (int64_t)sp * a.M * a.N;
         const int64_t wld = compact ? GB : a.N;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -767,29 +767,6 @@ __device__ __forceinline__ void gemm_dw4_body(const GemmArgs& a, const int bid) 
             }
         }
     }
-}
-
-template <bool STAGGER, bool SPLITK = false, bool TAIL = false, bool CUT = false>
-__global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
-    gemm_dw4_body<STAGGER, SPLITK, TAIL, CUT>(a, blockIdx.x);
-}
-
-// Several weight-gradient GEMMs as ONE grid (ar_gemm_dw_group): workgroup -> (problem, tile).  Tiles of different problems fill
-// common rounds of 256 workgroups -- Llama-3-8B's down / o / merged q-k-v gradients are 896 + 256 + 384 tiles = six full rounds
-// instead of 4 + 1 + 2 -- and nothing else changes: every tile is summed by the same code in the same order.
-constexpr int kMaxGroup = 4;
-struct GroupArgs {
-    GemmArgs p[kMaxGroup];
-    int first[kMaxGroup + 1];      // first workgroup of each problem (multiples of 8: the XCD-aware tile order counts from there)
-    int n;
-};
-template <bool TAIL>
-__global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4_group(GroupArgs g) {
-    int i = 0;
-#pragma unroll
-    for (int j = 1; j < kMaxGroup; ++j)
-        if (j < g.n && (int)blockIdx.x >= g.first[j]) i = j;
-    gemm_dw4_body<true, false, TAIL, true>(g.p[i], (int)blockIdx.x - g.first[i]);
 }
 
 #ifdef AR_GEMM_EXPERIMENTS
@@ -1167,53 +1144,6 @@ extern "C" int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M,
     }
     if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, true, true>), grid, GTHREADS, GEMM_LDS, st, a);
     else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, false, true>), grid, GTHREADS, GEMM_LDS, st, a);
-    return launch_status();
-}
-
-// n <= 4 weight-gradient GEMMs in one launch (see k_gemm_dw4_group).  Arrays of n entries each; kcut[i] may be null (every tile of
-// problem i in one pass; then workspace[i] is not needed), else as ar_gemm_dw_sk.  All problems: M, N multiples of 256, tile counts
-// multiples of 8, K >= 128.  Anything else: AR_ERR_UNSUPPORTED, nothing launched.
-extern "C" int ar_gemm_dw_group(int n, const void* const* dY, const void* const* X, void* const* dW, const int64_t* M, const int64_t* N,
-                                const int64_t* K, const int64_t* ldy, const int64_t* ldx, const int64_t* ldw, void* const* workspace,
-                                const int64_t* workspace_bytes, const int32_t* const* kcut, const int32_t* zero_kcut, ar_stream_t stream) {
-    if (n < 1 || n > kMaxGroup || !zero_kcut) return AR_ERR_UNSUPPORTED;
-    GroupArgs g;
-    g.n = n;
-    int total = 0;
-    bool tail = false;
-    for (int i = 0; i < n; ++i) {
-        if (M[i] <= 0 || N[i] <= 0 || M[i] % GB || N[i] % GB || K[i] < 128 || (ldy[i] % 8) || (ldx[i] % 8) || (ldw[i] % 4)) return AR_ERR_UNSUPPORTED;
-        if ((((uintptr_t)dY[i] | (uintptr_t)X[i]) & 15) || ((uintptr_t)dW[i] & 7)) return AR_ERR_UNSUPPORTED;
-        GemmArgs& a = g.p[i];
-        a.nsplit = 1; a.tile0 = 0;
-        a.Y = (const uint16_t*)dY[i]; a.X = (const uint16_t*)X[i]; a.W = (uint16_t*)dW[i];
-        a.M = (int)M[i]; a.N = (int)N[i]; a.K = (int)K[i]; a.ldy = ldy[i]; a.ldx = ldx[i]; a.ldw = ldw[i]; a.accumulate = 0;
-        a.tiles_m = (int)(M[i] / GB); a.tiles_n = (int)(N[i] / GB); a.order = g_gemm_order;
-        const int tiles = a.tiles_m * a.tiles_n;
-        if (tiles % 8) return AR_ERR_UNSUPPORTED;
-        if (kcut[i]) {
-            if (!workspace[i] || workspace_bytes[i] < (int64_t)tiles * GB * GB * 4 || ((uintptr_t)workspace[i] & 15)) return AR_ERR_UNSUPPORTED;
-            a.kcut = kcut[i]; a.ws = (float*)workspace[i];
-        } else {
-            if (tiles > (1 << 20)) return AR_ERR_UNSUPPORTED;      // zero_kcut: at least max(tiles) zero entries, caller-owned
-            a.kcut = zero_kcut; a.ws = nullptr;
-        }
-        g.first[i] = total;
-        total += tiles;
-        tail = tail || (K[i] % 128);
-    }
-    for (int i = n; i <= kMaxGroup; ++i) g.first[i] = total;
-    for (int i = n; i < kMaxGroup; ++i) g.p[i] = g.p[0];
-    hipStream_t st = (hipStream_t)stream;
-    static PerDeviceOnce once;
-    if (once.first()) {
-        (void)hipFuncSetAttribute((const void*)k_gemm_dw4_group<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        (void)hipFuncSetAttribute((const void*)k_gemm_dw4_group<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    }
-    int64_t work = 0;
-    for (int i = 0; i < n; ++i) work += M[i] * N[i];
-    if (tail) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, work, (k_gemm_dw4_group<true>), total, GTHREADS, GEMM_LDS, st, g);
-    else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, work, (k_gemm_dw4_group<false>), total, GTHREADS, GEMM_LDS, st, g);
     return launch_status();
 }
 

@@ -144,7 +144,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
     def base_plan() -> Dict[str, bool]:
         """every segment on torch's own ops, every GEMM as the module path issues it"""
         plan = {k: False for k in KERNEL_OPTS + GEMM_OPTS}
-        plan.update(swiglu_contract=True, norm_rsqrt_f32=False, group_dw=False)
+        plan.update(swiglu_contract=True, norm_rsqrt_f32=False)
         return plan
 
     def set_plan(self, plan: Dict[str, bool]):
@@ -175,37 +175,24 @@ class ExactLlamaBlock(FusedLlamaBlock):
         b = self.layers[key].orig_layer.bias
         return None if b is None else b.to(self.dtype)
 
-    def _dw_target(self, key):
-        """layers and arena slice a weight gradient `key` ("q" ... "d", or the merged "qkv" / "gu") is written to"""
-        if key in ("qkv", "gu"):
-            lyrs = [self.layers[n] for n in ("q", "k", "v")] if key == "qkv" else [self.layers["g"], self.layers["u"]]
-            return lyrs, (self.dWqkv if key == "qkv" else self.dWgu)
-        return [self.layers[key]], self.layers[key].weight_grad
-
-    def _dw_table(self, key, lyrs, dY2d, X2d):
-        """the cut table of plan value STREAMK for this GEMM (found on the proof's minibatch, a dictionary lookup afterwards), or None"""
-        if len(lyrs) > 1:                                   # merged rows: every layer's rows in the structure of ITS OWN library GEMM
-            return streamk.find_merged_on_device(dY2d, X2d, [l.weight_q.shape[0] for l in lyrs])
-        st = streamk.find_on_device(dY2d, X2d)
-        return None if st is None else st[1]
-
-    @staticmethod
-    def _dw_done(lyrs):
-        for lyr in lyrs:
-            lyr._dw_accum[0] = True
-            post = getattr(lyr, "_post_dw", None)
-            if post is not None:
-                post()
-
     def _dw_x(self, key, dY2d, X2d):
         """dW of layer `key` (or of the merged "qkv" / "gu" slices) into the arena: the library GEMM exactly as _QLinearFn.backward
-        issues it, or the MFMA kernel with the summation structure the plan found bit-equal"""
-        lyrs, out2d = self._dw_target(key)
+        issues it, or the MFMA kernel with the whole K in one pass where the plan found it bit-equal"""
+        if key in ("qkv", "gu"):
+            lyrs = [self.layers[n] for n in ("q", "k", "v")] if key == "qkv" else [self.layers["g"], self.layers["u"]]
+            out2d = self.dWqkv if key == "qkv" else self.dWgu
+        else:
+            lyrs = [self.layers[key]]
+            out2d = lyrs[0].weight_grad
         acc = lyrs[0]._dw_accum[0]
         done = False
         mode = int(self.plan.get("dw_" + key) or 0)         # 0: library; 1: MFMA kernel, one pass over K; n >= 2: n contiguous K slices;
         if mode == STREAMK and not acc and out2d.is_contiguous():      # -1: the library kernel's own stream-K structure (streamk.py)
-            kcut = self._dw_table(key, lyrs, dY2d, X2d)
+            if len(lyrs) > 1:                               # merged rows: every layer's rows in the structure of ITS OWN library GEMM
+                kcut = streamk.find_merged_on_device(dY2d, X2d, [l.weight_q.shape[0] for l in lyrs])
+            else:
+                st = streamk.find_on_device(dY2d, X2d)      # found on the proof's minibatch, a dictionary lookup afterwards
+                kcut = None if st is None else st[1]
             if kcut is not None:
                 done = ops.gemm_dw_sk(dY2d, X2d, out2d, kcut)
         elif mode > 0 and not acc and out2d.is_contiguous():      # (accumulating micro-batches: the library's addmm_, as the module path -- the
@@ -215,31 +202,11 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 out2d.addmm_(dY2d.t(), X2d)
             else:
                 torch.mm(dY2d.t(), X2d, out=out2d)
-        self._dw_done(lyrs)
-
-    def _dw_group(self, items):
-        """Several weight gradients [(key, dY2d, X2d), ...] as ONE launch (ops.gemm_dw_group: their tiles share rounds of 256
-        workgroups) when each is a first-party form of the plan -- one pass or the stream-K structure --; otherwise one by one."""
-        probs, targets = [], []
-        for key, dY2d, X2d in items:
-            lyrs, out2d = self._dw_target(key)
-            mode = int(self.plan.get("dw_" + key) or 0)
-            if mode not in (1, STREAMK) or lyrs[0]._dw_accum[0] or not out2d.is_contiguous():
-                probs = None
-                break
-            kcut = self._dw_table(key, lyrs, dY2d, X2d) if mode == STREAMK else None
-            if mode == STREAMK and kcut is None:
-                probs = None
-                break
-            probs.append((dY2d, X2d, out2d, kcut))
-            targets.append(lyrs)
-        if probs and ops.gemm_dw_group(probs):
-            for lyrs in targets:
-                self._dw_done(lyrs)
-            return True
-        for key, dY2d, X2d in items:
-            self._dw_x(key, dY2d, X2d)
-        return False
+        for lyr in lyrs:
+            lyr._dw_accum[0] = True
+            post = getattr(lyr, "_post_dw", None)
+            if post is not None:
+                post()
 
     def _streamk_found(self, key):
         """what the last `_dw_x(key, ...)` with plan value STREAMK ran with: per layer of `key` the stream-K structure (None: one pass
@@ -393,19 +360,8 @@ class ExactLlamaBlock(FusedLlamaBlock):
         if dy2d.dtype != self.dtype:
             dy2d = dy2d.to(self.dtype)
         dy2d = dy2d.contiguous()
-        # group_dw: the weight gradients of down_proj and o_proj wait for the merged q/k/v one (the last GEMM of the backward: the block
-        # input needs no gradient) and the three go out as ONE grid -- 896 + 256 + 384 tiles are six full rounds of 256 workgroups
-        # instead of 4 + 1 + 2 (the same tile code on the same operands: no bit changes)
-        late = [] if (P.get("group_dw") and P["dw_qkv"]) else None
-
-        def dw(key, dY, X):
-            if late is None:
-                self._dw_x(key, dY, X)
-            else:
-                late.append((key, dY, X))
-
         # y = x2 + down(act_in)
-        dw("d", dy2d, s.pop("act_in"))
+        self._dw_x("d", dy2d, s.pop("act_in"))
         dact = bq(self._dx_x("d", dy2d), s.pop("act"), aq["d"])
         g2d, u2d, act_graph = s.pop("g2d"), s.pop("u2d"), s.pop("act_graph")
         Fd = self.Fdim
@@ -441,7 +397,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
             dx2 = gx.reshape(T, H) + dy2d
         del dh2, norm_graph
         # x2 = x + o(a_in)
-        dw("o", dx2, s.pop("a_in"))
+        self._dw_x("o", dx2, s.pop("a_in"))
         da = bq(self._dx_x("o", dx2), s.pop("a2d"), aq["o"])
         del dx2
         al, ao = s.pop("attn_leaves"), s.pop("attn_out")
@@ -465,10 +421,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
         h1_in = s.pop("h1_in")
         if dqkv is not None:
             dqkv[:, nq + nk:].view(B, S, hkv, hd).copy_(gv4.transpose(1, 2))
-            if late is None:
-                self._dw_x("qkv", dqkv, h1_in)
-            else:
-                self._dw_group(late + [("qkv", dqkv, h1_in)])
+            self._dw_x("qkv", dqkv, h1_in)
         else:
             dv2d = gv4.transpose(1, 2).reshape(T, nk)
             self._dw_x("q", dq2d.contiguous(), h1_in)
@@ -483,18 +436,6 @@ class ExactLlamaBlock(FusedLlamaBlock):
         y = _FusedBlockFn.apply(x, self.arena.token, self, others)
         y.backward(dpred)
         return y.detach(), [a.dWq.clone() for a in self.arenas]
-
-    def _time_plan(self, plan, x, others, dpred, reps=5) -> float:
-        """ms per forward + backward of `plan` on the proof minibatch (device events; the first run warms up)"""
-        self.set_plan(plan)
-        self._run_once(x, others, dpred)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            self._run_once(x, others, dpred)
-        b.record()
-        torch.cuda.synchronize(x.device)
-        return a.elapsed_time(b) / reps
 
     def plan_against_module(self, module_forward, x, others, ref, want=None) -> Optional[dict]:
         """One minibatch `x` ([rows, S, H], the loop's real minibatch shape: the library picks its GEMM kernels by shape) with targets
@@ -591,17 +532,6 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 # call, profiles/r04_digest_repeat.json): an option that failed once gets one more comparison before it is dropped
                 if opt in report["kept"] or opt.startswith("dw_"):
                     break
-        # down / o / merged q-k-v as one grid: the bits cannot change (proven anyway), the time can -- kept where it is faster
-        grouped = [plan["dw_" + k] in (1, STREAMK) for k in ("d", "o", "qkv")]
-        if (want is None or "group_dw" in want) and all(grouped) and x.is_cuda:
-            report["tried"].append("group_dw")
-            trial = dict(plan, group_dw=True)
-            if same(trial):
-                t_sep, t_grp = self._time_plan(plan, x, others, dpred), self._time_plan(trial, x, others, dpred)
-                report["group_dw_ms"] = dict(separate=round(t_sep, 3), one_grid=round(t_grp, 3))
-                if t_grp < t_sep * 0.995:
-                    plan = trial
-                    report["kept"].append("group_dw")
         self.set_plan(plan)
         reset()
         self.plan_report = dict(report, usable=True, plan={k: (int(v) if k.startswith("dw_") else bool(v)) for k, v in plan.items()})

@@ -829,67 +829,6 @@ def gemm_dw_sk(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, kcut: t
     return True
 
 
-_zero_kcut: dict = {}
-
-
-def gemm_dw_group(problems) -> bool:
-    """Up to four weight-gradient GEMMs as ONE launch (ar_gemm_dw_group): `problems` = [(dY2d[K,M], X2d[K,N], out[M,N], kcut | None), ...],
-    each as in gemm_dw_sk (kcut None: every tile in one pass).  Their 256 x 256 tiles form one grid, so problems that are not whole
-    rounds of 256 workgroups share rounds.  -> False (nothing launched) when a shape is outside what the kernel takes."""
-    import ctypes
-    n = len(problems)
-    if not 1 <= n <= 4:
-        return False
-    devs, tiles_max, ws_need = set(), 0, []
-    for dY, X, out, kcut in problems:
-        for t in (dY, X, out):
-            if t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
-                return False
-            if not t.is_cuda:
-                raise _lib.Mi355xLibraryError("gemm_dw_group: the MI355X path only runs on a HIP device and has no CPU fallback")
-            devs.add(t.device.index)
-        K, M = dY.shape
-        N = X.shape[1]
-        if X.shape[0] != K or tuple(out.shape) != (M, N):
-            raise ValueError("gemm_dw_group: shape mismatch")
-        if M % 256 or N % 256 or ((M // 256) * (N // 256)) % 8 or K < 128:
-            return False
-        tiles = (M // 256) * (N // 256)
-        tiles_max = max(tiles_max, tiles)
-        if kcut is not None:
-            if kcut.dtype != torch.int32 or kcut.dim() != 1 or not kcut.is_contiguous() or kcut.numel() != tiles:
-                raise ValueError("gemm_dw_group: kcut must be a contiguous int32 table with one entry per 256 x 256 output tile")
-            devs.add(kcut.device.index)
-        ws_need.append(tiles * 256 * 256 * 4 if kcut is not None else 0)
-    if len(devs) != 1:
-        raise _lib.Mi355xLibraryError("gemm_dw_group: tensors live on different HIP devices")
-    (dev,) = devs
-    zk = _zero_kcut.get(dev)
-    if zk is None or zk.numel() < tiles_max:
-        zk = torch.zeros(max(tiles_max, 4096), dtype=torch.int32, device=f"cuda:{dev}")
-        _zero_kcut[dev] = zk
-    total = sum(ws_need)
-    ws = _gemm_ws.get(dev)
-    if total and (ws is None or ws.numel() < total):
-        ws = torch.empty(total, dtype=torch.uint8, device=f"cuda:{dev}")
-        _gemm_ws[dev] = ws
-    PA, LA = ctypes.c_void_p * n, ctypes.c_int64 * n
-    off, wptr = 0, []
-    for need in ws_need:
-        wptr.append(ws.data_ptr() + off if need else None)
-        off += need
-    args = (PA(*[p[0].data_ptr() for p in problems]), PA(*[p[1].data_ptr() for p in problems]), PA(*[p[2].data_ptr() for p in problems]),
-            LA(*[p[0].shape[1] for p in problems]), LA(*[p[1].shape[1] for p in problems]), LA(*[p[0].shape[0] for p in problems]),
-            LA(*[p[0].stride(0) for p in problems]), LA(*[p[1].stride(0) for p in problems]), LA(*[p[2].stride(0) for p in problems]),
-            PA(*wptr), LA(*ws_need), PA(*[None if p[3] is None else p[3].data_ptr() for p in problems]))
-    with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
-        rc = load().ar_gemm_dw_group(n, *args, zk.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
-    if rc == _lib.AR_ERR_UNSUPPORTED:
-        return False
-    check(rc, "ar_gemm_dw_group")
-    return True
-
-
 # ---- optional device-side timing of the hot kernels (ar_profile_*; bench.py and tools only) ----------------------------
 PROF_INT_FWD, PROF_INT_BWD, PROF_FP4_FWD, PROF_FP4_BWD, PROF_GEMM_DW, PROF_NORM, PROF_SWIGLU, PROF_ROPE = range(8)
 

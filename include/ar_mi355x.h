@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 24
+#define AR_ABI_VERSION 23
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -363,14 +363,6 @@ int ar_gemm_dw_ex(const void* dY, const void* X, void* dW, int64_t M, int64_t N,
  * finds the structure).  kcut is a device array of tiles entries; workspace = tiles * 256 * 256 * 4 bytes, 16-byte aligned. */
 int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx,
                   int64_t ldw, void* workspace, int64_t workspace_bytes, const int32_t* kcut, ar_stream_t stream);
-/* n <= 4 such GEMMs as ONE launch: the 256 x 256 output tiles of all problems form one grid, so problems whose tile counts are not
- * multiples of the 256 compute units share rounds (the weight gradients of one decoder block's backward, auto_round/wrapper.py:528-556,
- * whose operands are all alive at its end).  Arrays of n entries; kcut[i] as in ar_gemm_dw_sk or NULL (every tile of problem i in one
- * pass; workspace[i] unused); zero_kcut: a device array of at least max_i(tiles_i) zero int32 entries.  Every problem: M, N multiples of
- * 256 with a tile count that is a multiple of 8, K >= 128; anything else returns AR_ERR_UNSUPPORTED with nothing launched. */
-int ar_gemm_dw_group(int n, const void* const* dY, const void* const* X, void* const* dW, const int64_t* M, const int64_t* N,
-                     const int64_t* K, const int64_t* ldy, const int64_t* ldx, const int64_t* ldw, void* const* workspace,
-                     const int64_t* workspace_bytes, const int32_t* const* kcut, const int32_t* zero_kcut, ar_stream_t stream);
 /* caller-owned scratch ar_gemm_dw wants for (M, N, K) (the library never allocates): 0 when the output tiles alone fill the
  * chip; otherwise the fp32 partial tiles of its split-K form (few tiles, deep K -- e.g. OPT-125M's 768x768 weight against 16384
  * tokens), which are summed in slice order, i.e. deterministically.  Without the workspace the call still works, unsplit. */

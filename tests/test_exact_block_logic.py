@@ -176,39 +176,3 @@ def test_streamk_plan_value_routes_the_weight_gradient_through_the_found_structu
     assert eb._streamk_found("gu") == [st, st]
     monkeypatch.setattr(streamk, "_merged", {})
     assert eb._streamk_found("gu") is None
-
-
-def test_group_dw_sends_first_party_gradients_out_as_one_launch_and_everything_else_one_by_one(monkeypatch):
-    from auto_round_amd import exact_block, ops, streamk
-    cfg, blk, x, pe = _layer()
-    eb, layers, mods = _exact_over(blk, cfg, pe)
-    T = x.shape[0] * x.shape[1]
-    H = cfg.hidden_size
-    items = [("d", torch.randn(T, H).to(torch.bfloat16), torch.randn(T, layers["d"].weight_q.shape[1]).to(torch.bfloat16)),
-             ("o", torch.randn(T, H).to(torch.bfloat16), torch.randn(T, H).to(torch.bfloat16))]
-    launches = []
-
-    def fake_group(problems):
-        launches.append([None if p[3] is None else p[3] for p in problems])
-        for dY, X, out, _ in problems:
-            torch.mm(dY.t(), X, out=out)
-        return True
-
-    monkeypatch.setattr(ops, "gemm_dw_group", fake_group)
-    monkeypatch.setattr(streamk, "find_on_device", lambda a, b: (None, "table-of-" + str(a.shape[1])))
-    eb.plan.update(dw_d=exact_block.STREAMK, dw_o=1)
-    for n in ("d", "o"):
-        layers[n]._dw_accum[0] = False
-    assert eb._dw_group(items) is True
-    assert launches == [["table-of-%d" % H, None]]
-    for key, dY, X in items:
-        assert layers[key]._dw_accum[0] and torch.equal(layers[key].weight_grad, torch.mm(dY.t(), X))
-    # one gradient on the library (plan value 0), or micro-batches accumulating: no group, the ordinary calls
-    eb.plan.update(dw_o=0)
-    for n in ("d", "o"):
-        layers[n]._dw_accum[0] = False
-        layers[n].weight_grad.zero_()
-    monkeypatch.setattr(ops, "gemm_dw_sk", lambda dY, X, out, kcut: bool(torch.mm(dY.t(), X, out=out) is not None))
-    assert eb._dw_group(items) is False and len(launches) == 1
-    for key, dY, X in items:
-        assert layers[key]._dw_accum[0] and torch.equal(layers[key].weight_grad, torch.mm(dY.t(), X))

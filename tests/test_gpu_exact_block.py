@@ -307,30 +307,3 @@ def test_streamk_structure_found_on_one_gradient_pair_reproduces_the_library_on_
         got = torch.empty_like(lib)
         assert ops.gemm_dw_sk(dY2, X2, got, kcut)
         assert torch.equal(got.view(torch.int16), torch.mm(dY2.t(), X2).view(torch.int16))
-
-
-def test_gemm_dw_group_gives_every_problem_the_bits_of_its_own_launch():
-    """three weight-gradient GEMMs as one grid (one of them with a cut table, one with a ragged K) against the same GEMMs alone"""
-    from auto_round_amd import ops
-    shapes = [(2048, 1024, 512), (2048, 512, 1024), (2048, 256, 2048)]      # (K, M, N): 8 + 8 + 8 tiles
-    probs, alone = [], []
-    for i, (K, M, N) in enumerate(shapes):
-        dY, X = _operands(K, M, N, 40 + i)
-        tiles = (M // 256) * (N // 256)
-        kcut = None
-        if i == 1:
-            kcut = torch.tensor([32 * (3 + 7 * t) for t in range(tiles)], dtype=torch.int32, device=DEV)
-        want = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        if kcut is None:
-            assert ops.gemm_dw(dY, X, want, split=False)
-        else:
-            assert ops.gemm_dw_sk(dY, X, want, kcut)
-        probs.append((dY, X, torch.empty_like(want), kcut))
-        alone.append(want)
-    assert ops.gemm_dw_group(probs)
-    for (dY, X, out, kcut), want in zip(probs, alone):
-        assert torch.equal(out.view(torch.int16), want.view(torch.int16))
-    # a tile count that is not a multiple of 8, or five problems: refused, nothing launched
-    dY, X = _operands(256, 256, 256, 50)
-    assert ops.gemm_dw_group([(dY, X, torch.empty(256, 256, dtype=torch.bfloat16, device=DEV), None)]) is False
-    assert ops.gemm_dw_group(probs + probs) is False
