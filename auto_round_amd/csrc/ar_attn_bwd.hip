@@ -90,8 +90,14 @@ __global__ __launch_bounds__(kTPB) void k_attn_bwd_prep(const uint16_t* __restri
 // (Head size 128 was compiled in round 4 for the masked form -- the library's additive-bias backward is slow there -- and dropped:
 //  16 resident b-operand registers + 8 accumulator tiles per lane do not fit the 256 registers a wave has at two waves per SIMD;
 //  the MODE 1 kernel spilled 157 registers to scratch.  It needs another decomposition, not this skeleton.)
-template <int MODE, int WAVES, int AD, bool MASKED = false>
+// OUT (MODE 1): 3 = dK and dV (head size 64), 1 = dV only, 2 = dK only -- head size 128 runs the key side as TWO kernels, each
+// with one resident operand set less and half the accumulators (8 GEMM passes instead of 7), which is what fits 256 registers.
+template <int MODE, int WAVES, int AD, bool MASKED = false, int OUT = 3>
 __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
+    constexpr bool NEED_S1 = MODE == 0 || (OUT & 2);      // the dP = dO . V product (feeds dQ and dK)
+    constexpr bool NEED_A0 = MODE == 0 || (OUT & 2);      // acc0: dQ (MODE 0) / dK
+    constexpr bool NEED_A1 = MODE == 1 && (OUT & 1);      // acc1: dV
+    constexpr int KB = AD == 128 ? 4 : AD / 16;      // k-steps of a score product whose row fragments are in flight together
     constexpr int AROW = AD * 2;         // bytes per staged row
     constexpr int ATILE = BK * AROW;     // one tensor's tile
     constexpr int ABUF = 2 * ATILE;      // R0 tile + R1 tile; two buffers
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
     constexpr int CPR = AROW / 16;
     constexpr int NP = RPW / RPI;
     static_assert(NP >= 1, "a wave stages at least one DMA instruction per tensor");
-    static_assert(AD == 64, "head size 64 only (register budget at 128: see the comment above)");
+    static_assert(AD == 64 || (AD == 128 && (MODE == 0 || OUT != 3)), "head size 128: the key side as two kernels (register budget)");
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         bf0[ks] = __builtin_bit_cast(bbf16x8_t, *reinterpret_cast<const uint4*>(B0b + (int64_t)myrow * lb0 + 16 * ks + 8 * h));
-        bf1[ks] = __builtin_bit_cast(bbf16x8_t, *reinterpret_cast<const uint4*>(B1b + (int64_t)myrow * lb1 + 16 * ks + 8 * h));
+        if (NEED_S1) bf1[ks] = __builtin_bit_cast(bbf16x8_t, *reinterpret_cast<const uint4*>(B1b + (int64_t)myrow * lb1 + 16 * ks + 8 * h));
     }
     const float* L2row = a.L2 + ((int64_t)b * a.H + head) * a.S;
     const float* Dvrow = a.Dv + ((int64_t)b * a.H + head) * a.S;
@@ -213,9 +219,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
             // (q.k - lse / scale) and (dO.v - D): the softmax shift and the "- D" of dS cost no VALU instruction (at head size 64
             // the elementwise step, not the MFMA pipe, bounds this kernel: exp2 issues at quarter rate).
             bf32x16_t s0, s1;
-            u32x4_t f0[NKS], f1[NKS];
+            u32x4_t f0[KB], f1[KB];                                   // row fragments of KB k-steps (head size 128: two batches -- registers)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) { BW_RREAD(f0[ks], ks, t, 0); BW_RREAD(f1[ks], ks, t, 1); }
+            for (int ks = 0; ks < KB; ++ks) {
+                BW_RREAD(f0[ks], ks, t, 0);
+                if (NEED_S1) BW_RREAD(f1[ks], ks, t, 1);
+            }
             if (MODE == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s0[r] = myL2; s1[r] = myD; }
@@ -225,27 +234,42 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 x = *reinterpret_cast<const float4*>(vL + t0 + 32 * t + 4 * h + 8 * j);
-                    const float4 y = *reinterpret_cast<const float4*>(vD + t0 + 32 * t + 4 * h + 8 * j);
                     s0[4 * j] = x.x; s0[4 * j + 1] = x.y; s0[4 * j + 2] = x.z; s0[4 * j + 3] = x.w;
-                    s1[4 * j] = y.x; s1[4 * j + 1] = y.y; s1[4 * j + 2] = y.z; s1[4 * j + 3] = y.w;
+                    if (NEED_S1) {
+                        const float4 y = *reinterpret_cast<const float4*>(vD + t0 + 32 * t + 4 * h + 8 * j);
+                        s1[4 * j] = y.x; s1[4 * j + 1] = y.y; s1[4 * j + 2] = y.z; s1[4 * j + 3] = y.w;
+                    }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            BW_PIN();
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8_t, f0[ks]), bf0[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8_t, f1[ks]), bf1[ks], s1, 0, 0, 0);
+            for (int kb = 0; kb < NKS; kb += KB) {
+                if (kb > 0) {
+#pragma unroll
+                    for (int ks = 0; ks < KB; ++ks) {
+                        BW_RREAD(f0[ks], kb + ks, t, 0);
+                        if (NEED_S1) BW_RREAD(f1[ks], kb + ks, t, 1);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                BW_PIN();
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks) {
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8_t, f0[ks]), bf0[kb + ks], s0, 0, 0, 0);
+                    if (NEED_S1) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8_t, f1[ks]), bf1[kb + ks], s1, 0, 0, 0);
+                }
+                if (kb + KB < NKS) BW_PIN();
             }
             // transposed fragments of this half: 2 sixteen-row steps x ND d-tiles x (R0 and, in MODE 1, R1): in flight under the
             // elementwise step
+            // (head size 128: the second step's fragments are read under the first step's MFMAs instead -- registers)
+            constexpr bool LATE_Q = AD == 128;
             bs16x4_t q0lo[2][ND], q0hi[2][ND], q1lo[2][ND], q1hi[2][ND];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < (LATE_Q ? 1 : 2); ++s2)
 #pragma unroll
                 for (int dt = 0; dt < ND; ++dt) {
-                    BW_TREAD(q0lo[s2][dt], q0hi[s2][dt], dt, 2 * t + s2, 0);
-                    if (MODE == 1) BW_TREAD(q1lo[s2][dt], q1hi[s2][dt], dt, 2 * t + s2, 1);
+                    if (NEED_A0) BW_TREAD(q0lo[s2][dt], q0hi[s2][dt], dt, 2 * t + s2, 0);
+                    if (NEED_A1) BW_TREAD(q1lo[s2][dt], q1hi[s2][dt], dt, 2 * t + s2, 1);
                 }
             BW_PIN();
             // ---- P = exp2(s0 * c) (0 where key > query), E = P * s1; register r <-> streamed row 32 t + 4 h + (r & 3) + 8 (r >> 2)
@@ -258,14 +282,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
                         const float bias = (key <= query && key < a.valid_len) ? a.bias_in_l2 : a.bias_out_l2;
                         const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], a.scale_log2e, bias));
                         s0[r] = p;
-                        s1[r] = p * s1[r];
+                        if (NEED_S1) s1[r] = p * s1[r];
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], a.scale_log2e, a.bias_in_l2));
                         s0[r] = p;
-                        s1[r] = p * s1[r];
+                        if (NEED_S1) s1[r] = p * s1[r];
                     }
                 }
             } else if (diag) {
@@ -275,14 +299,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
                     const bool masked = MODE == 0 ? (srow > myrow) : (myrow > srow);
                     const float p = masked ? 0.f : __builtin_amdgcn_exp2f(s0[r] * a.scale_log2e);
                     s0[r] = p;
-                    s1[r] = p * s1[r];
+                    if (NEED_S1) s1[r] = p * s1[r];
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float p = __builtin_amdgcn_exp2f(s0[r] * a.scale_log2e);
                     s0[r] = p;
-                    s1[r] = p * s1[r];
+                    if (NEED_S1) s1[r] = p * s1[r];
                 }
             }
             BW_PIN();
@@ -292,20 +316,34 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
                 bs16x8_t pe, pp;
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    const uint32_t we = pack_bf16x2(s1[8 * s2 + e], s1[8 * s2 + e + 1]);
-                    pe[e] = (short)(we & 0xffffu); pe[e + 1] = (short)(we >> 16);
-                    const uint32_t wp = pack_bf16x2(s0[8 * s2 + e], s0[8 * s2 + e + 1]);
-                    pp[e] = (short)(wp & 0xffffu); pp[e + 1] = (short)(wp >> 16);
+                    if (NEED_A0) {
+                        const uint32_t we = pack_bf16x2(s1[8 * s2 + e], s1[8 * s2 + e + 1]);
+                        pe[e] = (short)(we & 0xffffu); pe[e + 1] = (short)(we >> 16);
+                    }
+                    if (NEED_A1) {
+                        const uint32_t wp = pack_bf16x2(s0[8 * s2 + e], s0[8 * s2 + e + 1]);
+                        pp[e] = (short)(wp & 0xffffu); pp[e + 1] = (short)(wp >> 16);
+                    }
                 }
                 // (the second step's reads may stay in flight; the counter field holds at most 15)
-                if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((MODE == 1 ? 4 * ND : 2 * ND) > 15 ? 15 : (MODE == 1 ? 4 * ND : 2 * ND)) : "memory");
+                constexpr int INFL = ((NEED_A0 ? 2 : 0) + (NEED_A1 ? 2 : 0)) * ND;
+                if (LATE_Q && s2 == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt) {
+                        if (NEED_A0) BW_TREAD(q0lo[1][dt], q0hi[1][dt], dt, 2 * t + 1, 0);
+                        if (NEED_A1) BW_TREAD(q1lo[1][dt], q1hi[1][dt], dt, 2 * t + 1, 1);
+                    }
+                }
+                if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(INFL > 15 ? 15 : INFL) : "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 BW_PIN();
 #pragma unroll
                 for (int dt = 0; dt < ND; ++dt) {
-                    const bs16x8_t a0 = __builtin_shufflevector(q0lo[s2][dt], q0hi[s2][dt], 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc0[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8_t, a0), __builtin_bit_cast(bbf16x8_t, pe), acc0[dt], 0, 0, 0);
-                    if (MODE == 1) {
+                    if (NEED_A0) {
+                        const bs16x8_t a0 = __builtin_shufflevector(q0lo[s2][dt], q0hi[s2][dt], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc0[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8_t, a0), __builtin_bit_cast(bbf16x8_t, pe), acc0[dt], 0, 0, 0);
+                    }
+                    if (NEED_A1) {
                         const bs16x8_t a1 = __builtin_shufflevector(q1lo[s2][dt], q1hi[s2][dt], 0, 1, 2, 3, 4, 5, 6, 7);
                         acc1[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8_t, a1), __builtin_bit_cast(bbf16x8_t, pp), acc1[dt], 0, 0, 0);
                     }
@@ -355,7 +393,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_attn_bwd(AttnBwdArgs a) {
             }
     };
     if (MODE == 0) store(a.dQ, a.lddq, acc0, a.scale);
-    else { store(a.dK, a.lddk, acc0, a.scale); store(a.dV, a.lddv, acc1, 1.0f); }
+    else {
+        if (NEED_A0) store(a.dK, a.lddk, acc0, a.scale);
+        if (NEED_A1) store(a.dV, a.lddv, acc1, 1.0f);
+    }
 }
 
 }  // namespace ar
@@ -392,7 +433,7 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
                          void* dV, int64_t B, int64_t S, int64_t H, int64_t D, float scale, int causal, int64_t ldq, int64_t ldk,
                          int64_t ldv, int64_t ldo_, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, void* workspace,
                          int64_t workspace_bytes, bool masked, float bias_in, float bias_out, int64_t valid_len, ar_stream_t stream) {
-    if (D != 64 || !causal || S % 256 || S > 4096 || B <= 0 || H <= 0) return AR_ERR_UNSUPPORTED;
+    if ((D != 64 && !(D == 128 && masked)) || !causal || S % 256 || S > 4096 || B <= 0 || H <= 0) return AR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < ar_attn_bwd_workspace_bytes(B, S, H)) return AR_ERR_UNSUPPORTED;
     const int64_t hd = H * D;
     if (ldq <= 0) ldq = hd;
@@ -426,6 +467,7 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
     a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     a.bias_in_l2 = bias_in * 1.4426950408889634f; a.bias_out_l2 = bias_out * 1.4426950408889634f; a.valid_len = (int)valid_len;
     constexpr int LDS_T = 4 * BK * 64 * 2;                            // 2 buffers x (R0 tile + R1 tile) at head size 64
+    constexpr int LDS_T128 = 4 * BK * 128 * 2;
     const int vec = (int)(2 * S * sizeof(float));
     static PerDeviceOnce attr;
     if (attr.first()) {
@@ -434,9 +476,16 @@ static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void
         (void)hipFuncSetAttribute((const void*)k_attn_bwd<1, 8, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T + VEC_MAX);
         (void)hipFuncSetAttribute((const void*)k_attn_bwd<0, 8, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T);
         (void)hipFuncSetAttribute((const void*)k_attn_bwd<1, 8, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T + VEC_MAX);
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd<0, 8, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128);
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd<1, 8, 128, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + VEC_MAX);
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd<1, 8, 128, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + VEC_MAX);
     }
     const int grid = (int)(B * H * (S / 256));
-    if (masked) {
+    if (D == 128) {                                                    // (masked only) the key side as two kernels, then the query side
+        hipLaunchKernelGGL((k_attn_bwd<1, 8, 128, true, 1>), grid, 512, LDS_T128 + vec, st, a);
+        hipLaunchKernelGGL((k_attn_bwd<1, 8, 128, true, 2>), grid, 512, LDS_T128 + vec, st, a);
+        hipLaunchKernelGGL((k_attn_bwd<0, 8, 128, true>), grid, 512, LDS_T128, st, a);
+    } else if (masked) {
         hipLaunchKernelGGL((k_attn_bwd<1, 8, 64, true>), grid, 512, LDS_T + vec, st, a);
         hipLaunchKernelGGL((k_attn_bwd<0, 8, 64, true>), grid, 512, LDS_T, st, a);
     } else {

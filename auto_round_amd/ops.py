@@ -695,11 +695,12 @@ _attn_ws: dict = {}
 def attn_bwd(q, k, v, out, lse, dout, batch: int, seq: int, heads: int, head_dim: int, scale=None, dq=None, dk=None, dv=None, mask_struct=None):
     """mask_struct = (bias_in, bias_out, valid_len): the calibration flow's structured additive mask instead of causality
     (ar_attn_bwd_masked; `out` / `lse` then come from `attn_fwd(..., mask_struct=...)`).
+    (head size 64 or 128).
     Causal attention backward (head size 64, deterministic) on token-major operands [batch * seq, heads * 64] with unit inner
     stride (column slices of merged buffers are fine; so are dq / dk / dv given as such slices): -> (dq, dk, dv), or None when the
     kernel does not take the shape -- the caller then keeps the library backward."""
-    if head_dim != 64 or seq % 256 or seq > 4096 or q.dtype != torch.bfloat16:
-        return None
+    if head_dim not in (64, 128) or (head_dim == 128 and mask_struct is None) or seq % 256 or seq > 4096 or q.dtype != torch.bfloat16:
+        return None          # (causal at head size 128: the library's flash backward is the faster one)
     ts = [q, k, v, out, dout]
     if any(t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16 or t.dtype != torch.bfloat16 for t in ts):
         return None

@@ -435,15 +435,17 @@ def test_masked_attention_forward_vs_fp32_attention_with_the_calibration_mask(B,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,S,H,cleared", [(1, 256, 2, 1), (2, 512, 12, 1), (1, 2048, 3, 1), (2, 1024, 4, 130)])
-def test_masked_attention_backward_head_size_64_vs_fp32_autograd(B, S, H, cleared):
-    """`ar_attn_bwd_masked` (head size 64, deterministic) under the calibration mask against fp32 autograd of
-    softmax(QK^T / sqrt(d) + mask)V, next to the library's additive-bias backward on the same inputs; run twice: bit-identical."""
+@pytest.mark.parametrize("B,S,H,cleared,D", [(1, 256, 2, 1, 64), (2, 512, 12, 1, 64), (1, 2048, 3, 1, 64), (2, 1024, 4, 130, 64),
+                                             (1, 256, 2, 1, 128), (2, 512, 4, 0, 128), (1, 2048, 3, 1, 128), (2, 1024, 8, 130, 128)])
+def test_masked_attention_backward_vs_fp32_autograd(B, S, H, cleared, D):
+    """`ar_attn_bwd_masked` (head size 64: two kernels; 128: the key side as two kernels + the query side; deterministic) under the
+    calibration mask against fp32 autograd of softmax(QK^T / sqrt(d) + mask)V, next to the library's additive-bias backward on the
+    same inputs; run twice: bit-identical."""
     import math
 
     from auto_round_amd import ops
 
-    D, T = 64, B * S
+    T = B * S
     HD = H * D
     q, k, v = (_rand(T, HD, seed=71 + i) for i in range(3))
     do = _rand(T, HD, seed=74, scale=0.1)

@@ -1,4 +1,4 @@
-"""ar_attn_fwd_masked vs torch SDPA (AOTriton efficient, additive mask) at the Llama-3-8B minibatch: ms per call."""
+"""ar_attn_fwd_masked / ar_attn_bwd_masked vs torch SDPA (AOTriton efficient, additive mask) at the Llama-3-8B minibatch: ms per call."""
 import json
 import os
 import sys
@@ -34,6 +34,14 @@ out = dict(struct=st,
            ms_first_party_causal=timed(lambda: ops.attn_fwd(q, k, v, B, S, H, D)),
            ms_torch_sdpa_mask=timed(lambda: torch.nn.functional.scaled_dot_product_attention(q4, k4, v4, attn_mask=mask)),
            ms_torch_sdpa_causal=timed(lambda: torch.nn.functional.scaled_dot_product_attention(q4, k4, v4, is_causal=True)))
+do = (0.1 * torch.randn(B * S, H * D, device=dev, generator=g)).to(torch.bfloat16)
+o_mine, lse = ops.attn_fwd(q, k, v, B, S, H, D, mask_struct=st)
+z = torch.zeros((), dtype=torch.int64)
+bias = mask.expand(B, H, S, S)
+o4, do4 = o_mine.view(B, S, H, D).transpose(1, 2), do.view(B, S, H, D).transpose(1, 2)
+out["ms_bwd_first_party_masked"] = timed(lambda: ops.attn_bwd(q, k, v, o_mine, lse, do, B, S, H, D, mask_struct=st))
+out["ms_bwd_torch_efficient_bias"] = timed(lambda: torch.ops.aten._scaled_dot_product_efficient_attention_backward(
+    do4, q4, k4, v4, bias, o4, lse, z, z, 0.0, (True, True, True, False), False))
 print(json.dumps(out))
 os.makedirs("gpurun_out/r04i", exist_ok=True)
 json.dump(out, open("gpurun_out/r04i/masked_attn_time.json", "w"), indent=1)
