@@ -1,4 +1,5 @@
-// ar_attn_bwd.hip -- causal flash-attention BACKWARD for gfx950, head dimension 64, bf16, token-major operands, deterministic.
+// ar_attn_bwd.hip -- flash-attention BACKWARD for gfx950, bf16, token-major operands, deterministic: causal at head dimension 64;
+// under the calibration flow's structured mask at head dimensions 64 and 128.
 //
 // replaces: the attention backward of the decoder block inside the tuning loop -- autograd of transformers' sdpa_attention_forward
 //           (transformers/integrations/sdpa_attention.py -> torch scaled_dot_product_attention(..., is_causal=True)), which on
@@ -87,9 +88,8 @@ __global__ __launch_bounds__(kTPB) void k_attn_bwd_prep(const uint16_t* __restri
 // MASKED (round 4): the calibration flow's structured additive mask instead of causality -- bias(q, k) = bias_in where `k <= q and
 // k < valid_len`, bias_out elsewhere, both finite (csrc/ar_attn.hip k_attn_fwd<.., MASKED>): every (query, key) pair contributes, no
 // tile is skipped, P = exp2((q.k - lse / scale) * c + bias * log2 e); dS = P (dP - D) as before (the bias is a constant).
-// (Head size 128 was compiled in round 4 for the masked form -- the library's additive-bias backward is slow there -- and dropped:
-//  16 resident b-operand registers + 8 accumulator tiles per lane do not fit the 256 registers a wave has at two waves per SIMD;
-//  the MODE 1 kernel spilled 157 registers to scratch.  It needs another decomposition, not this skeleton.)
+// (Head size 128, masked form: the two-kernel skeleton -- 16 resident b-operand registers + 8 accumulator tiles per lane -- does not fit
+//  the 256 registers a wave has at two waves per SIMD (MODE 1 spilled 157); see OUT below.)
 // OUT (MODE 1): 3 = dK and dV (head size 64), 1 = dV only, 2 = dK only -- head size 128 runs the key side as TWO kernels, each
 // with one resident operand set less and half the accumulators (8 GEMM passes instead of 7), which is what fits 256 registers.
 template <int MODE, int WAVES, int AD, bool MASKED = false, int OUT = 3>

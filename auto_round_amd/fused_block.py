@@ -502,8 +502,8 @@ class FusedLlamaBlock:
             if bias is not None:
                 bias = bias.to(q2d.dtype).expand(B, self.hq, S, S)
             if (bias is None or st is not None) and getattr(self, "flash_bwd", True):
-                # head size 64 (Llama-3.2-1B, Qwen2-0.5B ...): the first-party deterministic backward, token-major like rope_bwd wants
-                # (causal, or the calibration flow's structured mask)
+                # the first-party deterministic backward, token-major like rope_bwd wants: head size 64 (Llama-3.2-1B, Qwen2-0.5B ...)
+                # causal or under the calibration flow's structured mask, head size 128 under that mask
                 done = ops.attn_bwd(q2d, k2d, v2d, out2d, lse, dattn, B, S, self.hq, self.hd, scale=self.scaling, mask_struct=st)
             if done is None:
                 h4 = lambda t: t.view(B, S, self.hq, self.hd).transpose(1, 2)
