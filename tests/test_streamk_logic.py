@@ -101,3 +101,36 @@ def test_merged_table_is_the_parts_tables_in_row_order(monkeypatch):
     dY2 = torch.zeros(64, 768 + 256, dtype=torch.bfloat16)
     assert sk.find_merged_on_device(dY2, X, [768, 256]) is None  # a part without a reproducing structure
     sk._merged.clear()
+
+
+def test_structure_invariants_over_random_problems():
+    """what every structure must satisfy, whatever the library chose: the one-pass tiles are whole rounds of the grid, at most
+    grid - 1 tiles are cut, cuts are multiples of the iteration depth strictly inside (0, K), the launch order is a permutation, and the
+    row-major table is the launch-order table re-indexed"""
+    rng = np.random.default_rng(7)
+    seen = 0
+    for _ in range(400):
+        tm, tn = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        depth = int(rng.choice([32, 64, 128]))
+        K = depth * int(rng.integers(1, 600))
+        grid = int(rng.integers(1, 400))
+        wgm = int(rng.choice(sk.WGMS))
+        st = sk.structure(tm, tn, K, grid, wgm, depth)
+        if st is None:
+            continue
+        seen += 1
+        tiles = tm * tn
+        assert sorted(st.tlist.tolist()) == list(range(tiles))
+        assert len(st.ksplit) == tiles - st.n_dp
+        if tiles > grid:
+            assert st.n_dp % grid == 0 and grid <= tiles - st.n_dp < 2 * grid
+        else:
+            assert st.n_dp == 0
+        assert st.two_part_tiles <= grid - 1 or grid == 1
+        cuts = st.ksplit[st.ksplit > 0]
+        assert ((cuts % depth) == 0).all() and (cuts < K).all()
+        kc = st.kcut()
+        assert kc.shape == (tiles,) and int((kc > 0).sum()) == st.two_part_tiles
+        assert (kc[st.tlist[:st.n_dp]] == 0).all()
+        assert (kc[st.tlist[st.n_dp:]] == st.ksplit).all()
+    assert seen > 100
