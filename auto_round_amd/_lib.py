@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -73,6 +73,9 @@ SIGNATURES = {
     "ar_swiglu_fwd_exact": (c_int, [P, L, P, L, P, L, L, I, P]),
     "ar_swiglu_bwd_exact": (c_int, [P, P, L, P, L, P, L, P, L, L, L, I, I, P]),
     "ar_gemm_dw": (c_int, [P, P, P, L, L, L, L, L, L, I, P, L, P]),
+    "ar_gemm_dw_grouped": (c_int, [P, P, P, L, L, L, L, L, P, P, I, P]),
+    "ar_gemm_nt": (c_int, [P, P, P, L, L, L, L, L, L, P]),
+    "ar_gemm_nt_grouped": (c_int, [P, P, P, L, L, L, L, L, L, P, P, I, P]),
     "ar_gemm_dw_ex": (c_int, [P, P, P, L, L, L, L, L, L, I, P, L, I, P]),
     "ar_gemm_dw_sk": (c_int, [P, P, P, L, L, L, L, L, L, P, L, P, P]),
     "ar_gemm_dw_workspace_bytes": (c_int64, [L, L, L]),

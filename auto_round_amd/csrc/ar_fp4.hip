@@ -665,16 +665,18 @@ __global__ __launch_bounds__(kTPB) void k_search_fp4_scale(const void* __restric
             const float coeff = cand[ci];
             float sc, aux, rsc;
             fp4_group_scale(mode, amax, coeff, 1.0f, gscale, sc, aux, rsc);
-            float part = 0.f;
+            float t[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float q;
                 if (mode == 0) q = mx_e2m1(clamp3(x[k] * rsc, -6.f, 6.f)) * sc;
                 else q = nv_e2m1(clamp3(x[k] * sc, -6.f, 6.f)) * rsc;
                 const float d = q - x[k];
-                part += (d * d) * qw[k];
+                t[k] = (d * d) * qw[k];
             }
-            const float loss = lanes_sum(part, cpg);
+            // rows of 32 / 16 values: torch's reduction kernel adds them as a pairwise tree, neighbours first (see k_fp4_bwd) -- the
+            // bits `loss < best_loss` compares in search_mx_scale / search_nvfp4_scale on the GPU
+            const float loss = lanes_sum_torch(sum8_torch<true>(t), cpg);
             if (ci == 0 || loss < best) { best = loss; best_c = coeff; }
         }
         if (ok && (c % cpg) == 0) best_out[g] = best_c;

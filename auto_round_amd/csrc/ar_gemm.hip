@@ -53,6 +53,8 @@ struct GemmArgs {
     int tile0;           // > 0: split-K over the LAST tiles of the launch order only (tile0 = first of them); partial tiles are
                          // then stored compactly, [tile - tile0][nsplit][256][256]
     const int* kcut;     // ar_gemm_dw_sk: per row-major tile the k-row where its two parts meet (0 = one part); ws = [tile][256 * 256] fp32
+    const int32_t* goff; // ar_gemm_dw_grouped: [groups + 1] k-row ranges of the groups (device memory)
+    const int64_t* woff; // ar_gemm_dw_grouped: [groups] element offsets of the groups' outputs relative to W (device memory)
 };
 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& a, int bid, int& tm, int& tn) {
@@ -542,8 +544,12 @@ __device__ __attribute__((aligned(512))) uint16_t g_zero_row[256];
 // kernel that hands the tile's K range to two workgroups.  One workgroup still walks the whole K in order (same operand traffic
 // and L2 sharing as the plain kernel): at the cut it parks its accumulators in the workspace (fp32, lane-major), restarts from zero,
 // and adds the parked part back before the one rounding to bf16.
-template <bool STAGGER, bool SPLITK = false, bool TAIL = false, bool CUT = false>
+// GROUPED (ar_gemm_dw_grouped, round 5): the launch holds one full tile grid per group (an expert of a sparse-MoE block); a workgroup's
+// K range is its group's row range [goff[g], goff[g+1]) read from device memory -- completed with zero rows like TAIL (which it implies)
+// -- and its output is that group's own matrix W + woff[g].  A group without rows writes zeros.
+template <bool STAGGER, bool SPLITK = false, bool TAIL = false, bool CUT = false, bool GROUPED = false>
 __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
+    static_assert(!GROUPED || (TAIL && !SPLITK && !CUT), "the grouped form is the ragged-K form per group");
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -565,6 +571,14 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
         const int c0 = (int)((int64_t)chunks * sp / a.nsplit), c1 = (int)((int64_t)chunks * (sp + 1) / a.nsplit);
         krow0 = (int64_t)c0 * 128;
         U = (c1 - c0) * 8;
+    } else if (GROUPED) {
+        const int tiles = a.tiles_m * a.tiles_n;
+        const int g = blockIdx.x / tiles;
+        tile_of_block(a, blockIdx.x - g * tiles, tm, tn);
+        krow0 = a.goff[g];
+        kend = a.goff[g + 1];
+        U = (int)((kend - krow0 + 127) / 128) * 8;
+        a.W += a.woff[g];
     } else {
         tile_of_block(a, blockIdx.x, tm, tn);
     }
@@ -1130,7 +1144,7 @@ extern "C" int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M,
     if (M % GB || N % GB || K < 128 || (ldy % 8) || (ldx % 8) || (ldw % 4) || !kcut) return AR_ERR_UNSUPPORTED;
     if ((((uintptr_t)dY | (uintptr_t)X) & 15) || ((uintptr_t)dW & 7) || ((uintptr_t)workspace & 15)) return AR_ERR_UNSUPPORTED;
     GemmArgs a;
-    a.nsplit = 1; a.tile0 = 0; a.kcut = kcut; a.ws = (float*)workspace;
+    a.nsplit = 1; a.tile0 = 0; a.kcut = kcut; a.ws = (float*)workspace; a.goff = nullptr; a.woff = nullptr;
     a.Y = (const uint16_t*)dY; a.X = (const uint16_t*)X; a.W = (uint16_t*)dW;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = 0;
     a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = g_gemm_order;
@@ -1147,6 +1161,29 @@ extern "C" int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M,
     return launch_status();
 }
 
+// One launch for all the experts of a sparse-MoE projection: n_groups tile grids, every workgroup reads its group's k-row range from
+// device memory (see the GROUPED note at k_gemm_dw4).
+extern "C" int ar_gemm_dw_grouped(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t ldy, int64_t ldx, int64_t ldw,
+                                  const int32_t* row_off, const int64_t* w_off, int n_groups, ar_stream_t stream) {
+    if (M <= 0 || N <= 0 || n_groups <= 0) return AR_OK;
+    if (M % GB || N % GB || (ldy % 8) || (ldx % 8) || (ldw % 4) || !row_off || !w_off) return AR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)dY | (uintptr_t)X) & 15) || ((uintptr_t)dW & 7)) return AR_ERR_UNSUPPORTED;
+    GemmArgs a;
+    a.ws = nullptr; a.nsplit = 1; a.tile0 = 0; a.kcut = nullptr;
+    a.Y = (const uint16_t*)dY; a.X = (const uint16_t*)X; a.W = (uint16_t*)dW;
+    a.M = (int)M; a.N = (int)N; a.K = 0; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = 0;
+    a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = g_gemm_order;
+    a.goff = row_off; a.woff = w_off;
+    const int64_t grid = (int64_t)a.tiles_m * a.tiles_n * n_groups;
+    if (grid > (1 << 30)) return AR_ERR_UNSUPPORTED;
+    static PerDeviceOnce once;
+    if (once.first())
+        (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N * n_groups, (k_gemm_dw4<true, false, true, false, true>), (int)grid, GTHREADS, GEMM_LDS,
+                   (hipStream_t)stream, a);
+    return launch_status();
+}
+
 static int gemm_dw_impl(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t ldx, int64_t ldw,
                         int accumulate, void* workspace, int64_t workspace_bytes, int force_ns, ar_stream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return AR_OK;
@@ -1154,7 +1191,7 @@ static int gemm_dw_impl(const void* dY, const void* X, void* dW, int64_t M, int6
     if (K % 128 && g_gemm_kernel != 7) return AR_ERR_UNSUPPORTED;       // only the default kernel completes a ragged K with zeros
     if (((uintptr_t)dY | (uintptr_t)X) & 15 || ((uintptr_t)dW & 7)) return AR_ERR_UNSUPPORTED;
     GemmArgs a;
-    a.ws = nullptr; a.nsplit = 1; a.tile0 = 0; a.kcut = nullptr;
+    a.ws = nullptr; a.nsplit = 1; a.tile0 = 0; a.kcut = nullptr; a.goff = nullptr; a.woff = nullptr;
     a.Y = (const uint16_t*)dY; a.X = (const uint16_t*)X; a.W = (uint16_t*)dW;
     a.M = (int)M; a.N = (int)N; a.K = (int)K; a.ldy = ldy; a.ldx = ldx; a.ldw = ldw; a.accumulate = accumulate;
     a.tiles_m = (int)(M / GB); a.tiles_n = (int)(N / GB); a.order = g_gemm_order;

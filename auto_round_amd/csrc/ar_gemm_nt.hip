@@ -1,0 +1,312 @@
+// ar_gemm_nt.hip -- hand-written MFMA "NT" GEMM for gfx950:  C[M,N] = A[M,K] B[N,K]^T, both operands K-contiguous bf16, fp32
+// accumulation, one rounding to bf16.  SURVEY section 8 row f1, forward side (round 5).
+//
+// replaces: the forward of F.linear(x, weight_q) inside WrapperLinear.forward (auto_round/wrapper.py:528-556: x [tokens, in] against
+//           the fake-quant weight [out, in]) and, through a transposed weight copy, its input gradient dX = dY Wq; grouped over the
+//           experts of a sparse-MoE block it replaces the Python loop of per-expert GEMMs of the reference's "linear loop" experts
+//           (auto_round/modeling/fused_moe/moe_experts_interface.py:173-289): one launch per projection, row ranges read from device
+//           memory (no host synchronisation, deterministic).
+//
+// Not the weight-gradient kernel (csrc/ar_gemm.hip) fed transposed operands -- round 3's A/B -- but a kernel designed for K-contiguous
+// rows (CDNA4-first):
+//   * 256 x 256 output tile per 512-thread workgroup, 8 waves as 2 (m) x 4 (n), wave tile 128 x 64 = acc[4][2] of
+//     v_mfma_f32_32x32x16_bf16 (a-operand = B rows, b-operand = A rows: a lane then owns ONE output row and runs of 4 consecutive n).
+//   * K is staged 64 deep: a stage is four HALF-tiles of [128 rows][128 bytes] (A rows 0-127 / 128-255, B rows likewise), 16 KB each,
+//     two stages in 128 KB of LDS.  Every row of a half-tile is one full 128-byte line of HBM -- LDS-DMA (global_load_lds, 16 bytes
+//     per lane, no staging VGPRs) moves 8 rows per wave-instruction.
+//   * the fragments are plain ds_read_b128 (8 consecutive k of one row = one lane's MFMA operand; no transposing read).  Rows are 128
+//     bytes apart, so the 16-byte chunk index is XOR-swizzled with bits 1..3 of the row: chunk ^= (row >> 1) & 7, applied to the
+//     per-lane SOURCE address of the DMA (the chunks of a row are permuted inside their own 128-byte line: coalescing is untouched)
+//     and to the read address; every 16-lane group of a read then covers all 16 bank slots (checked in tools/gemm_nt_index_model.py).
+//   * a phase is K = 32: 12 fragment reads (L part), a barrier, 16 MFMAs with the wave's 4 DMA pieces issued in between (M part), a
+//     barrier.  The two wave groups (m halves) run half a period apart, so one wave of a SIMD is in its MFMA cluster while the other
+//     reads: the same skeleton as the weight-gradient kernel.
+//   * who stages what is chosen so that no wave ever writes a buffer another group may still read, with two stages only: group g
+//     stages A-half g (read by group g alone) and B-half g (read by everybody).  On odd phases (2t+1) a wave issues its "X" pieces
+//     of stage t+2 (group 0: A, group 1: B), on even phases (2t) its "Y" pieces of stage t+1 (group 0: B, group 1: A); counted
+//     s_waitcnt vmcnt(4) at the end of the L and M parts of odd phases -- never 0 in the loop.  The hazard table is in DESIGN.md.
+//   * XCD-aware tile order: each XCD (own L2) walks 4 x 8-tile patches, so its 32 resident workgroups share 4 A panels and 8 B panels.
+//   * rows past the end of a (ragged) row range are clamped on the load side and masked on the store side, so M need not be a
+//     multiple of 256 and the grouped form needs no padding between experts.
+#include "ar_common.hpp"
+
+namespace ar {
+
+typedef __bf16 nt_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float nt_f32x16_t __attribute__((ext_vector_type(16)));
+
+constexpr int NT_B = 256;                      // tile edge
+constexpr int NT_K = 64;                       // k per stage
+constexpr int NT_HALF = 128 * 128;             // bytes of a half-tile
+constexpr int NT_LDS = 8 * NT_HALF;            // 131072
+constexpr int NT_THREADS = 512;
+
+struct NtArgs {
+    const uint16_t* A;        // [M, K] (lda)
+    const uint16_t* B;        // [N, K] (ldb); grouped: group e's matrix starts at B + b_off[e]
+    uint16_t* C;              // [M, N] (ldc)
+    int64_t lda, ldb, ldc;
+    int M, N, K;              // grouped: M = total rows of all groups
+    int tiles_m, tiles_n, order;
+    const int32_t* row_off;   // grouped: [E + 1] prefix sums of the groups' row counts (device memory)
+    const int64_t* b_off;     // grouped: [E] element offsets (device memory)
+    int E;
+};
+
+template <int N>
+__device__ __forceinline__ void nt_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool GROUPED>
+__global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- which tile
+    int64_t m0;
+    int n0, rows_valid;
+    const uint16_t* Bp = a.B;
+    if (GROUPED) {
+        const int nwg = gridDim.x;
+        int id = blockIdx.x;
+        if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);            // a contiguous run of tiles per XCD
+        const int gmt = id / a.tiles_n, tn = id - gmt * a.tiles_n;
+        int e = -1, base = 0, r0 = 0, r1 = 0;
+        for (int i = 0; i < a.E; ++i) {
+            const int s0 = a.row_off[i], s1 = a.row_off[i + 1];
+            const int mt = (s1 - s0 + NT_B - 1) / NT_B;
+            if (e < 0 && gmt < base + mt) { e = i; r0 = s0 + (gmt - base) * NT_B; r1 = s1; }
+            base += mt;
+        }
+        if (e < 0) return;                                                     // past the last tile of the last group (whole workgroup)
+        m0 = r0;
+        rows_valid = (r1 - r0) < NT_B ? (r1 - r0) : NT_B;
+        n0 = tn * NT_B;
+        Bp = a.B + a.b_off[e];
+    } else {
+        const int nwg = a.tiles_m * a.tiles_n;
+        const int bid = blockIdx.x;
+        int tm, tn;
+        if (a.order == 2 && (a.tiles_m % 4 == 0) && (a.tiles_n % 8 == 0) && (nwg % 256 == 0)) {
+            const int x = bid & 7, s = bid >> 3, pi = s >> 5, w = s & 31;
+            const int P = pi * 8 + x, pn = a.tiles_n >> 3;
+            tm = (P / pn) * 4 + (w >> 3);
+            tn = (P % pn) * 8 + (w & 7);
+        } else {
+            int id = bid;
+            if (a.order >= 1 && nwg % 8 == 0) id = (bid & 7) * (nwg >> 3) + (bid >> 3);
+            tm = id / a.tiles_n;
+            tn = id % a.tiles_n;
+        }
+        m0 = (int64_t)tm * NT_B;
+        n0 = tn * NT_B;
+        const int64_t left = (int64_t)a.M - m0;
+        rows_valid = left < NT_B ? (int)left : NT_B;
+    }
+    const int T = a.K / NT_K;                       // stages; even (K % 128 == 0, checked by the host)
+
+    // ---- DMA: this wave's four pieces of a half-tile are rows wc*32 + 8j + (lane >> 3), j = 0..3; lane -> physical chunk lane & 7
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    uint32_t voffA[4], voffB[4];
+    {
+        const int rr = wc * 32 + (lane >> 3);
+        const int pc = lane & 7;
+        const int64_t last = (int64_t)a.M - 1 - m0;             // last row of A that exists, relative to the tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lc = pc ^ ((4 * j + (lane >> 4)) & 7);
+            int64_t ra = wr * 128 + rr + 8 * j;
+            if (ra > last) ra = last;                           // (rows past the end: any existing row -- their results are never stored)
+            voffA[j] = (uint32_t)(ra * a.lda * 2 + lc * 16);
+            voffB[j] = (uint32_t)((int64_t)(wr * 128 + rr + 8 * j) * a.ldb * 2 + lc * 16);
+        }
+    }
+    const uint8_t* gA = reinterpret_cast<const uint8_t*>(a.A + m0 * a.lda);
+    const uint8_t* gB = reinterpret_cast<const uint8_t*>(Bp + (int64_t)n0 * a.ldb);
+    // the two piece streams of this wave: X on odd phases, Y on even phases (group 0: X = A, Y = B; group 1: X = B, Y = A)
+    const uint8_t* gX = wr ? gB : gA;
+    const uint8_t* gY = wr ? gA : gB;
+    uint32_t voffX[4], voffY[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        voffX[j] = wr ? voffB[j] : voffA[j];
+        voffY[j] = wr ? voffA[j] : voffB[j];
+    }
+    const uint32_t dstA = lds0 + wr * 32768 + wc * 32 * 128;
+    const uint32_t dstB = dstA + 65536;
+    const uint32_t dstX = wr ? dstB : dstA, dstY = wr ? dstA : dstB;
+    int sx = 0, sy = 0;                              // next stage of each stream
+
+    // ---- fragment read addresses: X[a][u] = row * 128 + 16 * ((4a + 2u + h) ^ s)
+    uint32_t adA[2][2], adB[2][2];
+    {
+        const int l31 = lane & 31, h = lane >> 5, s = (l31 >> 1) & 7;
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t X = l31 * 128 + 16 * ((4 * ah + 2 * u + h) ^ s);
+                adA[ah][u] = lds0 + wr * 32768 + X;
+                adB[ah][u] = lds0 + 65536 + (wc >> 1) * 32768 + (wc & 1) * 8192 + X;
+            }
+    }
+
+    nt_f32x16_t acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // one piece (1 KB: 8 rows x 128 B) of a stream; SO = byte offset of the stage buffer (0 / 16384), J = piece
+#define NT_ISSUE_X(SO, J)                                                                                               \
+    __builtin_amdgcn_global_load_lds((const void*)(gX + voffX[J]),                                                      \
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)(dstX + (SO) + (J) * 1024), 16, 0, 0)
+#define NT_ISSUE_Y(SO, J)                                                                                               \
+    __builtin_amdgcn_global_load_lds((const void*)(gY + voffY[J]),                                                      \
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)(dstY + (SO) + (J) * 1024), 16, 0, 0)
+    // past the last stage the pointers stay on it (staged again into a buffer nobody reads any more)
+#define NT_ADV_X() do { ++sx; gX += (sx < T) ? 128 : 0; } while (0)
+#define NT_ADV_Y() do { ++sy; gY += (sy < T) ? 128 : 0; } while (0)
+    // Fragment reads are inline asm on purpose (as in ar_gemm.hip): to hipcc an LDS-DMA in flight is a pending store to "some LDS" and
+    // it would put s_waitcnt vmcnt(0) in front of the first LDS read it can see.  Ordering against the DMA is the counted vmcnt +
+    // barrier protocol; the MFMAs wait for their operands with the explicit lgkmcnt(0) of the L part.
+#define NT_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define NT_PIN() __builtin_amdgcn_sched_barrier(0)
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    u32x4_t fa[2][4], fb[2][2];
+#define NT_MMA(U, MI, NI)                                                                                               \
+    acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nt_bf16x8_t, fb[U][NI]),                   \
+                                                          __builtin_bit_cast(nt_bf16x8_t, fa[U][MI]), acc[MI][NI], 0, 0, 0)
+    // phase S of the loop body (0..3): stage parity SG = S >> 1, K half AH = S & 1
+#define NT_PHASE(S)                                                                                                     \
+    do {                                                                                                                \
+        constexpr int SG = (S) >> 1, AH = (S) & 1, O = SG * 16384;                                                      \
+        constexpr int OI = AH ? O : (16384 - O);      /* odd phase: stage t+2 -> this parity; even: stage t+1 -> the other */ \
+        NT_RD(fb[0][0], adB[AH][0], O);        NT_RD(fb[0][1], adB[AH][0], O + 4096);                                   \
+        NT_RD(fa[0][0], adA[AH][0], O);        NT_RD(fa[0][1], adA[AH][0], O + 4096);                                   \
+        NT_RD(fa[0][2], adA[AH][0], O + 8192); NT_RD(fa[0][3], adA[AH][0], O + 12288);                                  \
+        NT_RD(fb[1][0], adB[AH][1], O);        NT_RD(fb[1][1], adB[AH][1], O + 4096);                                   \
+        NT_RD(fa[1][0], adA[AH][1], O);        NT_RD(fa[1][1], adA[AH][1], O + 4096);                                   \
+        NT_RD(fa[1][2], adA[AH][1], O + 8192); NT_RD(fa[1][3], adA[AH][1], O + 12288);                                  \
+        if (AH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+        bar();                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        NT_MMA(0, 0, 0); NT_MMA(0, 0, 1); NT_PIN(); if (AH) NT_ISSUE_X(OI, 0); else NT_ISSUE_Y(OI, 0); NT_PIN();          \
+        NT_MMA(0, 1, 0); NT_MMA(0, 1, 1); NT_MMA(0, 2, 0); NT_MMA(0, 2, 1); NT_PIN();                                   \
+        if (AH) NT_ISSUE_X(OI, 1); else NT_ISSUE_Y(OI, 1); NT_PIN();                                                    \
+        NT_MMA(0, 3, 0); NT_MMA(0, 3, 1); NT_MMA(1, 0, 0); NT_MMA(1, 0, 1); NT_PIN();                                   \
+        if (AH) NT_ISSUE_X(OI, 2); else NT_ISSUE_Y(OI, 2); NT_PIN();                                                    \
+        NT_MMA(1, 1, 0); NT_MMA(1, 1, 1); NT_MMA(1, 2, 0); NT_MMA(1, 2, 1); NT_PIN();                                   \
+        if (AH) { NT_ISSUE_X(OI, 3); NT_ADV_X(); } else { NT_ISSUE_Y(OI, 3); NT_ADV_Y(); } NT_PIN();                     \
+        NT_MMA(1, 3, 0); NT_MMA(1, 3, 1);                                                                               \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        if (AH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                        \
+        bar();                                                                                                          \
+    } while (0)
+
+    // ---- prologue: X(0), Y(0) into parity 0, X(1) into parity 1; stage 0 landed for everybody (Y(1) is the first even phase's issue)
+    NT_ISSUE_X(0, 0); NT_ISSUE_X(0, 1); NT_ISSUE_X(0, 2); NT_ISSUE_X(0, 3); NT_ADV_X();
+    NT_ISSUE_Y(0, 0); NT_ISSUE_Y(0, 1); NT_ISSUE_Y(0, 2); NT_ISSUE_Y(0, 3); NT_ADV_Y();
+    NT_ISSUE_X(16384, 0); NT_ISSUE_X(16384, 1); NT_ISSUE_X(16384, 2); NT_ISSUE_X(16384, 3); NT_ADV_X();
+    nt_wait_vm<4>();
+    bar();
+    if (wr == 1) bar();
+    for (int t = 0; t < T; t += 2) {
+        NT_PHASE(0);
+        NT_PHASE(1);
+        NT_PHASE(2);
+        NT_PHASE(3);
+    }
+    if (wr == 0) bar();
+    nt_wait_vm<0>();          // no LDS-DMA may outlive the workgroup's LDS allocation
+#undef NT_PHASE
+#undef NT_MMA
+#undef NT_RD
+#undef NT_PIN
+#undef NT_ISSUE_X
+#undef NT_ISSUE_Y
+#undef NT_ADV_X
+#undef NT_ADV_Y
+
+    // ---- epilogue: lane owns row m = m0 + wr*128 + mi*32 + (lane & 31); n = n0 + wc*64 + ni*32 + 8*t + 4*(lane >> 5) + r
+    const int h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int ml = wr * 128 + mi * 32 + (lane & 31);
+        if (ml < rows_valid) {
+            uint16_t* rowp = a.C + (m0 + ml) * a.ldc + n0 + wc * 64 + 4 * h;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    uint2 o;
+                    o.x = pack_bf16x2(acc[mi][ni][4 * t + 0], acc[mi][ni][4 * t + 1]);
+                    o.y = pack_bf16x2(acc[mi][ni][4 * t + 2], acc[mi][ni][4 * t + 3]);
+                    *reinterpret_cast<uint2*>(rowp + ni * 32 + 8 * t) = o;
+                }
+        }
+    }
+}
+
+}  // namespace ar
+
+using namespace ar;
+
+static int nt_check(const void* A, const void* B, void* C, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc) {
+    if (N % NT_B || K < 128 || K % 128 || (lda % 8) || (ldb % 8) || (ldc % 4)) return AR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)A | (uintptr_t)B) & 15) || ((uintptr_t)C & 7)) return AR_ERR_UNSUPPORTED;
+    // per-lane byte offsets inside a tile are 32-bit: 256 rows x the leading dimension
+    if (lda * 2 * 256 >= (int64_t)1 << 32 || ldb * 2 * 256 >= (int64_t)1 << 32) return AR_ERR_UNSUPPORTED;
+    return AR_OK;
+}
+
+// C[M, N] = A[M, K] B[N, K]^T.  M any, N % 256 == 0, K % 128 == 0.
+extern "C" int ar_gemm_nt(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                          ar_stream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return AR_OK;
+    const int rc = nt_check(A, B, C, N, K, lda, ldb, ldc);
+    if (rc != AR_OK) return rc;
+    NtArgs a;
+    a.A = (const uint16_t*)A; a.B = (const uint16_t*)B; a.C = (uint16_t*)C;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.tiles_m = (int)((M + NT_B - 1) / NT_B); a.tiles_n = (int)(N / NT_B); a.order = 2;
+    a.row_off = nullptr; a.b_off = nullptr; a.E = 0;
+    static PerDeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)k_gemm_nt<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+    AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (k_gemm_nt<false>), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+// Grouped form: group e owns rows [row_off[e], row_off[e+1]) of A and of C and multiplies them with its own matrix B + b_off[e]
+// ([N, K], ldb).  row_off ([n_groups + 1] int32) and b_off ([n_groups] int64, in elements) live on the DEVICE: the launch needs no
+// host knowledge of the row counts -- the grid covers the worst case, M / 256 + n_groups row tiles, and workgroups past the last
+// real tile exit at once.  M = row_off[n_groups] = rows of A.  Deterministic (no atomics, fixed summation order).
+extern "C" int ar_gemm_nt_grouped(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                                  int64_t ldc, const int32_t* row_off, const int64_t* b_off, int n_groups, ar_stream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || n_groups <= 0) return AR_OK;
+    if (!row_off || !b_off || n_groups > 4096) return AR_ERR_UNSUPPORTED;
+    const int rc = nt_check(A, B, C, N, K, lda, ldb, ldc);
+    if (rc != AR_OK) return rc;
+    NtArgs a;
+    a.A = (const uint16_t*)A; a.B = (const uint16_t*)B; a.C = (uint16_t*)C;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.tiles_n = (int)(N / NT_B); a.order = 1;
+    a.tiles_m = (int)(M / NT_B) + n_groups;             // worst case: every group ends with a partial tile
+    a.row_off = row_off; a.b_off = b_off; a.E = n_groups;
+    int grid = a.tiles_m * a.tiles_n;
+    grid = (grid + 7) / 8 * 8;                          // (a multiple of 8: the per-XCD runs of the tile order)
+    static PerDeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)k_gemm_nt<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+    AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (k_gemm_nt<true>), grid, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
+    return launch_status();
+}

@@ -1061,16 +1061,21 @@ template <int XDT> __device__ __forceinline__ float recip_dt(float t) {
     const float eps = round_to<XDT>(XDT == AR_DT_F16 ? 1e-5f : 1e-30f);
     return fabsf(t) >= eps ? round_to<XDT>(1.0f / t) : 0.f;
 }
-template <int XDT> __device__ __forceinline__ float search_loss8(const float (&x)[8], const float (&qw)[8], float isc, float sc,
-                                                                 float nmax) {
-    float part = 0.f;
+// A lane's eight importance-weighted squared errors are added in the association torch's reduction kernel gives `torch.sum(loss,
+// dim=-1)` on this GPU (TREE: rows shorter than 128 values, one value per torch thread -> a pairwise tree; otherwise two float4 runs;
+// see sum8_torch): with the lanes combined neighbours first (lanes_sum_torch) a group's loss then carries the bits the reference's
+// `loss < best_loss` compares when it runs on the GPU -- a near-tie between two candidates picks the same scale (round 5; before,
+// eight in a row + a far-stride butterfly: the same value, another rounding, ~0.5 % other scales).
+template <int XDT, bool TREE> __device__ __forceinline__ float search_loss8(const float (&x)[8], const float (&qw)[8], float isc, float sc,
+                                                                            float nmax) {
+    float t[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const float L = clamp3(__builtin_rintf(round_to<XDT>(isc * x[k])), -nmax, nmax - 1.f);
         const float e = round_to<XDT>(round_to<XDT>(sc * L) - x[k]);
-        part += (e * e) * qw[k];
+        t[k] = (e * e) * qw[k];
     }
-    return part;
+    return sum8_torch<TREE>(t);
 }
 // first-index arg-max of |x| over `width` lanes: (abs, flat index, signed value)
 __device__ __forceinline__ void lanes_argmax(float& a, int& idx, float& v, int width) {
@@ -1114,7 +1119,8 @@ __global__ __launch_bounds__(kTPB) void k_search_int_scale(const void* __restric
         for (int ci = 0; ci < n_cand; ++ci) {
             const float isc = round_to<XDT>((-cand[ci]) * rg);
             const float sc = recip_dt<XDT>(isc);
-            const float loss = lanes_sum(search_loss8<XDT>(x, qw, isc, sc, nmax), cpg);
+            const float loss = lanes_sum_torch(cpg < 16 ? search_loss8<XDT, true>(x, qw, isc, sc, nmax)
+                                                        : search_loss8<XDT, false>(x, qw, isc, sc, nmax), cpg);
             if (ci == 0 || loss < best) { best = loss; best_s = sc; }
         }
         if (ok && cin == 0) {
@@ -1157,7 +1163,7 @@ __global__ __launch_bounds__(kTPB) void k_search_int_scale_wave(const void* __re
 #pragma unroll
                 for (int k = 0; k < 8; ++k) qw[k] = 1.f;
                 if (qw_row) unpack_f8(load8_f32(qw_row, ((g % groups_per_row) * cpg + ch) * kEPT), qw);
-                part += search_loss8<XDT>(x, qw, isc, sc, nmax);
+                part += search_loss8<XDT, false>(x, qw, isc, sc, nmax);
             }
             const float loss = lanes_sum(part, kWave);
             if (ci == 0 || loss < best) { best = loss; best_s = sc; }

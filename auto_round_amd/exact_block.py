@@ -52,6 +52,14 @@ def _bits_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
     return bool(torch.equal(a.contiguous().view(it), b.contiguous().view(it)))
 
 
+def _count_diff(a: torch.Tensor, b: torch.Tensor) -> int:
+    """number of values whose bits differ (everything, when the shapes or dtypes do)"""
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return int(max(a.numel(), b.numel()))
+    it = {2: torch.int16, 4: torch.int32}[a.element_size()]
+    return int((a.contiguous().view(it) != b.contiguous().view(it)).sum())
+
+
 class ExactLlamaBlock(FusedLlamaBlock):
     capturable = False          # the attention runs in a local autograd graph: the iteration is host-driven
     exact = True
@@ -74,6 +82,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
         self.amp = bool(amp)
         self.plan: Dict[str, bool] = self.base_plan()
         self._tnx: Dict[str, torch.Tensor] = {}
+        self._last_sk: Dict[str, Optional[list]] = {}
         self.plan_report: Optional[dict] = None
         return self
 
@@ -104,6 +113,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
         self.amp = bool(amp)
         self.plan = self.base_plan()
         self._tnx = {}
+        self._last_sk = {}
         self.plan_report = None
         return self
 
@@ -187,14 +197,22 @@ class ExactLlamaBlock(FusedLlamaBlock):
         acc = lyrs[0]._dw_accum[0]
         done = False
         mode = int(self.plan.get("dw_" + key) or 0)         # 0: library; 1: MFMA kernel, one pass over K; n >= 2: n contiguous K slices;
+        if mode == STREAMK:
+            self._last_sk[key] = None                       # (what this call really launched: read by the plan proof)
         if mode == STREAMK and not acc and out2d.is_contiguous():      # -1: the library kernel's own stream-K structure (streamk.py)
+            K, N, dev = int(dY2d.shape[0]), int(X2d.shape[1]), dY2d.device.index
             if len(lyrs) > 1:                               # merged rows: every layer's rows in the structure of ITS OWN library GEMM
-                kcut = streamk.find_merged_on_device(dY2d, X2d, [l.weight_q.shape[0] for l in lyrs])
+                rows = [int(l.weight_q.shape[0]) for l in lyrs]
+                kcut = streamk.find_merged_on_device(dY2d, X2d, rows)
+                sts = [streamk._found.get((dev, r, N, K)) for r in rows]
             else:
                 st = streamk.find_on_device(dY2d, X2d)      # found on the proof's minibatch, a dictionary lookup afterwards
                 kcut = None if st is None else st[1]
+                sts = [st]
             if kcut is not None:
                 done = ops.gemm_dw_sk(dY2d, X2d, out2d, kcut)
+                if done and all(t is not None for t in sts):
+                    self._last_sk[key] = [t[0] for t in sts]         # per layer: its Structure, or None = one pass IS its library sum
         elif mode > 0 and not acc and out2d.is_contiguous():      # (accumulating micro-batches: the library's addmm_, as the module path -- the
             done = ops.gemm_dw(dY2d, X2d, out2d, accumulate=False, split=(False if mode == 1 else mode))      # proof covered the plain product)
         if not done:
@@ -209,23 +227,15 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 post()
 
     def _streamk_found(self, key):
-        """what the last `_dw_x(key, ...)` with plan value STREAMK ran with: per layer of `key` the stream-K structure (None: one pass
-        is that layer's library sum), or None when the call fell through to the library"""
-        names = {"qkv": ("q", "k", "v"), "gu": ("g", "u")}.get(key, (key,))
-        dev = self.layers[names[0]].weight_q.device.index
-        if len(names) > 1:
-            rows = tuple(int(self.layers[n].weight_q.shape[0]) for n in names)
-            if not any(v is not None for (d, r, _n, _k), v in streamk._merged.items() if d == dev and r == rows):
-                return None
-        out = []
-        for n in names:
-            M, N = self.layers[n].weight_q.shape
-            hits = [v for (d, m, nn, _k), v in streamk._found.items() if d == dev and (m, nn) == (M, N) and v is not None]
-            if not hits:
-                return None
-            out.append(hits[-1][0])
-        if all(st is None for st in out):      # every layer is a one-pass sum: plan value 1 covers that, STREAMK proves nothing new
-            return None if len(names) == 1 else out
+        """what the last `_dw_x(key, ...)` with plan value STREAMK really launched: per layer of `key` the stream-K structure found for
+        THAT call's (M, N, K) (None: one pass is that layer's library sum), or None when the call fell through to the library -- or
+        when every layer is a one-pass sum, which plan value 1 already covers (STREAMK would prove nothing new).  Recorded by `_dw_x`
+        itself (a structure cached for another K must not be reported as the one this trial ran with)."""
+        out = self._last_sk.get(key)
+        if out is None:
+            return None
+        if all(st is None for st in out):
+            return None if len(out) == 1 else out
         return out
 
     def _dx_x(self, key, dY2d):
@@ -437,41 +447,68 @@ class ExactLlamaBlock(FusedLlamaBlock):
         y.backward(dpred)
         return y.detach(), [a.dWq.clone() for a in self.arenas]
 
-    def plan_against_module(self, module_forward, x, others, ref, want=None) -> Optional[dict]:
+    def plan_against_module(self, module_forward, x, others, ref, want=None, second=None) -> Optional[dict]:
         """One minibatch `x` ([rows, S, H], the loop's real minibatch shape: the library picks its GEMM kernels by shape) with targets
         `ref`: forward + loss gradient + backward through the module code (`module_forward(x, others)` -> prediction attached to
         autograd) and through this class, same frozen parameters.  -> the plan (also installed), or None when not even the
         all-torch form reproduces the module path's bits (the caller then keeps the module path).  `want`: options to try
-        (default: every kernel and GEMM form)."""
+        (default: every kernel and GEMM form).  `second` = (x, others, ref) of ANOTHER minibatch of the same shape.
+
+        Acceptance (round 5): an option joins the plan only after TWO CONSECUTIVE runs with nothing differing -- the
+        second one on the second minibatch when there is one -- so that a form that is only usually equal, or an intermittent
+        first-party defect, cannot pass as "1 of 2".  The library under the comparison is itself not perfectly repeatable (about one
+        200-iteration digest run in sixty parts, profiles/r04_digest_repeat.json), so a non-GEMM option whose pair of runs failed gets
+        ONE more pair; that, and every option that ends up dropped (with the number of differing values), is reported through
+        `warnings.warn` and in `plan_report` -- a library bump must not cost 20 % silently."""
+        import warnings
+
         for a in self.arenas:
             if not a.wq_fresh:
                 a.qdq_forward()
         reset = lambda: [l._dw_accum.__setitem__(0, False) for a in self.arenas for l in a.layers]  # noqa: E731
-        reset()
-        pred = module_forward(x, others)
-        pred_c = pred if pred.is_contiguous() else pred.contiguous()
-        dpred = torch.empty_like(pred_c)
-        scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
-        ops.mse_loss_fwd_bwd(pred_c, ref.to(pred_c.dtype), dpred=dpred, loss_accum=scratch, accum_scale=1.0, grad_scale=1000.0)
-        pred_c.backward(dpred)
-        y_ref = pred_c.detach()
-        dw_ref = [a.dWq.clone() for a in self.arenas]
-        del pred, pred_c
 
-        def same(plan):
+        def module_reference(xb, ob, rb):
+            reset()
+            pred = module_forward(xb, ob)
+            pred_c = pred if pred.is_contiguous() else pred.contiguous()
+            dpred = torch.empty_like(pred_c)
+            scratch = torch.zeros(1, dtype=torch.float32, device=xb.device)
+            ops.mse_loss_fwd_bwd(pred_c, rb.to(pred_c.dtype), dpred=dpred, loss_accum=scratch, accum_scale=1.0, grad_scale=1000.0)
+            pred_c.backward(dpred)
+            return xb, ob, dpred, pred_c.detach(), [a.dWq.clone() for a in self.arenas]
+
+        mbs = [module_reference(x, others, ref)]
+        if second is not None:
+            mbs.append(module_reference(*second))
+        report = dict(errors={}, tried=[], kept=[], skipped={}, dropped={}, minibatches=len(mbs))
+
+        def mismatches(plan, mb=0) -> int:
+            """number of values of the block output and of every weight gradient that differ from the module path's (-1: the form
+            refused the shape)"""
+            xb, ob, dpred, y_ref, dw_ref = mbs[mb]
             self.set_plan(plan)
             try:
-                y, dws = self._run_once(x, others, dpred)
+                y, dws = self._run_once(xb, ob, dpred)
             except (RuntimeError, ValueError, NotImplementedError) as e:      # a kernel refusing the shape: not an option here
                 report["errors"][",".join(k for k, v in plan.items() if v)] = repr(e)[:200]
-                return False
-            return _bits_equal(y, y_ref) and all(_bits_equal(a, b) for a, b in zip(dws, dw_ref))
+                return -1
+            return _count_diff(y, y_ref) + sum(_count_diff(a, b) for a, b in zip(dws, dw_ref))
 
-        report = dict(errors={}, tried=[], kept=[], skipped={})
+        def proven(plan):
+            """two consecutive runs without a differing value -> (True, 0), else (False, differing values of the run that failed)"""
+            n = mismatches(plan, 0)
+            if n != 0:
+                return False, n
+            n = mismatches(plan, len(mbs) - 1)
+            return n == 0, n
+
         plan = self.base_plan()
-        if not same(plan):
+        ok, n_bad = proven(plan)
+        if not ok:
             reset()
-            self.plan_report = dict(report, usable=False)
+            self.plan_report = dict(report, usable=False, base_mismatches=n_bad)
+            warnings.warn(f"exact_rounding: even with every segment on torch's own ops {type(self.block).__name__} differs from the module "
+                          f"path ({n_bad} values); blocks of this kind keep the module path")
             return None
 
         def norm_stats_match(rsqrt_f32):
@@ -512,13 +549,17 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 if not variants:
                     report["errors"][opt] = "row statistics differ from torch's (rsqrt / reduction order)"
             report["tried"].append(opt)
+            worst = {}
             for attempt in (0, 1):
-                for tv in variants:
-                    if not same(tv):
+                for vi, tv in enumerate(variants):
+                    ok, n_bad = proven(tv)
+                    if not ok:
+                        worst[str(tv.get(opt)) if opt.startswith("dw_") else str(vi)] = n_bad
                         continue
                     if tv.get(opt) == STREAMK:
                         sts = self._streamk_found(opt[3:])
                         if sts is None:        # no structure found: the call fell through to the library, nothing was proven
+                            worst["STREAMK"] = "no structure reproduces the library's result"
                             continue
                         report.setdefault("streamk", {})[opt] = [
                             dict(one_pass=True) if st is None else dict(grid=st.grid, wgm=st.wgm, depth=st.depth, one_pass_tiles=st.n_dp,
@@ -527,11 +568,16 @@ class ExactLlamaBlock(FusedLlamaBlock):
                     report["kept"].append(opt)
                     if attempt:
                         report.setdefault("kept_on_second_try", []).append(opt)
+                        warnings.warn(f"exact_rounding: option {opt} differed from the module path in its first pair of runs ({worst}) and "
+                                      f"matched in the second pair -- kept; the library under the comparison is not perfectly repeatable")
                     break
-                # the library is not perfectly repeatable (about one GEMM result in thousands differs between two runs of the same
-                # call, profiles/r04_digest_repeat.json): an option that failed once gets one more comparison before it is dropped
                 if opt in report["kept"] or opt.startswith("dw_"):
                     break
+            if opt not in report["kept"]:
+                report["dropped"][opt] = worst
+        if report["dropped"]:
+            warnings.warn(f"exact_rounding: {type(self.block).__name__}: not bit-equal to the module path on this stack and left on the "
+                          f"module path's own form (slower): {report['dropped']} (differing values per tried form)")
         self.set_plan(plan)
         reset()
         self.plan_report = dict(report, usable=True, plan={k: (int(v) if k.startswith("dw_") else bool(v)) for k, v in plan.items()})

@@ -91,9 +91,11 @@ def register():
             try:
                 from auto_round.logger import logger
 
+                path = "fused block" if q.last_fused_block and not q.last_exact else ("module path" if not q.last_exact else "exact_rounding " + ",".join(
+                    f"{k}={v}" if k.startswith("dw_") else k for k, v in sorted((st.get("exact_plan") or {}).items()) if v))
                 logger.infoclean(
                     f"quantized {st['quantized']}/{st['quantized'] + st['unquantized']} layers in the block, "
-                    f"loss iter 0: {st['init_loss']:.6f} -> iter {st['best_iter']}: {st['best_loss']:.6f}")
+                    f"loss iter 0: {st['init_loss']:.6f} -> iter {st['best_iter']}: {st['best_loss']:.6f} [{path}]")
             except Exception:  # pragma: no cover
                 pass
             return best

@@ -336,6 +336,7 @@ class SignRoundQuantizer:
         self.last_fused_block = False
         self.last_hip_graph = False
         self._fused_verdict: Dict[Any, bool] = {}        # block signature -> did the fused kernels agree with the module code
+        self._exact_warned: set = set()
         self._exact_plans: Dict[Any, Any] = {}           # (block signature, minibatch shape) -> proven exact_rounding plan | False
         self.last_exact = False
         self.last_exact_report: Optional[dict] = None
@@ -431,6 +432,16 @@ class SignRoundQuantizer:
             fused = self._build_exact(block, arenas, input_others, per_sample_others, X, Y,
                                       min(cfg.batch_size, min(nsamples, cfg.batch_size * cfg.gradient_accumulate_steps)))
             self.last_exact = fused is not None
+            if fused is None:      # loud, once per kind of block: the module path is bit-identical too, but ~20 % slower
+                kind = type(block).__name__
+                if kind not in self._exact_warned:
+                    self._exact_warned.add(kind)
+                    import warnings
+
+                    rep = self.last_exact_report if isinstance(self.last_exact_report, dict) and not self.last_exact_report.get("usable", True) else None
+                    warnings.warn(f"exact_rounding: {kind} runs on the module path ("
+                                  + ("the proof against the module code failed: " + str({k: rep[k] for k in ('base_mismatches', 'errors') if k in rep})
+                                     if rep else "no exact form for this kind of block / these inputs") + ")")
         elif cfg.fused_block and cfg.amp:
             from .fused_block import build_fused_block
 
@@ -619,6 +630,10 @@ class SignRoundQuantizer:
                                iters_run=last_iter + 1, quantized=len(quantized_names),
                                unquantized=len(unquantized_names), n_improved=n_improved, hip_graph=bool(self.last_hip_graph),
                                loss_trace=loss_hist[:last_iter + 1].tolist())
+        if cfg.exact_rounding:      # which path really ran, and with which proven forms (flat: the plugin's log line prints them)
+            rep = (self.last_exact_report or {}) if self.last_exact else {}
+            self.last_stats.update(exact_block=bool(self.last_exact), exact_plan=rep.get("plan"), exact_streamk=rep.get("streamk"),
+                                   exact_dropped=rep.get("dropped") or None, exact_kept_on_second_try=rep.get("kept_on_second_try"))
         with torch.no_grad():
             unwrapper_block(block, best_params)
         # hand out independent copies: the arenas' best_* buffers are released with the block's wrappers
@@ -637,14 +652,20 @@ class SignRoundQuantizer:
         if eb is None:
             return None
         mask = input_others.get("attention_mask")
-        key = ("exact", self._block_signature(block), rows, tuple(X.shape[1:]), str(X.dtype), bool(per_sample_others),
-               None if mask is None else (tuple(mask.shape), str(mask.dtype)), cfg.sdpa_backend, cfg.materialise_shared_rows)
+        key = ("exact", self._block_signature(block), self._shape_signature(block), rows, tuple(X.shape[1:]), str(X.dtype),
+               bool(per_sample_others), None if mask is None else (tuple(mask.shape), str(mask.dtype)), cfg.sdpa_backend,
+               cfg.materialise_shared_rows)
         plan = self._exact_plans.get(key)
         if plan is None:
-            others_chk = input_others if not per_sample_others else {**input_others, **{k: t[:rows] for k, t in per_sample_others.items()}}
+            def others_of(lo):
+                o = input_others if not per_sample_others else {**input_others, **{k: t[lo:lo + rows] for k, t in per_sample_others.items()}}
+                return self._others_for(rows, o)
+
+            # a second minibatch of the same shape for the confirming run of every option (exact_block.plan_against_module)
+            second = (X[rows:2 * rows].clone(), others_of(rows), Y[rows:2 * rows]) if X.shape[0] >= 2 * rows else None
             try:
-                plan = eb.plan_against_module(lambda x, o: self.block_forward(block, x, o), X[:rows].clone(),
-                                              self._others_for(rows, others_chk), Y[:rows])
+                plan = eb.plan_against_module(lambda x, o: self.block_forward(block, x, o), X[:rows].clone(), others_of(0), Y[:rows],
+                                              second=second)
             except Exception as e:  # noqa: BLE001 -- a block the class does not fit after all: the module path, never an aborted run
                 import warnings
 
@@ -677,7 +698,7 @@ class SignRoundQuantizer:
         if eb is None:
             return None
         mask = input_others.get("attention_mask")
-        key = ("exact_plain", self._block_signature(block), rows, tuple(inputs.shape[1:]), str(inputs.dtype),
+        key = ("exact_plain", self._block_signature(block), self._shape_signature(block), rows, tuple(inputs.shape[1:]), str(inputs.dtype),
                None if mask is None else (tuple(mask.shape), str(mask.dtype)), cfg.sdpa_backend, cfg.materialise_shared_rows)
         plan = self._exact_plans.get(key)
         if plan is None:
@@ -714,6 +735,24 @@ class SignRoundQuantizer:
             warnings.warn(f"fused block path: {type(block).__name__} is on the class whitelist but its fused form does not agree with the "
                           f"module code on the check minibatch (distance / block contribution = {d}); every block of this kind keeps "
                           f"the module path")
+
+    @staticmethod
+    def _shape_signature(block):
+        """What a PROVEN exact_rounding plan is specific to besides the block's classes: every linear's (name, out, in, weight dtype,
+        bias) and the attention's head geometry.  The plan holds shape-specific GEMM forms (`dw_*` = n K-slices or a stream-K cut table
+        found for ONE (M, N, K); `tn_*`), and hipBLASLt picks its kernel by shape: a later block of the same class with another FFN or
+        KV width (variable-width Llama derivatives) must get its own proof, not inherit one."""
+        lins = []
+        for n, m in block.named_modules():
+            w = getattr(m, "weight", None)
+            if isinstance(w, torch.Tensor) and w.dim() == 2 and (isinstance(m, torch.nn.Linear) or hasattr(m, "orig_layer")):
+                lins.append((n.replace(".orig_layer", ""), tuple(w.shape), str(w.dtype), getattr(m, "bias", None) is not None))
+        att = getattr(block, "self_attn", None)
+        geo = tuple(getattr(att, k, None) if not isinstance(getattr(att, k, None), torch.Tensor) else None
+                    for k in ("head_dim", "num_key_value_groups", "scaling", "num_heads", "num_key_value_heads")) if att is not None else ()
+        acfg = getattr(att, "config", None)
+        geo += tuple(getattr(acfg, k, None) for k in ("num_attention_heads", "num_key_value_heads", "head_dim")) if acfg is not None else ()
+        return (tuple(sorted(set(lins))), geo)
 
     @staticmethod
     def _block_signature(block):

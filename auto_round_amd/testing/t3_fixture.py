@@ -151,6 +151,10 @@ def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw
         p.requires_grad_(False)
     tokens = calib_tokens(arch, nsamples, seqlen)
     block = decoder_blocks(model)[0]
+    if ARCHS[arch]["family"] == "moe":      # fused 3-D expert parameters -> per-expert nn.Linear, as the reference's model preparation does
+        from auto_round_amd.moe_unfuse import unfuse_moe_experts
+
+        unfuse_moe_experts(model)
     sch = resolve_scheme(scheme, **(scheme_kw or {}))
     apply_scheme(block, sch)
     x0, others = capture_block_inputs(model, block, tokens, device)
@@ -309,6 +313,7 @@ def digest_of(tensors: Dict[str, Dict[str, np.ndarray]]) -> Dict[str, str]:
 
 
 FULL_PREFIX = 1 << 16
+STAT_PREFIX = 1 << 16      # values per tuned layer kept in a statistical (two-reference-run) fixture
 
 
 def write_digest_v2(path: str, case: dict, tensors, ref_trace, x_sha: str, y_sha: str, meta_extra: dict, full_layer: Optional[str] = None) -> int:
@@ -348,3 +353,57 @@ def check_against_digest_v2(path: str, fused: bool = False, exact: bool = False)
                 init_loss_ref=ref_trace[0], best_loss=r["stats"]["best_loss"], best_loss_ref=min(ref_trace),
                 best_loss_ratio=r["stats"]["best_loss"] / min(ref_trace), first_divergence_iter=trace_divergence(ref_trace, tr),
                 tune_s=r["tune_s"], device=m.get("device"), torch=m.get("torch"))
+
+
+# ---- statistical fixtures (round 5): two runs of the REAL reference, for blocks whose library kernels are not run-to-run reproducible ----
+def stat_thresholds(rvr: dict) -> dict:
+    """What the reference-vs-reference statistics a t3s fixture carries would allow (tests/t3_baseline_shapes.py `write_stat_fixture`):
+    as far from reference run 1 as twice the distance reference run 2 kept, plus two points; the best loss within three times the
+    reference's own spread, at least 1 %.  Reported next to the measurements; with the committed fixtures (ref_vs_ref = 1.0: both
+    reference runs identical) they amount to "0.98 / 1 %", and the tests use bit identity first and documented floors after a retry."""
+    same = float(rvr["prefix_identical_weights"])
+    ratio = rvr.get("best_loss_ratio")
+    spread = abs(float(ratio) - 1.0) if ratio else 0.0
+    return dict(min_identical=max(0.0, 1.0 - 2.0 * (1.0 - same) - 0.02), loss_band=max(0.01, 3.0 * spread))
+
+
+def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = False, graph: Optional[bool] = None) -> dict:
+    """Re-tune a t3s fixture's block with this package, reference-free, and measure how close the result is to reference run 1 over
+    the same per-layer prefixes reference run 2 was measured on -> a flat record with the derived thresholds next to the measurements."""
+    z = np.load(path, allow_pickle=False)
+    m = json.loads(str(z["meta"]))
+    kw = dict(m.get("scheme_kw") or {})
+    alg_ext = bool(kw.pop("enable_alg_ext", False))
+    lr, mmlr = kw.pop("lr", None), kw.pop("minmax_lr", None)
+    r = tune_with_product(m["arch"], scheme=m["scheme"], scheme_kw=kw, iters=m["iters"], nsamples=m["nsamples"], seqlen=m["seqlen"],
+                          batch_size=m["batch_size"], fused=fused, seed=m["seed"], exact=exact, alg_ext=alg_ext, lr=lr, minmax_lr=mmlr, graph=graph)
+    mine = tuned_layer_tensors(r["block"])
+    P = int(m["prefix"])
+    tot = same = stot = ssame = 0
+    per_layer = {}
+    for n in m["layers"]:
+        want_w, want_s = z[f"{n}::weight"], z[f"{n}::scale"]
+        got_w = mine[n]["weight"].reshape(-1)[:P]
+        got_s = mine[n]["scale"].reshape(-1)[:P]
+        e = got_w == want_w
+        tot += e.size
+        same += int(e.sum())
+        es = got_s == want_s
+        stot += es.size
+        ssame += int(es.sum())
+        per_layer[n] = float(e.mean())
+    got = digest_of({n: dict(weight=d["weight"], scale=d["scale"]) for n, d in mine.items()})
+    differing = sorted(k for k, want in m["digests"].items() if got.get(k) != want)
+    ref_trace = [float(x) for x in z["loss_trace"]]
+    tr = r["loss_trace"] or []
+    rvr = m["ref_vs_ref"]
+    return dict(case=os.path.basename(path), fused_block=r["fused_block"], exact_block=r["exact_block"], hip_graph=r["hip_graph"],
+                inputs_identical=(r["x_sha"] == m["x_sha"]), targets_identical=(r["y_sha"] == m["y_sha"]), same_layer_set=sorted(mine) == sorted(m["layers"]),
+                prefix_identical_weights=same / max(tot, 1), prefix_identical_scales=ssame / max(stot, 1), prefix_values=tot,
+                worst_layer=min(per_layer.items(), key=lambda t: t[1]) if per_layer else None,
+                bit_identical=(not differing), tensors=len(m["digests"]), tensors_identical=len(m["digests"]) - len(differing),
+                init_loss=r["stats"]["init_loss"], init_loss_ref=ref_trace[0], best_loss=r["stats"]["best_loss"], best_loss_ref=min(ref_trace),
+                best_loss_ratio=r["stats"]["best_loss"] / min(ref_trace), first_divergence_iter=trace_divergence(ref_trace, tr),
+                ref_vs_ref_prefix_identical_weights=rvr["prefix_identical_weights"], ref_vs_ref_best_loss_ratio=rvr.get("best_loss_ratio"),
+                ref_vs_ref_first_divergence_iter=rvr.get("first_divergence_iter"), **stat_thresholds(rvr), tune_s=r["tune_s"],
+                device=m.get("device"), torch=m.get("torch"))

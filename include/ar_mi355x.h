@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 23
+#define AR_ABI_VERSION 24
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -367,6 +367,33 @@ int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M, int64_t N,
  * chip; otherwise the fp32 partial tiles of its split-K form (few tiles, deep K -- e.g. OPT-125M's 768x768 weight against 16384
  * tokens), which are summed in slice order, i.e. deterministically.  Without the workspace the call still works, unsplit. */
 int64_t ar_gemm_dw_workspace_bytes(int64_t M, int64_t N, int64_t K);
+/* The same weight-gradient GEMM GROUPED over the experts of a sparse-MoE block: group e owns k-rows [row_off[e], row_off[e+1]) of
+ * dY [R, M] and X [R, N] (the rows of the tokens routed to expert e, sorted by expert) and writes its own dW_e [M, N] = dY_e^T X_e
+ * to dW + w_off[e] (elements, ldw).  ONE launch of n_groups * (M/256) * (N/256) workgroups; row_off ([n_groups + 1] int32) and
+ * w_off ([n_groups] int64) are DEVICE arrays, so the launch needs no host knowledge of the row counts (hipGraph-capturable); a group
+ * without rows writes zeros (sign(0) = 0: the sign-SGD step then leaves its parameters untouched, as a missing gradient does).
+ * replaces: the autograd backward of the per-expert F.linear calls in the reference's "linear loop" experts
+ *           (auto_round/modeling/fused_moe/moe_experts_interface.py:173-289 around auto_round/wrapper.py:528-556).  Deterministic. */
+int ar_gemm_dw_grouped(const void* dY, const void* X, void* dW, int64_t M, int64_t N, int64_t ldy, int64_t ldx, int64_t ldw,
+                       const int32_t* row_off, const int64_t* w_off, int n_groups, ar_stream_t stream);
+
+/* ---- forward / input-gradient GEMM (hand-written MFMA "NT" kernel, gfx950; SURVEY 8 row f1 forward side) ---------------------
+ * replaces: the forward of F.linear(x, weight_q) inside WrapperLinear.forward (auto_round/wrapper.py:528-556): C[M,N] = A[M,K] B[N,K]^T,
+ *           A = activations [tokens, in], B = the fake-quant weight [out, in], both K-contiguous bf16 (leading dimensions in elements),
+ *           fp32 accumulation over K in ascending order in steps of 16 (v_mfma_f32_32x32x16_bf16), one rounding to bf16 -- the
+ *           summation the library's kernel performs for these shapes; with B = a transposed weight copy [in, out] the same call is the
+ *           input gradient dX = dY Wq.  M any (rows past M are clamped on the load side, masked on the store side), N % 256 == 0,
+ *           K % 128 == 0, operands 16-byte aligned, lda / ldb multiples of 8, ldc a multiple of 4; anything else returns
+ *           AR_ERR_UNSUPPORTED and the caller keeps the library GEMM.  No bias.  Needs 128 KB of dynamic LDS per workgroup. */
+int ar_gemm_nt(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+               ar_stream_t stream);
+/* Grouped over the experts of a sparse-MoE block (one launch per projection instead of a Python loop of per-expert GEMMs with a host
+ * read of the token counts, auto_round/modeling/fused_moe/moe_experts_interface.py:173-289): group e multiplies rows
+ * [row_off[e], row_off[e+1]) of A (and writes the same rows of C) with ITS matrix B + b_off[e] ([N, K], ldb).  row_off
+ * ([n_groups + 1] int32) and b_off ([n_groups] int64, elements) are DEVICE arrays; M = row_off[n_groups] = rows of A.  The grid covers
+ * M / 256 + n_groups row tiles (every group may end in a partial tile); workgroups past the last real tile exit.  Deterministic. */
+int ar_gemm_nt_grouped(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                       const int32_t* row_off, const int64_t* b_off, int n_groups, ar_stream_t stream);
 /* experiment knobs of the kernel above for tools/gemm_dw_probe.py (binding hygiene; -1 keeps a value): sem = lane->piece rule
  * of the transposing LDS read (1 | 2), order = tile order (0 identity, 1 XCD chunks, 2 XCD 2x8 patches).  Returns sem*10+order. */
 int ar_gemm_dw_config(int sem, int order);
@@ -425,7 +452,7 @@ int ar_attn_bwd_masked(const void* Q, const void* K, const void* V, const void* 
  * kernels, output elements for the GEMM), so that bench.py's live roofline fraction is honest for an 11 us kernel too.
  * These three calls are the only ones that allocate (events) or synchronise (read / reset). */
 enum { AR_PROF_INT_FWD = 0, AR_PROF_INT_BWD = 1, AR_PROF_FP4_FWD = 2, AR_PROF_FP4_BWD = 3, AR_PROF_GEMM_DW = 4,
-       AR_PROF_NORM = 5, AR_PROF_SWIGLU = 6, AR_PROF_ROPE = 7 };
+       AR_PROF_NORM = 5, AR_PROF_SWIGLU = 6, AR_PROF_ROPE = 7, AR_PROF_GEMM_NT = 8 };
 int ar_profile_enable(int on);
 int ar_profile_reset(void);
 int ar_profile_read(int kernel_id, int64_t min_units, double* total_ms, double* min_ms, int64_t* launches);

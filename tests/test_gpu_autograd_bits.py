@@ -85,3 +85,54 @@ def test_fp4_backward_is_bit_identical_to_torch_autograd_on_the_gpu(kind):
                                     gs=gs, global_scale=gs_dev, want_grads=True)
     assert _values_equal(dV, V.grad.reshape(-1)), _bits_equal(dV, V.grad.reshape(-1))
     assert _values_equal(dmax, mx.grad), _bits_equal(dmax, mx.grad)
+
+
+# ---- round 5: the init-scale searches of the algorithm extension, against the torch restatement ON THE GPU -------------------------
+def _search_problem(out_f, in_f, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    W = (torch.randn(out_f, in_f, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    # an importance row the way the imatrix hooks leave it: sums of squares over many tokens, a few decades of dynamic range
+    im = (torch.randn(in_f, generator=g, device="cuda") ** 2 * torch.exp(2.0 * torch.randn(in_f, generator=g, device="cuda")) * 4096.0).float()
+    return W, im
+
+
+@pytest.mark.parametrize("bits,gs", [(2, 32), (4, 128), (4, 32), (3, 64), (8, 128)])
+@pytest.mark.parametrize("weighted", [True, False], ids=["imatrix", "ones"])
+def test_int_init_scale_search_is_bit_identical_to_torch_on_the_gpu(bits, gs, weighted):
+    """search_scales (data_type/int.py:24-86) is a chain of `loss < best_loss` over ~180-400 candidates per group: one low bit of a
+    group's loss decides a near-tie, and the searched scale seeds the whole trajectory of an algorithm-extension run (W2G32 sym, the
+    recipe the reference recommends).  The kernel adds a group's errors in the association torch's reduction kernel uses for
+    `sum(dim=-1)` of an [G, gs] fp32 tensor on this GPU -- every group must come out with the same scale, bit for bit."""
+    from auto_round_amd import ops
+    from oracle import torch_ref as tr
+
+    out_f, in_f = 1024, 4096
+    W, im = _search_problem(out_f, in_f, seed=bits * 1000 + gs)
+    Wg = W.reshape(-1, gs)
+    qw = im.view(1, -1).expand(out_f, -1).reshape(-1, gs) if weighted else None
+    want = tr.search_int_scale(Wg, bits, qw=qw).reshape(-1)
+    got = ops.search_int_scale(W.view(-1), gs=gs, bits=bits, qw_row=im if weighted else None, groups_per_row=in_f // gs)
+    same = got.view(torch.int16) == want.view(torch.int16)
+    assert bool(same.all()), (bits, gs, weighted, float(same.float().mean()))
+
+
+@pytest.mark.parametrize("kind", ["mxfp4", "nvfp4"])
+@pytest.mark.parametrize("weighted", [True, False], ids=["imatrix", "ones"])
+def test_fp4_init_scale_search_is_bit_identical_to_torch_on_the_gpu(kind, weighted):
+    """search_mx_scale (mxfp.py:103-170: coefficients 1, 0.5, 2) and search_nvfp4_scale (nvfp.py:329-386: 1.0, then 0.50 ... 1.51)."""
+    from auto_round_amd import ops
+    from oracle import torch_ref as tr
+
+    out_f, in_f = 1024, 4096
+    gs, mode = (32, 0) if kind == "mxfp4" else (16, 1)
+    W, im = _search_problem(out_f, in_f, seed=7 + mode)
+    Wg = W.reshape(-1, gs)
+    qw = im.view(1, -1).expand(out_f, -1).reshape(-1, gs) if weighted else None
+    want = (tr.search_mx_coeff(Wg, qw=qw) if mode == 0 else tr.search_nv_coeff(Wg, qw=qw)).reshape(-1)
+    absmax, tmax = ops.group_absmax(W.view(-1), gs, want_tensor_max=True)
+    gsc = (448.0 * 6.0 * (1.0 / tmax)).to(torch.float32) if mode else None
+    cand = torch.tensor(ops.fp4_search_candidates(mode), dtype=torch.float32, device="cuda")
+    got = ops.search_fp4_scale(W.view(-1), absmax, cand, mode=mode, gs=gs, qw_row=im if weighted else None, groups_per_row=in_f // gs,
+                               global_scale=gsc)
+    same = got == want
+    assert bool(same.all()), (kind, weighted, float(same.float().mean()))
