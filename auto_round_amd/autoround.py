@@ -65,6 +65,16 @@ class AutoRound:
         # reference's: faster, different rounding points inside the block.
         for k in ("low_gpu_mem_usage", "low_cpu_mem_usage"):
             kwargs.pop(k, None)
+        # The reference's constructor turns torch's deterministic-algorithms mode ON (compressors/base.py:339-351: warn-only by default,
+        # strict with enable_deterministic_algorithms=True).  That is process-global state and part of what the reference COMPUTES: under
+        # it torch takes its deterministic forms of index_add_ / index_put_(accumulate) / scatter, and on this stack the library picks
+        # other kernels where the default ones accumulate with atomics -- OPT-125M's head-size-64 attention backward, the per-expert
+        # GEMMs of a Mixtral block over ragged row counts.  Round 5 found it the hard way: with the mode on (the reference itself, and
+        # this package behind the reference's front door) both blocks reproduce the reference bit for bit, without it the same code
+        # parts from it after ~55 iterations.  Mirrored here, same keywords, same default.
+        strict = bool(kwargs.pop("enable_deterministic_algorithms", False)) or not bool(kwargs.pop("disable_deterministic_algorithms", True))
+        os.environ.setdefault("CUBLAS_WORKSPACE_CONFIG", ":4096:8")
+        torch.use_deterministic_algorithms(True, warn_only=not strict)
         fused = bool(kwargs.pop("enable_torch_compile", False))
         # MI355X-only: Llama-family blocks through the first-party kernels that keep the eager path's bits (exact_block.py) -- on by
         # default: same results as the module code (proven per kind of block before use, module path otherwise), fewer launches

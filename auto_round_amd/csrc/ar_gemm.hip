@@ -547,7 +547,15 @@ __device__ __attribute__((aligned(512))) uint16_t g_zero_row[256];
 // GROUPED (ar_gemm_dw_grouped, round 5): the launch holds one full tile grid per group (an expert of a sparse-MoE block); a workgroup's
 // K range is its group's row range [goff[g], goff[g+1]) read from device memory -- completed with zero rows like TAIL (which it implies)
 // -- and its output is that group's own matrix W + woff[g].  A group without rows writes zeros.
-template <bool STAGGER, bool SPLITK = false, bool TAIL = false, bool CUT = false, bool GROUPED = false>
+// DMAL (round 5): the four LDS-DMA pieces of a phase are issued at the END of the L part -- after the wave's fragment reads have
+// returned (lgkmcnt(0)), before the barrier -- instead of between the MFMAs of the M part.  Why: the two waves of a SIMD alternate
+// (one in its 16-MFMA cluster, the other in its L part), every barrier interval is as long as the LONGER of the two, and a DMA piece
+// issued among the MFMAs costs the issuing wave ~60 cycles during which the matrix pipe has no taker -- 4 pieces stretch a 512-cycle
+// cluster to ~750 (MfmaUtil 68 %, profiles/r04_pmc_mfma_kernels.json).  The L part idles at its barrier for most of that time; v1
+// (round 2) had the pieces there too, but issued them while the fragment reads were still in flight (100-185 cycles each, the L part
+// outgrew the cluster).  Same ring, same counted vmcnt(4), same arithmetic: the slot of pair S+3 is the slot of pair S-1, whose reads
+// both groups finished before this wave entered L(S); the data is waited for in L(S+2) and read in L(S+3).
+template <bool STAGGER, bool SPLITK = false, bool TAIL = false, bool CUT = false, bool GROUPED = false, bool DMAL = false>
 __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     static_assert(!GROUPED || (TAIL && !SPLITK && !CUT), "the grouped form is the ragged-K form per group");
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
@@ -685,12 +693,13 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
         AR_RD(f.plo[1][0], f.phi[1][0], aP[H][0], O + UNIT); AR_RD(f.plo[1][1], f.phi[1][1], aP[H][1], O + UNIT);       \
         AR_RD(f.plo[1][2], f.phi[1][2], aP[H][2], O + UNIT); AR_RD(f.plo[1][3], f.phi[1][3], aP[H][3], O + UNIT);       \
         asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        if (DMAL) { AR_PIN(); issue_p(DU); issue_q(DU); issue_p(DU + 1); issue_q(DU + 1); }                              \
         bar();                                                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                                  \
-        AR_MMA(0, 0, 0); AR_MMA(0, 0, 1); AR_PIN(); issue_p(DU); AR_PIN();                                              \
-        AR_MMA(0, 0, 2); AR_MMA(0, 0, 3); AR_MMA(0, 1, 0); AR_MMA(0, 1, 1); AR_PIN(); issue_q(DU); AR_PIN();            \
-        AR_MMA(0, 1, 2); AR_MMA(0, 1, 3); AR_MMA(1, 0, 0); AR_MMA(1, 0, 1); AR_PIN(); issue_p(DU + 1); AR_PIN();        \
-        AR_MMA(1, 0, 2); AR_MMA(1, 0, 3); AR_MMA(1, 1, 0); AR_MMA(1, 1, 1); AR_PIN(); issue_q(DU + 1); AR_PIN();        \
+        AR_MMA(0, 0, 0); AR_MMA(0, 0, 1); AR_PIN(); if (!DMAL) issue_p(DU); AR_PIN();                                   \
+        AR_MMA(0, 0, 2); AR_MMA(0, 0, 3); AR_MMA(0, 1, 0); AR_MMA(0, 1, 1); AR_PIN(); if (!DMAL) issue_q(DU); AR_PIN(); \
+        AR_MMA(0, 1, 2); AR_MMA(0, 1, 3); AR_MMA(1, 0, 0); AR_MMA(1, 0, 1); AR_PIN(); if (!DMAL) issue_p(DU + 1); AR_PIN(); \
+        AR_MMA(1, 0, 2); AR_MMA(1, 0, 3); AR_MMA(1, 1, 0); AR_MMA(1, 1, 1); AR_PIN(); if (!DMAL) issue_q(DU + 1); AR_PIN(); \
         AR_MMA(1, 1, 2); AR_MMA(1, 1, 3);                                                                               \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
         bar();                                                                                                          \
@@ -1065,6 +1074,7 @@ __global__ __launch_bounds__(kTPB) void k_splitk_reduce_tiles(GemmArgs a) {
 static int g_gemm_kernel = 7;     // 0: v0  1: v1 staggered  2: v1 lockstep  3: v2 (split reads)  4-6: timing ablations  7: v3 (DMA in the MFMA cluster)
 static int g_gemm_tail = 1;       // hybrid split of the last partial round (ar_gemm_dw_config(20 | 21) switches it for the A/B)
 static int g_gemm_sem = 1, g_gemm_order = 2;    // rule 1 is what the hardware does (profiles/r02_mfma_probe.json)
+static int g_gemm_dmal = 0;       // DMA pieces at the end of the L part (ar_gemm_dw_config(30 | 31) switches it for the A/B)
 
 }  // namespace ar
 
@@ -1076,8 +1086,21 @@ extern "C" int ar_gemm_dw_config(int sem, int order) {      // experiment knobs 
     if (sem >= 10 && sem <= 19) g_gemm_kernel = sem - 10;       // 10: v0, 11: v1 staggered, 12: v1 lockstep, 14-16: ablations, 17: v3, 18 / 19: v4
 #endif
     if (sem == 20 || sem == 21) g_gemm_tail = sem - 20;
+    if (sem == 30 || sem == 31) g_gemm_dmal = sem - 30;
     if (order >= 0 && order <= 2) g_gemm_order = order;
     return g_gemm_kernel * 100 + g_gemm_sem * 10 + g_gemm_order;
+}
+
+// kernel of a given form with the DMA pieces in the M part (round 2-4) or at the end of the L part (round 5), by the A/B knob
+typedef void (*dw4_fn)(GemmArgs);
+template <bool SPLITK, bool TAIL, bool CUT, bool GROUPED>
+static dw4_fn dw4_kernel() {
+    static PerDeviceOnce once;
+    if (once.first()) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, SPLITK, TAIL, CUT, GROUPED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, SPLITK, TAIL, CUT, GROUPED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    }
+    return g_gemm_dmal ? k_gemm_dw4<true, SPLITK, TAIL, CUT, GROUPED, true> : k_gemm_dw4<true, SPLITK, TAIL, CUT, GROUPED, false>;
 }
 
 // One 512-thread workgroup holds a CU (128 KB of LDS): 256 run at a time, and a launch of 256 r + t workgroups costs r + 1 rounds
@@ -1156,8 +1179,8 @@ extern "C" int ar_gemm_dw_sk(const void* dY, const void* X, void* dW, int64_t M,
         (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     }
-    if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, true, true>), grid, GTHREADS, GEMM_LDS, st, a);
-    else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, false, true>), grid, GTHREADS, GEMM_LDS, st, a);
+    if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (dw4_kernel<false, true, true, false>()), grid, GTHREADS, GEMM_LDS, st, a);
+    else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (dw4_kernel<false, false, true, false>()), grid, GTHREADS, GEMM_LDS, st, a);
     return launch_status();
 }
 
@@ -1179,7 +1202,7 @@ extern "C" int ar_gemm_dw_grouped(const void* dY, const void* X, void* dW, int64
     static PerDeviceOnce once;
     if (once.first())
         (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N * n_groups, (k_gemm_dw4<true, false, true, false, true>), (int)grid, GTHREADS, GEMM_LDS,
+    AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N * n_groups, (dw4_kernel<false, true, false, true>()), (int)grid, GTHREADS, GEMM_LDS,
                    (hipStream_t)stream, a);
     return launch_status();
 }
@@ -1231,8 +1254,8 @@ static int gemm_dw_impl(const void* dY, const void* X, void* dW, int64_t M, int6
                 return AR_ERR_UNSUPPORTED;          // a forced structure is either delivered or refused, never silently replaced
             if (ns > 1 && workspace && workspace_bytes >= (int64_t)ns * M * N * 4 && (ldw % 8) == 0 && !((uintptr_t)dW & 15)) {
                 a.ws = (float*)workspace; a.nsplit = ns;
-                if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, true, true>), grid * ns, GTHREADS, GEMM_LDS, st, a);
-                else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, true>), grid * ns, GTHREADS, GEMM_LDS, st, a);
+                if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (dw4_kernel<true, true, false, false>()), grid * ns, GTHREADS, GEMM_LDS, st, a);
+                else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (dw4_kernel<true, false, false, false>()), grid * ns, GTHREADS, GEMM_LDS, st, a);
                 const int rgrid = (int)((M * (N / kEPT) + kTPB - 1) / kTPB);
                 hipLaunchKernelGGL(k_splitk_reduce, rgrid, kTPB, 0, st, a.ws, ns, M, N, a.W, ldw, accumulate);
                 return launch_status();
@@ -1241,14 +1264,14 @@ static int gemm_dw_impl(const void* dY, const void* X, void* dW, int64_t M, int6
             const int rtail = (K % 128 == 0 && g_gemm_tail && force_ns == 0) ? tail_plan(M, N, K, &tns) : 0;
             if (rtail && workspace && workspace_bytes >= (int64_t)rtail * tns * GB * GB * 4 && (ldw % 8) == 0 && !((uintptr_t)dW & 15)) {
                 // full rounds with the whole K, then the last (partial) round split along K, then its slices summed in order
-                AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true>), grid - rtail, GTHREADS, GEMM_LDS, st, a);
+                AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (dw4_kernel<false, false, false, false>()), grid - rtail, GTHREADS, GEMM_LDS, st, a);
                 a.ws = (float*)workspace; a.nsplit = tns; a.tile0 = grid - rtail;
-                hipLaunchKernelGGL((k_gemm_dw4<true, true>), rtail * tns, GTHREADS, GEMM_LDS, st, a);
+                hipLaunchKernelGGL((dw4_kernel<true, false, false, false>()), rtail * tns, GTHREADS, GEMM_LDS, st, a);
                 hipLaunchKernelGGL(k_splitk_reduce_tiles, rtail * 32, kTPB, 0, st, a);
                 return launch_status();
             }
-            if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true, false, true>), grid, GTHREADS, GEMM_LDS, st, a);
-            else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (k_gemm_dw4<true>), grid, GTHREADS, GEMM_LDS, st, a);
+            if (K % 128) AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (dw4_kernel<false, true, false, false>()), grid, GTHREADS, GEMM_LDS, st, a);
+            else AR_LAUNCH_PROF(AR_PROF_GEMM_DW, M * N, (dw4_kernel<false, false, false, false>()), grid, GTHREADS, GEMM_LDS, st, a);
             return launch_status();
         }
 #ifdef AR_GEMM_EXPERIMENTS

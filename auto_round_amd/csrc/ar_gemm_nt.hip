@@ -58,7 +58,12 @@ __device__ __forceinline__ void nt_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool GROUPED>
+// DMAL = false: the protocol of the header (4 pieces per M part, streams X / Y).  DMAL = true (see the note at k_gemm_dw4): the M part
+// is 16 bare MFMAs and ALL 8 pieces of stage tau+1 (the wave's B pieces, then its A pieces) are issued at the end of the L part of the
+// even phase 2 tau, after the fragment reads returned: the buffer is the one stage tau-1 lived in, whose last reads (L(2 tau - 1) of both
+// groups) are behind the barrier this wave passed to enter L(2 tau); `vmcnt(4)` at the end of L(2 tau + 1) retires the B pieces (read by
+// both groups from L(2 tau + 2) on), `vmcnt(0)` at the end of M(2 tau + 1) the A pieces (read by the issuing group alone).
+template <bool GROUPED, bool DMAL>
 __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -73,7 +78,14 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
         const int nwg = gridDim.x;
         int id = blockIdx.x;
         if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);            // a contiguous run of tiles per XCD
-        const int gmt = id / a.tiles_n, tn = id - gmt * a.tiles_n;
+        // bands of 8 column tiles, row tiles inside a band, columns fastest: 32 consecutive ids = 4 row tiles x 8 column tiles, i.e. the
+        // 32 workgroups an XCD runs at a time share 4 A panels and 8 B panels (walking a whole row of 112 column tiles first -- the first
+        // cut -- made them fetch 1 + 32 panels per stage: 0.96 PF on Mixtral's merged gate|up against 1.11 on the down projection)
+        const int bw = (a.tiles_n % 8 == 0) ? 8 : a.tiles_n;
+        const int per_band = a.tiles_m * bw;
+        const int band = id / per_band, rem = id - band * per_band;
+        const int gmt = rem / bw, tn = band * bw + (rem - gmt * bw);
+        if (tn >= a.tiles_n) return;
         int e = -1, base = 0, r0 = 0, r1 = 0;
         for (int i = 0; i < a.E; ++i) {
             const int s0 = a.row_off[i], s1 = a.row_off[i + 1];
@@ -139,6 +151,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
     const uint32_t dstB = dstA + 65536;
     const uint32_t dstX = wr ? dstB : dstA, dstY = wr ? dstA : dstB;
     int sx = 0, sy = 0;                              // next stage of each stream
+    const uint8_t* gA2 = gA;                         // DMAL: running pointers of the two operands (stage sx)
+    const uint8_t* gB2 = gB;
 
     // ---- fragment read addresses: X[a][u] = row * 128 + 16 * ((4a + 2u + h) ^ s)
     uint32_t adA[2][2], adB[2][2];
@@ -169,6 +183,13 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
 #define NT_ISSUE_Y(SO, J)                                                                                               \
     __builtin_amdgcn_global_load_lds((const void*)(gY + voffY[J]),                                                      \
                                      (__attribute__((address_space(3))) void*)(uintptr_t)(dstY + (SO) + (J) * 1024), 16, 0, 0)
+#define NT_ISSUE_A(SO, J)                                                                                               \
+    __builtin_amdgcn_global_load_lds((const void*)(gA2 + voffA[J]),                                                     \
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)(dstA + (SO) + (J) * 1024), 16, 0, 0)
+#define NT_ISSUE_B(SO, J)                                                                                               \
+    __builtin_amdgcn_global_load_lds((const void*)(gB2 + voffB[J]),                                                     \
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)(dstB + (SO) + (J) * 1024), 16, 0, 0)
+#define NT_ADV_AB() do { ++sx; const int st_ = (sx < T) ? 128 : 0; gA2 += st_; gB2 += st_; } while (0)
     // past the last stage the pointers stay on it (staged again into a buffer nobody reads any more)
 #define NT_ADV_X() do { ++sx; gX += (sx < T) ? 128 : 0; } while (0)
 #define NT_ADV_Y() do { ++sy; gY += (sy < T) ? 128 : 0; } while (0)
@@ -199,26 +220,40 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
         NT_RD(fa[1][2], adA[AH][1], O + 8192); NT_RD(fa[1][3], adA[AH][1], O + 12288);                                  \
         if (AH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                        \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+        if (DMAL && !AH) {      /* stage tau + 1 into the other parity: the wave's B pieces first, then its A pieces */         \
+            NT_PIN();                                                                                                   \
+            NT_ISSUE_B(16384 - O, 0); NT_ISSUE_B(16384 - O, 1); NT_ISSUE_B(16384 - O, 2); NT_ISSUE_B(16384 - O, 3);       \
+            NT_ISSUE_A(16384 - O, 0); NT_ISSUE_A(16384 - O, 1); NT_ISSUE_A(16384 - O, 2); NT_ISSUE_A(16384 - O, 3);       \
+            NT_ADV_AB();                                                                                                \
+        }                                                                                                               \
         bar();                                                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                                  \
-        NT_MMA(0, 0, 0); NT_MMA(0, 0, 1); NT_PIN(); if (AH) NT_ISSUE_X(OI, 0); else NT_ISSUE_Y(OI, 0); NT_PIN();          \
+        NT_MMA(0, 0, 0); NT_MMA(0, 0, 1); NT_PIN(); if (!DMAL) { if (AH) NT_ISSUE_X(OI, 0); else NT_ISSUE_Y(OI, 0); } NT_PIN(); \
         NT_MMA(0, 1, 0); NT_MMA(0, 1, 1); NT_MMA(0, 2, 0); NT_MMA(0, 2, 1); NT_PIN();                                   \
-        if (AH) NT_ISSUE_X(OI, 1); else NT_ISSUE_Y(OI, 1); NT_PIN();                                                    \
+        if (!DMAL) { if (AH) NT_ISSUE_X(OI, 1); else NT_ISSUE_Y(OI, 1); } NT_PIN();                                      \
         NT_MMA(0, 3, 0); NT_MMA(0, 3, 1); NT_MMA(1, 0, 0); NT_MMA(1, 0, 1); NT_PIN();                                   \
-        if (AH) NT_ISSUE_X(OI, 2); else NT_ISSUE_Y(OI, 2); NT_PIN();                                                    \
+        if (!DMAL) { if (AH) NT_ISSUE_X(OI, 2); else NT_ISSUE_Y(OI, 2); } NT_PIN();                                      \
         NT_MMA(1, 1, 0); NT_MMA(1, 1, 1); NT_MMA(1, 2, 0); NT_MMA(1, 2, 1); NT_PIN();                                   \
-        if (AH) { NT_ISSUE_X(OI, 3); NT_ADV_X(); } else { NT_ISSUE_Y(OI, 3); NT_ADV_Y(); } NT_PIN();                     \
+        if (!DMAL) { if (AH) { NT_ISSUE_X(OI, 3); NT_ADV_X(); } else { NT_ISSUE_Y(OI, 3); NT_ADV_Y(); } } NT_PIN();        \
         NT_MMA(1, 3, 0); NT_MMA(1, 3, 1);                                                                               \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
-        if (AH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                        \
+        if (AH) { if (DMAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
         bar();                                                                                                          \
     } while (0)
 
-    // ---- prologue: X(0), Y(0) into parity 0, X(1) into parity 1; stage 0 landed for everybody (Y(1) is the first even phase's issue)
-    NT_ISSUE_X(0, 0); NT_ISSUE_X(0, 1); NT_ISSUE_X(0, 2); NT_ISSUE_X(0, 3); NT_ADV_X();
-    NT_ISSUE_Y(0, 0); NT_ISSUE_Y(0, 1); NT_ISSUE_Y(0, 2); NT_ISSUE_Y(0, 3); NT_ADV_Y();
-    NT_ISSUE_X(16384, 0); NT_ISSUE_X(16384, 1); NT_ISSUE_X(16384, 2); NT_ISSUE_X(16384, 3); NT_ADV_X();
-    nt_wait_vm<4>();
+    if (DMAL) {
+        // ---- prologue: stage 0 (the first even phase issues stage 1)
+        NT_ISSUE_B(0, 0); NT_ISSUE_B(0, 1); NT_ISSUE_B(0, 2); NT_ISSUE_B(0, 3);
+        NT_ISSUE_A(0, 0); NT_ISSUE_A(0, 1); NT_ISSUE_A(0, 2); NT_ISSUE_A(0, 3);
+        NT_ADV_AB();
+        nt_wait_vm<0>();
+    } else {
+        // ---- prologue: X(0), Y(0) into parity 0, X(1) into parity 1; stage 0 landed for everybody (Y(1) is the first even phase's issue)
+        NT_ISSUE_X(0, 0); NT_ISSUE_X(0, 1); NT_ISSUE_X(0, 2); NT_ISSUE_X(0, 3); NT_ADV_X();
+        NT_ISSUE_Y(0, 0); NT_ISSUE_Y(0, 1); NT_ISSUE_Y(0, 2); NT_ISSUE_Y(0, 3); NT_ADV_Y();
+        NT_ISSUE_X(16384, 0); NT_ISSUE_X(16384, 1); NT_ISSUE_X(16384, 2); NT_ISSUE_X(16384, 3); NT_ADV_X();
+        nt_wait_vm<4>();
+    }
     bar();
     if (wr == 1) bar();
     for (int t = 0; t < T; t += 2) {
@@ -235,6 +270,9 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
 #undef NT_PIN
 #undef NT_ISSUE_X
 #undef NT_ISSUE_Y
+#undef NT_ISSUE_A
+#undef NT_ISSUE_B
+#undef NT_ADV_AB
 #undef NT_ADV_X
 #undef NT_ADV_Y
 
@@ -262,6 +300,24 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
 
 using namespace ar;
 
+static int g_nt_dmal = 0;        // 1: the DMA pieces at the end of the L part (ar_gemm_nt_config)
+// experiment knob (binding hygiene, tools/gpu/r05_gemm_nt_probe.py): variant 0 / 1 selects where the LDS-DMA pieces are issued; -1 keeps.
+extern "C" int ar_gemm_nt_config(int variant) {
+    if (variant == 0 || variant == 1) g_nt_dmal = variant;
+    return g_nt_dmal;
+}
+
+typedef void (*nt_fn)(NtArgs);
+template <bool GROUPED>
+static nt_fn nt_kernel() {
+    static PerDeviceOnce once;
+    if (once.first()) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_nt<GROUPED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+        (void)hipFuncSetAttribute((const void*)k_gemm_nt<GROUPED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+    }
+    return g_nt_dmal ? k_gemm_nt<GROUPED, true> : k_gemm_nt<GROUPED, false>;
+}
+
 static int nt_check(const void* A, const void* B, void* C, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc) {
     if (N % NT_B || K < 128 || K % 128 || (lda % 8) || (ldb % 8) || (ldc % 4)) return AR_ERR_UNSUPPORTED;
     if ((((uintptr_t)A | (uintptr_t)B) & 15) || ((uintptr_t)C & 7)) return AR_ERR_UNSUPPORTED;
@@ -281,9 +337,7 @@ extern "C" int ar_gemm_nt(const void* A, const void* B, void* C, int64_t M, int6
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.tiles_m = (int)((M + NT_B - 1) / NT_B); a.tiles_n = (int)(N / NT_B); a.order = 2;
     a.row_off = nullptr; a.b_off = nullptr; a.E = 0;
-    static PerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)k_gemm_nt<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
-    AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (k_gemm_nt<false>), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
+    AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (nt_kernel<false>()), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
     return launch_status();
 }
 
@@ -305,8 +359,6 @@ extern "C" int ar_gemm_nt_grouped(const void* A, const void* B, void* C, int64_t
     a.row_off = row_off; a.b_off = b_off; a.E = n_groups;
     int grid = a.tiles_m * a.tiles_n;
     grid = (grid + 7) / 8 * 8;                          // (a multiple of 8: the per-XCD runs of the tile order)
-    static PerDeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)k_gemm_nt<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
-    AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (k_gemm_nt<true>), grid, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
+    AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (nt_kernel<true>()), grid, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
     return launch_status();
 }

@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -850,11 +852,17 @@ class FusedMoEBlock(FusedLlamaBlock):
         per expert:                  D[r_e] = act_q[r_e] Wd_e^T
         y = x2 + sum_k w[t, k] D[pos[t, k]]          (ar_moe_combine: fp32 sum, one rounding, residual add fused, no atomics)
 
-    and the mirrored backward (weight gradients through the ragged-K MFMA GEMM where it pays; the routing-weight gradient is a
-    row dot product, sent back through the router's local graph).  The per-expert GEMM sizes come from the counts, so one host
-    synchronisation per iteration remains (as in the module path) and the iteration is not captured as a hipGraph."""
+    and the mirrored backward (the routing-weight gradient is a row dot product, sent back through the router's local graph).
+
+    Round 5: the per-expert GEMMs are GROUPED launches (`ops.gemm_nt_grouped` for the forward and -- through per-expert transposed
+    weight copies refreshed once per iteration -- the input gradients, `ops.gemm_dw_grouped` for the weight gradients): one launch per
+    projection whose row ranges are a device-side prefix sum of the routing counts, so the iteration has NO host read of the counts
+    when every expert shares one activation-quant plan (MXFP4, INT; NVFP4's static per-expert scales still need the counts for their
+    per-expert fake-quant launches), and its result does not depend on the library's choice of kernel per ragged row count (run-to-run
+    reproducible).  Shapes the grouped kernels do not take (widths that are not multiples of 256) keep the per-expert loop."""
 
     capturable = False
+    grouped = os.environ.get("AR_MOE_GROUPED", "1") != "0"     # (tests / A-B: False or AR_MOE_GROUPED=0 forces the per-expert loop of rounds 3-4)
 
     @classmethod
     def try_build(cls, block, arenas, input_others, amp_dtype=torch.bfloat16, sdpa_ctx=None, use_mfma_dw=True,
@@ -950,7 +958,35 @@ class FusedMoEBlock(FusedLlamaBlock):
         self.dWd = [d.weight_grad for g, u, d in trip]
         self.b_qkv = self.b_o = None
         self.set_tn_dx(tn_dx_gemm)
+        # grouped expert GEMMs: every expert's layers in ONE arena (offsets relative to its flat buffers), widths the kernels take
+        ea = trip[0][0].arena
+        self._grp = None
+        if (all(l.arena is ea for t in trip for l in t) and ea.w_dtype == torch.bfloat16 and H % 256 == 0 and Fd % 256 == 0):
+            dev = ea.Wq.device
+            self._grp = dict(arena=ea,
+                             off_gu=torch.tensor([g._off for g, u, d in trip], dtype=torch.int64, device=dev),
+                             off_d=torch.tensor([d._off for g, u, d in trip], dtype=torch.int64, device=dev),
+                             offT_gu=torch.arange(len(trip), dtype=torch.int64, device=dev) * (H * 2 * Fd),
+                             offT_d=torch.arange(len(trip), dtype=torch.int64, device=dev) * (Fd * H),
+                             WguT=None, WdT=None)
+        self._uniform_plans = all(pl == pl_gu_e[0] for pl in pl_gu_e) and all(pl == pl_d_e[0] for pl in pl_d_e)
         return self
+
+    def _use_grouped(self) -> bool:
+        return self.grouped and self._grp is not None
+
+    def _refresh_expert_transposes(self):
+        """W_e^T copies for the grouped input-gradient GEMMs (dX = dY W_e is an "NN" product; the NT kernel wants the reduction
+        dimension contiguous in both operands): [E, H, 2F] and [E, F, H], rewritten once per iteration from the fresh fake-quant weights
+        (16 transposes, ~1 ms of a ~90 ms Mixtral iteration)."""
+        g = self._grp
+        E, H, Fd = self.E, self.H, self.Fdim
+        if g["WguT"] is None:
+            g["WguT"] = torch.empty((E, H, 2 * Fd), dtype=self.dtype, device=g["arena"].Wq.device)
+            g["WdT"] = torch.empty((E, Fd, H), dtype=self.dtype, device=g["arena"].Wq.device)
+        for e in range(E):
+            ops.transpose16(self.Wgu[e], out=g["WguT"][e])
+            ops.transpose16(self.Wd[e], out=g["WdT"][e])
 
     def _dx_weights(self):
         """Only the o-projection keeps a transposed copy.  (Transposed copies of every expert's merged gate/up and down weights were
@@ -975,6 +1011,24 @@ class FusedMoEBlock(FusedLlamaBlock):
                 torch.mm(a[whole:], w, out=out[whole:])
                 return out
         return torch.mm(a, w, out=out)
+
+    @staticmethod
+    def _host_counts(r):
+        """the per-expert row counts on the host, read (once per iteration) only when a per-expert loop needs them"""
+        if r["counts"] is None:
+            ro = r["row_off"].tolist()
+            r["counts"] = [ro[i + 1] - ro[i] for i in range(len(ro) - 1)]
+        return r["counts"]
+
+    @staticmethod
+    def _dw_done(layers) -> bool:
+        """bookkeeping after a grouped weight-gradient launch wrote EVERY listed layer's gradient (zeros for an expert without rows)"""
+        for lyr in layers:
+            lyr._dw_accum[0] = True
+            post = getattr(lyr, "_post_dw", None)
+            if post is not None:
+                post()
+        return True
 
     @staticmethod
     def _rows_fq(t, plans, counts, raw, grad_of=None):
@@ -1011,14 +1065,19 @@ class FusedMoEBlock(FusedLlamaBlock):
             K = ri.shape[1]
             flat = ri.t().reshape(-1)                                   # index = slot * T + token (the module path's row order)
             order = torch.argsort(flat, stable=True)
-            counts = torch.bincount(flat, minlength=self.E).tolist()    # the one synchronisation of the iteration
+            # per-expert row counts WITHOUT a host read (torch.bincount reads its input's maximum on the host): a compare-and-sum
+            cnt = (flat.unsqueeze(1) == torch.arange(self.E, device=flat.device, dtype=flat.dtype)).sum(dim=0)
+            row_off = torch.zeros(self.E + 1, dtype=torch.int32, device=flat.device)
+            row_off[1:] = torch.cumsum(cnt, dim=0)
+            # the counts on the host only where something still needs them: the per-expert loop, or per-expert activation-quant plans
+            counts = None if (self._use_grouped() and self._uniform_plans) else cnt.tolist()
             tok = (order % T).contiguous()
             inv = torch.empty_like(order)
             inv[order] = torch.arange(order.numel(), device=order.device, dtype=order.dtype)
             pos = inv.view(K, T).t().contiguous()                       # [T, K]: row of token t's k-th routed copy
             w_tk = rw.detach().to(torch.float32).contiguous()           # [T, K]
             w_sorted = w_tk[tok, order // T].contiguous()               # [T K]
-        return dict(leaf=leaf, rw=rw, counts=counts, tok=tok, pos=pos, w_tk=w_tk, w_sorted=w_sorted)
+        return dict(leaf=leaf, rw=rw, counts=counts, row_off=row_off, tok=tok, pos=pos, w_tk=w_tk, w_sorted=w_sorted)
 
     def _forward_impl(self, x, others, ctx):
         from .wrapper import act_quant_fwd_raw
@@ -1031,19 +1090,22 @@ class FusedMoEBlock(FusedLlamaBlock):
         xs_q = self._rows_fq(xs, self.pl_gu_e, r["counts"], act_quant_fwd_raw)
         R = xs.shape[0]
         GU = torch.empty((R, 2 * self.Fdim), dtype=self.dtype, device=x.device)
-        start = 0
-        for e, cnt in enumerate(r["counts"]):
-            if cnt:
-                self._mm_rows(xs_q[start:start + cnt], self.Wgu[e].t(), GU[start:start + cnt])
-            start += cnt
+        grp = self._grp if self._use_grouped() else None
+        if grp is None or not ops.gemm_nt_grouped(xs_q, grp["arena"].Wq, GU, r["row_off"], grp["off_gu"], 2 * self.Fdim, H):
+            start = 0
+            for e, cnt in enumerate(self._host_counts(r)):
+                if cnt:
+                    self._mm_rows(xs_q[start:start + cnt], self.Wgu[e].t(), GU[start:start + cnt])
+                start += cnt
         act = ops.swiglu_fwd(GU, self.Fdim)
         act_q = self._rows_fq(act, self.pl_d_e, r["counts"], act_quant_fwd_raw)
         D = torch.empty((R, H), dtype=self.dtype, device=x.device)
-        start = 0
-        for e, cnt in enumerate(r["counts"]):
-            if cnt:
-                self._mm_rows(act_q[start:start + cnt], self.Wd[e].t(), D[start:start + cnt])
-            start += cnt
+        if grp is None or not ops.gemm_nt_grouped(act_q, grp["arena"].Wq, D, r["row_off"], grp["off_d"], H, self.Fdim):
+            start = 0
+            for e, cnt in enumerate(self._host_counts(r)):
+                if cnt:
+                    self._mm_rows(act_q[start:start + cnt], self.Wd[e].t(), D[start:start + cnt])
+                start += cnt
         y = ops.moe_combine(D, r["pos"], r["w_tk"], res=x2)
         if ctx is not None:
             saved.update(x2=x2, rstd2=rstd2, route=r, xs=xs, xs_q=xs_q, GU=GU, act=act, act_q=act_q, D=D)
@@ -1068,26 +1130,47 @@ class FusedMoEBlock(FusedLlamaBlock):
         del D
         act_q = s.pop("act_q")
         dact_q = torch.empty_like(act_q)
-        start = 0
-        for e, cnt in enumerate(counts):
-            if cnt:
-                rows = slice(start, start + cnt)
-                self._dw(dD[rows], act_q[rows], self.dWd[e], [self.trip[e][2]])
-                self._mm_rows(dD[rows], self.Wd[e], dact_q[rows])
-            start += cnt
+        grp = self._grp if self._use_grouped() else None
+        if grp is not None and any(l._dw_accum[0] for t in self.trip for l in t):
+            grp = None                       # accumulating micro-batches: the per-expert addmm_ path
+        if grp is not None:
+            self._refresh_expert_transposes()
+        d_layers = [t[2] for t in self.trip]
+        if not (grp is not None and ops.gemm_dw_grouped(dD, act_q, grp["arena"].dWq, r["row_off"], grp["off_d"], self.Fdim) and self._dw_done(d_layers)):
+            start = 0
+            for e, cnt in enumerate(self._host_counts(r)):
+                if cnt:
+                    rows = slice(start, start + cnt)
+                    self._dw(dD[rows], act_q[rows], self.dWd[e], [self.trip[e][2]])
+                start += cnt
+        if grp is None or not ops.gemm_nt_grouped(dD, grp["WdT"], dact_q, r["row_off"], grp["offT_d"], self.Fdim, self.H):
+            start = 0
+            for e, cnt in enumerate(self._host_counts(r)):
+                if cnt:
+                    rows = slice(start, start + cnt)
+                    self._mm_rows(dD[rows], self.Wd[e], dact_q[rows])
+                start += cnt
         del dD, act_q
         dact = self._rows_fq(dact_q, self.pl_d_e, counts, act_quant_bwd_raw, grad_of=s.pop("act"))
         dGU = ops.swiglu_bwd_(dact, s.pop("GU"), self.Fdim)
         del dact, dact_q
         xs_q = s.pop("xs_q")
         dxs_q = torch.empty_like(xs_q)
-        start = 0
-        for e, cnt in enumerate(counts):
-            if cnt:
-                rows = slice(start, start + cnt)
-                self._dw(dGU[rows], xs_q[rows], self.dWgu[e], [self.trip[e][0], self.trip[e][1]])
-                self._mm_rows(dGU[rows], self.Wgu[e], dxs_q[rows])
-            start += cnt
+        gu_layers = [l for t in self.trip for l in t[:2]]
+        if not (grp is not None and ops.gemm_dw_grouped(dGU, xs_q, grp["arena"].dWq, r["row_off"], grp["off_gu"], self.H) and self._dw_done(gu_layers)):
+            start = 0
+            for e, cnt in enumerate(self._host_counts(r)):
+                if cnt:
+                    rows = slice(start, start + cnt)
+                    self._dw(dGU[rows], xs_q[rows], self.dWgu[e], [self.trip[e][0], self.trip[e][1]])
+                start += cnt
+        if grp is None or not ops.gemm_nt_grouped(dGU, grp["WguT"], dxs_q, r["row_off"], grp["offT_gu"], self.H, 2 * self.Fdim):
+            start = 0
+            for e, cnt in enumerate(self._host_counts(r)):
+                if cnt:
+                    rows = slice(start, start + cnt)
+                    self._mm_rows(dGU[rows], self.Wgu[e], dxs_q[rows])
+                start += cnt
         del dGU, xs_q
         dxs = self._rows_fq(dxs_q, self.pl_gu_e, counts, act_quant_bwd_raw, grad_of=s.pop("xs"))
         (dh2_router,) = torch.autograd.grad(r["rw"], r["leaf"], drw.to(r["rw"].dtype))

@@ -28,32 +28,55 @@ def _is_fused_experts(m: nn.Module) -> bool:
 
 
 def _linear_loop_forward(self, hidden_states: torch.Tensor, top_k_index: torch.Tensor, top_k_weights: torch.Tensor):
-    """Same routing arithmetic as the fused implementation, one expert at a time through its nn.Linear children (which may be
-    tuning wrappers).  Experts that received no token are not called (their parameters get no gradient).
+    """The reference's `linear_loop_experts_forward` (auto_round/modeling/fused_moe/moe_experts_interface.py:173-289) op for op -- the
+    same tensors in the same order, so that a block unfused by THIS package computes, bit for bit, what the reference's unfused block
+    computes (round 5: the reference-free flow's targets and module-path trajectory at Mixtral-8x7B's real width are the reference's):
 
-    The (token, slot) pairs are grouped by expert with ONE stable sort and one host read of the per-expert counts; each expert's
-    rows keep the order `torch.where(one_hot(top_k_index).permute(2, 1, 0)[e])` would give them (slot-major, then token) -- the
-    reference's order -- so every GEMM sees the same rows in the same places, without a device->host synchronisation per expert."""
-    out = torch.zeros_like(hidden_states)
+        selected = hidden_states[token of every (token, slot) pair]         pairs in TOKEN-major order, S = tokens * top_k rows
+        per expert e, rows sample_idx = the pairs routed to e, ascending:   down_e(act(gate_e(x)) * up_e(x))  -> index_copy_ into [S, H]
+        out = (per-pair outputs * routing weights).view(tokens, top_k, H).sum(dim=1)
+
+    The row ORDER inside an expert's GEMMs matters: for ragged row counts the library picks kernels that split K per tile, so a row's
+    bits depend on the tile it lands in (rounds 3-4 grouped the pairs slot-major: same function, other bits).  One difference in how the
+    row sets are found: one stable sort + ONE host read of the per-expert counts instead of a `nonzero` (a device->host synchronisation)
+    per expert -- `order[start:start + cnt]` IS `nonzero(expert_ids == e)`.  Experts that received no token are not called (their
+    parameters get no gradient)."""
+    shape3 = None
+    if hidden_states.dim() == 3:
+        shape3 = hidden_states.shape
+        hidden_states = hidden_states.view(-1, shape3[-1])
+        top_k_index = top_k_index.view(-1, top_k_index.size(-1))
+        top_k_weights = top_k_weights.view(-1, top_k_weights.size(-1))
     T, K = top_k_index.shape
+    H = hidden_states.size(-1)
+    dev = hidden_states.device
+    token_idx = torch.arange(T, device=dev).unsqueeze(1).expand(-1, K).reshape(-1)
+    sample_weights = top_k_weights.reshape(-1).to(hidden_states.dtype)
+    expert_ids = top_k_index.reshape(-1)
+    selected = hidden_states[token_idx]
+    out_per_sample = torch.zeros_like(selected)
     with torch.no_grad():
-        flat = top_k_index.t().reshape(-1)                                  # index = slot * T + token
-        order = torch.argsort(flat, stable=True)
-        counts = torch.bincount(flat, minlength=self.num_experts).tolist()  # the one synchronisation
+        order = torch.argsort(expert_ids, stable=True)
+        counts = torch.bincount(expert_ids, minlength=self.num_experts).tolist()      # the one synchronisation
     start = 0
     for e, cnt in enumerate(counts):
         if cnt == 0 or e >= self.num_experts:
             start += cnt
             continue
-        sel = order[start:start + cnt]
+        sample_idx = order[start:start + cnt]
         start += cnt
-        pos, tok = sel // T, sel % T
         ex = getattr(self, str(e))
-        x = hidden_states[tok]
-        h = self.act_fn(ex.gate_proj(x)) * ex.up_proj(x)
-        h = ex.down_proj(h) * top_k_weights[tok, pos, None]
-        out.index_add_(0, tok, h.to(out.dtype))
-    return out
+        x = selected.index_select(0, sample_idx)
+        gate_out, up_out = ex.gate_proj(x), ex.up_proj(x)
+        if hasattr(self, "_apply_gate"):
+            gated = self._apply_gate(torch.cat([gate_out, up_out], dim=-1))
+        else:
+            gated = self.act_fn(gate_out) * up_out
+        y = ex.down_proj(gated)
+        out_per_sample.index_copy_(0, sample_idx, y.to(out_per_sample.dtype))
+    out_per_sample = out_per_sample * sample_weights.unsqueeze(-1)
+    out = out_per_sample.view(T, K, H).sum(dim=1)
+    return out.view(shape3) if shape3 is not None else out
 
 
 @torch.no_grad()

@@ -830,8 +830,90 @@ def gemm_dw_sk(dY2d: torch.Tensor, X2d: torch.Tensor, out: torch.Tensor, kcut: t
     return True
 
 
+def _same_device(name, *ts):
+    devs = set()
+    for t in ts:
+        if not t.is_cuda:
+            raise _lib.Mi355xLibraryError(f"{name}: the MI355X path only runs on a HIP device and has no CPU fallback")
+        devs.add(t.device.index)
+    if len(devs) != 1:
+        raise _lib.Mi355xLibraryError(f"{name}: tensors live on different HIP devices")
+    return devs.pop()
+
+
+def _nt_operands_ok(A, B, out) -> bool:
+    if A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
+        return False
+    return A.dim() == 2 and B.dim() == 2 and out.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1
+
+
+def gemm_nt(A: torch.Tensor, B: torch.Tensor, out: torch.Tensor) -> bool:
+    """out[M,N] = A[M,K] @ B[N,K]^T through the hand-written MFMA NT kernel (ar_gemm_nt: bf16, fp32 accumulate over K in ascending
+    order, one rounding) -- the forward of F.linear(x, weight_q) (auto_round/wrapper.py:528-556), or with B a transposed weight copy
+    its input gradient.  Operands may be row slices / column slices of wider row-major buffers (unit inner stride).  -> False when the
+    shape / alignment is outside what the kernel takes (N % 256, K % 128: the caller keeps the library GEMM); raises on a failed launch."""
+    if not _nt_operands_ok(A, B, out):
+        return False
+    M, K = A.shape
+    N = B.shape[0]
+    if B.shape[1] != K or tuple(out.shape) != (M, N):
+        raise ValueError("gemm_nt: shape mismatch")
+    dev = _same_device("gemm_nt", A, B, out)
+    with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
+        rc = load().ar_gemm_nt(A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, A.stride(0), B.stride(0), out.stride(0),
+                               torch.cuda.current_stream(dev).cuda_stream)
+    if rc == _lib.AR_ERR_UNSUPPORTED:
+        return False
+    check(rc, "ar_gemm_nt")
+    return True
+
+
+def gemm_nt_grouped(A: torch.Tensor, Bbase: torch.Tensor, out: torch.Tensor, row_off: torch.Tensor, b_off: torch.Tensor, N: int, ldb: int) -> bool:
+    """Grouped NT GEMM over the experts of a sparse-MoE projection (ar_gemm_nt_grouped): out[r] = A[r] @ B_e^T for the rows r of group e,
+    row_off int32 [E + 1] (prefix sums of the groups' row counts, ON THE DEVICE: no host read), B_e = the [N, K] matrix (leading
+    dimension ldb) that starts b_off[e] ELEMENTS into `Bbase` (int64 [E], device).  One launch, deterministic."""
+    if not Bbase.is_contiguous() or not _nt_operands_ok(A, Bbase.view(-1, 1), out):      # (Bbase: any contiguous buffer holding the matrices)
+        return False
+    M, K = A.shape
+    if tuple(out.shape) != (M, N):
+        raise ValueError("gemm_nt_grouped: shape mismatch")
+    E = int(b_off.numel())
+    if row_off.dtype != torch.int32 or b_off.dtype != torch.int64 or row_off.numel() != E + 1 or not row_off.is_contiguous() or not b_off.is_contiguous():
+        raise ValueError("gemm_nt_grouped: row_off must be int32 [E + 1] and b_off int64 [E], contiguous")
+    dev = _same_device("gemm_nt_grouped", A, Bbase, out, row_off, b_off)
+    with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
+        rc = load().ar_gemm_nt_grouped(A.data_ptr(), Bbase.data_ptr(), out.data_ptr(), M, N, K, A.stride(0), ldb, out.stride(0),
+                                       row_off.data_ptr(), b_off.data_ptr(), E, torch.cuda.current_stream(dev).cuda_stream)
+    if rc == _lib.AR_ERR_UNSUPPORTED:
+        return False
+    check(rc, "ar_gemm_nt_grouped")
+    return True
+
+
+def gemm_dw_grouped(dY2d: torch.Tensor, X2d: torch.Tensor, Wbase: torch.Tensor, row_off: torch.Tensor, w_off: torch.Tensor, ldw: int) -> bool:
+    """Grouped weight-gradient GEMM (ar_gemm_dw_grouped): dW_e[M,N] = dY2d[rows of group e]^T @ X2d[rows of group e], written to the
+    [M, N] matrix (leading dimension ldw) that starts w_off[e] ELEMENTS into `Wbase`; row_off int32 [E + 1] and w_off int64 [E] live on
+    the device.  A group without rows gets zeros.  One launch, deterministic."""
+    if dY2d.dtype != torch.bfloat16 or X2d.dtype != torch.bfloat16 or Wbase.dtype != torch.bfloat16:
+        return False
+    if dY2d.dim() != 2 or X2d.dim() != 2 or dY2d.stride(1) != 1 or X2d.stride(1) != 1 or dY2d.shape[0] != X2d.shape[0]:
+        return False
+    M, N = int(dY2d.shape[1]), int(X2d.shape[1])
+    E = int(w_off.numel())
+    if row_off.dtype != torch.int32 or w_off.dtype != torch.int64 or row_off.numel() != E + 1 or not row_off.is_contiguous() or not w_off.is_contiguous():
+        raise ValueError("gemm_dw_grouped: row_off must be int32 [E + 1] and w_off int64 [E], contiguous")
+    dev = _same_device("gemm_dw_grouped", dY2d, X2d, Wbase, row_off, w_off)
+    with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
+        rc = load().ar_gemm_dw_grouped(dY2d.data_ptr(), X2d.data_ptr(), Wbase.data_ptr(), M, N, dY2d.stride(0), X2d.stride(0), ldw,
+                                       row_off.data_ptr(), w_off.data_ptr(), E, torch.cuda.current_stream(dev).cuda_stream)
+    if rc == _lib.AR_ERR_UNSUPPORTED:
+        return False
+    check(rc, "ar_gemm_dw_grouped")
+    return True
+
+
 # ---- optional device-side timing of the hot kernels (ar_profile_*; bench.py and tools only) ----------------------------
-PROF_INT_FWD, PROF_INT_BWD, PROF_FP4_FWD, PROF_FP4_BWD, PROF_GEMM_DW, PROF_NORM, PROF_SWIGLU, PROF_ROPE = range(8)
+PROF_INT_FWD, PROF_INT_BWD, PROF_FP4_FWD, PROF_FP4_BWD, PROF_GEMM_DW, PROF_NORM, PROF_SWIGLU, PROF_ROPE, PROF_GEMM_NT = range(9)
 
 
 def profile_enable(on: bool = True) -> bool:

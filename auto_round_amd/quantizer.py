@@ -316,6 +316,23 @@ class SignRoundConfig:
 # ----------------------------------------------------------------------------------------------------------------------
 # the quantizer
 # ----------------------------------------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def _no_uninitialised_fill():
+    """Behind the reference's front door (and this package's, which mirrors it) torch runs in deterministic-algorithms mode, whose
+    default also FILLS every `torch.empty` with NaN (torch.utils.deterministic.fill_uninitialized_memory): a memset launch per scratch
+    buffer of every iteration.  Nothing here reads memory it did not write, so the fill is switched off for the tuning loop and put
+    back afterwards; the mode itself (which ops / library kernels run) is left exactly as the caller set it."""
+    det = getattr(torch.utils, "deterministic", None)
+    if det is None or not torch.are_deterministic_algorithms_enabled() or not getattr(det, "fill_uninitialized_memory", False):
+        yield
+        return
+    det.fill_uninitialized_memory = False
+    try:
+        yield
+    finally:
+        det.fill_uninitialized_memory = True
+
+
 class SignRoundQuantizer:
     """MI355X implementation of the reference's block quantizer contract (quantization/base.py:148-179):
     `quantize_block(...) -> best_params`; post-conditions identical to the reference (block unwrapped in place,
@@ -402,7 +419,7 @@ class SignRoundQuantizer:
                        **kwargs) -> dict:
         # the whole block is tuned with the quantizer's device current: torch's ops take the device from their tensors, the
         # C-ABI launches take the stream of their tensors' device (ops._launch) -- both agree for any `device=`
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), _no_uninitialised_fill():
             return self._quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs)
 
     def _quantize_block(self, block, fp_inputs, input_others, fp_outputs, q_inputs=None, block_ctx=None, input_ids=None,

@@ -394,6 +394,9 @@ int ar_gemm_nt(const void* A, const void* B, void* C, int64_t M, int64_t N, int6
  * M / 256 + n_groups row tiles (every group may end in a partial tile); workgroups past the last real tile exit.  Deterministic. */
 int ar_gemm_nt_grouped(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                        const int32_t* row_off, const int64_t* b_off, int n_groups, ar_stream_t stream);
+/* experiment knob of the two entry points above for tools/gpu/r05_gemm_nt_probe.py (binding hygiene): variant 0 = LDS-DMA pieces
+ * issued between the MFMAs, 1 = at the end of the fragment-read part of every second phase; -1 keeps.  Returns the variant in use. */
+int ar_gemm_nt_config(int variant);
 /* experiment knobs of the kernel above for tools/gemm_dw_probe.py (binding hygiene; -1 keeps a value): sem = lane->piece rule
  * of the transposing LDS read (1 | 2), order = tile order (0 identity, 1 XCD chunks, 2 XCD 2x8 patches).  Returns sem*10+order. */
 int ar_gemm_dw_config(int sem, int order);

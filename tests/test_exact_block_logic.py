@@ -46,6 +46,7 @@ def _exact_over(blk, cfg, pe):
     eb.plan = {k: False for k in KERNEL_OPTS + GEMM_OPTS}
     eb.plan["swiglu_contract"] = True
     eb._tnx = {}
+    eb._last_sk = {}
     # merged gradient buffers as the arena lays them out: [q; k; v] and [gate; up] contiguous, the per-layer gradients are views
     eb.dWqkv = torch.zeros(sum(mods[n].weight.shape[0] for n in "qkv"), cfg.hidden_size, dtype=torch.bfloat16)
     eb.dWgu = torch.zeros(2 * cfg.intermediate_size, cfg.hidden_size, dtype=torch.bfloat16)
@@ -167,12 +168,19 @@ def test_streamk_plan_value_routes_the_weight_gradient_through_the_found_structu
     eb.plan["dw_gu"] = exact_block.STREAMK
     asked = []
     monkeypatch.setattr(streamk, "find_merged_on_device", lambda a, b, rows: asked.append(list(rows)) or "merged-table")
+    monkeypatch.setattr(streamk, "_found", {(None, M, N, T): (st, "kcut-table")})
     for n in ("g", "u"):
         layers[n]._dw_accum[0] = False
     eb._dw_x("gu", dgu, X)
     assert asked == [[F, F]] and calls[-1] == "merged-table" and torch.equal(eb.dWgu, torch.mm(dgu.t(), X))
-    monkeypatch.setattr(streamk, "_merged", {(None, (F, F), N, T): "merged-table"})
-    monkeypatch.setattr(streamk, "_found", {(None, M, N, T): (st, "kcut-table")})
-    assert eb._streamk_found("gu") == [st, st]
-    monkeypatch.setattr(streamk, "_merged", {})
+    assert eb._streamk_found("gu") == [st, st]                    # what THIS call launched: each layer's own structure at this (M, N, K)
+    # a structure cached for another K is not this call's: with no table for the call's own K the library runs, and the proof is told so
+    # (`_streamk_found` used to scan the cache for any K with the same (M, N))
+    monkeypatch.setattr(streamk, "_found", {(None, M, N, T + 128): (st, "kcut-table")})
+    monkeypatch.setattr(streamk, "find_merged_on_device", lambda a, b, rows: None)
+    for n in ("g", "u"):
+        layers[n]._dw_accum[0] = False
+    n_calls = len(calls)
+    eb._dw_x("gu", dgu, X)
+    assert len(calls) == n_calls and torch.equal(eb.dWgu, torch.mm(dgu.t(), X))
     assert eb._streamk_found("gu") is None

@@ -271,14 +271,14 @@ def test_module_path_reproduces_reference_run_1_of_the_two_run_fixtures(path, re
     record_property("ref_vs_ref_prefix_identical_weights", m["ref_vs_ref"]["prefix_identical_weights"])
     if not r["bit_identical"]:
         warnings.warn(f"[t3s] RETRY {name} module path: the first run parted from reference run 1 at iteration {r['first_divergence_iter']} "
-                      f"({r['prefix_identical_weights']:.4f} identical over the fixture's prefixes); repeating once")
+                      f"({r['prefix_identical_codes']:.4f} identical codes over the fixture's prefixes); repeating once")
         r = fx.check_against_stat_fixture(path)
     if r["bit_identical"]:
         assert r["first_divergence_iter"] is None and abs(r["best_loss_ratio"] - 1.0) < 1e-5, _full(r)
         return
     warnings.warn(f"[t3s] STATISTICAL {name} module path: two runs parted from reference run 1 (library kernels not run-to-run "
-                  f"reproducible at this shape); held to the floor instead: {r['prefix_identical_weights']:.4f} identical")
-    assert r["prefix_identical_weights"] >= MODULE_FLOOR[m["arch"]], _full(r)
+                  f"reproducible at this shape); held to the floor instead: {r['prefix_identical_codes']:.4f} identical codes")
+    assert r["prefix_identical_codes"] >= MODULE_FLOOR[m["arch"]], _full(r)
     assert abs(r["best_loss_ratio"] - 1.0) <= 0.01, _full(r)
 
 
@@ -291,5 +291,47 @@ def test_fused_moe_path_stays_on_the_reference_trajectory_level_at_real_width(pa
     r = fx.check_against_stat_fixture(path, fused=True)
     assert r["fused_block"] and r["inputs_identical"] and r["targets_identical"], r
     assert abs(r["init_loss"] - r["init_loss_ref"]) <= 5e-3 * r["init_loss_ref"], _full(r)
-    assert r["prefix_identical_weights"] >= FUSED_FLOOR[os.path.basename(path)[4:-4]], _full(r)
+    assert r["prefix_identical_codes"] >= FUSED_FLOOR[os.path.basename(path)[4:-4]], _full(r)
     assert abs(r["best_loss_ratio"] - 1.0) <= 0.02, _full(r)
+
+
+def test_a_wrong_stream_k_table_is_rejected_by_the_proof_loudly_and_the_run_stays_bit_identical(monkeypatch):
+    """bit identity of the headline rests on a reverse-engineered map of the library's stream-K summation structure
+    (auto_round_amd/streamk.py).  If that map is ever wrong for the installed library -- simulated here by corrupting every cut table
+    `find_on_device` hands out -- the plan proof must notice (the gradients differ from the module path's), drop the option WITH A
+    WARNING, and the 200-iteration result must still hash to the reference's digest on the library's own weight-gradient GEMMs."""
+    import warnings
+
+    import torch
+
+    from auto_round_amd import streamk
+    from auto_round_amd.exact_block import STREAMK
+    from auto_round_amd.testing import t3_fixture as fx
+
+    same_stack, why = _digest_stack()
+    if not same_stack:
+        pytest.skip(f"bit identity is only claimed on the digest's own stack ({why})")
+    real = streamk.find_on_device
+    streamk._found.clear()
+    streamk._merged.clear()
+
+    def corrupted(dY2d, X2d, lib_out=None):
+        got = real(dY2d, X2d, lib_out)
+        if got is None or got[0] is None:
+            return got
+        st, kc = got
+        bad = torch.where(kc > 0, torch.clamp(kc + 32, max=int(dY2d.shape[0]) - 32), kc)      # every cut one k-iteration late
+        return st, bad
+
+    monkeypatch.setattr(streamk, "find_on_device", corrupted)
+    try:
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            r = fx.check_against_digest(exact=True)
+    finally:
+        streamk._found.clear()
+        streamk._merged.clear()
+    plan = r["exact_plan"] or {}
+    assert r["exact_block"] and plan.get("dw_d") != STREAMK and plan.get("dw_gu") != STREAMK, plan      # the corrupted structure was not accepted
+    assert any("not bit-equal to the module path" in str(w.message) and "dw_" in str(w.message) for w in caught), [str(w.message)[:200] for w in caught]
+    assert r["bit_identical"] and r["first_divergence_iter"] is None, _full(r)

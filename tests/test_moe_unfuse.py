@@ -81,8 +81,9 @@ def test_unfusing_equals_the_reference_preparation():
 
 def test_expert_grouping_keeps_the_reference_row_order():
     """The loop groups (token, slot) pairs with one stable sort; every expert must see its rows in the order the reference's
-    `torch.where(one_hot(top_k_index).permute(2, 1, 0)[e])` yields (slot-major, then token), empty experts included -- the GEMM
-    row order is part of bit-for-bit parity.  Checked through the forward itself with recording experts."""
+    `nonzero(expert_ids == e)` over the token-major pair list yields (moe_experts_interface.py:224-233), empty experts included -- the
+    GEMM row order is part of bit-for-bit parity (rounds 3-4 used the slot-major order of transformers' own one_hot loop: same
+    function, other bits at ragged row counts).  Checked through the forward itself with recording experts."""
     from auto_round_amd.moe_unfuse import _linear_loop_forward
 
     class Rec(torch.nn.Module):
@@ -111,13 +112,61 @@ def test_expert_grouping_keeps_the_reference_row_order():
         hidden = torch.zeros(T, 4)
         hidden[:, 0] = torch.arange(T, dtype=torch.float32)
         _linear_loop_forward(holder, hidden, idx, torch.ones(T, K))
-        mask = torch.nn.functional.one_hot(idx, num_classes=E).permute(2, 1, 0)
+        # the reference's row sets (moe_experts_interface.py:224-233): pairs in token-major order, `nonzero(expert_ids == e)` ascending
+        token_idx = torch.arange(T).unsqueeze(1).expand(-1, K).reshape(-1)
+        expert_ids = idx.reshape(-1)
         for e in range(E):
-            pos, tok = torch.where(mask[e])
-            if tok.numel() == 0:
+            sample_idx = torch.nonzero(expert_ids == e, as_tuple=False).squeeze(-1)
+            if sample_idx.numel() == 0:
                 assert e not in log                              # not called
             else:
-                assert torch.equal(log[e], tok.float()), (trial, e)
+                assert torch.equal(log[e], token_idx[sample_idx].float()), (trial, e)
+
+
+def test_unfused_forward_is_the_references_linear_loop_bit_for_bit_with_gradients():
+    """Live against /root/reference (skipped where the tree is absent): this package's `_linear_loop_forward` and the reference's
+    `linear_loop_experts_forward` on the same experts, routing and inputs -- outputs, input gradients and every expert weight gradient
+    identical bits (same ops in the same order: on the GPU the library then sees the same GEMM operands row for row)."""
+    import pytest
+
+    from ref_tree import import_reference, reference_root
+
+    if reference_root() is None:
+        pytest.skip("reference tree not present")
+    import_reference()
+    from auto_round.modeling.fused_moe.moe_experts_interface import linear_loop_experts_forward
+
+    from auto_round_amd.moe_unfuse import ExpertContainer, _linear_loop_forward
+
+    g = torch.Generator().manual_seed(11)
+    T, K, E, H, F = 37, 2, 5, 16, 24
+
+    def build():
+        torch.manual_seed(5)
+        holder = torch.nn.Module()
+        holder.num_experts, holder.act_fn = E, torch.nn.SiLU()
+        for e in range(E):
+            c = ExpertContainer()
+            c.gate_proj, c.up_proj, c.down_proj = torch.nn.Linear(H, F, bias=False), torch.nn.Linear(H, F, bias=False), torch.nn.Linear(F, H, bias=False)
+            holder.add_module(str(e), c.to(torch.bfloat16))
+        return holder
+
+    idx = torch.stack([torch.randperm(E, generator=g)[:K] for _ in range(T)])
+    idx[idx == 3] = 1                                            # expert 3 stays empty
+    w = torch.rand(T, K, generator=g).to(torch.bfloat16)
+    x0 = torch.randn(T, H, generator=g).to(torch.bfloat16)
+    outs = []
+    for fn in (_linear_loop_forward, linear_loop_experts_forward):
+        m = build()
+        x = x0.clone().requires_grad_(True)
+        wv = w.clone().requires_grad_(True)
+        y = fn(m, x, idx, wv)
+        y.backward(torch.ones_like(y) * 0.37)
+        outs.append((y.detach(), x.grad, wv.grad, [p.grad for p in m.parameters()]))
+    (y1, gx1, gw1, gp1), (y2, gx2, gw2, gp2) = outs
+    eq = lambda a, b: (a is None and b is None) or torch.equal(a.view(torch.int16), b.view(torch.int16))  # noqa: E731
+    assert eq(y1, y2) and eq(gx1, gx2) and eq(gw1, gw2)
+    assert len(gp1) == len(gp2) and all(eq(a, b) for a, b in zip(gp1, gp2))
 
 
 def test_the_references_linear_loop_experts_are_recognised_like_this_packages_own():

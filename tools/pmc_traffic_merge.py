@@ -7,8 +7,22 @@ fixed order (REP plain, REP with snapshot, REP with next forward) and this scrip
 
     python tools/pmc_traffic_merge.py rows_FETCH_SIZE.csv rows_WRITE_SIZE.csv > profiles/pmc_traffic.json"""
 import csv
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCES = ("auto_round_amd/csrc/ar_int.hip", "auto_round_amd/csrc/ar_common.hpp")      # what K1 / K2 are compiled from
+
+
+def sources_sha256():
+    """bench.py's `read_traffic` reports the counters only while the kernels' sources are the ones that were profiled"""
+    h = hashlib.sha256()
+    for rel in SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 N, G, REP = 218103808, 1703936, 4
 
@@ -48,7 +62,8 @@ def main():
         calib = {"kernel": cp[0][:80], "FETCH_SIZE_KiB": mean(f[cp[0]][:2]), "WRITE_SIZE_KiB": mean(w.get(cp[0], [0.0])[:2]), "bytes_copied": 2 * N}
     alg = {"k_int_fwd": 8 * N + 12 * G, "k_int_bwd": 12 * N + 8 * G, "k_int_bwd_with_snapshot": 16 * N + 16 * G,
            "k_int_bwd_with_next_fwd": 14 * N + 8 * G}
-    out = {"_note": "HBM bytes per launch at the Llama-3-8B block size (218,103,808 weights, 1,703,936 groups of 128), round 3 kernels: "
+    out = {"round": int(sys.argv[3]) if len(sys.argv) > 3 else None, "sources": list(SOURCES), "sources_sha256": sources_sha256(),
+           "_note": "HBM bytes per launch at the Llama-3-8B block size (218,103,808 weights, 1,703,936 groups of 128), this round's kernels: "
                     "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes over tools/pmc_traffic_probe.py, "
                     "per-dispatch rows by tools/rocprof_summary.py --pmc-rows, merged by tools/pmc_traffic_merge.py. traffic = "
                     "(2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE reports half of a wide coalesced read stream; see the calibration copy).",
