@@ -77,6 +77,7 @@ SIGNATURES = {
     "ar_gemm_nt": (c_int, [P, P, P, L, L, L, L, L, L, P]),
     "ar_gemm_nt_grouped": (c_int, [P, P, P, L, L, L, L, L, L, P, P, I, P]),
     "ar_gemm_nt_config": (c_int, [I]),
+    "ar_gemm_nt_trace": (c_int, [P, P, P, L, L, L, L, L, L, P, I, P]),
     "ar_gemm_dw_ex": (c_int, [P, P, P, L, L, L, L, L, L, I, P, L, I, P]),
     "ar_gemm_dw_sk": (c_int, [P, P, P, L, L, L, L, L, L, P, L, P, P]),
     "ar_gemm_dw_workspace_bytes": (c_int64, [L, L, L]),

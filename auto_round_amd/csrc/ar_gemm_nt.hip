@@ -51,6 +51,8 @@ struct NtArgs {
     const int32_t* row_off;   // grouped: [E + 1] prefix sums of the groups' row counts (device memory)
     const int64_t* b_off;     // grouped: [E] element offsets (device memory)
     int E;
+    unsigned long long* trace;   // TRACE builds: [workgroup][wave][6] cycle sums (s_memtime): L part, barrier after L, M part, barrier after M,
+                                 // whole loop, phases
 };
 
 template <int N>
@@ -63,7 +65,10 @@ __device__ __forceinline__ void nt_wait_vm() {
 // even phase 2 tau, after the fragment reads returned: the buffer is the one stage tau-1 lived in, whose last reads (L(2 tau - 1) of both
 // groups) are behind the barrier this wave passed to enter L(2 tau); `vmcnt(4)` at the end of L(2 tau + 1) retires the B pieces (read by
 // both groups from L(2 tau + 2) on), `vmcnt(0)` at the end of M(2 tau + 1) the A pieces (read by the issuing group alone).
-template <bool GROUPED, bool DMAL>
+// TRACE (ar_gemm_nt_trace, tools only): every wave sums, over all its phases, the shader cycles (s_memtime) it spends in the four segments
+// of a phase -- fragment reads until they have returned; parked at the barrier that ends the L part; the 16 MFMAs (+ DMA issues) until
+// the last one is issued; parked at the barrier that ends the M part -- the per-phase cycle table of DESIGN.md section 3.
+template <bool GROUPED, bool DMAL, bool TRACE = false>
 __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -204,6 +209,17 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     };
     u32x4_t fa[2][4], fb[2][2];
+    unsigned long long tr_acc[4] = {0, 0, 0, 0}, tr_last = 0, tr_begin = 0;
+#define NT_TRACE(I)                                                                                                     \
+    do {                                                                                                                \
+        if (TRACE) {                                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            const unsigned long long now_ = __builtin_readcyclecounter();                                               \
+            tr_acc[I] += now_ - tr_last;                                                                                \
+            tr_last = now_;                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+        }                                                                                                               \
+    } while (0)
 #define NT_MMA(U, MI, NI)                                                                                               \
     acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nt_bf16x8_t, fb[U][NI]),                   \
                                                           __builtin_bit_cast(nt_bf16x8_t, fa[U][MI]), acc[MI][NI], 0, 0, 0)
@@ -226,7 +242,9 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
             NT_ISSUE_A(16384 - O, 0); NT_ISSUE_A(16384 - O, 1); NT_ISSUE_A(16384 - O, 2); NT_ISSUE_A(16384 - O, 3);       \
             NT_ADV_AB();                                                                                                \
         }                                                                                                               \
+        NT_TRACE(0);                                                                                                    \
         bar();                                                                                                          \
+        NT_TRACE(1);                                                                                                    \
         __builtin_amdgcn_s_setprio(1);                                                                                  \
         NT_MMA(0, 0, 0); NT_MMA(0, 0, 1); NT_PIN(); if (!DMAL) { if (AH) NT_ISSUE_X(OI, 0); else NT_ISSUE_Y(OI, 0); } NT_PIN(); \
         NT_MMA(0, 1, 0); NT_MMA(0, 1, 1); NT_MMA(0, 2, 0); NT_MMA(0, 2, 1); NT_PIN();                                   \
@@ -238,7 +256,9 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
         NT_MMA(1, 3, 0); NT_MMA(1, 3, 1);                                                                               \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
         if (AH) { if (DMAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+        NT_TRACE(2);                                                                                                    \
         bar();                                                                                                          \
+        NT_TRACE(3);                                                                                                    \
     } while (0)
 
     if (DMAL) {
@@ -256,11 +276,17 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
     }
     bar();
     if (wr == 1) bar();
+    if (TRACE) { tr_begin = tr_last = __builtin_readcyclecounter(); }
     for (int t = 0; t < T; t += 2) {
         NT_PHASE(0);
         NT_PHASE(1);
         NT_PHASE(2);
         NT_PHASE(3);
+    }
+    if (TRACE && a.trace && lane == 0) {
+        unsigned long long* o = a.trace + ((size_t)blockIdx.x * 8 + wave) * 6;
+        o[0] = tr_acc[0]; o[1] = tr_acc[1]; o[2] = tr_acc[2]; o[3] = tr_acc[3];
+        o[4] = tr_last - tr_begin; o[5] = (unsigned long long)(2 * T);
     }
     if (wr == 0) bar();
     nt_wait_vm<0>();          // no LDS-DMA may outlive the workgroup's LDS allocation
@@ -273,6 +299,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
 #undef NT_ISSUE_A
 #undef NT_ISSUE_B
 #undef NT_ADV_AB
+#undef NT_TRACE
 #undef NT_ADV_X
 #undef NT_ADV_Y
 
@@ -336,7 +363,7 @@ extern "C" int ar_gemm_nt(const void* A, const void* B, void* C, int64_t M, int6
     a.A = (const uint16_t*)A; a.B = (const uint16_t*)B; a.C = (uint16_t*)C;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.tiles_m = (int)((M + NT_B - 1) / NT_B); a.tiles_n = (int)(N / NT_B); a.order = 2;
-    a.row_off = nullptr; a.b_off = nullptr; a.E = 0;
+    a.row_off = nullptr; a.b_off = nullptr; a.E = 0; a.trace = nullptr;
     AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (nt_kernel<false>()), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
     return launch_status();
 }
@@ -356,9 +383,32 @@ extern "C" int ar_gemm_nt_grouped(const void* A, const void* B, void* C, int64_t
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.tiles_n = (int)(N / NT_B); a.order = 1;
     a.tiles_m = (int)(M / NT_B) + n_groups;             // worst case: every group ends with a partial tile
-    a.row_off = row_off; a.b_off = b_off; a.E = n_groups;
+    a.row_off = row_off; a.b_off = b_off; a.E = n_groups; a.trace = nullptr;
     int grid = a.tiles_m * a.tiles_n;
     grid = (grid + 7) / 8 * 8;                          // (a multiple of 8: the per-XCD runs of the tile order)
     AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (nt_kernel<true>()), grid, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+// The dense kernel with s_memtime bookkeeping per phase (tools/gpu/r05_gemm_nt_trace.py -> DESIGN.md's per-phase cycle table): trace gets
+// [tiles][8 waves][6] uint64 -- cycles in the fragment-read part, parked at the barrier after it, in the MFMA part, parked at the barrier
+// after it, the whole K loop, the number of phases.  variant as ar_gemm_nt_config.  Costs ~10 % of the kernel's speed; C is still written.
+extern "C" int ar_gemm_nt_trace(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                unsigned long long* trace, int variant, ar_stream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !trace) return AR_ERR_UNSUPPORTED;
+    const int rc = nt_check(A, B, C, N, K, lda, ldb, ldc);
+    if (rc != AR_OK) return rc;
+    NtArgs a;
+    a.A = (const uint16_t*)A; a.B = (const uint16_t*)B; a.C = (uint16_t*)C;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.tiles_m = (int)((M + NT_B - 1) / NT_B); a.tiles_n = (int)(N / NT_B); a.order = 2;
+    a.row_off = nullptr; a.b_off = nullptr; a.E = 0; a.trace = trace;
+    static PerDeviceOnce once;
+    if (once.first()) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_nt<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+        (void)hipFuncSetAttribute((const void*)k_gemm_nt<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+    }
+    if (variant) hipLaunchKernelGGL((k_gemm_nt<false, true, true>), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_gemm_nt<false, false, true>), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
     return launch_status();
 }

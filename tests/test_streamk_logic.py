@@ -1,5 +1,5 @@
 """Host logic of the stream-K summation structure (auto_round_amd/streamk.py) against the map measured on the library
-(tests/golden/streamk_llama8b_dw_map.json, made by tools/gpu/r04_dw_streamk_probe.py on an MI355X)."""
+(tests/golden/streamk_llama8b_dw_map.json, made by tools/gpu/r04_dw_streamk_probe.py on an MI355X in round 4; the script is kept)."""
 import json
 import os
 
