@@ -51,8 +51,8 @@ struct NtArgs {
     const int32_t* row_off;   // grouped: [E + 1] prefix sums of the groups' row counts (device memory)
     const int64_t* b_off;     // grouped: [E] element offsets (device memory)
     int E;
-    unsigned long long* trace;   // TRACE builds: [workgroup][wave][6] cycle sums (s_memtime): L part, barrier after L, M part, barrier after M,
-                                 // whole loop, phases
+    unsigned long long* trace;   // TRACE builds: [workgroup][wave][8] cycle sums (s_memtime): L part, barrier after L, M part, barrier after M,
+                                 // whole loop, phases, the whole loop in 100 MHz ticks (s_memrealtime), 0
 };
 
 template <int N>
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     };
     u32x4_t fa[2][4], fb[2][2];
-    unsigned long long tr_acc[4] = {0, 0, 0, 0}, tr_last = 0, tr_begin = 0;
+    unsigned long long tr_acc[4] = {0, 0, 0, 0}, tr_last = 0, tr_begin = 0, tr_wall = 0;
 #define NT_TRACE(I)                                                                                                     \
     do {                                                                                                                \
         if (TRACE) {                                                                                                    \
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
     }
     bar();
     if (wr == 1) bar();
-    if (TRACE) { tr_begin = tr_last = __builtin_readcyclecounter(); }
+    if (TRACE) { tr_wall = __builtin_amdgcn_s_memrealtime(); tr_begin = tr_last = __builtin_readcyclecounter(); }
     for (int t = 0; t < T; t += 2) {
         NT_PHASE(0);
         NT_PHASE(1);
@@ -284,9 +284,11 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
         NT_PHASE(3);
     }
     if (TRACE && a.trace && lane == 0) {
-        unsigned long long* o = a.trace + ((size_t)blockIdx.x * 8 + wave) * 6;
+        unsigned long long* o = a.trace + ((size_t)blockIdx.x * 8 + wave) * 8;
         o[0] = tr_acc[0]; o[1] = tr_acc[1]; o[2] = tr_acc[2]; o[3] = tr_acc[3];
         o[4] = tr_last - tr_begin; o[5] = (unsigned long long)(2 * T);
+        o[6] = __builtin_amdgcn_s_memrealtime() - tr_wall;        // the same loop on the constant 100 MHz counter: cycles / this = the shader clock
+        o[7] = 0;
     }
     if (wr == 0) bar();
     nt_wait_vm<0>();          // no LDS-DMA may outlive the workgroup's LDS allocation
@@ -323,6 +325,218 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
     }
 }
 
+
+// ---- nt2: one wave per SIMD, 128 x 128 per wave (round 5) -------------------------------------------------------------------
+// The per-phase cycle table of k_gemm_nt (profiles/r05_gemm_nt_phase_cycles.json) says the eight-wave form issues MFMAs 85 % of its
+// cycles and the chip clocks it at ~1.55 GHz: it is bound by POWER, not by issue slots, and the library's forward kernel (1.5-1.6 PF)
+// must be spending less energy per MFMA.  The obvious candidate is operand traffic: a 128 x 64 wave tile reads 6 KB of LDS per 8 MFMAs,
+// a 128 x 128 tile 8 KB per 16.  nt2 is that shape on the same LDS image, DMA mapping and swizzle as k_gemm_nt:
+//   * 4 waves (2 x 2), acc[4][4] = 256 accumulator registers, one wave per SIMD (512-register budget);
+//   * no wave has a partner to hide its fragment reads: the reads of k16 unit u+1 and the LDS-DMA pieces are interleaved BETWEEN the
+//     16 MFMAs of unit u (two fragment register sets; an in-order wave hides ~5 single-issue instructions per 32-cycle MFMA);
+//   * one barrier per 64-deep stage, placed BEFORE the last unit's MFMAs: at that point every wave has waited for its own pieces of
+//     stage t+1 (vmcnt(0): nothing of stage t+2 has been issued yet) and has finished reading stage t (its unit-3 fragments are in
+//     registers), so behind the barrier stage t+1 may be read and stage t's buffer may be refilled with stage t+2.  Pieces of stage
+//     t+2 are issued in unit 3 of stage t (6) and units 0 / 1 of stage t+1 (5 + 5); unit 2 is their landing slack.
+template <bool GROUPED>
+__global__ __launch_bounds__(256, 1) void k_gemm_nt2(NtArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    int64_t m0;
+    int n0, rows_valid;
+    const uint16_t* Bp = a.B;
+    if (GROUPED) {
+        const int nwg = gridDim.x;
+        int id = blockIdx.x;
+        if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
+        const int bw = (a.tiles_n % 8 == 0) ? 8 : a.tiles_n;
+        const int per_band = a.tiles_m * bw;
+        const int band = id / per_band, rem = id - band * per_band;
+        const int gmt = rem / bw, tn = band * bw + (rem - gmt * bw);
+        if (tn >= a.tiles_n) return;
+        int e = -1, base = 0, r0 = 0, r1 = 0;
+        for (int i = 0; i < a.E; ++i) {
+            const int s0 = a.row_off[i], s1 = a.row_off[i + 1];
+            const int mt = (s1 - s0 + NT_B - 1) / NT_B;
+            if (e < 0 && gmt < base + mt) { e = i; r0 = s0 + (gmt - base) * NT_B; r1 = s1; }
+            base += mt;
+        }
+        if (e < 0) return;
+        m0 = r0;
+        rows_valid = (r1 - r0) < NT_B ? (r1 - r0) : NT_B;
+        n0 = tn * NT_B;
+        Bp = a.B + a.b_off[e];
+    } else {
+        const int nwg = a.tiles_m * a.tiles_n;
+        const int bid = blockIdx.x;
+        int tm, tn;
+        if (a.order == 2 && (a.tiles_m % 4 == 0) && (a.tiles_n % 8 == 0) && (nwg % 256 == 0)) {
+            const int x = bid & 7, s = bid >> 3, pi = s >> 5, w = s & 31;
+            const int P = pi * 8 + x, pn = a.tiles_n >> 3;
+            tm = (P / pn) * 4 + (w >> 3);
+            tn = (P % pn) * 8 + (w & 7);
+        } else {
+            int id = bid;
+            if (a.order >= 1 && nwg % 8 == 0) id = (bid & 7) * (nwg >> 3) + (bid >> 3);
+            tm = id / a.tiles_n;
+            tn = id % a.tiles_n;
+        }
+        m0 = (int64_t)tm * NT_B;
+        n0 = tn * NT_B;
+        const int64_t left = (int64_t)a.M - m0;
+        rows_valid = left < NT_B ? (int)left : NT_B;
+    }
+    const int T = a.K / NT_K;
+
+    // ---- DMA: wave w stages rows [64 w, 64 w + 64) of the A tile and of the B tile: 8 pieces each, piece j = rows 64 w + 8 j + (lane >> 3)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    uint32_t voffA[8], voffB[8];
+    {
+        const int pc = lane & 7;
+        const int64_t last = (int64_t)a.M - 1 - m0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lc = pc ^ ((4 * j + (lane >> 4)) & 7);
+            const int row = wave * 64 + 8 * j + (lane >> 3);
+            int64_t ra = row;
+            if (ra > last) ra = last;
+            voffA[j] = (uint32_t)(ra * a.lda * 2 + lc * 16);
+            voffB[j] = (uint32_t)((int64_t)row * a.ldb * 2 + lc * 16);
+        }
+    }
+    const uint8_t* gA = reinterpret_cast<const uint8_t*>(a.A + m0 * a.lda);
+    const uint8_t* gB = reinterpret_cast<const uint8_t*>(Bp + (int64_t)n0 * a.ldb);
+    // rows 64 w .. 64 w + 63 live in half w >> 1 at within-half row (w & 1) * 64
+    const uint32_t dstA = lds0 + (wave >> 1) * 32768 + (wave & 1) * 64 * 128;
+    const uint32_t dstB = dstA + 65536;
+    int sdma = 0;                                    // stage the DMA pointers stand on
+
+    // ---- fragment read addresses: unit u of a stage = logical chunks 2u, 2u + 1
+    uint32_t adA[4], adB[4];
+    {
+        const int l31 = lane & 31, h = lane >> 5, s = (l31 >> 1) & 7;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t X = l31 * 128 + 16 * ((2 * u + h) ^ s);
+            adA[u] = lds0 + wr * 32768 + X;
+            adB[u] = lds0 + 65536 + wc * 32768 + X;
+        }
+    }
+
+    nt_f32x16_t acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // piece P of the stage the pointers stand on (0..7: A pieces, 8..15: B pieces) into the buffer at byte offset SO (0 / 16384)
+#define N2_ISSUE(SO, P)                                                                                                 \
+    do {                                                                                                                \
+        if ((P) < 8)                                                                                                    \
+            __builtin_amdgcn_global_load_lds((const void*)(gA + voffA[(P) & 7]),                                        \
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(dstA + (SO) + ((P) & 7) * 1024), 16, 0, 0); \
+        else                                                                                                            \
+            __builtin_amdgcn_global_load_lds((const void*)(gB + voffB[(P) & 7]),                                        \
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(dstB + (SO) + ((P) & 7) * 1024), 16, 0, 0); \
+    } while (0)
+#define N2_ADV() do { ++sdma; const int st_ = (sdma < T) ? 128 : 0; gA += st_; gB += st_; } while (0)
+#define N2_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define N2_PIN() __builtin_amdgcn_sched_barrier(0)
+    u32x4_t fa[2][4], fb[2][4];
+#define N2_MMA(FB, MI, NI)                                                                                              \
+    acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nt_bf16x8_t, fb[FB][NI]),                  \
+                                                          __builtin_bit_cast(nt_bf16x8_t, fa[FB][MI]), acc[MI][NI], 0, 0, 0)
+    // the 8 fragment reads of unit RU (0..3) of the stage in the buffer at RO into register set NB, one per slot i = 0..7
+#define N2_READ(NB, RU, RO, I)                                                                                          \
+    do {                                                                                                                \
+        if ((I) < 4) N2_RD(fa[NB][(I) & 3], adA[RU], (RO) + ((I) & 3) * 4096);                                          \
+        else N2_RD(fb[NB][(I) & 3], adB[RU], (RO) + ((I) & 3) * 4096);                                                  \
+    } while (0)
+    // one k16 unit: 16 MFMAs from register set FB; between them the 8 reads of the next unit (into FB ^ 1) and up to 6 DMA pieces
+    // (pieces P0 .. P0 + NP - 1 into the buffer at DO); every slot is pinned: MFMA, then at most one read or one piece
+#define N2_UNIT(FB, RU, RO, DO, P0, NP)                                                                                 \
+    do {                                                                                                                \
+        N2_MMA(FB, 0, 0); N2_PIN(); N2_READ((FB) ^ 1, RU, RO, 0); N2_PIN();                                             \
+        N2_MMA(FB, 0, 1); N2_PIN(); N2_READ((FB) ^ 1, RU, RO, 4); N2_PIN();                                             \
+        N2_MMA(FB, 0, 2); N2_PIN(); if ((NP) > 0) N2_ISSUE(DO, (P0) + 0); N2_PIN();                                     \
+        N2_MMA(FB, 0, 3); N2_PIN(); N2_READ((FB) ^ 1, RU, RO, 1); N2_PIN();                                             \
+        N2_MMA(FB, 1, 0); N2_PIN(); N2_READ((FB) ^ 1, RU, RO, 5); N2_PIN();                                             \
+        N2_MMA(FB, 1, 1); N2_PIN(); if ((NP) > 1) N2_ISSUE(DO, (P0) + 1); N2_PIN();                                     \
+        N2_MMA(FB, 1, 2); N2_PIN(); N2_READ((FB) ^ 1, RU, RO, 2); N2_PIN();                                             \
+        N2_MMA(FB, 1, 3); N2_PIN(); N2_READ((FB) ^ 1, RU, RO, 6); N2_PIN();                                             \
+        N2_MMA(FB, 2, 0); N2_PIN(); if ((NP) > 2) N2_ISSUE(DO, (P0) + 2); N2_PIN();                                     \
+        N2_MMA(FB, 2, 1); N2_PIN(); N2_READ((FB) ^ 1, RU, RO, 3); N2_PIN();                                             \
+        N2_MMA(FB, 2, 2); N2_PIN(); N2_READ((FB) ^ 1, RU, RO, 7); N2_PIN();                                             \
+        N2_MMA(FB, 2, 3); N2_PIN(); if ((NP) > 3) N2_ISSUE(DO, (P0) + 3); N2_PIN();                                     \
+        N2_MMA(FB, 3, 0); N2_PIN(); if ((NP) > 4) N2_ISSUE(DO, (P0) + 4); N2_PIN();                                     \
+        N2_MMA(FB, 3, 1); N2_PIN(); if ((NP) > 5) N2_ISSUE(DO, (P0) + 5); N2_PIN();                                     \
+        N2_MMA(FB, 3, 2); N2_MMA(FB, 3, 3); N2_PIN();                                                                   \
+    } while (0)
+    // one stage in the buffer at O (0 / 16384); OO = the other buffer
+#define N2_STAGE(O, OO)                                                                                                 \
+    do {                                                                                                                \
+        /* unit 0: reads unit 1; pieces 6..10 of stage t+1 (pointers stand on it) into the other buffer */              \
+        N2_UNIT(0, 1, O, OO, 6, 5);                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); N2_PIN();                                                    \
+        N2_UNIT(1, 2, O, OO, 11, 5); N2_ADV();                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); N2_PIN();                                                    \
+        N2_UNIT(0, 3, O, OO, 0, 0);                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+        N2_PIN(); __builtin_amdgcn_s_barrier(); N2_PIN();                                                               \
+        /* unit 3: reads unit 0 of stage t+1 from the other buffer; pieces 0..5 of stage t+2 into THIS buffer */        \
+        N2_UNIT(1, 0, OO, O, 0, 6);                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); N2_PIN();                                                    \
+    } while (0)
+
+    // ---- prologue: stage 0 whole, stage 1's pieces 0..5 (what "unit 3 of stage -1" would have issued)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) N2_ISSUE(0, p);
+    N2_ADV();
+#pragma unroll
+    for (int p = 0; p < 6; ++p) N2_ISSUE(16384, p);
+    nt_wait_vm<6>();
+    N2_PIN(); __builtin_amdgcn_s_barrier(); N2_PIN();
+    N2_READ(0, 0, 0, 0); N2_READ(0, 0, 0, 1); N2_READ(0, 0, 0, 2); N2_READ(0, 0, 0, 3);
+    N2_READ(0, 0, 0, 4); N2_READ(0, 0, 0, 5); N2_READ(0, 0, 0, 6); N2_READ(0, 0, 0, 7);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); N2_PIN();
+    for (int t = 0; t < T; t += 2) {
+        N2_STAGE(0, 16384);
+        N2_STAGE(16384, 0);
+    }
+    nt_wait_vm<0>();
+#undef N2_STAGE
+#undef N2_UNIT
+#undef N2_READ
+#undef N2_MMA
+#undef N2_PIN
+#undef N2_RD
+#undef N2_ADV
+#undef N2_ISSUE
+
+    const int h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int ml = wr * 128 + mi * 32 + (lane & 31);
+        if (ml < rows_valid) {
+            uint16_t* rowp = a.C + (m0 + ml) * a.ldc + n0 + wc * 128 + 4 * h;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    uint2 o;
+                    o.x = pack_bf16x2(acc[mi][ni][4 * t + 0], acc[mi][ni][4 * t + 1]);
+                    o.y = pack_bf16x2(acc[mi][ni][4 * t + 2], acc[mi][ni][4 * t + 3]);
+                    *reinterpret_cast<uint2*>(rowp + ni * 32 + 8 * t) = o;
+                }
+        }
+    }
+}
+
 }  // namespace ar
 
 using namespace ar;
@@ -330,7 +544,7 @@ using namespace ar;
 static int g_nt_dmal = 0;        // 1: the DMA pieces at the end of the L part (ar_gemm_nt_config)
 // experiment knob (binding hygiene, tools/gpu/r05_gemm_nt_probe.py): variant 0 / 1 selects where the LDS-DMA pieces are issued; -1 keeps.
 extern "C" int ar_gemm_nt_config(int variant) {
-    if (variant == 0 || variant == 1) g_nt_dmal = variant;
+    if (variant >= 0 && variant <= 2) g_nt_dmal = variant;        // 2: nt2 (one wave per SIMD, 128 x 128 per wave)
     return g_nt_dmal;
 }
 
@@ -341,9 +555,12 @@ static nt_fn nt_kernel() {
     if (once.first()) {
         (void)hipFuncSetAttribute((const void*)k_gemm_nt<GROUPED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
         (void)hipFuncSetAttribute((const void*)k_gemm_nt<GROUPED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+        (void)hipFuncSetAttribute((const void*)k_gemm_nt2<GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
     }
+    if (g_nt_dmal == 2) return k_gemm_nt2<GROUPED>;
     return g_nt_dmal ? k_gemm_nt<GROUPED, true> : k_gemm_nt<GROUPED, false>;
 }
+static int nt_threads() { return g_nt_dmal == 2 ? 256 : NT_THREADS; }
 
 static int nt_check(const void* A, const void* B, void* C, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc) {
     if (N % NT_B || K < 128 || K % 128 || (lda % 8) || (ldb % 8) || (ldc % 4)) return AR_ERR_UNSUPPORTED;
@@ -364,7 +581,7 @@ extern "C" int ar_gemm_nt(const void* A, const void* B, void* C, int64_t M, int6
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.tiles_m = (int)((M + NT_B - 1) / NT_B); a.tiles_n = (int)(N / NT_B); a.order = 2;
     a.row_off = nullptr; a.b_off = nullptr; a.E = 0; a.trace = nullptr;
-    AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (nt_kernel<false>()), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
+    AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (nt_kernel<false>()), a.tiles_m * a.tiles_n, nt_threads(), NT_LDS, (hipStream_t)stream, a);
     return launch_status();
 }
 
@@ -386,13 +603,13 @@ extern "C" int ar_gemm_nt_grouped(const void* A, const void* B, void* C, int64_t
     a.row_off = row_off; a.b_off = b_off; a.E = n_groups; a.trace = nullptr;
     int grid = a.tiles_m * a.tiles_n;
     grid = (grid + 7) / 8 * 8;                          // (a multiple of 8: the per-XCD runs of the tile order)
-    AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (nt_kernel<true>()), grid, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
+    AR_LAUNCH_PROF(AR_PROF_GEMM_NT, M * N, (nt_kernel<true>()), grid, nt_threads(), NT_LDS, (hipStream_t)stream, a);
     return launch_status();
 }
 
 // The dense kernel with s_memtime bookkeeping per phase (tools/gpu/r05_gemm_nt_trace.py -> DESIGN.md's per-phase cycle table): trace gets
-// [tiles][8 waves][6] uint64 -- cycles in the fragment-read part, parked at the barrier after it, in the MFMA part, parked at the barrier
-// after it, the whole K loop, the number of phases.  variant as ar_gemm_nt_config.  Costs ~10 % of the kernel's speed; C is still written.
+// [tiles][8 waves][8] uint64 -- cycles in the fragment-read part, parked at the barrier after it, in the MFMA part, parked at the barrier
+// after it, the whole K loop, the number of phases, the whole K loop in ticks of the constant 100 MHz counter, 0.  variant as ar_gemm_nt_config.  Costs ~10 % of the kernel's speed; C is still written.
 extern "C" int ar_gemm_nt_trace(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                                 unsigned long long* trace, int variant, ar_stream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !trace) return AR_ERR_UNSUPPORTED;

@@ -277,11 +277,14 @@ class SignRoundConfig:
     # 1.49 ms per iteration: ~2 us between graph nodes against ~1.5 from the queue); the graph pays where kernels are shorter than
     # the host's launch cost, i.e. for smaller blocks.  Hence the automatic mode stops at 4 M weights; `hip_graph=True` forces it.
     hip_graph_max_weights: int = 4 * 1024 * 1024
-    # Module path only: hand the block its shared keyword tensors (one attention mask for every sample, ...) materialised at the
-    # minibatch's own row count -- what the reference's per-sample input cache produces by concatenation (block_runner.py:368-422)
-    # -- instead of one broadcastable row.  Same values; SDPA may pick another kernel for a batch-broadcast mask, and with it other
-    # last bits.  Costs a [batch, 1, S, S] copy per forward, so it is off unless bit parity with the reference's forward is wanted.
-    materialise_shared_rows: bool = False
+    # Module path (and exact_rounding, whose attention is the module path's call): hand the block its shared keyword tensors (one
+    # attention mask for every sample, ...) materialised at the minibatch's own row count -- what the reference's per-sample input
+    # cache produces by concatenation (block_runner.py:368-422: an [8, 1, S, S] mask, not a broadcastable [1, 1, S, S]).  Same values;
+    # the library's attention picks another kernel for a batch-broadcast mask and returns other last bits at some shapes: Llama-3-8B's
+    # are unaffected, but OPT-125M's block and Mixtral-8x7B's parted from the reference for exactly this reason (round 5: with the mask
+    # materialised the reference-free flow reproduces the reference's targets and results at both).  ON by default since round 5 --
+    # results identical to the reference's come first; the cost is one [batch, 1, S, S] copy per block forward (67 MB at 8 x 2048).
+    materialise_shared_rows: bool = True
     # Llama-family blocks through first-party kernels that keep the MODULE PATH'S BITS (auto_round_amd/exact_block.py,
     # csrc/ar_exact.hip): eager torch's rounding points and reduction order in the elementwise kernels, the module path's GEMM
     # shapes plus whichever faster GEMM forms prove bit-equal on this GPU / software stack.  Verified against the module code on
@@ -407,7 +410,11 @@ class SignRoundQuantizer:
                 return tuple(mat(t) for t in v)
             return v
 
-        return {k: (mat(v) if k != "positional_inputs" else v) for k, v in input_others.items()}
+        # exactly what the reference's runner concatenates per minibatch: the per-sample keys (the attention mask); its SHARED keys --
+        # position_ids, position_embeddings, cache_position (utils/common.py:676) -- stay one row there and must stay one row here: a
+        # [8, S, 128] cos / sin instead of [1, S, 128] changes the layout `q * cos` returns, and with it the attention kernel's bits
+        # (found on the Mixtral block, profiles/r05_t3_mixtral_forward_compare_*.json)
+        return {k: (mat(v) if (k != "positional_inputs" and k not in SHARED_CACHE_KEYS) else v) for k, v in input_others.items()}
 
     def block_forward(self, block, x, input_others):
         input_others = self._others_for(x.shape[0], input_others)

@@ -132,7 +132,7 @@ def capture_block_inputs(model, block, tokens: torch.Tensor, device, amp_dtype=t
 
 def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw: Optional[dict] = None, iters: int = 200,
                       nsamples: int = 128, seqlen: int = 2048, batch_size: int = 8, fused: bool = False, alg_ext: bool = False,
-                      seed: int = 42, device="cuda:0", graph: Optional[bool] = None, materialise: bool = False, exact: bool = False,
+                      seed: int = 42, device="cuda:0", graph: Optional[bool] = None, materialise: bool = True, exact: bool = False,
                       lr: Optional[float] = None, minmax_lr: Optional[float] = None) -> dict:
     """The plugin-mode flow without the reference around it: same seeded block, same block inputs, targets from the module-path
     forward (what the reference's orchestrator hands to `quantize_block`), `transformers.set_seed(seed)` right before the block
@@ -198,7 +198,8 @@ def _tune_with_product(arch, *, scheme, scheme_kw, iters, nsamples, seqlen, batc
     tune_s = time.perf_counter() - t0
     stats = dict(q.last_stats)
     loss_trace = stats.pop("loss_trace", None)      # recorded on the device by ar_best_loss_update, one read per block
-    return dict(block=block, stats=stats, loss_trace=loss_trace, x_sha=sha(x0), y_sha=sha(y),
+    extra = {"y": y.detach().cpu()} if os.environ.get("AR_T3_KEEP_TARGETS") == "1" else {}
+    return dict(block=block, stats=stats, loss_trace=loss_trace, x_sha=sha(x0), y_sha=sha(y), y_dtype=str(y.dtype), **extra,
                 fused_block=bool(q.last_fused_block), hip_graph=bool(q.last_hip_graph), others_keys=sorted(others),
                 exact_block=bool(q.last_exact), exact_report=q.last_exact_report, tune_s=tune_s)
 
@@ -261,7 +262,7 @@ def trace_divergence(a, b, rel=1e-4):
     return next((i for i in range(n) if abs(a[i] - b[i]) > rel * max(abs(a[i]), 1e-30)), None)
 
 
-def check_against_fixture(fused: bool, path: str = FIXTURE, graph: Optional[bool] = None, materialise: bool = False) -> dict:
+def check_against_fixture(fused: bool, path: str = FIXTURE, graph: Optional[bool] = None, materialise: bool = True) -> dict:
     """Re-tune the fixture's block with this package and compare -> a flat record (what bench.py prints as `parity`)."""
     fix = load_fixture(path)
     m = fix["meta"]
@@ -439,4 +440,5 @@ def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = Fal
                 best_loss_ratio=r["stats"]["best_loss"] / min(ref_trace), first_divergence_iter=trace_divergence(ref_trace, tr),
                 ref_vs_ref_prefix_identical_weights=rvr["prefix_identical_weights"], ref_vs_ref_best_loss_ratio=rvr.get("best_loss_ratio"),
                 ref_vs_ref_first_divergence_iter=rvr.get("first_divergence_iter"), **stat_thresholds(rvr), tune_s=r["tune_s"],
+                result_digest=hashlib.sha256("".join(f"{k}:{v};" for k, v in sorted(got.items())).encode()).hexdigest(), y_dtype=r.get("y_dtype"),
                 device=m.get("device"), torch=m.get("torch"))

@@ -398,8 +398,9 @@ int ar_gemm_nt_grouped(const void* A, const void* B, void* C, int64_t M, int64_t
  * issued between the MFMAs, 1 = at the end of the fragment-read part of every second phase; -1 keeps.  Returns the variant in use. */
 int ar_gemm_nt_config(int variant);
 /* measurement hygiene (tools/gpu/r05_gemm_nt_trace.py; no reference counterpart): ar_gemm_nt with s_memtime bookkeeping -- trace receives
- * [row tiles * column tiles][8 waves][6] uint64: shader cycles a wave spent, summed over its phases, in the fragment-read part, parked at
- * the barrier after it, in the MFMA part, parked at the barrier after it; the cycles of the whole K loop; the number of phases. */
+ * [row tiles * column tiles][8 waves][8] uint64: shader cycles a wave spent, summed over its phases, in the fragment-read part, parked at
+ * the barrier after it, in the MFMA part, parked at the barrier after it; the cycles of the whole K loop; the number of phases; the whole
+ * K loop in ticks of the constant 100 MHz counter (s_memrealtime: cycles / ticks * 100 MHz = the shader clock the kernel ran at); 0. */
 int ar_gemm_nt_trace(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                      unsigned long long* trace, int variant, ar_stream_t stream);
 /* experiment knobs of the kernel above for tools/gemm_dw_probe.py (binding hygiene; -1 keeps a value): sem = lane->piece rule

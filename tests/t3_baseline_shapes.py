@@ -71,6 +71,9 @@ BIG_CASES = {
     # configs[4]'s other scheme at real width
     "mixtral8x7b_nvfp4_100": dict(arch="mixtral8x7b", scheme="NVFP4", kw=dict(lr=5e-3, minmax_lr=5e-3), iters=100, nsamples=64, seqlen=2048,
                                   batch_size=8),
+    # (diagnostic: the reference's targets vs the reference-free flow's at real width, two iterations)
+    "mixtral8x7b_mxfp4_2": dict(arch="mixtral8x7b", scheme="MXFP4", kw=dict(lr=5e-3, minmax_lr=5e-3), iters=2, nsamples=64, seqlen=2048,
+                                batch_size=8),
 }
 
 
@@ -204,6 +207,10 @@ class _InputSpy:
 
                 rec = dict(x_sha=sha(stack(fp_inputs)), y_sha=sha(stack(fp_outputs)), q_inputs=q_inputs is not None,
                            others={k: desc(v) for k, v in (input_others or {}).items()})
+                ys = stack(fp_outputs)
+                rec["y_dtype"], rec["y_shape"] = str(ys.dtype), list(ys.shape)
+                if os.environ.get("AR_T3_KEEP_TARGETS") == "1":
+                    spy.y_ref = ys.detach().cpu()
                 am = (input_others or {}).get("attention_mask")
                 am0 = am[0] if isinstance(am, (list, tuple)) and len(am) else am
                 if isinstance(am0, torch.Tensor):
@@ -220,6 +227,127 @@ class _InputSpy:
 
     def remove(self):
         self._R.quantize_block = self._orig
+
+
+class _FwdSpy:
+    """Diagnostic (AR_T3_KEEP_TARGETS=1): inside the REFERENCE's first block forward of a run -- the one that produces the targets --
+    record the block's parameter checksums, the classes of its submodules, what the runner passes as `input_others`, and the outputs
+    of the block's main submodules for the first minibatch; `compare_with(block, forward)` then does the same through this package's
+    flow and lists what differs first."""
+
+    NAMES = ("input_layernorm", "self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "self_attn",
+             "post_attention_layernorm", "mlp.gate", "mlp.experts", "mlp", "")
+
+    def __init__(self):
+        self.rec = None
+
+    @staticmethod
+    def _capture(block, run):
+        from auto_round_amd.testing.t3_fixture import sha
+
+        store, hs = {}, []
+
+        def hook(name):
+            def f(mod, inp, outp):
+                o = outp[0] if isinstance(outp, (tuple, list)) else outp
+                if isinstance(o, torch.Tensor) and name not in store:
+                    store[name] = o.detach().float().cpu()
+            return f
+
+        def pre(name):
+            def f(mod, args, kwargs):
+                t = args[0] if args else kwargs.get("input")
+                if isinstance(t, torch.Tensor) and name not in store:
+                    store[name] = t.detach().float().cpu()
+            return f
+
+        for n, m in block.named_modules():
+            if n in _FwdSpy.NAMES:
+                hs.append(m.register_forward_hook(hook(n or "<block>")))
+            if n == "self_attn.o_proj":
+                hs.append(m.register_forward_pre_hook(pre("self_attn.o_proj<input: the attention's own output>"), with_kwargs=True))
+            if n == "self_attn":
+                def grab_kwargs(mod, args, kwargs, _store=store):
+                    from auto_round_amd.testing.t3_fixture import sha as _sha
+
+                    d = {}
+                    for k, v in kwargs.items():
+                        if isinstance(v, torch.Tensor):
+                            d[k] = [str(v.dtype), list(v.shape), list(v.stride()), _sha(v)]
+                        elif isinstance(v, (tuple, list)) and v and isinstance(v[0], torch.Tensor):
+                            d[k] = [[str(t.dtype), list(t.shape), list(t.stride()), _sha(t)] for t in v]
+                        else:
+                            d[k] = repr(v)[:60]
+                    _store["__attn_kwargs__"] = d
+                hs.append(m.register_forward_pre_hook(grab_kwargs, with_kwargs=True))
+        try:
+            run()
+        finally:
+            for h in hs:
+                h.remove()
+        params = {n: sha(p) for n, p in block.named_parameters()}
+        classes = {n or "<block>": type(m).__name__ for n, m in block.named_modules() if n.count(".") <= 1}
+        attn_kwargs = store.pop("__attn_kwargs__", None)
+        flags = dict(deterministic=torch.are_deterministic_algorithms_enabled(), flash_sdp=torch.backends.cuda.flash_sdp_enabled(),
+                     mem_efficient_sdp=torch.backends.cuda.mem_efficient_sdp_enabled(), math_sdp=torch.backends.cuda.math_sdp_enabled(),
+                     autocast=torch.is_autocast_enabled(), attn_impl=getattr(getattr(getattr(block, "self_attn", None), "config", None), "_attn_implementation", None))
+        return dict(outputs=store, params=params, classes=classes, attn_kwargs=attn_kwargs, flags=flags)
+
+    def install(self):
+        import auto_round.algorithms.block_runner as BR
+
+        spy = self
+        self._BR, self._orig = BR.BlockForwardRunner, BR.BlockForwardRunner._forward_one_batch
+
+        def _forward_one_batch(runner, block, batch_inputs, batch_others):
+            if spy.rec is not None:
+                return spy._orig(runner, block, batch_inputs, batch_others)
+            out = {}
+
+            def run():
+                out["y"] = spy._orig(runner, block, batch_inputs, batch_others)
+
+            def desc(v):
+                if isinstance(v, torch.Tensor):
+                    return [str(v.dtype), list(v.shape), list(v.stride())]
+                if isinstance(v, (list, tuple)):
+                    return [type(v).__name__, len(v), desc(v[0]) if len(v) else None]
+                return repr(v)[:40]
+
+            spy.rec = self._capture(block, run)
+            spy.rec["others"] = {k: desc(v) for k, v in (batch_others or {}).items()}
+            spy.rec["amp"] = [bool(runner.amp), str(runner.amp_dtype), str(runner.device), int(runner.batch_size)]
+            return out["y"]
+
+        BR.BlockForwardRunner._forward_one_batch = _forward_one_batch
+        return self
+
+    def remove(self):
+        self._BR._forward_one_batch = self._orig
+
+    def compare_with(self, block, run):
+        mine = self._capture(block, run)
+        ref = self.rec
+        out = dict(ref_amp=ref.get("amp"), ref_others=ref.get("others"), classes_ref=ref["classes"], classes_mine=mine["classes"],
+                   attn_kwargs_ref=ref.get("attn_kwargs"), attn_kwargs_mine=mine.get("attn_kwargs"), flags_ref=ref.get("flags"), flags_mine=mine.get("flags"))
+        pr, pm = ref["params"], mine["params"]
+        out["params_only_in_ref"] = sorted(set(pr) - set(pm))[:10]
+        out["params_only_in_mine"] = sorted(set(pm) - set(pr))[:10]
+        out["params_differing"] = [n for n in sorted(set(pr) & set(pm)) if pr[n] != pm[n]][:20]
+        out["params_compared"] = len(set(pr) & set(pm))
+        outs = {}
+        for n in list(self.NAMES) + ["self_attn.o_proj<input: the attention's own output>"]:
+            n = n or "<block>"
+            a, b = ref["outputs"].get(n), mine["outputs"].get(n)
+            if a is None or b is None:
+                outs[n] = "missing (ref: %s, mine: %s)" % (a is not None, b is not None)
+            elif a.shape != b.shape:
+                outs[n] = f"shapes {list(a.shape)} vs {list(b.shape)}"
+            else:
+                d = (a - b).abs()
+                outs[n] = dict(differing=int((d > 0).sum()), of=int(d.numel()), max_abs=float(d.max()), rms_ref=float(a.pow(2).mean().sqrt()))
+        out["outputs"] = outs
+        return out
 
 
 def _tuned_layers(model):
@@ -405,10 +533,13 @@ def run_big_case(name, fixture_path=None, skip_alone=False, digest_path=None, re
                       batch_size=case["batch_size"], enable_torch_compile=False, seed=42, scheme=case["scheme"], **case["kw"])
         # ---- (ref) the reference's own engine on the GPU, with probes
         probe, gprobe, spy = _LossProbe().install(), _GradSignProbe().install(), _InputSpy().install()
+        fwdspy = _FwdSpy().install() if os.environ.get("AR_T3_KEEP_TARGETS") == "1" else None
         t0 = time.perf_counter()
         try:
             q_ref, _ = AutoRound(copy.deepcopy(base), iters=iters, **common).quantize()
         finally:
+            if fwdspy is not None:
+                fwdspy.remove()
             spy.remove(); gprobe.remove(); probe.remove()          # reverse order of installation
         torch.cuda.synchronize()
         rec["ref_wall_s"] = time.perf_counter() - t0
@@ -514,7 +645,32 @@ def run_big_case(name, fixture_path=None, skip_alone=False, digest_path=None, re
                 for n, p in a["block"].named_modules():
                     if isinstance(p, torch.nn.Linear) and hasattr(p, "scale"):
                         L_al[n.replace(".orig_layer", "")] = p
-                r = dict(stats=a["stats"], fused_block=a["fused_block"], exact_block=a["exact_block"], tune_s=a["tune_s"], hip_graph=a["hip_graph"], inputs_identical=a["x_sha"] == spy.rec["x_sha"],
+                y_mine = a.pop("y", None)
+                ycmp = None
+                if y_mine is not None and getattr(spy, "y_ref", None) is not None:
+                    yr = spy.y_ref
+                    ycmp = dict(dtype_ref=str(yr.dtype), dtype_mine=str(y_mine.dtype), shape_ref=list(yr.shape), shape_mine=list(y_mine.shape))
+                    if yr.shape == y_mine.shape:
+                        d = (yr.float() - y_mine.float()).abs()
+                        ycmp.update(max_abs_diff=float(d.max()), values_differing=int((d > 0).sum()), rms_ref=float(yr.float().pow(2).mean().sqrt()),
+                                    differing_per_sample_first16=[int((d[i] > 0).sum()) for i in range(min(16, d.shape[0]))])
+                if fwdspy is not None and fwdspy.rec is not None and tag == "alone_module":
+                    from auto_round_amd.quantizer import SignRoundConfig as _C, SignRoundQuantizer as _Q
+
+                    _q = _Q(_C(iters=1, batch_size=case["batch_size"], bits=4, sdpa_backend="auto", fused_block=False, exact_rounding=False,
+                               materialise_shared_rows=True), device="cuda:0")
+                    m2 = fx.build_model(case["arch"]).to("cuda:0")
+                    b2 = fx.decoder_blocks(m2)[0]
+                    if fx.ARCHS[case["arch"]]["family"] == "moe":
+                        from auto_round_amd.moe_unfuse import unfuse_moe_experts
+
+                        unfuse_moe_experts(m2)
+                    x2, o2 = fx.capture_block_inputs(m2, b2, tokens, torch.device("cuda:0"))
+                    with torch.no_grad():
+                        rec["forward_compare"] = fwdspy.compare_with(b2, lambda: _q.block_forward(b2, x2[:case["batch_size"]], o2))
+                    del m2, b2, x2, o2
+                    _free()
+                r = dict(stats=a["stats"], targets_compare=ycmp, fused_block=a["fused_block"], exact_block=a["exact_block"], tune_s=a["tune_s"], hip_graph=a["hip_graph"], inputs_identical=a["x_sha"] == spy.rec["x_sha"],
                          targets_identical=a["y_sha"] == spy.rec["y_sha"], others_keys=a["others_keys"],
                          first_divergence_iter=fx.trace_divergence(ref_trace, a["loss_trace"] or []), loss_trace=a["loss_trace"])
                 r.update(compare_layers(L_ref, L_al))

@@ -88,6 +88,63 @@ def epilogue_cover():
     return bool((hit == 1).all())
 
 
+# ---- nt2 (one wave per SIMD, 128 x 128 per wave): same LDS image; wave w stages rows [64 w, 64 w + 64) of each operand tile (8 pieces),
+# reads A rows wr * 128 + mi * 32 + l31 (wr = w >> 1) and B rows wc * 128 + ni * 32 + l31 (wc = w & 1); unit u of a stage = chunks 2u, 2u+1
+def dma_stage_nt2(lds, t, sg):
+    for wave in range(4):
+        for op in (0, 1):
+            for j in range(8):
+                dst = op * 65536 + (wave >> 1) * 32768 + sg * 16384 + ((wave & 1) * 64 + 8 * j) * 128
+                for lane in range(64):
+                    row = wave * 64 + 8 * j + (lane >> 3)
+                    lc = (lane & 7) ^ ((4 * j + (lane >> 4)) & 7)
+                    assert (((row & 127) >> 1) & 7) == ((4 * j + (lane >> 4)) & 7)
+                    lds[(dst + lane * 16) // 16] = (op, row, t * 8 + lc)
+
+
+def check_reads_nt2(lds, t, sg):
+    seen_a, seen_b = set(), set()
+    for wave in range(4):
+        wr, wc = wave >> 1, wave & 1
+        for u in range(4):
+            for lane in range(64):
+                l31, h = lane & 31, lane >> 5
+                x = l31 * 128 + 16 * ((2 * u + h) ^ ((l31 >> 1) & 7))
+                for i in range(4):
+                    op, row, ch = lds[(wr * 32768 + x + sg * 16384 + i * 4096) // 16]
+                    assert (op, row, ch) == (0, wr * 128 + i * 32 + l31, t * 8 + 2 * u + h)
+                    seen_a.add((row, ch))
+                    op, row, ch = lds[(65536 + wc * 32768 + x + sg * 16384 + i * 4096) // 16]
+                    assert (op, row, ch) == (1, wc * 128 + i * 32 + l31, t * 8 + 2 * u + h)
+                    seen_b.add((row, ch))
+    assert len(seen_a) == 256 * 8 and len(seen_b) == 256 * 8
+
+
+def epilogue_cover_nt2():
+    hit = np.zeros((256, 256), dtype=np.int32)
+    for wave in range(4):
+        wr, wc = wave >> 1, wave & 1
+        for lane in range(64):
+            for mi in range(4):
+                for ni in range(4):
+                    for t in range(4):
+                        for r in range(4):
+                            hit[wr * 128 + mi * 32 + (lane & 31), wc * 128 + ni * 32 + 8 * t + 4 * (lane >> 5) + r] += 1
+    return bool((hit == 1).all())
+
+
+def main_nt2():
+    lds = np.full((131072 // 16, 3), -1, dtype=np.int64)
+    dma_stage_nt2(lds, 0, 0)
+    dma_stage_nt2(lds, 1, 1)
+    check_reads_nt2(lds, 0, 0)
+    check_reads_nt2(lds, 1, 1)
+    dma_stage_nt2(lds, 2, 0)
+    check_reads_nt2(lds, 2, 0)
+    check_reads_nt2(lds, 1, 1)
+    return epilogue_cover_nt2()
+
+
 def main():
     lds = np.full((131072 // 16, 3), -1, dtype=np.int64)
     dma_stage(lds, 0, 0)
@@ -99,8 +156,10 @@ def main():
     check_reads(lds, 1, 1)          # restaging parity 0 left parity 1 alone
     w = worst_bank_multiplicity()
     ok = epilogue_cover()
-    print(f"mapping ok; worst distinct addresses per 16-byte bank slot within a lane group: {w}; epilogue covers the tile exactly once: {ok}")
-    return w, ok
+    ok2 = main_nt2()
+    print(f"mapping ok; worst distinct addresses per 16-byte bank slot within a lane group: {w}; epilogue covers the tile exactly once: {ok}; "
+          f"nt2 mapping ok, epilogue: {ok2}")
+    return w, ok and ok2
 
 
 if __name__ == "__main__":

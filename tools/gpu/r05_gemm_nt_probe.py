@@ -187,7 +187,7 @@ def ab_variants(gen):
         A, B = rnd((M, K), gen), rnd((N, K), gen, 0.05)
         lib_out = torch.mm(A, B.t())
         outs, rec = {}, dict(shape=name, M=M, N=N, K=K)
-        for v in (0, 1):
+        for v in (0, 1, 2):
             lib.ar_gemm_nt_config(v)
             o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
             ops.gemm_nt(A, B, o)
@@ -199,17 +199,17 @@ def ab_variants(gen):
             outs[v] = o
             rec[f"v{v}_bits_differ_from_library"] = bits_diff(o, lib_out)
             rec[f"v{v}_repeat_runs_differing"] = flaky
-        t = {0: [], 1: [], "lib": []}
+        t = {0: [], 1: [], 2: [], "lib": []}
         o = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
         for _ in range(4):
-            for v in (0, 1):
+            for v in (0, 1, 2):
                 lib.ar_gemm_nt_config(v)
                 t[v].append(timeit(lambda: ops.gemm_nt(A, B, o), rounds=1, inner=10)["ms_min"])
             t["lib"].append(timeit(lambda: torch.mm(A, B.t(), out=o), rounds=1, inner=10)["ms_min"])
         fl = 2.0 * M * N * K
         med = lambda x: sorted(x)[len(x) // 2]  # noqa: E731
-        rec.update(v0_ms=med(t[0]), v1_ms=med(t[1]), lib_ms=med(t["lib"]), v0_pflops=fl / med(t[0]) / 1e12, v1_pflops=fl / med(t[1]) / 1e12,
-                   lib_pflops=fl / med(t["lib"]) / 1e12)
+        rec.update(v0_ms=med(t[0]), v1_ms=med(t[1]), v2_ms=med(t[2]), lib_ms=med(t["lib"]), v0_pflops=fl / med(t[0]) / 1e12, v1_pflops=fl / med(t[1]) / 1e12,
+                   v2_pflops=fl / med(t[2]) / 1e12, lib_pflops=fl / med(t["lib"]) / 1e12)
         print(json.dumps(rec), flush=True)
         out["nt"].append(rec)
     lib.ar_gemm_nt_config(0)
@@ -267,10 +267,10 @@ def main():
     if args.ab:
         res["ab"] = ab_variants(gen)
         flush()
-        v1_wins = sum(1 for r in res["ab"]["nt"] if r["v1_ms"] < r["v0_ms"] and r["v1_bits_differ_from_library"] == 0 and r["v1_repeat_runs_differing"] == 0)
+        v2_wins = sum(1 for r in res["ab"]["nt"] if r["v2_ms"] < r["v0_ms"] and r["v2_bits_differ_from_library"] == 0 and r["v2_repeat_runs_differing"] == 0)
         from auto_round_amd import _lib
-        _lib.load().ar_gemm_nt_config(1 if v1_wins >= 2 else 0)
-        res["grouped_variant"] = 1 if v1_wins >= 2 else 0
+        _lib.load().ar_gemm_nt_config(2 if v2_wins >= 2 else 0)
+        res["grouped_variant"] = 2 if v2_wins >= 2 else 0
     for M, N, K in ([] if args.ab else [(256, 256, 128), (512, 512, 256), (1000, 256, 384), (4096, 1024, 4096), (16384, 4096, 4096), (16384, 4096, 14336)]):
         r = dense_case(M, N, K, gen)
         print(json.dumps(r), flush=True)
