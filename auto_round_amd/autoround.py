@@ -469,10 +469,13 @@ def _compressed_tensors_config(preset: str, ignore, fmt: str):
                       f"{LLMC_LITERAL_PINNED_TO}")
         return None
     out["provider"] = "auto-round"
-    try:        # which version wrote the dict: the same run gives the same checkpoint only on the same version
+    try:        # which version wrote the dict goes to the log, not into quantization_config: the reference's export writes the
+        import logging      # compressed-tensors dict + provider only, and a strict loader may refuse an unknown field
+
         import compressed_tensors
 
-        out["compressed_tensors_version"] = str(getattr(compressed_tensors, "__version__", "unknown"))
+        logging.getLogger("auto_round_amd").info("llm_compressor quantization_config written by compressed-tensors %s",
+                                                 getattr(compressed_tensors, "__version__", "unknown"))
     except Exception:  # noqa: BLE001
         pass
     return out

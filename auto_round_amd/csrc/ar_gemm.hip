@@ -792,6 +792,247 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     }
 }
 
+// ---- v6 (round 5): the same kernel on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------------
+// Why (tools/mfma_power.hip, profiles/r05_mfma_power.jsonl): on random operands the chip is POWER-bound, and the 16x16x32 shape draws
+// less per flop than 32x32x16 -- bare streams sustain 2.05 vs 1.85 PFLOP/s (2.08 vs 1.77 GHz), with the fragment reads of a 128 x 64
+// wave tile 1.87 vs 1.63, with the LDS-DMA of a 256 x 256 x 64 tile step on top 1.55 vs 1.29: the two ends of that last pair are
+// hipBLASLt's MI16x16x1 kernels (1.5-1.6 PF) and v3 (1.25-1.37).  A 32 x 32 accumulator tile is read and written once per 32768
+// flops (8 KB), a 16 x 16 one once per 16384 (2 KB): a quarter of the accumulator traffic per flop for twice the operand traffic
+// (2 KB per MFMA either way), 0.25 vs 0.31 register-file bytes per flop.
+// Same ring, same DMA protocol, same barriers, same 64(m) x 128(n) wave tile as v3; a phase is ONE K-step of 32: 24 transposing
+// reads (4 dY + 8 X fragments, k-rows 8q .. 8q+7 for the 16-lane group q: the operand's k = 8 (lane / 16) + j layout), then
+// 32 MFMAs with the 4 DMA pieces among them.  The 4 groups of a wave now read the SAME 16 columns at k-rows 8 apart, so the
+// swizzle gains bit 3 of the k-row:  chunk ^= ((k & 3) << 2) | (((k >> 3) & 1) << 1)  -- the eight 32-byte pieces a half-wave
+// touches (2 groups x 4 k-rows) fall on 256 disjoint bytes.  Transposed tile as in v3 (a-operand = X fragment): a lane owns output
+// row m = lane % 16 of a 16 x 16 tile and 4 consecutive n = 4 (lane / 16) .. +3.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <bool SPLITK = false, bool TAIL = false, bool CUT = false, bool GROUPED = false>
+__global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw6(GemmArgs a) {
+    static_assert(!GROUPED || (TAIL && !SPLITK && !CUT), "the grouped form is the ragged-K form per group");
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wm = wave & 3, wn = wave >> 2;
+    int tm, tn;
+    int sp = 0;
+    int64_t krow0 = 0, kend = a.K;
+    int U = (a.K + 127) / 128 * 8;
+    if (SPLITK) {
+        sp = blockIdx.x % a.nsplit;
+        const int tile = blockIdx.x / a.nsplit;
+        if (a.tile0 > 0) {
+            tile_of_block(a, a.tile0 + tile, tm, tn);
+        } else {
+            tm = tile / a.tiles_n;
+            tn = tile % a.tiles_n;
+        }
+        const int chunks = (a.K + 127) / 128;
+        const int c0 = (int)((int64_t)chunks * sp / a.nsplit), c1 = (int)((int64_t)chunks * (sp + 1) / a.nsplit);
+        krow0 = (int64_t)c0 * 128;
+        U = (c1 - c0) * 8;
+    } else if (GROUPED) {
+        const int tiles = a.tiles_m * a.tiles_n;
+        const int g = blockIdx.x / tiles;
+        tile_of_block(a, blockIdx.x - g * tiles, tm, tn);
+        krow0 = a.goff[g];
+        kend = a.goff[g + 1];
+        U = (int)((kend - krow0 + 127) / 128) * 8;
+        a.W += a.woff[g];
+    } else {
+        tile_of_block(a, blockIdx.x, tm, tn);
+    }
+    const int64_t m0 = (int64_t)tm * GB, n0 = (int64_t)tn * GB;
+    const int tile_id = tm * a.tiles_n + tn;
+    int cut_u = 0;
+    if (CUT) {
+        const int cut = a.kcut[tile_id];
+        if (cut > 0 && cut < a.K && (cut & 31) == 0) cut_u = cut >> 4;
+    }
+    // the parked accumulators of a lane are 512 contiguous bytes: ONE address register and immediate offsets (32 separate 64-bit
+    // addresses do not fit beside the accumulators; spilled ones would come back through scratch loads, which share the vmcnt queue
+    // the DMA protocol counts on)
+    float* park = CUT ? a.ws + (int64_t)tile_id * (GB * GB) + tid * 128 : nullptr;
+
+    const int drow = 2 * wave + (lane >> 5);                                     // k-row (0..15) of a unit's piece this lane stages
+    const int lchunk = (lane & 31) ^ (((drow & 3) << 2) | (((drow >> 3) & 1) << 1));
+    const uint16_t* srcP = a.X + (krow0 + drow) * a.ldx + n0 + lchunk * 8;
+    const uint16_t* srcQ = a.Y + (krow0 + drow) * a.ldy + m0 + lchunk * 8;
+    const int64_t stepP = (int64_t)GU * a.ldx, stepQ = (int64_t)GU * a.ldy;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    const uint32_t dmabase = lds0 + 2 * wave * ROWB;
+    const uint16_t* zsrc = g_zero_row + (lane & 31) * 8;
+    int64_t vrow = krow0 + drow;
+
+    // fragment read addresses: group q of the wave reads k-rows 8q .. 8q+7 of the pair's 32 (unit q >> 1, rows 8 (q & 1) ..), lane i of
+    // the group supplies k-row i >> 2 (+4 for the second read) and the 8-byte piece i & 3 of the fragment's 16 columns
+    const int q = lane >> 4, i = lane & 15;
+    const int rowsel = i >> 2, piece = i & 3;
+    const int swz = (rowsel << 2) | ((q & 1) << 1);
+    const int rowoff = (q >> 1) * UNIT + (8 * (q & 1) + rowsel) * ROWB + (piece & 1) * 8;
+    uint32_t aP[2][8], aQ[2][4];                                                  // [64 KB half][fragment]
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+        const int chunk = wn * 16 + ni * 2 + (piece >> 1);
+        aP[0][ni] = lds0 + rowoff + ((chunk ^ swz) << 4);
+        aP[1][ni] = aP[0][ni] + 65536;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int chunk = wm * 8 + mi * 2 + (piece >> 1);
+        aQ[0][mi] = lds0 + PIECE + rowoff + ((chunk ^ swz) << 4);
+        aQ[1][mi] = aQ[0][mi] + 65536;
+    }
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+
+    int vnext = 0;
+    auto issue_unit = [&](int slot_unit) {
+        const bool real = !TAIL || vrow < kend;
+        __builtin_amdgcn_global_load_lds((const void*)(real ? srcP : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(real ? srcQ : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
+        ++vnext;
+        vrow += GU;
+        const bool more = vnext < U;
+        srcP += more ? stepP : 0;
+        srcQ += more ? stepQ : 0;
+    };
+    auto issue_p = [&](int slot_unit) {
+        const bool real = !TAIL || vrow < kend;
+        __builtin_amdgcn_global_load_lds((const void*)(real ? srcP : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT), 16, 0, 0);
+    };
+    auto issue_q = [&](int slot_unit) {
+        const bool real = !TAIL || vrow < kend;
+        __builtin_amdgcn_global_load_lds((const void*)(real ? srcQ : zsrc), (__attribute__((address_space(3))) void*)(uintptr_t)(dmabase + slot_unit * UNIT + PIECE), 16, 0, 0);
+        ++vnext;
+        vrow += GU;
+        const bool more = vnext < U;
+        srcP += more ? stepP : 0;
+        srcQ += more ? stepQ : 0;
+    };
+    struct Frags { s16x4_t plo[8], phi[8], qlo[4], qhi[4]; };
+#define AR_RD(LO, HI, ADDR, OFF)                                                                                        \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                           \
+                 : "=&v"(LO), "=&v"(HI)                                                                                 \
+                 : "v"(ADDR), "n"(OFF), "n"((OFF) + 4 * ROWB)                                                            \
+                 : "memory")
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    auto cat = [](const s16x4_t& lo, const s16x4_t& hi) -> bf16x8_t {
+        return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Frags f;
+#define AR_MMA(MI, NI) acc[MI][NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat(f.plo[NI], f.phi[NI]), cat(f.qlo[MI], f.qhi[MI]), acc[MI][NI], 0, 0, 0)
+#define AR_MMA4(MI, N0) AR_MMA(MI, N0); AR_MMA(MI, N0 + 1); AR_MMA(MI, N0 + 2); AR_MMA(MI, N0 + 3)
+#define AR_PIN() __builtin_amdgcn_sched_barrier(0)
+#define AR_PHASE(S)                                                                                                     \
+    do {                                                                                                                \
+        constexpr int H = (S) >> 1;                                                                                     \
+        constexpr int O = ((S) & 1) * 2 * UNIT;                                                                         \
+        constexpr int DU = (((S) + 3) & 3) * 2;                                                                         \
+        AR_RD(f.qlo[0], f.qhi[0], aQ[H][0], O); AR_RD(f.qlo[1], f.qhi[1], aQ[H][1], O);                                 \
+        AR_RD(f.plo[0], f.phi[0], aP[H][0], O); AR_RD(f.plo[1], f.phi[1], aP[H][1], O);                                 \
+        AR_RD(f.plo[2], f.phi[2], aP[H][2], O); AR_RD(f.plo[3], f.phi[3], aP[H][3], O);                                 \
+        AR_RD(f.plo[4], f.phi[4], aP[H][4], O); AR_RD(f.plo[5], f.phi[5], aP[H][5], O);                                 \
+        AR_RD(f.plo[6], f.phi[6], aP[H][6], O); AR_RD(f.plo[7], f.phi[7], aP[H][7], O);                                 \
+        AR_RD(f.qlo[2], f.qhi[2], aQ[H][2], O); AR_RD(f.qlo[3], f.qhi[3], aQ[H][3], O);                                 \
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        bar();                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        AR_MMA4(0, 0); AR_PIN(); issue_p(DU); AR_PIN();                                                                 \
+        AR_MMA4(0, 4); AR_MMA4(1, 0); AR_PIN(); issue_q(DU); AR_PIN();                                                  \
+        AR_MMA4(1, 4); AR_MMA4(2, 0); AR_PIN(); issue_p(DU + 1); AR_PIN();                                              \
+        AR_MMA4(2, 4); AR_MMA4(3, 0); AR_PIN(); issue_q(DU + 1); AR_PIN();                                              \
+        AR_MMA4(3, 4);                                                                                                  \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        bar();                                                                                                          \
+    } while (0)
+
+#pragma unroll
+    for (int v = 0; v < 6; ++v) issue_unit(v);
+    wait_vm<8>();
+    bar();
+    if (grp == 1) bar();
+    auto park_acc = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                st16f(park + (mi * 8 + ni) * 4, make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]));
+                acc[mi][ni][0] = 0.f; acc[mi][ni][1] = 0.f; acc[mi][ni][2] = 0.f; acc[mi][ni][3] = 0.f;
+            }
+    };
+    for (int u = 0; u < U; u += 8) {
+        AR_PHASE(0);
+        if (CUT && u + 2 == cut_u) park_acc();
+        AR_PHASE(1);
+        if (CUT && u + 4 == cut_u) park_acc();
+        AR_PHASE(2);
+        if (CUT && u + 6 == cut_u) park_acc();
+        AR_PHASE(3);
+        if (CUT && u + 8 == cut_u) park_acc();
+    }
+    if (grp == 0) bar();
+    wait_vm<0>();
+    if (CUT && cut_u > 0) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                const float4 p = *reinterpret_cast<const float4*>(park + (mi * 8 + ni) * 4);
+                acc[mi][ni][0] += p.x; acc[mi][ni][1] += p.y; acc[mi][ni][2] += p.z; acc[mi][ni][3] += p.w;
+            }
+    }
+#undef AR_PHASE
+#undef AR_RD
+#undef AR_MMA
+#undef AR_MMA4
+#undef AR_PIN
+
+    const int mrow = lane & 15, ncol = 4 * (lane >> 4);
+    if (SPLITK) {
+        const bool compact = a.tile0 > 0;
+        float* wsp = compact ? a.ws + ((int64_t)(blockIdx.x / a.nsplit) * a.nsplit + sp) * (GB * GB) : a.ws + (int64_t)sp * a.M * a.N;
+        const int64_t wld = compact ? GB : a.N;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int64_t m = (compact ? 0 : m0) + wm * 64 + mi * 16 + mrow;
+            float* rowp = wsp + m * wld + (compact ? 0 : n0) + wn * 128 + ncol;
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+                st16f(rowp + ni * 16, make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]));
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 16 + mrow;
+        uint16_t* rowp = a.W + m * a.ldw + n0 + wn * 128 + ncol;
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+            uint16_t* p = rowp + ni * 16;
+            float v0 = acc[mi][ni][0], v1 = acc[mi][ni][1], v2 = acc[mi][ni][2], v3 = acc[mi][ni][3];
+            if (a.accumulate) {
+                const uint2 old = *reinterpret_cast<const uint2*>(p);
+                v0 += bf16_lo(old.x); v1 += bf16_hi(old.x); v2 += bf16_lo(old.y); v3 += bf16_hi(old.y);
+            }
+            uint2 o;
+            o.x = pack_bf16x2(v0, v1);
+            o.y = pack_bf16x2(v2, v3);
+            *reinterpret_cast<uint2*>(p) = o;
+        }
+    }
+}
+
 #ifdef AR_GEMM_EXPERIMENTS
 // ---- v4: four waves, one per SIMD, 128 x 128 per wave; operands staged through registers -------------------------------------
 // What v3 taught (profiles/r02_gemm_dw_ablation.jsonl, r02_gemm_dw_pmc.json): with eight waves the fragment reads move 6 KB of LDS
@@ -1074,7 +1315,7 @@ __global__ __launch_bounds__(kTPB) void k_splitk_reduce_tiles(GemmArgs a) {
 static int g_gemm_kernel = 7;     // 0: v0  1: v1 staggered  2: v1 lockstep  3: v2 (split reads)  4-6: timing ablations  7: v3 (DMA in the MFMA cluster)
 static int g_gemm_tail = 1;       // hybrid split of the last partial round (ar_gemm_dw_config(20 | 21) switches it for the A/B)
 static int g_gemm_sem = 1, g_gemm_order = 2;    // rule 1 is what the hardware does (profiles/r02_mfma_probe.json)
-static int g_gemm_dmal = 0;       // DMA pieces at the end of the L part (ar_gemm_dw_config(30 | 31) switches it for the A/B)
+static int g_gemm_dmal = 2;       // 2: v6 (16x16x32, the default since round 5);  0: v3 (32x32x16);  1: v3 with the DMA pieces at the end of the L part   (ar_gemm_dw_config(32 | 30 | 31))
 
 }  // namespace ar
 
@@ -1086,12 +1327,13 @@ extern "C" int ar_gemm_dw_config(int sem, int order) {      // experiment knobs 
     if (sem >= 10 && sem <= 19) g_gemm_kernel = sem - 10;       // 10: v0, 11: v1 staggered, 12: v1 lockstep, 14-16: ablations, 17: v3, 18 / 19: v4
 #endif
     if (sem == 20 || sem == 21) g_gemm_tail = sem - 20;
-    if (sem == 30 || sem == 31) g_gemm_dmal = sem - 30;
+    if (sem >= 30 && sem <= 32) g_gemm_dmal = sem - 30;
     if (order >= 0 && order <= 2) g_gemm_order = order;
     return g_gemm_kernel * 100 + g_gemm_sem * 10 + g_gemm_order;
 }
 
-// kernel of a given form with the DMA pieces in the M part (round 2-4) or at the end of the L part (round 5), by the A/B knob
+// kernel of a given form, by the A/B knob ar_gemm_dw_config(30 | 31 | 32): v3 with the DMA pieces in the M part (rounds 2-4), v3 with
+// them at the end of the L part (round 5, slower), v6 = the 16x16x32 form (round 5)
 typedef void (*dw4_fn)(GemmArgs);
 template <bool SPLITK, bool TAIL, bool CUT, bool GROUPED>
 static dw4_fn dw4_kernel() {
@@ -1099,7 +1341,9 @@ static dw4_fn dw4_kernel() {
     if (once.first()) {
         (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, SPLITK, TAIL, CUT, GROUPED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         (void)hipFuncSetAttribute((const void*)k_gemm_dw4<true, SPLITK, TAIL, CUT, GROUPED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute((const void*)k_gemm_dw6<SPLITK, TAIL, CUT, GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     }
+    if (g_gemm_dmal == 2) return k_gemm_dw6<SPLITK, TAIL, CUT, GROUPED>;
     return g_gemm_dmal ? k_gemm_dw4<true, SPLITK, TAIL, CUT, GROUPED, true> : k_gemm_dw4<true, SPLITK, TAIL, CUT, GROUPED, false>;
 }
 

@@ -34,6 +34,7 @@ namespace ar {
 
 typedef __bf16 nt_bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float nt_f32x16_t __attribute__((ext_vector_type(16)));
+typedef float nt_f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int NT_B = 256;                      // tile edge
 constexpr int NT_K = 64;                       // k per stage
@@ -68,8 +69,14 @@ __device__ __forceinline__ void nt_wait_vm() {
 // TRACE (ar_gemm_nt_trace, tools only): every wave sums, over all its phases, the shader cycles (s_memtime) it spends in the four segments
 // of a phase -- fragment reads until they have returned; parked at the barrier that ends the L part; the 16 MFMAs (+ DMA issues) until
 // the last one is issued; parked at the barrier that ends the M part -- the per-phase cycle table of DESIGN.md section 3.
-template <bool GROUPED, bool DMAL, bool TRACE = false>
+// M16 (round 5): the same kernel on v_mfma_f32_16x16x32_bf16 -- the shape this chip sustains at a higher clock on random operands
+// (tools/mfma_power.hip; the note at k_gemm_dw6 in ar_gemm.hip).  Same LDS image, same DMA protocol; a phase is still K = 32 and 12
+// fragment reads, now one ds_read_b128 per 16-row fragment (lane = row lane % 16, k chunk lane / 16: the operand's k = 8 (lane / 16) + j
+// layout; 8 A + 4 B fragments), then 32 MFMAs into acc[8][4] of 16 x 16; a lane owns output row m = lane % 16 of a fragment and the
+// 4 consecutive n = 4 (lane / 16) .. +3.
+template <bool GROUPED, bool DMAL, bool TRACE = false, bool M16 = false>
 __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
+    static_assert(!(M16 && DMAL), "the 16x16x32 form keeps the DMA pieces in the MFMA part");
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -173,13 +180,31 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
             }
     }
 
-    nt_f32x16_t acc[4][2];
+    uint32_t adA16[2], adB16[2];      // M16: row = 16 f + lane % 16 (fragment f by immediate offset), chunk (4 AH + lane / 16) ^ ((lane % 16) >> 1)
+    {
+        const int l15 = lane & 15, kg = lane >> 4, s = l15 >> 1;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int ah = 0; ah < 2; ++ah) {
+            const uint32_t X = l15 * 128 + 16 * ((4 * ah + kg) ^ s);
+            adA16[ah] = lds0 + wr * 32768 + X;
+            adB16[ah] = lds0 + 65536 + (wc >> 1) * 32768 + (wc & 1) * 8192 + X;
+        }
+    }
+
+    nt_f32x16_t acc[M16 ? 1 : 4][2];
+    nt_f32x4_t acc16[M16 ? 8 : 1][4];
+#pragma unroll
+    for (int mi = 0; mi < (M16 ? 1 : 4); ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < (M16 ? 8 : 1); ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc16[mi][ni][r] = 0.f;
 
     // one piece (1 KB: 8 rows x 128 B) of a stream; SO = byte offset of the stage buffer (0 / 16384), J = piece
 #define NT_ISSUE_X(SO, J)                                                                                               \
@@ -209,6 +234,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     };
     u32x4_t fa[2][4], fb[2][2];
+    u32x4_t fa16[8], fb16[4];
     unsigned long long tr_acc[4] = {0, 0, 0, 0}, tr_last = 0, tr_begin = 0, tr_wall = 0;
 #define NT_TRACE(I)                                                                                                     \
     do {                                                                                                                \
@@ -223,6 +249,38 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
 #define NT_MMA(U, MI, NI)                                                                                               \
     acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nt_bf16x8_t, fb[U][NI]),                   \
                                                           __builtin_bit_cast(nt_bf16x8_t, fa[U][MI]), acc[MI][NI], 0, 0, 0)
+#define NT_MMA16(MI, NI)                                                                                                \
+    acc16[MI][NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nt_bf16x8_t, fb16[NI]),                  \
+                                                            __builtin_bit_cast(nt_bf16x8_t, fa16[MI]), acc16[MI][NI], 0, 0, 0)
+#define NT_MMA16R(MI) NT_MMA16(MI, 0); NT_MMA16(MI, 1); NT_MMA16(MI, 2); NT_MMA16(MI, 3)
+#define NT_PHASE16(S)                                                                                                   \
+    do {                                                                                                                \
+        constexpr int SG = (S) >> 1, AH = (S) & 1, O = SG * 16384;                                                      \
+        constexpr int OI = AH ? O : (16384 - O);                                                                        \
+        NT_RD(fb16[0], adB16[AH], O);         NT_RD(fb16[1], adB16[AH], O + 2048);                                      \
+        NT_RD(fb16[2], adB16[AH], O + 4096);  NT_RD(fb16[3], adB16[AH], O + 6144);                                      \
+        NT_RD(fa16[0], adA16[AH], O);         NT_RD(fa16[1], adA16[AH], O + 2048);                                      \
+        NT_RD(fa16[2], adA16[AH], O + 4096);  NT_RD(fa16[3], adA16[AH], O + 6144);                                      \
+        NT_RD(fa16[4], adA16[AH], O + 8192);  NT_RD(fa16[5], adA16[AH], O + 10240);                                     \
+        NT_RD(fa16[6], adA16[AH], O + 12288); NT_RD(fa16[7], adA16[AH], O + 14336);                                     \
+        if (AH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+        NT_TRACE(0);                                                                                                    \
+        bar();                                                                                                          \
+        NT_TRACE(1);                                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        NT_MMA16R(0); NT_PIN(); if (AH) NT_ISSUE_X(OI, 0); else NT_ISSUE_Y(OI, 0); NT_PIN();                            \
+        NT_MMA16R(1); NT_MMA16R(2); NT_PIN(); if (AH) NT_ISSUE_X(OI, 1); else NT_ISSUE_Y(OI, 1); NT_PIN();              \
+        NT_MMA16R(3); NT_MMA16R(4); NT_PIN(); if (AH) NT_ISSUE_X(OI, 2); else NT_ISSUE_Y(OI, 2); NT_PIN();              \
+        NT_MMA16R(5); NT_MMA16R(6); NT_PIN();                                                                           \
+        if (AH) { NT_ISSUE_X(OI, 3); NT_ADV_X(); } else { NT_ISSUE_Y(OI, 3); NT_ADV_Y(); } NT_PIN();                    \
+        NT_MMA16R(7);                                                                                                   \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        if (AH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                        \
+        NT_TRACE(2);                                                                                                    \
+        bar();                                                                                                          \
+        NT_TRACE(3);                                                                                                    \
+    } while (0)
     // phase S of the loop body (0..3): stage parity SG = S >> 1, K half AH = S & 1
 #define NT_PHASE(S)                                                                                                     \
     do {                                                                                                                \
@@ -278,10 +336,17 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
     if (wr == 1) bar();
     if (TRACE) { tr_wall = __builtin_amdgcn_s_memrealtime(); tr_begin = tr_last = __builtin_readcyclecounter(); }
     for (int t = 0; t < T; t += 2) {
-        NT_PHASE(0);
-        NT_PHASE(1);
-        NT_PHASE(2);
-        NT_PHASE(3);
+        if constexpr (M16) {
+            NT_PHASE16(0);
+            NT_PHASE16(1);
+            NT_PHASE16(2);
+            NT_PHASE16(3);
+        } else {
+            NT_PHASE(0);
+            NT_PHASE(1);
+            NT_PHASE(2);
+            NT_PHASE(3);
+        }
     }
     if (TRACE && a.trace && lane == 0) {
         unsigned long long* o = a.trace + ((size_t)blockIdx.x * 8 + wave) * 8;
@@ -293,6 +358,9 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
     if (wr == 0) bar();
     nt_wait_vm<0>();          // no LDS-DMA may outlive the workgroup's LDS allocation
 #undef NT_PHASE
+#undef NT_PHASE16
+#undef NT_MMA16R
+#undef NT_MMA16
 #undef NT_MMA
 #undef NT_RD
 #undef NT_PIN
@@ -305,10 +373,27 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt(NtArgs a) {
 #undef NT_ADV_X
 #undef NT_ADV_Y
 
+    if constexpr (M16) {      // lane owns row m = m0 + wr*128 + mi*16 + lane % 16; n = n0 + wc*64 + ni*16 + 4 (lane / 16) + r
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int ml = wr * 128 + mi * 16 + (lane & 15);
+            if (ml < rows_valid) {
+                uint16_t* rowp = a.C + (m0 + ml) * a.ldc + n0 + wc * 64 + 4 * (lane >> 4);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    uint2 o;
+                    o.x = pack_bf16x2(acc16[mi][ni][0], acc16[mi][ni][1]);
+                    o.y = pack_bf16x2(acc16[mi][ni][2], acc16[mi][ni][3]);
+                    *reinterpret_cast<uint2*>(rowp + ni * 16) = o;
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: lane owns row m = m0 + wr*128 + mi*32 + (lane & 31); n = n0 + wc*64 + ni*32 + 8*t + 4*(lane >> 5) + r
     const int h = lane >> 5;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < (M16 ? 1 : 4); ++mi) {
         const int ml = wr * 128 + mi * 32 + (lane & 31);
         if (ml < rows_valid) {
             uint16_t* rowp = a.C + (m0 + ml) * a.ldc + n0 + wc * 64 + 4 * h;
@@ -541,10 +626,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_nt2(NtArgs a) {
 
 using namespace ar;
 
-static int g_nt_dmal = 0;        // 1: the DMA pieces at the end of the L part (ar_gemm_nt_config)
+static int g_nt_dmal = 3;        // 3: the 16x16x32 form (default since round 5); 0: 32x32x16; 1: 32x32x16 with the DMA pieces at the end of the L part; 2: nt2
 // experiment knob (binding hygiene, tools/gpu/r05_gemm_nt_probe.py): variant 0 / 1 selects where the LDS-DMA pieces are issued; -1 keeps.
 extern "C" int ar_gemm_nt_config(int variant) {
-    if (variant >= 0 && variant <= 2) g_nt_dmal = variant;        // 2: nt2 (one wave per SIMD, 128 x 128 per wave)
+    if (variant >= 0 && variant <= 3) g_nt_dmal = variant;        // 2: nt2 (one wave per SIMD, 128 x 128 per wave); 3: 16x16x32
     return g_nt_dmal;
 }
 
@@ -556,7 +641,9 @@ static nt_fn nt_kernel() {
         (void)hipFuncSetAttribute((const void*)k_gemm_nt<GROUPED, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
         (void)hipFuncSetAttribute((const void*)k_gemm_nt<GROUPED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
         (void)hipFuncSetAttribute((const void*)k_gemm_nt2<GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+        (void)hipFuncSetAttribute((const void*)k_gemm_nt<GROUPED, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
     }
+    if (g_nt_dmal == 3) return k_gemm_nt<GROUPED, false, false, true>;
     if (g_nt_dmal == 2) return k_gemm_nt2<GROUPED>;
     return g_nt_dmal ? k_gemm_nt<GROUPED, true> : k_gemm_nt<GROUPED, false>;
 }
@@ -624,8 +711,10 @@ extern "C" int ar_gemm_nt_trace(const void* A, const void* B, void* C, int64_t M
     if (once.first()) {
         (void)hipFuncSetAttribute((const void*)k_gemm_nt<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
         (void)hipFuncSetAttribute((const void*)k_gemm_nt<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
+        (void)hipFuncSetAttribute((const void*)k_gemm_nt<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS);
     }
-    if (variant) hipLaunchKernelGGL((k_gemm_nt<false, true, true>), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
+    if (variant == 3) hipLaunchKernelGGL((k_gemm_nt<false, false, true, true>), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
+    else if (variant) hipLaunchKernelGGL((k_gemm_nt<false, true, true>), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_gemm_nt<false, false, true>), a.tiles_m * a.tiles_n, NT_THREADS, NT_LDS, (hipStream_t)stream, a);
     return launch_status();
 }

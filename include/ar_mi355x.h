@@ -404,7 +404,9 @@ int ar_gemm_nt_config(int variant);
 int ar_gemm_nt_trace(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                      unsigned long long* trace, int variant, ar_stream_t stream);
 /* experiment knobs of the kernel above for tools/gemm_dw_probe.py (binding hygiene; -1 keeps a value): sem = lane->piece rule
- * of the transposing LDS read (1 | 2), order = tile order (0 identity, 1 XCD chunks, 2 XCD 2x8 patches).  Returns sem*10+order. */
+ * of the transposing LDS read (1 | 2), order = tile order (0 identity, 1 XCD chunks, 2 XCD 2x8 patches); sem 20 | 21 = hybrid split of the
+ * last partial round off | on; sem 32 | 30 | 31 = the kernel on v_mfma_f32_16x16x32_bf16 (default since round 5) | on 32x32x16 (rounds
+ * 2-4) | on 32x32x16 with the LDS-DMA issued outside the MFMA cluster -- all three produce identical bits.  Returns sem*10+order. */
 int ar_gemm_dw_config(int sem, int order);
 
 /* ---- causal attention forward (hand-written MFMA flash attention, gfx950) ------------------------------------------

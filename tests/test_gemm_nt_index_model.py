@@ -20,6 +20,8 @@ def test_the_model_restates_the_kernels_formulas():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "auto_round_amd", "csrc", "ar_gemm_nt.hip")).read()
     for frag in ("pc ^ ((4 * j + (lane >> 4)) & 7)", "l31 * 128 + 16 * ((4 * ah + 2 * u + h) ^ s)", "(l31 >> 1) & 7",
                  "lds0 + 65536 + (wc >> 1) * 32768 + (wc & 1) * 8192 + X", "lds0 + wr * 32768 + wc * 32 * 128",
+                 # the 16x16x32 form
+                 "l15 * 128 + 16 * ((4 * ah + kg) ^ s)", "adB16[ah] = lds0 + 65536 + (wc >> 1) * 32768 + (wc & 1) * 8192 + X;",
                  # nt2
                  "const int row = wave * 64 + 8 * j + (lane >> 3);", "lds0 + (wave >> 1) * 32768 + (wave & 1) * 64 * 128", "l31 * 128 + 16 * ((2 * u + h) ^ s)",
                  "adB[u] = lds0 + 65536 + wc * 32768 + X;"):

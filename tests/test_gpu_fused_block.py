@@ -131,6 +131,55 @@ def test_gemm_dw_vs_fp32_reference_including_strides_and_accumulation(K, M, N):
     assert ops.gemm_dw(dY[:, :M - 8], X, torch.empty(M - 8, N, dtype=torch.bfloat16, device=_dev())) is False
 
 
+@pytest.mark.parametrize("K,M,N", [(256, 512, 256), (1000, 256, 512), (4096, 768, 768), (8192, 1024, 2048)])
+def test_gemm_dw_on_16x16x32_and_on_32x32x16_mfma_give_the_same_bits_in_every_form(K, M, N):
+    """Round 5: the default weight-gradient kernel is built on v_mfma_f32_16x16x32_bf16 (k_gemm_dw6: the shape the chip sustains at a
+    higher clock, tools/mfma_power.hip); the round 2-4 kernel on 32x32x16 stays selectable (ar_gemm_dw_config(30)).  Both sum K in
+    ascending order with one rounding -- one pass, forced slices, the launch-shape plans, a cut table, accumulate, grouped: identical
+    bits, and run-to-run identical."""
+    from auto_round_amd import _lib, ops
+
+    lib = _lib.load()
+    dY, X = _rand(K, M, seed=40), _rand(K, N, seed=41)
+    tiles = (M // 256) * (N // 256)
+    kcut = torch.zeros(tiles, dtype=torch.int32, device=_dev())
+    if K >= 1024:
+        kcut[0], kcut[tiles - 1] = 32, (K // 64) * 32
+    counts = [K // 3, 0, K - K // 3 - 5, 5]
+    row_off = torch.tensor([0] + torch.tensor(counts).cumsum(0).tolist(), dtype=torch.int32, device=_dev())
+    w_off = torch.arange(len(counts), dtype=torch.int64, device=_dev()) * (M * N)
+    got = {}
+    try:
+        for code in (32, 30):
+            lib.ar_gemm_dw_config(code, -1)
+            outs = []
+            for split in (True, False) + ((2, 3) if K >= 1024 else ()):
+                o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=_dev())
+                assert ops.gemm_dw(dY, X, o, split=split)
+                outs.append(o)
+            acc = _rand(M, N, seed=42)
+            assert ops.gemm_dw(dY, X, acc, accumulate=True, split=False)
+            outs.append(acc)
+            sk = torch.empty(M, N, dtype=torch.bfloat16, device=_dev())
+            assert ops.gemm_dw_sk(dY, X, sk, kcut)
+            outs.append(sk)
+            if M % 256 == 0 and N % 256 == 0:
+                grp = torch.full((len(counts) * M, N), float("nan"), dtype=torch.bfloat16, device=_dev())
+                assert ops.gemm_dw_grouped(dY, X, grp, row_off, w_off, N)
+                outs.append(grp)
+            again = torch.empty(M, N, dtype=torch.bfloat16, device=_dev())
+            assert ops.gemm_dw(dY, X, again, split=False)
+            assert torch.equal(again.view(torch.int16), outs[1].view(torch.int16)), "two launches, different bits"
+            got[code] = outs
+    finally:
+        lib.ar_gemm_dw_config(32, -1)
+    ref = dY.float().t() @ X.float()
+    assert torch.allclose(got[32][1].float(), ref, rtol=1e-2, atol=1e-2)
+    for a, b in zip(got[32], got[30]):
+        assert not torch.isnan(a.float()).any()
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
 def _llama_layer(hidden=256, ffn=512, heads=4, kv_heads=2, seed=0, bits=4, gs=32):
     from transformers import LlamaConfig
     from transformers.models.llama.modeling_llama import LlamaDecoderLayer, LlamaRotaryEmbedding

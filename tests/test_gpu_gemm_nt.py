@@ -20,7 +20,7 @@ def _bits(a, b):
     return int((a.contiguous().view(torch.int16) != b.contiguous().view(torch.int16)).sum())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 512, 384), (37, 256, 256), (4096, 1024, 4096), (16384, 4096, 4096)])
 def test_gemm_nt_matches_fp32_and_the_library_and_is_reproducible(M, N, K, variant):
     from auto_round_amd import _lib, ops

@@ -133,6 +133,68 @@ def epilogue_cover_nt2():
     return bool((hit == 1).all())
 
 
+# ---- the 16x16x32 form (k_gemm_nt<.., M16 = true>): same LDS image and DMA; fragment f (16 rows) of K half a: lane (l15 = lane & 15,
+# kg = lane >> 4) reads row 16 f + l15 at physical chunk (4 a + kg) ^ (l15 >> 1); fragments are immediate offsets f * 2048
+def frag_offset_m16(lane, a):
+    l15, kg = lane & 15, lane >> 4
+    return l15 * 128 + 16 * ((4 * a + kg) ^ (l15 >> 1))
+
+
+def check_reads_m16(lds, t, sg):
+    seen_a, seen_b = set(), set()
+    for wave in range(8):
+        wr, wc = wave >> 2, wave & 3
+        for a in (0, 1):
+            for lane in range(64):
+                l15, kg = lane & 15, lane >> 4
+                x = frag_offset_m16(lane, a)
+                for f in range(8):
+                    op, row, ch = lds[(halfbase(0, wr, 0) + x + sg * 16384 + f * 2048) // 16]
+                    assert (op, row, ch) == (0, wr * 128 + f * 16 + l15, t * 8 + 4 * a + kg)
+                    seen_a.add((row, ch))
+                for f in range(4):
+                    op, row, ch = lds[(65536 + (wc >> 1) * 32768 + (wc & 1) * 8192 + x + sg * 16384 + f * 2048) // 16]
+                    assert (op, row, ch) == (1, wc * 64 + f * 16 + l15, t * 8 + 4 * a + kg)
+                    seen_b.add((row, ch))
+    assert len(seen_a) == 256 * 8 and len(seen_b) == 256 * 8
+
+
+def worst_bank_multiplicity_m16():
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[x + 32 for x in g] for g in groups]
+    worst = 0
+    for a in (0, 1):
+        for g in groups:
+            slots = {}
+            for lane in g:
+                x = frag_offset_m16(lane, a)
+                slots.setdefault((x // 16) % 16, set()).add(x)
+            worst = max(worst, max(len(v) for v in slots.values()))
+    return worst
+
+
+def epilogue_cover_m16():
+    """lane owns row wr*128 + mi*16 + lane % 16, columns wc*64 + ni*16 + 4 (lane / 16) + r (register r of acc16[mi][ni])"""
+    hit = np.zeros((256, 256), dtype=np.int32)
+    for wave in range(8):
+        wr, wc = wave >> 2, wave & 3
+        for lane in range(64):
+            for mi in range(8):
+                for ni in range(4):
+                    for r in range(4):
+                        hit[wr * 128 + mi * 16 + (lane & 15), wc * 64 + ni * 16 + 4 * (lane >> 4) + r] += 1
+    return bool((hit == 1).all())
+
+
+def main_m16():
+    lds = np.full((131072 // 16, 3), -1, dtype=np.int64)
+    dma_stage(lds, 0, 0)
+    dma_stage(lds, 1, 1)
+    check_reads_m16(lds, 0, 0)
+    check_reads_m16(lds, 1, 1)
+    return worst_bank_multiplicity_m16(), epilogue_cover_m16()
+
+
 def main_nt2():
     lds = np.full((131072 // 16, 3), -1, dtype=np.int64)
     dma_stage_nt2(lds, 0, 0)
@@ -157,9 +219,10 @@ def main():
     w = worst_bank_multiplicity()
     ok = epilogue_cover()
     ok2 = main_nt2()
+    w16, ok16 = main_m16()
     print(f"mapping ok; worst distinct addresses per 16-byte bank slot within a lane group: {w}; epilogue covers the tile exactly once: {ok}; "
-          f"nt2 mapping ok, epilogue: {ok2}")
-    return w, ok and ok2
+          f"nt2 mapping ok, epilogue: {ok2}; 16x16x32 form: mapping ok, worst {w16}, epilogue: {ok16}")
+    return max(w, w16), ok and ok2 and ok16
 
 
 if __name__ == "__main__":
