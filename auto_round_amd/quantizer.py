@@ -281,16 +281,20 @@ class SignRoundConfig:
     # attention mask for every sample, ...) materialised at the minibatch's own row count -- what the reference's per-sample input
     # cache produces by concatenation (block_runner.py:368-422: an [8, 1, S, S] mask, not a broadcastable [1, 1, S, S]).  Same values;
     # the library's attention picks another kernel for a batch-broadcast mask and returns other last bits at some shapes: Llama-3-8B's
-    # are unaffected, but OPT-125M's block and Mixtral-8x7B's parted from the reference for exactly this reason (round 5: with the mask
-    # materialised the reference-free flow reproduces the reference's targets and results at both).  ON by default since round 5 --
-    # results identical to the reference's come first; the cost is one [batch, 1, S, S] copy per block forward (67 MB at 8 x 2048).
+    # are unaffected, but OPT-125M's block parted from the reference for exactly this reason (round 5: with the mask materialised -- and
+    # torch's deterministic-algorithms mode on, as the reference's constructor leaves it -- the reference-free flow reproduces the
+    # reference's targets and results bit for bit there; Mixtral-8x7B's targets still differ in 0.7 % of the attention output's last
+    # bits).  ON by default since round 5 -- results identical to the reference's come first; the cost is one
+    # [batch, 1, S, S] copy per block forward (67 MB at 8 x 2048).
     materialise_shared_rows: bool = True
     # Llama-family blocks through first-party kernels that keep the MODULE PATH'S BITS (auto_round_amd/exact_block.py,
     # csrc/ar_exact.hip): eager torch's rounding points and reduction order in the elementwise kernels, the module path's GEMM
     # shapes plus whichever faster GEMM forms prove bit-equal on this GPU / software stack.  Verified against the module code on
     # one real minibatch per kind of block before it is used; where the proof fails the module path runs.  Takes precedence over
     # `fused_block` (whose rounding points differ): with this switch on a block is never tuned on a path that is not bit-identical
-    # to the module path.
+    # to the module path.  The proof is a one-off cost per kind of block (classes, every linear's shape and dtype, minibatch shape,
+    # mask): about 50 forward + backward passes with clones of the weight gradients -- ~1.5 s at Llama-3-8B's block dimensions, ~10 s
+    # at Llama-3-70B's -- after which every later block of that kind is a dictionary lookup.
     exact_rounding: bool = False
 
     def __post_init__(self):
