@@ -511,6 +511,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the opt125m and variants objects")
+    ap.add_argument("--gemm-mfma", type=int, default=16, choices=[16, 32],
+                    help="A/B knob: the first-party GEMM kernels on v_mfma_f32_16x16x32_bf16 (default) or on 32x32x16 (rounds 2-4); same bits")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -550,6 +552,10 @@ def main():
             _lib.build()
         if dist is not None:
             dist.barrier()
+
+    if args.gemm_mfma == 32:
+        _lib.load().ar_gemm_dw_config(30, -1)
+        _lib.load().ar_gemm_nt_config(0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -642,6 +648,7 @@ def main():
                        "hip_graph": bool(getattr(b.quantizer, "last_hip_graph", False)),
                        "sdpa_backend": b.sdpa, "alg_ext": bool(args.alg_ext),
                        "deterministic_algorithms": "warn_only (as the reference's front door sets it)",
+                       "first_party_gemm_mfma": f"v_mfma_f32_{'16x16x32' if args.gemm_mfma == 16 else '32x32x16'}_bf16",
                        "attention_mask": ("calibration: the [1, 1, S, S] 0/1 additive mask of the reference's calibration flow "
                                           "(calibration/llm.py:360-402, inputs.py:100-107) -- the attention is the library's (torch SDPA), as in the reference"
                                           if args.mask == "calibration" else
