@@ -579,8 +579,7 @@ class SignRoundQuantizer:
                     others_b = {**input_others, **{k: t.index_select(0, idx) for k, t in per_sample_others.items()}}
                 ctx = None
                 if direct:          # captured iterations: the fused block's own forward / backward, no autograd graph in between
-                    # (an exact block gets its shared tensors in the form its proof ran with, as in the host-driven branch below)
-                    pred, ctx = fused.forward_direct(x, self._others_for(nb, others_b) if self.last_exact else others_b, donate_input=True)
+                    pred, ctx = fused.forward_direct(x, others_b, donate_input=True)      # (exact blocks are never captured: capturable = False)
                 else:
                     if fused is not None:
                         pred = fused.forward(x, self._others_for(nb, others_b) if self.last_exact else others_b, donate_input=True)
