@@ -7,6 +7,7 @@
 //
 // Design (CDNA4-first):
 //   * 256x256 output tile per 512-thread workgroup (8 waves = 2 per SIMD), wave tile 64(m) x 128(n), v_mfma_f32_32x32x16_bf16
+//     (k_gemm_dw4, rounds 2-4) or v_mfma_f32_16x16x32_bf16 (k_gemm_dw6, round 5: the default -- identical bits, 6-10 % faster)
 //     computing the TRANSPOSED tile (a-operand = X fragment, b-operand = dY fragment): every lane then owns, for ONE output
 //     row m, runs of 4 consecutive n -- 8-byte stores, and a quant group (128 consecutive n of one row) lives in one lane
 //     pair, which is what the fused backward + sign-SGD epilogue wants.

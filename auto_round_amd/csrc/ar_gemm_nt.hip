@@ -9,8 +9,9 @@
 //
 // Not the weight-gradient kernel (csrc/ar_gemm.hip) fed transposed operands -- round 3's A/B -- but a kernel designed for K-contiguous
 // rows (CDNA4-first):
-//   * 256 x 256 output tile per 512-thread workgroup, 8 waves as 2 (m) x 4 (n), wave tile 128 x 64 = acc[4][2] of
-//     v_mfma_f32_32x32x16_bf16 (a-operand = B rows, b-operand = A rows: a lane then owns ONE output row and runs of 4 consecutive n).
+//   * 256 x 256 output tile per 512-thread workgroup, 8 waves as 2 (m) x 4 (n), wave tile 128 x 64 = acc[8][4] of
+//     v_mfma_f32_16x16x32_bf16 in the default form (M16; acc[4][2] of v_mfma_f32_32x32x16_bf16 in the round-5 first cut, still
+//     selectable: identical bits) -- a-operand = B rows, b-operand = A rows: a lane then owns ONE output row and runs of 4 consecutive n.
 //   * K is staged 64 deep: a stage is four HALF-tiles of [128 rows][128 bytes] (A rows 0-127 / 128-255, B rows likewise), 16 KB each,
 //     two stages in 128 KB of LDS.  Every row of a half-tile is one full 128-byte line of HBM -- LDS-DMA (global_load_lds, 16 bytes
 //     per lane, no staging VGPRs) moves 8 rows per wave-instruction.

@@ -394,8 +394,10 @@ int ar_gemm_nt(const void* A, const void* B, void* C, int64_t M, int64_t N, int6
  * M / 256 + n_groups row tiles (every group may end in a partial tile); workgroups past the last real tile exit.  Deterministic. */
 int ar_gemm_nt_grouped(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                        const int32_t* row_off, const int64_t* b_off, int n_groups, ar_stream_t stream);
-/* experiment knob of the two entry points above for tools/gpu/r05_gemm_nt_probe.py (binding hygiene): variant 0 = LDS-DMA pieces
- * issued between the MFMAs, 1 = at the end of the fragment-read part of every second phase; -1 keeps.  Returns the variant in use. */
+/* experiment knob of the two entry points above for tools/gpu/r05_gemm_nt*_probe.py (binding hygiene): variant 3 = the kernel on
+ * v_mfma_f32_16x16x32_bf16 (default since round 5), 0 = on 32x32x16 with the LDS-DMA pieces issued between the MFMAs, 1 = 32x32x16 with
+ * the pieces at the end of the fragment-read part of every second phase, 2 = 32x32x16 with one wave per SIMD and 128 x 128 wave tiles;
+ * all four produce identical bits; -1 keeps.  Returns the variant in use. */
 int ar_gemm_nt_config(int variant);
 /* measurement hygiene (tools/gpu/r05_gemm_nt_trace.py; no reference counterpart): ar_gemm_nt with s_memtime bookkeeping -- trace receives
  * [row tiles * column tiles][8 waves][8] uint64: shader cycles a wave spent, summed over its phases, in the fragment-read part, parked at
