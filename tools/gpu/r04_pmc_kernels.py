@@ -12,7 +12,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
-def summarise(path):
+def summarise(path, names=("k_gemm_dw4", "k_attn_fwd", "k_attn_bwd", "Cijk", "attn_fwd", "bwd_kernel", "fmha")):
     per = {}
     with open(path) as f:
         for r in csv.DictReader(f):
@@ -25,7 +25,7 @@ def summarise(path):
             e[1] += 1
     out = {}
     for k, d in per.items():
-        if not any(t in k for t in ("k_gemm_dw4", "k_attn_fwd", "k_attn_bwd", "Cijk", "attn_fwd", "bwd_kernel", "fmha")):
+        if not any(t in k for t in names):
             continue
         rec = {c: e[0] / e[1] for c, e in d.items()}
         rec["dispatches"] = max(e[1] for e in d.values())
