@@ -19,7 +19,7 @@ def efficient_backward_ok(seq: int) -> bool:
     """torch 2.10 + ROCm 7.2: the backward of the "efficient" SDPA kernels (aiter fmha_bwd behind AOTriton) returns wrong
     gradients (relative error ~1, NaNs) for token-major [B, S, H, D] operands when S % 256 == 128 and S > 128 (384, 640, 896, ...);
     contiguous [B, H, S, D] operands and every other length checked are right, and so are the "flash" and "math" backends
-    (measured against fp32 autograd: tools/sdpa_backward_check.py, profiles/r02_sdpa_backward_check.json).  Callers route those
+    (measured against fp32 autograd: tools/sdpa_backward_check.py, profiles/archive/r02_sdpa_backward_check.json).  Callers route those
     lengths to the flash kernels."""
     return seq <= 128 or seq % 256 != 128
 

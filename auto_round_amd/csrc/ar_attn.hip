@@ -3,7 +3,7 @@
 // replaces: the attention forward of the decoder block inside the tuning loop -- transformers' sdpa_attention_forward
 //           (transformers/integrations/sdpa_attention.py) -> torch scaled_dot_product_attention, which on ROCm 7.2 / torch 2.10 is
 //           AOTriton's `attn_fwd`: 0.84 ms per call at the tuning minibatch (8 x 32 heads x 2048 x 128), 14 % MFMA utilisation
-//           (profiles/r02_llama8b_fused_pmc_MfmaUtil.csv).  The backward stays the library's (aiter fmha_bwd, 50 %): this kernel
+//           (profiles/archive/r02_llama8b_fused_pmc_MfmaUtil.csv).  The backward stays the library's (aiter fmha_bwd, 50 %): this kernel
 //           returns the output and the natural-log row sums in the layout aten::_scaled_dot_product_efficient_attention_backward
 //           takes (out [B,S,H,D] token-major, logsumexp [B,H,S] fp32).
 //

@@ -4,7 +4,7 @@
 // (auto_round/utils/device.py:112-122, compressors/base.py:1177-1179, "about 20 %") on the block code transformers runs eagerly:
 //   LlamaRMSNorm.forward, apply_rotary_pos_emb + repeat_kv, act_fn(gate) * up and their autograd backwards
 //   (transformers/models/llama/modeling_llama.py).  On MI355X these were ~90 launches and 20 % of a Llama-3-8B tuning iteration
-//   (profiles/r01_llama8b_block_kernel_stats.csv); here they are six streaming kernels, 16-byte accesses, one pass each.
+//   (profiles/archive/r01_llama8b_block_kernel_stats.csv); here they are six streaming kernels, 16-byte accesses, one pass each.
 //
 // Forward kernels round where the eager module code rounds (so the fused forward tracks transformers' bf16 forward closely);
 // backward kernels evaluate the exact fp32 derivative and round once.  All tensors are token-major: [tokens, features].

@@ -3,7 +3,7 @@
 // replaces: the autograd backward of F.linear(x, weight_q) w.r.t. weight_q inside WrapperLinear.forward
 //           (auto_round/wrapper.py:528-556) -- torch.mm(dY.t(), X), a "TN" GEMM whose two operands are both strided in the
 //           reduction dimension (tokens).  hipBLASLt runs it at ~1.0 PFLOP/s on MI355X (MT256x256x32, 47 % MFMA utilisation);
-//           it is 27 % of a Llama-3-8B tuning iteration (profiles/r01_llama8b_block_kernel_stats.csv).
+//           it is 27 % of a Llama-3-8B tuning iteration (profiles/archive/r01_llama8b_block_kernel_stats.csv).
 //
 // Design (CDNA4-first):
 //   * 256x256 output tile per 512-thread workgroup (8 waves = 2 per SIMD), wave tile 64(m) x 128(n), v_mfma_f32_32x32x16_bf16
@@ -84,7 +84,7 @@ __device__ __forceinline__ void wait_vm() {
 // switch the tuner's weight-gradient GEMM to another kernel.
 #ifdef AR_GEMM_EXPERIMENTS
 // SEM selects which (k-row, 4-column piece) a lane of a 16-lane group hands to the transposing read: 1 = row i>>2, piece i&3 --
-// the hardware's rule, pinned on the GPU by tools/mfma_probe (profiles/r02_mfma_probe.json: within a 16-lane group, lane L
+// the hardware's rule, pinned on the GPU by tools/mfma_probe (profiles/archive/r02_mfma_probe.json: within a 16-lane group, lane L
 // receives element L%4 of the 8-byte pieces supplied by lanes L/4, L/4+4, L/4+8, L/4+12); 2 = row i&3, piece i>>2 (kept as the
 // negative control of tools/gemm_dw_probe.py).
 template <int SEM>
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw2_abl(GemmArgs a) {
 #endif  // AR_GEMM_EXPERIMENTS
 
 // (v2 -- v1 with half of the fragment reads moved into the MFMA cluster so that both waves of a SIMD feed the LDS pipe all the
-//  time -- measured equal to v1 within noise on every shape, profiles/r02_gemm_dw_v2_split_reads_no_gain.jsonl, and was removed.)
+//  time -- measured equal to v1 within noise on every shape, profiles/archive/r02_gemm_dw_v2_split_reads_no_gain.jsonl, and was removed.)
 
 // ---- v3: v1 with the DMA pieces issued from inside the MFMA cluster (copy of the v1 setup) --------------------------------
 // SPLITK: few output tiles but a deep K (OPT-125M's 768x768 weight against 16384 tokens is 9 tiles): the grid is tiles x nsplit,
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw4(GemmArgs a) {
     // L part: the 24 fragment reads of this pair, then wait for them and for the wave's own DMA of the NEXT pair; M part: 16 MFMAs
     // with the 4 DMA pieces of pair S+3 issued in between (an LDS-DMA piece costs ~60 issue cycles among bare MFMAs but
     // 100-185 inside a phase that also carries the fragment reads -- in v1 the four of them made the L part longer than the
-    // partner's MFMA cluster: the no-DMA ablation of v1 ran 18-23 % faster, profiles/r02_gemm_dw_ablation.jsonl)
+    // partner's MFMA cluster: the no-DMA ablation of v1 ran 18-23 % faster, profiles/archive/r02_gemm_dw_ablation.jsonl)
 #define AR_PHASE(S)                                                                                                     \
     do {                                                                                                                \
         constexpr int H = (S) >> 1;                                                                                     \
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw6(GemmArgs a) {
 
 #ifdef AR_GEMM_EXPERIMENTS
 // ---- v4: four waves, one per SIMD, 128 x 128 per wave; operands staged through registers -------------------------------------
-// What v3 taught (profiles/r02_gemm_dw_ablation.jsonl, r02_gemm_dw_pmc.json): with eight waves the fragment reads move 6 KB of LDS
+// What v3 taught (profiles/archive/r02_gemm_dw_ablation.jsonl, r02_gemm_dw_pmc.json): with eight waves the fragment reads move 6 KB of LDS
 // per wave and K-step of 16 for 64x128 of output, and every LDS-DMA piece issued among the MFMAs stalls its wave for 60-185 issue
 // cycles -- the no-DMA ablation ran 15-20 % faster.  hipBLASLt's NT kernels (forward GEMMs, 1.5 PFLOP/s here) use the other
 // classical shape: 4 waves x (128 x 128), i.e. 8 KB of fragments per K-step for twice the output, 256 accumulator registers per
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void k_gemm_dw6(GemmArgs a) {
 // v4 is that shape for the TN problem: same [k][256] swizzled LDS image and transposing fragment reads as v0-v3; a K-unit of 16 per
 // phase = 16 MFMAs (512 matrix-pipe cycles) that shadow the 16 fragment reads of the next unit, the 4 ds_write_b128 of unit +3
 // and the 4 global_load_dwordx4 of unit +3+L (L units = 16*L registers of loads in flight); one s_barrier every second phase.
-// Result (profiles/r02_gemm_dw_v4_vs_v3.jsonl): bit-identical output, 1.19-1.33 PFLOP/s against v3's 1.23-1.36 on the same shapes,
+// Result (profiles/archive/r02_gemm_dw_v4_vs_v3.jsonl): bit-identical output, 1.19-1.33 PFLOP/s against v3's 1.23-1.36 on the same shapes,
 // so v3 stays the default and v4 is reachable only through ar_gemm_dw_config(18 | 19) for tools/gemm_dw_probe.py.  Its timing
 // ablations (r02_gemm_dw_v4_ablation.json) are the useful part: MFMAs + barriers alone 1.6-2.0 PFLOP/s (the matrix pipe at the
 // clock the chip sustains), without the LDS stores 1.45-1.55, without the loads 1.22-1.36, without the fragment reads 1.25-1.7 --
@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(kTPB) void k_splitk_reduce_tiles(GemmArgs a) {
 
 static int g_gemm_kernel = 7;     // 0: v0  1: v1 staggered  2: v1 lockstep  3: v2 (split reads)  4-6: timing ablations  7: v3 (DMA in the MFMA cluster)
 static int g_gemm_tail = 1;       // hybrid split of the last partial round (ar_gemm_dw_config(20 | 21) switches it for the A/B)
-static int g_gemm_sem = 1, g_gemm_order = 2;    // rule 1 is what the hardware does (profiles/r02_mfma_probe.json)
+static int g_gemm_sem = 1, g_gemm_order = 2;    // rule 1 is what the hardware does (profiles/archive/r02_mfma_probe.json)
 static int g_gemm_dmal = 2;       // 2: v6 (16x16x32, the default since round 5);  0: v3 (32x32x16);  1: v3 with the DMA pieces at the end of the L part   (ar_gemm_dw_config(32 | 30 | 31))
 
 }  // namespace ar

@@ -217,7 +217,7 @@ class FusedLlamaBlock:
         """Keep W^T next to the o / gate-up / down weights (refreshed by one transpose kernel each per iteration) so that the three
         input-gradient GEMMs dX = dY W run with both operands contiguous along the reduction -- the layout the library's tuned
         kernel covers (1.52-1.58 PFLOP/s against 1.02-1.35 for the K-strided form on the Llama-3-8B shapes,
-        profiles/r02_dx_gemm_layout_probe.json).  Costs one extra copy of those weights in HBM."""
+        profiles/archive/r02_dx_gemm_layout_probe.json).  Costs one extra copy of those weights in HBM."""
         self._tn = None
         if not on or self.arena is None:
             return
@@ -1199,7 +1199,7 @@ def build_fused_block_plain(block, input_others, amp_dtype=torch.bfloat16, sdpa_
 
 
 def mfma_dw_pays(M: int, N: int, K: int) -> bool:
-    """Where the hand-written weight-gradient GEMM beats hipBLASLt on MI355X (tools/gemm_dw_probe.py, profiles/r02_gemm_dw_*):
+    """Where the hand-written weight-gradient GEMM beats hipBLASLt on MI355X (tools/gemm_dw_probe.py, profiles/archive/r02_gemm_dw_*):
     256x256 tiles that fill the 256 CUs at least once, deep K."""
     # (few tiles x deep K go through the kernel's deterministic split-K form: OPT-125M's 768x768 / 3072x768 weights, k/v projections;
     #  a K that is not a multiple of 128 -- an expert's share of the tokens -- is completed with zero rows inside the kernel)

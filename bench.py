@@ -932,11 +932,11 @@ def run_opt125m(args, device, barrier, fused, with_cpu):
                                 "what": "the extra block the roofline objects below were timed on (per-dispatch events cost ~1 us per launch)"}
     rec.update(v.rooflines())
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_reference_cpu_opt125m_full_block.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "archive", "r01_reference_cpu_opt125m_full_block.json")) as f:
             ref = json.load(f)
         rec["cpu_reference_quoted"] = {"value": ref["reference_blocks_per_s"], "unit": "blocks/s", "cores": ref["threads"],
                                        "kind": "reference", "sec_per_block": ref["reference_whole_block_s_incl_cache_and_forwards"],
-                                       "source": "profiles/r01_reference_cpu_opt125m_full_block.json: the REAL reference's "
+                                       "source": "profiles/archive/r01_reference_cpu_opt125m_full_block.json: the REAL reference's "
                                                  "AutoRound(...).quantize() on the build container's 8 vCPUs (it does not exist on the GPU box)"}
         rec["speedup_vs_cpu_reference_quoted"] = rec["value"] / ref["reference_blocks_per_s"]
     except Exception:  # pragma: no cover

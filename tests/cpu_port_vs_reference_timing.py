@@ -1,7 +1,7 @@
 """Build container only: is the CPU baseline `bench.py` reports (kind "port": oracle/torch_ref timed on the host) representative
 of the REAL reference's CPU path?  Times the reference's own `AutoRound(...).quantize()` tuning loop and the restated flow
 (tests/pipeline_flow.py + oracle/torch_ref) on the same OPT-125M-shaped 2-block model, same calibration data, same iterations, same
-thread count, and prints seconds per tuning iteration for both.  -> profiles/r01_cpu_port_vs_reference_timing.json"""
+thread count, and prints seconds per tuning iteration for both.  -> profiles/archive/r01_cpu_port_vs_reference_timing.json"""
 import copy
 import json
 import os

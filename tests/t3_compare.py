@@ -8,7 +8,7 @@ Compared per block: the iteration-0 loss (identical fake-quant weights -> identi
 fraction of identical tuned weights / integer codes, and scale / zero-point equality where the codes agree.
 
 `run_case(...)` returns the numbers; tests/test_gpu_t3_reference.py asserts on them; `python tests/t3_compare.py --out f.json`
-writes the report committed as profiles/r02_t3_reference_on_mi355x.json.  Needs the reference tree (tests/ref_tree.py)."""
+writes the report committed as profiles/archive/r02_t3_reference_on_mi355x.json.  Needs the reference tree (tests/ref_tree.py)."""
 import copy
 import json
 import os

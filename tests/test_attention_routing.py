@@ -1,5 +1,5 @@
 """Host logic of auto_round_amd/attention.py and of the activation-quant plans (no GPU): which SDPA backend order a sequence length
-gets -- torch 2.10 / ROCm 7.2's efficient backward is wrong for token-major operands at S % 256 == 128 (profiles/r02_sdpa_backward_check.json)
+gets -- torch 2.10 / ROCm 7.2's efficient backward is wrong for token-major operands at S % 256 == 128 (profiles/archive/r02_sdpa_backward_check.json)
 -- and which fake-quant a layer's activation attributes select (reference: WrapperLinear._qdq_act, auto_round/wrapper.py:295-321)."""
 import types
 

@@ -3,7 +3,7 @@
 (v_mfma_f32_16x16x32_bf16).  The LDS image of a K-step of 32 (two units of 16 k-rows, each an X piece and a dY piece of [16][256]
 bf16) is filled the way the kernels' LDS-DMA lanes address it, then every transposing fragment read (ds_read_b64_tr_b16) of every wave
 is replayed with the hardware's rule -- within a 16-lane group, lane L receives element L % 4 of the 8-byte pieces supplied by lanes
-L / 4, L / 4 + 4, L / 4 + 8, L / 4 + 12 (profiles/r02_mfma_probe.json) -- and checked:
+L / 4, L / 4 + 4, L / 4 + 8, L / 4 + 12 (profiles/archive/r02_mfma_probe.json) -- and checked:
   * every lane gets, for its MFMA operand, the (column, 8 consecutive k) the instruction's layout wants
         32x32x16: column lane % 32 of the fragment, k = 8 (lane / 32) + j;   16x16x32: column lane % 16, k = 8 (lane / 16) + j;
   * every (k, column) of both pieces is read exactly as often as the wave grid implies;
