@@ -13,6 +13,9 @@
 //   m16_lds_dma   likewise on 16x16x32 (the VGPR-path arm does not fit 256 registers beside 32 accumulator tiles + double-buffered fragments)
 //   *_big_*      one wave per SIMD with 128 x 128 wave tiles (512 registers): half the fragment reads per flop
 // The load arms run twice: loads wrapping inside 2 MiB (L2 hits) and inside 64 MiB (no reuse).
+// Reading the output: `tflops` is the figure of merit.  `ticks_per_us` (s_memtime ticks of wave 0 per microsecond of kernel time) is the
+// shader clock only in the one-wave-per-SIMD (big) arms: with two waves per SIMD the older wave of a bare MFMA stream gets every issue
+// slot and finishes first, so wave 0's ticks cover about half the kernel.
 // Prints JSON lines.   hipcc --offload-arch=gfx950 -O3 tools/mfma_power.hip -o tools/bin/mfma_power
 #include <hip/hip_runtime.h>
 #include <stdint.h>
