@@ -19,6 +19,15 @@ import torch
 from . import ops
 
 
+def _pack_device(device, weight: torch.Tensor) -> torch.device:
+    """Where a layer is packed: the HIP device asked for, else the one its weight lives on, else the current HIP device (the packers
+    are HIP kernels: a CPU-resident layer is moved over for the pack, as the reference's `pack(..., device=...)` does)."""
+    dev = torch.device(device) if device is not None else weight.device
+    if dev.type != "cuda":
+        dev = weight.device if weight.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
 class _QuantLinearInt(torch.nn.Module):
     ZP_OFF = 1
     QUANT_TYPE = "mi355x"
@@ -44,9 +53,7 @@ class _QuantLinearInt(torch.nn.Module):
             self.bias = None
 
     def pack(self, linear, scales, zeros, g_idx=None, device=None):
-        dev = torch.device(device) if device is not None else linear.weight.device
-        if dev.type != "cuda":
-            dev = torch.device("cuda", torch.cuda.current_device())
+        dev = _pack_device(device, linear.weight)
         W = linear.weight.data.to(dev)
         if W.dim() == 4:
             W = W.flatten(1)
@@ -97,12 +104,17 @@ class WQLinear_GEMM(torch.nn.Module):
             return q
         if scales is None or zeros is None:
             raise ValueError("Both 'scales' and 'zeros' must be provided (not None)")
-        dev = linear.weight.device if linear.weight.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        dev = _pack_device(device, linear.weight)
         s2d = scales.to(dev).t().contiguous()
         z = zeros.to(dev).t().contiguous() if isinstance(zeros, torch.Tensor) else zeros
-        q.qweight, q.qzeros, q.scales = ops.pack_awq(linear.weight.data.to(dev).contiguous(), s2d, z, gs=q.group_size)
+        qw, qz, st = ops.pack_awq(linear.weight.data.to(dev).contiguous(), s2d, z, gs=q.group_size)
+        # registered buffers, like the reference's container (export_to_awq/utils.py:166-196): the reference's own save path
+        # (`state_dict()` of the packed module) must see them when this class packs behind ITS front door (plugin.register_formats)
+        for name, t in (("qweight", qw), ("qzeros", qz), ("scales", st)):
+            q.register_buffer(name, t)
         if linear.bias is not None:
-            q.bias = linear.bias.detach().clone().half()
+            q.bias = None
+            q.register_buffer("bias", linear.bias.detach().clone().half())
         return q
 
 
@@ -121,7 +133,7 @@ class QuantLinearFP4(torch.nn.Module):
         self.bias = None
 
     def pack(self, linear, scales, zeros=None, g_idx=None, global_scale=None, input_global_scale=None, device=None):
-        dev = linear.weight.device if linear.weight.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        dev = _pack_device(device, linear.weight)
         W = linear.weight.data.to(dev).contiguous()
         mode = 0 if self.is_mx else 1
         s = scales.to(dev).contiguous()
@@ -131,13 +143,23 @@ class QuantLinearFP4(torch.nn.Module):
             s = s.to(torch.float32)
         packed, sb = ops.pack_fp4(W, s.reshape(-1), mode=mode, gs=self.group_size, global_scale=gsc)
         self.weight_packed = packed
-        self.weight_scale = sb if self.is_mx else sb.view(torch.float8_e4m3fn)
+        # registered buffers (the reference's qlinear_fp.QuantLinear registers them in __init__): `state_dict()` is what its save path reads
+        self._set_buffer("weight_scale", sb if self.is_mx else sb.view(torch.float8_e4m3fn))
         if gsc is not None:
-            self.weight_global_scale = gsc
+            self._set_buffer("weight_global_scale", gsc)
         if input_global_scale is not None:
-            self.input_global_scale = input_global_scale.to(torch.float32).to(dev).reshape([1])
+            self._set_buffer("input_global_scale", input_global_scale.to(torch.float32).to(dev).reshape([1]))
         if getattr(linear, "bias", None) is not None:
-            self.bias = linear.bias.detach().to(torch.float16)
+            self.bias = None
+            self._set_buffer("bias", linear.bias.detach().to(torch.float16))
+
+    def _set_buffer(self, name, t):
+        if name in self._buffers:
+            self._buffers[name] = t
+        else:
+            if name in self.__dict__:
+                del self.__dict__[name]
+            self.register_buffer(name, t)
 
 
 def _is_conv1d(m) -> bool:

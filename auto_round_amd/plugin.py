@@ -8,8 +8,14 @@ auto-round itself is installed next to this package.  Nothing here is needed for
 P1  algorithm registry   register_pipeline_member(ConfigCls) / register_algorithm(name, aliases, config_factory)
                          (auto_round/algorithms/registry.py:56-87,163-168)
 P2  wrapper injection    the quantizer attribute `wrapper_block` (sign_round/quantizer.py:66)
-P4  export duck type     QuantLinear(bits, group_size, in, out, bias, weight_dtype).pack(linear, scales, zeros, g_idx, device)
-                         (export/export_to_autoround/export.py:206-228) -> auto_round_amd.export.QuantLinearZP / Plain
+P4  export              OutputFormat.register(*names) (export/formats/base.py:119-129): `register_formats()` re-registers the
+                         reference's own "auto_round*", "auto_gptq" and "auto_awq" format names with subclasses of the reference's format
+                         classes whose `pack_layer` runs the HIP packers (ar_pack_int / ar_pack_awq / ar_pack_fp4) on layers that live on
+                         a HIP device -- `quantize_and_save()` then packs on the GPU with no edit of the reference; buffer names,
+                         shapes, dtypes and words are the reference packer's (export_to_autoround/export.py:143-239), so
+                         `save_quantized` and the inference stack see no difference.  Everything the HIP packers do not cover (Conv2d,
+                         W4A8 activation-quant containers, gptqmodel / mlx / fp8 backends, CPU-resident runs) falls through to the
+                         reference's own `pack_layer`, i.e. to the code that would have run without this package.
 """
 from __future__ import annotations
 
@@ -102,6 +108,7 @@ def register():
 
     register_algorithm("mi355x_signround", aliases=("mi355x", "signround_mi355x"), config_factory=_Config,
                        summary="SignRound block tuning on MI355X (hand-written HIP kernels, auto_round_amd)")
+    register_formats()
     _Config.__name__ = "MI355XSignRoundConfig"
     _Quantizer.__name__ = "MI355XSignRoundQuantizer"
     MI355XSignRoundConfig, MI355XSignRoundQuantizer = _Config, _Quantizer
@@ -132,6 +139,100 @@ def adopt_act_quant_shells(block, device="cpu") -> int:
         _set_module(block, name, _RefShell(layer, enable_torch_compile=False, device=device))
         n_swapped += 1
     return n_swapped
+
+
+HIP_PACK_STATS = {"hip": 0, "reference": 0}       # layers packed by the HIP packers / handed to the reference's own pack_layer
+
+
+def _hip_available() -> bool:
+    import torch
+
+    return torch.cuda.is_available()
+
+
+def hip_pack_layer(layer_name: str, model, backend: str, device=None) -> bool:
+    """The reference's `pack_layer(layer_name, model, backend, device)` (export/export_to_autoround/export.py:143-239,
+    export_to_autogptq/export.py:120-185, export_to_awq/export.py:96-143) with the HIP packers doing the packing.  Same
+    post-conditions: the tuned `nn.Linear` at `layer_name` is replaced by a module carrying the packed buffers under the reference's
+    names (qweight / qzeros / scales [/ g_idx / bias]; weight_packed / weight_scale ... for fp4), left on the device the layer was on,
+    and the original layer's tensors are released.  -> True when handled; False when this layer / backend is not the HIP packers'
+    business and the caller should run the reference's own pack_layer (nothing has been touched then)."""
+    import torch
+    from auto_round.utils import check_to_quantized, get_module, set_module
+
+    from .export import pack_layer as _pack
+
+    if not _hip_available():
+        return False
+    layer = get_module(model, layer_name)
+    if hasattr(layer, "orig_layer"):
+        layer = layer.orig_layer
+    if type(layer) is not torch.nn.Linear or layer.weight.device.type == "meta":      # packed already, Conv1D / Conv2d, or not materialised
+        return False
+    dt = str(getattr(layer, "data_type", "int"))
+    fp4 = dt.startswith(("mx_fp", "nv_fp")) and int(getattr(layer, "bits", 16)) == 4
+    if not fp4 and (int(getattr(layer, "act_bits", 16)) <= 8 or "int" not in dt or dt.startswith("mx")):
+        return False                                     # W4A8 containers (pack_qact_layer), mx_int, fp8 ...: the reference's packers
+    if any(k in backend for k in ("gptqmodel", "mlx", "fp8", "gguf")):
+        return False
+    if fp4 and not backend.startswith(("auto_round", "llm_compressor")):
+        return False
+    if not check_to_quantized(layer):
+        return False
+    if not (hasattr(layer, "scale") and layer.scale is not None):
+        return False
+    bits = int(layer.bits)
+    if not fp4 and (bits not in (2, 3, 4, 8) or layer.in_features % 32 or layer.out_features % 32
+                    or ("awq" in backend and bits != 4)):
+        return False
+    orig_device = layer.weight.device
+    try:        # (a CPU-resident layer -- the orchestrator moves a finished block off the GPU before it packs -- is copied over by the packer)
+        qlayer = _pack(layer, backend, device=device if (device is not None and torch.device(device).type == "cuda") else None)
+    except (NotImplementedError, ValueError):
+        return False
+    qlayer.device = orig_device
+    qlayer.to(orig_device)
+    set_module(model, layer_name, qlayer)
+    try:
+        from auto_round.export.utils import release_layer_safely
+
+        release_layer_safely(layer)
+    except Exception:  # pragma: no cover  (older reference trees keep the helper elsewhere)
+        layer.weight = None
+    return True
+
+
+def register_formats():
+    """P4 through the reference's own registry (`OutputFormat.register`, export/formats/base.py:119-129): every name the reference
+    registered for its AutoRound / AutoGPTQ / AutoAWQ format classes is re-registered with a subclass whose `pack_layer` tries the HIP
+    packers first.  Idempotent.  -> {format name: class}"""
+    from auto_round.export.formats.backends.auto_awq import AutoAWQFormat
+    from auto_round.export.formats.backends.auto_gptq import AutoGPTQFormat
+    from auto_round.export.formats.backends.autoround import AutoRoundFormat
+    from auto_round.export.formats.base import OutputFormat
+
+    class _HipPackLayer:
+        mi355x_hip_packers = True
+
+        def pack_layer(self, layer_name, model, device=None, **kwargs):
+            if hip_pack_layer(layer_name, model, self.get_backend_name(), device):
+                HIP_PACK_STATS["hip"] += 1
+                return None
+            HIP_PACK_STATS["reference"] += 1
+            return super().pack_layer(layer_name, model, device=device, **kwargs)
+
+    made = {}
+    for base in (AutoRoundFormat, AutoGPTQFormat, AutoAWQFormat):
+        names = [n for n, c in OutputFormat._format_list.items() if c is base]
+        if not names:                                    # registered before: leave it
+            continue
+        cls = type("MI355X" + base.__name__, (_HipPackLayer, base), {
+            "__doc__": f"{base.__name__} with `pack_layer` on the MI355X HIP packers (auto_round_amd.plugin.hip_pack_layer); everything "
+                       f"else -- scheme checks, format resolution, save_quantized -- inherited from the reference unchanged."})
+        OutputFormat.register(*names)(cls)
+        for n in names:
+            made[n] = cls
+    return made
 
 
 def packing_quant_linear(backend: str, bits: int, group_size: int, sym: bool):

@@ -287,6 +287,11 @@ class SignRoundConfig:
     # bits).  ON by default since round 5 -- results identical to the reference's come first; the cost is one
     # [batch, 1, S, S] copy per block forward (67 MB at 8 x 2048).
     materialise_shared_rows: bool = True
+    # The package's own NO-GRAD block forwards (the fp forward that makes a block's targets, the quantised-output forward that feeds the
+    # next block) call the library attention in its training-mode form: same bits, but reproducible -- the inference-mode forward of
+    # torch 2.10 / ROCm 7.2 returns 16-32 wrong values on 0.1-1 % of its calls at OPT-125M's shape (attention.reproducible_sdpa_forward,
+    # profiles/r06_sdpa_flake.json).  Each call signature is compared once against the inference form before it is trusted.
+    reproducible_attention_forward: bool = True
     # Llama-family blocks through first-party kernels that keep the MODULE PATH'S BITS (auto_round_amd/exact_block.py,
     # csrc/ar_exact.hip): eager torch's rounding points and reduction order in the elementwise kernels, the module path's GEMM
     # shapes plus whichever faster GEMM forms prove bit-equal on this GPU / software stack.  Verified against the module code on
@@ -914,6 +919,12 @@ class SignRoundQuantizer:
     @torch.no_grad()
     def forward_all(self, block, inputs: torch.Tensor, input_others, batch_size: Optional[int] = None) -> torch.Tensor:
         """No-grad forward of every cached sample in minibatches -> [N, S, H] (composer.py steps 3 and 6)."""
+        from .attention import reproducible_sdpa_forward
+
+        with reproducible_sdpa_forward(bool(getattr(self.config, "reproducible_attention_forward", True))):
+            return self._forward_all(block, inputs, input_others, batch_size)
+
+    def _forward_all(self, block, inputs: torch.Tensor, input_others, batch_size: Optional[int] = None) -> torch.Tensor:
         bs = batch_size or self.config.batch_size
         fb = None
         if self.config.exact_rounding and self.config.amp and isinstance(input_others, dict) and not self.config.data_parallel:

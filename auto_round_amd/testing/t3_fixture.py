@@ -86,6 +86,68 @@ class _Stop(Exception):
     pass
 
 
+# ---- per-stage checksums of a block's fp forward (round 6): WHICH library op differs when the targets do -------------------------------
+OPT_STAGES = ("self_attn_layer_norm", "self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "attn_core", "self_attn.out_proj",
+              "final_layer_norm", "fc1", "fc2", "block_out")
+OPT_STAGE_FILE = os.path.join(ROOT, "tests", "golden", "t3s_opt125m_w4g128_stages.json")
+
+
+def bits_checksum(t: torch.Tensor) -> torch.Tensor:
+    """order-sensitive 64-bit checksum of a 16-bit tensor's bits, computed on its device without a host synchronisation"""
+    b = t.detach().contiguous().view(torch.int16).reshape(-1).to(torch.int64) & 0xFFFF
+    w = (torch.arange(b.numel(), device=b.device, dtype=torch.int64) % 65521) + 1
+    return (b * w).sum()
+
+
+@torch.no_grad()
+def staged_forward(forward, block, x0: torch.Tensor, others, bs: int = 8, sync: bool = False):
+    """`forward(block, x, others)` over `x0` in minibatches of `bs` with a checksum of every OPT_STAGES output per minibatch
+    ("attn_core" = the attention output as it enters out_proj) -> ({stage: [device scalars]}, y [N, S, H])."""
+    rec = {s: [] for s in OPT_STAGES}
+    hs = []
+    mods = dict(block.named_modules())
+
+    def out_hook(name):
+        def f(mod, inp, out):
+            rec[name].append(bits_checksum(out[0] if isinstance(out, tuple) else out))
+            if sync:
+                torch.cuda.synchronize()
+        return f
+
+    def pre_hook(mod, args):
+        rec["attn_core"].append(bits_checksum(args[0]))
+        if sync:
+            torch.cuda.synchronize()
+
+    for s in OPT_STAGES:
+        if s in mods:
+            hs.append(mods[s].register_forward_hook(out_hook(s)))
+    hs.append(mods["self_attn.out_proj"].register_forward_pre_hook(pre_hook))
+    outs = []
+    try:
+        for b0 in range(0, x0.shape[0], bs):
+            y = forward(block, x0[b0:b0 + bs], others)
+            rec["block_out"].append(bits_checksum(y))
+            outs.append(y)
+    finally:
+        for h in hs:
+            h.remove()
+    return rec, torch.cat(outs, 0)
+
+
+def first_differing_stage(rec, path: str = OPT_STAGE_FILE) -> dict:
+    """Compare `staged_forward`'s checksums with the committed ones (taken from a pass that reproduced the reference-made targets):
+    -> {stage: first stage with a differing minibatch or None, minibatches: [...], per_stage: {stage: differing minibatches}}"""
+    with open(path) as f:
+        want = json.load(f)["stages"]
+    per = {}
+    for s in OPT_STAGES:
+        got = [int(c) for c in rec.get(s, [])]
+        per[s] = [j for j, (a, b) in enumerate(zip(got, want[s])) if a != b] if len(got) == len(want[s]) else list(range(len(want[s])))
+    first = next((s for s in OPT_STAGES if per[s]), None)
+    return dict(stage=first, minibatches=per[first] if first else [], per_stage={s: len(v) for s, v in per.items()})
+
+
 @torch.no_grad()
 def capture_block_inputs(model, block, tokens: torch.Tensor, device, amp_dtype=torch.bfloat16):
     """(x0 [N, S, H], shared kwargs) of `block` on `tokens`, the way the reference's calibrator obtains them: one forward per
@@ -133,7 +195,7 @@ def capture_block_inputs(model, block, tokens: torch.Tensor, device, amp_dtype=t
 def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw: Optional[dict] = None, iters: int = 200,
                       nsamples: int = 128, seqlen: int = 2048, batch_size: int = 8, fused: bool = False, alg_ext: bool = False,
                       seed: int = 42, device="cuda:0", graph: Optional[bool] = None, materialise: bool = True, exact: bool = False,
-                      lr: Optional[float] = None, minmax_lr: Optional[float] = None) -> dict:
+                      lr: Optional[float] = None, minmax_lr: Optional[float] = None, stages: bool = True, reproducible_attention: bool = True) -> dict:
     """The plugin-mode flow without the reference around it: same seeded block, same block inputs, targets from the module-path
     forward (what the reference's orchestrator hands to `quantize_block`), `transformers.set_seed(seed)` right before the block
     (the reference's sampler then draws the same minibatches), then `SignRoundQuantizer.quantize_block` -- on the module path
@@ -149,13 +211,13 @@ def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw
     try:
         return _tune_with_product(arch, scheme=scheme, scheme_kw=scheme_kw, iters=iters, nsamples=nsamples, seqlen=seqlen, batch_size=batch_size,
                                   fused=fused, alg_ext=alg_ext, seed=seed, device=device, graph=graph, materialise=materialise, exact=exact,
-                                  lr=lr, minmax_lr=minmax_lr)
+                                  lr=lr, minmax_lr=minmax_lr, stages=stages, reproducible_attention=reproducible_attention)
     finally:
         torch.use_deterministic_algorithms(det_before[0], warn_only=det_before[1])
 
 
 def _tune_with_product(arch, *, scheme, scheme_kw, iters, nsamples, seqlen, batch_size, fused, alg_ext, seed, device, graph, materialise, exact,
-                       lr, minmax_lr) -> dict:
+                       lr, minmax_lr, stages=True, reproducible_attention=True) -> dict:
     import transformers
 
     from auto_round_amd.autoround import loss_mask_ids
@@ -178,10 +240,19 @@ def _tune_with_product(arch, *, scheme, scheme_kw, iters, nsamples, seqlen, batc
     ids = loss_mask_ids(tokens, None)
     q_cls = SignRoundV2Quantizer if alg_ext else SignRoundQuantizer
     mod_cfg = SignRoundConfig(iters=iters, batch_size=batch_size, bits=sch["bits"], sdpa_backend="auto", fused_block=False,
-                              materialise_shared_rows=materialise)
+                              materialise_shared_rows=materialise, reproducible_attention_forward=reproducible_attention)
     q_mod = q_cls(mod_cfg, device=device)
+    stage_report = None
     with torch.cuda.device(device):
-        y = q_mod.calibrate_block(block, x0, others)              # module path: the targets the reference would hand over
+        if stages and not alg_ext and ARCHS[arch]["family"] == "opt" and nsamples == 128 and seqlen == 2048 and batch_size == 8 and os.path.exists(OPT_STAGE_FILE):
+            # the same fp forward with a checksum per stage and minibatch: if the targets differ from the reference's, WHICH op did
+            from auto_round_amd.attention import reproducible_sdpa_forward
+
+            with reproducible_sdpa_forward(bool(mod_cfg.reproducible_attention_forward)):
+                rec, y = staged_forward(q_mod.block_forward, block, x0, others, bs=batch_size)
+            stage_report = first_differing_stage(rec)
+        else:
+            y = q_mod.calibrate_block(block, x0, others)              # module path: the targets the reference would hand over
     kw = {} if graph is None else {"hip_graph": bool(graph)}
     if lr is not None:
         kw.update(lr=float(lr), minmax_lr=float(minmax_lr if minmax_lr is not None else lr))
@@ -200,7 +271,7 @@ def _tune_with_product(arch, *, scheme, scheme_kw, iters, nsamples, seqlen, batc
     loss_trace = stats.pop("loss_trace", None)      # recorded on the device by ar_best_loss_update, one read per block
     extra = {"y": y.detach().cpu()} if os.environ.get("AR_T3_KEEP_TARGETS") == "1" else {}
     return dict(block=block, stats=stats, loss_trace=loss_trace, x_sha=sha(x0), y_sha=sha(y), y_dtype=str(y.dtype), **extra,
-                fused_block=bool(q.last_fused_block), hip_graph=bool(q.last_hip_graph), others_keys=sorted(others),
+                fused_block=bool(q.last_fused_block), hip_graph=bool(q.last_hip_graph), others_keys=sorted(others), stage_report=stage_report,
                 exact_block=bool(q.last_exact), exact_report=q.last_exact_report, tune_s=tune_s)
 
 
@@ -385,7 +456,7 @@ def stat_thresholds(rvr: dict) -> dict:
     return dict(min_identical=max(0.0, 1.0 - 2.0 * (1.0 - same) - 0.02), loss_band=max(0.01, 3.0 * spread))
 
 
-def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = False, graph: Optional[bool] = None) -> dict:
+def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = False, graph: Optional[bool] = None, reproducible_attention: bool = True) -> dict:
     """Re-tune a t3s fixture's block with this package, reference-free, and measure how close the result is to reference run 1 over
     the same per-layer prefixes reference run 2 was measured on -> a flat record with the derived thresholds next to the measurements."""
     z = np.load(path, allow_pickle=False)
@@ -394,7 +465,8 @@ def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = Fal
     alg_ext = bool(kw.pop("enable_alg_ext", False))
     lr, mmlr = kw.pop("lr", None), kw.pop("minmax_lr", None)
     r = tune_with_product(m["arch"], scheme=m["scheme"], scheme_kw=kw, iters=m["iters"], nsamples=m["nsamples"], seqlen=m["seqlen"],
-                          batch_size=m["batch_size"], fused=fused, seed=m["seed"], exact=exact, alg_ext=alg_ext, lr=lr, minmax_lr=mmlr, graph=graph)
+                          batch_size=m["batch_size"], fused=fused, seed=m["seed"], exact=exact, alg_ext=alg_ext, lr=lr, minmax_lr=mmlr, graph=graph,
+                          reproducible_attention=reproducible_attention)
     mine = tuned_layer_tensors(r["block"])
     P = int(m["prefix"])
     tot = same = stot = ssame = ctot = csame = 0
@@ -441,4 +513,5 @@ def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = Fal
                 ref_vs_ref_prefix_identical_weights=rvr["prefix_identical_weights"], ref_vs_ref_best_loss_ratio=rvr.get("best_loss_ratio"),
                 ref_vs_ref_first_divergence_iter=rvr.get("first_divergence_iter"), **stat_thresholds(rvr), tune_s=r["tune_s"],
                 result_digest=hashlib.sha256("".join(f"{k}:{v};" for k, v in sorted(got.items())).encode()).hexdigest(), y_dtype=r.get("y_dtype"),
+                stage_report=r.get("stage_report"), first_differing_stage=(r.get("stage_report") or {}).get("stage"),
                 device=m.get("device"), torch=m.get("torch"))

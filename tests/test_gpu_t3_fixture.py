@@ -76,20 +76,35 @@ def _full(r):
 
 def _run_with_one_retry(check, record_property, what):
     """Bit identity with the reference rests on the LIBRARY kernels under the block (hipBLASLt GEMMs, AOTriton attention) returning
-    the same bits run to run.  They almost always do at Llama-3-8B's shapes; once in a few dozen 200-iteration runs one of them does
-    not (seen in round 4: one of ~40 digest runs parted from a digest that the same code reproduced before and after; at OPT-125M's
-    shape it is routine, profiles/r03_opt125m_determinism.json).  A first-party defect would fail every time -- so a run that differs
-    is repeated ONCE, and the retry is printed and recorded."""
+    the same bits run to run.  Round 6 found the one that does not (tools/gpu/r06_sdpa_flake.py): the library's INFERENCE-mode attention
+    forward returns other values on 0.1-1 % of its calls; since then the package's own no-grad forwards call the attention in its
+    training-mode form (same bits, reproducible), and what is left is rare.  A first-party defect would fail every time -- so a run that
+    differs is repeated ONCE; the second-try pass is NOT a plain pass: it is accounted for -- recorded in
+    `conftest.SECOND_TRY` (printed as a `[library-flake accounting]` line in the terminal summary, also under `-q`) and the test ends
+    as XFAIL (`_account` below, called after every other assertion of the test held), so the driver's tail shows `N xfailed`."""
     import warnings
 
+    import conftest
+
+    conftest.DIGEST_RUNS.append(what)
     r = check()
     if r["bit_identical"]:
         return r
     # (a warning, not a print: it must show in the `-q` tail of the driver's record -- VERDICT r04 weak #2)
-    warnings.warn(f"[t3-digest] RETRY {what}: the first run differed from the digest ({r['tensors_identical']}/{r['tensors']} tensors, first "
-                  f"divergence at iteration {r['first_divergence_iter']}); repeating once")
-    record_property("digest_retry", f"first run: {r['tensors_identical']}/{r['tensors']} identical, diverged at {r['first_divergence_iter']}")
-    return check()
+    note = (f"{what}: first run differed from the digest ({r['tensors_identical']}/{r['tensors']} tensors, first divergence at "
+            f"iteration {r['first_divergence_iter']}, targets_identical={r.get('targets_identical')})")
+    warnings.warn(f"[t3-digest] RETRY {note}; repeating once")
+    record_property("digest_retry", note)
+    r2 = check()
+    conftest.SECOND_TRY.append(note + (" -- second run matched" if r2["bit_identical"] else " -- second run differed too"))
+    r2["_second_try"] = note
+    return r2
+
+
+def _account(r):
+    """last line of a digest test: everything asserted held, but only on the second try -> the test is reported as XFAIL, not as a pass"""
+    if isinstance(r, dict) and r.get("_second_try"):
+        pytest.xfail("bit-identical to the reference's digest only on the SECOND try (library flake, accounted): " + r["_second_try"])
 
 
 def _digest_stack():
@@ -136,6 +151,7 @@ def test_llama8b_block_at_the_full_recipe_is_bit_identical_to_the_reference_dige
     r = _run_with_one_retry(fx.check_against_digest, record_property, "module path") if same_stack else fx.check_against_digest()
     assert not r["fused_block"] and r["inputs_identical"] and r["targets_identical"], r
     _check_digest(r, same_stack, "module path")
+    _account(r)
 
 
 def test_llama8b_block_on_the_exact_rounding_path_is_bit_identical_to_the_reference_digest(record_property):
@@ -152,6 +168,7 @@ def test_llama8b_block_on_the_exact_rounding_path_is_bit_identical_to_the_refere
     plan = r["exact_plan"] or {}
     assert plan.get("rope") and plan.get("swiglu") and plan.get("norm1") and plan.get("norm2"), plan      # the elementwise kernels are in use
     _check_digest(r, same_stack, "exact_rounding path")
+    _account(r)
 
 
 def test_llama8b_block_on_the_fused_path_stays_on_the_reference_trajectory_level():
@@ -206,6 +223,7 @@ def test_module_path_reproduces_the_reference_digest_of_every_baseline_scheme(pa
 
         warnings.warn(f"[t3v2] {os.path.basename(path)}: STATISTICAL branch -- the stack differs from the digest's, bit-identity is not checked here")
         assert r["full_layer_identical_weights"] > 0.5 and abs(r["best_loss_ratio"] - 1.0) < 0.03, r
+    _account(r)
 
 
 @pytest.mark.parametrize("path", _v2_digests(), ids=lambda p: os.path.basename(p)[5:-4])
@@ -228,6 +246,7 @@ def test_exact_rounding_path_reproduces_the_reference_digest_of_the_other_scheme
 
         warnings.warn(f"[t3v2] {os.path.basename(path)} exact_rounding: STATISTICAL branch -- the stack differs from the digest's")
         assert r["full_layer_identical_weights"] > 0.5 and abs(r["best_loss_ratio"] - 1.0) < 0.03, r
+    _account(r)
 
 
 # ---- round 5: two-reference-run fixtures (tests/golden/t3s_*.npz, tests/t3_baseline_shapes.py --ref-twice ... --stat-fixture-dir) ----------
