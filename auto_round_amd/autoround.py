@@ -9,6 +9,16 @@ iters=..., nsamples=..., seqlen=..., batch_size=...).quantize() / .save_quantize
   4. pack + stream to safetensors shards                    (export.pack_block, shard_writer.ShardWriter), config.json with
      the reference's `quantization_config` keys for format "auto_round"
 
+Multi-GPU (round 6): launched as one process per GPU (`torchrun --nproc-per-node N ...`, or any launcher that sets RANK / LOCAL_RANK /
+WORLD_SIZE), `device_map="0,1,...,N-1"` names the devices and every rank takes the one at its LOCAL_RANK.  With
+`enable_quanted_input=False` the blocks are SHARDED over the ranks (sharding.tune_sharded: RCCL broadcast of the calibration
+activations, pipelined point-to-point relay of the fp chain, no per-iteration collective; every rank packs and writes the blocks it
+tuned into its own shard files, rank 0 writes the rest of the model and the one index); with the default quantised-input chaining the
+blocks are sequential and every block is tuned DATA-PARALLEL instead (SignRoundConfig.data_parallel: each rank a share of every
+minibatch, one bf16 all-reduce of the weight-gradient buffer per iteration).  The reference's own `device_map="0,1,..."`
+(algorithms/quantization/sign_round/quantizer.py:82-118, utils/device.py:923-1040) spreads ONE block over the devices of one process to
+make it fit; on 288 GB parts a block always fits, so the same argument buys throughput here.
+
 Not rebuilt (use the reference with `auto_round_amd.plugin` for these): dataset download/tokenisation (no network here:
 `dataset` must be token ids), multimodal / diffusion models, AutoScheme, GGUF / FP8 formats, lm_head / embedding quantisation,
 low-memory offloading."""
@@ -20,7 +30,7 @@ from typing import Dict, List, Optional, Union
 
 import torch
 
-from .model_tuner import tune_blocks
+from .model_tuner import tune_blocks, tune_blocks_sharded
 from .quantizer import SignRoundConfig, SignRoundQuantizer, SignRoundV2Quantizer
 from .schemes import SCHEME_KEYS, apply_scheme, expand_layer_config, is_quantizable, layer_pattern_regex, resolve_scheme
 from .shard_writer import ShardWriter
@@ -100,14 +110,20 @@ class AutoRound:
                     self.scheme[k] = v
         self.nsamples, self.seqlen, self.seed = nsamples, seqlen, seed
         self.dataset = dataset
-        if isinstance(device_map, str) and device_map.strip().isdigit():
-            device_map = int(device_map)
-        if device_map in (None, "auto", "cuda"):
-            device_map = 0
-        self.device = torch.device("cuda", device_map) if isinstance(device_map, int) else torch.device(device_map)
-        if self.device.type != "cuda" or not torch.cuda.is_available():
+        self.rank, self.world, local_rank = dist_env()
+        self.devices = parse_device_map(device_map)
+        if not torch.cuda.is_available() or any(d.type != "cuda" for d in self.devices):
             raise RuntimeError(f"AutoRound (MI355X path) needs a HIP device, got device_map={device_map!r} with "
                                f"torch.cuda.is_available()={torch.cuda.is_available()}; there is no CPU fallback")
+        self.device = pick_rank_device(self.devices, local_rank, self.world, torch.cuda.device_count())
+        if self.world == 1 and len(self.devices) > 1:
+            import warnings
+
+            warnings.warn(f"device_map={device_map!r} names {len(self.devices)} devices but this is a single process: the MI355X path runs one "
+                          f"process per GPU (torchrun --nproc-per-node {len(self.devices)} ...); tuning on {self.device} alone")
+        # one process per GPU: blocks shard over the ranks when they are independent (fp chain), else every block is tuned data-parallel
+        self.sharded = self.world > 1 and not enable_quanted_input
+        self.data_parallel = self.world > 1 and bool(enable_quanted_input)
         self.enable_alg_ext = enable_alg_ext
         amp_dtype = next(model.parameters()).dtype
         if amp_dtype not in (torch.bfloat16, torch.float16):
@@ -116,7 +132,7 @@ class AutoRound:
                                       enable_minmax_tuning=enable_minmax_tuning, enable_quanted_input=enable_quanted_input,
                                       gradient_accumulate_steps=gradient_accumulate_steps, not_use_best_mse=not_use_best_mse,
                                       dynamic_max_gap=dynamic_max_gap, amp=amp, amp_dtype=amp_dtype, momentum=momentum, fused_block=fused,
-                                      mfma_dw_gemm=fused, exact_rounding=exact)
+                                      mfma_dw_gemm=fused, exact_rounding=exact, data_parallel=self.data_parallel)
         self.layer_config_in = layer_config
         self.layer_config: Dict[str, dict] = {}
         self.block_names: List[str] = []
@@ -176,6 +192,8 @@ class AutoRound:
         import transformers
 
         transformers.set_seed(self.seed)        # seeds `random` (IndexSampler) like the reference's compressor does
+        if self.world > 1:
+            init_process_group(self.device)
         model = self.model.to(self.device).eval()
         for p in model.parameters():
             p.requires_grad_(False)
@@ -202,8 +220,17 @@ class AutoRound:
             x0, others = self._capture_block0_inputs(blocks, tokens)
             q_cls = SignRoundV2Quantizer if self.enable_alg_ext else SignRoundQuantizer
             self.quantizer = q_cls(self.config, device=self.device)
-            self.records = tune_blocks(blocks, x0, others, self.quantizer, input_ids=ids_for_mask,
-                                       block_names=self.block_names)
+            if self.sharded:        # every rank tunes the blocks it owns against the fp chain; then every rank gets every tuned block
+                with torch.cuda.device(self.device):
+                    recs = tune_blocks_sharded(blocks, x0, others, self.quantizer, seed=self.seed, input_ids=ids_for_mask,
+                                               block_names=self.block_names)
+                    self.owned_blocks = sorted(recs)
+                    self.records = [recs.get(k) for k in range(len(blocks))]
+                    sync_tuned_blocks(blocks, self.world, self.device)
+            else:
+                self.owned_blocks = list(range(len(blocks)))
+                self.records = tune_blocks(blocks, x0, others, self.quantizer, input_ids=ids_for_mask,
+                                           block_names=self.block_names)
         finally:
             if old_attn is not None:
                 cfg_obj._attn_implementation = old_attn
@@ -361,15 +388,36 @@ class AutoRound:
         else:                    # AutoRoundFormat's defaults (export/formats/backends/autoround.py:59-70)
             backend = format if ":" in format else ("auto_round:auto_gptq" if sym else
                                                     ("auto_round:auto_awq" if bits == 4 else "auto_round"))
-        writer = ShardWriter(output_dir, max_shard_bytes=max_shard_bytes)
+        # block-sharded runs: every rank packs (HIP packers) and writes the blocks IT tuned into its own shard files, rank 0 adds the
+        # rest of the model, the merged index and the configs; data-parallel runs hold identical models everywhere: rank 0 writes
+        multi = self.world > 1
+        if multi and not self.sharded and self.rank != 0:
+            _barrier()
+            return None
+        writer = ShardWriter(output_dir, max_shard_bytes=max_shard_bytes, tag=f"rank{self.rank}" if (multi and self.sharded) else None)
         packed_prefixes = []
-        for name in self.block_names:
+        mine = set(getattr(self, "owned_blocks", range(len(self.block_names))))
+        for bi, name in enumerate(self.block_names):
             block = self.model.get_submodule(name)
+            if multi and self.sharded and bi not in mine:       # another rank's block: only its tensor names are needed here
+                for ln, m in block.named_modules():
+                    if hasattr(m, "scale") and int(getattr(m, "bits", 16)) < 16:
+                        ln = ln[:-len(".orig_layer")] if ln.endswith(".orig_layer") else ln
+                        packed_prefixes.append(f"{name}.{ln}.")
+                continue
             packed = pack_block(block, backend if int_scheme else None)
             writer.write_block(name, packed)
             for ln in packed:
                 ln = ln[:-len(".orig_layer")] if ln.endswith(".orig_layer") else ln
                 packed_prefixes.append(f"{name}.{ln}.")
+        if multi and self.sharded:
+            import torch.distributed as dist
+
+            if self.rank != 0:
+                part = writer.finish()
+                dist.gather_object(part, None, dst=0)
+                _barrier()
+                return None
         rest = {}
         tied = bool(getattr(getattr(self.model, "config", None), "tie_word_embeddings", False))
         emb = self.model.get_input_embeddings() if hasattr(self.model, "get_input_embeddings") else None
@@ -381,7 +429,14 @@ class AutoRound:
                 continue        # tied output embedding: stored once, like save_pretrained does
             rest[k2] = v.detach().to("cpu").contiguous()
         writer.write(rest)
-        index = writer.close()
+        if multi and self.sharded:
+            import torch.distributed as dist
+
+            parts = [None] * self.world
+            dist.gather_object(writer.finish(), parts, dst=0)
+            index = ShardWriter.write_index(output_dir, parts)
+        else:
+            index = writer.close()
         cfg = self.model.config.to_dict() if hasattr(self.model, "config") else {}
         if format == "llm_compressor":
             cfg["quantization_config"] = llmc_cfg
@@ -399,12 +454,131 @@ class AutoRound:
             json.dump(cfg["quantization_config"], f, indent=2, default=str)
         if self.tokenizer is not None and hasattr(self.tokenizer, "save_pretrained"):
             self.tokenizer.save_pretrained(output_dir)
+        if multi:
+            _barrier()
         return index
 
     def quantize_and_save(self, output_dir: str = "tmp_autoround", format: str = "auto_round", inplace: bool = True, **kw):
         model, _ = self.quantize()
         self.save_quantized(output_dir, format=format, inplace=inplace, **kw)
         return model, output_dir
+
+
+# ---- one process per GPU ---------------------------------------------------------------------------------------------------------------
+def dist_env():
+    """(rank, world, local_rank) of this process: torch.distributed's if a group exists, else the launcher's environment
+    (RANK / WORLD_SIZE / LOCAL_RANK as torchrun sets them), else (0, 1, 0)."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), int(os.environ.get("LOCAL_RANK", dist.get_rank()))
+    world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    rank = int(os.environ.get("RANK", "0") or 0)
+    return rank, world, int(os.environ.get("LOCAL_RANK", rank) or 0)
+
+
+def parse_device_map(device_map) -> List[torch.device]:
+    """The reference's `device_map` values this path understands (autoround.py:750-757, utils/device.py:923-1040): an int, "cuda:1",
+    "0,1,2,3" / [0, 1, 2, 3] (one device per rank), None / "auto" / "cuda" (device 0, or LOCAL_RANK's under a launcher)."""
+    if device_map in (None, "auto", "cuda"):
+        return [torch.device("cuda", 0)]
+    if isinstance(device_map, int):
+        return [torch.device("cuda", device_map)]
+    if isinstance(device_map, torch.device):
+        return [device_map]
+    if isinstance(device_map, (list, tuple)):
+        return [d for x in device_map for d in parse_device_map(x)]
+    if isinstance(device_map, str):
+        parts = [p.strip() for p in device_map.split(",") if p.strip()]
+        if len(parts) > 1:
+            return [d for x in parts for d in parse_device_map(x)]
+        p = parts[0] if parts else "0"
+        return [torch.device("cuda", int(p))] if p.isdigit() else [torch.device(p)]
+    raise TypeError(f"device_map={device_map!r}: an int, a device string, or a comma separated list / a list of them")
+
+
+def pick_rank_device(devices: List[torch.device], local_rank: int, world: int, device_count: int) -> torch.device:
+    """This rank's device: the `local_rank`-th entry of a multi-device map; with ONE entry and several ranks the launcher's
+    convention (cuda:LOCAL_RANK) where the node has that many devices, else the entry itself (several ranks sharing one GPU)."""
+    if len(devices) > 1:
+        return devices[local_rank % len(devices)]
+    d = devices[0]
+    if world > 1 and d.type == "cuda" and d.index in (None, 0) and local_rank < device_count:
+        return torch.device("cuda", local_rank)
+    return d
+
+
+def init_process_group(device: torch.device):
+    """torch.distributed's default group for a front-door run (backend "nccl" = RCCL over xGMI on ROCm; `AR_DIST_BACKEND=gloo` for
+    ranks that share one GPU, which RCCL refuses); rendezvous from the launcher's MASTER_ADDR / MASTER_PORT (127.0.0.1 by default)."""
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    backend = os.environ.get("AR_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group(backend)
+
+
+def _barrier():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+
+TUNED_ATTRS = ("scale", "zp", "weight_global_scale", "input_global_scale", "act_max", "act_scale")
+
+
+@torch.no_grad()
+def sync_tuned_blocks(blocks, world: int, device, policy: str = "round_robin") -> int:
+    """After a block-sharded run every rank holds the tuned form of ITS blocks only.  Each owner broadcasts what tuning left in its
+    blocks -- every tuned linear's fake-quant weight (device to device over RCCL) and the small per-layer results (`scale`, `zp`,
+    global scales, activation maxima; pickled) plus which layers now sit in an activation-quant shell -- so that `quantize()` returns
+    the whole tuned model on every rank, as the sequential run does.  The one exchange step of the sharded path besides the
+    calibration broadcast and the fp relay: 2 bytes per weight, once.  -> number of layers received."""
+    import torch.distributed as dist
+
+    from .sharding import owner_of
+    from .wrapper import WrapperWALayer, _set_module
+
+    rank = dist.get_rank()
+    n, got = len(blocks), 0
+    for k, block in enumerate(blocks):
+        own = owner_of(k, n, world, policy)
+        if own == rank:
+            tuned = [(name, m) for name, m in block.named_modules() if isinstance(m, torch.nn.Module) and hasattr(m, "scale")
+                     and int(getattr(m, "bits", 16)) < 16 and not isinstance(m, WrapperWALayer)]
+            meta = [{"name": name[:-len(".orig_layer")] if name.endswith(".orig_layer") else name, "shell": name.endswith(".orig_layer"),
+                     "attrs": {a: (getattr(m, a).detach().cpu() if isinstance(getattr(m, a), torch.Tensor) else getattr(m, a))
+                               for a in TUNED_ATTRS if hasattr(m, a)}} for name, m in tuned]
+            box = [meta]
+        else:
+            box = [None]
+        dist.broadcast_object_list(box, src=own)
+        meta = box[0]
+        if own != rank:
+            block.to(device)
+        for item in meta:
+            m = block.get_submodule(item["name"])
+            if own != rank:
+                if isinstance(m, WrapperWALayer):
+                    m = m.orig_layer
+                for a, v in item["attrs"].items():
+                    setattr(m, a, v)
+                if item["shell"] and not isinstance(block.get_submodule(item["name"]), WrapperWALayer):
+                    _set_module(block, item["name"], WrapperWALayer(m))
+                got += 1
+            elif isinstance(m, WrapperWALayer):
+                m = m.orig_layer
+            dist.broadcast(m.weight.data, src=own)
+    return got
 
 
 def loss_mask_ids(tokens: torch.Tensor, pad_token_id=None) -> torch.Tensor:

@@ -46,13 +46,36 @@ def tune_blocks(blocks: Sequence[torch.nn.Module], block0_inputs, input_others: 
 
 
 def tune_blocks_sharded(blocks, block0_inputs, input_others, quantizer, seed: int = 42, policy: str = "round_robin",
-                        group=None, input_ids=None):
-    """Multi-GPU form: requires enable_quanted_input=False (blocks are only independent on the fp chain).  Every owned block
-    goes through the same pre-tuning calibration and loss mask as `tune_blocks` (sharding.tune_sharded)."""
+                        group=None, input_ids=None, block_names: Optional[List[str]] = None, pack: bool = False,
+                        on_block_done: Optional[Callable] = None, shard_writer=None) -> Dict[int, Dict]:
+    """Multi-GPU form of `tune_blocks`: requires enable_quanted_input=False (blocks are only independent on the fp chain).  Every
+    owned block goes through the same pre-tuning calibration and loss mask as `tune_blocks` (sharding.tune_sharded); the blocks
+    this rank does not own are never touched.  `block0_inputs` as for `tune_blocks` (a list of per-sample tensors or one [N, S, H]
+    tensor; every rank passes the same shape, rank 0's values are the ones used).  -> {block index: the record `tune_blocks` makes
+    for that block} for the blocks THIS rank tuned; with `shard_writer` every finished block is packed and streamed out at once."""
     from . import sharding
 
     if quantizer.config.enable_quanted_input:
         raise ValueError("block sharding needs enable_quanted_input=False: with quantised-input chaining block k+1 "
-                         "depends on the tuned block k (SURVEY 8e) -- run replicas instead")
-    return sharding.tune_sharded(blocks, block0_inputs, input_others, quantizer, seed=seed, policy=policy, group=group,
-                                 input_ids=input_ids)
+                         "depends on the tuned block k (SURVEY 8e) -- run replicas, or data_parallel=True inside each block")
+    device = quantizer.device
+    x0 = stack_samples(block0_inputs, device)
+    owned = sharding.assign_blocks(len(blocks), sharding.dp_world(group)[1], policy)[sharding.dp_world(group)[0]]
+    for k in owned:
+        blocks[k].to(device)
+    out: Dict[int, Dict] = {}
+
+    def done(k, block, rec):
+        name = block_names[k] if block_names else str(k)
+        r = {"name": name, "stats": rec["stats"], "best_params": rec["best_params"]}
+        if pack or shard_writer is not None:
+            r["packed"] = pack_block(block)
+            if shard_writer is not None:
+                shard_writer.write_block(name, r["packed"])
+        out[k] = r
+        if on_block_done is not None:
+            on_block_done(k, block, r)
+
+    sharding.tune_sharded(blocks, x0, input_others, quantizer, seed=seed, policy=policy, group=group, input_ids=input_ids,
+                          on_block_done=done)
+    return out

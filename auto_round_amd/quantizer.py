@@ -677,11 +677,16 @@ class SignRoundQuantizer:
         bit-equal to the module code on one real minibatch (first `rows` samples) -- once per kind of block and minibatch shape;
         later blocks of the same kind reuse the plan."""
         from .exact_block import ExactLlamaBlock
+        from .exact_opt_block import ExactOPTBlock
 
         cfg = self.config
         if cfg.data_parallel or not isinstance(input_others, dict):
             return None
-        eb = ExactLlamaBlock.try_build(block, arenas, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx, amp=cfg.amp)
+        eb = None
+        for cls in (ExactLlamaBlock, ExactOPTBlock):        # Llama family (round 4), OPT family (round 6: BASELINE configs[0])
+            eb = cls.try_build(block, arenas, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx, amp=cfg.amp)
+            if eb is not None:
+                break
         if eb is None:
             return None
         mask = input_others.get("attention_mask")
@@ -722,12 +727,17 @@ class SignRoundQuantizer:
         """The exact_rounding form of an UNWRAPPED block for the no-grad passes (targets, quantised-output forward), proven against the
         module code's output bits once per kind of block; None: the module path."""
         from .exact_block import ExactLlamaBlock
+        from .exact_opt_block import ExactOPTBlock
 
         cfg = self.config
-        try:
-            eb = ExactLlamaBlock.try_build_plain(block, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx, amp=cfg.amp)
-        except Exception:  # noqa: BLE001 -- anything unexpected about the block: the module path
-            eb = None
+        eb = None
+        for cls in (ExactLlamaBlock, ExactOPTBlock):
+            try:
+                eb = cls.try_build_plain(block, input_others, cfg.amp_dtype, sdpa_ctx=self._sdpa_ctx, amp=cfg.amp)
+            except Exception:  # noqa: BLE001 -- anything unexpected about the block: the module path
+                eb = None
+            if eb is not None:
+                break
         if eb is None:
             return None
         mask = input_others.get("attention_mask")

@@ -29,8 +29,12 @@ class ShardWriter:
     """reference: ShardWriter (auto_round/compressors/shard_writer.py:37): size-bounded safetensors shards written while the
     run is still tuning later blocks, `model.safetensors.index.json` on close."""
 
-    def __init__(self, out_dir: str, max_shard_bytes: int = 5 * 1024 ** 3, metadata: Optional[dict] = None):
+    def __init__(self, out_dir: str, max_shard_bytes: int = 5 * 1024 ** 3, metadata: Optional[dict] = None, tag: Optional[str] = None):
+        """tag: a per-writer infix of the shard file names ("rank3" -> model-rank3-00001-of-00002.safetensors) for runs in which
+        several processes stream into ONE checkpoint directory (block sharding: every rank writes the blocks it tuned, rank 0
+        merges the weight maps into the one index -- `finish()` / `write_index()`)."""
         self.out_dir = out_dir
+        self.tag = f"{tag}-" if tag else ""
         self.max_shard_bytes = int(max_shard_bytes)
         self.metadata = {"format": "pt", **(metadata or {})}
         self._pending: Dict[str, torch.Tensor] = {}
@@ -61,7 +65,7 @@ class ShardWriter:
             return
         from safetensors.torch import save_file
 
-        fname = f"model-{len(self._shards) + 1:05d}.safetensors"
+        fname = f"model-{self.tag}{len(self._shards) + 1:05d}.safetensors"
         save_file(self._pending, os.path.join(self.out_dir, fname), metadata={k: str(v) for k, v in self.metadata.items()})
         for name in self._pending:
             self._weight_map[name] = fname
@@ -69,17 +73,34 @@ class ShardWriter:
         self._shards.append(fname)
         self._pending, self._pending_bytes = {}, 0
 
-    def close(self) -> str:
-        """Flush, rename shards to `-of-` form and write `model.safetensors.index.json`.  Returns the index path."""
+    def finish(self):
+        """Flush and rename this writer's shards to their `-of-` form WITHOUT writing an index -> ({tensor: file}, total bytes):
+        what a rank of a block-sharded run hands to rank 0."""
         self._flush()
         n = len(self._shards)
         renamed = {}
         for i, old in enumerate(self._shards):
-            new = "model.safetensors" if n == 1 else f"model-{i + 1:05d}-of-{n:05d}.safetensors"
+            new = "model.safetensors" if (n == 1 and not self.tag) else f"model-{self.tag}{i + 1:05d}-of-{n:05d}.safetensors"
             os.replace(os.path.join(self.out_dir, old), os.path.join(self.out_dir, new))
             renamed[old] = new
-        index = {"metadata": {"total_size": self._total}, "weight_map": {k: renamed[v] for k, v in self._weight_map.items()}}
-        path = os.path.join(self.out_dir, "model.safetensors.index.json")
+        self._shards = []
+        return {k: renamed[v] for k, v in self._weight_map.items()}, self._total
+
+    @staticmethod
+    def write_index(out_dir: str, parts) -> str:
+        """`parts`: [(weight_map, total_bytes), ...] of every writer that streamed into `out_dir` -> the one index file."""
+        weight_map, total = {}, 0
+        for wm, t in parts:
+            dup = set(weight_map) & set(wm)
+            if dup:
+                raise KeyError(f"tensors written by more than one writer: {sorted(dup)[:4]}")
+            weight_map.update(wm)
+            total += int(t)
+        path = os.path.join(out_dir, "model.safetensors.index.json")
         with open(path, "w") as f:
-            json.dump(index, f, indent=1)
+            json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=1)
         return path
+
+    def close(self) -> str:
+        """Flush, rename shards to `-of-` form and write `model.safetensors.index.json`.  Returns the index path."""
+        return self.write_index(self.out_dir, [self.finish()])
