@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -72,6 +72,8 @@ SIGNATURES = {
     "ar_rope_bwd_exact": (c_int, [P, L, L, L, P, L, L, L, P, P, L, P, L, P, L, L, L, I, I, I, I, P]),
     "ar_swiglu_fwd_exact": (c_int, [P, L, P, L, P, L, L, I, P]),
     "ar_swiglu_bwd_exact": (c_int, [P, P, L, P, L, P, L, P, L, L, L, I, I, P]),
+    "ar_layernorm_fwd_exact": (c_int, [P, P, P, P, P, P, L, I, F, I, I, P]),
+    "ar_layernorm_bwd_exact": (c_int, [P, P, P, P, P, P, P, L, I, I, P]),
     "ar_gemm_dw": (c_int, [P, P, P, L, L, L, L, L, L, I, P, L, P]),
     "ar_gemm_dw_grouped": (c_int, [P, P, P, L, L, L, L, L, P, P, I, P]),
     "ar_gemm_nt": (c_int, [P, P, P, L, L, L, L, L, L, P]),

@@ -553,6 +553,37 @@ def rmsnorm_bwd_exact(dy2d, x2d, weight, rstd, dres=None, out=None):
     return dx
 
 
+def layernorm_fwd_exact(x2d, weight, bias, eps, flags=0, want_stats=True):
+    """nn.LayerNorm as the module path computes it under autocast (fp32 `native_layer_norm` on x.float(), result cast to the activation
+    dtype) with the bits of torch's own kernel -> (y, mean [rows] fp32, rstd [rows] fp32) (stats None unless wanted); None where ATen
+    would take a code path csrc/ar_exact_ln.hip does not restate (hidden % 4, unaligned rows)."""
+    rows, H = x2d.shape
+    if H < 4 or H % 4 or weight is None or bias is None or weight.dtype != x2d.dtype or bias.dtype != x2d.dtype or not x2d.is_contiguous() \
+            or x2d.dtype not in (torch.bfloat16, torch.float16) or (x2d.data_ptr() | weight.data_ptr() | bias.data_ptr()) % 8:
+        return None
+    y = torch.empty_like(x2d)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device) if want_stats else None
+    _launch("ar_layernorm_fwd_exact", _p(x2d, "x"), _p(weight, "weight"), _p(bias, "bias"), _p(y), _p(mean), _p(rstd), rows, H, float(eps),
+            int(flags), dt_code(x2d.dtype))
+    return y, mean, rstd
+
+
+def layernorm_bwd_exact(dy2d, x2d, weight, mean, rstd, dres=None, flags=0, out=None):
+    """torch autograd's input gradient of that LayerNorm (fp32 `layer_norm_grad_input_kernel`, cast to the activation dtype) + dres,
+    the residual branch's gradient, added in the activation dtype.  Raises Mi355xLibraryError for rows >= 32768 (ATen's ROCm build
+    switches kernels there): callers check `layernorm_bwd_exact_ok` first."""
+    rows, H = x2d.shape
+    dx = out if out is not None else torch.empty_like(x2d)
+    _launch("ar_layernorm_bwd_exact", _p(dy2d, "dy"), _p(x2d, "x"), _p(weight, "weight"), _p(mean, "mean"), _p(rstd, "rstd"), _p(dres), _p(dx),
+            rows, H, dt_code(x2d.dtype))
+    return dx
+
+
+def layernorm_bwd_exact_ok(rows: int, H: int) -> bool:
+    return H >= 4 and H % 4 == 0 and rows < 32768
+
+
 def rope_fwd_exact(q2d, k2d, cos, sin, seq, hq, hkv, d):
     """apply_rotary_pos_emb on separate q [tokens, hq*d] / k [tokens, hkv*d] projections (column slices allowed) -> contiguous q, k"""
     tokens = q2d.shape[0]

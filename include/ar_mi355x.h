@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 24
+#define AR_ABI_VERSION 25
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -338,6 +338,25 @@ int ar_swiglu_fwd_exact(const void* g, int64_t ldg, const void* u, int64_t ldu, 
                         ar_stream_t stream);
 int ar_swiglu_bwd_exact(const void* da, const void* g, int64_t ldg, const void* u, int64_t ldu, void* dg, int64_t lddg, void* du, int64_t lddu,
                         int64_t rows, int64_t F, int contract, int dt, ar_stream_t stream);
+
+/* ---- nn.LayerNorm with the bits of torch's own kernels (round 6; csrc/ar_exact_ln.hip) -------------------------------------------
+ * replaces: the two LayerNorms of an OPT-style decoder block as the reference's DEFAULT (eager) path runs them through block_forward
+ *           (auto_round/compressors/utils.py:109-172; transformers/models/opt/modeling_opt.py OPTDecoderLayer.self_attn_layer_norm /
+ *           final_layer_norm): under autocast `layer_norm` is an fp32 op -- x.float() -> at::native::vectorized_layer_norm_kernel
+ *           <float, float, false> -> the next linear's cast to the activation dtype -- and torch autograd's backward of it
+ *           (at::native::layer_norm_grad_input_kernel<float, float, false>); both kernels restated from the gfx950 code objects of
+ *           the installed torch, the two dtype conversions folded in (auto_round_amd/exact_opt_block.py proves the result against
+ *           the module code before it is used).  x / gamma / beta / y / dy / dx in dt (BF16 | F16), mean / rstd fp32 [rows].
+ *   ar_layernorm_fwd_exact   y = dt(fma(rstd * (x - mean), gamma, beta)) with ATen's Welford statistics (per-thread online update,
+ *                            shuffle-down and shared-memory combines); mean_out / rstd_out may be NULL; flags bit 0: IEEE 1/x
+ *                            instead of v_rcp_f32 in the Welford updates, bit 1: rsqrt evaluated in double (other torch builds)
+ *   ar_layernorm_bwd_exact   dx = dt(ATen's grad-input formula) (+ dres, added in dt: the residual branch's gradient); rows < 32768
+ *                            (above that ATen's ROCm build runs another kernel)
+ * hidden % 4 != 0, unaligned pointers, rows >= 32768 (backward): AR_ERR_UNSUPPORTED and the caller keeps torch's own ops. */
+int ar_layernorm_fwd_exact(const void* x, const void* gamma, const void* beta, void* y, float* mean_out, float* rstd_out, int64_t rows,
+                           int hidden, float eps, int flags, int dt, ar_stream_t stream);
+int ar_layernorm_bwd_exact(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd, const void* dres, void* dx,
+                           int64_t rows, int hidden, int dt, ar_stream_t stream);
 
 /* ---- weight-gradient GEMM (hand-written MFMA, gfx950) -------------------------------------------------------------
  * replaces: the autograd backward of F.linear(x, weight_q) with respect to weight_q inside WrapperLinear.forward

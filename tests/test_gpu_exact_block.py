@@ -214,7 +214,7 @@ def test_exact_plan_is_reused_for_later_blocks_of_the_same_kind_and_refused_for_
         x = fp_out
     kinds = [k[0] for k in q._exact_plans]
     assert kinds.count("exact") == 1 and kinds.count("exact_plain") == 1        # one proof per form, two blocks
-    # an OPT block is not covered: exact_rounding then means the module path, never the (inexact) fused path
+    # a block of no known family is not covered: exact_rounding then means the module path, never the (inexact) fused path
     assert ExactLlamaBlock.try_build(torch.nn.Linear(4, 4), [], {}) is None
 
 
@@ -307,3 +307,99 @@ def test_streamk_structure_found_on_one_gradient_pair_reproduces_the_library_on_
         got = torch.empty_like(lib)
         assert ops.gemm_dw_sk(dY2, X2, got, kcut)
         assert torch.equal(got.view(torch.int16), torch.mm(dY2.t(), X2).view(torch.int16))
+
+
+# ---- round 6: nn.LayerNorm with torch's bits (csrc/ar_exact_ln.hip) and the exact form of OPT-style blocks -------------------------------
+@pytest.mark.parametrize("T,H", [(16384, 768), (256, 768), (4096, 2048), (1000, 1024), (64, 5120), (4096, 12)])
+def test_layernorm_forward_and_backward_have_torchs_bits(T, H):
+    """What the module path computes for an OPT block's norms under autocast: x.float() -> native_layer_norm (fp32) -> the next linear's
+    cast, and autograd's backward of exactly that chain -- against ar_layernorm_fwd_exact / ar_layernorm_bwd_exact, bit for bit,
+    including the fp32 row statistics.  OPT-125M's minibatch (16384 x 768: one float4 per thread), rows with several vectors per
+    thread, rows shorter than the workgroup, and a row count that is no multiple of anything."""
+    from auto_round_amd import ops
+
+    g = gen(T * 7 + H)
+    x = (0.7 * torch.randn(T, H, device=DEV, generator=g) + 0.1).to(BF)
+    w = (1 + 0.2 * torch.randn(H, device=DEV, generator=g)).to(BF)
+    b = (0.1 * torch.randn(H, device=DEV, generator=g)).to(BF)
+    dy = (0.01 * torch.randn(T, H, device=DEV, generator=g)).to(BF)
+    dres = (0.01 * torch.randn(T, H, device=DEV, generator=g)).to(BF)
+    xl = x.detach().requires_grad_(True)
+    with torch.autocast("cuda", dtype=BF):
+        yf = torch.nn.functional.layer_norm(xl, (H,), w, b, 1e-5)
+    assert yf.dtype == torch.float32                      # autocast's fp32 list
+    y_ref = yf.to(BF)
+    y_ref.backward(dy)
+    _, mean_t, rstd_t = torch.ops.aten.native_layer_norm(x.float(), [H], w.float(), b.float(), 1e-5)
+
+    y, mean, rstd = ops.layernorm_fwd_exact(x, w, b, 1e-5)
+    assert same(mean, mean_t.view(-1)) and same(rstd, rstd_t.view(-1))
+    assert same(y, y_ref.detach())
+    assert ops.layernorm_fwd_exact(x, w, b, 1e-5, want_stats=False)[1] is None
+    dx = ops.layernorm_bwd_exact(dy, x, w, mean, rstd)
+    assert same(dx, xl.grad)
+    assert same(ops.layernorm_bwd_exact(dy, x, w, mean, rstd, dres=dres), xl.grad + dres)
+
+
+def test_layernorm_exact_refuses_what_it_does_not_mirror():
+    from auto_round_amd import ops
+    from auto_round_amd._lib import Mi355xLibraryError
+
+    x = torch.randn(64, 770, device=DEV).to(BF)           # hidden % 4 != 0: ATen's non-vectorised kernels
+    assert ops.layernorm_fwd_exact(x, torch.ones(770, device=DEV, dtype=BF), torch.zeros(770, device=DEV, dtype=BF), 1e-5) is None
+    assert not ops.layernorm_bwd_exact_ok(32768, 768) and ops.layernorm_bwd_exact_ok(16384, 768)
+    x = torch.randn(32768, 64, device=DEV).to(BF)         # rows >= 32768: ATen's ROCm build runs cuComputeGradInput there
+    w = torch.ones(64, device=DEV, dtype=BF)
+    y, mean, rstd = ops.layernorm_fwd_exact(x, w, torch.zeros(64, device=DEV, dtype=BF), 1e-5)
+    with pytest.raises(Mi355xLibraryError):
+        ops.layernorm_bwd_exact(x, x, w, mean, rstd)
+
+
+def _small_opt(hidden=512, ffn=2048, heads=8, layers=1, seq=256, nsamples=16):
+    from transformers import OPTConfig, OPTForCausalLM
+
+    torch.manual_seed(0)
+    cfg = OPTConfig(hidden_size=hidden, ffn_dim=ffn, num_attention_heads=heads, num_hidden_layers=layers, vocab_size=512,
+                    max_position_embeddings=1024, word_embed_proj_dim=hidden)
+    cfg._attn_implementation = "sdpa"
+    model = OPTForCausalLM(cfg).to(BF).eval().to(DEV)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    tokens = torch.randint(0, 512, (nsamples, seq), generator=torch.Generator().manual_seed(1))
+    return model, tokens
+
+
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_exact_opt_block_is_proven_against_the_module_path_and_tunes_to_identical_packed_weights(with_mask):
+    """An OPT block (hidden 512, head size 64, biases everywhere, ReLU MLP) through the whole tuning loop twice: module path and
+    exact_rounding (auto_round_amd/exact_opt_block.py).  The plan must have been proven with both LayerNorm kernels in it, the loss
+    traces and every packed tensor must be identical."""
+    model, tokens = _small_opt()
+    q_mod, packed_mod = _tune(model, tokens, exact=False, with_mask=with_mask)
+    q_ex, packed_ex = _tune(model, tokens, exact=True, with_mask=with_mask)
+    assert not q_mod.last_exact and q_ex.last_exact
+    assert type(q_ex).__name__ == "SignRoundQuantizer"
+    rep = q_ex.last_exact_report
+    assert rep and rep["usable"], rep
+    assert rep["plan"]["ln1"] and rep["plan"]["ln2"], rep
+    assert q_ex.last_stats["loss_trace"] == q_mod.last_stats["loss_trace"]
+    assert sorted(packed_ex) == sorted(packed_mod)
+    for n in packed_mod:
+        for a, b in zip(packed_ex[n], packed_mod[n]):
+            assert torch.equal(a, b), n
+
+
+def test_opt_no_grad_passes_run_on_the_exact_form_and_keep_the_module_codes_bits():
+    from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.testing import t3_fixture as fx
+
+    model, tokens = _small_opt()
+    block = fx.decoder_blocks(model)[0]
+    x0, others = fx.capture_block_inputs(model, block, tokens, torch.device(DEV))
+    q_mod = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=8, bits=4, sdpa_backend="auto"), device=DEV)
+    q_ex = SignRoundQuantizer(SignRoundConfig(iters=1, batch_size=8, bits=4, sdpa_backend="auto", exact_rounding=True), device=DEV)
+    y_mod = q_mod.forward_all(block, x0, others)
+    y_ex = q_ex.forward_all(block, x0, others)
+    plans = [v for k, v in q_ex._exact_plans.items() if k[0] == "exact_plain"]
+    assert plans and plans[0] and plans[0]["ln1"] and plans[0]["ln2"], plans
+    assert same(y_ex, y_mod)

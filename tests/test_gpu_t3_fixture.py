@@ -314,6 +314,21 @@ def test_module_path_reproduces_reference_run_1_of_the_two_run_fixtures(path, re
     assert abs(r["best_loss_ratio"] - 1.0) <= 0.015, _full(r)
 
 
+def test_opt125m_on_exact_rounding_reproduces_reference_run_1(record_property):
+    """BASELINE configs[0] on its bit-identical FAST path (round 6, auto_round_amd/exact_opt_block.py: one autograd node, ATen's
+    LayerNorm kernels restated, module-shaped GEMMs, the library attention): the OPT-125M-dimension block at the full recipe against
+    what the REAL reference produced (tests/golden/t3s_opt125m_w4g128.npz).  The proof must have put both LayerNorm kernels in the
+    plan; the result must be the reference's bit for bit (one accounted repeat: the library attention slips once in ~4000 calls)."""
+    from auto_round_amd.testing import t3_fixture as fx
+
+    path = next(p for p in _t3s_fixtures() if "opt125m" in p)
+    chk = lambda: fx.check_against_stat_fixture(path, exact=True)  # noqa: E731
+    r = _run_with_one_retry(chk, record_property, "opt125m exact_rounding")
+    assert r["exact_block"] and r["inputs_identical"] and r["targets_identical"], _full(r)
+    assert r["bit_identical"] and r["first_divergence_iter"] is None and abs(r["best_loss_ratio"] - 1.0) < 1e-5, _full(r)
+    _account(r)
+
+
 @pytest.mark.parametrize("path", [p for p in _t3s_fixtures() if "mixtral" in p], ids=lambda p: os.path.basename(p)[4:-4])
 def test_fused_moe_path_stays_on_the_reference_trajectory_level_at_real_width(path):
     """The fused MoE block (grouped expert GEMMs, one sorted-row pass) against the same reference-made fixtures: other rounding
