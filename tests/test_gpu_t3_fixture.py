@@ -249,6 +249,34 @@ def test_exact_rounding_path_reproduces_the_reference_digest_of_the_other_scheme
     _account(r)
 
 
+# ---- round 6: BASELINE configs[2] at its own length (iters = 1000, lr = 2 / iters) -----------------------------------------------------
+def test_exact_rounding_stays_on_the_module_paths_bits_over_configs2s_1000_iterations(record_property):
+    """W2 group_size=32 asym + the algorithm extension at Llama-3-8B's block dimensions, 1000 iterations (125 passes over the 64
+    samples, the reference's lr = 2 / iters rule for <= 3 bits, best iteration 999): `tests/golden/t3m_llama8b_w2g32_asym_algext_1000.npz`
+    was made by THIS package's module path (two identical runs; tools/gpu/r06_make_cfg2_1000_digest.py) -- the reference tree cannot
+    run on the GPU box, and the module path is what reproduces the reference-made 200-iteration digest of the same configuration bit
+    for bit (the t3v2 tests above).  Here `exact_rounding`, the headline's path, must reproduce it over the 5x longer trajectory."""
+    import json
+
+    import numpy as np
+
+    from auto_round_amd.testing import t3_fixture as fx
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "t3m_llama8b_w2g32_asym_algext_1000.npz")
+    m = json.loads(str(np.load(path, allow_pickle=False)["meta"]))
+    assert m["iters"] == 1000 and "NOT the reference" in m["made_by"]
+    same_stack, _ = _v2_stack(path)
+    chk = lambda: fx.check_against_digest_v2(path, exact=True)  # noqa: E731
+    r = _run_with_one_retry(chk, record_property, "configs[2] at 1000 iterations, exact_rounding") if same_stack else chk()
+    record_property("tune_s", r["tune_s"])
+    assert r["exact_block"] and r["inputs_identical"] and r["targets_identical"], _full(r)
+    if same_stack:
+        assert r["bit_identical"] and r["first_divergence_iter"] is None, _full(r)
+    else:
+        assert r["full_layer_identical_weights"] > 0.5 and abs(r["best_loss_ratio"] - 1.0) < 0.03, _full(r)
+    _account(r)
+
+
 # ---- round 5: two-reference-run fixtures (tests/golden/t3s_*.npz, tests/t3_baseline_shapes.py --ref-twice ... --stat-fixture-dir) ----------
 # OPT-125M (BASELINE configs[0], the north-star's own model) and Mixtral-8x7B's MoE block at real width under MXFP4 and NVFP4
 # (configs[4]): the REAL reference ran TWICE on an MI355X with the same seed; both runs came out IDENTICAL (ref_vs_ref = 1.0 in every
