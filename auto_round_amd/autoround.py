@@ -82,9 +82,14 @@ class AutoRound:
         # GEMMs of a Mixtral block over ragged row counts.  Round 5 found it the hard way: with the mode on (the reference itself, and
         # this package behind the reference's front door) both blocks reproduce the reference bit for bit, without it the same code
         # parts from it after ~55 iterations.  Mirrored here, same keywords, same default.
+        # NOTE the side effect: like the reference's, this constructor leaves the mode ON for the whole process -- outside
+        # `quantize_block` every `torch.empty` of the caller's process is then NaN-filled (torch.utils.deterministic.
+        # fill_uninitialized_memory), calibration and export included.  `keep_torch_determinism_mode=True` (MI355X-only keyword) leaves
+        # the process's mode untouched for callers who manage it themselves; results are then only the reference's if they set it too.
         strict = bool(kwargs.pop("enable_deterministic_algorithms", False)) or not bool(kwargs.pop("disable_deterministic_algorithms", True))
-        os.environ.setdefault("CUBLAS_WORKSPACE_CONFIG", ":4096:8")
-        torch.use_deterministic_algorithms(True, warn_only=not strict)
+        if not bool(kwargs.pop("keep_torch_determinism_mode", False)):
+            os.environ.setdefault("CUBLAS_WORKSPACE_CONFIG", ":4096:8")
+            torch.use_deterministic_algorithms(True, warn_only=not strict)
         fused = bool(kwargs.pop("enable_torch_compile", False))
         # MI355X-only: Llama-family blocks through the first-party kernels that keep the eager path's bits (exact_block.py) -- on by
         # default: same results as the module code (proven per kind of block before use, module path otherwise), fewer launches

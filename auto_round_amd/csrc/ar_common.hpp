@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t f32_to_f16(float f) {
     return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);   // v_cvt_f16_f32, RNE
 }
 // two fp32 -> packed bf16x2 with the gfx950 conversion instruction (v_cvt_pk_bf16_f32: RNE, NaN quieted); verified
-// against the integer RNE formula over all 2^32 inputs by tools/exactcheck (profiles/r01_exactcheck.json).
+// against the integer RNE formula over all 2^32 inputs by tools/exactcheck (profiles/archive/r01_exactcheck.json).
 #ifndef AR_HW_BF16
 #define AR_HW_BF16 1
 #endif

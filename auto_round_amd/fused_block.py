@@ -961,7 +961,10 @@ class FusedMoEBlock(FusedLlamaBlock):
         # grouped expert GEMMs: every expert's layers in ONE arena (offsets relative to its flat buffers), widths the kernels take
         ea = trip[0][0].arena
         self._grp = None
-        if (all(l.arena is ea for t in trip for l in t) and ea.w_dtype == torch.bfloat16 and H % 256 == 0 and Fd % 256 == 0):
+        # (every expert offset a multiple of 8 elements: the grouped kernels move 16 bytes per LDS-DMA lane and store 8; an arena layer
+        #  with an odd element count in front of the experts would misalign them -- ADVICE r05)
+        if (all(l.arena is ea for t in trip for l in t) and ea.w_dtype == torch.bfloat16 and H % 256 == 0 and Fd % 256 == 0
+                and all(l._off % 8 == 0 for t in trip for l in t)):
             dev = ea.Wq.device
             self._grp = dict(arena=ea,
                              off_gu=torch.tensor([g._off for g, u, d in trip], dtype=torch.int64, device=dev),
@@ -1063,7 +1066,7 @@ class FusedMoEBlock(FusedLlamaBlock):
             _, rw, ri = self.router(h2)
         with torch.no_grad():
             K = ri.shape[1]
-            flat = ri.t().reshape(-1)                                   # index = slot * T + token (the module path's row order)
+            flat = ri.t().reshape(-1)                                   # index = slot * T + token (slot-major; the module path sorts token-major since round 5)
             order = torch.argsort(flat, stable=True)
             # per-expert row counts WITHOUT a host read (torch.bincount reads its input's maximum on the host): a compare-and-sum
             cnt = (flat.unsqueeze(1) == torch.arange(self.E, device=flat.device, dtype=flat.dtype)).sum(dim=0)

@@ -208,6 +208,10 @@ def set_amax_for_uncalibrated_experts(block, attr_name="act_max") -> int:
     return filled
 
 
+# keyword arguments of a decoder block that the reference's input cache keeps PER SAMPLE and its runner concatenates per minibatch
+PER_SAMPLE_MASK_KEYS = ("attention_mask", "attn_mask", "mask", "encoder_attention_mask", "causal_mask")
+
+
 @dataclass
 class BlockContext:
     """reference: algorithms BlockContext -- only the fields the quantizer reads."""
@@ -413,7 +417,8 @@ class SignRoundQuantizer:
             return input_others
 
         def mat(v):
-            if isinstance(v, torch.Tensor) and v.dim() >= 3 and v.shape[0] == 1 and rows > 1 and v.is_floating_point():
+            # (whatever the dtype: transformers may hand the sdpa path a BOOLEAN mask, and the reference's runner concatenates that too)
+            if isinstance(v, torch.Tensor) and v.dim() >= 3 and v.shape[0] == 1 and rows > 1:
                 return v.expand(rows, *v.shape[1:]).contiguous()
             if isinstance(v, tuple):
                 return tuple(mat(t) for t in v)
@@ -423,7 +428,9 @@ class SignRoundQuantizer:
         # position_ids, position_embeddings, cache_position (utils/common.py:676) -- stay one row there and must stay one row here: a
         # [8, S, 128] cos / sin instead of [1, S, 128] changes the layout `q * cos` returns, and with it the attention kernel's bits
         # (found on the Mixtral block, profiles/r05_t3_mixtral_forward_compare_*.json)
-        return {k: (mat(v) if (k != "positional_inputs" and k not in SHARED_CACHE_KEYS) else v) for k, v in input_others.items()}
+        # selected BY NAME: the attention mask and its aliases are the per-sample keys of a decoder block (block_runner.py:368-422);
+        # any other [1, ...] keyword tensor stays as it was handed over
+        return {k: (mat(v) if k in PER_SAMPLE_MASK_KEYS else v) for k, v in input_others.items()}
 
     def block_forward(self, block, x, input_others):
         input_others = self._others_for(x.shape[0], input_others)
@@ -483,6 +490,11 @@ class SignRoundQuantizer:
             if fused is not None:
                 fused.flash_fwd = bool(cfg.flash_attention)
                 fused.flash_bwd = bool(cfg.flash_attention_bwd)
+                if cfg.momentum and getattr(fused, "grouped", False):
+                    # the grouped weight-gradient launch writes a ZERO gradient for an expert that got no rows and marks it as
+                    # computed; with momentum the step then decays that expert's buffer and applies sign(buf), where the reference's
+                    # SignSGD skips parameters whose grad is None (sign_sgd.py:356-389) -- the per-expert loop keeps that distinction
+                    fused.grouped = False
                 # the fused kernels must compute what the block's own code computes: one small minibatch through both
                 # (once per kind of block: the verdict is remembered by class and by whether any submodule carries its own forward)
                 key = ("tune", self._block_signature(block), self._others_signature(block, input_others))

@@ -389,7 +389,7 @@ int64_t ar_gemm_dw_workspace_bytes(int64_t M, int64_t N, int64_t K);
 /* The same weight-gradient GEMM GROUPED over the experts of a sparse-MoE block: group e owns k-rows [row_off[e], row_off[e+1]) of
  * dY [R, M] and X [R, N] (the rows of the tokens routed to expert e, sorted by expert) and writes its own dW_e [M, N] = dY_e^T X_e
  * to dW + w_off[e] (elements, ldw).  ONE launch of n_groups * (M/256) * (N/256) workgroups; row_off ([n_groups + 1] int32) and
- * w_off ([n_groups] int64) are DEVICE arrays, so the launch needs no host knowledge of the row counts (hipGraph-capturable); a group
+ * w_off ([n_groups] int64, multiples of 8 elements) are DEVICE arrays, so the launch needs no host knowledge of the row counts (hipGraph-capturable); a group
  * without rows writes zeros (sign(0) = 0: the sign-SGD step then leaves its parameters untouched, as a missing gradient does).
  * replaces: the autograd backward of the per-expert F.linear calls in the reference's "linear loop" experts
  *           (auto_round/modeling/fused_moe/moe_experts_interface.py:173-289 around auto_round/wrapper.py:528-556).  Deterministic. */
@@ -399,7 +399,8 @@ int ar_gemm_dw_grouped(const void* dY, const void* X, void* dW, int64_t M, int64
 /* ---- forward / input-gradient GEMM (hand-written MFMA "NT" kernel, gfx950; SURVEY 8 row f1 forward side) ---------------------
  * replaces: the forward of F.linear(x, weight_q) inside WrapperLinear.forward (auto_round/wrapper.py:528-556): C[M,N] = A[M,K] B[N,K]^T,
  *           A = activations [tokens, in], B = the fake-quant weight [out, in], both K-contiguous bf16 (leading dimensions in elements),
- *           fp32 accumulation over K in ascending order in steps of 16 (v_mfma_f32_32x32x16_bf16), one rounding to bf16 -- the
+ *           fp32 accumulation over K in ascending order (default: v_mfma_f32_16x16x32_bf16; ar_gemm_nt_config(0): 32x32x16 -- identical
+ *           bits in both shapes, an EMPIRICAL result held by tests/test_gpu_gemm_nt.py), one rounding to bf16 -- the
  *           summation the library's kernel performs for these shapes; with B = a transposed weight copy [in, out] the same call is the
  *           input gradient dX = dY Wq.  M any (rows past M are clamped on the load side, masked on the store side), N % 256 == 0,
  *           K % 128 == 0, operands 16-byte aligned, lda / ldb multiples of 8, ldc a multiple of 4; anything else returns
@@ -409,7 +410,8 @@ int ar_gemm_nt(const void* A, const void* B, void* C, int64_t M, int64_t N, int6
 /* Grouped over the experts of a sparse-MoE block (one launch per projection instead of a Python loop of per-expert GEMMs with a host
  * read of the token counts, auto_round/modeling/fused_moe/moe_experts_interface.py:173-289): group e multiplies rows
  * [row_off[e], row_off[e+1]) of A (and writes the same rows of C) with ITS matrix B + b_off[e] ([N, K], ldb).  row_off
- * ([n_groups + 1] int32) and b_off ([n_groups] int64, elements) are DEVICE arrays; M = row_off[n_groups] = rows of A.  The grid covers
+ * ([n_groups + 1] int32) and b_off ([n_groups] int64, elements, EVERY ENTRY A MULTIPLE OF 8: 16-byte LDS-DMA reads; device values
+ * cannot be validated here -- auto_round_amd/fused_block.py checks its arena offsets) are DEVICE arrays; M = row_off[n_groups] = rows of A.  The grid covers
  * M / 256 + n_groups row tiles (every group may end in a partial tile); workgroups past the last real tile exit.  Deterministic. */
 int ar_gemm_nt_grouped(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                        const int32_t* row_off, const int64_t* b_off, int n_groups, ar_stream_t stream);
