@@ -87,6 +87,33 @@ def reproducible_sdpa_forward(enabled: bool = True):
         F.scaled_dot_product_attention = real
 
 
+@contextlib.contextmanager
+def verified_sdpa_forward(flag: torch.Tensor):
+    """Every GRAD-MODE `F.scaled_dot_product_attention` call inside the context is issued TWICE (the second one detached, same
+    training-mode kernel) and `flag` (a one-element device tensor) is set when the two results differ in any bit -- no host
+    synchronisation.  The library's attention forward slips about once in 4000 calls at OPT-125M's shape even in its training-mode
+    form (profiles/r06_opt_loop_flake2.json: the one op of a tuning iteration that is not reproducible); a tuning run whose flag is
+    set at the end has -- or may have -- taken a corrupted step and is repeated by the caller (`SignRoundConfig.
+    verify_attention_forward`), which makes the tuned block a deterministic function of its inputs on a library that is not."""
+    real = F.scaled_dot_product_attention
+
+    def sdpa(query, key, value, *a, **kw):
+        out = real(query, key, value, *a, **kw)
+        if torch.is_grad_enabled() and out.requires_grad and query.is_cuda and not kw.get("dropout_p", 0.0):
+            with torch.enable_grad():
+                again = real(query.detach().requires_grad_(True), key.detach(), value.detach(), *a, **kw).detach()
+            it = {2: torch.int16, 4: torch.int32}.get(out.element_size())
+            if it is not None:
+                flag.logical_or_((out.detach().view(it) != again.view(it)).any())
+        return out
+
+    F.scaled_dot_product_attention = sdpa
+    try:
+        yield
+    finally:
+        F.scaled_dot_product_attention = real
+
+
 def efficient_backward_ok(seq: int) -> bool:
     """torch 2.10 + ROCm 7.2: the backward of the "efficient" SDPA kernels (aiter fmha_bwd behind AOTriton) returns wrong
     gradients (relative error ~1, NaNs) for token-major [B, S, H, D] operands when S % 256 == 128 and S > 128 (384, 640, 896, ...);

@@ -195,7 +195,8 @@ def capture_block_inputs(model, block, tokens: torch.Tensor, device, amp_dtype=t
 def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw: Optional[dict] = None, iters: int = 200,
                       nsamples: int = 128, seqlen: int = 2048, batch_size: int = 8, fused: bool = False, alg_ext: bool = False,
                       seed: int = 42, device="cuda:0", graph: Optional[bool] = None, materialise: bool = True, exact: bool = False,
-                      lr: Optional[float] = None, minmax_lr: Optional[float] = None, stages: bool = True, reproducible_attention: bool = True) -> dict:
+                      lr: Optional[float] = None, minmax_lr: Optional[float] = None, stages: bool = True, reproducible_attention: bool = True,
+                      verify_attention: bool = False) -> dict:
     """The plugin-mode flow without the reference around it: same seeded block, same block inputs, targets from the module-path
     forward (what the reference's orchestrator hands to `quantize_block`), `transformers.set_seed(seed)` right before the block
     (the reference's sampler then draws the same minibatches), then `SignRoundQuantizer.quantize_block` -- on the module path
@@ -211,13 +212,14 @@ def tune_with_product(arch: str = "opt125m", *, scheme: str = "W4A16", scheme_kw
     try:
         return _tune_with_product(arch, scheme=scheme, scheme_kw=scheme_kw, iters=iters, nsamples=nsamples, seqlen=seqlen, batch_size=batch_size,
                                   fused=fused, alg_ext=alg_ext, seed=seed, device=device, graph=graph, materialise=materialise, exact=exact,
-                                  lr=lr, minmax_lr=minmax_lr, stages=stages, reproducible_attention=reproducible_attention)
+                                  lr=lr, minmax_lr=minmax_lr, stages=stages, reproducible_attention=reproducible_attention,
+                                  verify_attention=verify_attention)
     finally:
         torch.use_deterministic_algorithms(det_before[0], warn_only=det_before[1])
 
 
 def _tune_with_product(arch, *, scheme, scheme_kw, iters, nsamples, seqlen, batch_size, fused, alg_ext, seed, device, graph, materialise, exact,
-                       lr, minmax_lr, stages=True, reproducible_attention=True) -> dict:
+                       lr, minmax_lr, stages=True, reproducible_attention=True, verify_attention=False) -> dict:
     import transformers
 
     from auto_round_amd.autoround import loss_mask_ids
@@ -254,6 +256,8 @@ def _tune_with_product(arch, *, scheme, scheme_kw, iters, nsamples, seqlen, batc
         else:
             y = q_mod.calibrate_block(block, x0, others)              # module path: the targets the reference would hand over
     kw = {} if graph is None else {"hip_graph": bool(graph)}
+    if verify_attention:
+        kw["verify_attention_forward"] = True
     if lr is not None:
         kw.update(lr=float(lr), minmax_lr=float(minmax_lr if minmax_lr is not None else lr))
     cfg = SignRoundConfig(iters=iters, batch_size=batch_size, bits=sch["bits"], sdpa_backend="auto", fused_block=bool(fused),
@@ -456,7 +460,8 @@ def stat_thresholds(rvr: dict) -> dict:
     return dict(min_identical=max(0.0, 1.0 - 2.0 * (1.0 - same) - 0.02), loss_band=max(0.01, 3.0 * spread))
 
 
-def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = False, graph: Optional[bool] = None, reproducible_attention: bool = True) -> dict:
+def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = False, graph: Optional[bool] = None, reproducible_attention: bool = True,
+                               verify_attention: bool = False) -> dict:
     """Re-tune a t3s fixture's block with this package, reference-free, and measure how close the result is to reference run 1 over
     the same per-layer prefixes reference run 2 was measured on -> a flat record with the derived thresholds next to the measurements."""
     z = np.load(path, allow_pickle=False)
@@ -466,7 +471,7 @@ def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = Fal
     lr, mmlr = kw.pop("lr", None), kw.pop("minmax_lr", None)
     r = tune_with_product(m["arch"], scheme=m["scheme"], scheme_kw=kw, iters=m["iters"], nsamples=m["nsamples"], seqlen=m["seqlen"],
                           batch_size=m["batch_size"], fused=fused, seed=m["seed"], exact=exact, alg_ext=alg_ext, lr=lr, minmax_lr=mmlr, graph=graph,
-                          reproducible_attention=reproducible_attention)
+                          reproducible_attention=reproducible_attention, verify_attention=verify_attention)
     mine = tuned_layer_tensors(r["block"])
     P = int(m["prefix"])
     tot = same = stot = ssame = ctot = csame = 0
@@ -514,4 +519,5 @@ def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = Fal
                 ref_vs_ref_first_divergence_iter=rvr.get("first_divergence_iter"), **stat_thresholds(rvr), tune_s=r["tune_s"],
                 result_digest=hashlib.sha256("".join(f"{k}:{v};" for k, v in sorted(got.items())).encode()).hexdigest(), y_dtype=r.get("y_dtype"),
                 stage_report=r.get("stage_report"), first_differing_stage=(r.get("stage_report") or {}).get("stage"),
+                attention_forward_retries=r["stats"].get("attention_forward_retries"),
                 device=m.get("device"), torch=m.get("torch"))

@@ -31,7 +31,16 @@ def test_single_gpu_line_has_the_contract_fields_and_live_roofline():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and "workload" in d["config"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["launches"] == 2 * 4 and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    # the bench measures what ships (round 6): fuse_next_forward on -- K1 runs once per block, iteration i+1's Wq comes out of the fused
+    # backward kernel, whose launches are the per-iteration ones
+    assert d["config"]["fuse_next_forward"] is True
+    assert rf["bound"] == "hbm" and rf["launches"] == 2 and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert d["roofline_bwd_sgd"]["launches"] == 2 * 4 and "next forward" in d["roofline_bwd_sgd"]["kernel"]
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-extras", "--no-fuse-next-forward", "--no-cpu-baseline"] + SMALL,
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["fuse_next_forward"] is False and d["roofline"]["launches"] == 2 * 4          # the A/B form: K1 every iteration
 
 
 def test_two_ranks_run_the_sharded_pipeline():

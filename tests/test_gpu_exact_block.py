@@ -403,3 +403,56 @@ def test_opt_no_grad_passes_run_on_the_exact_form_and_keep_the_module_codes_bits
     plans = [v for k, v in q_ex._exact_plans.items() if k[0] == "exact_plain"]
     assert plans and plans[0] and plans[0]["ln1"] and plans[0]["ln2"], plans
     assert same(y_ex, y_mod)
+
+
+def test_a_block_whose_attention_forward_was_caught_differing_is_restored_and_tuned_again(monkeypatch):
+    """`verify_attention_forward`: the retry machinery on a tiny OPT block (activation-quantised, so the finished run leaves shells to
+    undo): a first attempt whose flag is forced is thrown away -- fp weights, scheme attributes and the `random` stream restored -- and
+    the second attempt must give exactly what an unverified run gives."""
+    import transformers
+
+    from auto_round_amd import attention
+    from auto_round_amd.autoround import loss_mask_ids
+    from auto_round_amd.export import pack_block
+    from auto_round_amd.quantizer import BlockContext, SignRoundConfig, SignRoundQuantizer
+    from auto_round_amd.schemes import apply_scheme, resolve_scheme
+    from auto_round_amd.testing import t3_fixture as fx
+
+    import copy
+
+    base, tokens = _small_opt(hidden=256, ffn=512, heads=4, seq=128, nsamples=8)
+
+    def run(verify):
+        model = copy.deepcopy(base)
+        block = fx.decoder_blocks(model)[0]
+        sch = resolve_scheme("MXFP4")
+        apply_scheme(block, sch)
+        x0, others = fx.capture_block_inputs(model, block, tokens, torch.device(DEV))
+        q = SignRoundQuantizer(SignRoundConfig(iters=6, batch_size=4, bits=4, sdpa_backend="auto", verify_attention_forward=verify), device=DEV)
+        y = q.calibrate_block(block, x0, others)
+        transformers.set_seed(7)
+        q.quantize_block(block, x0, others, y, None, BlockContext(0, 1, "0"), input_ids=loss_mask_ids(tokens, None))
+        return q, {n: (m.weight_packed.clone(), m.weight_scale.clone().view(torch.uint8)) for n, m in pack_block(block).items()}
+
+    q0, plain = run(False)
+    real = attention.verified_sdpa_forward
+    calls = {"n": 0}
+
+    import contextlib
+
+    @contextlib.contextmanager
+    def forced(flag):
+        calls["n"] += 1
+        with real(flag):
+            yield
+        if calls["n"] == 1:
+            flag.fill_(True)            # "a pair differed" during the first attempt
+
+    monkeypatch.setattr(attention, "verified_sdpa_forward", forced)
+    with pytest.warns(UserWarning, match="verify_attention_forward"):
+        q1, verified = run(True)
+    assert calls["n"] == 2 and q1.last_stats["attention_forward_retries"] == 1 and not q1.last_stats["attention_forward_unverified"]
+    assert q1.last_stats["loss_trace"] == q0.last_stats["loss_trace"]
+    assert sorted(verified) == sorted(plain)
+    for n in plain:
+        assert torch.equal(verified[n][0], plain[n][0]) and torch.equal(verified[n][1], plain[n][1]), n
