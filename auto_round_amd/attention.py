@@ -88,6 +88,61 @@ def reproducible_sdpa_forward(enabled: bool = True):
 
 
 @contextlib.contextmanager
+def guarded_sdpa(mode: str):
+    """EXPERIMENT / mitigation (round 6): small device-side operations around every `F.scaled_dot_product_attention` call.  mode is a
+    comma list of: "before" (a one-element kernel on the query before the call), "after" (one on the output after it), "touch" (a
+    full read of the output after the call: `out.sum()` into a scratch scalar).  Same values in and out; only the launch sequence
+    around the library kernel changes (tools/gpu/r06_sdpa_guard_ab.py measures what that does to run-to-run reproducibility)."""
+    modes = {m.strip() for m in (mode or "").split(",") if m.strip()}
+    if not modes:
+        yield
+        return
+    real = F.scaled_dot_product_attention
+    scratch = {}
+
+    def sdpa(query, key, value, *a, **kw):
+        if query.is_cuda:
+            s = scratch.get(query.device)
+            if s is None:
+                s = scratch[query.device] = torch.zeros(4, dtype=torch.float32, device=query.device)
+            if "before" in modes:
+                s[0:1].add_(1.0)
+            if "flush_before" in modes or "flush_after" in modes:
+                big = scratch.get("big")
+                if big is None:
+                    big = scratch["big"] = torch.zeros(1 << 25, dtype=torch.float32, device=query.device)      # 128 MB read + written
+            if "flush_before" in modes:
+                big.add_(1.0)
+            if "touch_inputs" in modes:          # read q / k / v / mask right before the call (pull them towards the caches)
+                with torch.no_grad():
+                    m = kw.get("attn_mask")
+                    acc = query.detach().float().sum() + key.detach().float().sum() + value.detach().float().sum()
+                    if m is not None:
+                        acc = acc + m.float().sum()
+                    s[3:4].copy_(acc.reshape(1))
+            if "sync_before" in modes:
+                torch.cuda.synchronize(query.device)
+        out = real(query, key, value, *a, **kw)
+        if query.is_cuda:
+            if "sync_after" in modes:
+                torch.cuda.synchronize(query.device)
+            if "flush_after" in modes:
+                big.add_(1.0)
+            if "after" in modes:
+                s[1:2].add_(1.0)
+            if "touch" in modes:
+                with torch.no_grad():
+                    s[2:3].copy_(out.detach().float().sum().reshape(1))
+        return out
+
+    F.scaled_dot_product_attention = sdpa
+    try:
+        yield
+    finally:
+        F.scaled_dot_product_attention = real
+
+
+@contextlib.contextmanager
 def verified_sdpa_forward(flag: torch.Tensor):
     """Every GRAD-MODE `F.scaled_dot_product_attention` call inside the context is issued TWICE (the second one detached, same
     training-mode kernel) and `flag` (a one-element device tensor) is set when the two results differ in any bit -- no host

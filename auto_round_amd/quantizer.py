@@ -301,6 +301,8 @@ class SignRoundConfig:
     # weights and tuned again (same minibatch schedule), up to two times.  Cost: one more attention forward per iteration (+13 % at
     # OPT-125M on the exact path); without it about one OPT-125M run in fifteen takes a corrupted step -- as the reference itself does.
     verify_attention_forward: bool = False
+    # small device-side operations around every attention call of the tuning loop (attention.guarded_sdpa: "before", "after", "touch")
+    sdpa_guard: str = ""
     # Llama-family blocks through first-party kernels that keep the MODULE PATH'S BITS (auto_round_amd/exact_block.py,
     # csrc/ar_exact.hip): eager torch's rounding points and reduction order in the elementwise kernels, the module path's GEMM
     # shapes plus whichever faster GEMM forms prove bit-equal on this GPU / software stack.  Verified against the module code on
@@ -447,7 +449,9 @@ class SignRoundQuantizer:
                        **kwargs) -> dict:
         # the whole block is tuned with the quantizer's device current: torch's ops take the device from their tensors, the
         # C-ABI launches take the stream of their tensors' device (ops._launch) -- both agree for any `device=`
-        with torch.cuda.device(self.device), _no_uninitialised_fill():
+        from .attention import guarded_sdpa
+
+        with torch.cuda.device(self.device), _no_uninitialised_fill(), guarded_sdpa(getattr(self.config, "sdpa_guard", "") or ""):
             if not getattr(self.config, "verify_attention_forward", False):
                 return self._quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs)
             return self._quantize_block_verified(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs)

@@ -258,10 +258,15 @@ def _tune_with_product(arch, *, scheme, scheme_kw, iters, nsamples, seqlen, batc
     kw = {} if graph is None else {"hip_graph": bool(graph)}
     if verify_attention:
         kw["verify_attention_forward"] = True
+    if os.environ.get("AR_SDPA_GUARD"):
+        kw["sdpa_guard"] = os.environ["AR_SDPA_GUARD"].replace("broadcast_mask", "").strip(",")
+    if "broadcast_mask" in os.environ.get("AR_SDPA_GUARD", ""):      # (probe: the mask as one broadcastable row in the tuning loop)
+        kw["materialise_shared_rows"] = False
     if lr is not None:
         kw.update(lr=float(lr), minmax_lr=float(minmax_lr if minmax_lr is not None else lr))
+    kw.setdefault("materialise_shared_rows", materialise)
     cfg = SignRoundConfig(iters=iters, batch_size=batch_size, bits=sch["bits"], sdpa_backend="auto", fused_block=bool(fused),
-                          mfma_dw_gemm=bool(fused), materialise_shared_rows=materialise, exact_rounding=bool(exact), **kw)
+                          mfma_dw_gemm=bool(fused), exact_rounding=bool(exact), **kw)
     q = q_cls(cfg, device=device)
     transformers.set_seed(seed)
     import time

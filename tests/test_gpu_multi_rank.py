@@ -69,7 +69,9 @@ def test_block_sharded_front_door_equals_the_single_process_run(tmp_path, scheme
     assert r.returncode == 0, r.stderr[-2000:]
     backend, tried = _two_ranks(shd, False, scheme)
     record_property("backend", backend)
-    print(f"\n[multi-rank] block-sharded front door ran over {backend} (tried: {[(b, rc) for b, rc, _ in tried]})")
+    why = [ln.strip()[:200] for b, rc, err in tried if rc for ln in err.splitlines() if ("NCCL" in ln or "RCCL" in ln or "uplicate" in ln)][-2:]
+    print(f"\n[multi-rank] block-sharded front door ran over {backend} (tried: {[(b, rc) for b, rc, _ in tried]}; refused with: {why})")
+    record_property("nccl_refusal", "; ".join(why))
     run = json.load(open(os.path.join(shd, "run.json")))
     assert [m["rank"] for m in run] == [0, 1] and all(m["world"] == 2 and m["sharded"] and not m["data_parallel"] for m in run)
     assert run[0]["owned_blocks"] == [0, 2] and run[1]["owned_blocks"] == [1, 3] and run[0]["backend"] == backend

@@ -1,9 +1,9 @@
 #!/bin/bash
 # HBM traffic of K1 / K2 from the PMC counters, as MI355X_MICROARCH.md prescribes: two SEPARATE passes (FETCH_SIZE, WRITE_SIZE), kernel
-# trace + counters only, over tools/pmc_traffic_probe.py; merged into gpurun_out/r05/pmc_traffic.json (-> profiles/r05_pmc_traffic.json).
+# trace + counters only, over tools/pmc_traffic_probe.py; merged into gpurun_out/r06/pmc_traffic.json (-> profiles/r06_pmc_traffic.json).
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
-O=$GRAFT_REPO_ROOT/gpurun_out/r05; mkdir -p "$O"
+O=$GRAFT_REPO_ROOT/gpurun_out/r06; mkdir -p "$O"
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
