@@ -322,7 +322,7 @@ def parity_vs_reference_fixture():
 
 
 def read_traffic(kernel, abytes=None):
-    """HBM bytes per launch from THIS tree's PMC passes (profiles/r05_pmc_traffic.json: tools/gpu/r05_pmc_traffic.sh), or null: the file
+    """HBM bytes per launch from THIS tree's PMC passes (the newest profiles/rNN_pmc_traffic.json: tools/gpu/r06_pmc_traffic.sh), or null: the file
     carries the sha256 of the kernels' sources (csrc/ar_int.hip, ar_common.hpp) it was measured on and is refused when they have changed
     since (the line used to quote a round-3 constant).  The PMC run is made at the Llama-3-8B g128 block size; it is
     only reported when this run launches the same number of algorithmic bytes."""

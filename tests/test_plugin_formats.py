@@ -82,9 +82,7 @@ CASES = [
     ("w4g32_asym_auto_round", dict(scheme="W4A16", group_size=32, sym=False), "auto_round", "pack_awq"),   # -> auto_round:auto_awq
     ("w2g32_asym_auto_round", dict(scheme="W2A16G32", sym=False), "auto_round", "pack_int"),          # -> plain auto_round (zp)
     ("w3g32_sym_auto_round", dict(scheme="W3A16", group_size=32), "auto_round", "pack_int"),
-    ("w8g32_sym_auto_round", dict(scheme="W8A16", group_size=32), "auto_round", "pack_int"),
     ("w4g32_sym_auto_gptq", dict(scheme="W4A16", group_size=32), "auto_gptq", "pack_int"),            # plain GPTQ layout (+ g_idx)
-    ("w4g32_asym_auto_awq", dict(scheme="W4A16", group_size=32, sym=False), "auto_awq", "pack_awq"),
     ("mxfp4_auto_round", dict(scheme="MXFP4"), "auto_round", "pack_fp4"),
     ("nvfp4_auto_round", dict(scheme="NVFP4"), "auto_round", "pack_fp4"),
     ("w4a8_auto_round", dict(scheme="W4A16", group_size=32, act_bits=8), "auto_round", None),         # W4A8 container: falls through
