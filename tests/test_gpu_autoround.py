@@ -309,3 +309,24 @@ def test_two_identical_front_door_runs_give_identical_weights(kw):
     for n, p in outs[0].items():
         q = outs[1][n]
         assert torch.equal(p.view(torch.int16) if p.dtype == torch.bfloat16 else p, q.view(torch.int16) if q.dtype == torch.bfloat16 else q), n
+
+
+def test_a_cpu_resident_layer_is_packed_on_the_gpu_and_equals_the_gpu_resident_pack():
+    """What `plugin.hip_pack_layer` meets behind the reference's front door: the orchestrator has moved the finished block off the GPU
+    before it packs (`mv_module_from_gpu`), and hands `device=<the HIP device>` to `pack_layer`.  The packers copy the layer over,
+    pack with the HIP kernels and the caller moves the buffers back: same words as packing the layer where it was tuned."""
+    from auto_round_amd.export import pack_layer
+
+    torch.manual_seed(3)
+    for backend, sym, bits in (("auto_round:auto_gptq", True, 4), ("auto_round:auto_awq", False, 4), ("auto_round", False, 2)):
+        lin = torch.nn.Linear(256, 128, bias=True).to(torch.bfloat16)
+        lin.bits, lin.group_size, lin.sym, lin.data_type, lin.act_bits = bits, 32, sym, "int", 16
+        maxq = (1 << (bits - 1)) if sym else (1 << bits) - 1
+        lin.scale = (torch.rand(128, 8) * 0.02 + 0.01).to(torch.float16)
+        lin.zp = maxq if sym else torch.randint(0, maxq + 1, (128, 8)).float()
+        on_cpu = pack_layer(lin, backend, device="cuda:0")
+        gpu = pack_layer(lin.to("cuda:0"), backend)
+        for k in ("qweight", "qzeros", "scales", "bias"):
+            a, b = getattr(on_cpu, k), getattr(gpu, k)
+            assert a.is_cuda and torch.equal(a, b), (backend, k)
+        assert {"qweight", "qzeros", "scales", "bias"} <= set(on_cpu.state_dict())          # registered buffers: the reference's save path reads state_dict()

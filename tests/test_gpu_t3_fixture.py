@@ -306,8 +306,10 @@ def _t3s_fixtures():
     return sorted(glob.glob(os.path.join(here, "golden", "t3s_*.npz")))
 
 
-MODULE_FLOOR = {"opt125m_w4g128": 0.80, "mixtral8x7b_mxfp4_100": 0.93, "mixtral8x7b_nvfp4_100": 0.72}
-FUSED_FLOOR = {"mixtral8x7b_mxfp4_100": 0.93, "mixtral8x7b_nvfp4_100": 0.70}      # (measured 0.957 / 0.771)
+# (Mixtral: measured 0.9574 / 0.7741 on the module path and 0.957 / 0.771 on the fused path in every suite run of rounds 5 and 6 -- the
+#  targets differ from the reference's deterministically, so the fractions repeat; the floors sit 1.5 points under them)
+MODULE_FLOOR = {"opt125m_w4g128": 0.80, "mixtral8x7b_mxfp4_100": 0.94, "mixtral8x7b_nvfp4_100": 0.76}
+FUSED_FLOOR = {"mixtral8x7b_mxfp4_100": 0.94, "mixtral8x7b_nvfp4_100": 0.755}
 
 
 @pytest.mark.parametrize("path", _t3s_fixtures(), ids=lambda p: os.path.basename(p)[4:-4])
