@@ -70,7 +70,7 @@ class _QuantLinearInt(torch.nn.Module):
         qw, qz, st = ops.pack_int(W, s, z, gs=self.group_size, bits=self.bits, zp_off=self.ZP_OFF)
         self.qweight, self.qzeros, self.scales = qw, qz, st
         if getattr(linear, "bias", None) is not None:
-            self.bias = linear.bias.detach().clone().half()
+            self.bias = linear.bias.detach().to(dev).clone().half()
 
 
 class QuantLinearZP(_QuantLinearInt):
@@ -113,8 +113,8 @@ class WQLinear_GEMM(torch.nn.Module):
         for name, t in (("qweight", qw), ("qzeros", qz), ("scales", st)):
             q.register_buffer(name, t)
         if linear.bias is not None:
-            q.bias = None
-            q.register_buffer("bias", linear.bias.detach().clone().half())
+            q.__dict__.pop("bias", None)        # (the constructor's placeholder attribute)
+            q.register_buffer("bias", linear.bias.detach().to(dev).clone().half())
         return q
 
 
@@ -150,8 +150,7 @@ class QuantLinearFP4(torch.nn.Module):
         if input_global_scale is not None:
             self._set_buffer("input_global_scale", input_global_scale.to(torch.float32).to(dev).reshape([1]))
         if getattr(linear, "bias", None) is not None:
-            self.bias = None
-            self._set_buffer("bias", linear.bias.detach().to(torch.float16))
+            self._set_buffer("bias", linear.bias.detach().to(dev).to(torch.float16))
 
     def _set_buffer(self, name, t):
         if name in self._buffers:
