@@ -47,3 +47,37 @@ def test_activation_quant_plans_follow_the_layer_attributes():
         act_quant_plan(_layer(act_bits=8, act_group_size=48), 4096 + 8)                           # groups must divide the row
     with pytest.raises(NotImplementedError):
         act_quant_plan(_layer(act_bits=8, act_dynamic=False, act_group_size=32), 4096)            # static int activations: not built
+
+
+def test_the_sdpa_context_managers_leave_torch_as_they_found_it_and_pass_cpu_calls_through():
+    """attention.reproducible_sdpa_forward / verified_sdpa_forward / guarded_sdpa patch `torch.nn.functional.scaled_dot_product_attention`
+    for the length of a `with` block (the module code looks the function up at call time); CPU tensors -- and every call the patches are
+    not about -- go straight to torch's function, and the original is back afterwards, also after an exception, also when nested."""
+    import torch
+    import torch.nn.functional as F
+
+    from auto_round_amd import attention as at
+
+    real = F.scaled_dot_product_attention
+    q = torch.randn(1, 2, 8, 16)
+    want = real(q, q, q)
+    flag = torch.zeros(1, dtype=torch.bool)
+    with at.reproducible_sdpa_forward():
+        assert F.scaled_dot_product_attention is not real
+        with at.reproducible_sdpa_forward():                     # nested: the inner one is a no-op
+            with torch.no_grad():
+                assert torch.equal(F.scaled_dot_product_attention(q, q, q), want)
+        assert F.scaled_dot_product_attention is not real
+    assert F.scaled_dot_product_attention is real
+    with at.reproducible_sdpa_forward(False):
+        assert F.scaled_dot_product_attention is real
+    for ctx in (lambda: at.verified_sdpa_forward(flag), lambda: at.guarded_sdpa("before,after,touch")):
+        try:
+            with ctx():
+                assert torch.equal(F.scaled_dot_product_attention(q, q, q), want)
+                raise KeyError("boom")
+        except KeyError:
+            pass
+        assert F.scaled_dot_product_attention is real and not bool(flag)
+    with at.guarded_sdpa(""):
+        assert F.scaled_dot_product_attention is real

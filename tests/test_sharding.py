@@ -192,3 +192,79 @@ def test_data_parallel_gradient_sync_world2_gloo():
     for rank, g, loss, loss_sum, ran, (r, w) in res:
         assert g == expect and loss == 1.5 and loss_sum == 3.0 and ran == [True, True] and (r, w) == (rank, 2)
     assert sh.dp_world() == (0, 1)
+
+
+def _front_door_worker(rank, world, port, tmp):
+    """model_tuner.tune_blocks_sharded + ShardWriter(tag=...) + autoround.sync_tuned_blocks over gloo on CPU tensors: what the front
+    door's sharded mode is made of (the HIP engine and packers stood in for: they need a GPU)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+
+        from auto_round_amd import autoround as ar
+        from auto_round_amd import model_tuner as mt
+        from auto_round_amd.shard_writer import ShardWriter
+
+        n_blocks, N, H = 5, 8, 16
+        torch.manual_seed(0)
+        blocks = [torch.nn.Sequential(torch.nn.Linear(H, H), torch.nn.Tanh()) for _ in range(n_blocks)]
+        for b in blocks:
+            b[0].bits = 4
+        samples = [torch.randn(1, 4, H, generator=torch.Generator().manual_seed(7 + i)) for i in range(N)]      # un-stacked, as a cache hands them over
+
+        class Q(_FakeQuantizer):
+            device = torch.device("cpu")
+
+            def quantize_block(self, block, xin, others, yout, q_inputs, ctx, input_ids=None, index_schedule=None):
+                best = super().quantize_block(block, xin, others, yout, q_inputs, ctx, input_ids=input_ids, index_schedule=index_schedule)
+                with torch.no_grad():                       # "tuning": something only the owner knows afterwards
+                    block[0].weight.mul_(0.5)
+                    block[0].scale = torch.full((H, 1), float(self.last_stats["sched_sum"]))
+                    block[0].zp = 8
+                return best
+
+        class _Packed(torch.nn.Module):
+            def __init__(self, lin):
+                super().__init__()
+                self.qweight, self.scales, self.qzeros = lin.weight.detach().clone(), lin.scale.clone(), torch.zeros(1)
+
+        monkey = mt.pack_block
+        mt.pack_block = lambda block, backend=None: {"0": _Packed(block[0])}
+        try:
+            w = ShardWriter(tmp, tag=f"rank{rank}")
+            names = [f"model.layers.{k}" for k in range(n_blocks)]
+            recs = mt.tune_blocks_sharded(blocks, samples if rank == 0 else [torch.zeros_like(s) for s in samples], {}, Q(), seed=42,
+                                          input_ids="ids", block_names=names, shard_writer=w)
+        finally:
+            mt.pack_block = monkey
+        assert sorted(recs) == sh.assign_blocks(n_blocks, world)[rank]
+        assert all(r["name"] == names[k] and "packed" in r and r["best_params"] for k, r in recs.items())
+        part = w.finish()
+        parts = [None] * world
+        dist.all_gather_object(parts, part)
+        got = ar.sync_tuned_blocks(blocks, world, torch.device("cpu"))
+        assert got == n_blocks - len(recs)                  # one tuned layer per block received from its owner
+        # every rank now holds every block's tuned weight and scale
+        torch.manual_seed(0)
+        fresh = [torch.nn.Sequential(torch.nn.Linear(H, H), torch.nn.Tanh()) for _ in range(n_blocks)]
+        for k in range(n_blocks):
+            assert torch.equal(blocks[k][0].weight, fresh[k][0].weight * 0.5), (rank, k)
+            assert blocks[k][0].zp == 8 and blocks[k][0].scale.shape == (H, 1)
+        if rank == 0:
+            index = json.load(open(ShardWriter.write_index(tmp, parts)))
+            wm = index["weight_map"]
+            assert len(wm) == 3 * n_blocks
+            for k in range(n_blocks):
+                assert wm[f"model.layers.{k}.0.qweight"].startswith(f"model-rank{k % world}-")
+            open(os.path.join(tmp, "ok2"), "w").write("1")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_sharded_front_door_pieces(tmp_path):
+    port = _free_port()
+    mp.spawn(_front_door_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok2").exists()
