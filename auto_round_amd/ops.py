@@ -680,6 +680,43 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq:
     return out, lse
 
 
+def attn_fwd_exact(q4: torch.Tensor, k4: torch.Tensor, v4: torch.Tensor, mask_struct, scale: float):
+    """The attention forward with the LIBRARY'S bits (ar_attn_fwd_exact, csrc/ar_attn_exact.hip): what
+    `F.scaled_dot_product_attention(q4, repeat_kv(k4), repeat_kv(v4), attn_mask=<the structured 0 / 1 mask>, scale=scale)` returns on
+    this stack, value for value -- callers PROVE that per call signature before relying on it (exact_block.plan_against_module).
+    q4 [B, H, S, D], k4 / v4 [B, H / kv_rep, S, D]: bf16 views with unit stride along D (token-major or head-major).
+    mask_struct = (bias_in, bias_out, valid_len) from `mask_structure`.  -> (out [B, S, H, D] contiguous, lse [B, H, S] fp32), or
+    None when the kernel does not take the call (the caller keeps torch's SDPA)."""
+    if mask_struct is None or q4.dim() != 4 or q4.dtype != torch.bfloat16 or k4.dtype != q4.dtype or v4.dtype != q4.dtype:
+        return None
+    B, H, S, D = (int(x) for x in q4.shape)
+    if D not in (64, 128) or S % 128 or k4.shape != v4.shape or k4.shape[0] != B or k4.shape[2] != S or k4.shape[3] != D:
+        return None
+    hk = int(k4.shape[1])
+    if hk < 1 or H % hk:
+        return None
+    for t in (q4, k4, v4):
+        if t.stride(3) != 1 or any(s % 8 for s in t.stride()[:3]) or t.data_ptr() % 16:
+            return None
+        if not t.is_cuda:
+            raise _lib.Mi355xLibraryError("attn_fwd_exact: the MI355X path only runs on a HIP device and has no CPU fallback")
+    dev = q4.device.index
+    if k4.device.index != dev or v4.device.index != dev:
+        raise _lib.Mi355xLibraryError("attn_fwd_exact: tensors live on different HIP devices")
+    out = torch.empty((B, S, H, D), dtype=q4.dtype, device=q4.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=q4.device)
+    b_in, b_out, valid = mask_struct
+    with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
+        rc = load().ar_attn_fwd_exact(q4.data_ptr(), k4.data_ptr(), v4.data_ptr(), out.data_ptr(), lse.data_ptr(), B, S, H, D, H // hk,
+                                      float(scale), float(b_in), float(b_out), int(valid), q4.stride(0), q4.stride(1), q4.stride(2),
+                                      k4.stride(0), k4.stride(1), k4.stride(2), v4.stride(0), v4.stride(1), v4.stride(2),
+                                      torch.cuda.current_stream(dev).cuda_stream)
+    if rc == _lib.AR_ERR_UNSUPPORTED:
+        return None
+    check(rc, "ar_attn_fwd_exact")
+    return out, lse
+
+
 _mask_struct_cache: dict = {}
 
 

@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 25
+#define AR_ABI_VERSION 26
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -455,6 +455,24 @@ int ar_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE
  * unstructured biases return AR_ERR_UNSUPPORTED: the caller keeps torch's SDPA. */
 int ar_attn_fwd_masked(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
                        float scale, float bias_in, float bias_out, int64_t valid_len, int64_t ldq, int64_t ldkv, ar_stream_t stream);
+
+/* ---- attention forward with the library's bits (csrc/ar_attn_exact.hip; round 6) ---------------------------------------------
+ * replaces: the same call as ar_attn_fwd_masked -- transformers' sdpa_attention_forward -> F.scaled_dot_product_attention(q, k, v,
+ *           attn_mask = the calibration flow's 0 / 1 additive mask) under the reference's block_forward
+ *           (auto_round/compressors/utils.py:109-172, auto_round/calibration/llm.py:360-402, inputs.py:100-107) -- on the
+ *           BIT-IDENTICAL paths: O and LSE equal, value for value, what torch 2.10.0+rocm7.0 returns for that call on gfx950 (AOTriton
+ *           0.11.1 `attn_fwd` with an additive bias; the arithmetic was read off the shipped code objects: key blocks of 32 keys at head
+ *           size 64 and 64 at head size 128, the bias scaled in bf16, the block row sums in the bias tile's lane order, ...: the
+ *           kernel's header).  Equality is an empirical property of one library build: callers prove it per call signature against
+ *           torch before using it (auto_round_amd/exact_block.py `plan_against_module`).
+ *           Q / K / V bf16 with element strides (batch, head, token; unit stride along D): any of [B, S, H, D] / [B, H, S, D] views;
+ *           K / V hold H / kv_rep heads (query head h reads key head h / kv_rep: transformers' repeat_kv only copies).  O is written
+ *           token-major contiguous [B, S, H, D]; LSE [B, H, S] fp32 (natural log).  bias_in / bias_out / valid_len: ar_attn_fwd_masked's
+ *           structured mask; both values must be bf16 numbers.  D in {64, 128}, S % 128 == 0; anything else AR_ERR_UNSUPPORTED. */
+int ar_attn_fwd_exact(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
+                      int64_t kv_rep, float scale, float bias_in, float bias_out, int64_t valid_len, int64_t q_bs, int64_t q_hs,
+                      int64_t q_ts, int64_t k_bs, int64_t k_hs, int64_t k_ts, int64_t v_bs, int64_t v_hs, int64_t v_ts,
+                      ar_stream_t stream);
 
 /* ---- causal attention backward, head size 64 (deterministic: two MFMA kernels, no float atomics) ---------------------------
  * replaces: autograd of the same attention call -- torch's aten::_scaled_dot_product_efficient_attention_backward, i.e. aiter's
