@@ -366,3 +366,423 @@ extern "C" int ar_attn_fwd_exact(const void* Q, const void* K, const void* V, vo
     }
     return launch_status();
 }
+
+namespace ar {
+
+// ================================================================================================================================
+// BACKWARD with the library's bits: what aten::_scaled_dot_product_efficient_attention_backward returns on this stack (AOTriton
+// 0.11.1 `bwd_preprocess` + `bwd_kernel_dk_dv` + `bwd_kernel_dq` with an additive bias), value for value.
+//
+// replaces: autograd of the attention call above on the bit-identical paths (library: 3.64 + 2.15 + 0.05 ms per call at Llama-3-8B's
+//           minibatch, 0.68 + 0.40 + 0.01 ms at OPT-125M's: 64 x 32 / 64 x 64 tiles on two waves, P and dS through LDS).
+// Read off the shipped code objects (bwd_kernel_dk_dv 64_32 wave1|2 warp2, bwd_kernel_dq 64_64 wave1|2 warp2, bwd_preprocess 128):
+//   * delta[row] = sum_d o * do over BLOCKED lanes: 8 consecutive d per lane, t = o1 do1 (rounded), t = fma(o0, do0, t),
+//     t = fma(o_e, do_e, t) for e = 2 .. 7; the D / 8 lanes of a row pairwise over lane-xor D/16 .. 1; + 0.0;
+//   * l2[row] = fl(lse * fl32(log2 e));   qk_scale = fl(sm_scale * fl32(log2 e));   bias_scale = 1 / sm_scale (IEEE);
+//   * scores: MFMA chain over d ascending (16 per step) whose accumulator STARTS at fl(bias * bias_scale) (fp32);
+//   * p = exp2(fma(qk_scale, s, -l2)) -- except, in bwd_kernel_dk_dv only, accumulator register 15 of the key block (keys 27 and 31
+//     of every 32): exp2(fl(qk_scale * s) - l2), two roundings (the compiler folded that element's multiply into a packed multiply
+//     with the l2 product);
+//   * dp = MFMA chain from zero; ds = p * (dp - delta), two roundings; p and ds rounded to bf16 (RNE) for the accumulating products;
+//   * dV^T += dO^T P and dK^T += Q^T dS over query blocks ascending, dQ^T += K^T dS over key blocks ascending, 16 rows per MFMA with
+//     lane half h holding rows 4 h + i and 8 + 4 h + i of the 16 (i = 0 .. 3) -- the accumulator registers adopted as the k order in
+//     bwd_kernel_dq, a k-width-4 dot-operand layout read back from LDS in bwd_kernel_dk_dv: the same k-slot sets either way (what
+//     matters to the hardware is WHICH 8 of the 16 k-slots sit in which lane half, not their order inside it:
+//     tools/gpu/r06_mfma_kslot_probe.hip);
+//   * dq = sm_scale * acc, dk = sm_scale * acc, dv = acc, rounded to bf16.
+// The kernels are csrc/ar_attn_bwd.hip's (own row on the lane, two resident b-operands, two streamed tensors through LDS-DMA) with
+// that arithmetic; dK / dV are written per QUERY head (the caller sums the kv_rep heads of a group as autograd's expand does).
+
+struct XBwdArgs {
+    const uint16_t* Q; const uint16_t* K; const uint16_t* V; const uint16_t* dO;
+    const float* L2; const float* Dv;                              // [B, H, S] fp32: fl(lse * log2 e), delta
+    uint16_t* dQ; uint16_t* dK; uint16_t* dV;                      // token-major [B, S, H, D] with token strides below
+    int B, S, H, kv_rep;
+    int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ts, v_bs, v_hs, v_ts, o_bs, o_hs, o_ts;      // element strides (batch, head, token); o = dO
+    int64_t lddq, lddk, lddv;
+    float sm_scale, qk_scale;
+    float bias_in_s, bias_out_s;                                   // fl(bias * bias_scale)
+    int valid_len;
+};
+
+// delta and l2 per (batch, head, token) row (the library's bwd_preprocess order; l2 as bwd_kernel_* compute it)
+__global__ __launch_bounds__(kTPB) void k_xattn_bwd_prep(const uint16_t* __restrict__ dO, int64_t do_bs, int64_t do_hs, int64_t do_ts,
+                                                          const uint16_t* __restrict__ O, int64_t o_bs, int64_t o_hs, int64_t o_ts,
+                                                          const float* __restrict__ lse, float* __restrict__ Dv, float* __restrict__ L2,
+                                                          int B, int S, int H, int AD) {
+    const int lpr = AD / 8;
+    const int64_t row = ((int64_t)blockIdx.x * kTPB + threadIdx.x) / lpr;
+    const int part = threadIdx.x % lpr;
+    const int64_t rows = (int64_t)B * S * H;
+    float s = 0.f;
+    int64_t b = 0, sq = 0; int h = 0;
+    if (row < rows) {
+        const int64_t tok = row / H;
+        h = (int)(row % H);
+        b = tok / S; sq = tok % S;
+        float a[8], c[8];
+        unpack8<AR_DT_BF16>(load8_raw<AR_DT_BF16>(dO, b * do_bs + h * do_hs + sq * do_ts + part * 8), a);
+        unpack8<AR_DT_BF16>(load8_raw<AR_DT_BF16>(O, b * o_bs + h * o_hs + sq * o_ts + part * 8), c);
+        s = a[1] * c[1];
+        s = __builtin_fmaf(a[0], c[0], s);
+#pragma unroll
+        for (int e = 2; e < 8; ++e) s = __builtin_fmaf(a[e], c[e], s);
+    }
+    for (int m = lpr >> 1; m >= 1; m >>= 1) s = s + __shfl_xor(s, m, kWave);
+    s = s + 0.0f;
+    if (row < rows && part == 0) {
+        const int64_t o = (b * H + h) * S + sq;
+        Dv[o] = s;
+        L2[o] = lse[o] * 1.44269502162933349609375f;
+    }
+}
+
+// MODE 0: dQ (own rows = queries; K / V tiles stream).  MODE 1: dK / dV (own rows = keys; Q / dO tiles stream); OUT: 3 = both,
+// 1 = dV only, 2 = dK only (head size 128 runs the key side as two kernels: registers, csrc/ar_attn_bwd.hip).
+template <int MODE, int WAVES, int AD, int OUT = 3>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_bwd(XBwdArgs a) {
+    constexpr bool NEED_S1 = MODE == 0 || (OUT & 2);
+    constexpr bool NEED_A0 = MODE == 0 || (OUT & 2);
+    constexpr bool NEED_A1 = MODE == 1 && (OUT & 1);
+    constexpr int KB = AD == 128 ? 4 : AD / 16;
+    constexpr int AROW = AD * 2;
+    constexpr int ATILE = XK * AROW;
+    constexpr int ABUF = 2 * ATILE;
+    constexpr int NKS = AD / 16;
+    constexpr int ND = AD / 32;
+    constexpr int AQ = 32 * WAVES;
+    constexpr int RPW = XK / WAVES;
+    constexpr int RPI = 1024 / AROW;
+    constexpr int CPR = AROW / 16;
+    constexpr int NP = RPW / RPI;
+    static_assert(NP >= 1, "a wave stages at least one DMA instruction per tensor");
+    static_assert(AD == 64 || (AD == 128 && (MODE == 0 || OUT != 3)), "head size 128: the key side as two kernels (register budget)");
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, lq = lane & 31;
+    const int n_ob = a.S / AQ;
+    const int n_bh = a.B * a.H;
+    int ob, bh;
+    if ((n_bh & 7) == 0) {
+        const int j = blockIdx.x >> 3, per = n_bh >> 3;
+        bh = (j % per) * 8 + (int)(blockIdx.x & 7);
+        ob = j / per;
+    } else {
+        ob = (int)(blockIdx.x % n_ob);
+        bh = blockIdx.x / n_ob;
+    }
+    const int b = bh / a.H, head = bh % a.H, kvh = head / a.kv_rep;
+    const int o0 = ob * AQ;
+    const int myrow = o0 + 32 * wave + lq;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    constexpr int VEC_OFF = 2 * ABUF;
+
+    const uint16_t* Qh = a.Q + (int64_t)b * a.q_bs + (int64_t)head * a.q_hs;
+    const uint16_t* Kh = a.K + (int64_t)b * a.k_bs + (int64_t)kvh * a.k_hs;
+    const uint16_t* Vh = a.V + (int64_t)b * a.v_bs + (int64_t)kvh * a.v_hs;
+    const uint16_t* Oh = a.dO + (int64_t)b * a.o_bs + (int64_t)head * a.o_hs;
+    const int64_t ld0 = MODE == 0 ? a.k_ts : a.q_ts, ld1 = MODE == 0 ? a.v_ts : a.o_ts;
+    const uint16_t* R0b = MODE == 0 ? Kh : Qh;
+    const uint16_t* R1b = MODE == 0 ? Vh : Oh;
+    const int64_t lb0 = MODE == 0 ? a.q_ts : a.k_ts, lb1 = MODE == 0 ? a.o_ts : a.v_ts;
+    const uint16_t* B0b = MODE == 0 ? Qh : Kh;
+    const uint16_t* B1b = MODE == 0 ? Oh : Vh;
+    xbf16x8_t bf0[NKS], bf1[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        bf0[ks] = __builtin_bit_cast(xbf16x8_t, *reinterpret_cast<const uint4*>(B0b + (int64_t)myrow * lb0 + 16 * ks + 8 * h));
+        if (NEED_S1) bf1[ks] = __builtin_bit_cast(xbf16x8_t, *reinterpret_cast<const uint4*>(B1b + (int64_t)myrow * lb1 + 16 * ks + 8 * h));
+    }
+    const float* L2row = a.L2 + ((int64_t)b * a.H + head) * a.S;
+    const float* Dvrow = a.Dv + ((int64_t)b * a.H + head) * a.S;
+    float myL2 = 0.f, myD = 0.f;
+    if (MODE == 0) { myL2 = L2row[myrow]; myD = Dvrow[myrow]; }
+    if (MODE == 1) {
+        float* vL = reinterpret_cast<float*>(lds + VEC_OFF);
+        float* vD = vL + a.S;
+        for (int i = tid; i < a.S; i += 64 * WAVES) { vL[i] = L2row[i]; vD[i] = Dvrow[i]; }
+    }
+    // MODE 1: the library's non-fused element -- accumulator register 15 of its key block = keys 27 and 31 of every 32
+    const bool quirk = MODE == 1 && (lq == 27 || lq == 31);
+    const float qmul = quirk ? 1.0f : a.qk_scale;
+
+    const int drow = lane / CPR, pchunk = lane % CPR;
+    uint32_t doff0[NP], doff1[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int r = RPW * wave + RPI * p + drow;
+        doff0[p] = (uint32_t)(r * ld0 + (pchunk ^ xattn_swz<AD>(r)) * 8);
+        doff1[p] = (uint32_t)(r * ld1 + (pchunk ^ xattn_swz<AD>(r)) * 8);
+    }
+    auto issue_tile = [&](int t, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2 * NP; ++j) {
+            const int p = j % NP;
+            const uint16_t* T = (j < NP ? R0b + (int64_t)t * XK * ld0 + doff0[p] : R1b + (int64_t)t * XK * ld1 + doff1[p]);
+            const uint32_t dst = lds0 + buf * ABUF + (j < NP ? 0 : ATILE) + (RPW * wave + RPI * p) * AROW;
+            __builtin_amdgcn_global_load_lds((const void*)T, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
+        }
+    };
+
+    uint32_t rA[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) rA[ks] = lds0 + lq * AROW + ((uint32_t)((2 * ks + h) ^ xattn_swz<AD>(lq)) << 4);
+    const int gi = lane & 15, gg = lane >> 4;
+    // transposed fragments in the adopted k order (rows 4 h + .. and 8 + 4 h + ..)
+    const int vrow = 4 * h + (gi >> 2);
+    const int vrow_hi = vrow + 8;
+    const int vcol0 = 16 * (gg & 1) + 4 * (gi & 3);
+    uint32_t tAlo[ND], tAhi[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+        const int col = 32 * dt + vcol0;
+        tAlo[dt] = lds0 + vrow * AROW + ((uint32_t)((col >> 3) ^ xattn_swz<AD>(vrow)) << 4) + (col & 7) * 2;
+        tAhi[dt] = lds0 + vrow_hi * AROW + ((uint32_t)((col >> 3) ^ xattn_swz<AD>(vrow_hi)) << 4) + (col & 7) * 2;
+    }
+
+    xf32x16_t acc0[ND], acc1[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[dt][r] = 0.f; acc1[dt][r] = 0.f; }
+
+#define XB_PIN() __builtin_amdgcn_sched_barrier(0)
+#define XB_RREAD(DST, KS, T, REG) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(DST) : "v"(rA[KS]), "n"(BUF * ABUF + (REG) * ATILE + (T) * 32 * AROW) : "memory")
+#define XB_TREAD(LO, HI, DT, ST, REG)                                                                                          \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"                                  \
+                 : "=&v"(LO), "=&v"(HI) : "v"(tAlo[DT]), "v"(tAhi[DT]), "n"(BUF * ABUF + (REG) * ATILE + (ST) * 16 * AROW) : "memory")
+
+    auto tile = [&](auto bufc, int t0) {
+        constexpr int BUF = decltype(bufc)::value;
+        // `plain`: every (query, key) pair between the wave's own rows and this tile is inside the kept region
+        const bool plain = MODE == 0 ? (t0 + XK - 1 <= o0 + 32 * wave && t0 + XK <= a.valid_len)
+                                     : (t0 >= o0 + 32 * wave + 31 && o0 + 32 * wave + 31 < a.valid_len);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            xf32x16_t s0, s1;
+            u32x4_t f0[KB], f1[KB];
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) {
+                XB_RREAD(f0[ks], ks, t, 0);
+                if (NEED_S1) XB_RREAD(f1[ks], ks, t, 1);
+            }
+            // the score accumulator starts at fl(bias * bias_scale); dp at zero
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = t0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
+                const int query = MODE == 0 ? myrow : srow, key = MODE == 0 ? srow : myrow;
+                s0[r] = (plain || (key <= query && key < a.valid_len)) ? a.bias_in_s : a.bias_out_s;
+                s1[r] = 0.f;
+            }
+#pragma unroll
+            for (int kb = 0; kb < NKS; kb += KB) {
+                if (kb > 0) {
+#pragma unroll
+                    for (int ks = 0; ks < KB; ++ks) {
+                        XB_RREAD(f0[ks], kb + ks, t, 0);
+                        if (NEED_S1) XB_RREAD(f1[ks], kb + ks, t, 1);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                XB_PIN();
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks) {
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8_t, f0[ks]), bf0[kb + ks], s0, 0, 0, 0);
+                    if (NEED_S1) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8_t, f1[ks]), bf1[kb + ks], s1, 0, 0, 0);
+                }
+                if (kb + KB < NKS) XB_PIN();
+            }
+            constexpr bool LATE_Q = AD == 128;
+            xs16x4_t q0lo[2][ND], q0hi[2][ND], q1lo[2][ND], q1hi[2][ND];
+#pragma unroll
+            for (int s2 = 0; s2 < (LATE_Q ? 1 : 2); ++s2)
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    if (NEED_A0) XB_TREAD(q0lo[s2][dt], q0hi[s2][dt], dt, 2 * t + s2, 0);
+                    if (NEED_A1) XB_TREAD(q1lo[s2][dt], q1hi[s2][dt], dt, 2 * t + s2, 1);
+                }
+            XB_PIN();
+            // ---- p = exp2(fma(qk_scale, s, -l2)) (the quirk lanes: exp2(fl(qk_scale * s) - l2)); ds = p * (dp - delta)
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(a.qk_scale, s0[r], -myL2));
+                    s0[r] = p;
+                    const float dd = s1[r] - myD;
+                    s1[r] = p * dd;
+                }
+            } else {
+                const float* vL = reinterpret_cast<const float*>(lds + VEC_OFF);
+                const float* vD = vL + a.S;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(vL + t0 + 32 * t + 4 * h + 8 * j);
+                    float4 d4 = {0.f, 0.f, 0.f, 0.f};
+                    if (NEED_S1) d4 = *reinterpret_cast<const float4*>(vD + t0 + 32 * t + 4 * h + 8 * j);
+                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * j + i;
+                        const float prod = a.qk_scale * s0[r];
+                        const float tv = quirk ? prod : s0[r];
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(qmul, tv, -lv[i]));
+                        s0[r] = p;
+                        if (NEED_S1) {
+                            const float dd = s1[r] - dv[i];
+                            s1[r] = p * dd;
+                        }
+                    }
+                }
+            }
+            XB_PIN();
+            // ---- bf16 operands of the accumulating products
+            uint32_t pk0[8], pk1[8];                   // pk[m] = rows (r = 2 m, 2 m + 1) of P (pk0) and dS (pk1)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (NEED_A1) pk0[m] = pack_bf16x2(s0[2 * m], s0[2 * m + 1]);
+                if (NEED_A0) pk1[m] = pack_bf16x2(s1[2 * m], s1[2 * m + 1]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4_t pe, pp;
+                if (NEED_A0) { pe.x = pk1[4 * s2]; pe.y = pk1[4 * s2 + 1]; pe.z = pk1[4 * s2 + 2]; pe.w = pk1[4 * s2 + 3]; }
+                if (NEED_A1) { pp.x = pk0[4 * s2]; pp.y = pk0[4 * s2 + 1]; pp.z = pk0[4 * s2 + 2]; pp.w = pk0[4 * s2 + 3]; }
+                constexpr int INFL = ((NEED_A0 ? 2 : 0) + (NEED_A1 ? 2 : 0)) * ND;
+                if (LATE_Q && s2 == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt) {
+                        if (NEED_A0) XB_TREAD(q0lo[1][dt], q0hi[1][dt], dt, 2 * t + 1, 0);
+                        if (NEED_A1) XB_TREAD(q1lo[1][dt], q1hi[1][dt], dt, 2 * t + 1, 1);
+                    }
+                }
+                if (s2 == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(INFL > 15 ? 15 : INFL) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                XB_PIN();
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    if (NEED_A0) {
+                        const xs16x8_t a0 = __builtin_shufflevector(q0lo[s2][dt], q0hi[s2][dt], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc0[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8_t, a0), __builtin_bit_cast(xbf16x8_t, pe), acc0[dt], 0, 0, 0);
+                    }
+                    if (NEED_A1) {
+                        const xs16x8_t a1 = __builtin_shufflevector(q1lo[s2][dt], q1hi[s2][dt], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc1[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8_t, a1), __builtin_bit_cast(xbf16x8_t, pp), acc1[dt], 0, 0, 0);
+                    }
+                }
+                XB_PIN();
+            }
+        }
+    };
+
+    const int t_end = a.S / XK;
+    __syncthreads();
+    issue_tile(0, 0);
+    for (int t = 0; t < t_end; t += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_tile(t + 1, 1);
+        tile(std::integral_constant<int, 0>{}, t * XK);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < t_end) issue_tile(t + 2, 0);
+        tile(std::integral_constant<int, 1>{}, (t + 1) * XK);
+    }
+#undef XB_RREAD
+#undef XB_TREAD
+#undef XB_PIN
+    auto store = [&](uint16_t* base, int64_t ld, const xf32x16_t (&acc)[ND], float mul, bool scaled) {
+        uint16_t* orow = base + ((int64_t)b * a.S + myrow) * ld + head * AD;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint2 w;
+                if (scaled) {
+                    w.x = pack_bf16x2(mul * acc[dt][4 * j + 0], mul * acc[dt][4 * j + 1]);
+                    w.y = pack_bf16x2(mul * acc[dt][4 * j + 2], mul * acc[dt][4 * j + 3]);
+                } else {
+                    w.x = pack_bf16x2(acc[dt][4 * j + 0], acc[dt][4 * j + 1]);
+                    w.y = pack_bf16x2(acc[dt][4 * j + 2], acc[dt][4 * j + 3]);
+                }
+                *reinterpret_cast<uint2*>(orow + 32 * dt + 8 * j + 4 * h) = w;
+            }
+    };
+    if (MODE == 0) store(a.dQ, a.lddq, acc0, a.sm_scale, true);
+    else {
+        if (NEED_A0) store(a.dK, a.lddk, acc0, a.sm_scale, true);
+        if (NEED_A1) store(a.dV, a.lddv, acc1, 1.0f, false);
+    }
+}
+
+}  // namespace ar
+
+extern "C" int64_t ar_attn_bwd_exact_workspace_bytes(int64_t B, int64_t S, int64_t H) { return 2 * B * S * H * (int64_t)sizeof(float); }
+
+extern "C" int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ, void* dK,
+                                 void* dV, int64_t B, int64_t S, int64_t H, int64_t D, int64_t kv_rep, float scale, float bias_in,
+                                 float bias_out, int64_t valid_len, int64_t q_bs, int64_t q_hs, int64_t q_ts, int64_t k_bs, int64_t k_hs,
+                                 int64_t k_ts, int64_t v_bs, int64_t v_hs, int64_t v_ts, int64_t o_bs, int64_t o_hs, int64_t o_ts,
+                                 int64_t do_bs, int64_t do_hs, int64_t do_ts, int64_t lddq, int64_t lddk, int64_t lddv, void* workspace,
+                                 int64_t workspace_bytes, ar_stream_t stream) {
+    if ((D != 64 && D != 128) || S % 256 || S > 4096 || B <= 0 || H <= 0 || kv_rep < 1 || H % kv_rep) return AR_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < ar_attn_bwd_exact_workspace_bytes(B, S, H)) return AR_ERR_UNSUPPORTED;
+    if (!(bias_in == bias_in) || !(bias_out == bias_out) || fabsf(bias_in) > 1e4f || fabsf(bias_out) > 1e4f || valid_len < 1 || valid_len > S)
+        return AR_ERR_UNSUPPORTED;
+    {
+        uint32_t u0, u1; memcpy(&u0, &bias_in, 4); memcpy(&u1, &bias_out, 4);
+        if ((u0 | u1) & 0xffffu) return AR_ERR_UNSUPPORTED;
+    }
+    const int64_t hd = H * D;
+    if (lddq <= 0) lddq = hd;
+    if (lddk <= 0) lddk = hd;
+    if (lddv <= 0) lddv = hd;
+    const int64_t st[18] = {q_bs, q_hs, q_ts, k_bs, k_hs, k_ts, v_bs, v_hs, v_ts, o_bs, o_hs, o_ts, do_bs, do_hs, do_ts, lddq, lddk, lddv};
+    for (int i = 0; i < 18; ++i)
+        if (st[i] < 0 || (st[i] % 8)) return AR_ERR_UNSUPPORTED;
+    if (lddq < hd || lddk < hd || lddv < hd) return AR_ERR_UNSUPPORTED;
+    if (64 * q_ts > 0x7fffffffLL || 64 * k_ts > 0x7fffffffLL || 64 * v_ts > 0x7fffffffLL || 64 * do_ts > 0x7fffffffLL) return AR_ERR_UNSUPPORTED;
+    if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & 15)
+        return AR_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    float* Dv = (float*)workspace;
+    float* L2 = Dv + B * S * H;
+    {
+        const int64_t rows = B * S * H, lanes = rows * (D / 8);
+        hipLaunchKernelGGL(k_xattn_bwd_prep, (int)((lanes + kTPB - 1) / kTPB), kTPB, 0, s, (const uint16_t*)dO, do_bs, do_hs, do_ts,
+                           (const uint16_t*)O, o_bs, o_hs, o_ts, LSE, Dv, L2, (int)B, (int)S, (int)H, (int)D);
+    }
+    XBwdArgs a;
+    a.Q = (const uint16_t*)Q; a.K = (const uint16_t*)K; a.V = (const uint16_t*)V; a.dO = (const uint16_t*)dO;
+    a.L2 = L2; a.Dv = Dv;
+    a.dQ = (uint16_t*)dQ; a.dK = (uint16_t*)dK; a.dV = (uint16_t*)dV;
+    a.B = (int)B; a.S = (int)S; a.H = (int)H; a.kv_rep = (int)kv_rep;
+    a.q_bs = q_bs; a.q_hs = q_hs; a.q_ts = q_ts; a.k_bs = k_bs; a.k_hs = k_hs; a.k_ts = k_ts; a.v_bs = v_bs; a.v_hs = v_hs; a.v_ts = v_ts;
+    a.o_bs = do_bs; a.o_hs = do_hs; a.o_ts = do_ts;
+    a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+    a.sm_scale = scale;
+    a.qk_scale = scale * 1.44269502162933349609375f;
+    const float bias_scale = 1.0f / scale;                 // correctly rounded (the library: v_div_scale / v_div_fmas / v_div_fixup)
+    a.bias_in_s = bias_in * bias_scale; a.bias_out_s = bias_out * bias_scale; a.valid_len = (int)valid_len;
+    constexpr int LDS_T = 4 * XK * 64 * 2, LDS_T128 = 4 * XK * 128 * 2;
+    const int vec = (int)(2 * S * sizeof(float));
+    static PerDeviceOnce attr;
+    if (attr.first()) {
+        constexpr int VEC_MAX = 2 * 4096 * (int)sizeof(float);
+        (void)hipFuncSetAttribute((const void*)k_xattn_bwd<0, 8, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T);
+        (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 8, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T + VEC_MAX);
+        (void)hipFuncSetAttribute((const void*)k_xattn_bwd<0, 8, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128);
+        (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 8, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + VEC_MAX);
+        (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 8, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + VEC_MAX);
+    }
+    const int grid = (int)(B * H * (S / 256));
+    if (D == 128) {
+        hipLaunchKernelGGL((k_xattn_bwd<1, 8, 128, 1>), grid, 512, LDS_T128 + vec, s, a);
+        hipLaunchKernelGGL((k_xattn_bwd<1, 8, 128, 2>), grid, 512, LDS_T128 + vec, s, a);
+        hipLaunchKernelGGL((k_xattn_bwd<0, 8, 128>), grid, 512, LDS_T128, s, a);
+    } else {
+        hipLaunchKernelGGL((k_xattn_bwd<1, 8, 64>), grid, 512, LDS_T + vec, s, a);
+        hipLaunchKernelGGL((k_xattn_bwd<0, 8, 64>), grid, 512, LDS_T, s, a);
+    }
+    return launch_status();
+}

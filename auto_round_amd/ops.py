@@ -717,6 +717,58 @@ def attn_fwd_exact(q4: torch.Tensor, k4: torch.Tensor, v4: torch.Tensor, mask_st
     return out, lse
 
 
+_xattn_ws: dict = {}
+
+
+def attn_bwd_exact(q4, k4, v4, out, lse, dout, mask_struct, scale: float, dq=None, dk=None, dv=None):
+    """The attention backward with the LIBRARY'S bits (ar_attn_bwd_exact): autograd of the call `attn_fwd_exact` replaces.
+    q4 [B, H, S, D], k4 / v4 [B, H / kv_rep, S, D] (the forward's operands), out [B, S, H, D] and lse [B, H, S] (the forward's
+    results), dout [B, S, H, D]-shaped gradient of out (any strides with unit stride along D).
+    -> (dq, dk_exp, dv_exp), each [B, S, H, D] (token-major; dk_exp / dv_exp per QUERY head: sum the kv_rep heads of a group as
+    autograd's expand backward does), or None when the kernel does not take the call.  dq / dk / dv: optional [B * S, >= H * D]
+    destinations (column slices of a merged buffer)."""
+    if mask_struct is None or q4.dim() != 4 or q4.dtype != torch.bfloat16:
+        return None
+    B, H, S, D = (int(x) for x in q4.shape)
+    if D not in (64, 128) or S % 256 or S > 4096 or k4.shape != v4.shape or tuple(out.shape) != (B, S, H, D) or tuple(dout.shape) != (B, S, H, D):
+        return None
+    hk = int(k4.shape[1])
+    if hk < 1 or H % hk or k4.shape[0] != B or k4.shape[2] != S or k4.shape[3] != D:
+        return None
+    for t in (q4, k4, v4, out, dout):
+        if t.dtype != torch.bfloat16 or t.stride(3) != 1 or any(s % 8 for s in t.stride()[:3]) or t.data_ptr() % 16:
+            return None
+    _chk(lse, "lse", torch.float32, (B, H, S))
+    dev = q4.device.index
+    if any((not t.is_cuda) or t.device.index != dev for t in (q4, k4, v4, out, dout, lse)):
+        raise _lib.Mi355xLibraryError("attn_bwd_exact: every tensor must live on one HIP device (no CPU fallback)")
+    outs = []
+    for t in (dq, dk, dv):
+        if t is None:
+            t = torch.empty((B * S, H * D), dtype=q4.dtype, device=q4.device)
+        if t.dim() != 2 or tuple(t.shape) != (B * S, H * D) or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16 or t.dtype != q4.dtype:
+            return None
+        outs.append(t)
+    need = load().ar_attn_bwd_exact_workspace_bytes(B, S, H)
+    ws = _xattn_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _xattn_ws[dev] = torch.empty(need, dtype=torch.uint8, device=q4.device)
+    b_in, b_out, valid = mask_struct
+    # out / dout are [B, S, H, D]-shaped: (batch, head, token) strides = (0, 2, 1)
+    with (torch.cuda.device(dev) if dev != torch.cuda.current_device() else _NULLCTX):
+        rc = load().ar_attn_bwd_exact(q4.data_ptr(), k4.data_ptr(), v4.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                      outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), B, S, H, D, H // hk, float(scale),
+                                      float(b_in), float(b_out), int(valid),
+                                      q4.stride(0), q4.stride(1), q4.stride(2), k4.stride(0), k4.stride(1), k4.stride(2),
+                                      v4.stride(0), v4.stride(1), v4.stride(2), out.stride(0), out.stride(2), out.stride(1),
+                                      dout.stride(0), dout.stride(2), dout.stride(1), outs[0].stride(0), outs[1].stride(0), outs[2].stride(0),
+                                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+    if rc == _lib.AR_ERR_UNSUPPORTED:
+        return None
+    check(rc, "ar_attn_bwd_exact")
+    return tuple(t.view(B, S, H, D) if t.is_contiguous() else t for t in outs)
+
+
 _mask_struct_cache: dict = {}
 
 

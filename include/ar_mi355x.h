@@ -474,6 +474,22 @@ int ar_attn_fwd_exact(const void* Q, const void* K, const void* V, void* O, floa
                       int64_t q_ts, int64_t k_bs, int64_t k_hs, int64_t k_ts, int64_t v_bs, int64_t v_hs, int64_t v_ts,
                       ar_stream_t stream);
 
+/* The matching BACKWARD with the library's bits: what aten::_scaled_dot_product_efficient_attention_backward returns for the same call
+ * on this stack (AOTriton 0.11.1 bwd_preprocess + bwd_kernel_dk_dv + bwd_kernel_dq with an additive bias; autograd of the call
+ * ar_attn_fwd_exact replaces; the arithmetic -- delta in the library's lane order, scores accumulated on top of fl(bias / sm_scale),
+ * p = exp2(fma(..)) with the one non-fused element of the key-side kernel, natural / adopted k orders of the accumulating products -- is
+ * in csrc/ar_attn_exact.hip).  Q / K / V / O / dO bf16 with element strides (batch, head, token), K / V grouped as in the forward;
+ * O / LSE are the forward's results.  dQ, dK, dV are written token-major [B, S, H, D] with token strides lddq / lddk / lddv (0 = H * D;
+ * larger strides: column slices of a merged buffer); dK / dV hold one gradient per QUERY head -- the caller adds the kv_rep heads of a
+ * group, as autograd's expand backward does.  workspace: ar_attn_bwd_exact_workspace_bytes(B, S, H) bytes.  D in {64, 128},
+ * S % 256 == 0, S <= 4096; anything else AR_ERR_UNSUPPORTED.  Equality with the library is proven per call signature by the caller. */
+int64_t ar_attn_bwd_exact_workspace_bytes(int64_t B, int64_t S, int64_t H);
+int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ, void* dK,
+                      void* dV, int64_t B, int64_t S, int64_t H, int64_t D, int64_t kv_rep, float scale, float bias_in, float bias_out,
+                      int64_t valid_len, int64_t q_bs, int64_t q_hs, int64_t q_ts, int64_t k_bs, int64_t k_hs, int64_t k_ts, int64_t v_bs,
+                      int64_t v_hs, int64_t v_ts, int64_t o_bs, int64_t o_hs, int64_t o_ts, int64_t do_bs, int64_t do_hs, int64_t do_ts,
+                      int64_t lddq, int64_t lddk, int64_t lddv, void* workspace, int64_t workspace_bytes, ar_stream_t stream);
+
 /* ---- causal attention backward, head size 64 (deterministic: two MFMA kernels, no float atomics) ---------------------------
  * replaces: autograd of the same attention call -- torch's aten::_scaled_dot_product_efficient_attention_backward, i.e. aiter's
  *           fmha_bwd (+ pre / post-process kernels), which accumulates dQ with fp32 atomics (0.42 ms per call at OPT-125M's minibatch,

@@ -30,6 +30,24 @@ __global__ void k(const uint16_t* A, const uint16_t* B, const float* C, float* D
         for (int r = 0; r < 16; ++r) D[(t * 32 + (8 * (r >> 2) + 4 * h + (r & 3))) * 32 + l] = c[r];
     }
 }
+// the same products with the operand ROLES swapped: D2 = B^T A^T (a-operand rows = columns of B, b-operand columns = rows of A)
+__global__ void k_swapped(const uint16_t* A, const uint16_t* B, const float* C, float* D, int n) {
+    const int lane = threadIdx.x, h = lane >> 5, l = lane & 31;
+    for (int t = blockIdx.x; t < n; t += gridDim.x) {
+        uint16_t a[8], b[8];
+        for (int e = 0; e < 8; ++e) {
+            const int kk = 8 * h + e;
+            a[e] = B[(t * 16 + kk) * 32 + l];          // a-operand row l = column l of B
+            b[e] = A[(t * 32 + l) * 16 + kk];          // b-operand column l = row l of A
+        }
+        bf8 av, bv;
+        __builtin_memcpy(&av, a, 16); __builtin_memcpy(&bv, b, 16);
+        f16v c;       // D2[m = column of the original][n = row of the original]
+        for (int r = 0; r < 16; ++r) c[r] = C[(t * 32 + l) * 32 + (8 * (r >> 2) + 4 * h + (r & 3))];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) D[(t * 32 + l) * 32 + (8 * (r >> 2) + 4 * h + (r & 3))] = c[r];
+    }
+}
 static uint16_t rnd_bf16(int spread) {
     float m = 1.0f + (rand() % 128) / 128.0f;
     int e = rand() % (2 * spread + 1) - spread;
@@ -66,6 +84,14 @@ int main() {
             long diff = 0;
             for (size_t i = 0; i < R[0].size(); ++i) diff += memcmp(&R[0][i], &R[p][i], 4) != 0;
             printf("spread 2^+-%d  perm %d: %ld of %zu result words differ\n", spread, p, diff, R[0].size());
+        }
+        {
+            std::vector<float> R2(n * 1024);
+            hipLaunchKernelGGL(k_swapped, 256, 64, 0, 0, dA, dB, dC, dD, n);
+            hipMemcpy(R2.data(), dD, C.size() * 4, hipMemcpyDeviceToHost);
+            long diff = 0;
+            for (size_t i = 0; i < R2.size(); ++i) diff += memcmp(&R[0][i], &R2[i], 4) != 0;
+            printf("spread 2^+-%d  operand roles swapped: %ld of %zu result words differ\n", spread, diff, R2.size());
         }
         // and: one K = 16 instruction against the exact fp64 sum rounded once (how the hardware rounds)
         long exact = 0;
