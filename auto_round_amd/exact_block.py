@@ -33,7 +33,10 @@ from .fused_block import LLAMA_FAMILY, FusedLlamaBlock, _FusedBlockFn, _class_in
 
 # segments that have a first-party kernel form (False = torch's own ops in a local autograd graph)
 STREAMK = -1        # plan value of a dw_* option: the library kernel's stream-K summation structure
-KERNEL_OPTS = ("norm1", "norm2", "rope", "swiglu")
+KERNEL_OPTS = ("norm1", "norm2", "rope", "swiglu", "attn")
+# "attn": the attention forward + backward on csrc/ar_attn_exact.hip (the library attention's arithmetic restated from the code objects
+# torch ships) instead of torch's SDPA -- held to torch's attention output and q / k / v gradients DIRECTLY on the probe minibatches
+# (`_attn_diffs`), not only through the block output
 # GEMM forms that may be faster than the module path's and may or may not be bit-equal to it: input-gradient GEMMs through a
 # transposed weight copy (tn_*), weight-gradient GEMMs on the MFMA kernel -- merged over q/k/v and gate/up (one launch, the
 # elementwise backward kernels write straight into the merged gradient buffer) or per layer; plan value 1 = one pass over K,
@@ -60,6 +63,40 @@ def _count_diff(a: torch.Tensor, b: torch.Tensor) -> int:
     return int((a.contiguous().view(it) != b.contiguous().view(it)).sum())
 
 
+def exact_attention_forward(q4, k4, v4, mask, scale, S):
+    """first-party attention with the library's bits (ops.attn_fwd_exact) when the call is one it takes: the calibration flow's
+    structured additive mask, head size 64 / 128, a sequence the backward kernels take too.  -> (q4, k4, v4, out [B, S, H, D], lse,
+    mask_struct) or None"""
+    if mask is None or S % 256 or S > 4096:
+        return None
+    st = ops.mask_structure(mask, S)
+    if st is None:
+        return None
+    got = ops.attn_fwd_exact(q4, k4, v4, st, float(scale))
+    if got is None:
+        return None
+    return (q4, k4, v4, got[0], got[1], st)
+
+
+def exact_attention_backward(xa, dattn4, scale):
+    """gradients of the call `exact_attention_forward` made: -> (gq4 [B, H, S, D], gk4, gv4 [B, H / kv_rep, S, D]) -- the kv_rep query
+    heads of a group summed as autograd's expand backward does (one fp32 sum per value, rounded once)"""
+    q4, k4, v4, o4, lse, st = xa
+    got = ops.attn_bwd_exact(q4, k4, v4, o4, lse, dattn4, st, float(scale))
+    if got is None:
+        raise RuntimeError("ar_attn_bwd_exact refused a call whose forward it took")
+    dq, dke, dve = got
+    B, H, S, D = q4.shape
+    hk = k4.shape[1]
+    gq4 = dq.transpose(1, 2)
+    if hk == H:
+        return gq4, dke.transpose(1, 2), dve.transpose(1, 2)
+    rep = H // hk
+    gk4 = dke.transpose(1, 2).reshape(B, hk, rep, S, D).sum(2)
+    gv4 = dve.transpose(1, 2).reshape(B, hk, rep, S, D).sum(2)
+    return gq4, gk4, gv4
+
+
 class ExactLlamaBlock(FusedLlamaBlock):
     capturable = False          # the attention runs in a local autograd graph: the iteration is host-driven
     exact = True
@@ -84,6 +121,8 @@ class ExactLlamaBlock(FusedLlamaBlock):
         self._tnx: Dict[str, torch.Tensor] = {}
         self._last_sk: Dict[str, Optional[list]] = {}
         self.plan_report: Optional[dict] = None
+        self._attn_verify = False
+        self._attn_diffs: Dict[str, int] = {}
         return self
 
     @classmethod
@@ -115,6 +154,8 @@ class ExactLlamaBlock(FusedLlamaBlock):
         self._tnx = {}
         self._last_sk = {}
         self.plan_report = None
+        self._attn_verify = False
+        self._attn_diffs = {}
         return self
 
     def plan_forward_against_module(self, module_forward, x, others) -> Optional[dict]:
@@ -142,7 +183,15 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 if opt in ("norm1", "norm2") and not stats_ok:
                     continue
                 trial = dict(plan, **{opt: True})
-                if same(trial):
+                if opt == "attn":
+                    if others.get("attention_mask") is None:
+                        continue
+                    self._attn_verify, self._attn_diffs = True, {}
+                ok = same(trial)
+                if opt == "attn":
+                    self._attn_verify = False
+                    ok = ok and self._attn_diffs.get("out", -1) == 0
+                if ok:
                     plan = trial
                     kept.append(opt)
             self.set_plan(plan)
@@ -302,12 +351,20 @@ class ExactLlamaBlock(FusedLlamaBlock):
         from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
         mask = others.get("attention_mask")
-        with torch.enable_grad() if grad else contextlib.nullcontext():
-            al = [t.detach().requires_grad_(grad) for t in (qr4, kr4, v4)]
-            with self._ctx(S):
-                ao, _ = sdpa_attention_forward(self.attn, al[0], al[1], al[2], mask, dropout=0.0, scaling=self.attn.scaling)
-                ao = ao.reshape(B, S, -1).contiguous()
-        a2d = ao.detach().view(T, hq * hd)
+        xa = exact_attention_forward(qr4, kr4, v4, mask, self.attn.scaling, S) if P.get("attn") else None
+        al = ao = None
+        if xa is None or self._attn_verify:
+            with torch.enable_grad() if grad else contextlib.nullcontext():
+                al = [t.detach().requires_grad_(grad) for t in (qr4, kr4, v4)]
+                with self._ctx(S):
+                    ao, _ = sdpa_attention_forward(self.attn, al[0], al[1], al[2], mask, dropout=0.0, scaling=self.attn.scaling)
+                    ao = ao.reshape(B, S, -1).contiguous()
+        if xa is not None:
+            if ao is not None:          # the proof: torch's attention output beside the first-party one
+                self._attn_diffs["out"] = self._attn_diffs.get("out", 0) + _count_diff(xa[3].view(B, S, -1), ao.detach())
+            a2d = xa[3].view(T, hq * hd)
+        else:
+            a2d = ao.detach().view(T, hq * hd)
         a_in = fq(a2d, aq["o"])
         o_out = F.linear(a_in, L["o"].weight_q, self._bias("o"))
         # residual + post_attention_layernorm
@@ -346,7 +403,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
         d_out = F.linear(act_in, L["d"].weight_q, self._bias("d"))
         y = x2 + d_out
         if grad:
-            sv.update(B=B, S=S, h1_in=h1_in, cos=cos, sin=sin, rope_graph=rope_graph, attn_leaves=al, attn_out=ao, a2d=a2d, a_in=a_in,
+            sv.update(B=B, S=S, h1_in=h1_in, cos=cos, sin=sin, rope_graph=rope_graph, attn_leaves=al, attn_out=ao, attn_x=xa, a2d=a2d, a_in=a_in,
                       x2=x2, rstd2=rstd2, norm_graph=norm_graph, h2=h2, h2_in=h2_in, g2d=g2d, u2d=u2d, act_graph=act_graph, act=act,
                       act_in=act_in)
             ctx.saved = sv
@@ -410,9 +467,15 @@ class ExactLlamaBlock(FusedLlamaBlock):
         self._dw_x("o", dx2, s.pop("a_in"))
         da = bq(self._dx_x("o", dx2), s.pop("a2d"), aq["o"])
         del dx2
-        al, ao = s.pop("attn_leaves"), s.pop("attn_out")
-        gq4, gk4, gv4 = torch.autograd.grad(ao, al, da.view(B, S, hq * hd))
-        del al, ao, da
+        al, ao, xa = s.pop("attn_leaves"), s.pop("attn_out"), s.pop("attn_x")
+        if xa is not None:
+            gq4, gk4, gv4 = exact_attention_backward(xa, da.view(B, S, hq, hd), self.attn.scaling)
+            if ao is not None:          # the proof: torch's gradients beside the first-party ones
+                for name, mine, ref in zip(("dq", "dk", "dv"), (gq4, gk4, gv4), torch.autograd.grad(ao, al, da.view(B, S, hq * hd))):
+                    self._attn_diffs[name] = self._attn_diffs.get(name, 0) + _count_diff(mine, ref)
+        else:
+            gq4, gk4, gv4 = torch.autograd.grad(ao, al, da.view(B, S, hq * hd))
+        del al, ao, xa, da
         rope_graph = s.pop("rope_graph")
         nq, nk = hq * hd, hkv * hd
         dqkv = torch.empty((T, nq + 2 * nk), dtype=self.dtype, device=dy2d.device) if P["dw_qkv"] else None
@@ -548,11 +611,22 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 variants = [tv for tv in (trial, dict(trial, norm_rsqrt_f32=True)) if norm_stats_match(tv["norm_rsqrt_f32"])]
                 if not variants:
                     report["errors"][opt] = "row statistics differ from torch's (rsqrt / reduction order)"
+            if opt == "attn" and others.get("attention_mask") is None:
+                report["skipped"][opt] = "no additive attention mask: the call is not the one the kernel restates"
+                continue
             report["tried"].append(opt)
             worst = {}
             for attempt in (0, 1):
                 for vi, tv in enumerate(variants):
+                    if opt == "attn":           # torch's attention runs beside the kernels: outputs and gradients compared directly
+                        self._attn_verify, self._attn_diffs = True, {}
                     ok, n_bad = proven(tv)
+                    if opt == "attn":
+                        self._attn_verify = False
+                        direct = dict(self._attn_diffs)
+                        report.setdefault("attn_direct", []).append(direct)
+                        if set(direct) != {"out", "dq", "dk", "dv"} or any(direct.values()):
+                            ok, n_bad = False, (n_bad if n_bad else sum(direct.values()) or -1)
                     if not ok:
                         worst[str(tv.get(opt)) if opt.startswith("dw_") else str(vi)] = n_bad
                         continue

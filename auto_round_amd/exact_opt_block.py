@@ -34,10 +34,10 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .exact_block import _bits_equal, _count_diff
+from .exact_block import _bits_equal, _count_diff, exact_attention_backward, exact_attention_forward
 from .fused_block import OPT_FAMILY, FusedOPTBlock, _class_in, _FusedBlockFn
 
-KERNEL_OPTS = ("ln1", "ln2")
+KERNEL_OPTS = ("ln1", "ln2", "attn")     # "attn": csrc/ar_attn_exact.hip instead of torch's SDPA (exact_block.py)
 # flag bits of the LayerNorm kernels that an installed torch build may resolve either way (csrc/ar_exact_ln.hip): tried in this order
 LN_VARIANTS = (0, 1, 2, 3)
 
@@ -57,6 +57,8 @@ class ExactOPTBlock(FusedOPTBlock):
         self.amp = bool(amp)
         self.plan = self.base_plan()
         self.plan_report = None
+        self._attn_verify = False
+        self._attn_diffs = {}
         return self
 
     @classmethod
@@ -75,6 +77,8 @@ class ExactOPTBlock(FusedOPTBlock):
         self.amp = bool(amp)
         self.plan = self.base_plan()
         self.plan_report = None
+        self._attn_verify = False
+        self._attn_diffs = {}
         return self
 
     def _usable(self) -> bool:
@@ -94,7 +98,7 @@ class ExactOPTBlock(FusedOPTBlock):
     @staticmethod
     def base_plan() -> Dict[str, object]:
         """every segment on torch's own ops (exact by construction)"""
-        return dict(ln1=False, ln2=False, ln_flags=0)
+        return dict(ln1=False, ln2=False, ln_flags=0, attn=False)
 
     def set_plan(self, plan):
         self.plan = {**self.base_plan(), **plan}
@@ -166,13 +170,22 @@ class ExactOPTBlock(FusedOPTBlock):
         k2d = F.linear(h1_in, L["k"].weight_q, self._bias("k"))
         v2d = F.linear(h1_in, L["v"].weight_q, self._bias("v"))
         mask = others.get("attention_mask")
-        with torch.enable_grad() if grad else contextlib.nullcontext():
-            al = [t.view(B, S, hq, hd).transpose(1, 2).detach().requires_grad_(grad) for t in (q2d, k2d, v2d)]
-            with self._ctx(S):
-                ao, _ = sdpa_attention_forward(self.attn, al[0], al[1], al[2], mask, dropout=0.0, scaling=1.0)
-                ao = ao.reshape(B, S, -1).contiguous()
+        q4, k4, v4 = (t.view(B, S, hq, hd).transpose(1, 2) for t in (q2d, k2d, v2d))
+        xa = exact_attention_forward(q4, k4, v4, mask, 1.0, S) if P.get("attn") else None
+        al = ao = None
+        if xa is None or getattr(self, "_attn_verify", False):
+            with torch.enable_grad() if grad else contextlib.nullcontext():
+                al = [t.detach().requires_grad_(grad) for t in (q4, k4, v4)]
+                with self._ctx(S):
+                    ao, _ = sdpa_attention_forward(self.attn, al[0], al[1], al[2], mask, dropout=0.0, scaling=1.0)
+                    ao = ao.reshape(B, S, -1).contiguous()
         del q2d, k2d, v2d
-        a2d = ao.detach().view(T, H)
+        if xa is not None:
+            if ao is not None:          # the proof: torch's attention output beside the first-party one
+                self._attn_diffs["out"] = self._attn_diffs.get("out", 0) + _count_diff(xa[3].view(B, S, -1), ao.detach())
+            a2d = xa[3].view(T, H)
+        else:
+            a2d = ao.detach().view(T, H)
         a_in = fq(a2d, aq["o"])
         x2 = x2d + F.linear(a_in, L["o"].weight_q, self._bias("o"))                   # residual + out_proj(attn)
         # final_layer_norm
@@ -187,7 +200,7 @@ class ExactOPTBlock(FusedOPTBlock):
         f_in = fq(a, aq["f2"])
         y = x2 + F.linear(f_in, L["f2"].weight_q, self._bias("f2"))
         if grad:
-            ctx.saved = dict(B=B, S=S, h1_in=h1_in, h1=h1, leaves=al, ao=ao, a2d=a2d, a_in=a_in, x2=x2, mean2=mean2, rstd2=rstd2,
+            ctx.saved = dict(B=B, S=S, h1_in=h1_in, h1=h1, leaves=al, ao=ao, attn_x=xa, a2d=a2d, a_in=a_in, x2=x2, mean2=mean2, rstd2=rstd2,
                              norm_graph=norm_graph, h2=h2, h2_in=h2_in, a=a, f_in=f_in)
         return y.view(B, S, H)
 
@@ -230,9 +243,15 @@ class ExactOPTBlock(FusedOPTBlock):
         self._dw_x("o", dx2, s.pop("a_in"))
         dattn = bq(torch.mm(dx2, L["o"].weight_q), s.pop("a2d"), aq["o"])
         del dx2
-        al, ao = s.pop("leaves"), s.pop("ao")
-        gq4, gk4, gv4 = torch.autograd.grad(ao, al, dattn.view(B, S, H))
-        del al, ao, dattn
+        al, ao, xa = s.pop("leaves"), s.pop("ao"), s.pop("attn_x")
+        if xa is not None:
+            gq4, gk4, gv4 = exact_attention_backward(xa, dattn.view(B, S, self.hq, self.hd), 1.0)
+            if ao is not None:          # the proof: torch's gradients beside the first-party ones
+                for name, mine, ref in zip(("dq", "dk", "dv"), (gq4, gk4, gv4), torch.autograd.grad(ao, al, dattn.view(B, S, H))):
+                    self._attn_diffs[name] = self._attn_diffs.get(name, 0) + _count_diff(mine, ref)
+        else:
+            gq4, gk4, gv4 = torch.autograd.grad(ao, al, dattn.view(B, S, H))
+        del al, ao, xa, dattn
         dq2d = gq4.transpose(1, 2).reshape(T, H) * self.qscale        # MulBackward0 of q_proj(x) * scaling
         dk2d = gk4.transpose(1, 2).reshape(T, H)
         dv2d = gv4.transpose(1, 2).reshape(T, H)
@@ -320,15 +339,26 @@ class ExactOPTBlock(FusedOPTBlock):
         # the LayerNorm kernels: which of the build-dependent forms (fast reciprocal, contraction, rsqrt) reproduces torch's statistics
         flags = next((f for f in LN_VARIANTS if self._ln_stats_match(x, f)), None)
         for opt in [o for o in KERNEL_OPTS if want is None or o in want]:
+            if opt == "attn" and others.get("attention_mask") is None:
+                report["skipped"][opt] = "no additive attention mask: the call is not the one the kernel restates"
+                continue
             report["tried"].append(opt)
-            if flags is None:
+            if flags is None and opt != "attn":
                 report["errors"][opt] = "no form of the LayerNorm kernel reproduces torch's row statistics / output on this stack"
                 report["dropped"][opt] = {"stats": "differ"}
                 continue
-            trial = dict(plan, **{opt: True, "ln_flags": flags})
+            trial = dict(plan, **{opt: True}) if opt == "attn" else dict(plan, **{opt: True, "ln_flags": flags})
             worst = {}
             for attempt in (0, 1):
+                if opt == "attn":               # torch's attention runs beside the kernels: outputs and gradients compared directly
+                    self._attn_verify, self._attn_diffs = True, {}
                 ok, n_bad = proven(trial)
+                if opt == "attn":
+                    self._attn_verify = False
+                    direct = dict(self._attn_diffs)
+                    report.setdefault("attn_direct", []).append(direct)
+                    if set(direct) != {"out", "dq", "dk", "dv"} or any(direct.values()):
+                        ok, n_bad = False, (n_bad if n_bad else sum(direct.values()) or -1)
                 if ok:
                     plan = trial
                     report["kept"].append(opt)
@@ -366,12 +396,22 @@ class ExactOPTBlock(FusedOPTBlock):
                 return None
             flags = next((f for f in LN_VARIANTS if self._ln_stats_match(x, f)), None)
             kept = []
-            if flags is not None:
-                for opt in KERNEL_OPTS:
+            for opt in KERNEL_OPTS:
+                if opt == "attn":
+                    if others.get("attention_mask") is None:
+                        continue
+                    trial = dict(plan, attn=True)
+                    self._attn_verify, self._attn_diffs = True, {}
+                    ok = same(trial) and same(trial) and self._attn_diffs.get("out", -1) == 0
+                    self._attn_verify = False
+                elif flags is not None:
                     trial = dict(plan, **{opt: True, "ln_flags": flags})
-                    if same(trial) and same(trial):
-                        plan = trial
-                        kept.append(opt)
+                    ok = same(trial) and same(trial)
+                else:
+                    continue
+                if ok:
+                    plan = trial
+                    kept.append(opt)
             self.set_plan(plan)
             self.plan_report = dict(usable=True, kept=kept, plan={k: (int(v) if k == "ln_flags" else bool(v)) for k, v in plan.items()})
         return plan
