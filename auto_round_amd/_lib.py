@@ -87,6 +87,7 @@ SIGNATURES = {
     "ar_attn_fwd": (c_int, [P, P, P, P, P, L, L, L, L, F, I, L, L, P]),
     "ar_attn_fwd_masked": (c_int, [P, P, P, P, P, L, L, L, L, F, F, F, L, L, L, P]),
     "ar_attn_fwd_exact": (c_int, [P, P, P, P, P, L, L, L, L, L, F, F, F, L, L, L, L, L, L, L, L, L, L, P]),
+    "ar_attn_exact_config": (c_int, [I]),
     "ar_attn_bwd_exact_workspace_bytes": (c_int64, [L, L, L]),
     "ar_attn_bwd_exact": (c_int, [P, P, P, P, P, P, P, P, P, L, L, L, L, L, F, F, F, L] + [L] * 18 + [P, L, P]),
     "ar_attn_bwd_workspace_bytes": (c_int64, [L, L, L]),

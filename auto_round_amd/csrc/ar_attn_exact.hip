@@ -45,6 +45,7 @@ typedef short xs16x4_t __attribute__((ext_vector_type(4)));
 typedef short xs16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 xbf16x8_t __attribute__((ext_vector_type(8)));
 typedef float xf32x16_t __attribute__((ext_vector_type(16)));
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int XK = 64;               // keys per staged tile
 
@@ -57,7 +58,7 @@ __device__ __forceinline__ int xattn_swz(int r) {          // csrc/ar_attn.hip a
 // v_permlane32_swap of a value with itself: lo <- {x[0:31], x[0:31]}, hi <- {x[32:63], x[32:63]}
 __device__ __forceinline__ void xhalves(float x, float& lo, float& hi) {
     lo = x; hi = x;
-    asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 4" : "+v"(lo), "+v"(hi));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
 }
 
 struct XAttnArgs {
@@ -185,20 +186,34 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_fwd(XAttnArgs a) {
             XA_PIN();
         }
         xs16x4_t vlo[2][ND], vhi[2][ND];
-        XA_VREAD(0)
-        XA_VREAD(1)
+        XA_VREAD(0)                                   // (the second step's fragments are read behind the softmax: registers)
         XA_PIN();
-        const bool plain = k0 + XK - 1 <= q0 + 32 * wave && k0 + XK <= a.valid_len;      // wave-uniform: every pair of the tile is kept
+        // wave-uniform shortcuts: every (query, key) pair of the tile inside the kept region / every pair outside it (a tile above the
+        // diagonal or behind the valid keys) -- only the tiles the region's edge crosses pay for a per-element choice
+        const bool plain = k0 + XK - 1 <= q0 + 32 * wave && k0 + XK <= a.valid_len;
+        const bool all_out = k0 > q0 + 32 * wave + 31 || k0 >= a.valid_len;
         // x = fl(s * qk_scale) + bias2 (two roundings)
+        if (plain || all_out) {
+            const float bias = plain ? a.bias_in2 : a.bias_out2;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
-                const float bias = (plain || (key <= myq && key < a.valid_len)) ? a.bias_in2 : a.bias_out2;
-                const float x = s[t][r] * a.qk_scale;
-                s[t][r] = x + bias;
-            }
+                for (int r = 0; r < 16; r += 2) {
+                    const xf32x2 x = xf32x2{s[t][r], s[t][r + 1]} * xf32x2{a.qk_scale, a.qk_scale};
+                    const xf32x2 y = x + xf32x2{bias, bias};
+                    s[t][r] = y.x; s[t][r + 1] = y.y;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
+                    const float bias = (key <= myq && key < a.valid_len) ? a.bias_in2 : a.bias_out2;
+                    const float x = s[t][r] * a.qk_scale;
+                    s[t][r] = x + bias;
+                }
+        }
         // one online-softmax step over the sub-tiles [T0, T1)
         // one online-softmax step over the sub-tiles [T0, T1) (compile-time constants after inlining)
         auto step = [&](const int T0, const int T1) __attribute__((always_inline)) {
@@ -214,16 +229,27 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_fwd(XAttnArgs a) {
 #pragma unroll
             for (int t = T0; t < T1; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - m_new);
+                for (int r = 0; r < 16; r += 2) {
+                    const xf32x2 d = xf32x2{s[t][r], s[t][r + 1]} - xf32x2{m_new, m_new};
+                    s[t][r] = __builtin_amdgcn_exp2f(d.x);
+                    s[t][r + 1] = __builtin_amdgcn_exp2f(d.y);
+                }
             // block row sum in the library's order (header): group g = 8 consecutive keys = (sub-tile t, j) of both lane halves
             float sg[8];
 #pragma unroll
-            for (int g = 0; g < 4 * (T1 - T0); ++g) {
+            for (int g = 0; g < 4 * (T1 - T0); g += 2) {                   // groups g, g + 1 as the two halves of packed adds
                 const int t = T0 + (g >> 2), j = g & 3;
-                const float part = ((s[t][4 * j] + s[t][4 * j + 1]) + s[t][4 * j + 2]) + s[t][4 * j + 3];
-                float lo, hi;
-                xhalves(part, lo, hi);                                     // lo = lane half 0's partial, on both halves
-                sg[g] = (((lo + s[t][4 * j]) + s[t][4 * j + 1]) + s[t][4 * j + 2]) + s[t][4 * j + 3];       // meaningful on lane half 1
+                xf32x2 part = xf32x2{s[t][4 * j], s[t][4 * j + 4]} + xf32x2{s[t][4 * j + 1], s[t][4 * j + 5]};
+                part = part + xf32x2{s[t][4 * j + 2], s[t][4 * j + 6]};
+                part = part + xf32x2{s[t][4 * j + 3], s[t][4 * j + 7]};
+                float lo0, hi0, lo1, hi1;
+                xhalves(part.x, lo0, hi0);                                 // lo = lane half 0's partial, on both halves
+                xhalves(part.y, lo1, hi1);
+                xf32x2 c = xf32x2{lo0, lo1} + xf32x2{s[t][4 * j], s[t][4 * j + 4]};       // meaningful on lane half 1
+                c = c + xf32x2{s[t][4 * j + 1], s[t][4 * j + 5]};
+                c = c + xf32x2{s[t][4 * j + 2], s[t][4 * j + 6]};
+                c = c + xf32x2{s[t][4 * j + 3], s[t][4 * j + 7]};
+                sg[g] = c.x; sg[g + 1] = c.y;
             }
             float l_blk;
             if (T1 - T0 == 1) l_blk = (sg[0] + sg[2]) + (sg[1] + sg[3]);
@@ -231,7 +257,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_fwd(XAttnArgs a) {
             l_run = __builtin_fmaf(l_run, alpha, l_blk);                   // (lane half 1 carries the row's l)
             m_run = m_new;
             if (__any(alpha != 1.0f)) {
-                typedef float xf32x2 __attribute__((ext_vector_type(2)));
                 const xf32x2 a2 = {alpha, alpha};
 #pragma unroll
                 for (int dt = 0; dt < ND; ++dt)
@@ -244,7 +269,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_fwd(XAttnArgs a) {
         };
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-            if (st == 0) { step(0, BN == 64 ? 2 : 1); XA_PIN(); }
+            if (st == 0) { step(0, BN == 64 ? 2 : 1); XA_PIN(); XA_VREAD(1) XA_PIN(); }
             if (BN == 32 && st == 2) { step(1, 2); XA_PIN(); }
             const int t = st >> 1, s2 = st & 1;
             xs16x8_t pb;
@@ -324,6 +349,15 @@ static float bias_log2e_bf16(float bias) {
 
 using namespace ar;
 
+// launch forms (equal results; measured A/B, profiles/r06_attn_exact_waves_ab.json): bits 0-1 forward, bits 2-3 backward -- 0 default
+// (8 waves at head size 128, 4 at head size 64), 1 = workgroups of 4 waves (128 own rows), 2 = workgroups of 8 waves (256 own rows)
+static int g_xattn_cfg = 0;
+extern "C" int ar_attn_exact_config(int cfg) {
+    const int old = g_xattn_cfg;
+    if (cfg >= 0) g_xattn_cfg = cfg & 15;
+    return old;
+}
+
 extern "C" int ar_attn_fwd_exact(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
                                  int64_t kv_rep, float scale, float bias_in, float bias_out, int64_t valid_len, int64_t q_bs, int64_t q_hs,
                                  int64_t q_ts, int64_t k_bs, int64_t k_hs, int64_t k_ts, int64_t v_bs, int64_t v_hs, int64_t v_ts,
@@ -357,11 +391,13 @@ extern "C" int ar_attn_fwd_exact(const void* Q, const void* K, const void* V, vo
         (void)hipFuncSetAttribute((const void*)k_xattn_fwd<8, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
     }
     hipStream_t s = (hipStream_t)stream;
+    const int form = g_xattn_cfg & 3;
+    const bool eight = S % 256 == 0 && (form == 2 || (form == 0 && D == 128));      // measured (profiles/r06_attn_exact_waves_ab.json)
     if (D == 128) {
-        if (S % 256 == 0) hipLaunchKernelGGL((k_xattn_fwd<8, 128, 64>), (int)(B * H * (S / 256)), 512, LDS128, s, a);
+        if (eight) hipLaunchKernelGGL((k_xattn_fwd<8, 128, 64>), (int)(B * H * (S / 256)), 512, LDS128, s, a);
         else hipLaunchKernelGGL((k_xattn_fwd<4, 128, 64>), (int)(B * H * (S / 128)), 256, LDS128, s, a);
     } else {
-        if (S % 256 == 0) hipLaunchKernelGGL((k_xattn_fwd<8, 64, 32>), (int)(B * H * (S / 256)), 512, LDS64, s, a);
+        if (eight) hipLaunchKernelGGL((k_xattn_fwd<8, 64, 32>), (int)(B * H * (S / 256)), 512, LDS64, s, a);
         else hipLaunchKernelGGL((k_xattn_fwd<4, 64, 32>), (int)(B * H * (S / 128)), 256, LDS64, s, a);
     }
     return launch_status();
@@ -558,6 +594,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_bwd(XBwdArgs a) {
         // `plain`: every (query, key) pair between the wave's own rows and this tile is inside the kept region
         const bool plain = MODE == 0 ? (t0 + XK - 1 <= o0 + 32 * wave && t0 + XK <= a.valid_len)
                                      : (t0 >= o0 + 32 * wave + 31 && o0 + 32 * wave + 31 < a.valid_len);
+        // ... or every pair outside it (keys after the queries, or invalid keys only)
+        const bool all_out = MODE == 0 ? (t0 > o0 + 32 * wave + 31 || t0 >= a.valid_len)
+                                       : (o0 + 32 * wave > t0 + XK - 1 || o0 + 32 * wave >= a.valid_len);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             xf32x16_t s0, s1;
@@ -568,12 +607,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_bwd(XBwdArgs a) {
                 if (NEED_S1) XB_RREAD(f1[ks], ks, t, 1);
             }
             // the score accumulator starts at fl(bias * bias_scale); dp at zero
+            if (plain || all_out) {
+                const float bias = plain ? a.bias_in_s : a.bias_out_s;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int srow = t0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
-                const int query = MODE == 0 ? myrow : srow, key = MODE == 0 ? srow : myrow;
-                s0[r] = (plain || (key <= query && key < a.valid_len)) ? a.bias_in_s : a.bias_out_s;
-                s1[r] = 0.f;
+                for (int r = 0; r < 16; ++r) { s0[r] = bias; s1[r] = 0.f; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int srow = t0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
+                    const int query = MODE == 0 ? myrow : srow, key = MODE == 0 ? srow : myrow;
+                    s0[r] = (key <= query && key < a.valid_len) ? a.bias_in_s : a.bias_out_s;
+                    s1[r] = 0.f;
+                }
             }
 #pragma unroll
             for (int kb = 0; kb < NKS; kb += KB) {
@@ -774,6 +819,23 @@ extern "C" int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, co
         (void)hipFuncSetAttribute((const void*)k_xattn_bwd<0, 8, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128);
         (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 8, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + VEC_MAX);
         (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 8, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + VEC_MAX);
+        (void)hipFuncSetAttribute((const void*)k_xattn_bwd<0, 4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128);
+        (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 4, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + VEC_MAX);
+        (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 4, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + VEC_MAX);
+        (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T + VEC_MAX);
+    }
+    const int bform = (g_xattn_cfg >> 2) & 3;
+    if (bform == 1 || (bform == 0 && D == 64)) {         // workgroups of 4 waves (the default at head size 64: measured)
+        const int grid4 = (int)(B * H * (S / 128));
+        if (D == 128) {
+            hipLaunchKernelGGL((k_xattn_bwd<1, 4, 128, 1>), grid4, 256, LDS_T128 + vec, s, a);
+            hipLaunchKernelGGL((k_xattn_bwd<1, 4, 128, 2>), grid4, 256, LDS_T128 + vec, s, a);
+            hipLaunchKernelGGL((k_xattn_bwd<0, 4, 128>), grid4, 256, LDS_T128, s, a);
+        } else {
+            hipLaunchKernelGGL((k_xattn_bwd<1, 4, 64>), grid4, 256, LDS_T + vec, s, a);
+            hipLaunchKernelGGL((k_xattn_bwd<0, 4, 64>), grid4, 256, LDS_T, s, a);
+        }
+        return launch_status();
     }
     const int grid = (int)(B * H * (S / 256));
     if (D == 128) {

@@ -490,6 +490,11 @@ int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, const void* O
                       int64_t v_hs, int64_t v_ts, int64_t o_bs, int64_t o_hs, int64_t o_ts, int64_t do_bs, int64_t do_hs, int64_t do_ts,
                       int64_t lddq, int64_t lddk, int64_t lddv, void* workspace, int64_t workspace_bytes, ar_stream_t stream);
 
+/* Launch form of ar_attn_fwd_exact / ar_attn_bwd_exact (binding hygiene: a tuning knob for A/B measurements, results are identical
+ * in every form -- the per-row arithmetic does not depend on how many rows a workgroup owns).  Bits 0-1 forward, bits 2-3 backward:
+ * 0 default, 1 workgroups of 4 waves (128 own rows), 2 workgroups of 8 waves (256).  cfg < 0 only reads.  -> the previous value. */
+int ar_attn_exact_config(int cfg);
+
 /* ---- causal attention backward, head size 64 (deterministic: two MFMA kernels, no float atomics) ---------------------------
  * replaces: autograd of the same attention call -- torch's aten::_scaled_dot_product_efficient_attention_backward, i.e. aiter's
  *           fmha_bwd (+ pre / post-process kernels), which accumulates dQ with fp32 atomics (0.42 ms per call at OPT-125M's minibatch,
