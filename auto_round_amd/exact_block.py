@@ -353,6 +353,8 @@ class ExactLlamaBlock(FusedLlamaBlock):
         mask = others.get("attention_mask")
         xa = exact_attention_forward(qr4, kr4, v4, mask, self.attn.scaling, S) if P.get("attn") else None
         al = ao = None
+        if xa is None and mask is not None and getattr(self, "materialise_mask_rows", False) and mask.shape[0] == 1 and B > 1:
+            mask = mask.expand(B, *mask.shape[1:]).contiguous()      # (the quantizer handed the shared mask over un-materialised)
         if xa is None or self._attn_verify:
             with torch.enable_grad() if grad else contextlib.nullcontext():
                 al = [t.detach().requires_grad_(grad) for t in (qr4, kr4, v4)]

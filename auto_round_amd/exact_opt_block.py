@@ -173,6 +173,8 @@ class ExactOPTBlock(FusedOPTBlock):
         q4, k4, v4 = (t.view(B, S, hq, hd).transpose(1, 2) for t in (q2d, k2d, v2d))
         xa = exact_attention_forward(q4, k4, v4, mask, 1.0, S) if P.get("attn") else None
         al = ao = None
+        if xa is None and mask is not None and getattr(self, "materialise_mask_rows", False) and mask.shape[0] == 1 and B > 1:
+            mask = mask.expand(B, *mask.shape[1:]).contiguous()      # (the quantizer handed the shared mask over un-materialised)
         if xa is None or getattr(self, "_attn_verify", False):
             with torch.enable_grad() if grad else contextlib.nullcontext():
                 al = [t.detach().requires_grad_(grad) for t in (q4, k4, v4)]

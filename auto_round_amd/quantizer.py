@@ -418,9 +418,16 @@ class SignRoundQuantizer:
         except TypeError:  # pragma: no cover  (older torch without set_priority)
             return sdpa_kernel(order)
 
-    def _others_for(self, rows: int, input_others):
-        """`materialise_shared_rows`: the block's shared keyword tensors at the minibatch's own row count (see SignRoundConfig)"""
+    def _others_for(self, rows: int, input_others, consumer=None):
+        """`materialise_shared_rows`: the block's shared keyword tensors at the minibatch's own row count (see SignRoundConfig).
+        `consumer`: an exact block whose proven plan runs the attention on the first-party kernels (plan["attn"]) reads the mask's
+        STRUCTURE, not its rows (ops.mask_structure, cached per tensor object): the shared one-row mask is handed over as it is -- no
+        64 MB copy and no host read per iteration -- and the block materialises the rows itself should it ever fall back to torch's
+        attention (`materialise_mask_rows`)."""
         if not (self.config.materialise_shared_rows and input_others):
+            return input_others
+        if consumer is not None and getattr(consumer, "exact", False) and (getattr(consumer, "plan", None) or {}).get("attn"):
+            consumer.materialise_mask_rows = True
             return input_others
 
         def mat(v):
@@ -650,7 +657,7 @@ class SignRoundQuantizer:
                     pred, ctx = fused.forward_direct(x, others_b, donate_input=True)      # (exact blocks are never captured: capturable = False)
                 else:
                     if fused is not None:
-                        pred = fused.forward(x, self._others_for(nb, others_b) if self.last_exact else others_b, donate_input=True)
+                        pred = fused.forward(x, self._others_for(nb, others_b, consumer=fused) if self.last_exact else others_b, donate_input=True)
                     else:
                         pred = self.block_forward(block, x, others_b)      # x: scratch rows
                 pred_c = pred if pred.is_contiguous() else pred.contiguous()
@@ -1003,7 +1010,7 @@ class SignRoundQuantizer:
         if self.config.exact_rounding and self.config.amp and isinstance(input_others, dict) and not self.config.data_parallel:
             fb = self._build_exact_plain(block, inputs, input_others, min(bs, inputs.shape[0]))
             if fb is not None:
-                outs = [fb.forward_nograd(inputs[b0:b0 + bs], self._others_for(min(bs, inputs.shape[0] - b0), input_others))
+                outs = [fb.forward_nograd(inputs[b0:b0 + bs], self._others_for(min(bs, inputs.shape[0] - b0), input_others, consumer=fb))
                         for b0 in range(0, inputs.shape[0], bs)]
                 return torch.cat(outs, dim=0)
         elif self.config.fused_block and self.config.amp and isinstance(input_others, dict):
