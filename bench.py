@@ -677,7 +677,10 @@ def main():
                        "deterministic_algorithms": "warn_only (as the reference's front door sets it)",
                        "first_party_gemm_mfma": f"v_mfma_f32_{'16x16x32' if args.gemm_mfma == 16 else '32x32x16'}_bf16",
                        "attention_mask": ("calibration: the [1, 1, S, S] 0/1 additive mask of the reference's calibration flow "
-                                          "(calibration/llm.py:360-402, inputs.py:100-107) -- the attention is the library's (torch SDPA), as in the reference"
+                                          "(calibration/llm.py:360-402, inputs.py:100-107) -- the attention is " +
+                                          ("FIRST-PARTY with the library's bits (csrc/ar_attn_exact.hip, proven against torch's SDPA on this block)"
+                                           if ((getattr(b.quantizer, "last_exact_report", None) or {}).get("plan") or {}).get("attn")
+                                           else "the library's (torch SDPA), as in the reference")
                                           if args.mask == "calibration" else
                                           "none: causal attention (attention_mask=None; the fused path then runs csrc/ar_attn*.hip)"),
                        "parallelism": (f"data-parallel inside the block x{world}" if dp else
@@ -878,7 +881,7 @@ CONFIG_HEAD = ("workload", "path", "attention_mask", "bit_identical", "digest_te
                "opt125m_parity_first_differing_stage", "opt125m_exact_blocks_per_s",
                "opt125m_module_blocks_per_s", "opt125m_fused_nomask_blocks_per_s", "fused_mask_blocks_per_s", "fused_nomask_blocks_per_s",
                "speedup_vs_reference_same_gpu",
-               "fuse_next_forward", "first_party_dw_gemm", "dx_through_transposed_weight", "iters", "nsamples", "seqlen", "batch_size", "bits",
+               "fuse_next_forward", "first_party_attention", "first_party_dw_gemm", "dx_through_transposed_weight", "iters", "nsamples", "seqlen", "batch_size", "bits",
                "group_size", "sym")
 CPU_BASELINE_HEAD = ("value", "unit", "cores", "kind", "sample", "reference_quoted_value", "reference_quoted_cores", "speedup_vs_reference_quoted",
                      "speedup_vs_port", "note")
@@ -926,6 +929,7 @@ def flat_for_the_driver(out, path, mask):
     if path in ("exact", "module"):        # these four describe the FUSED path's engines; on the other paths they only mislead
         for k in ("flash_attention", "flash_attention_bwd", "tn_dx_gemm", "mfma_dw_gemm"):
             cfg.pop(k, None)
+        cfg["first_party_attention"] = bool(plan.get("attn"))
         cfg["first_party_dw_gemm"] = any(k.startswith("dw_") and v for k, v in plan.items())
         cfg["dx_through_transposed_weight"] = any(k.startswith("tn_") and v for k, v in plan.items())
     cfg["opt125m_module_bit_identical"] = par.get("opt125m_module_path_bit_identical")
