@@ -312,6 +312,12 @@ class SignRoundConfig:
     # mask): about 50 forward + backward passes with clones of the weight gradients -- ~1.5 s at Llama-3-8B's block dimensions, ~10 s
     # at Llama-3-70B's -- after which every later block of that kind is a dictionary lookup.
     exact_rounding: bool = False
+    # MODULE-PATH blocks (no exact form: Mixtral, Qwen3, ...): run the block's attention on csrc/ar_attn_exact.hip -- the library
+    # attention's bits at less than half its time -- through a transformers attention function installed for the block's tuning run,
+    # AFTER a proof on two real minibatches: block output and every weight gradient equal to the stock module path's, and the
+    # attention outputs / q, k, v gradients equal to torch's own directly.  Where the proof fails (other shapes, other masks, another
+    # library build) the stock attention stays.  Only read when `exact_rounding` is on (the switch that asks for the module path's bits).
+    exact_attention: bool = True
 
     def __post_init__(self):
         if self.iters < 0:
@@ -378,6 +384,8 @@ class SignRoundQuantizer:
         self._fused_verdict: Dict[Any, bool] = {}        # block signature -> did the fused kernels agree with the module code
         self._exact_warned: set = set()
         self._exact_plans: Dict[Any, Any] = {}           # (block signature, minibatch shape) -> proven exact_rounding plan | False
+        self._modattn_verdict: Dict[Any, Any] = {}       # module-path attention on the first-party kernels: proven? (exact_attention)
+        self._attn_restore: list = []                    # (config object, its _attn_implementation) to put back after the block
         self.last_exact = False
         self.last_exact_report: Optional[dict] = None
         self._graph_stream = None
@@ -429,6 +437,8 @@ class SignRoundQuantizer:
         if consumer is not None and getattr(consumer, "exact", False) and (getattr(consumer, "plan", None) or {}).get("attn"):
             consumer.materialise_mask_rows = True
             return input_others
+        if consumer is None and self._attn_restore:      # module path with the proven first-party attention installed (exact_attention)
+            return input_others
 
         def mat(v):
             # (whatever the dtype: transformers may hand the sdpa path a BOOLEAN mask, and the reference's runner concatenates that too)
@@ -459,9 +469,12 @@ class SignRoundQuantizer:
         from .attention import guarded_sdpa
 
         with torch.cuda.device(self.device), _no_uninitialised_fill(), guarded_sdpa(getattr(self.config, "sdpa_guard", "") or ""):
-            if not getattr(self.config, "verify_attention_forward", False):
-                return self._quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs)
-            return self._quantize_block_verified(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs)
+            try:
+                if not getattr(self.config, "verify_attention_forward", False):
+                    return self._quantize_block(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs)
+                return self._quantize_block_verified(block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs)
+            finally:
+                self._restore_module_attention()
 
     def _quantize_block_verified(self, block, fp_inputs, input_others, fp_outputs, q_inputs, block_ctx, input_ids, **kwargs):
         """`verify_attention_forward`: tune, and tune again from the block's fp weights and the same `random` state when the attention
@@ -564,6 +577,11 @@ class SignRoundQuantizer:
                 if not self._fused_verdict[key]:
                     fused = None
         self.last_fused_block = fused is not None
+        self.last_module_exact_attention = False
+        if fused is None and cfg.exact_rounding and cfg.exact_attention and cfg.amp and not cfg.data_parallel:
+            self.last_module_exact_attention = self._install_module_attention(
+                block, arenas, input_others, per_sample_others, X, Y,
+                min(cfg.batch_size, min(nsamples, cfg.batch_size * cfg.gradient_accumulate_steps)))
 
         # one (round, minmax) pair of param groups per arena; lr by the arena's bit-width (quantizer.py:374-417)
         groups = []
@@ -741,6 +759,91 @@ class SignRoundQuantizer:
             unwrapper_block(block, best_params)
         # hand out independent copies: the arenas' best_* buffers are released with the block's wrappers
         return {n: {k: v.clone() for k, v in d.items()} for n, d in best_params.items()}
+
+    # -- module path: the block's attention on the first-party kernels (exact_attention) ------------------------------------------
+    def _restore_module_attention(self):
+        from . import attention as A
+
+        while self._attn_restore:
+            cfg_obj, old = self._attn_restore.pop()
+            cfg_obj._attn_implementation = old
+        A.exact_state["materialise"] = False
+
+    def _install_module_attention(self, block, arenas, input_others, per_sample_others, X, Y, rows) -> bool:
+        """Proof, then installation for this block's tuning run: the module code with transformers' attention function swapped for
+        `attention.exact_sdpa_attention` must return the stock module path's block output and weight gradients bit for bit on two
+        real minibatches, with every attention call's output and q / k / v gradients equal to torch's own (compared inside the call).
+        The verdict is remembered per kind of block and minibatch shape."""
+        import warnings
+
+        from . import attention as A
+        from .exact_block import _count_diff
+
+        mask = input_others.get("attention_mask") if isinstance(input_others, dict) else None
+        cfgs = {}
+        for m in block.modules():
+            c = getattr(m, "config", None)
+            if c is not None and getattr(c, "_attn_implementation", None) == "sdpa":
+                cfgs[id(c)] = c
+        if mask is None or not cfgs or per_sample_others or X.shape[0] < rows:
+            return False
+        key = ("modattn", self._block_signature(block), self._shape_signature(block), rows, tuple(X.shape[1:]), str(X.dtype),
+               (tuple(mask.shape), str(mask.dtype)), self.config.sdpa_backend, self.config.materialise_shared_rows)
+        verdict = self._modattn_verdict.get(key)
+        name = A.register_exact_sdpa()
+
+        def install():
+            for c in cfgs.values():
+                self._attn_restore.append((c, c._attn_implementation))
+                c._attn_implementation = name
+            A.exact_state["materialise"] = bool(self.config.materialise_shared_rows)
+
+        if verdict is not None:
+            if verdict:
+                install()
+            return bool(verdict)
+        for a in arenas:
+            if not a.wq_fresh:
+                a.qdq_forward()
+        reset = lambda: [l._dw_accum.__setitem__(0, False) for a in arenas for l in a.layers]  # noqa: E731
+
+        def run(lo):
+            reset()
+            xb = X[lo:lo + rows].clone()
+            pred = self.block_forward(block, xb, input_others)
+            pred_c = pred if pred.is_contiguous() else pred.contiguous()
+            dpred = torch.empty_like(pred_c)
+            scratch = torch.zeros(1, dtype=torch.float32, device=xb.device)
+            ops.mse_loss_fwd_bwd(pred_c, Y[lo:lo + rows].to(pred_c.dtype), dpred=dpred, loss_accum=scratch, accum_scale=1.0, grad_scale=1000.0)
+            pred_c.backward(dpred)
+            return pred_c.detach(), [a.dWq.clone() for a in arenas]
+
+        los = [0] + ([rows] if X.shape[0] >= 2 * rows else [])
+        report = dict(minibatches=len(los))
+        try:
+            refs = [run(lo) for lo in los]
+            install()
+            A.exact_state.update(verify=True, diffs={}, calls=0, fallbacks=0)
+            n_bad = 0
+            for lo, (y_ref, dw_ref) in zip(los, refs):
+                y, dws = run(lo)
+                n_bad += _count_diff(y, y_ref) + sum(_count_diff(a, b) for a, b in zip(dws, dw_ref))
+            direct = dict(A.exact_state["diffs"])
+            report.update(block_mismatches=n_bad, attn_direct=direct, calls=A.exact_state["calls"], fallbacks=A.exact_state["fallbacks"])
+            verdict = (n_bad == 0 and A.exact_state["calls"] > 0 and A.exact_state["fallbacks"] == 0
+                       and set(direct) == {"out", "dq", "dk", "dv"} and not any(direct.values()))
+        except Exception as e:  # noqa: BLE001 -- never an aborted run: the stock attention stays
+            report["error"] = repr(e)[:200]
+            verdict = False
+        finally:
+            A.exact_state["verify"] = False
+            reset()
+        self._modattn_verdict[key] = verdict
+        self.last_module_attention_report = dict(report, usable=bool(verdict))
+        if not verdict:
+            self._restore_module_attention()
+            warnings.warn(f"exact_attention: {type(block).__name__} keeps torch's own attention on the module path ({report})")
+        return bool(verdict)
 
     def _build_exact(self, block, arenas, input_others, per_sample_others, X, Y, rows: int):
         """The exact_rounding form of a wrapped block, or None (module path): recognised by exact_block.ExactLlamaBlock and PROVEN
