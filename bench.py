@@ -395,6 +395,7 @@ class Bench:
             kw["mfma_dw_gemm"] = fused_block
         kw["flash_attention"] = not getattr(args, "no_flash_attn", False)
         kw["flash_attention_bwd"] = not getattr(args, "no_attn_bwd", False)
+        kw["exact_attention"] = not getattr(args, "no_exact_attention", False)
         kw["hip_graph"] = True if getattr(args, "hip_graph", False) else (False if getattr(args, "no_hip_graph", False) else None)
         self.qcfg = SignRoundConfig(iters=args.iters, batch_size=args.batch_size, bits=self.bits,
                                     fuse_next_forward=fuse_next_forward, sdpa_backend=self.sdpa, data_parallel=dp,
@@ -529,6 +530,11 @@ def main():
                     help="tune with the algorithm extension (SignRoundV2: imatrix, searched init scales, outlier loss)")
     ap.add_argument("--no-flash-attn", action="store_true", help="fused block: keep torch's SDPA forward instead of csrc/ar_attn.hip")
     ap.add_argument("--no-attn-bwd", action="store_true", help="fused block, head size 64: keep the library's attention backward instead of csrc/ar_attn_bwd.hip")
+    ap.add_argument("--force-exact", action="store_true",
+                    help="--path exact on a family without an exact form (Mixtral, ...): exact_rounding stays on, the block then runs on the "
+                         "MODULE path with its attention on the first-party exact kernels (exact_attention) instead of switching to the fused path")
+    ap.add_argument("--no-exact-attention", action="store_true",
+                    help="A/B: module-path blocks (no exact form) keep torch's own attention instead of csrc/ar_attn_exact.hip (SignRoundConfig.exact_attention)")
     ap.add_argument("--hip-graph", action="store_true",
                     help="replay each tuning iteration as one captured hipGraph even while per-dispatch kernel timing is on (the roofline "
                          "objects then only see iteration 0 of every block); without the flag: automatic for small blocks when timing is off")
@@ -591,7 +597,7 @@ def main():
     dp = bool(args.data_parallel and world > 1)
     sharded = world > 1 and not dp
     path = "module" if args.no_fused_block else args.path
-    if path == "exact" and (dp or WORKLOADS[args.workload]["family"] not in ("llama", "opt")):
+    if path == "exact" and (dp or WORKLOADS[args.workload]["family"] not in ("llama", "opt")) and not args.force_exact:
         path = "fused"          # exact_rounding covers the Llama and OPT families, one rank per block; everything else: the fused path
     fused = path == "fused"
     profile = not args.no_kernel_timing
@@ -673,6 +679,7 @@ def main():
                        "exact_kept_on_second_try": (getattr(b.quantizer, "last_exact_report", None) or {}).get("kept_on_second_try"),
                        "exact_streamk": (getattr(b.quantizer, "last_exact_report", None) or {}).get("streamk"),
                        "hip_graph": bool(getattr(b.quantizer, "last_hip_graph", False)),
+                       "module_path_exact_attention": bool(getattr(b.quantizer, "last_module_exact_attention", False)),
                        "sdpa_backend": b.sdpa, "alg_ext": bool(args.alg_ext),
                        "deterministic_algorithms": "warn_only (as the reference's front door sets it)",
                        "first_party_gemm_mfma": f"v_mfma_f32_{'16x16x32' if args.gemm_mfma == 16 else '32x32x16'}_bf16",
