@@ -10,7 +10,11 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 SHAPES = [pytest.param(8, 32, 2048, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-minibatch"),
-          pytest.param(8, 12, 2048, 64, 12, 1.0, 0.35, id="opt-125m-minibatch")]
+          pytest.param(8, 12, 2048, 64, 12, 1.0, 0.35, id="opt-125m-minibatch"),
+          pytest.param(8, 64, 2048, 128, 8, 128 ** -0.5, 1.0, id="llama3-70b-minibatch"),
+          pytest.param(4, 32, 2048, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-batch4"),
+          pytest.param(8, 32, 1024, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-seq1024"),
+          pytest.param(8, 32, 4096, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-seq4096")]
 
 
 def _case(B, H, S, D, hk, std, seed=0, valid=None):
