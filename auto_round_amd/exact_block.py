@@ -12,7 +12,9 @@ transformers/models/llama/modeling_llama.py).  This file runs that block with
     whichever faster forms PROVE bit-equal on this GPU and software stack: merged q/k/v and gate/up GEMMs, the hand-written MFMA
     weight-gradient GEMM (csrc/ar_gemm.hip, unsplit K), input-gradient GEMMs through a transposed weight copy;
   * the attention through transformers' own `sdpa_attention_forward` (the library kernels the module path calls, same operand
-    layouts), in a local autograd graph.
+    layouts) in a local autograd graph -- or, round 6, on csrc/ar_attn_exact.hip: the library attention's arithmetic restated from the
+    gfx950 code objects torch ships (option `attn`: output, log-sum-exp and q / k / v gradients equal torch's value for value at the
+    tuning minibatch's shape, at less than half the library's time), proven like everything else.
 
 Nothing is assumed: `ExactLlamaBlock.plan_against_module` runs ONE real minibatch forward + backward through the module code and
 through this class on the same frozen state and compares the block output and every weight gradient bit for bit -- first with every

@@ -15,7 +15,10 @@ What the module path computes, op by op (eval mode: the dropouts are identities)
                                             input gradients `torch.mm(dY, Wq)` -- the module path's own calls.
   q_proj(x) * scaling                       torch's multiply by a python scalar (its own rounding), backward the same.
   attention                                 transformers' `sdpa_attention_forward` on the layouts `OPTAttention` hands over
-                                            (scaling = 1.0), in a local autograd graph: the library kernels the module path calls.
+                                            (scaling = 1.0), in a local autograd graph: the library kernels the module path calls --
+                                            or (round 6, option `attn`) csrc/ar_attn_exact.hip, the library attention's arithmetic
+                                            restated from torch's gfx950 code objects: the same bits at 0.59 instead of 1.46 ms,
+                                            and without the library forward's run-to-run slips at head size 64.
   residual adds, ReLU                       torch's add / relu / threshold_backward: one rounding each, as eager.
 
 Nothing is assumed: `plan_against_module` runs real minibatches forward + backward through the module code and through this class on
