@@ -80,16 +80,20 @@ def exact_attention_forward(q4, k4, v4, mask, scale, S):
     return (q4, k4, v4, got[0], got[1], st)
 
 
-def exact_attention_backward(xa, dattn4, scale):
+def exact_attention_backward(xa, dattn4, scale, outs=None):
     """gradients of the call `exact_attention_forward` made: -> (gq4 [B, H, S, D], gk4, gv4 [B, H / kv_rep, S, D]) -- the kv_rep query
-    heads of a group summed as autograd's expand backward does (one fp32 sum per value, rounded once)"""
+    heads of a group summed as autograd's expand backward does (one fp32 sum per value, rounded once).
+    outs (kv_rep == 1 only): three [B * S, H * D] destinations (column slices of a merged gradient buffer) the kernels write into."""
     q4, k4, v4, o4, lse, st = xa
-    got = ops.attn_bwd_exact(q4, k4, v4, o4, lse, dattn4, st, float(scale))
-    if got is None:
-        raise RuntimeError("ar_attn_bwd_exact refused a call whose forward it took")
-    dq, dke, dve = got
     B, H, S, D = q4.shape
     hk = k4.shape[1]
+    kw = {}
+    if outs is not None and hk == H:
+        kw = dict(dq=outs[0], dk=outs[1], dv=outs[2])
+    got = ops.attn_bwd_exact(q4, k4, v4, o4, lse, dattn4, st, float(scale), **kw)
+    if got is None:
+        raise RuntimeError("ar_attn_bwd_exact refused a call whose forward it took")
+    dq, dke, dve = (t if t.dim() == 4 else t.view(B, S, H, D) for t in got)
     gq4 = dq.transpose(1, 2)
     if hk == H:
         return gq4, dke.transpose(1, 2), dve.transpose(1, 2)

@@ -40,6 +40,7 @@ from . import ops
 from .exact_block import _bits_equal, _count_diff, exact_attention_backward, exact_attention_forward
 from .fused_block import OPT_FAMILY, FusedOPTBlock, _class_in, _FusedBlockFn
 
+GEMM_OPTS = ("merged_qkv", "dw_qkv")      # q / k / v as ONE library GEMM forward (N = 3 H) and ONE weight-gradient GEMM -- kept when bit-equal
 KERNEL_OPTS = ("ln1", "ln2", "attn")     # "attn": csrc/ar_attn_exact.hip instead of torch's SDPA (exact_block.py)
 # flag bits of the LayerNorm kernels that an installed torch build may resolve either way (csrc/ar_exact_ln.hip): tried in this order
 LN_VARIANTS = (0, 1, 2, 3)
@@ -101,7 +102,7 @@ class ExactOPTBlock(FusedOPTBlock):
     @staticmethod
     def base_plan() -> Dict[str, object]:
         """every segment on torch's own ops (exact by construction)"""
-        return dict(ln1=False, ln2=False, ln_flags=0, attn=False)
+        return dict(ln1=False, ln2=False, ln_flags=0, attn=False, merged_qkv=False, dw_qkv=False)
 
     def set_plan(self, plan):
         self.plan = {**self.base_plan(), **plan}
@@ -169,9 +170,16 @@ class ExactOPTBlock(FusedOPTBlock):
         res = ops.layernorm_fwd_exact(x2d, self.n1.weight, self.n1.bias, float(self.n1.eps), flags=int(P["ln_flags"]), want_stats=False) if P["ln1"] else None
         h1 = res[0] if res is not None else self._ln_module(self.n1, x2d, B, S, False)[0]
         h1_in = fq(h1, aq["qkv"])
-        q2d = F.linear(h1_in, L["q"].weight_q, self._bias("q")) * self.qscale         # OPTAttention: q_proj(x) * scaling
-        k2d = F.linear(h1_in, L["k"].weight_q, self._bias("k"))
-        v2d = F.linear(h1_in, L["v"].weight_q, self._bias("v"))
+        if P.get("merged_qkv"):      # one GEMM over the three projections' rows (adjacent in the arena): column slices go on
+            qkv = F.linear(h1_in, self.Wqkv, self.b_qkv)
+            at = {n: i * H for i, n in enumerate(self.order)}
+            q2d = qkv[:, at["q"]:at["q"] + H] * self.qscale
+            k2d, v2d = qkv[:, at["k"]:at["k"] + H], qkv[:, at["v"]:at["v"] + H]
+            del qkv
+        else:
+            q2d = F.linear(h1_in, L["q"].weight_q, self._bias("q")) * self.qscale         # OPTAttention: q_proj(x) * scaling
+            k2d = F.linear(h1_in, L["k"].weight_q, self._bias("k"))
+            v2d = F.linear(h1_in, L["v"].weight_q, self._bias("v"))
         mask = others.get("attention_mask")
         q4, k4, v4 = (t.view(B, S, hq, hd).transpose(1, 2) for t in (q2d, k2d, v2d))
         xa = exact_attention_forward(q4, k4, v4, mask, 1.0, S) if P.get("attn") else None
@@ -249,18 +257,42 @@ class ExactOPTBlock(FusedOPTBlock):
         dattn = bq(torch.mm(dx2, L["o"].weight_q), s.pop("a2d"), aq["o"])
         del dx2
         al, ao, xa = s.pop("leaves"), s.pop("ao"), s.pop("attn_x")
+        dqkv = torch.empty((T, 3 * H), dtype=self.dtype, device=dy2d.device) if P.get("dw_qkv") else None
+        outs = None
+        if dqkv is not None:
+            at = {n: i * H for i, n in enumerate(self.order)}
+            outs = tuple(dqkv[:, at[n]:at[n] + H] for n in "qkv")
         if xa is not None:
-            gq4, gk4, gv4 = exact_attention_backward(xa, dattn.view(B, S, self.hq, self.hd), 1.0)
+            gq4, gk4, gv4 = exact_attention_backward(xa, dattn.view(B, S, self.hq, self.hd), 1.0, outs=outs)
             if ao is not None:          # the proof: torch's gradients beside the first-party ones
                 for name, mine, ref in zip(("dq", "dk", "dv"), (gq4, gk4, gv4), torch.autograd.grad(ao, al, dattn.view(B, S, H))):
                     self._attn_diffs[name] = self._attn_diffs.get(name, 0) + _count_diff(mine, ref)
         else:
             gq4, gk4, gv4 = torch.autograd.grad(ao, al, dattn.view(B, S, H))
+        first_party = xa is not None
         del al, ao, xa, dattn
+        h1_in = s.pop("h1_in")
+        if dqkv is not None:          # the merged gradient buffer: one weight-gradient GEMM over the three projections' rows
+            if not first_party:
+                for n, g in zip("qkv", (gq4, gk4, gv4)):
+                    outs["qkv".index(n)].view(B, S, self.hq, self.hd).copy_(g.transpose(1, 2))
+            outs[0].mul_(self.qscale)                                  # MulBackward0 of q_proj(x) * scaling (its own rounding)
+            acc = [l._dw_accum[0] for l in self.trio]
+            if all(acc):
+                self.dWqkv.addmm_(dqkv.t(), h1_in)
+            elif not any(acc):
+                torch.mm(dqkv.t(), h1_in, out=self.dWqkv)
+            else:
+                raise RuntimeError("q / k / v weight gradients in different accumulation states")
+            for lyr in self.trio:
+                lyr._dw_accum[0] = True
+                post = getattr(lyr, "_post_dw", None)
+                if post is not None:
+                    post()
+            return
         dq2d = gq4.transpose(1, 2).reshape(T, H) * self.qscale        # MulBackward0 of q_proj(x) * scaling
         dk2d = gk4.transpose(1, 2).reshape(T, H)
         dv2d = gv4.transpose(1, 2).reshape(T, H)
-        h1_in = s.pop("h1_in")
         self._dw_x("q", dq2d, h1_in)
         self._dw_x("k", dk2d, h1_in)
         self._dw_x("v", dv2d, h1_in)
@@ -371,6 +403,21 @@ class ExactOPTBlock(FusedOPTBlock):
                         report.setdefault("kept_on_second_try", []).append(opt)
                         warnings.warn(f"exact_rounding: option {opt} differed from the module path in its first pair of runs ({worst}) and "
                                       f"matched in the second pair -- kept; the library under the comparison is not perfectly repeatable")
+                    break
+                worst[str(attempt)] = n_bad
+            if opt not in report["kept"]:
+                report["dropped"][opt] = worst
+        for opt in [o for o in GEMM_OPTS if want is None or o in want]:
+            report["tried"].append(opt)
+            trial = dict(plan, **{opt: True})
+            worst = {}
+            for attempt in (0, 1):
+                ok, n_bad = proven(trial)
+                if ok:
+                    plan = trial
+                    report["kept"].append(opt)
+                    if attempt:
+                        report.setdefault("kept_on_second_try", []).append(opt)
                     break
                 worst[str(attempt)] = n_bad
             if opt not in report["kept"]:

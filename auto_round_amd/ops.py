@@ -766,7 +766,7 @@ def attn_bwd_exact(q4, k4, v4, out, lse, dout, mask_struct, scale: float, dq=Non
     if rc == _lib.AR_ERR_UNSUPPORTED:
         return None
     check(rc, "ar_attn_bwd_exact")
-    return tuple(t.view(B, S, H, D) if t.is_contiguous() else t for t in outs)
+    return tuple(t.view(B, S, H, D) for t in outs)      # (a column slice of a merged buffer views as [B, S, H, D] with its row stride)
 
 
 _mask_struct_cache: dict = {}
