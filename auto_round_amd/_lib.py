@@ -17,7 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 AR_DT_BF16, AR_DT_F16, AR_DT_F32 = 0, 1, 2
 AR_ERR_UNSUPPORTED = -1
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 
 class Mi355xLibraryError(RuntimeError):
@@ -86,7 +86,7 @@ SIGNATURES = {
     "ar_gemm_dw_config": (c_int, [I, I]),
     "ar_attn_fwd": (c_int, [P, P, P, P, P, L, L, L, L, F, I, L, L, P]),
     "ar_attn_fwd_masked": (c_int, [P, P, P, P, P, L, L, L, L, F, F, F, L, L, L, P]),
-    "ar_attn_fwd_exact": (c_int, [P, P, P, P, P, L, L, L, L, L, F, F, F, L, L, L, L, L, L, L, L, L, L, P]),
+    "ar_attn_fwd_exact": (c_int, [P, P, P, P, P, L, L, L, L, L, F, F, F, L, L, L, L, L, L, L, L, L, L, L, P]),
     "ar_attn_exact_config": (c_int, [I]),
     "ar_attn_bwd_exact_workspace_bytes": (c_int64, [L, L, L]),
     "ar_attn_bwd_exact": (c_int, [P, P, P, P, P, P, P, P, P, L, L, L, L, L, F, F, F, L] + [L] * 18 + [P, L, P]),

@@ -224,7 +224,7 @@ def register_mi355x_sdpa() -> str:
 EXACT_NAME = "mi355x_exact_sdpa"
 # verify: torch's own attention runs beside every call and the outputs / gradients are compared (the quantizer's proof);
 # materialise: the caller hands the shared one-row mask over un-materialised -- a fallback call expands it as the module path would
-exact_state = {"verify": False, "diffs": {}, "calls": 0, "fallbacks": 0, "materialise": False}
+exact_state = {"verify": False, "diffs": {}, "calls": 0, "fallbacks": 0, "materialise": False, "key_block": 0}
 
 
 def _count_bits_differ(a: torch.Tensor, b: torch.Tensor) -> int:
@@ -242,7 +242,8 @@ class _ExactAttnFn(torch.autograd.Function):
     def forward(ctx, q, k, v, st, scale, ref):
         from . import ops
 
-        got = ops.attn_fwd_exact(q, k, v, st, float(scale))
+        kb = int(exact_state.get("key_block") or 0) or ops.attn_key_block_guess(int(q.shape[-1]), int(q.shape[2]))
+        got = ops.attn_fwd_exact(q, k, v, st, float(scale), key_block=kb)
         if got is None:
             raise RuntimeError("ar_attn_fwd_exact refused a call its caller checked")
         o, lse = got

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_fwd(XAttnArgs a) {
     constexpr int CPR = AROW / 16;
     constexpr int NP = RPW / RPI;
     static_assert(NP >= 1, "a wave stages at least one DMA instruction per operand");
-    static_assert(BN == 32 || BN == 64, "key block of the online softmax");
+    static_assert(BN == 16 || BN == 32 || BN == 64, "key block of the online softmax");
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -215,21 +215,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_fwd(XAttnArgs a) {
                 }
         }
         // one online-softmax step over the sub-tiles [T0, T1)
-        // one online-softmax step over the sub-tiles [T0, T1) (compile-time constants after inlining)
-        auto step = [&](const int T0, const int T1) __attribute__((always_inline)) {
+        // one online-softmax step over the 8-key groups [G0, G1) of the tile (group g = sub-tile g >> 2, accumulator rows 4 (g & 3) ..
+        // + 3 of both lane halves; compile-time constants after inlining)
+        auto step = [&](const int G0, const int G1) __attribute__((always_inline)) {
             float mx = -INFINITY;
 #pragma unroll
-            for (int t = T0; t < T1; ++t)
+            for (int g = G0; g < G1; ++g)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[g >> 2][4 * (g & 3) + i]);
             float mlo, mhi;
             xhalves(mx, mlo, mhi);
             const float m_new = fmaxf(m_run, fmaxf(mlo, mhi));
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
-            for (int t = T0; t < T1; ++t)
+            for (int g = G0; g < G1; ++g)
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
+                for (int i = 0; i < 4; i += 2) {
+                    const int t = g >> 2, r = 4 * (g & 3) + i;
                     const xf32x2 d = xf32x2{s[t][r], s[t][r + 1]} - xf32x2{m_new, m_new};
                     s[t][r] = __builtin_amdgcn_exp2f(d.x);
                     s[t][r + 1] = __builtin_amdgcn_exp2f(d.y);
@@ -237,8 +239,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_fwd(XAttnArgs a) {
             // block row sum in the library's order (header): group g = 8 consecutive keys = (sub-tile t, j) of both lane halves
             float sg[8];
 #pragma unroll
-            for (int g = 0; g < 4 * (T1 - T0); g += 2) {                   // groups g, g + 1 as the two halves of packed adds
-                const int t = T0 + (g >> 2), j = g & 3;
+            for (int g = G0; g < G1; g += 2) {                             // groups g, g + 1 as the two halves of packed adds
+                const int t = g >> 2, j = g & 3;
                 xf32x2 part = xf32x2{s[t][4 * j], s[t][4 * j + 4]} + xf32x2{s[t][4 * j + 1], s[t][4 * j + 5]};
                 part = part + xf32x2{s[t][4 * j + 2], s[t][4 * j + 6]};
                 part = part + xf32x2{s[t][4 * j + 3], s[t][4 * j + 7]};
@@ -249,10 +251,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_fwd(XAttnArgs a) {
                 c = c + xf32x2{s[t][4 * j + 1], s[t][4 * j + 5]};
                 c = c + xf32x2{s[t][4 * j + 2], s[t][4 * j + 6]};
                 c = c + xf32x2{s[t][4 * j + 3], s[t][4 * j + 7]};
-                sg[g] = c.x; sg[g + 1] = c.y;
+                sg[g - G0] = c.x; sg[g - G0 + 1] = c.y;
             }
             float l_blk;
-            if (T1 - T0 == 1) l_blk = (sg[0] + sg[2]) + (sg[1] + sg[3]);
+            if (G1 - G0 == 2) l_blk = sg[0] + sg[1];
+            else if (G1 - G0 == 4) l_blk = (sg[0] + sg[2]) + (sg[1] + sg[3]);
             else l_blk = ((sg[0] + sg[4]) + (sg[2] + sg[6])) + ((sg[1] + sg[5]) + (sg[3] + sg[7]));
             l_run = __builtin_fmaf(l_run, alpha, l_blk);                   // (lane half 1 carries the row's l)
             m_run = m_new;
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_fwd(XAttnArgs a) {
         };
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-            if (st == 0) { step(0, BN == 64 ? 2 : 1); XA_PIN(); XA_VREAD(1) XA_PIN(); }
-            if (BN == 32 && st == 2) { step(1, 2); XA_PIN(); }
+            if ((16 * st) % BN == 0) { step(2 * st, 2 * st + BN / 8); XA_PIN(); }      // the key block of the softmax starts here
+            if (st == 0) { XA_VREAD(1) XA_PIN(); }
             const int t = st >> 1, s2 = st & 1;
             xs16x8_t pb;
 #pragma unroll
@@ -361,7 +364,7 @@ extern "C" int ar_attn_exact_config(int cfg) {
 extern "C" int ar_attn_fwd_exact(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
                                  int64_t kv_rep, float scale, float bias_in, float bias_out, int64_t valid_len, int64_t q_bs, int64_t q_hs,
                                  int64_t q_ts, int64_t k_bs, int64_t k_hs, int64_t k_ts, int64_t v_bs, int64_t v_hs, int64_t v_ts,
-                                 ar_stream_t stream) {
+                                 int64_t key_block, ar_stream_t stream) {
     const int64_t q_strides[3] = {q_bs, q_hs, q_ts}, k_strides[3] = {k_bs, k_hs, k_ts}, v_strides[3] = {v_bs, v_hs, v_ts};
     if ((D != 128 && D != 64) || S % 128 || B <= 0 || H <= 0 || S <= 0 || kv_rep < 1 || H % kv_rep) return AR_ERR_UNSUPPORTED;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return AR_ERR_UNSUPPORTED;
@@ -389,17 +392,32 @@ extern "C" int ar_attn_fwd_exact(const void* Q, const void* K, const void* V, vo
     if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)k_xattn_fwd<4, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
         (void)hipFuncSetAttribute((const void*)k_xattn_fwd<8, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+        (void)hipFuncSetAttribute((const void*)k_xattn_fwd<4, 128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+        (void)hipFuncSetAttribute((const void*)k_xattn_fwd<8, 128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+        (void)hipFuncSetAttribute((const void*)k_xattn_fwd<4, 128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
+        (void)hipFuncSetAttribute((const void*)k_xattn_fwd<8, 128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS128);
     }
     hipStream_t s = (hipStream_t)stream;
     const int form = g_xattn_cfg & 3;
     const bool eight = S % 256 == 0 && (form == 2 || (form == 0 && D == 128));      // measured (profiles/r06_attn_exact_waves_ab.json)
+    if (key_block == 0) key_block = D == 128 ? 64 : 32;       // the library's choice at the tuning minibatch's shape
+    if (key_block != 16 && key_block != 32 && key_block != 64) return AR_ERR_UNSUPPORTED;
+    const int g8 = (int)(B * H * (S / 256)), g4 = (int)(B * H * (S / 128));
+#define XA_LAUNCH(DD, BNN)                                                                                          \
+    do {                                                                                                            \
+        if (eight) hipLaunchKernelGGL((k_xattn_fwd<8, DD, BNN>), g8, 512, DD == 128 ? LDS128 : LDS64, s, a);        \
+        else hipLaunchKernelGGL((k_xattn_fwd<4, DD, BNN>), g4, 256, DD == 128 ? LDS128 : LDS64, s, a);              \
+    } while (0)
     if (D == 128) {
-        if (eight) hipLaunchKernelGGL((k_xattn_fwd<8, 128, 64>), (int)(B * H * (S / 256)), 512, LDS128, s, a);
-        else hipLaunchKernelGGL((k_xattn_fwd<4, 128, 64>), (int)(B * H * (S / 128)), 256, LDS128, s, a);
+        if (key_block == 64) XA_LAUNCH(128, 64);
+        else if (key_block == 32) XA_LAUNCH(128, 32);
+        else XA_LAUNCH(128, 16);
     } else {
-        if (eight) hipLaunchKernelGGL((k_xattn_fwd<8, 64, 32>), (int)(B * H * (S / 256)), 512, LDS64, s, a);
-        else hipLaunchKernelGGL((k_xattn_fwd<4, 64, 32>), (int)(B * H * (S / 128)), 256, LDS64, s, a);
+        if (key_block == 64) XA_LAUNCH(64, 64);
+        else if (key_block == 32) XA_LAUNCH(64, 32);
+        else XA_LAUNCH(64, 16);
     }
+#undef XA_LAUNCH
     return launch_status();
 }
 

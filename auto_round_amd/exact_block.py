@@ -47,7 +47,10 @@ GEMM_OPTS = ("tn_o", "tn_g", "tn_u", "tn_d", "dw_qkv", "dw_gu", "dw_q", "dw_k", 
 # measured at Llama-3-8B's minibatch (profiles/r04_exact_probe.json): the merged forward GEMMs are bit-equal but not faster than
 # the separate ones (0.64 vs 0.62 ms, 2.57 vs 2.46 ms), so the plan does not ask for them unless told to
 DEFAULT_SKIP = ("merged_qkv", "merged_gu")
-FLAG_OPTS = ("swiglu_contract", "norm_rsqrt_f32")
+FLAG_OPTS = ("swiglu_contract", "norm_rsqrt_f32", "attn_kb")
+# attn_kb: the attention forward's key block (keys per online-softmax step: the one tile size of the library's configuration its bits
+# depend on); 0 = the measured guess for the head size and sequence length (ops.attn_key_block_guess), else 16 / 32 / 64 -- the proof
+# tries the guess first, then the others
 
 
 def _bits_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
@@ -65,7 +68,7 @@ def _count_diff(a: torch.Tensor, b: torch.Tensor) -> int:
     return int((a.contiguous().view(it) != b.contiguous().view(it)).sum())
 
 
-def exact_attention_forward(q4, k4, v4, mask, scale, S):
+def exact_attention_forward(q4, k4, v4, mask, scale, S, key_block=0):
     """first-party attention with the library's bits (ops.attn_fwd_exact) when the call is one it takes: the calibration flow's
     structured additive mask, head size 64 / 128, a sequence the backward kernels take too.  -> (q4, k4, v4, out [B, S, H, D], lse,
     mask_struct) or None"""
@@ -74,7 +77,8 @@ def exact_attention_forward(q4, k4, v4, mask, scale, S):
     st = ops.mask_structure(mask, S)
     if st is None:
         return None
-    got = ops.attn_fwd_exact(q4, k4, v4, st, float(scale))
+    kb = int(key_block) or ops.attn_key_block_guess(int(q4.shape[-1]), int(S))
+    got = ops.attn_fwd_exact(q4, k4, v4, st, float(scale), key_block=kb)
     if got is None:
         return None
     return (q4, k4, v4, got[0], got[1], st)
@@ -192,16 +196,23 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 if opt == "attn":
                     if others.get("attention_mask") is None:
                         continue
-                    self._attn_verify, self._attn_diffs = True, {}
-                ok = same(trial)
-                if opt == "attn":
-                    self._attn_verify = False
-                    ok = ok and self._attn_diffs.get("out", -1) == 0
+                    ok = False
+                    guess = ops.attn_key_block_guess(self.hd, int(x.shape[1]))
+                    for kb in [0] + [b for b in (64, 32, 16) if b != guess]:
+                        trial = dict(plan, attn=True, attn_kb=kb)
+                        self._attn_verify, self._attn_diffs = True, {}
+                        ok = same(trial)
+                        self._attn_verify = False
+                        ok = ok and self._attn_diffs.get("out", -1) == 0
+                        if ok:
+                            break
+                else:
+                    ok = same(trial)
                 if ok:
                     plan = trial
                     kept.append(opt)
             self.set_plan(plan)
-            self.plan_report = dict(usable=True, kept=kept, plan={k: bool(v) for k, v in plan.items() if k in KERNEL_OPTS})
+            self.plan_report = dict(usable=True, kept=kept, plan={**{k: bool(v) for k, v in plan.items() if k in KERNEL_OPTS}, "attn_kb": int(plan.get("attn_kb", 0))})
         return plan
 
     # -- plumbing ---------------------------------------------------------------------------------------------------------
@@ -209,7 +220,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
     def base_plan() -> Dict[str, bool]:
         """every segment on torch's own ops, every GEMM as the module path issues it"""
         plan = {k: False for k in KERNEL_OPTS + GEMM_OPTS}
-        plan.update(swiglu_contract=True, norm_rsqrt_f32=False)
+        plan.update(swiglu_contract=True, norm_rsqrt_f32=False, attn_kb=0)
         return plan
 
     def set_plan(self, plan: Dict[str, bool]):
@@ -357,7 +368,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
         from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
         mask = others.get("attention_mask")
-        xa = exact_attention_forward(qr4, kr4, v4, mask, self.attn.scaling, S) if P.get("attn") else None
+        xa = exact_attention_forward(qr4, kr4, v4, mask, self.attn.scaling, S, P.get("attn_kb", 0)) if P.get("attn") else None
         al = ao = None
         if xa is None and mask is not None and getattr(self, "materialise_mask_rows", False) and mask.shape[0] == 1 and B > 1:
             mask = mask.expand(B, *mask.shape[1:]).contiguous()      # (the quantizer handed the shared mask over un-materialised)
@@ -615,6 +626,9 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 variants = [dict(trial, **{opt: n}) for n in (1, 2, 3, 4, STREAMK)]
             if opt == "swiglu":
                 variants.append(dict(trial, swiglu_contract=False))
+            if opt == "attn":       # the library picks its forward configuration by shape: the measured guess first, then the other key blocks
+                guess = ops.attn_key_block_guess(self.hd, int(x.shape[1]))
+                variants = [dict(trial, attn_kb=0)] + [dict(trial, attn_kb=kb) for kb in (64, 32, 16) if kb != guess]
             if opt in ("norm1", "norm2") and not (plan["norm1"] or plan["norm2"]):
                 variants = [tv for tv in (trial, dict(trial, norm_rsqrt_f32=True)) if norm_stats_match(tv["norm_rsqrt_f32"])]
                 if not variants:
@@ -662,5 +676,5 @@ class ExactLlamaBlock(FusedLlamaBlock):
                           f"module path's own form (slower): {report['dropped']} (differing values per tried form)")
         self.set_plan(plan)
         reset()
-        self.plan_report = dict(report, usable=True, plan={k: (int(v) if k.startswith("dw_") else bool(v)) for k, v in plan.items()})
+        self.plan_report = dict(report, usable=True, plan={k: (int(v) if (k.startswith("dw_") or k == "attn_kb") else bool(v)) for k, v in plan.items()})
         return plan

@@ -102,7 +102,7 @@ class ExactOPTBlock(FusedOPTBlock):
     @staticmethod
     def base_plan() -> Dict[str, object]:
         """every segment on torch's own ops (exact by construction)"""
-        return dict(ln1=False, ln2=False, ln_flags=0, attn=False, merged_qkv=False, dw_qkv=False)
+        return dict(ln1=False, ln2=False, ln_flags=0, attn=False, attn_kb=0, merged_qkv=False, dw_qkv=False)
 
     def set_plan(self, plan):
         self.plan = {**self.base_plan(), **plan}
@@ -182,7 +182,7 @@ class ExactOPTBlock(FusedOPTBlock):
             v2d = F.linear(h1_in, L["v"].weight_q, self._bias("v"))
         mask = others.get("attention_mask")
         q4, k4, v4 = (t.view(B, S, hq, hd).transpose(1, 2) for t in (q2d, k2d, v2d))
-        xa = exact_attention_forward(q4, k4, v4, mask, 1.0, S) if P.get("attn") else None
+        xa = exact_attention_forward(q4, k4, v4, mask, 1.0, S, P.get("attn_kb", 0)) if P.get("attn") else None
         al = ao = None
         if xa is None and mask is not None and getattr(self, "materialise_mask_rows", False) and mask.shape[0] == 1 and B > 1:
             mask = mask.expand(B, *mask.shape[1:]).contiguous()      # (the quantizer handed the shared mask over un-materialised)
@@ -384,16 +384,21 @@ class ExactOPTBlock(FusedOPTBlock):
                 report["errors"][opt] = "no form of the LayerNorm kernel reproduces torch's row statistics / output on this stack"
                 report["dropped"][opt] = {"stats": "differ"}
                 continue
-            trial = dict(plan, **{opt: True}) if opt == "attn" else dict(plan, **{opt: True, "ln_flags": flags})
+            trials = [dict(plan, **{opt: True, "ln_flags": flags})]
+            if opt == "attn":       # the library picks its forward configuration by shape: the measured guess first, then the other key blocks
+                guess = ops.attn_key_block_guess(self.hd, int(x.shape[1]))
+                trials = [dict(plan, attn=True, attn_kb=kb) for kb in [0] + [b for b in (64, 32, 16) if b != guess]]
             worst = {}
-            for attempt in (0, 1):
+            for attempt, trial in [(0, t) for t in trials] + [(1, trials[0])]:
+                if opt in report["kept"]:
+                    break
                 if opt == "attn":               # torch's attention runs beside the kernels: outputs and gradients compared directly
                     self._attn_verify, self._attn_diffs = True, {}
                 ok, n_bad = proven(trial)
                 if opt == "attn":
                     self._attn_verify = False
                     direct = dict(self._attn_diffs)
-                    report.setdefault("attn_direct", []).append(direct)
+                    report.setdefault("attn_direct", []).append(dict(direct, attn_kb=trial["attn_kb"]))
                     if set(direct) != {"out", "dq", "dk", "dv"} or any(direct.values()):
                         ok, n_bad = False, (n_bad if n_bad else sum(direct.values()) or -1)
                 if ok:
@@ -404,7 +409,7 @@ class ExactOPTBlock(FusedOPTBlock):
                         warnings.warn(f"exact_rounding: option {opt} differed from the module path in its first pair of runs ({worst}) and "
                                       f"matched in the second pair -- kept; the library under the comparison is not perfectly repeatable")
                     break
-                worst[str(attempt)] = n_bad
+                worst[f"{attempt}:{trial.get('attn_kb', 0)}" if opt == "attn" else str(attempt)] = n_bad
             if opt not in report["kept"]:
                 report["dropped"][opt] = worst
         for opt in [o for o in GEMM_OPTS if want is None or o in want]:
@@ -427,7 +432,7 @@ class ExactOPTBlock(FusedOPTBlock):
                           f"ops (slower): {report['dropped']} (differing values per tried pair)")
         self.set_plan(plan)
         reset()
-        self.plan_report = dict(report, usable=True, plan={k: (int(v) if k == "ln_flags" else bool(v)) for k, v in plan.items()})
+        self.plan_report = dict(report, usable=True, plan={k: (int(v) if k in ("ln_flags", "attn_kb") else bool(v)) for k, v in plan.items()})
         return plan
 
     def plan_forward_against_module(self, module_forward, x, others) -> Optional[dict]:
@@ -452,10 +457,15 @@ class ExactOPTBlock(FusedOPTBlock):
                 if opt == "attn":
                     if others.get("attention_mask") is None:
                         continue
-                    trial = dict(plan, attn=True)
-                    self._attn_verify, self._attn_diffs = True, {}
-                    ok = same(trial) and same(trial) and self._attn_diffs.get("out", -1) == 0
-                    self._attn_verify = False
+                    ok = False
+                    guess = ops.attn_key_block_guess(self.hd, int(x.shape[1]))
+                    for kb in [0] + [b for b in (64, 32, 16) if b != guess]:
+                        trial = dict(plan, attn=True, attn_kb=kb)
+                        self._attn_verify, self._attn_diffs = True, {}
+                        ok = same(trial) and same(trial) and self._attn_diffs.get("out", -1) == 0
+                        self._attn_verify = False
+                        if ok:
+                            break
                 elif flags is not None:
                     trial = dict(plan, **{opt: True, "ln_flags": flags})
                     ok = same(trial) and same(trial)
@@ -465,5 +475,5 @@ class ExactOPTBlock(FusedOPTBlock):
                     plan = trial
                     kept.append(opt)
             self.set_plan(plan)
-            self.plan_report = dict(usable=True, kept=kept, plan={k: (int(v) if k == "ln_flags" else bool(v)) for k, v in plan.items()})
+            self.plan_report = dict(usable=True, kept=kept, plan={k: (int(v) if k in ("ln_flags", "attn_kb") else bool(v)) for k, v in plan.items()})
         return plan

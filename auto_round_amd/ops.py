@@ -680,12 +680,22 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, seq:
     return out, lse
 
 
-def attn_fwd_exact(q4: torch.Tensor, k4: torch.Tensor, v4: torch.Tensor, mask_struct, scale: float):
+def attn_key_block_guess(head_dim: int, seq: int) -> int:
+    """The key block (keys per online-softmax step) of the configuration the library's attention forward uses for a problem, as
+    measured on torch 2.10.0+rocm7.0 / AOTriton 0.11.1 (profiles/r06_attn_exact_keyblock_probe.json: it depends on the head size and
+    the sequence length only) -- the first candidate of a caller's proof, never trusted by itself."""
+    if head_dim == 128:
+        return 32 if seq <= 512 else 64
+    return 64 if (seq <= 512 or seq > 2048) else 32
+
+
+def attn_fwd_exact(q4: torch.Tensor, k4: torch.Tensor, v4: torch.Tensor, mask_struct, scale: float, key_block: int = 0):
     """The attention forward with the LIBRARY'S bits (ar_attn_fwd_exact, csrc/ar_attn_exact.hip): what
     `F.scaled_dot_product_attention(q4, repeat_kv(k4), repeat_kv(v4), attn_mask=<the structured 0 / 1 mask>, scale=scale)` returns on
     this stack, value for value -- callers PROVE that per call signature before relying on it (exact_block.plan_against_module).
     q4 [B, H, S, D], k4 / v4 [B, H / kv_rep, S, D]: bf16 views with unit stride along D (token-major or head-major).
-    mask_struct = (bias_in, bias_out, valid_len) from `mask_structure`.  -> (out [B, S, H, D] contiguous, lse [B, H, S] fp32), or
+    mask_struct = (bias_in, bias_out, valid_len) from `mask_structure`.  key_block: keys per online-softmax step (0 = the tuning
+    minibatch's; 16 / 32 / 64: the library's other configurations, see the header).  -> (out [B, S, H, D] contiguous, lse [B, H, S] fp32), or
     None when the kernel does not take the call (the caller keeps torch's SDPA)."""
     if mask_struct is None or q4.dim() != 4 or q4.dtype != torch.bfloat16 or k4.dtype != q4.dtype or v4.dtype != q4.dtype:
         return None
@@ -710,7 +720,7 @@ def attn_fwd_exact(q4: torch.Tensor, k4: torch.Tensor, v4: torch.Tensor, mask_st
         rc = load().ar_attn_fwd_exact(q4.data_ptr(), k4.data_ptr(), v4.data_ptr(), out.data_ptr(), lse.data_ptr(), B, S, H, D, H // hk,
                                       float(scale), float(b_in), float(b_out), int(valid), q4.stride(0), q4.stride(1), q4.stride(2),
                                       k4.stride(0), k4.stride(1), k4.stride(2), v4.stride(0), v4.stride(1), v4.stride(2),
-                                      torch.cuda.current_stream(dev).cuda_stream)
+                                      int(key_block), torch.cuda.current_stream(dev).cuda_stream)
     if rc == _lib.AR_ERR_UNSUPPORTED:
         return None
     check(rc, "ar_attn_fwd_exact")

@@ -34,7 +34,7 @@ enum { AR_DT_BF16 = 0, AR_DT_F16 = 1, AR_DT_F32 = 2 };
 enum { AR_OK = 0, AR_ERR_UNSUPPORTED = -1 };
 
 /* ABI version of this header; bump on any signature change.  ar_abi_version() of the loaded library must equal it. */
-#define AR_ABI_VERSION 26
+#define AR_ABI_VERSION 27
 int ar_abi_version(void);
 /* Human-readable text for a non-zero return code of any function below. */
 const char* ar_error_string(int code);
@@ -468,11 +468,15 @@ int ar_attn_fwd_masked(const void* Q, const void* K, const void* V, void* O, flo
  *           Q / K / V bf16 with element strides (batch, head, token; unit stride along D): any of [B, S, H, D] / [B, H, S, D] views;
  *           K / V hold H / kv_rep heads (query head h reads key head h / kv_rep: transformers' repeat_kv only copies).  O is written
  *           token-major contiguous [B, S, H, D]; LSE [B, H, S] fp32 (natural log).  bias_in / bias_out / valid_len: ar_attn_fwd_masked's
- *           structured mask; both values must be bf16 numbers.  D in {64, 128}, S % 128 == 0; anything else AR_ERR_UNSUPPORTED. */
+ *           structured mask; both values must be bf16 numbers.  key_block: the keys per online-softmax step -- the one tile size of the
+ *           library's configuration the bits depend on (it picks the configuration by sequence length and head size): 0 = the tuning
+ *           minibatch's (64 at head size 128, 32 at 64; what the library uses for S = 1024 .. 2048, at head size 128 also 4096), or 16 /
+ *           32 / 64 (callers try them in their proof: auto_round_amd/exact_block.py).  D in {64, 128}, S % 128 == 0; anything else
+ *           AR_ERR_UNSUPPORTED. */
 int ar_attn_fwd_exact(const void* Q, const void* K, const void* V, void* O, float* LSE, int64_t B, int64_t S, int64_t H, int64_t D,
                       int64_t kv_rep, float scale, float bias_in, float bias_out, int64_t valid_len, int64_t q_bs, int64_t q_hs,
                       int64_t q_ts, int64_t k_bs, int64_t k_hs, int64_t k_ts, int64_t v_bs, int64_t v_hs, int64_t v_ts,
-                      ar_stream_t stream);
+                      int64_t key_block, ar_stream_t stream);
 
 /* The matching BACKWARD with the library's bits: what aten::_scaled_dot_product_efficient_attention_backward returns for the same call
  * on this stack (AOTriton 0.11.1 bwd_preprocess + bwd_kernel_dk_dv + bwd_kernel_dq with an additive bias; autograd of the call

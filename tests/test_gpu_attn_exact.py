@@ -14,7 +14,12 @@ SHAPES = [pytest.param(8, 32, 2048, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-mini
           pytest.param(8, 64, 2048, 128, 8, 128 ** -0.5, 1.0, id="llama3-70b-minibatch"),
           pytest.param(4, 32, 2048, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-batch4"),
           pytest.param(8, 32, 1024, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-seq1024"),
-          pytest.param(8, 32, 4096, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-seq4096")]
+          pytest.param(8, 32, 4096, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-seq4096"),
+          # other sequence lengths: the library's forward uses another key block there (ops.attn_key_block_guess)
+          pytest.param(4, 32, 512, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-seq512-keyblock32"),
+          pytest.param(4, 12, 512, 64, 12, 1.0, 0.35, id="opt-125m-seq512-keyblock64"),
+          pytest.param(2, 12, 4096, 64, 12, 1.0, 0.35, id="opt-125m-seq4096-keyblock64"),
+          pytest.param(4, 16, 768, 64, 16, 1.0, 0.35, id="head64-seq768-keyblock32")]
 
 
 def _case(B, H, S, D, hk, std, seed=0, valid=None):
@@ -54,7 +59,7 @@ def test_forward_and_backward_have_the_librarys_bits(B, H, S, D, hk, scale, std)
     with torch.no_grad():
         lse_ref = torch.ops.aten._scaled_dot_product_efficient_attention(q, ke.detach(), ve.detach(), mask.expand(B, H, S, S), True, 0.0, False,
                                                                          scale=scale)[1]
-        got = ops.attn_fwd_exact(q, k, v, st, scale)
+        got = ops.attn_fwd_exact(q, k, v, st, scale, key_block=ops.attn_key_block_guess(D, S))
         assert got is not None
         mo, mlse = got
         assert _ndiff(mo, ao.detach()) == 0                      # bit for bit: 67 M values at Llama-3-8B's minibatch

@@ -195,6 +195,21 @@ def test_exact_block_is_proven_against_the_module_path_and_tunes_to_identical_pa
             assert torch.equal(a, b), n
 
 
+def test_attention_joins_the_plan_at_a_sequence_length_where_the_library_uses_another_key_block():
+    """seq 512 at head size 128: the library's forward runs 32-key blocks there (64 at the tuning minibatch's 2048) -- the proof finds the
+    key block (`attn_kb`: 0 = the measured guess matched) and the attention runs first-party; packed weights equal the module path's"""
+    model, tokens = _small_llama(seq=512, nsamples=16)
+    q_mod, packed_mod = _tune(model, tokens, exact=False, with_mask=True, iters=6)
+    q_ex, packed_ex = _tune(model, tokens, exact=True, with_mask=True, iters=6)
+    rep = q_ex.last_exact_report
+    assert q_ex.last_exact and rep["usable"] and rep["plan"]["attn"], rep
+    assert rep["attn_direct"][-1] == {"out": 0, "dq": 0, "dk": 0, "dv": 0}, rep
+    assert q_ex.last_stats["loss_trace"] == q_mod.last_stats["loss_trace"]
+    for n in packed_mod:
+        for a, b in zip(packed_ex[n], packed_mod[n]):
+            assert torch.equal(a, b), n
+
+
 def test_exact_plan_is_reused_for_later_blocks_of_the_same_kind_and_refused_for_unsupported_ones():
     from auto_round_amd.exact_block import ExactLlamaBlock
     from auto_round_amd.quantizer import SignRoundConfig, SignRoundQuantizer
