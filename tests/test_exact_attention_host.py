@@ -62,3 +62,23 @@ def test_registration_name_and_restore():
     A.exact_state["materialise"] = True
     qz._restore_module_attention()
     assert cfg_obj._attn_implementation == "sdpa" and not qz._attn_restore and A.exact_state["materialise"] is False
+
+
+def test_key_block_table_is_the_measured_one():
+    """ops.attn_key_block_guess: the forward key block per (head size, sequence length) measured against torch
+    (profiles/r06_attn_exact_keyblock_probe.json) -- only ever a proof's first candidate"""
+    import json
+    import os
+
+    from auto_round_amd import ops
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_attn_exact_keyblock_probe.json")
+    rows = json.load(open(path))
+    checked = 0
+    for r in rows:
+        exact = [kb for kb in (16, 32, 64) if r.get(f"kb{kb}") == [0, 0]]
+        if not exact:
+            continue                      # head size 128 at S <= 256: no key block reproduces the library there
+        assert ops.attn_key_block_guess(r["D"], r["S"]) in exact, r
+        checked += 1
+    assert checked >= 12
