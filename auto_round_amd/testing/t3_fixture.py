@@ -513,6 +513,7 @@ def check_against_stat_fixture(path: str, fused: bool = False, exact: bool = Fal
     tr = r["loss_trace"] or []
     rvr = m["ref_vs_ref"]
     return dict(case=os.path.basename(path), fused_block=r["fused_block"], exact_block=r["exact_block"], hip_graph=r["hip_graph"],
+                exact_plan=(r["exact_report"] or {}).get("plan"),
                 inputs_identical=(r["x_sha"] == m["x_sha"]), targets_identical=(r["y_sha"] == m["y_sha"]), same_layer_set=sorted(mine) == sorted(m["layers"]),
                 prefix_identical_weights=same / max(tot, 1), prefix_identical_scales=ssame / max(stot, 1), prefix_values=tot,
                 prefix_identical_codes=(csame / ctot) if ctot else same / max(tot, 1),

@@ -163,7 +163,8 @@ def test_llama8b_block_at_the_full_recipe_is_bit_identical_to_the_reference_dige
 
 def test_llama8b_block_on_the_exact_rounding_path_is_bit_identical_to_the_reference_digest(record_property):
     """The same digest on `exact_rounding` (auto_round_amd/exact_block.py): the block through csrc/ar_exact.hip (eager torch's rounding
-    points and reduction order), the GEMM forms proven bit-equal on this stack, the library attention -- the path bench.py's headline
+    points and reduction order), the GEMM forms proven bit-equal on this stack, the attention on csrc/ar_attn_exact.hip (round 6: the
+    library attention's arithmetic restated, proven against torch's own inside the block) -- the path bench.py's headline
     is measured on.  Every packed tensor must hash to the reference's, and the proven plan must really contain first-party kernels."""
     from auto_round_amd.testing import t3_fixture as fx
 
@@ -174,6 +175,8 @@ def test_llama8b_block_on_the_exact_rounding_path_is_bit_identical_to_the_refere
     assert r["exact_block"] and r["inputs_identical"] and r["targets_identical"], r
     plan = r["exact_plan"] or {}
     assert plan.get("rope") and plan.get("swiglu") and plan.get("norm1") and plan.get("norm2"), plan      # the elementwise kernels are in use
+    if same_stack:      # round 6: the attention too (csrc/ar_attn_exact.hip restates THIS library build's kernels; another build drops it)
+        assert plan.get("attn"), plan
     _check_digest(r, same_stack, "exact_rounding path")
     _account(r)
 
@@ -362,6 +365,10 @@ def test_opt125m_on_exact_rounding_reproduces_reference_run_1(record_property):
     chk = lambda: fx.check_against_stat_fixture(path, exact=True)  # noqa: E731
     r = _run_with_one_retry(chk, record_property, "opt125m exact_rounding", max_runs=5)
     assert r["exact_block"] and r["inputs_identical"] and r["targets_identical"], _full(r)
+    plan = r.get("exact_plan") or {}
+    assert plan.get("ln1") and plan.get("ln2"), plan
+    if _digest_stack()[0]:      # round 6 (this library build): first-party attention, q / k / v as one forward and one weight-gradient GEMM
+        assert plan.get("attn") and plan.get("merged_qkv") and plan.get("dw_qkv"), plan
     if r["bit_identical"]:
         assert r["first_divergence_iter"] is None and abs(r["best_loss_ratio"] - 1.0) < 1e-5, _full(r)
     else:       # five runs in a row hit by the library's attention race (p ~ 0.45^5): held to the floor instead, loudly
