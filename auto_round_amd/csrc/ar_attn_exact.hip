@@ -17,14 +17,16 @@
 //     csrc/ar_attn.hip's product, which is why this kernel is that kernel with other arithmetic around the MFMAs;
 //   * x = fl(s * qk_scale) + bias2, two roundings; qk_scale = fl(sm_scale * fl32(log2 e)) computed in fp32;
 //     bias2 = bf16(bias * bf16(log2 e)) -- the bias is scaled in ITS OWN type, bf16 (log2 e -> 1.4453125);
-//   * online softmax per KEY BLOCK of BN keys -- 32 at head size 64 (BLOCK_M 64, BLOCK_N 32, 2 waves), 64 at head size 128
-//     (BLOCK_M 128, BLOCK_N 64, 4 waves): m' = max(m, max x); p = exp2(x - m') as v_sub + v_exp_f32; alpha = exp2(m - m');
-//     acc = acc * alpha; l = fma(l, alpha, l_blk);
+//   * online softmax per KEY BLOCK of BN keys -- at the tuning minibatch (S = 2048) 32 at head size 64 (BLOCK_M 64, BLOCK_N 32, 2 waves)
+//     and 64 at head size 128 (BLOCK_M 128, BLOCK_N 64, 4 waves); the library picks the configuration by head size and sequence length,
+//     and BN is the only number of it that reaches the bits, so it is a launch parameter (`key_block`: 16 / 32 / 64; measured table:
+//     ops.attn_key_block_guess, profiles/r06_attn_exact_keyblock_probe.json) -- m' = max(m, max x); p = exp2(x - m') as v_sub +
+//     v_exp_f32; alpha = exp2(m - m'); acc = acc * alpha; l = fma(l, alpha, l_blk);
 //   * l_blk, the block's row sum, is NOT summed in the MFMA accumulator layout: the library converts p to the bias tile's load layout
 //     (8 consecutive keys per lane, BN / 8 neighbouring lanes per query row) and reduces there -- 8 keys in ascending order within
 //     a lane, then the lanes pairwise over lane-xor 4, 2, 1 (head size 64: 2, 1):
 //         s_g = ((((((p[8g] + p[8g+1]) + p[8g+2]) + p[8g+3]) + p[8g+4]) + p[8g+5]) + p[8g+6]) + p[8g+7]
-//         BN = 32:  l_blk = (s0 + s2) + (s1 + s3)        BN = 64:  l_blk = ((s0 + s4) + (s2 + s6)) + ((s1 + s5) + (s3 + s7))
+//         BN = 16:  l_blk = s0 + s1      BN = 32:  l_blk = (s0 + s2) + (s1 + s3)      BN = 64:  l_blk = ((s0 + s4) + (s2 + s6)) + ((s1 + s5) + (s3 + s7))
 //     Here p stays in the accumulator layout (lane half h of a query holds keys 8 j + 4 h + i): lane half 0 sums its four keys of
 //     every group, hands the partial to lane half 1 (v_permlane32_swap), which continues the chain with its own four -- the same
 //     additions in the same order, one cross-lane move per 8 keys;
