@@ -386,6 +386,8 @@ class SignRoundQuantizer:
         self._exact_plans: Dict[Any, Any] = {}           # (block signature, minibatch shape) -> proven exact_rounding plan | False
         self._modattn_verdict: Dict[Any, Any] = {}       # module-path attention on the first-party kernels: proven? (exact_attention)
         self._attn_restore: list = []                    # (config object, its _attn_implementation) to put back after the block
+        self.last_module_exact_attention = False
+        self.last_module_attention_report: Optional[dict] = None
         self.last_exact = False
         self.last_exact_report: Optional[dict] = None
         self._graph_stream = None
