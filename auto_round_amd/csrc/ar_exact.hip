@@ -58,7 +58,7 @@ __device__ __forceinline__ float torch_rowsum(int l32, int nch, int Y, ChunkFn&&
 // >= 100 CUs: 1 / 8 thread-rows per row, or -1 where another code path would run (short rows: no vectorised loads; fewer than 8
 // rows: a wider thread-row; see setReduceConfig)
 static inline int torch_reduce_split(int64_t rows, int hidden) {
-    if (hidden < 256 || hidden % kEPT || rows < 8 || (int64_t)hidden * rows > 0x1fffffffLL) return -1;
+    if (hidden < 128 || hidden % kEPT || rows < 8 || (int64_t)hidden * rows > 0x1fffffffLL) return -1;
     const int values_per_thread = (hidden + 63) / 64;
     if (values_per_thread < 128) return 1;
     if ((hidden + 511) / 512 >= 256) return -1;       // would also split over thread blocks

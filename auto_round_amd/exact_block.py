@@ -35,7 +35,7 @@ from .fused_block import LLAMA_FAMILY, FusedLlamaBlock, _FusedBlockFn, _class_in
 
 # segments that have a first-party kernel form (False = torch's own ops in a local autograd graph)
 STREAMK = -1        # plan value of a dw_* option: the library kernel's stream-K summation structure
-KERNEL_OPTS = ("norm1", "norm2", "rope", "swiglu", "attn")
+KERNEL_OPTS = ("norm1", "norm2", "qknorm", "rope", "swiglu", "attn")
 # "attn": the attention forward + backward on csrc/ar_attn_exact.hip (the library attention's arithmetic restated from the code objects
 # torch ships) instead of torch's SDPA -- held to torch's attention output and q / k / v gradients DIRECTLY on the probe minibatches
 # (`_attn_diffs`), not only through the block output
@@ -116,7 +116,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
         if not _class_in(block, LLAMA_FAMILY):
             return None
         self = super().try_build(block, arenas, input_others, amp_dtype, sdpa_ctx=sdpa_ctx, use_mfma_dw=False, tn_dx_gemm=False)
-        if self is None or self.qk_norm is not None:
+        if self is None or not cls._qk_norm_ok(self):
             return None
         attn = self.attn
         if getattr(getattr(attn, "config", None), "_attn_implementation", None) != "sdpa":
@@ -146,7 +146,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
         if not _class_in(block, LLAMA_FAMILY):
             return None
         self = super().try_build_plain(block, input_others, amp_dtype, sdpa_ctx=sdpa_ctx)
-        if self is None or self.qk_norm is not None:
+        if self is None or not cls._qk_norm_ok(self):
             return None
         attn, mlp = self.attn, block.mlp
         if getattr(getattr(attn, "config", None), "_attn_implementation", None) != "sdpa":
@@ -167,6 +167,17 @@ class ExactLlamaBlock(FusedLlamaBlock):
         self._attn_verify = False
         self._attn_diffs = {}
         return self
+
+    @staticmethod
+    def _qk_norm_ok(self) -> bool:
+        """Qwen3-style per-head q_norm / k_norm (round 6): taken when both are plain RMSNorms over the head dimension with weights in the
+        activation dtype -- they run as torch's own modules in a local autograd graph, or (option `qknorm`) on the RMSNorm kernels of
+        csrc/ar_exact.hip with rows = tokens x heads (ATen reduces a 128-value row as it does a longer one: checked against torch,
+        tools/gpu/r06_headnorm_probe.py)."""
+        if self.qk_norm is None:
+            return True
+        wq, wk, _ = self.qk_norm
+        return wq.dtype == self.dtype and wk.dtype == self.dtype and self.hd >= 128 and self.hd % 8 == 0
 
     def plan_forward_against_module(self, module_forward, x, others) -> Optional[dict]:
         """Forward-only proof for the no-grad form: the module code's output on one real minibatch against this class's, first with every
@@ -190,7 +201,9 @@ class ExactLlamaBlock(FusedLlamaBlock):
             stats_ok = res is not None and _bits_equal(res[1], torch.rsqrt(x2d.float().pow(2).mean(-1, keepdim=True) + self.eps1).view(-1))
             kept = []
             for opt in KERNEL_OPTS:
-                if opt in ("norm1", "norm2") and not stats_ok:
+                if opt in ("norm1", "norm2", "qknorm") and not stats_ok:
+                    continue
+                if opt == "qknorm" and self.qk_norm is None:
                     continue
                 trial = dict(plan, **{opt: True})
                 if opt == "attn":
@@ -345,6 +358,26 @@ class ExactLlamaBlock(FusedLlamaBlock):
             q2d, k2d, v2d = qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:]
         else:
             q2d, k2d, v2d = (F.linear(h1_in, L[n].weight_q, self._bias(n)) for n in "qkv")
+        # Qwen3: RMSNorm of every query / key head before the rotation
+        qkn = None
+        if self.qk_norm is not None:
+            wq_n, wk_n, eps_qk = self.qk_norm
+            done = None
+            if P.get("qknorm"):
+                rq = ops.rmsnorm_fwd_exact(q2d.reshape(T * hq, hd), wq_n, eps_qk, rsqrt_f32=P["norm_rsqrt_f32"])
+                rk = ops.rmsnorm_fwd_exact(k2d.reshape(T * hkv, hd), wk_n, eps_qk, rsqrt_f32=P["norm_rsqrt_f32"])
+                if rq is not None and rk is not None:
+                    done = ("k", rq[2], rq[1], rk[2], rk[1])          # (raw rows, rstd) of q and k for the backward
+                    q2d, k2d = rq[0].view(T, hq * hd), rk[0].view(T, hkv * hd)
+            if done is None:
+                with torch.enable_grad() if grad else contextlib.nullcontext():
+                    ql_n = q2d.reshape(B, S, hq, hd).detach().requires_grad_(grad)
+                    kl_n = k2d.reshape(B, S, hkv, hd).detach().requires_grad_(grad)
+                    with self._ctx(S):
+                        qn_g, kn_g = self.attn.q_norm(ql_n), self.attn.k_norm(kl_n)
+                done = ("g", ql_n, kl_n, qn_g, kn_g)
+                q2d, k2d = qn_g.detach().reshape(T, hq * hd), kn_g.detach().reshape(T, hkv * hd)
+            qkn = done
         # rotary embedding
         cos, sin = self._cos_sin(others, B, S)
         rope_graph = None
@@ -422,7 +455,7 @@ class ExactLlamaBlock(FusedLlamaBlock):
         d_out = F.linear(act_in, L["d"].weight_q, self._bias("d"))
         y = x2 + d_out
         if grad:
-            sv.update(B=B, S=S, h1_in=h1_in, cos=cos, sin=sin, rope_graph=rope_graph, attn_leaves=al, attn_out=ao, attn_x=xa, a2d=a2d, a_in=a_in,
+            sv.update(B=B, S=S, h1_in=h1_in, cos=cos, sin=sin, rope_graph=rope_graph, qkn=qkn, attn_leaves=al, attn_out=ao, attn_x=xa, a2d=a2d, a_in=a_in,
                       x2=x2, rstd2=rstd2, norm_graph=norm_graph, h2=h2, h2_in=h2_in, g2d=g2d, u2d=u2d, act_graph=act_graph, act=act,
                       act_in=act_in)
             ctx.saved = sv
@@ -511,6 +544,23 @@ class ExactLlamaBlock(FusedLlamaBlock):
                 dq2d = dq4.transpose(1, 2).reshape(T, nq)
                 dk2d = dk4.transpose(1, 2).reshape(T, nk)
         h1_in = s.pop("h1_in")
+        qkn = s.pop("qkn", None)
+        if qkn is not None:          # gradient through the per-head norms (their weights are frozen): rows = tokens x heads
+            dqn = (slices[0] if slices is not None else dq2d).reshape(T * hq, hd)
+            dkn = (slices[1] if slices is not None else dk2d).reshape(T * hkv, hd)
+            if qkn[0] == "k":
+                wq_n, wk_n, _ = self.qk_norm
+                dq_raw = ops.rmsnorm_bwd_exact(dqn.contiguous(), qkn[1], wq_n, qkn[2]).view(T, nq)
+                dk_raw = ops.rmsnorm_bwd_exact(dkn.contiguous(), qkn[3], wk_n, qkn[4]).view(T, nk)
+            else:
+                _, ql_n, kl_n, qn_g, kn_g = qkn
+                gq_n, gk_n = torch.autograd.grad((qn_g, kn_g), (ql_n, kl_n), (dqn.view(B, S, hq, hd), dkn.view(B, S, hkv, hd)))
+                dq_raw, dk_raw = gq_n.reshape(T, nq), gk_n.reshape(T, nk)
+            if slices is not None:
+                slices[0].copy_(dq_raw)
+                slices[1].copy_(dk_raw)
+            else:
+                dq2d, dk2d = dq_raw, dk_raw
         if dqkv is not None:
             dqkv[:, nq + nk:].view(B, S, hkv, hd).copy_(gv4.transpose(1, 2))
             self._dw_x("qkv", dqkv, h1_in)
@@ -635,6 +685,10 @@ class ExactLlamaBlock(FusedLlamaBlock):
                     report["errors"][opt] = "row statistics differ from torch's (rsqrt / reduction order)"
             if opt == "attn" and others.get("attention_mask") is None:
                 report["skipped"][opt] = "no additive attention mask: the call is not the one the kernel restates"
+                continue
+            if opt == "qknorm" and (self.qk_norm is None or not (plan["norm1"] or plan["norm2"])):
+                if self.qk_norm is not None:
+                    report["skipped"][opt] = "the RMSNorm kernels did not reproduce torch's row statistics on this stack"
                 continue
             report["tried"].append(opt)
             worst = {}

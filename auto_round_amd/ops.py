@@ -534,7 +534,7 @@ def rmsnorm_fwd_exact(x2d, weight, eps, res=None, rsqrt_f32=False, raw_sum=False
     -> (y, rstd [rows] fp32, s or x2d); None when ATen would take a code path the kernel does not mirror (rows < 8, hidden < 256).
     rsqrt_f32: the float rsqrt instruction instead of torch-on-ROCm's double evaluation; raw_sum (probes): `rstd` holds the row sums."""
     rows, H = x2d.shape
-    if rows < 8 or H < 256 or H % 8 or weight.dtype != x2d.dtype or rows * H > 0x1fffffff:
+    if rows < 8 or H < 128 or H % 8 or weight.dtype != x2d.dtype or rows * H > 0x1fffffff:
         return None
     y = torch.empty_like(x2d)
     s = torch.empty_like(x2d) if res is not None else None

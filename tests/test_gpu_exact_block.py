@@ -23,7 +23,8 @@ def gen(seed=0):
 
 
 # (rows, hidden): short rows, a non-power-of-two row (Qwen2-7B), Llama-3-8B's minibatch, rows ATen splits over 8 thread-rows (70B)
-@pytest.mark.parametrize("T,H", [(64, 256), (128, 768), (2048, 3584), (16384, 4096), (4096, 8192), (512, 8320)])
+# ... and 128-value rows (round 6: Qwen3's per-head q / k norms, rows = tokens x heads)
+@pytest.mark.parametrize("T,H", [(64, 256), (128, 768), (2048, 3584), (16384, 4096), (4096, 8192), (512, 8320), (16384 * 8, 128), (4096, 128)])
 def test_rmsnorm_forward_and_backward_have_eager_torchs_bits(T, H):
     from transformers.models.llama.modeling_llama import LlamaRMSNorm
 
@@ -56,8 +57,8 @@ def test_rmsnorm_forward_and_backward_have_eager_torchs_bits(T, H):
 def test_rmsnorm_exact_refuses_what_it_does_not_mirror():
     from auto_round_amd import ops
 
-    w = torch.ones(128, dtype=BF, device=DEV)
-    assert ops.rmsnorm_fwd_exact(torch.zeros(64, 128, dtype=BF, device=DEV), w, 1e-5) is None            # short rows: another ATen path
+    w = torch.ones(64, dtype=BF, device=DEV)
+    assert ops.rmsnorm_fwd_exact(torch.zeros(64, 64, dtype=BF, device=DEV), w, 1e-5) is None             # short rows: another ATen path
     w = torch.ones(512, dtype=BF, device=DEV)
     assert ops.rmsnorm_fwd_exact(torch.zeros(4, 512, dtype=BF, device=DEV), w, 1e-5) is None             # < 8 rows: a wider thread row
 
@@ -204,6 +205,35 @@ def test_attention_joins_the_plan_at_a_sequence_length_where_the_library_uses_an
     rep = q_ex.last_exact_report
     assert q_ex.last_exact and rep["usable"] and rep["plan"]["attn"], rep
     assert rep["attn_direct"][-1] == {"out": 0, "dq": 0, "dk": 0, "dv": 0}, rep
+    assert q_ex.last_stats["loss_trace"] == q_mod.last_stats["loss_trace"]
+    for n in packed_mod:
+        for a, b in zip(packed_ex[n], packed_mod[n]):
+            assert torch.equal(a, b), n
+
+
+def test_qwen3_block_with_per_head_norms_runs_on_the_exact_path():
+    """Qwen3 (round 6): q_norm / k_norm over every 128-value head run on the RMSNorm kernels with rows = tokens x heads (option
+    `qknorm`; ATen reduces a 128-value row as it does a longer one: tools/gpu/r06_headnorm_probe.py) -- the block is proven against the
+    module code like a Llama block and tunes to the module path's packed weights"""
+    from transformers import Qwen3Config, Qwen3ForCausalLM
+
+    torch.manual_seed(0)
+    cfg = Qwen3Config(hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=2, head_dim=128,
+                      num_hidden_layers=1, vocab_size=512, max_position_embeddings=1024, tie_word_embeddings=False)
+    cfg._attn_implementation = "sdpa"
+    model = Qwen3ForCausalLM(cfg).to(BF).eval().to(DEV)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    with torch.no_grad():       # (non-trivial norm weights)
+        for m in model.modules():
+            if type(m).__name__ == "Qwen3RMSNorm" and m.weight.numel() == 128:
+                m.weight.copy_((1 + 0.1 * torch.randn(128, device=DEV)).to(BF))
+    tokens = torch.randint(0, 512, (16, 512), generator=torch.Generator().manual_seed(1))
+    q_mod, packed_mod = _tune(model, tokens, exact=False, with_mask=True, iters=6)
+    q_ex, packed_ex = _tune(model, tokens, exact=True, with_mask=True, iters=6)
+    rep = q_ex.last_exact_report
+    assert q_ex.last_exact and rep["usable"], rep
+    assert rep["plan"]["qknorm"] and rep["plan"]["norm1"] and rep["plan"]["rope"] and rep["plan"]["attn"], rep
     assert q_ex.last_stats["loss_trace"] == q_mod.last_stats["loss_trace"]
     for n in packed_mod:
         for a, b in zip(packed_ex[n], packed_mod[n]):

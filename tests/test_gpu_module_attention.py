@@ -1,4 +1,5 @@
-"""`exact_attention` (round 6): a block that has NO exact form (Qwen3: per-head q / k norms) is tuned on the module path with its
+"""`exact_attention` (round 6): a block that has NO exact form (Qwen3 at head size 64: per-head q / k norms over 64-value rows, which the
+exact RMSNorm kernels do not restate) is tuned on the module path with its
 attention on csrc/ar_attn_exact.hip -- installed through transformers' AttentionInterface only after the quantizer proved, on two
 real minibatches, that block output, weight gradients and every attention call's output / q, k, v gradients equal the stock module
 path's (reference: auto_round/compressors/utils.py:109-172 `block_forward` around the model's own attention,
@@ -12,7 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV, BF = "cuda", torch.bfloat16
 
 
-def _qwen3(hidden=4096, inter=1024, heads=32, kv=8, head_dim=128, seq=2048, nsamples=16, seed=0):
+def _qwen3(hidden=768, inter=1024, heads=12, kv=4, head_dim=64, seq=2048, nsamples=16, seed=0):
     from transformers import Qwen3Config, Qwen3ForCausalLM
 
     torch.manual_seed(seed)
@@ -69,10 +70,13 @@ def test_module_path_block_runs_its_attention_first_party_after_the_proof_and_tu
             assert torch.equal(a, b), n
 
 
-def test_a_shape_the_kernels_do_not_restate_keeps_the_stock_attention():
-    """seq 256 at 4 heads: the library picks another kernel configuration there -- the proof fails and nothing is installed"""
-    model, tokens = _qwen3(hidden=512, heads=4, kv=2, seq=256)
+def test_a_call_the_kernels_do_not_take_keeps_the_stock_attention():
+    """seq 128: the backward kernels take S % 256 == 0 only -- every call falls through to transformers' own attention, the proof says so
+    and nothing is installed"""
+    model, tokens = _qwen3(seq=128)
     with pytest.warns(UserWarning, match="exact_attention"):
         q, _, impl = _tune(model, tokens, exact_attention=True, iters=2)
+    assert not q.last_exact
     assert not q.last_module_exact_attention and not q.last_module_attention_report["usable"]
+    assert q.last_module_attention_report["calls"] == 0 and q.last_module_attention_report["fallbacks"] > 0
     assert impl == {"sdpa"}
