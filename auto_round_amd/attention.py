@@ -273,7 +273,7 @@ class _ExactAttnFn(torch.autograd.Function):
 def exact_sdpa_attention(module, query, key, value, attention_mask=None, dropout=0.0, scaling=None, is_causal=None, **kwargs):
     """transformers attention function (AttentionInterface) for the MODULE PATH: the call `sdpa_attention_forward` would hand to
     torch's SDPA runs on ar_attn_fwd_exact / ar_attn_bwd_exact when it is one those kernels restate (the calibration flow's structured
-    additive mask, head size 64 / 128, S % 256 == 0, no dropout) -- the library's bits, proven per block by the quantizer before this
+    additive mask, head size 64 / 128, S % 128 == 0, no dropout) -- the library's bits, proven per block by the quantizer before this
     function is installed -- and on `sdpa_attention_forward` itself for anything else."""
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
@@ -282,7 +282,7 @@ def exact_sdpa_attention(module, query, key, value, attention_mask=None, dropout
     B, H, S, D = query.shape
     st = None
     if (not dropout and attention_mask is not None and query.is_cuda and query.dtype == torch.bfloat16 and key.dtype == query.dtype
-            and value.dtype == query.dtype and D in (64, 128) and S % 256 == 0 and S <= 4096 and key.shape[2] == S
+            and value.dtype == query.dtype and D in (64, 128) and S % 128 == 0 and S <= 4096 and key.shape[2] == S
             and kwargs.get("position_bias") is None and not kwargs.get("output_attentions", False)
             and all(t.stride(3) == 1 and not any(x % 8 for x in t.stride()[:3]) and t.data_ptr() % 16 == 0 for t in (query, key, value))):
         st = ops.mask_structure(attention_mask, S)

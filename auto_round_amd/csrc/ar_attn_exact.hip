@@ -790,7 +790,7 @@ extern "C" int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, co
                                  int64_t k_ts, int64_t v_bs, int64_t v_hs, int64_t v_ts, int64_t o_bs, int64_t o_hs, int64_t o_ts,
                                  int64_t do_bs, int64_t do_hs, int64_t do_ts, int64_t lddq, int64_t lddk, int64_t lddv, void* workspace,
                                  int64_t workspace_bytes, ar_stream_t stream) {
-    if ((D != 64 && D != 128) || S % 256 || S > 4096 || B <= 0 || H <= 0 || kv_rep < 1 || H % kv_rep) return AR_ERR_UNSUPPORTED;
+    if ((D != 64 && D != 128) || S % 128 || S > 4096 || B <= 0 || H <= 0 || kv_rep < 1 || H % kv_rep) return AR_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < ar_attn_bwd_exact_workspace_bytes(B, S, H)) return AR_ERR_UNSUPPORTED;
     if (!(bias_in == bias_in) || !(bias_out == bias_out) || fabsf(bias_in) > 1e4f || fabsf(bias_out) > 1e4f || valid_len < 1 || valid_len > S)
         return AR_ERR_UNSUPPORTED;
@@ -845,7 +845,7 @@ extern "C" int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, co
         (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T + VEC_MAX);
     }
     const int bform = (g_xattn_cfg >> 2) & 3;
-    if (bform == 1 || (bform == 0 && D == 64)) {         // workgroups of 4 waves (the default at head size 64: measured)
+    if (bform == 1 || (bform == 0 && D == 64) || S % 256) {         // workgroups of 4 waves (the default at head size 64: measured; S % 256 != 0)
         const int grid4 = (int)(B * H * (S / 128));
         if (D == 128) {
             hipLaunchKernelGGL((k_xattn_bwd<1, 4, 128, 1>), grid4, 256, LDS_T128 + vec, s, a);

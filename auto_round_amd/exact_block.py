@@ -72,7 +72,7 @@ def exact_attention_forward(q4, k4, v4, mask, scale, S, key_block=0):
     """first-party attention with the library's bits (ops.attn_fwd_exact) when the call is one it takes: the calibration flow's
     structured additive mask, head size 64 / 128, a sequence the backward kernels take too.  -> (q4, k4, v4, out [B, S, H, D], lse,
     mask_struct) or None"""
-    if mask is None or S % 256 or S > 4096:
+    if mask is None or S % 128 or S > 4096:
         return None
     st = ops.mask_structure(mask, S)
     if st is None:

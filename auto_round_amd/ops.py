@@ -740,7 +740,7 @@ def attn_bwd_exact(q4, k4, v4, out, lse, dout, mask_struct, scale: float, dq=Non
     if mask_struct is None or q4.dim() != 4 or q4.dtype != torch.bfloat16:
         return None
     B, H, S, D = (int(x) for x in q4.shape)
-    if D not in (64, 128) or S % 256 or S > 4096 or k4.shape != v4.shape or tuple(out.shape) != (B, S, H, D) or tuple(dout.shape) != (B, S, H, D):
+    if D not in (64, 128) or S % 128 or S > 4096 or k4.shape != v4.shape or tuple(out.shape) != (B, S, H, D) or tuple(dout.shape) != (B, S, H, D):
         return None
     hk = int(k4.shape[1])
     if hk < 1 or H % hk or k4.shape[0] != B or k4.shape[2] != S or k4.shape[3] != D:

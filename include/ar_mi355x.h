@@ -486,7 +486,7 @@ int ar_attn_fwd_exact(const void* Q, const void* K, const void* V, void* O, floa
  * O / LSE are the forward's results.  dQ, dK, dV are written token-major [B, S, H, D] with token strides lddq / lddk / lddv (0 = H * D;
  * larger strides: column slices of a merged buffer); dK / dV hold one gradient per QUERY head -- the caller adds the kv_rep heads of a
  * group, as autograd's expand backward does.  workspace: ar_attn_bwd_exact_workspace_bytes(B, S, H) bytes.  D in {64, 128},
- * S % 256 == 0, S <= 4096; anything else AR_ERR_UNSUPPORTED.  Equality with the library is proven per call signature by the caller. */
+ * S % 128 == 0, S <= 4096; anything else AR_ERR_UNSUPPORTED.  Equality with the library is proven per call signature by the caller. */
 int64_t ar_attn_bwd_exact_workspace_bytes(int64_t B, int64_t S, int64_t H);
 int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ, void* dK,
                       void* dV, int64_t B, int64_t S, int64_t H, int64_t D, int64_t kv_rep, float scale, float bias_in, float bias_out,

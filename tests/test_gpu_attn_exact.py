@@ -19,7 +19,11 @@ SHAPES = [pytest.param(8, 32, 2048, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-mini
           pytest.param(4, 32, 512, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-seq512-keyblock32"),
           pytest.param(4, 12, 512, 64, 12, 1.0, 0.35, id="opt-125m-seq512-keyblock64"),
           pytest.param(2, 12, 4096, 64, 12, 1.0, 0.35, id="opt-125m-seq4096-keyblock64"),
-          pytest.param(4, 16, 768, 64, 16, 1.0, 0.35, id="head64-seq768-keyblock32")]
+          pytest.param(4, 16, 768, 64, 16, 1.0, 0.35, id="head64-seq768-keyblock32"),
+          # S % 256 != 0: workgroups of 4 waves in the backward
+          pytest.param(4, 32, 384, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-seq384"),
+          pytest.param(4, 12, 640, 64, 12, 1.0, 0.35, id="opt-125m-seq640"),
+          pytest.param(2, 32, 1152, 128, 8, 128 ** -0.5, 1.0, id="llama3-8b-seq1152")]
 
 
 def _case(B, H, S, D, hk, std, seed=0, valid=None):

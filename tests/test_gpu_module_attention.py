@@ -71,9 +71,9 @@ def test_module_path_block_runs_its_attention_first_party_after_the_proof_and_tu
 
 
 def test_a_call_the_kernels_do_not_take_keeps_the_stock_attention():
-    """seq 128: the backward kernels take S % 256 == 0 only -- every call falls through to transformers' own attention, the proof says so
-    and nothing is installed"""
-    model, tokens = _qwen3(seq=128)
+    """seq 192: the kernels take S % 128 == 0 only -- every call falls through to transformers' own attention, the proof says so and
+    nothing is installed"""
+    model, tokens = _qwen3(seq=192)
     with pytest.warns(UserWarning, match="exact_attention"):
         q, _, impl = _tune(model, tokens, exact_attention=True, iters=2)
     assert not q.last_exact
