@@ -27,7 +27,7 @@ def main():
     variants = (("opt125m_module_path", dict()), ("opt125m_exact_rounding", dict(exact=True)),
                 ("opt125m_exact_rounding_verified", dict(exact=True, verify_attention=True)),
                 ("opt125m_module_path_inference_mode_forwards", dict(reproducible_attention=False)))
-    for name, kw in variants:
+    for name, kw in (variants if N > 0 else ()):
         runs = []
         for _ in range(N):
             r = fx.check_against_stat_fixture(fixp, **kw)
