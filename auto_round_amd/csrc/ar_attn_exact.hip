@@ -355,7 +355,9 @@ static float bias_log2e_bf16(float bias) {
 using namespace ar;
 
 // launch forms (equal results; measured A/B, profiles/r06_attn_exact_waves_ab.json): bits 0-1 forward, bits 2-3 backward -- 0 default
-// (8 waves at head size 128, 4 at head size 64), 1 = workgroups of 4 waves (128 own rows), 2 = workgroups of 8 waves (256 own rows)
+// (forward: 8 waves at head size 128, 4 at 64; backward: head size 128 the fused key-side kernel on 4 waves + the 8-wave query-side
+// kernel, head size 64 4 waves), 1 = workgroups of 4 waves (128 own rows), 2 = workgroups of 8 waves (256 own rows; head size 128: the
+// key side as two kernels), 3 (backward) = the fused key-side kernel
 static int g_xattn_cfg = 0;
 extern "C" int ar_attn_exact_config(int cfg) {
     const int old = g_xattn_cfg;
@@ -495,8 +497,8 @@ __global__ __launch_bounds__(kTPB) void k_xattn_bwd_prep(const uint16_t* __restr
 
 // MODE 0: dQ (own rows = queries; K / V tiles stream).  MODE 1: dK / dV (own rows = keys; Q / dO tiles stream); OUT: 3 = both,
 // 1 = dV only, 2 = dK only (head size 128 runs the key side as two kernels: registers, csrc/ar_attn_bwd.hip).
-template <int MODE, int WAVES, int AD, int OUT = 3>
-__global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_bwd(XBwdArgs a) {
+template <int MODE, int WAVES, int AD, int OUT = 3, int OCC = 2>
+__global__ __launch_bounds__(64 * WAVES, OCC) void k_xattn_bwd(XBwdArgs a) {
     constexpr bool NEED_S1 = MODE == 0 || (OUT & 2);
     constexpr bool NEED_A0 = MODE == 0 || (OUT & 2);
     constexpr bool NEED_A1 = MODE == 1 && (OUT & 1);
@@ -512,7 +514,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_bwd(XBwdArgs a) {
     constexpr int CPR = AROW / 16;
     constexpr int NP = RPW / RPI;
     static_assert(NP >= 1, "a wave stages at least one DMA instruction per tensor");
-    static_assert(AD == 64 || (AD == 128 && (MODE == 0 || OUT != 3)), "head size 128: the key side as two kernels (register budget)");
+    static_assert(AD == 64 || (AD == 128 && (MODE == 0 || OUT != 3 || OCC == 1)),
+                  "head size 128: the key side as two kernels (register budget), or one wave per SIMD with the whole register file");
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -845,6 +848,17 @@ extern "C" int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, co
         (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T + VEC_MAX);
     }
     const int bform = (g_xattn_cfg >> 2) & 3;
+    if ((bform == 3 || bform == 0) && D == 128) {         // dK and dV in ONE kernel (7 GEMM passes instead of 8): 4 waves, one wave per SIMD with the
+                                                          // whole register file (accumulators in the AGPRs) -- 3 % faster than the two key-side kernels
+        static PerDeviceOnce attr1;
+        if (attr1.first())
+            (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 4, 128, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + 2 * 4096 * (int)sizeof(float));
+        const int grid4 = (int)(B * H * (S / 128));
+        hipLaunchKernelGGL((k_xattn_bwd<1, 4, 128, 3, 1>), grid4, 256, LDS_T128 + vec, s, a);
+        if (S % 256) hipLaunchKernelGGL((k_xattn_bwd<0, 4, 128>), grid4, 256, LDS_T128, s, a);
+        else hipLaunchKernelGGL((k_xattn_bwd<0, 8, 128>), (int)(B * H * (S / 256)), 512, LDS_T128, s, a);
+        return launch_status();
+    }
     if (bform == 1 || (bform == 0 && D == 64) || S % 256) {         // workgroups of 4 waves (the default at head size 64: measured; S % 256 != 0)
         const int grid4 = (int)(B * H * (S / 128));
         if (D == 128) {

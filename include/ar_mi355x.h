@@ -496,7 +496,8 @@ int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, const void* O
 
 /* Launch form of ar_attn_fwd_exact / ar_attn_bwd_exact (binding hygiene: a tuning knob for A/B measurements, results are identical
  * in every form -- the per-row arithmetic does not depend on how many rows a workgroup owns).  Bits 0-1 forward, bits 2-3 backward:
- * 0 default, 1 workgroups of 4 waves (128 own rows), 2 workgroups of 8 waves (256).  cfg < 0 only reads.  -> the previous value. */
+ * 0 default, 1 workgroups of 4 waves (128 own rows), 2 workgroups of 8 waves (256), 3 (backward, head size 128) dK and dV in one
+ * kernel on one wave per SIMD -- the default there.  cfg < 0 only reads.  -> the previous value. */
 int ar_attn_exact_config(int cfg);
 
 /* ---- causal attention backward, head size 64 (deterministic: two MFMA kernels, no float atomics) ---------------------------

@@ -25,7 +25,7 @@ for (B, H, S, D, hk, scale, std) in ((8, 32, 2048, 128, 8, 128 ** -0.5, 1.0), (8
     rec = {"shape": [B, H, S, D, hk]}
     base = None
     with torch.no_grad():
-        for name, cfg in (("waves8", 2 | (2 << 2)), ("waves4", 1 | (1 << 2)), ("default", 0)):
+        for name, cfg in (("waves8", 2 | (2 << 2)), ("waves4", 1 | (1 << 2)), ("default", 0), ("fused_key_side", 3 << 2)):
             lib.ar_attn_exact_config(cfg)
             o, lse = ops.attn_fwd_exact(q, k, v, st, scale)
             g = ops.attn_bwd_exact(q, k, v, o, lse, da, st, scale)
