@@ -215,9 +215,12 @@ class AutoRound:
                 self.layer_config[f"{n}.{ln}"] = cfg
         tokens = self._calibration_tokens()
         ids_for_mask = loss_mask_ids(tokens, getattr(self.tokenizer, "pad_token_id", None))
-        # grouped-query "sdpa" attention would silently run on the 2x slower flash kernels (attention.py)
+        # grouped-query "sdpa" attention would silently run on the 2x slower flash kernels (attention.py) -- on the fused / plain module
+        # paths; with `exact_rounding` the model keeps transformers' own "sdpa" function: that call is what the reference makes, what the
+        # exact blocks are proven against (they refuse any other attention function) and what `exact_attention` swaps per block
         cfg_obj, old_attn = getattr(model, "config", None), None
-        if self.config.sdpa_backend == "efficient" and getattr(cfg_obj, "_attn_implementation", None) == "sdpa":
+        if (self.config.sdpa_backend == "efficient" and not self.config.exact_rounding
+                and getattr(cfg_obj, "_attn_implementation", None) == "sdpa"):
             from .attention import register_mi355x_sdpa
 
             old_attn, cfg_obj._attn_implementation = cfg_obj._attn_implementation, register_mi355x_sdpa()

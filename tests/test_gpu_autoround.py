@@ -30,6 +30,21 @@ def unpack_w4_gptq(qweight, qzeros, scales, gs):
     return ((q - z[g]).float() * scales.float()[g]).t()
 
 
+def test_front_door_default_reaches_the_exact_path():
+    """`AutoRound(...)` with its defaults (exact_rounding on) tunes a Llama block on the exact path: the model keeps transformers' own
+    "sdpa" attention function -- the call the reference makes and the exact blocks are proven against (round 6: the front door used to
+    swap in its own attention function first, which made every exact block refuse)"""
+    from auto_round_amd.autoround import AutoRound
+
+    model = tiny_llama(layers=1, hidden=256, ffn=512, heads=2, kv=1)          # head size 128
+    tokens = torch.randint(0, 512, (8, 40), generator=torch.Generator().manual_seed(1))
+    ar = AutoRound(model, None, scheme="W4A16", group_size=32, iters=3, nsamples=8, seqlen=32, batch_size=4, dataset=tokens)
+    assert ar.config.exact_rounding
+    ar.quantize()
+    assert ar.quantizer.last_exact, ar.quantizer.last_exact_report
+    assert model.config._attn_implementation == "sdpa"
+
+
 @pytest.mark.parametrize("alg_ext", [False, True])
 def test_autoround_front_door_quantize_and_save(tmp_path, alg_ext):
     from safetensors import safe_open
