@@ -94,6 +94,14 @@ class AutoRound:
         # MI355X-only: Llama-family blocks through the first-party kernels that keep the eager path's bits (exact_block.py) -- on by
         # default: same results as the module code (proven per kind of block before use, module path otherwise), fewer launches
         exact = bool(kwargs.pop("exact_rounding", True)) and not fused
+        # The reference's calibrator drives the model with an attention mask whenever the dataset is not one of its named ones
+        # (calibration/llm.py:291-293, 362-402: ones, trailing repeats of a sample's last token cleared, the last position ALWAYS
+        # cleared so that no model folds an all-ones mask into None) -- a token tensor, the only kind of dataset this front door takes,
+        # is that case -- and its input cache casts the boolean [1, 1, S, S] mask transformers builds from it to the activation dtype
+        # (calibration/inputs.py:100-107): a 0 / 1 ADDITIVE bias from then on.  That mask is part of what the reference computes (the
+        # block's attention is then NOT causal), so it is mirrored by default; `calibration_attention_mask=False` (MI355X-only keyword)
+        # calibrates and tunes with plain causal attention instead.
+        self.calibration_attention_mask = bool(kwargs.pop("calibration_attention_mask", True))
         if kwargs.pop("platform", "hf") != "hf":
             raise NotImplementedError("only Hugging Face models (platform='hf') are handled")
         legacy_device = kwargs.pop("device", None)           # autoround.py:753-757: deprecated alias of device_map
@@ -179,16 +187,58 @@ class AutoRound:
                     shared[k] = _first_sample(v, bs)
             raise _StopForward
 
+        masks = []
+
+        def mask_hook(module, args, kwargs):          # (before `hook`: it raises) every batch's own mask rows, as the reference caches them
+            m = kwargs.get("attention_mask")
+            if isinstance(m, torch.Tensor) and m.dim() == 4:
+                masks.append(m.detach())
+
+        hm = first.register_forward_pre_hook(mask_hook, with_kwargs=True) if self.calibration_attention_mask else None
         h = first.register_forward_pre_hook(hook, with_kwargs=True)
         bs = self.config.batch_size
         try:
             for b0 in range(0, tokens.shape[0], bs):
+                ids = tokens[b0:b0 + bs].to(self.device)
+                kw = {"use_cache": False}
+                if self.calibration_attention_mask:
+                    kw["attention_mask"] = calibration_attention_mask(ids)
                 try:
-                    self.model(input_ids=tokens[b0:b0 + bs].to(self.device), use_cache=False)
+                    self.model(input_ids=ids, **kw)
                 except _StopForward:
                     pass
         finally:
             h.remove()
+            if hm is not None:
+                hm.remove()
+        if self.calibration_attention_mask and isinstance(shared.get("attention_mask"), torch.Tensor):
+            # the input cache's cast (inputs.py:100-107): boolean / half-precision mask -> the activation dtype, i.e. a 0 / 1 bias
+            rows = torch.cat(masks, dim=0) if masks else shared["attention_mask"]
+            if rows.shape[0] > 1 and not bool((rows == rows[:1]).all()):
+                import warnings
+
+                warnings.warn("calibration samples end in repeated tokens of different lengths: the reference would cache one attention mask "
+                              "per sample; this front door keeps ONE shared mask (the last position cleared) for all of them")
+                ids = tokens[:1].to(self.device)
+                am = torch.ones_like(ids)
+                am[:, -1] = 0
+                try:
+                    captured_n = len(captured)
+                    masks.clear()
+                    hm = first.register_forward_pre_hook(mask_hook, with_kwargs=True)
+                    h = first.register_forward_pre_hook(hook, with_kwargs=True)
+                    try:
+                        self.model(input_ids=ids, attention_mask=am, use_cache=False)
+                    except _StopForward:
+                        pass
+                finally:
+                    h.remove()
+                    hm.remove()
+                    del captured[captured_n:]
+                rows = masks[0] if masks else rows
+            m = rows[:1]
+            amp_dtype = self.config.amp_dtype
+            shared["attention_mask"] = m.to(amp_dtype) if (m.dtype == torch.bool or m.is_floating_point()) else m
         return torch.cat(captured, dim=0), shared
 
     # -- the run ---------------------------------------------------------------------------------------------------------
@@ -587,6 +637,24 @@ def sync_tuned_blocks(blocks, world: int, device, policy: str = "round_robin") -
                 m = m.orig_layer
             dist.broadcast(m.weight.data, src=own)
     return got
+
+
+def calibration_attention_mask(input_ids: torch.Tensor) -> torch.Tensor:
+    """The [batch, S] attention mask the reference's calibrator passes for a dataset that is not one of its named ones
+    (calibration/llm.py:374-402): ones; where a sample ends in repeats of its last token those repeats and the last position are
+    cleared; the last position of EVERY sample is cleared (so the mask is never all ones)."""
+    am = torch.ones_like(input_ids, dtype=torch.long)
+    bsz, seq = input_ids.shape
+    for i in range(bsz):
+        last, j, repeated = input_ids[i, -1], seq - 2, False
+        while j >= 0 and input_ids[i, j] == last:
+            repeated = True
+            am[i, j] = 0
+            j -= 1
+        if repeated:
+            am[i, -1] = 0
+    am[:, -1] = 0
+    return am
 
 
 def loss_mask_ids(tokens: torch.Tensor, pad_token_id=None) -> torch.Tensor:

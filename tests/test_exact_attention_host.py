@@ -82,3 +82,14 @@ def test_key_block_table_is_the_measured_one():
         assert ops.attn_key_block_guess(r["D"], r["S"]) in exact, r
         checked += 1
     assert checked >= 12
+
+
+def test_front_door_calibration_mask_is_the_reference_calibrators():
+    """auto_round/calibration/llm.py:374-402 for a dataset that is not one of the reference's named ones: ones; trailing repeats of a
+    sample's last token cleared together with the last position; the last position of every sample cleared"""
+    from auto_round_amd.autoround import calibration_attention_mask
+
+    ids = torch.tensor([[1, 2, 3, 4, 5], [7, 8, 9, 9, 9], [4, 4, 4, 4, 4], [1, 2, 2, 3, 2]])
+    want = torch.tensor([[1, 1, 1, 1, 0], [1, 1, 0, 0, 0], [0, 0, 0, 0, 0], [1, 1, 1, 1, 0]])
+    got = calibration_attention_mask(ids)
+    assert got.dtype == torch.long and torch.equal(got, want)
