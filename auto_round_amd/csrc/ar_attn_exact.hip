@@ -48,6 +48,7 @@ typedef short xs16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 xbf16x8_t __attribute__((ext_vector_type(8)));
 typedef float xf32x16_t __attribute__((ext_vector_type(16)));
 typedef float xf32x2 __attribute__((ext_vector_type(2)));
+typedef float xf32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int XK = 64;               // keys per staged tile
 
@@ -357,11 +358,11 @@ using namespace ar;
 // launch forms (equal results; measured A/B, profiles/r06_attn_exact_waves_ab.json): bits 0-1 forward, bits 2-3 backward -- 0 default
 // (forward: 8 waves at head size 128, 4 at 64; backward: head size 128 the fused key-side kernel on 4 waves + the 8-wave query-side
 // kernel, head size 64 4 waves), 1 = workgroups of 4 waves (128 own rows), 2 = workgroups of 8 waves (256 own rows; head size 128: the
-// key side as two kernels), 3 (backward) = the fused key-side kernel
+// key side as two kernels), 3 (backward) = the fused key-side kernel; bit 4 (16): the fused key-side kernel WITHOUT the hand pipeline
 static int g_xattn_cfg = 0;
 extern "C" int ar_attn_exact_config(int cfg) {
     const int old = g_xattn_cfg;
-    if (cfg >= 0) g_xattn_cfg = cfg & 15;
+    if (cfg >= 0) g_xattn_cfg = cfg & 63;
     return old;
 }
 
@@ -783,6 +784,329 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void k_xattn_bwd(XBwdArgs a) {
     }
 }
 
+
+// The key side (dK and dV) as ONE SOFTWARE-PIPELINED wave per SIMD.  k_xattn_bwd<1, 4, 128, 3, 1> above runs its phases one after the
+// other -- fragment reads, score MFMAs, softmax VALU, accumulating MFMAs -- and with a single wave on the SIMD nothing fills the gaps:
+// 4050 cycles per 32-query step against 1024 of MFMA, and the four waves of the workgroup ask the LDS for the same 32 KB at the same
+// time (128 B / clk = as long as the MFMAs take).  Here the two 32-query steps of a staged tile are interleaved by hand: the softmax of
+// step 0 is issued BETWEEN the score MFMAs of step 1, the softmax of step 1 between the accumulating MFMAs of step 0, every LDS read is
+// issued one stage before its use (two fragment buffers, two transposed-fragment sets), and the tile barrier sits in the middle of
+// the last stage with the next tile's first reads behind it.  Every value is computed by the same instructions in the same order per
+// accumulator as above (the chains S, dP, dK^T, dV^T are untouched), so the results are equal bit for bit (test_gpu_attn_exact.py).
+template <int AD>
+__global__ __launch_bounds__(256, 1) void k_xattn_bwd_kv(XBwdArgs a) {
+    constexpr int WAVES = 4;
+    constexpr int KB = AD / 32;                   // k-steps per fragment chunk (two chunks per score product)
+    constexpr int ND = AD / 32;
+    constexpr int NKS = AD / 16;
+    constexpr int EPM = 8 / (2 * KB);             // softmax elements issued behind each MFMA of a stage
+    constexpr int AROW = AD * 2;
+    constexpr int ATILE = XK * AROW;
+    constexpr int ABUF = 2 * ATILE;
+    constexpr int AQ = 32 * WAVES;
+    constexpr int RPW = XK / WAVES;
+    constexpr int RPI = 1024 / AROW;
+    constexpr int CPR = AROW / 16;
+    constexpr int NP = RPW / RPI;
+    constexpr int VEC_OFF = 2 * ABUF;
+    static_assert(EPM >= 1 && NP >= 1, "head sizes 64 and 128");
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, lq = lane & 31;
+    const int n_ob = a.S / AQ;
+    const int n_bh = a.B * a.H;
+    int ob, bh;
+    if ((n_bh & 7) == 0) {
+        const int j = blockIdx.x >> 3, per = n_bh >> 3;
+        bh = (j % per) * 8 + (int)(blockIdx.x & 7);
+        ob = j / per;
+    } else {
+        ob = (int)(blockIdx.x % n_ob);
+        bh = blockIdx.x / n_ob;
+    }
+    const int b = bh / a.H, head = bh % a.H, kvh = head / a.kv_rep;
+    const int o0 = ob * AQ;
+    const int myrow = o0 + 32 * wave + lq;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+
+    const uint16_t* Qh = a.Q + (int64_t)b * a.q_bs + (int64_t)head * a.q_hs;
+    const uint16_t* Kh = a.K + (int64_t)b * a.k_bs + (int64_t)kvh * a.k_hs;
+    const uint16_t* Vh = a.V + (int64_t)b * a.v_bs + (int64_t)kvh * a.v_hs;
+    const uint16_t* Oh = a.dO + (int64_t)b * a.o_bs + (int64_t)head * a.o_hs;
+    xbf16x8_t bf0[NKS], bf1[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        bf0[ks] = __builtin_bit_cast(xbf16x8_t, *reinterpret_cast<const uint4*>(Kh + (int64_t)myrow * a.k_ts + 16 * ks + 8 * h));
+        bf1[ks] = __builtin_bit_cast(xbf16x8_t, *reinterpret_cast<const uint4*>(Vh + (int64_t)myrow * a.v_ts + 16 * ks + 8 * h));
+    }
+    {
+        const float* L2row = a.L2 + ((int64_t)b * a.H + head) * a.S;
+        const float* Dvrow = a.Dv + ((int64_t)b * a.H + head) * a.S;
+        float* vL = reinterpret_cast<float*>(lds + VEC_OFF);
+        float* vD = vL + a.S;
+        for (int i = tid; i < a.S; i += 64 * WAVES) { vL[i] = L2row[i]; vD[i] = Dvrow[i]; }
+    }
+    const bool quirk = lq == 27 || lq == 31;      // the library's non-fused element (k_xattn_bwd)
+    const float qmul = quirk ? 1.0f : a.qk_scale;
+
+    const int drow = lane / CPR, pchunk = lane % CPR;
+    uint32_t doff0[NP], doff1[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int r = RPW * wave + RPI * p + drow;
+        doff0[p] = (uint32_t)(r * a.q_ts + (pchunk ^ xattn_swz<AD>(r)) * 8);
+        doff1[p] = (uint32_t)(r * a.o_ts + (pchunk ^ xattn_swz<AD>(r)) * 8);
+    }
+    auto issue_tile = [&](int t, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2 * NP; ++j) {
+            const int p = j % NP;
+            const uint16_t* T = (j < NP ? Qh + (int64_t)t * XK * a.q_ts + doff0[p] : Oh + (int64_t)t * XK * a.o_ts + doff1[p]);
+            const uint32_t dst = lds0 + buf * ABUF + (j < NP ? 0 : ATILE) + (RPW * wave + RPI * p) * AROW;
+            __builtin_amdgcn_global_load_lds((const void*)T, (__attribute__((address_space(3))) void*)(uintptr_t)dst, 16, 0, 0);
+        }
+    };
+    uint32_t rA[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) rA[ks] = lds0 + lq * AROW + ((uint32_t)((2 * ks + h) ^ xattn_swz<AD>(lq)) << 4);
+    const int gi = lane & 15, gg = lane >> 4;
+    const int vrow = 4 * h + (gi >> 2);
+    const int vrow_hi = vrow + 8;
+    const int vcol0 = 16 * (gg & 1) + 4 * (gi & 3);
+    uint32_t tAlo[ND], tAhi[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+        const int col = 32 * dt + vcol0;
+        tAlo[dt] = lds0 + vrow * AROW + ((uint32_t)((col >> 3) ^ xattn_swz<AD>(vrow)) << 4) + (col & 7) * 2;
+        tAhi[dt] = lds0 + vrow_hi * AROW + ((uint32_t)((col >> 3) ^ xattn_swz<AD>(vrow_hi)) << 4) + (col & 7) * 2;
+    }
+    const uint32_t vLa = lds0 + VEC_OFF + 16 * h;             // + 4 * (tile row + 32 t + 8 j): the four l2 of accumulator registers 4 j ..
+    const uint32_t vDa = vLa + 4 * a.S;
+
+    xf32x16_t acc0[ND], acc1[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[dt][r] = 0.f; acc1[dt][r] = 0.f; }
+
+    u32x4_t F[2][2][KB];                          // [chunk parity][Q | dO][k-step]: row fragments of the score products
+    xs16x4_t TL[2][2][ND], TH[2][2][ND];          // [set][Q | dO][d tile]: transposed fragments of the accumulating products
+    xf32x4_t LV[2][2], DV[2][2];                  // [half of the 16 elements][j]: l2 and delta of the streamed rows
+
+#define XK_PIN() __builtin_amdgcn_sched_barrier(0)
+#define XK_WAIT(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((N) > 15 ? 15 : (N)) : "memory")
+#define XK_RREAD(DST, KS, T, REG, BUFX) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(DST) : "v"(rA[KS]), "n"((BUFX) * ABUF + (REG) * ATILE + (T) * 32 * AROW) : "memory")
+#define XK_TREAD(LO, HI, DT, ST, REG, BUFX)                                                                                    \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"                                  \
+                 : "=&v"(LO), "=&v"(HI) : "v"(tAlo[DT]), "v"(tAhi[DT]), "n"((BUFX) * ABUF + (REG) * ATILE + (ST) * 16 * AROW) : "memory")
+#define XK_VREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+
+    // R(t, c): the row fragments of chunk c of step t into F[c]
+#define XK_ISSUE_R(BUFX, T, C)                                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < KB; ++ks) {                                                                        \
+        XK_RREAD(F[C][0][ks], (C) * KB + ks, T, 0, BUFX);                                                                      \
+        XK_RREAD(F[C][1][ks], (C) * KB + ks, T, 1, BUFX);                                                                      \
+    }
+    // T(t, s2): the transposed fragments of 16-row step 2 t + s2 into set s2
+#define XK_ISSUE_T(BUFX, T, S2)                                                                                                \
+    _Pragma("unroll") for (int dt = 0; dt < ND; ++dt) {                                                                        \
+        XK_TREAD(TL[S2][0][dt], TH[S2][0][dt], dt, 2 * (T) + (S2), 0, BUFX);                                                   \
+        XK_TREAD(TL[S2][1][dt], TH[S2][1][dt], dt, 2 * (T) + (S2), 1, BUFX);                                                   \
+    }
+    // L(t, half): l2 / delta of streamed rows 32 t + 4 h + 8 j + i, j = 2 half, 2 half + 1; VA = vLa + 4 * (first row of the tile)
+#define XK_ISSUE_L(VA, VD, T, HF, X)                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                            \
+        XK_VREAD(LV[HF][j], VA, 4 * ((X) + 32 * (T) + 8 * (2 * (HF) + j)));                                                    \
+        XK_VREAD(DV[HF][j], VD, 4 * ((X) + 32 * (T) + 8 * (2 * (HF) + j)));                                                    \
+    }
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    auto tile = [&](auto bufc, int tn, bool has_next, bool dma) {
+        constexpr int BUF = decltype(bufc)::value;
+        const int t0 = tn * XK;
+        const uint32_t va = vLa + 4 * t0, vd = vDa + 4 * t0;
+        const bool plain = t0 >= o0 + 32 * wave + 31 && o0 + 32 * wave + 31 < a.valid_len;
+        const bool all_out = o0 + 32 * wave > t0 + XK - 1 || o0 + 32 * wave >= a.valid_len;
+        xf32x16_t s0[2], s1[2];
+        uint32_t pkP[2][8], pkS[2][8];
+        auto init = [&](int t) __attribute__((always_inline)) {
+            if (plain || all_out) {
+                const float bias = plain ? a.bias_in_s : a.bias_out_s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s0[t][r] = bias; s1[t][r] = 0.f; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int query = t0 + 32 * t + 4 * h + (r & 3) + 8 * (r >> 2);
+                    s0[t][r] = (myrow <= query && myrow < a.valid_len) ? a.bias_in_s : a.bias_out_s;
+                    s1[t][r] = 0.f;
+                }
+            }
+        };
+        // MFMA i of score chunk c of step t:  i even -> S (K Q^T), i odd -> dP (V dO^T), k-step c KB + i / 2
+        auto score_mfma = [&](int t, int c, int i) __attribute__((always_inline)) {
+            const int ks = i >> 1;
+            if ((i & 1) == 0) s0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8_t, F[c][0][ks]), bf0[c * KB + ks], s0[t], 0, 0, 0);
+            else s1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8_t, F[c][1][ks]), bf1[c * KB + ks], s1[t], 0, 0, 0);
+        };
+        // MFMA i of the accumulating products of step t, 16-row half s2:  i even -> dK^T += Q^T dS, i odd -> dV^T += dO^T P, d tile i / 2
+        auto acc_mfma = [&](int t, int s2, int i) __attribute__((always_inline)) {
+            const int dt = i >> 1;
+            if ((i & 1) == 0) {
+                u32x4_t pe; pe.x = pkS[t][4 * s2]; pe.y = pkS[t][4 * s2 + 1]; pe.z = pkS[t][4 * s2 + 2]; pe.w = pkS[t][4 * s2 + 3];
+                const xs16x8_t a0 = __builtin_shufflevector(TL[s2][0][dt], TH[s2][0][dt], 0, 1, 2, 3, 4, 5, 6, 7);
+                acc0[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8_t, a0), __builtin_bit_cast(xbf16x8_t, pe), acc0[dt], 0, 0, 0);
+            } else {
+                u32x4_t pp; pp.x = pkP[t][4 * s2]; pp.y = pkP[t][4 * s2 + 1]; pp.z = pkP[t][4 * s2 + 2]; pp.w = pkP[t][4 * s2 + 3];
+                const xs16x8_t a1 = __builtin_shufflevector(TL[s2][1][dt], TH[s2][1][dt], 0, 1, 2, 3, 4, 5, 6, 7);
+                acc1[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8_t, a1), __builtin_bit_cast(xbf16x8_t, pp), acc1[dt], 0, 0, 0);
+            }
+        };
+        // softmax element r of step t:  p = exp2(fma(qk_scale, s, -l2)) (quirk lanes: two roundings), ds = p * (dp - delta); pairs packed
+        auto element = [&](int t, int r) __attribute__((always_inline)) {
+            const int hf = r >> 3, j = (r >> 2) & 1, i = r & 3;
+            const float prod = a.qk_scale * s0[t][r];
+            const float tv = quirk ? prod : s0[t][r];
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(qmul, tv, -LV[hf][j][i]));
+            const float dd = s1[t][r] - DV[hf][j][i];
+            s0[t][r] = p;
+            s1[t][r] = p * dd;
+            if (r & 1) {
+                pkP[t][r >> 1] = pack_bf16x2(s0[t][r - 1], s0[t][r]);
+                pkS[t][r >> 1] = pack_bf16x2(s1[t][r - 1], s1[t][r]);
+            }
+        };
+
+        // ---- stage 0   in flight: L(0) R(0,0) R(0,1)
+        init(0);
+        XK_WAIT(2 * KB);
+        XK_PIN();
+#pragma unroll
+        for (int i = 0; i < 2 * KB; ++i) score_mfma(0, 0, i);
+        XK_PIN();
+        // ---- stage 1
+        XK_WAIT(0);
+        XK_ISSUE_R(BUF, 1, 0);
+        XK_PIN();
+#pragma unroll
+        for (int i = 0; i < 2 * KB; ++i) score_mfma(0, 1, i);
+        XK_PIN();
+        // ---- stage 2   score MFMAs of step 1 (chunk 0) | softmax of step 0, elements 0 .. 7
+        init(1);
+        XK_WAIT(0);
+        XK_ISSUE_T(BUF, 0, 0);
+        XK_ISSUE_R(BUF, 1, 1);
+        XK_PIN();
+#pragma unroll
+        for (int i = 0; i < 2 * KB; ++i) {
+            score_mfma(1, 0, i);
+#pragma unroll
+            for (int e = 0; e < EPM; ++e) element(0, EPM * i + e);
+            XK_PIN();
+        }
+        // ---- stage 3   score MFMAs of step 1 (chunk 1) | softmax of step 0, elements 8 .. 15
+        XK_WAIT(0);
+        XK_ISSUE_T(BUF, 0, 1);
+        XK_ISSUE_L(va, vd, 1, 0, 0);
+        XK_PIN();
+#pragma unroll
+        for (int i = 0; i < 2 * KB; ++i) {
+            score_mfma(1, 1, i);
+#pragma unroll
+            for (int e = 0; e < EPM; ++e) element(0, 8 + EPM * i + e);
+            XK_PIN();
+        }
+        // ---- stage 4   accumulating MFMAs of step 0 (rows 0 .. 15) | softmax of step 1, elements 0 .. 7
+        XK_WAIT(0);
+        XK_ISSUE_L(va, vd, 1, 1, 0);
+        XK_PIN();
+#pragma unroll
+        for (int i = 0; i < 2 * ND; ++i) {
+            acc_mfma(0, 0, i);
+#pragma unroll
+            for (int e = 0; e < EPM; ++e) element(1, EPM * i + e);
+            XK_PIN();
+        }
+        XK_ISSUE_T(BUF, 1, 0);
+        // ---- stage 5   accumulating MFMAs of step 0 (rows 16 .. 31) | softmax of step 1, elements 8 .. 15
+        XK_WAIT(4 * ND);
+        XK_PIN();
+#pragma unroll
+        for (int i = 0; i < 2 * ND; ++i) {
+            acc_mfma(0, 1, i);
+#pragma unroll
+            for (int e = 0; e < EPM; ++e) element(1, 8 + EPM * i + e);
+            XK_PIN();
+        }
+        XK_ISSUE_T(BUF, 1, 1);
+        // ---- stage 6   accumulating MFMAs of step 1 (rows 0 .. 15); then the tile boundary
+        XK_WAIT(4 * ND);
+        XK_PIN();
+#pragma unroll
+        for (int i = 0; i < 2 * ND; ++i) acc_mfma(1, 0, i);
+        XK_PIN();
+        XK_WAIT(0);
+        if (has_next) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (dma) issue_tile(tn + 2, BUF);
+            XK_ISSUE_L(va, vd, 0, 0, XK);
+            XK_ISSUE_L(va, vd, 0, 1, XK);
+            XK_ISSUE_R((BUF ^ 1), 0, 0);
+            XK_ISSUE_R((BUF ^ 1), 0, 1);
+        }
+        XK_PIN();
+        // ---- stage 7   accumulating MFMAs of step 1 (rows 16 .. 31), over the next tile's first reads
+#pragma unroll
+        for (int i = 0; i < 2 * ND; ++i) acc_mfma(1, 1, i);
+        XK_PIN();
+    };
+
+    const int t_end = a.S / XK;
+    __syncthreads();
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_tile(1, 1);
+    XK_ISSUE_L(vLa, vDa, 0, 0, 0);
+    XK_ISSUE_L(vLa, vDa, 0, 1, 0);
+    XK_ISSUE_R(0, 0, 0);
+    XK_ISSUE_R(0, 0, 1);
+    for (int t = 0; t < t_end; t += 2) {
+        tile(I0{}, t, true, t + 2 < t_end);
+        tile(I1{}, t + 1, t + 2 < t_end, t + 3 < t_end);
+    }
+#undef XK_PIN
+#undef XK_WAIT
+#undef XK_RREAD
+#undef XK_TREAD
+#undef XK_VREAD
+#undef XK_ISSUE_R
+#undef XK_ISSUE_T
+#undef XK_ISSUE_L
+    auto store = [&](uint16_t* base, int64_t ld, const xf32x16_t (&acc)[ND], float mul, bool scaled) {
+        uint16_t* orow = base + ((int64_t)b * a.S + myrow) * ld + head * AD;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint2 w;
+                if (scaled) {
+                    w.x = pack_bf16x2(mul * acc[dt][4 * j + 0], mul * acc[dt][4 * j + 1]);
+                    w.y = pack_bf16x2(mul * acc[dt][4 * j + 2], mul * acc[dt][4 * j + 3]);
+                } else {
+                    w.x = pack_bf16x2(acc[dt][4 * j + 0], acc[dt][4 * j + 1]);
+                    w.y = pack_bf16x2(acc[dt][4 * j + 2], acc[dt][4 * j + 3]);
+                }
+                *reinterpret_cast<uint2*>(orow + 32 * dt + 8 * j + 4 * h) = w;
+            }
+    };
+    store(a.dK, a.lddk, acc0, a.sm_scale, true);
+    store(a.dV, a.lddv, acc1, 1.0f, false);
+}
+
 }  // namespace ar
 
 extern "C" int64_t ar_attn_bwd_exact_workspace_bytes(int64_t B, int64_t S, int64_t H) { return 2 * B * S * H * (int64_t)sizeof(float); }
@@ -854,7 +1178,13 @@ extern "C" int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, co
         if (attr1.first())
             (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 4, 128, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + 2 * 4096 * (int)sizeof(float));
         const int grid4 = (int)(B * H * (S / 128));
-        hipLaunchKernelGGL((k_xattn_bwd<1, 4, 128, 3, 1>), grid4, 256, LDS_T128 + vec, s, a);
+        if (g_xattn_cfg & 16) hipLaunchKernelGGL((k_xattn_bwd<1, 4, 128, 3, 1>), grid4, 256, LDS_T128 + vec, s, a);
+        else {                                            // the same kernel software-pipelined by hand
+            static PerDeviceOnce attr2;
+            if (attr2.first())
+                (void)hipFuncSetAttribute((const void*)k_xattn_bwd_kv<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + 2 * 4096 * (int)sizeof(float));
+            hipLaunchKernelGGL((k_xattn_bwd_kv<128>), grid4, 256, LDS_T128 + vec, s, a);
+        }
         if (S % 256) hipLaunchKernelGGL((k_xattn_bwd<0, 4, 128>), grid4, 256, LDS_T128, s, a);
         else hipLaunchKernelGGL((k_xattn_bwd<0, 8, 128>), (int)(B * H * (S / 256)), 512, LDS_T128, s, a);
         return launch_status();
