@@ -64,6 +64,36 @@ __device__ __forceinline__ void xhalves(float x, float& lo, float& hi) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
 }
 
+// blockIdx -> (block of own rows, batch * heads + head).  Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its
+// own 4 MB L2: the workgroups that stream the SAME rows -- forward / dQ: the kv_rep query heads x all row blocks of one key head
+// (K, V: 1 MB at S = 2048, head size 128); dK / dV: all row blocks of one query head (Q, dO) -- are made neighbours in time on ONE
+// XCD, so a stream crosses the fabric once per group instead of once per workgroup.  Measured (profiles/r06_attn_xcd_map_ab.json):
+// the backward 5.07 -> 4.67 ms at 64 query heads over 8 key heads (Llama-3-70B's block), 2.51 -> 2.33 ms at 32 heads without
+// grouping, the forward 0.81 -> 0.73 there; neutral at Llama-3-8B's 32 / 8 and at head size 64, whose streams already fit the
+// 256 MB Infinity Cache behind the L2s -- the kernels are not bound by this traffic.
+__device__ __forceinline__ void xattn_map(int bid, int n_ob, int B, int H, int kv_rep, bool by_kv, bool legacy, int& ob, int& bh) {
+    const int members = by_kv ? kv_rep * n_ob : n_ob;
+    const int groups = by_kv ? B * (H / kv_rep) : B * H;
+    if (!legacy && (groups & 7) == 0) {
+        const int j = bid >> 3, g = (j / members) * 8 + (bid & 7), m = j % members;
+        if (by_kv) {
+            const int hk = H / kv_rep;
+            bh = (g / hk) * H + (g % hk) * kv_rep + m % kv_rep;
+            ob = m / kv_rep;
+        } else {
+            bh = g;
+            ob = m;
+        }
+    } else if (((B * H) & 7) == 0) {
+        const int j = bid >> 3, per = (B * H) >> 3;
+        bh = (j % per) * 8 + (bid & 7);
+        ob = j / per;
+    } else {
+        ob = bid % n_ob;
+        bh = bid / n_ob;
+    }
+}
+
 struct XAttnArgs {
     const uint16_t* Q; const uint16_t* K; const uint16_t* V;
     uint16_t* O;                                                   // [B, S, H, D] token-major, contiguous
@@ -74,6 +104,7 @@ struct XAttnArgs {
     float qk_scale;                                                // fl(sm_scale * fl32(log2 e))
     float bias_in2, bias_out2;                                     // bf16(bias * bf16(log2 e)) inside / outside the kept region
     int valid_len;
+    int map_legacy;                                                // the blockIdx mapping before xattn_map (config bit 32; A/B)
 };
 
 template <int WAVES, int AD, int BN>
@@ -95,16 +126,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_xattn_fwd(XAttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, lq = lane & 31;
     const int n_qt = a.S / AQ;
-    const int n_bh = a.B * a.H;
     int qt, bh;
-    if ((n_bh & 7) == 0) {               // whole heads per XCD (ar_attn.hip)
-        const int j = blockIdx.x >> 3, per = n_bh >> 3;
-        bh = (j % per) * 8 + (int)(blockIdx.x & 7);
-        qt = j / per;
-    } else {
-        qt = (int)(blockIdx.x % n_qt);
-        bh = blockIdx.x / n_qt;
-    }
+    xattn_map((int)blockIdx.x, n_qt, a.B, a.H, a.kv_rep, true, a.map_legacy != 0, qt, bh);
     const int b = bh / a.H, head = bh % a.H, kvh = head / a.kv_rep;
     const int q0 = qt * AQ;
     const uint16_t* Qb = a.Q + (int64_t)b * a.q_bs + (int64_t)head * a.q_hs;
@@ -358,7 +381,7 @@ using namespace ar;
 // launch forms (equal results; measured A/B, profiles/r06_attn_exact_waves_ab.json): bits 0-1 forward, bits 2-3 backward -- 0 default
 // (forward: 8 waves at head size 128, 4 at 64; backward: head size 128 the fused key-side kernel on 4 waves + the 8-wave query-side
 // kernel, head size 64 4 waves), 1 = workgroups of 4 waves (128 own rows), 2 = workgroups of 8 waves (256 own rows; head size 128: the
-// key side as two kernels), 3 (backward) = the fused key-side kernel; bit 4 (16): the fused key-side kernel WITHOUT the hand pipeline
+// key side as two kernels), 3 (backward) = the fused key-side kernel; bit 4 (16): the fused key-side kernel WITHOUT the hand pipeline; bit 5 (32): the blockIdx mapping before xattn_map
 static int g_xattn_cfg = 0;
 extern "C" int ar_attn_exact_config(int cfg) {
     const int old = g_xattn_cfg;
@@ -392,6 +415,7 @@ extern "C" int ar_attn_fwd_exact(const void* Q, const void* K, const void* V, vo
     a.v_bs = v_strides[0]; a.v_hs = v_strides[1]; a.v_ts = v_strides[2];
     a.qk_scale = scale * 1.44269502162933349609375f;        // fp32 product with fl32(log2 e) = 0x3fb8aa3b, as the library computes it
     a.bias_in2 = bias_log2e_bf16(bias_in); a.bias_out2 = bias_log2e_bf16(bias_out); a.valid_len = (int)valid_len;
+    a.map_legacy = (g_xattn_cfg & 32) ? 1 : 0;
     constexpr int LDS128 = 4 * XK * 128 * 2, LDS64 = 4 * XK * 64 * 2;
     static PerDeviceOnce attr;
     if (attr.first()) {
@@ -462,6 +486,7 @@ struct XBwdArgs {
     float sm_scale, qk_scale;
     float bias_in_s, bias_out_s;                                   // fl(bias * bias_scale)
     int valid_len;
+    int map_legacy;
 };
 
 // delta and l2 per (batch, head, token) row (the library's bwd_preprocess order; l2 as bwd_kernel_* compute it)
@@ -522,16 +547,8 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void k_xattn_bwd(XBwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, lq = lane & 31;
     const int n_ob = a.S / AQ;
-    const int n_bh = a.B * a.H;
     int ob, bh;
-    if ((n_bh & 7) == 0) {
-        const int j = blockIdx.x >> 3, per = n_bh >> 3;
-        bh = (j % per) * 8 + (int)(blockIdx.x & 7);
-        ob = j / per;
-    } else {
-        ob = (int)(blockIdx.x % n_ob);
-        bh = blockIdx.x / n_ob;
-    }
+    xattn_map((int)blockIdx.x, n_ob, a.B, a.H, a.kv_rep, MODE == 0, a.map_legacy != 0, ob, bh);
     const int b = bh / a.H, head = bh % a.H, kvh = head / a.kv_rep;
     const int o0 = ob * AQ;
     const int myrow = o0 + 32 * wave + lq;
@@ -815,16 +832,8 @@ __global__ __launch_bounds__(256, 1) void k_xattn_bwd_kv(XBwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, lq = lane & 31;
     const int n_ob = a.S / AQ;
-    const int n_bh = a.B * a.H;
     int ob, bh;
-    if ((n_bh & 7) == 0) {
-        const int j = blockIdx.x >> 3, per = n_bh >> 3;
-        bh = (j % per) * 8 + (int)(blockIdx.x & 7);
-        ob = j / per;
-    } else {
-        ob = (int)(blockIdx.x % n_ob);
-        bh = blockIdx.x / n_ob;
-    }
+    xattn_map((int)blockIdx.x, n_ob, a.B, a.H, a.kv_rep, false, a.map_legacy != 0, ob, bh);
     const int b = bh / a.H, head = bh % a.H, kvh = head / a.kv_rep;
     const int o0 = ob * AQ;
     const int myrow = o0 + 32 * wave + lq;
@@ -1156,6 +1165,7 @@ extern "C" int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, co
     a.qk_scale = scale * 1.44269502162933349609375f;
     const float bias_scale = 1.0f / scale;                 // correctly rounded (the library: v_div_scale / v_div_fmas / v_div_fixup)
     a.bias_in_s = bias_in * bias_scale; a.bias_out_s = bias_out * bias_scale; a.valid_len = (int)valid_len;
+    a.map_legacy = (g_xattn_cfg & 32) ? 1 : 0;
     constexpr int LDS_T = 4 * XK * 64 * 2, LDS_T128 = 4 * XK * 128 * 2;
     const int vec = (int)(2 * S * sizeof(float));
     static PerDeviceOnce attr;

@@ -1,0 +1,46 @@
+"""The exact attention kernels with the blockIdx -> (row block, head) mapping that keeps the workgroups of one K / V (or Q / dO) stream
+together on one XCD (xattn_map) against the mapping before it (config bit 32), and the key-side kernel with / without the hand
+pipeline (bit 16): equal results, time per call."""
+import json, os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from auto_round_amd import ops, _lib
+lib = _lib.load()
+torch.manual_seed(0)
+res = []
+def tm(f, n=20):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+shapes = [(8, 32, 2048, 128, 8, 2047), (8, 12, 2048, 64, 12, 2047), (8, 64, 2048, 128, 8, 2047), (2, 32, 512, 128, 8, 500), (1, 16, 4096, 128, 16, 4000),
+          (3, 12, 640, 64, 12, 600), (8, 32, 2048, 128, 32, 2047)]
+for (B, H, S, D, hk, valid) in shapes:
+    scale = D ** -0.5
+    q = torch.randn(B, S, H, D, device="cuda").to(torch.bfloat16).transpose(1, 2)
+    k = torch.randn(B, S, hk, D, device="cuda").to(torch.bfloat16).transpose(1, 2)
+    v = torch.randn(B, S, hk, D, device="cuda").to(torch.bfloat16).transpose(1, 2)
+    idx = torch.arange(S, device="cuda")
+    keep = (idx[None, :] <= idx[:, None]) & (idx[None, :] < valid)
+    mask = keep.to(torch.bfloat16)[None, None].expand(B, 1, S, S).contiguous()
+    st = ops.mask_structure(mask, S)
+    da = (torch.randn(B, S, H, D, device="cuda") * 0.02).to(torch.bfloat16)
+    rec = {"shape": [B, H, S, D, hk], "valid_len": valid}
+    outs = {}
+    with torch.no_grad():
+        for name, cfg in (("old_map_phases", 32 | 16), ("old_map", 32), ("new_map_phases", 16), ("new_map", 0)):
+            lib.ar_attn_exact_config(cfg)
+            o, lse = ops.attn_fwd_exact(q, k, v, st, scale)
+            g = ops.attn_bwd_exact(q, k, v, o, lse, da, st, scale)
+            outs[name] = [o.clone(), lse.clone()] + [t.clone() for t in g]
+            rec[name + "_fwd_ms"] = round(tm(lambda: ops.attn_fwd_exact(q, k, v, st, scale)), 4)
+            rec[name + "_bwd_ms"] = round(tm(lambda: ops.attn_bwd_exact(q, k, v, o, lse, da, st, scale)), 4)
+        lib.ar_attn_exact_config(0)
+    base = outs["old_map_phases"]
+    rec["all_equal"] = all(all(torch.equal(a, b) for a, b in zip(base, outs[n])) for n in outs)
+    print(json.dumps(rec), flush=True)
+    res.append(rec)
+out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r06")
+os.makedirs(out, exist_ok=True)
+json.dump(res, open(os.path.join(out, "attn_xcd_map_ab.json"), "w"), indent=1)
