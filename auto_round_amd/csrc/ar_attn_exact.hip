@@ -381,11 +381,11 @@ using namespace ar;
 // launch forms (equal results; measured A/B, profiles/r06_attn_exact_waves_ab.json): bits 0-1 forward, bits 2-3 backward -- 0 default
 // (forward: 8 waves at head size 128, 4 at 64; backward: head size 128 the fused key-side kernel on 4 waves + the 8-wave query-side
 // kernel, head size 64 4 waves), 1 = workgroups of 4 waves (128 own rows), 2 = workgroups of 8 waves (256 own rows; head size 128: the
-// key side as two kernels), 3 (backward) = the fused key-side kernel; bit 4 (16): the fused key-side kernel WITHOUT the hand pipeline; bit 5 (32): the blockIdx mapping before xattn_map
+// key side as two kernels), 3 (backward) = the fused key-side kernel; bit 4 (16): the fused key-side kernel WITHOUT the hand pipeline; bit 5 (32): the blockIdx mapping before xattn_map; bit 6 (64): head size 64's key side on the pipelined kernel (slower: A/B)
 static int g_xattn_cfg = 0;
 extern "C" int ar_attn_exact_config(int cfg) {
     const int old = g_xattn_cfg;
-    if (cfg >= 0) g_xattn_cfg = cfg & 63;
+    if (cfg >= 0) g_xattn_cfg = cfg & 127;
     return old;
 }
 
@@ -1206,6 +1206,13 @@ extern "C" int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, co
             hipLaunchKernelGGL((k_xattn_bwd<1, 4, 128, 2>), grid4, 256, LDS_T128 + vec, s, a);
             hipLaunchKernelGGL((k_xattn_bwd<0, 4, 128>), grid4, 256, LDS_T128, s, a);
         } else {
+            if (g_xattn_cfg & 64) {                       // A/B only: the hand-pipelined key-side kernel at head size 64 (one wave per SIMD) is
+                                                          // SLOWER than two phase-kernel workgroups per CU: 0.56 against 0.45 ms per backward call
+                static PerDeviceOnce attr64;
+                if (attr64.first())
+                    (void)hipFuncSetAttribute((const void*)k_xattn_bwd_kv<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T + 2 * 4096 * (int)sizeof(float));
+                hipLaunchKernelGGL((k_xattn_bwd_kv<64>), grid4, 256, LDS_T + vec, s, a);
+            } else
             hipLaunchKernelGGL((k_xattn_bwd<1, 4, 64>), grid4, 256, LDS_T + vec, s, a);
             hipLaunchKernelGGL((k_xattn_bwd<0, 4, 64>), grid4, 256, LDS_T, s, a);
         }

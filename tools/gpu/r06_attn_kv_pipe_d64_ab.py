@@ -1,0 +1,34 @@
+import json, os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from auto_round_amd import ops, _lib
+lib = _lib.load()
+torch.manual_seed(0)
+def tm(f, n=30):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+for (B, H, S, D, hk, valid) in [(8, 12, 2048, 64, 12, 2047), (8, 12, 2048, 64, 12, 1500), (3, 12, 640, 64, 12, 600), (8, 16, 2048, 64, 16, 2047)]:
+    scale = 1.0
+    q = (torch.randn(B, S, H, D, device="cuda") * 0.35).to(torch.bfloat16).transpose(1, 2)
+    k = (torch.randn(B, S, hk, D, device="cuda") * 0.35).to(torch.bfloat16).transpose(1, 2)
+    v = torch.randn(B, S, hk, D, device="cuda").to(torch.bfloat16).transpose(1, 2)
+    idx = torch.arange(S, device="cuda")
+    keep = (idx[None, :] <= idx[:, None]) & (idx[None, :] < valid)
+    mask = keep.to(torch.bfloat16)[None, None].expand(B, 1, S, S).contiguous()
+    st = ops.mask_structure(mask, S)
+    da = (torch.randn(B, S, H, D, device="cuda") * 0.02).to(torch.bfloat16)
+    rec = {"shape": [B, H, S, D, hk]}
+    outs = {}
+    with torch.no_grad():
+        o, lse = ops.attn_fwd_exact(q, k, v, st, scale)
+        for name, cfg in (("phases", 0), ("pipelined", 64)):
+            lib.ar_attn_exact_config(cfg)
+            g = ops.attn_bwd_exact(q, k, v, o, lse, da, st, scale)
+            outs[name] = [t.clone() for t in g]
+            rec[name + "_bwd_ms"] = round(tm(lambda: ops.attn_bwd_exact(q, k, v, o, lse, da, st, scale)), 4)
+        lib.ar_attn_exact_config(0)
+    rec["differing"] = [int((a.view(torch.int16) != b.view(torch.int16)).sum()) for a, b in zip(outs["phases"], outs["pipelined"])]
+    print(json.dumps(rec), flush=True)
