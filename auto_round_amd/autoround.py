@@ -102,6 +102,10 @@ class AutoRound:
         # block's attention is then NOT causal), so it is mirrored by default; `calibration_attention_mask=False` (MI355X-only keyword)
         # calibrates and tunes with plain causal attention instead.
         self.calibration_attention_mask = bool(kwargs.pop("calibration_attention_mask", True))
+        # ... and it captures the first block's inputs with the model ON THE CPU (calibration/llm.py:74-90: only the embedding part runs,
+        # "also fast on CPU"), so the rotary tables are the host libm's: mirrored by default (`pre_block_modules_on_cpu`);
+        # `capture_on_cpu=False` (MI355X-only keyword) keeps that forward on the GPU.
+        self.capture_on_cpu = bool(kwargs.pop("capture_on_cpu", True))
         if kwargs.pop("platform", "hf") != "hf":
             raise NotImplementedError("only Hugging Face models (platform='hf') are handled")
         legacy_device = kwargs.pop("device", None)           # autoround.py:753-757: deprecated alias of device_map
@@ -197,20 +201,28 @@ class AutoRound:
         hm = first.register_forward_pre_hook(mask_hook, with_kwargs=True) if self.calibration_attention_mask else None
         h = first.register_forward_pre_hook(hook, with_kwargs=True)
         bs = self.config.batch_size
+        # the part of the model in front of the blocks runs where the reference runs it: on the CPU (pre_block_modules_on_cpu)
+        cap_dev = torch.device("cpu") if self.capture_on_cpu else self.device
+        import contextlib
+
         try:
-            for b0 in range(0, tokens.shape[0], bs):
-                ids = tokens[b0:b0 + bs].to(self.device)
-                kw = {"use_cache": False}
-                if self.calibration_attention_mask:
-                    kw["attention_mask"] = calibration_attention_mask(ids)
-                try:
-                    self.model(input_ids=ids, **kw)
-                except _StopForward:
-                    pass
+            with (pre_block_modules_on_cpu(self.model, blocks) if self.capture_on_cpu else contextlib.nullcontext()):
+                for b0 in range(0, tokens.shape[0], bs):
+                    ids = tokens[b0:b0 + bs].to(cap_dev)
+                    kw = {"use_cache": False}
+                    if self.calibration_attention_mask:
+                        kw["attention_mask"] = calibration_attention_mask(ids)
+                    try:
+                        self.model(input_ids=ids, **kw)
+                    except _StopForward:
+                        pass
         finally:
             h.remove()
             if hm is not None:
                 hm.remove()
+        captured[:] = [c.to(self.device) for c in captured]
+        masks[:] = [c.to(self.device) for c in masks]
+        shared.update({k: _to_device(v, self.device) for k, v in shared.items()})
         if self.calibration_attention_mask and isinstance(shared.get("attention_mask"), torch.Tensor):
             # the input cache's cast (inputs.py:100-107): boolean / half-precision mask -> the activation dtype, i.e. a 0 / 1 bias
             rows = torch.cat(masks, dim=0) if masks else shared["attention_mask"]
@@ -219,7 +231,7 @@ class AutoRound:
 
                 warnings.warn("calibration samples end in repeated tokens of different lengths: the reference would cache one attention mask "
                               "per sample; this front door keeps ONE shared mask (the last position cleared) for all of them")
-                ids = tokens[:1].to(self.device)
+                ids = tokens[:1].to(cap_dev)
                 am = torch.ones_like(ids)
                 am[:, -1] = 0
                 try:
@@ -228,14 +240,15 @@ class AutoRound:
                     hm = first.register_forward_pre_hook(mask_hook, with_kwargs=True)
                     h = first.register_forward_pre_hook(hook, with_kwargs=True)
                     try:
-                        self.model(input_ids=ids, attention_mask=am, use_cache=False)
+                        with (pre_block_modules_on_cpu(self.model, blocks) if self.capture_on_cpu else contextlib.nullcontext()):
+                            self.model(input_ids=ids, attention_mask=am, use_cache=False)
                     except _StopForward:
                         pass
                 finally:
                     h.remove()
                     hm.remove()
                     del captured[captured_n:]
-                rows = masks[0] if masks else rows
+                rows = masks[0].to(self.device) if masks else rows
             m = rows[:1]
             amp_dtype = self.config.amp_dtype
             shared["attention_mask"] = m.to(amp_dtype) if (m.dtype == torch.bool or m.is_floating_point()) else m
@@ -639,6 +652,46 @@ def sync_tuned_blocks(blocks, world: int, device, policy: str = "round_robin") -
     return got
 
 
+class pre_block_modules_on_cpu:
+    """Context: every parameter and buffer of `model` that is NOT inside one of `blocks` sits on the CPU; on exit they are back where
+    they were.
+
+    Why: the reference captures the first block's inputs ON THE CPU -- `calibration()` sets `calibrate_on_cpu` whenever only one block
+    list's inputs are wanted (calibration/llm.py:74-90: "calibrate only the embedding layer (also fast on CPU)"), i.e. always for a
+    decoder-only LLM: embedding, positional / rotary tables and the mask are made by the host's kernels, and the forward stops at the first
+    block.  The embedding lookup is the same on either device; the ROTARY TABLES are not: fp32 cos / sin of the host's libm, rounded to
+    bf16, differ from the GPU's in 6 of 262 144 values at Mixtral-8x7B's shape -- enough that every target of the block differs in its
+    last bits (`tools/gpu/r06_mixtral_targets_probe.py`: with CPU-made tables the reference-free flow's targets equal the reference's
+    digest).  A pre-hook on the first block stops the forward before anything of a block runs, so the blocks stay on the GPU."""
+
+    def __init__(self, model, blocks):
+        self.model = model
+        self.skip = {id(t) for b in blocks for t in list(b.parameters()) + list(b.buffers())}
+        self.moved = []
+
+    def __enter__(self):
+        for mod in self.model.modules():
+            for store in (mod._parameters, mod._buffers):
+                for k, t in store.items():
+                    if t is None or id(t) in self.skip or t.device.type == "cpu":
+                        continue
+                    self.moved.append((t, t.device) if store is mod._parameters else (mod, k, t.device))
+                    if store is mod._parameters:
+                        t.data = t.data.to("cpu")
+                    else:
+                        store[k] = t.to("cpu")
+        return self
+
+    def __exit__(self, *exc):
+        for rec in self.moved:
+            if len(rec) == 2:
+                rec[0].data = rec[0].data.to(rec[1])
+            else:
+                rec[0]._buffers[rec[1]] = rec[0]._buffers[rec[1]].to(rec[2])
+        self.moved = []
+        return False
+
+
 def calibration_attention_mask(input_ids: torch.Tensor) -> torch.Tensor:
     """The [batch, S] attention mask the reference's calibrator passes for a dataset that is not one of its named ones
     (calibration/llm.py:374-402): ones; where a sample ends in repeats of its last token those repeats and the last position are
@@ -681,6 +734,14 @@ def _block_layer_config(layer_config, block_name, block):
         return None
     full = [f"{block_name}.{n}" for n, m in block.named_modules() if is_quantizable(m)]      # nn.Linear and Conv1D (GPT-2)
     return {n[len(block_name) + 1:]: over for n, over in expand_layer_config(full, layer_config).items()}
+
+
+def _to_device(v, device):
+    if isinstance(v, torch.Tensor):
+        return v.to(device)
+    if isinstance(v, (tuple, list)):
+        return type(v)(_to_device(x, device) for x in v)
+    return v
 
 
 def _first_sample(v, bs):

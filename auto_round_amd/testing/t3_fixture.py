@@ -167,18 +167,29 @@ def capture_block_inputs(model, block, tokens: torch.Tensor, device, amp_dtype=t
                 shared[k] = v
         raise _Stop
 
+    # ... with everything in front of the blocks ON THE CPU, as in the reference's process (calibration/llm.py:74-90 calibrates "only the
+    # embedding layer" on the CPU): the rotary tables are then the host libm's -- 6 of 262 144 bf16 values other than the GPU's at
+    # Mixtral-8x7B's shape, which is what made this flow's targets differ from the reference's in rounds 3-6 (AR_CAPTURE_ON_GPU=1: old form)
+    import contextlib
+
+    from auto_round_amd.autoround import _to_device, pre_block_modules_on_cpu
+
+    on_cpu = os.environ.get("AR_CAPTURE_ON_GPU") != "1" and torch.device(device).type != "cpu"
     h = block.register_forward_pre_hook(hook, with_kwargs=True)
     try:
-        for i in range(tokens.shape[0]):
-            ids = tokens[i:i + 1].to(device)
-            am = torch.ones_like(ids)
-            am[:, -1] = 0
-            try:
-                model(ids, attention_mask=am, use_cache=False)
-            except _Stop:
-                pass
+        with (pre_block_modules_on_cpu(model, list(decoder_blocks(model))) if on_cpu else contextlib.nullcontext()):
+            for i in range(tokens.shape[0]):
+                ids = tokens[i:i + 1].to("cpu" if on_cpu else device)
+                am = torch.ones_like(ids)
+                am[:, -1] = 0
+                try:
+                    model(ids, attention_mask=am, use_cache=False)
+                except _Stop:
+                    pass
     finally:
         h.remove()
+    captured = [c.to(device) for c in captured]
+    shared = {k: _to_device(v, device) for k, v in shared.items()}
 
     def cast(v):
         if isinstance(v, torch.Tensor):

@@ -297,11 +297,14 @@ def test_exact_rounding_stays_on_the_module_paths_bits_over_configs2s_1000_itera
 #     mask being handed over as one broadcastable row instead of the reference's concatenated [8, 1, S, S] (the library's head-size-64
 #     attention then takes another kernel).  Claimed first; a run that parts is repeated once (warned about), then held to the floor
 #     recorded on runs that did part (0.87 in round 3, 0.909 in BENCH_r04).
-#   * Mixtral: the reference-free flow's TARGETS differ from the reference's in their last bits -- same parameters, same inputs, same
-#     mask, identical q / k / v projections, and the library attention returns 0.7 % other values inside the reference's process
-#     (profiles/r05_t3_mixtral_forward_compare_*.json; the router then sends a few tokens elsewhere) -- so this flow is held to the
-#     trajectory level the round's measurements give (MXFP4 0.957, NVFP4 0.774 identical weights; loss within 0.7 %), with
-#     `targets_identical` reported, not asserted.  Bit identity at this shape is the builder-side plugin result above.
+#   * Mixtral: BIT-IDENTICAL since the end of round 6.  Rounds 3-6 held this flow to the trajectory level (MXFP4 0.957, NVFP4 0.774
+#     identical weights) because its TARGETS differed from the reference's in their last bits -- same parameters, same inputs, same mask,
+#     identical q / k / v projections, 0.7 % other attention outputs -- and the library attention was suspected.  It was the ROTARY TABLES:
+#     the reference captures the first block's inputs with the model on the CPU (calibration/llm.py:74-90, "calibrate only the embedding
+#     layer (also fast on CPU)"), so cos / sin are the host libm's, 6 of 262 144 bf16 values other than the GPU's
+#     (tools/gpu/r06_mixtral_targets_probe.py: of 8 candidate causes only CPU-made tables reproduce the fixture's target digest).  The
+#     capture forward of the flow and of the front door now runs there too (autoround.pre_block_modules_on_cpu), and both reference-made
+#     fixtures are reproduced bit for bit: targets, the 100-iteration loss trace, all 56 tuned tensors.
 def _t3s_fixtures():
     import glob
 
@@ -309,9 +312,10 @@ def _t3s_fixtures():
     return sorted(glob.glob(os.path.join(here, "golden", "t3s_*.npz")))
 
 
-# (Mixtral: measured 0.9574 / 0.7741 on the module path and 0.957 / 0.771 on the fused path in every suite run of rounds 5 and 6 -- the
-#  targets differ from the reference's deterministically, so the fractions repeat; the floors sit 1.5 points under them)
-MODULE_FLOOR = {"opt125m_w4g128": 0.80, "mixtral8x7b_mxfp4_100": 0.94, "mixtral8x7b_nvfp4_100": 0.76}
+# (the fused MoE path -- other rounding points than the module code -- measured 0.957 / 0.771-0.773 identical weights in every suite run of
+#  rounds 5 and 6; its floors sit 1.5 points under that, VERDICT r05 weak #2.  The module path has no Mixtral floor any more: it is asserted
+#  bit-identical.)
+MODULE_FLOOR = {"opt125m_w4g128": 0.80}
 FUSED_FLOOR = {"mixtral8x7b_mxfp4_100": 0.94, "mixtral8x7b_nvfp4_100": 0.755}
 
 
@@ -343,10 +347,9 @@ def test_module_path_reproduces_reference_run_1_of_the_two_run_fixtures(path, re
             return
         warnings.warn(f"[t3s] STATISTICAL {name} module path: none of 5 runs reproduced reference run 1; held to the floor instead: "
                       f"{r['prefix_identical_codes']:.4f} identical codes")
-    elif not r["targets_identical"]:
-        warnings.warn(f"[t3s] {name} module path: the reference-free flow's targets differ from the reference's in their last bits (library "
-                      f"attention, see the note above the test): trajectory level, {r['prefix_identical_codes']:.4f} identical weights")
-    elif r["bit_identical"]:
+    else:       # Mixtral: the reference's targets, loss trace and every tuned tensor, bit for bit
+        assert r["targets_identical"] and r["bit_identical"] and r["tensors_identical"] == r["tensors"], _full(r)
+        assert r["first_divergence_iter"] is None and abs(r["best_loss_ratio"] - 1.0) < 1e-5, _full(r)
         return
     assert r["prefix_identical_codes"] >= MODULE_FLOOR[name], _full(r)
     assert abs(r["init_loss"] - r["init_loss_ref"]) <= 2e-3 * r["init_loss_ref"], _full(r)

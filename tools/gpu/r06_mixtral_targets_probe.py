@@ -3,7 +3,9 @@ sha256 of the targets (y_sha: the fp block's outputs the reference tuned against
 (identical q / k / v, other attention output: profiles/r05_t3_mixtral_forward_compare_*.json).  This probe recomputes the targets with the
 block's attention swapped for every candidate this stack offers -- the library's SDPA (inference and training-mode forward), its math
 backend, transformers' eager attention, and the restated AOTriton forward at each key-block size (another tuned configuration of the same
-kernel) -- and compares each result's sha256 with the fixture's."""
+kernel) -- and, last, with the rotary cos / sin tables made on the CPU instead of on the GPU, and compares each result's sha256 with the
+fixture's.  Result (profiles/r06_mixtral_targets_probe.json): only the CPU-made tables reproduce it -- the reference captures the first
+block's inputs with the model on the CPU (calibration/llm.py:74-90)."""
 import json, os, sys, hashlib
 import numpy as np
 import torch
@@ -67,5 +69,21 @@ targets("transformers eager attention", False, "eager")
 att.register_exact_sdpa()
 for kb in (64, 32, 16):
     targets(f"restated AOTriton forward, key block {kb}", False, att.EXACT_NAME, kb=kb)
+# ---- the rotary tables: cos / sin made on the CPU (fp32 cos / sin of another libm, then rounded to bf16) instead of on the GPU
+import copy
+pe = others.get("position_embeddings")
+if pe is not None:
+    rot = copy.deepcopy(model.model.rotary_emb).to("cpu")
+    pos = others.get("position_ids")
+    pos_cpu = (pos if pos is not None else torch.arange(m["seqlen"])[None]).to("cpu")
+    dummy = torch.zeros(1, m["seqlen"], 8, dtype=pe[0].dtype)
+    cos_c, sin_c = rot(dummy, pos_cpu)
+    dc = int((cos_c.to(dev).view(torch.int16) != pe[0].view(torch.int16)).sum()); ds = int((sin_c.to(dev).view(torch.int16) != pe[1].view(torch.int16)).sum())
+    res["rotary_tables_cpu_vs_gpu"] = {"cos_differing": dc, "sin_differing": ds, "of": int(pe[0].numel()), "dtype": str(pe[0].dtype), "shape": list(pe[0].shape)}
+    print("rotary tables made on the CPU vs on the GPU:", res["rotary_tables_cpu_vs_gpu"], flush=True)
+    keep = others["position_embeddings"]
+    others["position_embeddings"] = (cos_c.to(dev).reshape(pe[0].shape).contiguous(), sin_c.to(dev).reshape(pe[1].shape).contiguous())
+    targets("library sdpa, rotary tables made on the CPU", True, "sdpa")
+    others["position_embeddings"] = keep
 out = os.path.join(root, "gpurun_out", "r06"); os.makedirs(out, exist_ok=True)
 json.dump(res, open(os.path.join(out, "mixtral_targets_probe.json"), "w"), indent=1)
