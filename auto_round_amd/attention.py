@@ -28,8 +28,35 @@ def _sdpa_signature(query, key, value, kw):
             kw.get("scale"), bool(kw.get("enable_gqa", False)))
 
 
+# (signature) -> True: the restated forward (csrc/ar_attn_exact.hip) returned the library's bits for this kind of call
+_EXACT_FORWARD_PROVEN: dict = {}
+nograd_state = {"exact_calls": 0, "library_calls": 0}
+
+
+def _exact_nograd_forward(query, key, value, kw):
+    """The no-grad SDPA call on ar_attn_fwd_exact when it is one that kernel restates (additive mask with the calibration flow's structure,
+    head size 64 / 128, S % 128 == 0): [B, H, S, D] like the library's result, or None."""
+    from . import ops
+
+    m = kw.get("attn_mask")
+    if m is None or kw.get("is_causal") or kw.get("enable_gqa") or query.dim() != 4:
+        return None
+    B, H, S, D = query.shape
+    if not (query.dtype == torch.bfloat16 and key.dtype == query.dtype and value.dtype == query.dtype and D in (64, 128) and S % 128 == 0
+            and 128 <= S <= 4096 and key.shape[2] == S and value.shape == key.shape and H % key.shape[1] == 0
+            and all(t.stride(3) == 1 and not any(x % 8 for x in t.stride()[:3]) and t.data_ptr() % 16 == 0 for t in (query, key, value))):
+        return None
+    st = ops.mask_structure(m, S)
+    if st is None:
+        return None
+    scale = kw.get("scale")
+    got = ops.attn_fwd_exact(query, key, value, st, float(scale) if scale is not None else D ** -0.5,
+                             key_block=ops.attn_key_block_guess(int(D), int(S)))
+    return None if got is None else got[0].transpose(1, 2)
+
+
 @contextlib.contextmanager
-def reproducible_sdpa_forward(enabled: bool = True):
+def reproducible_sdpa_forward(enabled: bool = True, exact: bool = True):
     """Every NO-GRAD `F.scaled_dot_product_attention` call inside the context runs the library's TRAINING-mode forward (the one that
     also writes the log-sum-exp rows) instead of its inference-mode forward.
 
@@ -44,7 +71,12 @@ def reproducible_sdpa_forward(enabled: bool = True):
 
     Nothing is assumed about other shapes: the first call of every distinct signature runs BOTH forms and compares them bit for bit
     (once more if they differ: the inference form may just have slipped); a signature whose two forms differ keeps the inference form,
-    with a warning."""
+    with a warning.
+
+    `exact` (end of round 6): where the restated forward kernel (csrc/ar_attn_exact.hip: the library's bits, no cross-workgroup state,
+    so no race) takes the call, and its result equalled the library's on the first call of the signature, later calls run on it.  The
+    training-mode forward is rarely wrong too at head size 128 -- 1 of 16 Llama-3-8B full-recipe runs computed other TARGETS
+    (tools/gpu/r06_parity_repeat.py) -- and a block's targets are what the whole tuning run is measured against."""
     if not enabled:
         yield
         return
@@ -62,6 +94,28 @@ def reproducible_sdpa_forward(enabled: bool = True):
                 or kw.get("dropout_p", 0.0) or len(a) > 0:
             return real(query, key, value, *a, **kw)
         sig = _sdpa_signature(query, key, value, kw)
+        if exact:
+            xok = _EXACT_FORWARD_PROVEN.get(sig)
+            if xok is not False:
+                o_x = _exact_nograd_forward(query, key, value, kw)
+                if o_x is None:
+                    if xok is None:
+                        _EXACT_FORWARD_PROVEN[sig] = False
+                elif xok:
+                    nograd_state["exact_calls"] += 1
+                    return o_x.contiguous()
+                else:       # first call of the signature: the restated kernel against the library (which may slip: up to three comparisons)
+                    same = False
+                    for _ in range(3):
+                        o_l = training_forward(query, key, value, a, kw)
+                        if o_l.shape == o_x.shape and torch.equal(o_l.contiguous().view(torch.int16), o_x.contiguous().view(torch.int16)):
+                            same = True
+                            break
+                    _EXACT_FORWARD_PROVEN[sig] = same
+                    if same:
+                        nograd_state["exact_calls"] += 1
+                        return o_x.contiguous()
+        nograd_state["library_calls"] += 1
         ok = _TRAINING_FORWARD_PROVEN.get(sig)
         if ok is None:
             same = False

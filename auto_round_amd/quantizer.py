@@ -1117,7 +1117,8 @@ class SignRoundQuantizer:
         """No-grad forward of every cached sample in minibatches -> [N, S, H] (composer.py steps 3 and 6)."""
         from .attention import reproducible_sdpa_forward
 
-        with reproducible_sdpa_forward(bool(getattr(self.config, "reproducible_attention_forward", True))):
+        with reproducible_sdpa_forward(bool(getattr(self.config, "reproducible_attention_forward", True)),
+                                       exact=bool(getattr(self.config, "exact_attention", True))):
             return self._forward_all(block, inputs, input_others, batch_size)
 
     def _forward_all(self, block, inputs: torch.Tensor, input_others, batch_size: Optional[int] = None) -> torch.Tensor:

@@ -1,0 +1,20 @@
+"""Repeat the reference-free Mixtral module-path flow N times per fixture (optionally under another attention launch form:
+AR_XATTN_CFG = ar_attn_exact_config bits) and report, per run, whether the reference-made fixture was reproduced bit for bit."""
+import glob, json, os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from auto_round_amd.testing import t3_fixture as fx
+from auto_round_amd import _lib
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+which = sys.argv[2] if len(sys.argv) > 2 else "mixtral"
+cfg = int(os.environ.get("AR_XATTN_CFG", "0"))
+_lib.load().ar_attn_exact_config(cfg)
+res = []
+for path in sorted(glob.glob(os.path.join(root, "tests", "golden", f"t3s_{which}*.npz"))):
+    for i in range(N):
+        r = fx.check_against_stat_fixture(path)
+        rec = {"fixture": os.path.basename(path), "run": i, "attn_cfg": cfg, **{k: r[k] for k in ("targets_identical", "bit_identical", "tensors_identical", "first_divergence_iter", "prefix_identical_weights")}}
+        res.append(rec)
+        print(json.dumps(rec), flush=True)
+out = os.path.join(root, "gpurun_out", "r06"); os.makedirs(out, exist_ok=True)
+json.dump(res, open(os.path.join(out, f"mixtral_fixture_repeat_cfg{cfg}.json"), "w"), indent=1)
