@@ -20,6 +20,7 @@ The block's GEMMs/attention run through PyTorch-ROCm (hipBLASLt / SDPA on MFMA).
 from __future__ import annotations
 
 import contextlib
+import os
 import functools
 import copy
 import inspect
@@ -352,7 +353,8 @@ def _no_uninitialised_fill():
     buffer of every iteration.  Nothing here reads memory it did not write, so the fill is switched off for the tuning loop and put
     back afterwards; the mode itself (which ops / library kernels run) is left exactly as the caller set it."""
     det = getattr(torch.utils, "deterministic", None)
-    if det is None or not torch.are_deterministic_algorithms_enabled() or not getattr(det, "fill_uninitialized_memory", False):
+    if det is None or not torch.are_deterministic_algorithms_enabled() or not getattr(det, "fill_uninitialized_memory", False) \
+            or os.environ.get("AR_KEEP_NAN_FILL") == "1":      # (probe: keep the NaN fill -- a read of unwritten memory then shows as NaN)
         yield
         return
     det.fill_uninitialized_memory = False

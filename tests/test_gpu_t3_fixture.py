@@ -336,8 +336,8 @@ def test_module_path_reproduces_reference_run_1_of_the_two_run_fixtures(path, re
     assert m["ref_vs_ref"]["prefix_identical_weights"] == 1.0          # (both reference runs identical: what the fixtures were made to find out)
     if m["arch"] == "opt125m":      # up to five runs, accounted (the library attention's race: see _run_with_one_retry)
         r = _run_with_one_retry(lambda: fx.check_against_stat_fixture(path), record_property, f"{name} module path", max_runs=5)
-    else:       # Mixtral: accounted too -- NVFP4's module path parted inside the loop (targets identical, iteration 7) in 2 of 31 runs of the
-        #         round's last day, MXFP4's in 0 of 10 (tools/gpu/r06_mixtral_fixture_repeat.py; cause not found: DESIGN section 5)
+    else:       # Mixtral: accounted too -- NVFP4's module path parted inside the loop (targets identical, iteration 7) in 2 of 33 runs of the
+        #         round's last day, MXFP4's in 1 of 12 (tools/gpu/r06_mixtral_fixture_repeat.py; cause not found: DESIGN section 5)
         r = _run_with_one_retry(lambda: fx.check_against_stat_fixture(path), record_property, f"{name} module path", max_runs=3)
     assert not r["fused_block"] and r["inputs_identical"] and r["same_layer_set"], _full(r)
     record_property("targets_identical", r["targets_identical"])
