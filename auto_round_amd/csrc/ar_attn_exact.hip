@@ -381,7 +381,7 @@ using namespace ar;
 // launch forms (equal results; measured A/B, profiles/r06_attn_exact_waves_ab.json): bits 0-1 forward, bits 2-3 backward -- 0 default
 // (forward: 8 waves at head size 128, 4 at 64; backward: head size 128 the fused key-side kernel on 4 waves + the 8-wave query-side
 // kernel, head size 64 4 waves), 1 = workgroups of 4 waves (128 own rows), 2 = workgroups of 8 waves (256 own rows; head size 128: the
-// key side as two kernels), 3 (backward) = the fused key-side kernel; bit 4 (16): the fused key-side kernel WITHOUT the hand pipeline; bit 5 (32): the blockIdx mapping before xattn_map; bit 6 (64): head size 64's key side on the pipelined kernel (slower: A/B)
+// key side as two kernels), 3 (backward) = the fused key-side kernel; bit 4 (16): the fused key-side kernel WITH the hand pipeline (k_xattn_bwd_kv; off by default); bit 5 (32): the blockIdx mapping before xattn_map; bit 6 (64): head size 64's key side on the pipelined kernel (slower: A/B)
 static int g_xattn_cfg = 0;
 extern "C" int ar_attn_exact_config(int cfg) {
     const int old = g_xattn_cfg;
@@ -1188,8 +1188,10 @@ extern "C" int ar_attn_bwd_exact(const void* Q, const void* K, const void* V, co
         if (attr1.first())
             (void)hipFuncSetAttribute((const void*)k_xattn_bwd<1, 4, 128, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + 2 * 4096 * (int)sizeof(float));
         const int grid4 = (int)(B * H * (S / 128));
-        if (g_xattn_cfg & 16) hipLaunchKernelGGL((k_xattn_bwd<1, 4, 128, 3, 1>), grid4, 256, LDS_T128 + vec, s, a);
-        else {                                            // the same kernel software-pipelined by hand
+        if (!(g_xattn_cfg & 16)) hipLaunchKernelGGL((k_xattn_bwd<1, 4, 128, 3, 1>), grid4, 256, LDS_T128 + vec, s, a);
+        else {                                            // on request (config bit 16): the same kernel software-pipelined by hand -- 6 % faster, equal bits in
+                                                          // every direct comparison (1 650 stress calls, Llama-3-8B 33 full runs), but 4 of ~80 Mixtral module-path
+                                                          // runs with it parted inside the loop against 0 of ~70 with the phase kernel: not the default
             static PerDeviceOnce attr2;
             if (attr2.first())
                 (void)hipFuncSetAttribute((const void*)k_xattn_bwd_kv<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_T128 + 2 * 4096 * (int)sizeof(float));

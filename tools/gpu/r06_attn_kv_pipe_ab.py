@@ -1,4 +1,4 @@
-"""The hand-pipelined key-side backward kernel (k_xattn_bwd_kv) against the phase-by-phase one it replaces (config bit 16): equal
+"""The hand-pipelined key-side backward kernel (k_xattn_bwd_kv) against the phase-by-phase default (the pipelined one: config bit 16): equal
 results (dQ, dK, dV bit for bit, several mask lengths / sequence lengths) and the time of the whole backward call."""
 import json, os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
@@ -31,7 +31,7 @@ for (B, H, S, D, hk, valid) in shapes:
     with torch.no_grad():
         o, lse = ops.attn_fwd_exact(q, k, v, st, scale)
         outs = {}
-        for name, cfg in (("phases", 16), ("pipelined", 0)):
+        for name, cfg in (("phases", 0), ("pipelined", 16)):
             lib.ar_attn_exact_config(cfg)
             g = ops.attn_bwd_exact(q, k, v, o, lse, da, st, scale)
             outs[name] = [t.clone() for t in g]

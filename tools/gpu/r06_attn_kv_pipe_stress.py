@@ -1,5 +1,5 @@
 """Repeatability of the hand-pipelined key-side backward kernel: N backward calls per shape, every result compared with the phase-by-phase
-kernel's (config bit 16) -- a missing wait in a hand-placed schedule would show up as a rare difference, not as a constant one."""
+kernel's (the default; the pipelined one is config bit 16) -- a missing wait in a hand-placed schedule would show up as a rare difference, not as a constant one."""
 import json, os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from auto_round_amd import ops, _lib
@@ -20,9 +20,9 @@ for (B, H, S, D, hk, valid, seed) in [(8, 32, 2048, 128, 8, 2047, 0), (8, 32, 20
     da = (torch.randn(B, S, H, D, device="cuda") * 0.02).to(torch.bfloat16)
     with torch.no_grad():
         o, lse = ops.attn_fwd_exact(q, k, v, st, scale)
-        lib.ar_attn_exact_config(16)
-        ref = [t.clone() for t in ops.attn_bwd_exact(q, k, v, o, lse, da, st, scale)]
         lib.ar_attn_exact_config(0)
+        ref = [t.clone() for t in ops.attn_bwd_exact(q, k, v, o, lse, da, st, scale)]
+        lib.ar_attn_exact_config(16)
         bad = 0
         n = N if B * H * S <= 8 * 32 * 2048 else N // 2
         for i in range(n):
@@ -30,6 +30,7 @@ for (B, H, S, D, hk, valid, seed) in [(8, 32, 2048, 128, 8, 2047, 0), (8, 32, 20
             if i % 3 == 0:                      # other work between calls: the timing around the kernel varies
                 torch.mm(q.reshape(-1, D)[:4096].float(), k.reshape(-1, D)[:4096].float().t())
             bad += int(not all(torch.equal(a, b) for a, b in zip(ref, g)))
+    lib.ar_attn_exact_config(0)
     rec = {"shape": [B, H, S, D, hk], "valid_len": valid, "calls": n, "calls_differing": bad}
     print(json.dumps(rec), flush=True)
     res.append(rec)

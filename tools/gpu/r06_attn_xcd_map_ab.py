@@ -1,6 +1,6 @@
 """The exact attention kernels with the blockIdx -> (row block, head) mapping that keeps the workgroups of one K / V (or Q / dO) stream
 together on one XCD (xattn_map) against the mapping before it (config bit 32), and the key-side kernel with / without the hand
-pipeline (bit 16): equal results, time per call."""
+pipeline (bit 16 selects it): equal results, time per call."""
 import json, os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from auto_round_amd import ops, _lib
@@ -29,7 +29,7 @@ for (B, H, S, D, hk, valid) in shapes:
     rec = {"shape": [B, H, S, D, hk], "valid_len": valid}
     outs = {}
     with torch.no_grad():
-        for name, cfg in (("old_map_phases", 32 | 16), ("old_map", 32), ("new_map_phases", 16), ("new_map", 0)):
+        for name, cfg in (("old_map_phases", 32), ("old_map", 32 | 16), ("new_map_phases", 0), ("new_map", 16)):
             lib.ar_attn_exact_config(cfg)
             o, lse = ops.attn_fwd_exact(q, k, v, st, scale)
             g = ops.attn_bwd_exact(q, k, v, o, lse, da, st, scale)
