@@ -97,6 +97,32 @@ def test_other_key_padding_and_a_second_seed():
     assert (_ndiff(dq4, gq), _ndiff(dk4, gk), _ndiff(dv4, gv)) == (0, 0, 0)
 
 
+@pytest.mark.parametrize("B,H,S,hk,valid", [(8, 32, 2048, 8, 2047), (2, 32, 512, 8, 400), (2, 16, 1152, 16, 1100)])
+def test_launch_forms_give_equal_bits(B, H, S, hk, valid):
+    """ar_attn_exact_config: the hand-pipelined key-side kernel (bit 16; selectable, not the default) and the workgroup -> XCD mapping before
+    `xattn_map` (bit 32) must return the default form's bits -- output, log-sum-exp and all three gradients."""
+    from auto_round_amd import _lib, ops
+    from auto_round_amd.exact_block import exact_attention_backward
+
+    D, scale = 128, 128 ** -0.5
+    q, k, v, mask = _case(B, H, S, D, hk, 1.0, seed=5, valid=valid)
+    st = ops.mask_structure(mask, S)
+    da = (torch.randn(B, S, H, D, device=q.device) * 0.02).to(torch.bfloat16)
+    lib = _lib.load()
+    outs = {}
+    try:
+        for cfg in (0, 16, 32, 48):
+            lib.ar_attn_exact_config(cfg)
+            with torch.no_grad():
+                mo, mlse = ops.attn_fwd_exact(q, k, v, st, scale)
+                g = exact_attention_backward((q, k, v, mo, mlse, st), da, scale)
+            outs[cfg] = [mo.clone(), mlse.clone()] + [t.clone() for t in g]
+    finally:
+        lib.ar_attn_exact_config(0)
+    for cfg in (16, 32, 48):
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[cfg])), cfg
+
+
 def test_refusals():
     """calls the kernels do not restate are refused (the caller keeps torch's SDPA), never answered approximately"""
     from auto_round_amd import ops
